@@ -1,0 +1,157 @@
+"""CPU: the oracle against the golden vectors (torch-op outputs on the reference's real weights)."""
+import numpy as np
+import pytest
+
+from oracle import ppo_oracle as O
+from tests.util import ENVS, scaled_err, golden_adam, golden_hyper, golden_minibatch, golden_params, load_golden, rel_err
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_forward_matches_golden(env):
+    g = load_golden(env)
+    p = golden_params(g)
+    actions, clipped, value, logp = O.act(p, g["last_obs"], g["fwd/eps"])
+    mean, _ = O.policy_outputs(p, g["last_obs"])
+    # saturated policies: |mean| up to ~185, sigma up to ~150 -> compare relatively
+    assert scaled_err(mean, g["fwd/mean"]) < 1e-5
+    assert scaled_err(value, g["fwd/value"]) < 1e-5
+    assert scaled_err(actions, g["fwd/actions"]) < 1e-5
+    assert np.array_equal(clipped, np.clip(actions, -1, 1))
+    assert np.allclose(logp, g["fwd/log_prob"], rtol=1e-5, atol=1e-4)
+    assert np.allclose(O.gaussian_entropy(p["log_std"], len(value)), g["fwd/entropy"], rtol=1e-6, atol=1e-5)
+    det = O.predict(p, g["last_obs"], deterministic=True)
+    assert np.allclose(det, np.clip(g["fwd/mean"], -1, 1), atol=1e-4)
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_minibatch_step_matches_golden(env):
+    g = load_golden(env)
+    p, st, h = golden_params(g), golden_adam(g), golden_hyper(g)
+    stats, grads, aux = O.loss_and_grads(p, *golden_minibatch(g), h)
+    assert np.allclose(aux["adv"], g["step/adv_norm"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(aux["ratio"], g["step/ratio"], rtol=2e-4)  # exp of O(100)-magnitude log-probs
+    for k in ["loss", "policy_loss", "value_loss", "entropy_loss", "approx_kl", "clip_fraction"]:
+        assert abs(float(stats[k]) - float(g["step/" + k])) < 1e-4 * max(1.0, abs(float(g["step/" + k]))), k
+    gn = np.sqrt(sum(float(np.sum(np.asarray(v, np.float64) ** 2)) for v in grads.values()))
+    for k, v in grads.items():
+        ref = g["step/grad/" + k]
+        assert v.shape == ref.shape
+        assert np.max(np.abs(v - ref)) < 1e-4 * max(1.0, float(np.max(np.abs(ref)))), k
+    clipped, total = O.clip_grad_norm(grads, h.max_grad_norm)
+    assert abs(total - float(g["step/grad_norm"])) < 1e-4 * float(g["step/grad_norm"])
+    assert abs(gn - float(total)) < 1e-3 * gn
+    O.adam_step(p, clipped, st, h.learning_rate, h.beta1, h.beta2, h.adam_eps)
+    assert st.step == int(g["adam_step"]) + 1
+    for k in p:
+        assert np.max(np.abs(p[k] - g["step/p/" + k])) < 1e-6 + 1e-5 * float(np.max(np.abs(g["step/p/" + k]))), k
+        assert np.allclose(st.exp_avg[k], g["step/m/" + k], rtol=1e-4, atol=1e-7), k
+        assert np.allclose(st.exp_avg_sq[k], g["step/v/" + k], rtol=1e-4, atol=1e-9), k
+
+
+def test_grads_match_torch_autograd_random_net():
+    """Hand-derived backward vs torch autograd on a random 2x32 net incl. clip edge cases."""
+    import torch
+    rng = np.random.default_rng(3)
+    D, A, B = 7, 3, 64
+    p = O.init_params(D, A, (32, 32), (32, 32), seed=5)
+    p["log_std"] = rng.normal(0, 0.3, A).astype(np.float32)
+    obs = rng.standard_normal((B, D)).astype(np.float32)
+    mean, _ = O.policy_outputs(p, obs)
+    act = (mean + rng.standard_normal((B, A)).astype(np.float32) * np.exp(p["log_std"])).astype(np.float32)
+    lp = O.gaussian_log_prob(mean, p["log_std"], act)
+    old_lp = (lp + rng.normal(0, 0.2, B)).astype(np.float32)
+    old_lp[:4] = lp[:4]  # ratio == 1 exactly -> inside the clip range, tie between the two surrogates
+    adv = rng.standard_normal(B).astype(np.float32)
+    adv[5] = 0.0
+    ret = rng.standard_normal(B).astype(np.float32)
+    h = O.Hyper(ent_coef=0.01, normalize_advantage=False)
+    stats, grads, _ = O.loss_and_grads(p, obs, act, ret, old_lp, adv, ret, h)
+
+    tp = {k: torch.tensor(v, requires_grad=True) for k, v in p.items()}
+    x = torch.tensor(obs)
+    hpi = torch.tanh(torch.tanh(x @ tp["mlp_extractor.policy_net.0.weight"].T + tp["mlp_extractor.policy_net.0.bias"])
+                     @ tp["mlp_extractor.policy_net.2.weight"].T + tp["mlp_extractor.policy_net.2.bias"])
+    hvf = torch.tanh(torch.tanh(x @ tp["mlp_extractor.value_net.0.weight"].T + tp["mlp_extractor.value_net.0.bias"])
+                     @ tp["mlp_extractor.value_net.2.weight"].T + tp["mlp_extractor.value_net.2.bias"])
+    mu = hpi @ tp["action_net.weight"].T + tp["action_net.bias"]
+    v = (hvf @ tp["value_net.weight"].T + tp["value_net.bias"]).flatten()
+    dist = torch.distributions.Normal(mu, torch.ones_like(mu) * tp["log_std"].exp())
+    logp = dist.log_prob(torch.tensor(act)).sum(1)
+    ratio = torch.exp(logp - torch.tensor(old_lp))
+    a = torch.tensor(adv)
+    pl = -torch.min(a * ratio, a * torch.clamp(ratio, 0.8, 1.2)).mean()
+    vl = torch.nn.functional.mse_loss(torch.tensor(ret), v)
+    el = -dist.entropy().sum(1).mean()
+    loss = pl + 0.01 * el + 0.5 * vl
+    loss.backward()
+    assert abs(loss.item() - float(stats["loss"])) < 1e-5
+    for k in p:
+        assert np.allclose(grads[k], tp[k].grad.numpy(), rtol=2e-4, atol=2e-6), k
+
+
+def test_gae_properties():
+    rng = np.random.default_rng(0)
+    T, N = 50, 6
+    r = rng.standard_normal((T, N)).astype(np.float32)
+    v = rng.standard_normal((T, N)).astype(np.float32)
+    es = np.zeros((T, N), np.float32)
+    lv = rng.standard_normal(N).astype(np.float32)
+    dones = np.zeros(N, bool)
+    # lambda = 0 -> advantage == one-step TD error
+    adv, ret = O.gae(r, v, es, lv, dones, 0.99, 0.0)
+    nv = np.concatenate([v[1:], lv[None]], 0)
+    assert np.allclose(adv, r + np.float32(0.99) * nv - v, atol=1e-6)
+    assert np.allclose(ret, adv + v)
+    # no episode boundaries -> closed form in float64
+    adv, _ = O.gae(r, v, es, lv, dones, 0.97, 0.9)
+    delta = r.astype(np.float64) + 0.97 * nv - v
+    ref = np.zeros((T, N))
+    acc = np.zeros(N)
+    for t in reversed(range(T)):
+        acc = delta[t] + 0.97 * 0.9 * acc
+        ref[t] = acc
+    assert np.allclose(adv, ref, atol=1e-5)
+    # episode start at t+1 cuts both the bootstrap and the trace
+    es2 = es.copy()
+    es2[10, 2] = 1.0
+    adv2, _ = O.gae(r, v, es2, lv, dones, 0.97, 0.9)
+    assert abs(adv2[9, 2] - (r[9, 2] - v[9, 2])) < 1e-6
+    assert np.allclose(adv2[10:, 2], adv[10:, 2])
+    # dones at the last step cut the bootstrap from last_values
+    d2 = dones.copy()
+    d2[1] = True
+    adv3, _ = O.gae(r, v, es, lv, d2, 0.97, 0.9)
+    assert abs(adv3[T - 1, 1] - (r[T - 1, 1] - v[T - 1, 1])) < 1e-6
+    assert adv3.dtype == np.float32
+
+
+def test_feistel_is_permutation():
+    for n in [1, 2, 7, 100, 4096, 16000, 65537]:
+        perm = O.feistel_permutation(n, key=0xDEADBEEF12345 + n)
+        assert np.array_equal(np.sort(perm), np.arange(n))
+    a = O.feistel_permutation(16000, 1)
+    b = O.feistel_permutation(16000, 2)
+    assert (a != b).mean() > 0.99
+    assert abs(np.corrcoef(a, np.arange(16000))[0, 1]) < 0.05
+
+
+def test_flat_index_is_env_major():
+    T, N = 5, 3
+    x = np.arange(T * N).reshape(T, N)
+    flat = x.swapaxes(0, 1).reshape(T * N)  # SB3 swap_and_flatten
+    t, n = O.flat_to_tn(np.arange(T * N), T)
+    assert np.array_equal(x[t, n], flat)
+
+
+def test_checkpoint_sanity_anchors():
+    """Anchors recorded during the survey."""
+    g = load_golden("point")
+    p = golden_params(g)
+    mean, v = O.policy_outputs(p, g["last_obs"])
+    assert np.allclose(p["log_std"], [3.001, 3.634], atol=2e-3)
+    assert np.allclose(mean[0], [-24.102, -0.758], atol=2e-3)
+    assert np.allclose(v, [1.507, 1.516], atol=2e-3)
+    g = load_golden("doggo")
+    _, v = O.policy_outputs(golden_params(g), g["last_obs"])
+    assert np.allclose(v[:4], [3.464, 3.274, 3.692, 3.804], atol=2e-3)
+    assert int(g["adam_step"]) == 1499200 == int(g["hyper/_n_updates"]) * 160
