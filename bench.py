@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the PPO hot path (BASELINE.json metric) on N MI355X of one node.
+
+A "step" = one full PPO iteration on every rank: a T-step rollout of N vectorised envs from the
+device-resident synthetic env source (policy/value forward + sampling + store + time-limit bootstrap),
+the GAE(lambda) scan, and E epochs of minibatch updates (forward, loss, backward, global-norm clip, Adam),
+with one RCCL gradient all-reduce per optimizer step when N_gpus > 1.  value = env-steps of all ranks / time.
+
+Workload (config.workload): BASELINE.json configs[2] "doggo env (58 obs / 12 act), 1xMI355X, 4096 vec envs,
+2x256 MLP" with T=1000, E=5 from the reference YAML (data/configs/doggo-ppo.yaml:12-14) and a stated
+minibatch of 65536 per GPU (the YAML's batch_size=100 would be 40960 serial Adam steps per epoch).
+Inputs are resident in HBM (the synthetic env source generates observations on the device).
+
+Launch: python bench.py --gpus 1 --steps K --warmup W
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: obs, act, hidden, envs/GPU, T, E, minibatch/GPU, p_term, time_limit
+    "doggo-4096env-2x256": dict(D=58, A=12, H=256, N=4096, T=1000, E=5, B=65536, p_term=1 / 107.0, tl=1000),
+    "point-1024env-2x64": dict(D=14, A=2, H=64, N=1024, T=2048, E=10, B=65536, p_term=1 / 119.0, tl=1000),
+    "doggo-ref-16env-2x64": dict(D=58, A=12, H=64, N=16, T=1000, E=5, B=100, p_term=1 / 107.0, tl=1000),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def f_fwd(D, H, A):
+    return 2 * (2 * D * H + 2 * H * H + H * A + H)
+
+
+def init_params(D, A, H, seed):
+    """Orthogonal init with SB3 gains (random-init weights of the named architecture)."""
+    from mobrob_amd.rl_control.init import orthogonal_policy_init
+    return orthogonal_policy_init(D, A, (H, H), (H, H), seed)
+
+
+def cpu_baseline(w, budget_s=20.0):
+    """The CPU oracle (SB3-semantics NumPy restatement) on a bounded sample of the same workload."""
+    from oracle import ppo_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [os.cpu_count() or 1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    D, A, H, N = w["D"], w["A"], w["H"], w["N"]
+    Ts = max(2, min(w["T"], int(np.ceil(w["B"] / N))))  # at least one full minibatch
+    p = O.init_params(D, A, (H, H), (H, H), seed=0)
+    h = O.Hyper(n_epochs=w["E"], batch_size=w["B"], ent_coef=0.01)
+    rng = np.random.default_rng(0)
+    t0 = time.perf_counter()
+    done_steps, reps = 0, 0
+    while True:
+        env = O.NumpySyntheticVecEnv(N, D, A, p_term=w["p_term"], time_limit=w["tl"], seed=reps)
+        obs = env.reset()
+        buf, _, _ = O.collect_rollout(p, env, obs, np.ones(N, bool), Ts, h,
+                                      lambda t: rng.standard_normal((N, A), dtype=np.float32))
+        perms = [rng.permutation(Ts * N) for _ in range(h.n_epochs)]
+        O.train(p, O.AdamState.zeros_like(p), buf, h, perms)
+        done_steps += Ts * N
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or el + el / reps > 1.5 * budget_s:
+            break
+    return {"value": done_steps / el, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
+            "sample": f"{reps} x (rollout {Ts} steps x {N} envs + {h.n_epochs} epochs, minibatch {w['B']}) "
+                      f"= {done_steps} env-steps of the NumPy oracle in {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="doggo-4096env-2x256", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--generic", action="store_true", help="force the generic (unfused) kernels")
+    args = ap.parse_args()
+    w = WORKLOADS[args.workload]
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+    from mobrob_amd.engine import PPOEngine
+    from mobrob_amd.parallel import EngineBackend, train_data_parallel
+
+    D, A, H, N, T, E, B = w["D"], w["A"], w["H"], w["N"], w["T"], w["E"], w["B"]
+    eng = PPOEngine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B * world, n_epochs=E, pi=(H, H), vf=(H, H),
+                    gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.01, seed=0, device_id=local_rank,
+                    rank=rank, world_size=world, fast_kernels=not args.generic)
+    eng.set_params(init_params(D, A, H, seed=0))  # identical replicas on every rank
+    backend = EngineBackend(eng) if world > 1 else None
+
+    def iteration():
+        eng.collect_synthetic(p_term=w["p_term"], time_limit=w["tl"])
+        if world > 1:
+            train_data_parallel(backend)
+        else:
+            eng.train(None)
+
+    def fence():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        iteration()
+    fence()
+    eng.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        iteration()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        env_steps = N * T * world * args.steps
+        nmb = eng.n_minibatches
+        ms, calls = prof["train_grad"]
+        flops_per_launch = 3.0 * f_fwd(D, H, A) * B  # forward + 2x backward over one minibatch
+        achieved = (flops_per_launch * calls / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        out = {
+            "metric": "env-steps/sec (whole node), doggo PPO" if "doggo" in args.workload else "env-steps/sec (whole node)",
+            "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "obs_dim": D, "act_dim": A, "net_arch": [H, H], "envs_per_gpu": N,
+                       "n_steps": T, "n_epochs": E, "minibatch_per_gpu": B, "minibatches_per_epoch": nmb,
+                       "env_source": "device-resident synthetic (Philox)", "parallelism": f"dp{world}",
+                       "kernels": "generic" if args.generic else "fused"},
+            "roofline": {"bound": "mfma", "kernel": "minibatch forward+loss+backward (train_grad)",
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_ms": ms / max(calls, 1), "launches": calls,
+                         "flops_per_launch": flops_per_launch},
+            "phase_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,219 @@
+/*
+ * mobrob_ppo.h -- C ABI of libmobrob_ppo.so, the MI355X (gfx950) PPO training engine.
+ *
+ * Drop-in boundary for the ONE hot path of ZikangXiong/mobrob: everything that
+ * `PPOCtrl.__init__ -> stable_baselines3.PPO(...)`  (reference src/mobrob/rl_control/ppo.py:50-59),
+ * `PPOCtrl.learn -> PPO.learn`                       (reference src/mobrob/rl_control/ppo.py:73-74),
+ * `PPOCtrl.save_model -> PPO.save`                   (reference src/mobrob/rl_control/ppo.py:76-77),
+ * `load_policy -> PPO.load`                          (reference src/mobrob/utils.py:15-16) and
+ * `policy.predict(obs, deterministic=True)`          (reference examples/control.py:39)
+ * execute inside stable-baselines3 2.0.0 / torch-CPU (reference requirements.txt:9).
+ * Each entry point below cites the reference call site / SB3 routine it replaces.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a HOST pointer unless its name ends in `_dev`.
+ *   - all arithmetic is IEEE float32 ("f32"); GAE carries its accumulator in f64 exactly like
+ *     SB3's NumPy loop does (oracle/ppo_oracle.py:gae).
+ *   - parameters travel as ONE flat f32 vector in SB3 `policy.state_dict()` order:
+ *       log_std[A], pi.0.weight[H1,D], pi.0.bias[H1], pi.2.weight[H2,H1], pi.2.bias[H2],
+ *       vf.0.weight[G1,D], vf.0.bias[G1], vf.2.weight[G2,G1], vf.2.bias[G2],
+ *       action_net.weight[A,H2], action_net.bias[A], value_net.weight[1,G2], value_net.bias[1]
+ *     (weights row-major [out,in]; verified against data/policies/<env>-ppo.zip:policy.pth).
+ *   - rollout storage is [T][N][...] on the device; minibatch indices are SB3's ENV-MAJOR flat
+ *     index  flat = n*T + t  (SB3 RolloutBuffer.swap_and_flatten).
+ *   - every function returns MOBROB_OK (0) or a negative error code; mobrob_ppo_last_error()
+ *     returns a thread-local description.  Nothing here ever falls back to a CPU implementation.
+ *   - ownership: the caller owns host buffers (pin them with mobrob_ppo_host_alloc for truly
+ *     asynchronous H2D/D2H); the engine owns all device memory.
+ */
+#ifndef MOBROB_PPO_H
+#define MOBROB_PPO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOBROB_PPO_ABI_VERSION 1
+
+enum {
+  MOBROB_OK = 0,
+  MOBROB_ERR_INVALID = -1,     /* bad argument / unsupported shape (-> ValueError)            */
+  MOBROB_ERR_HIP = -2,         /* a HIP runtime call failed (-> RuntimeError)                  */
+  MOBROB_ERR_STATE = -3,       /* call sequence violated, e.g. train before finish_rollout     */
+  MOBROB_ERR_NO_DEVICE = -4    /* no gfx950 device visible                                     */
+};
+
+typedef struct mobrob_ppo_engine mobrob_ppo_engine_t;
+
+/* Hyper-parameters = the kwargs the reference splats into PPO(...) (ppo.py:58; data/configs/
+ * <env>-ppo.yaml `ppo_kwargs`) plus SB3 2.0.0 defaults for the rest. */
+typedef struct mobrob_ppo_config {
+  int32_t abi_version;        /* = MOBROB_PPO_ABI_VERSION                                        */
+  int32_t obs_dim;            /* D: 14 point, 26 car, 58 doggo, 12 drone, 43 turtlebot3          */
+  int32_t act_dim;            /* A:  2,        2,      12,       18,       2                     */
+  int32_t pi_hidden[2];       /* policy_kwargs.net_arch.pi  (default [64,64])                    */
+  int32_t vf_hidden[2];       /* policy_kwargs.net_arch.vf  (default [64,64])                    */
+  int32_t n_envs;             /* N: vectorised envs owned by THIS rank (yaml n_envs)             */
+  int32_t n_steps;            /* T: rollout horizon (ppo_kwargs.n_steps, default 2048)           */
+  int32_t batch_size;         /* GLOBAL minibatch size (ppo_kwargs.batch_size, default 64)       */
+  int32_t n_epochs;           /* ppo_kwargs.n_epochs (default 10)                                */
+  /* python floats are doubles: the engine rounds to f32 exactly where SB3/torch would */
+  double gamma;               /* default 0.99                                                    */
+  double gae_lambda;          /* default 0.95                                                    */
+  double clip_range;          /* constant schedule, default 0.2                                  */
+  double ent_coef;            /* default 0.0                                                     */
+  double vf_coef;             /* default 0.5                                                     */
+  double max_grad_norm;       /* default 0.5                                                     */
+  double learning_rate;       /* constant schedule, default 3e-4                                 */
+  double adam_beta1, adam_beta2, adam_eps; /* 0.9, 0.999, 1e-5 (SB3 passes eps=1e-5 to Adam)     */
+  double action_low, action_high; /* Box bounds used for the clipped action copy (-1, 1)         */
+  int32_t normalize_advantage;/* default 1                                                       */
+  uint64_t seed;              /* Philox key for eps / synthetic env / Feistel permutations       */
+  int32_t device_id;          /* HIP device ordinal                                              */
+  int32_t rank, world_size;   /* data-parallel position; batch_size is split batch_size/world    */
+  int32_t fast_kernels;       /* 1: use the fused MFMA kernels when the shape allows; 0: generic */
+  int32_t reserved[7];
+} mobrob_ppo_config_t;
+
+/* Fill `cfg` with SB3 2.0.0 defaults (Appendix A.1).  Replaces PPO.__init__'s default kwargs. */
+void mobrob_ppo_default_config(mobrob_ppo_config_t* cfg);
+
+/* PPO(...)/_setup_model (ppo.py:50-59): allocate rollout buffer, policy, Adam(eps) on the device;
+ * parameters are initialised to zero -- the caller uploads weights (set_params). */
+int mobrob_ppo_create(const mobrob_ppo_config_t* cfg, mobrob_ppo_engine_t** out);
+void mobrob_ppo_destroy(mobrob_ppo_engine_t* e);
+const char* mobrob_ppo_last_error(void);
+int mobrob_ppo_abi_version(void);
+
+/* Use an externally owned hipStream_t (e.g. torch's current stream, so that RCCL collectives
+ * issued through torch.distributed are ordered with the engine's kernels).  NULL -> own stream. */
+int mobrob_ppo_set_stream(mobrob_ppo_engine_t* e, void* hip_stream);
+int mobrob_ppo_synchronize(mobrob_ppo_engine_t* e);
+
+/* Pinned host memory for the rollout streamer (hipHostMalloc / hipHostFree). */
+void* mobrob_ppo_host_alloc(size_t bytes);
+void mobrob_ppo_host_free(void* p);
+
+/* policy.state_dict() / load_state_dict() (examples/train.py:31-33) and the optimizer state of
+ * policy.optimizer.pth.  n must equal mobrob_ppo_param_count(). */
+int64_t mobrob_ppo_param_count(const mobrob_ppo_engine_t* e);
+int mobrob_ppo_get_params(mobrob_ppo_engine_t* e, float* out, int64_t n);
+int mobrob_ppo_set_params(mobrob_ppo_engine_t* e, const float* in, int64_t n);
+int mobrob_ppo_get_optimizer_state(mobrob_ppo_engine_t* e, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                   int64_t* step);
+int mobrob_ppo_set_optimizer_state(mobrob_ppo_engine_t* e, const float* exp_avg, const float* exp_avg_sq,
+                                   int64_t n, int64_t step);
+
+/* ---- rollout: OnPolicyAlgorithm.collect_rollouts (SB3; reached via ppo.py:73-74) ------------- */
+
+/* rollout_buffer.reset(): position -> 0. */
+int mobrob_ppo_rollout_begin(mobrob_ppo_engine_t* e);
+
+/* `actions, values, log_probs = policy(obs)` + np.clip for the env.  obs[N*D] is streamed H2D into
+ * rollout slot t; eps[N*A] ~ N(0,I) may be NULL -> drawn on device (Philox4x32-10 + Box-Muller).
+ * Outputs (any may be NULL): raw actions (what the buffer stores), clipped actions (what the env
+ * sees), values, log_probs.  Blocks until the outputs are on the host. */
+int mobrob_ppo_act(mobrob_ppo_engine_t* e, const float* obs, const float* eps, float* actions_raw,
+                   float* actions_clipped, float* values, float* log_probs);
+
+/* rollout_buffer.add(...) for the step just acted: rewards[N]; dones[N] (terminated|truncated,
+ * becomes the NEXT step's episode_start); truncated[N] = infos["TimeLimit.truncated"] (may be
+ * NULL); terminal_obs[N*D] = infos["terminal_observation"] rows (only rows with truncated!=0 are
+ * read; may be NULL when nothing was truncated).  Applies rewards += gamma * V(terminal_obs). */
+int mobrob_ppo_store(mobrob_ppo_engine_t* e, const float* rewards, const uint8_t* dones,
+                     const uint8_t* truncated, const float* terminal_obs);
+
+/* `values = policy.predict_values(new_obs)` + RolloutBuffer.compute_returns_and_advantage
+ * (GAE(lambda) reverse scan).  last_obs[N*D], dones[N] = dones of the final step. */
+int mobrob_ppo_finish_rollout(mobrob_ppo_engine_t* e, const float* last_obs, const uint8_t* dones);
+
+/* Device-resident synthetic env source (SURVEY.md §8d / BASELINE.md §3): the whole T-step rollout
+ * (env draw -> act -> store -> bootstrap) runs on the GPU without host round trips, then GAE.
+ * obs ~ N(0,1), reward ~ N(0.03,0.1^2) + 5*terminated, terminated ~ Bernoulli(p_term),
+ * truncation at time_limit with a terminal observation.  State persists across calls. */
+int mobrob_ppo_collect_synthetic(mobrob_ppo_engine_t* e, float p_term, int32_t time_limit);
+
+/* ---- update: PPO.train (SB3 ppo/ppo.py) ----------------------------------------------------- */
+
+typedef struct mobrob_ppo_train_stats {
+  /* means over the minibatches of the LAST epoch run by the call (SB3 logs the same way) */
+  float policy_loss, value_loss, entropy_loss, loss, approx_kl, clip_fraction, grad_norm;
+  int32_t n_minibatches; /* optimizer steps taken by the call */
+} mobrob_ppo_train_stats_t;
+
+/* Whole PPO.train(): n_epochs x ceil(T*N / batch) optimizer steps.  perms = n_epochs concatenated
+ * env-major permutations of range(T*N) (what np.random.permutation would have produced), or NULL ->
+ * counter-based Feistel permutations keyed by (seed, rank, update counter).  world_size must be 1. */
+int mobrob_ppo_train(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_ppo_train_stats_t* stats);
+
+/* The same update split at the two points where data-parallel ranks exchange data:
+ *   epoch_begin   -> local (sum adv, sum adv^2, count) per minibatch into advstat_dev
+ *   [all-reduce advstat_dev, 3 doubles per minibatch]
+ *   minibatch_grad(mb) -> local gradient of the GLOBAL-mean loss into grad_dev (P floats)
+ *   [all-reduce grad_dev (sum)]
+ *   minibatch_apply -> clip_grad_norm_ + Adam.step on every rank (replicas stay identical) */
+int mobrob_ppo_epoch_begin(mobrob_ppo_engine_t* e, const int64_t* perm /* T*N or NULL */);
+int mobrob_ppo_num_minibatches(const mobrob_ppo_engine_t* e);
+int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb);
+int mobrob_ppo_minibatch_apply(mobrob_ppo_engine_t* e);
+/* per-minibatch stats of every optimizer step since the last call to this function:
+ * rows of 8 floats [policy_loss, value_loss, entropy_loss, loss, approx_kl, clip_fraction,
+ * grad_norm, 0]; returns rows written (<= max_rows) or a negative error. */
+int mobrob_ppo_fetch_step_stats(mobrob_ppo_engine_t* e, float* out, int32_t max_rows);
+
+/* ---- inference: policy.predict (examples/control.py:39) -------------------------------------- */
+int mobrob_ppo_predict(mobrob_ppo_engine_t* e, const float* obs, int32_t n, int32_t deterministic,
+                       const float* eps /* n*A or NULL */, float* actions_clipped, float* values);
+
+/* ---- device buffers (tests, DP collectives, profiling) --------------------------------------- */
+enum {
+  MOBROB_BUF_OBS = 0,        /* f32 [T+1][N][Dp]  (Dp = D rounded up to 8; slot T = last_obs)     */
+  MOBROB_BUF_ACTIONS = 1,    /* f32 [T][N][A]                                                    */
+  MOBROB_BUF_REWARDS = 2,    /* f32 [T][N]                                                       */
+  MOBROB_BUF_EPISODE_STARTS = 3, /* f32 [T][N]                                                   */
+  MOBROB_BUF_VALUES = 4,     /* f32 [T][N]                                                       */
+  MOBROB_BUF_LOG_PROBS = 5,  /* f32 [T][N]                                                       */
+  MOBROB_BUF_ADVANTAGES = 6, /* f32 [T][N]                                                       */
+  MOBROB_BUF_RETURNS = 7,    /* f32 [T][N]                                                       */
+  MOBROB_BUF_PARAMS = 8,     /* f32 [P]                                                          */
+  MOBROB_BUF_GRADS = 9,      /* f32 [P]   -- all-reduce target                                   */
+  MOBROB_BUF_ADVSTAT = 10,   /* f64 [n_minibatches][4] (sum, sumsq, count, pad) -- all-reduce    */
+  MOBROB_BUF_LAST_VALUES = 11, /* f32 [N]                                                        */
+  MOBROB_BUF_LAST_DONES = 12,  /* f32 [N] (0/1)                                                  */
+  MOBROB_BUF_CLIPPED_ACTIONS = 13, /* f32 [N][A] of the most recent act                          */
+  MOBROB_BUF_COUNT = 14
+};
+int mobrob_ppo_buffer_info(mobrob_ppo_engine_t* e, int32_t which, void** ptr_dev, size_t* bytes);
+/* copy with host layout [..][D] <-> device layout [..][Dp] handled for MOBROB_BUF_OBS */
+int mobrob_ppo_read_buffer(mobrob_ppo_engine_t* e, int32_t which, void* host_out, size_t bytes);
+int mobrob_ppo_write_buffer(mobrob_ppo_engine_t* e, int32_t which, const void* host_in, size_t bytes);
+/* mark the rollout as complete (tests that inject a rollout with write_buffer) */
+int mobrob_ppo_mark_rollout_ready(mobrob_ppo_engine_t* e);
+
+/* GAE on the buffers as they are (after write_buffer of rewards/values/episode_starts/
+ * last_values/last_dones): RolloutBuffer.compute_returns_and_advantage in isolation. */
+int mobrob_ppo_compute_gae(mobrob_ppo_engine_t* e);
+
+/* Feistel permutation used when perm == NULL (bit-exact vs oracle/ppo_oracle.py:feistel_permutation) */
+int mobrob_ppo_feistel_permutation(mobrob_ppo_engine_t* e, int64_t n, uint64_t key, int64_t* out);
+
+/* ---- kernel timing with HIP events on the engine's stream (bench.py roofline) ---------------- */
+enum {
+  MOBROB_K_ACT = 0,          /* rollout policy/value forward + sample                           */
+  MOBROB_K_GAE = 1,          /* GAE(lambda) scan                                                */
+  MOBROB_K_TRAIN_GRAD = 2,   /* minibatch forward + loss + backward (dominant)                  */
+  MOBROB_K_APPLY = 3,        /* grad-norm + clip + Adam                                         */
+  MOBROB_K_ENV = 4,          /* synthetic env source                                            */
+  MOBROB_K_COUNT = 5
+};
+int mobrob_ppo_profile_enable(mobrob_ppo_engine_t* e, int32_t on);
+/* accumulated since enable: total milliseconds and launch-group count per id */
+int mobrob_ppo_profile_read(mobrob_ppo_engine_t* e, double* ms /*[K_COUNT]*/, int64_t* calls /*[K_COUNT]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOBROB_PPO_H */

@@ -1,0 +1,113 @@
+"""ctypes binding of libmobrob_ppo.so (C ABI declared in include/mobrob_ppo.h).
+
+There is NO CPU fallback: if the shared library is missing or no gfx950 device is visible the
+product raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmobrob_ppo.so")
+ABI_VERSION = 1
+
+OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NO_DEVICE = 0, -1, -2, -3, -4
+
+BUF = dict(obs=0, actions=1, rewards=2, episode_starts=3, values=4, log_probs=5, advantages=6, returns=7,
+           params=8, grads=9, advstat=10, last_values=11, last_dones=12, clipped_actions=13)
+KERNEL_IDS = dict(act=0, gae=1, train_grad=2, apply=3, env=4)
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("obs_dim", C.c_int32), ("act_dim", C.c_int32),
+        ("pi_hidden", C.c_int32 * 2), ("vf_hidden", C.c_int32 * 2),
+        ("n_envs", C.c_int32), ("n_steps", C.c_int32), ("batch_size", C.c_int32), ("n_epochs", C.c_int32),
+        ("gamma", C.c_double), ("gae_lambda", C.c_double), ("clip_range", C.c_double), ("ent_coef", C.c_double),
+        ("vf_coef", C.c_double), ("max_grad_norm", C.c_double), ("learning_rate", C.c_double),
+        ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
+        ("action_low", C.c_double), ("action_high", C.c_double),
+        ("normalize_advantage", C.c_int32), ("seed", C.c_uint64), ("device_id", C.c_int32),
+        ("rank", C.c_int32), ("world_size", C.c_int32), ("fast_kernels", C.c_int32), ("reserved", C.c_int32 * 7),
+    ]
+
+
+class TrainStats(C.Structure):
+    _fields_ = [(k, C.c_float) for k in
+                ("policy_loss", "value_loss", "entropy_loss", "loss", "approx_kl", "clip_fraction", "grad_norm")] + \
+               [("n_minibatches", C.c_int32)]
+
+
+# every symbol include/mobrob_ppo.h declares: name -> (restype, argtypes)
+_P, _F, _U8, _I64 = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int64)
+SYMBOLS = {
+    "mobrob_ppo_default_config": (None, [C.POINTER(Config)]),
+    "mobrob_ppo_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "mobrob_ppo_destroy": (None, [_P]),
+    "mobrob_ppo_last_error": (C.c_char_p, []),
+    "mobrob_ppo_abi_version": (C.c_int, []),
+    "mobrob_ppo_set_stream": (C.c_int, [_P, _P]),
+    "mobrob_ppo_synchronize": (C.c_int, [_P]),
+    "mobrob_ppo_host_alloc": (_P, [C.c_size_t]),
+    "mobrob_ppo_host_free": (None, [_P]),
+    "mobrob_ppo_param_count": (C.c_int64, [_P]),
+    "mobrob_ppo_get_params": (C.c_int, [_P, _F, C.c_int64]),
+    "mobrob_ppo_set_params": (C.c_int, [_P, _F, C.c_int64]),
+    "mobrob_ppo_get_optimizer_state": (C.c_int, [_P, _F, _F, C.c_int64, _I64]),
+    "mobrob_ppo_set_optimizer_state": (C.c_int, [_P, _F, _F, C.c_int64, C.c_int64]),
+    "mobrob_ppo_rollout_begin": (C.c_int, [_P]),
+    "mobrob_ppo_act": (C.c_int, [_P, _F, _F, _F, _F, _F, _F]),
+    "mobrob_ppo_store": (C.c_int, [_P, _F, _U8, _U8, _F]),
+    "mobrob_ppo_finish_rollout": (C.c_int, [_P, _F, _U8]),
+    "mobrob_ppo_collect_synthetic": (C.c_int, [_P, C.c_float, C.c_int32]),
+    "mobrob_ppo_train": (C.c_int, [_P, _I64, C.POINTER(TrainStats)]),
+    "mobrob_ppo_epoch_begin": (C.c_int, [_P, _I64]),
+    "mobrob_ppo_num_minibatches": (C.c_int, [_P]),
+    "mobrob_ppo_minibatch_grad": (C.c_int, [_P, C.c_int32]),
+    "mobrob_ppo_minibatch_apply": (C.c_int, [_P]),
+    "mobrob_ppo_fetch_step_stats": (C.c_int, [_P, _F, C.c_int32]),
+    "mobrob_ppo_predict": (C.c_int, [_P, _F, C.c_int32, C.c_int32, _F, _F, _F]),
+    "mobrob_ppo_buffer_info": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "mobrob_ppo_read_buffer": (C.c_int, [_P, C.c_int32, _P, C.c_size_t]),
+    "mobrob_ppo_write_buffer": (C.c_int, [_P, C.c_int32, _P, C.c_size_t]),
+    "mobrob_ppo_mark_rollout_ready": (C.c_int, [_P]),
+    "mobrob_ppo_compute_gae": (C.c_int, [_P]),
+    "mobrob_ppo_feistel_permutation": (C.c_int, [_P, C.c_int64, C.c_uint64, _I64]),
+    "mobrob_ppo_profile_enable": (C.c_int, [_P, C.c_int32]),
+    "mobrob_ppo_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), _I64]),
+}
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the in-tree HIP library; raises ImportError with the build hint if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). mobrob_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.mobrob_ppo_abi_version() != ABI_VERSION:
+        raise ImportError(f"ABI mismatch: library {lib.mobrob_ppo_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    """C return code -> the exception class the reference would raise at this boundary."""
+    if rc >= 0:
+        return rc
+    msg = load().mobrob_ppo_last_error().decode()
+    if rc == ERR_INVALID:
+        raise ValueError(msg)
+    raise EngineError(f"[{rc}] {msg}")

@@ -1,0 +1,117 @@
+// Device-side helpers shared by all kernels: MFMA types, wave reductions, Philox4x32-10, Feistel.
+// gfx950 only: wavefront = 64 lanes, hard-coded.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mobrob {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum of one float per thread; result valid in thread 0.  `scratch` >= 16 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += scratch[i];
+  }
+  return r;
+}
+__device__ __forceinline__ double block_sum_d(double v, double* scratch) {
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += scratch[i];
+  }
+  return r;
+}
+
+// ---- Philox4x32-10 (Salmon et al. 2011); counter-based, restated bit-exactly in tests ----------
+struct Philox4 {
+  uint32_t x, y, z, w;
+};
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                          uint32_t k0, uint32_t k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  return Philox4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ float u32_to_unit_open(uint32_t x) {  // (0,1)
+  return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+// 4 uniforms -> 4 standard normals (Box-Muller)
+__device__ __forceinline__ void box_muller4(const Philox4& r, float out[4]) {
+  const float u0 = u32_to_unit_open(r.x), u1 = u32_to_unit_open(r.y);
+  const float u2 = u32_to_unit_open(r.z), u3 = u32_to_unit_open(r.w);
+  const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+  float s0, c0, s1, c1;
+  sincosf(6.28318530717958647692f * u1, &s0, &c0);
+  sincosf(6.28318530717958647692f * u3, &s1, &c1);
+  out[0] = ra * c0; out[1] = ra * s0; out[2] = rb * c1; out[3] = rb * s1;
+}
+
+// ---- Feistel permutation (oracle/ppo_oracle.py:feistel_permutation, bit-exact) ------------------
+__host__ __device__ __forceinline__ uint32_t feistel_rf(uint32_t r, int rnd, uint32_t k0, uint32_t k1,
+                                                        uint32_t mask) {
+  uint32_t x = r + 0x9E3779B9u * (uint32_t)(rnd + 1) + k0;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= k1; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x & mask;
+}
+__host__ __device__ __forceinline__ uint64_t feistel_perm(uint64_t i, uint64_t n, int half_bits, uint32_t k0,
+                                                          uint32_t k1) {
+  const uint32_t mask = (uint32_t)((1ull << half_bits) - 1ull);
+  uint64_t v = i;
+  do {
+    uint32_t l = (uint32_t)(v >> half_bits) & mask, r = (uint32_t)v & mask;
+#pragma unroll
+    for (int rnd = 0; rnd < 6; ++rnd) {
+      const uint32_t t = l ^ feistel_rf(r, rnd, k0, k1, mask);
+      l = r; r = t;
+    }
+    v = ((uint64_t)l << half_bits) | r;
+  } while (v >= n);
+  return v;
+}
+__host__ __device__ inline int feistel_half_bits(uint64_t n) {
+  int bits = 0;
+  uint64_t m = n > 1 ? n - 1 : 1;
+  while (m) { ++bits; m >>= 1; }
+  if (bits < 2) bits = 2;
+  if (bits & 1) ++bits;
+  return bits / 2;
+}
+
+}  // namespace mobrob

@@ -1,0 +1,815 @@
+// libmobrob_ppo.so -- host-side orchestration + C ABI (include/mobrob_ppo.h) of the MI355X PPO engine.
+// Reference surface replaced: stable_baselines3.PPO as configured by the reference's
+// src/mobrob/rl_control/ppo.py:50-59 and driven by :73-77 (see the header for per-entry citations).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mobrob_ppo.h"
+#include "kernels_generic.h"
+#include "kernels_fused.h"
+
+using namespace mobrob;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPC(expr)                                                                                            \
+  do {                                                                                                        \
+    hipError_t _e = (expr);                                                                                   \
+    if (_e != hipSuccess)                                                                                     \
+      return fail(MOBROB_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define CHK(expr)                   \
+  do {                              \
+    int _r = (expr);                \
+    if (_r != MOBROB_OK) return _r; \
+  } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int rup(int a, int b) { return cdiv(a, b) * b; }
+
+struct ProfSpan {
+  hipEvent_t a, b;
+  int id;
+};
+
+enum { T_LOGSTD = 0, T_PW1, T_PB1, T_PW2, T_PB2, T_VW1, T_VB1, T_VW2, T_VB2, T_AW, T_AB, T_VW, T_VB, T_COUNT };
+
+}  // namespace
+
+struct mobrob_ppo_engine {
+  mobrob_ppo_config_t cfg;
+  int D, Dp, A, Ap, H1, H2, G1, G2, N, T, P;
+  int Bl;        // local minibatch rows (batch_size / world)
+  int nmb;       // minibatches per epoch
+  int rows_max;  // max rows any forward sees at once
+  int offs[T_COUNT + 1];  // canonical parameter offsets (SB3 order); offs[13] = P
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // parameters / optimizer
+  float *params = nullptr, *grads = nullptr /* [P] + 8 loss sums */, *m = nullptr, *v = nullptr;
+  int* offs_dev = nullptr;
+  double* tensor_sq = nullptr;  // [13]
+  float *pW1p = nullptr, *vW1p = nullptr, *aWp = nullptr, *vWp = nullptr;  // zero-padded compute copies
+  int64_t adam_step = 0;
+  // rollout storage
+  float *obs = nullptr, *actions = nullptr, *rewards = nullptr, *es = nullptr, *values = nullptr, *logp = nullptr,
+        *adv = nullptr, *ret = nullptr;
+  float *last_values = nullptr, *last_dones = nullptr, *prev_dones = nullptr, *dones_tmp = nullptr;
+  float *clip_act = nullptr, *rew_tmp = nullptr, *term_obs = nullptr, *term_val = nullptr, *eps_dev = nullptr;
+  uint8_t *trunc_dev = nullptr, *dones_u8 = nullptr;
+  int* ep_len = nullptr;
+  bool env_started = false;
+  uint32_t draw_counter = 0;  // Philox draw index for eps
+  uint32_t env_step_counter = 0;
+  int t = 0;
+  bool rollout_ready = false;
+  // update
+  int* rows = nullptr;          // [T*N] device row index per permuted position
+  int64_t* perm_dev = nullptr;  // [T*N]
+  double* advstat = nullptr;    // [nmb][4]
+  uint64_t perm_counter = 0;
+  bool epoch_open = false;
+  float* stats = nullptr;  // [stats_cap][8]
+  int stats_cap = 0, stats_n = 0;
+  int cur_count = 0;
+  bool grad_pending = false;
+  // generic-path workspace
+  float *Xg = nullptr, *actg = nullptr, *lpg = nullptr, *advg = nullptr, *retg = nullptr;
+  float *h1p = nullptr, *h2p = nullptr, *h1v = nullptr, *h2v = nullptr, *mu = nullptr, *vout = nullptr;
+  float *dmu = nullptr, *dv = nullptr, *dz2p = nullptr, *dz1p = nullptr, *dz2v = nullptr, *dz1v = nullptr;
+  float *pred_obs = nullptr, *pred_act = nullptr;
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfSpan> spans;
+  std::vector<hipEvent_t> ev_pool;
+  double prof_ms[MOBROB_K_COUNT] = {0};
+  int64_t prof_calls[MOBROB_K_COUNT] = {0};
+  std::vector<void*> allocs;
+  FusedState fused;
+};
+
+namespace {
+
+template <typename Tp>
+int dalloc(mobrob_ppo_engine* e, Tp** p, size_t count) {
+  void* q = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(Tp);
+  HIPC(hipMalloc(&q, bytes));
+  HIPC(hipMemsetAsync(q, 0, bytes, e->stream));
+  e->allocs.push_back(q);
+  *p = static_cast<Tp*>(q);
+  return MOBROB_OK;
+}
+
+hipEvent_t get_event(mobrob_ppo_engine* e) {
+  if (!e->ev_pool.empty()) {
+    hipEvent_t ev = e->ev_pool.back();
+    e->ev_pool.pop_back();
+    return ev;
+  }
+  hipEvent_t ev;
+  (void)hipEventCreate(&ev);
+  return ev;
+}
+
+struct ProfScope {
+  mobrob_ppo_engine* e;
+  ProfSpan s;
+  bool on;
+  ProfScope(mobrob_ppo_engine* e_, int id) : e(e_), on(e_->prof_on) {
+    if (on) {
+      s.id = id;
+      s.a = get_event(e);
+      s.b = get_event(e);
+      (void)hipEventRecord(s.a, e->stream);
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      (void)hipEventRecord(s.b, e->stream);
+      e->spans.push_back(s);
+    }
+  }
+};
+
+void prof_resolve(mobrob_ppo_engine* e) {
+  for (auto& s : e->spans) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      e->prof_ms[s.id] += ms;
+      e->prof_calls[s.id] += 1;
+    }
+    e->ev_pool.push_back(s.a);
+    e->ev_pool.push_back(s.b);
+  }
+  e->spans.clear();
+}
+
+// ---- GEMM launchers --------------------------------------------------------------------------------
+template <int MODE, int EPI>
+void launch_gemm(mobrob_ppo_engine* e, const GemmArgs& g, int ksplit = 1) {
+  dim3 grid(cdiv(cdiv(g.M, 32), 4), cdiv(g.N, 32), ksplit);
+  hipLaunchKernelGGL((k_gemm<MODE, EPI>), grid, dim3(256), 0, e->stream, g);
+}
+
+// Y[M x Nn] = act(X[M x K] . W[Nn x K]^T + bias)
+void linear_fwd(mobrob_ppo_engine* e, const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y,
+                int ldy, int M, int Nn, int K, bool tanh_) {
+  GemmArgs g{};
+  g.A = X; g.B = W; g.C = Y; g.M = M; g.N = Nn; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldy; g.bias = bias;
+  if (tanh_) launch_gemm<MODE_NT, EPI_BIAS_TANH>(e, g);
+  else launch_gemm<MODE_NT, EPI_BIAS>(e, g);
+}
+// dZ[M x Nn] = (dY[M x K] . W[K x Nn]) * (1 - H^2) ; column sums -> bias grad
+void linear_bwd_input(mobrob_ppo_engine* e, const float* dY, int ldd, const float* W, int ldw, const float* H, int ldh,
+                      float* dZ, int ldz, float* bias_grad, int M, int Nn, int K) {
+  GemmArgs g{};
+  g.A = dY; g.B = W; g.C = dZ; g.M = M; g.N = Nn; g.K = K; g.lda = ldd; g.ldb = ldw; g.ldc = ldz;
+  g.Hact = H; g.ldh = ldh; g.colsum = bias_grad;
+  launch_gemm<MODE_NN, EPI_DTANH_COLSUM>(e, g);
+}
+// dW[M x Nn] += dY[rows x M]^T . X[rows x Nn]
+void linear_bwd_weight(mobrob_ppo_engine* e, const float* dY, int ldd, const float* X, int ldx, float* dW, int ldw,
+                       int M, int Nn, int rows) {
+  GemmArgs g{};
+  g.A = dY; g.B = X; g.C = dW; g.M = M; g.N = Nn; g.K = rows; g.lda = ldd; g.ldb = ldx; g.ldc = ldw;
+  const int tiles = cdiv(M, 32) * cdiv(Nn, 32);
+  int ksplit = std::max(1, std::min(cdiv(rows, 64), cdiv(4096, tiles)));
+  g.kchunk = rup(cdiv(rows, ksplit), 8);
+  ksplit = cdiv(rows, g.kchunk);
+  launch_gemm<MODE_TN, EPI_ATOMIC>(e, g, ksplit);
+}
+
+float* Pp(mobrob_ppo_engine* e, int t) { return e->params + e->offs[t]; }
+float* Gp(mobrob_ppo_engine* e, int t) { return e->grads + e->offs[t]; }
+
+void repack(mobrob_ppo_engine* e) {
+  auto pad = [&](const float* src, float* dst, int r, int c, int rp, int cp) {
+    hipLaunchKernelGGL(k_pad_rows, dim3(cdiv(rp * cp, 256)), dim3(256), 0, e->stream, src, dst, r, c, rp, cp);
+  };
+  pad(Pp(e, T_PW1), e->pW1p, e->H1, e->D, e->H1, e->Dp);
+  pad(Pp(e, T_VW1), e->vW1p, e->G1, e->D, e->G1, e->Dp);
+  pad(Pp(e, T_AW), e->aWp, e->A, e->H2, e->Ap, e->H2);
+  pad(Pp(e, T_VW), e->vWp, 1, e->G2, 8, e->G2);
+  fused_repack(e->fused, e->params, e->offs, e->stream);
+}
+
+// forward of both networks on `rows` device rows of padded observations (ld = Dp); mu ld = Ap, v ld = 1
+void forward_generic(mobrob_ppo_engine* e, const float* X, int rows, bool want_pi, float* mu_out, bool want_v,
+                     float* v_out) {
+  if (want_pi) {
+    linear_fwd(e, X, e->Dp, e->pW1p, e->Dp, Pp(e, T_PB1), e->h1p, e->H1, rows, e->H1, e->Dp, true);
+    linear_fwd(e, e->h1p, e->H1, Pp(e, T_PW2), e->H1, Pp(e, T_PB2), e->h2p, e->H2, rows, e->H2, e->H1, true);
+    linear_fwd(e, e->h2p, e->H2, e->aWp, e->H2, Pp(e, T_AB), mu_out, e->Ap, rows, e->A, e->H2, false);
+  }
+  if (want_v) {
+    linear_fwd(e, X, e->Dp, e->vW1p, e->Dp, Pp(e, T_VB1), e->h1v, e->G1, rows, e->G1, e->Dp, true);
+    linear_fwd(e, e->h1v, e->G1, Pp(e, T_VW2), e->G1, Pp(e, T_VB2), e->h2v, e->G2, rows, e->G2, e->G1, true);
+    linear_fwd(e, e->h2v, e->G2, e->vWp, e->G2, Pp(e, T_VB), v_out, 1, rows, 1, e->G2, false);
+  }
+}
+
+void forward(mobrob_ppo_engine* e, const float* X, int rows, bool want_pi, float* mu_out, bool want_v, float* v_out) {
+  if (e->fused.enabled && fused_forward(e->fused, X, rows, want_pi, mu_out, e->Ap, want_v, v_out, e->stream)) return;
+  forward_generic(e, X, rows, want_pi, mu_out, want_v, v_out);
+}
+
+void value_flagged(mobrob_ppo_engine* e, const float* obs_rows, const uint8_t* flags, float* out) {
+  const size_t sm = (size_t)(e->D + e->G1 + e->G2 + 16) * sizeof(float);
+  hipLaunchKernelGGL(k_value_flagged, dim3(e->N), dim3(256), sm, e->stream, obs_rows, e->Dp, flags, Pp(e, T_VW1),
+                     Pp(e, T_VB1), Pp(e, T_VW2), Pp(e, T_VB2), Pp(e, T_VW), Pp(e, T_VB), e->D, e->G1, e->G2, out);
+}
+
+void run_gae(mobrob_ppo_engine* e) {
+  ProfScope ps(e, MOBROB_K_GAE);
+  const double gl = e->cfg.gamma * e->cfg.gae_lambda;  // python: self.gamma * self.gae_lambda (float64)
+  hipLaunchKernelGGL(k_gae, dim3(cdiv(e->N, 64)), dim3(64), 0, e->stream, e->rewards, e->values, e->es, e->last_values,
+                     e->last_dones, (float)e->cfg.gamma, gl, e->T, e->N, e->adv, e->ret);
+}
+
+// policy forward + sample for rollout slot t (observations already in the slot)
+void act_slot(mobrob_ppo_engine* e, int t, const float* eps_dev_or_null) {
+  ProfScope ps(e, MOBROB_K_ACT);
+  const float* X = e->obs + (size_t)t * e->N * e->Dp;
+  forward(e, X, e->N, true, e->mu, true, e->values + (size_t)t * e->N);
+  hipLaunchKernelGGL(k_sample, dim3(cdiv(e->N, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, Pp(e, T_LOGSTD),
+                     eps_dev_or_null, e->N, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high, e->cfg.seed,
+                     e->draw_counter, e->actions + (size_t)t * e->N * e->A, e->clip_act, e->logp + (size_t)t * e->N);
+  e->draw_counter++;
+}
+
+int upload_obs(mobrob_ppo_engine* e, const float* host, float* dev_rows, int rows) {
+  HIPC(hipMemcpy2DAsync(dev_rows, (size_t)e->Dp * 4, host, (size_t)e->D * 4, (size_t)e->D * 4, rows,
+                        hipMemcpyHostToDevice, e->stream));
+  return MOBROB_OK;
+}
+
+int check_cfg(const mobrob_ppo_config_t* c) {
+  if (c->abi_version != MOBROB_PPO_ABI_VERSION) return fail(MOBROB_ERR_INVALID, "abi_version %d != %d", c->abi_version, MOBROB_PPO_ABI_VERSION);
+  if (c->obs_dim < 1 || c->act_dim < 1) return fail(MOBROB_ERR_INVALID, "obs_dim/act_dim must be >= 1");
+  for (int i = 0; i < 2; ++i)
+    if (c->pi_hidden[i] < 8 || c->pi_hidden[i] % 8 || c->vf_hidden[i] < 8 || c->vf_hidden[i] % 8)
+      return fail(MOBROB_ERR_INVALID, "hidden widths must be positive multiples of 8 (two layers per network)");
+  if (c->n_envs < 1 || c->n_steps < 1 || c->batch_size < 1 || c->n_epochs < 1)
+    return fail(MOBROB_ERR_INVALID, "n_envs, n_steps, batch_size, n_epochs must be >= 1");
+  if (c->world_size < 1 || c->rank < 0 || c->rank >= c->world_size) return fail(MOBROB_ERR_INVALID, "bad rank/world_size");
+  if (c->batch_size % c->world_size) return fail(MOBROB_ERR_INVALID, "batch_size must be divisible by world_size");
+  if ((int64_t)c->n_envs * c->n_steps > (int64_t)1 << 30) return fail(MOBROB_ERR_INVALID, "rollout too large");
+  return MOBROB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mobrob_ppo_abi_version(void) { return MOBROB_PPO_ABI_VERSION; }
+const char* mobrob_ppo_last_error(void) { return g_err.c_str(); }
+
+void mobrob_ppo_default_config(mobrob_ppo_config_t* c) {
+  memset(c, 0, sizeof *c);
+  c->abi_version = MOBROB_PPO_ABI_VERSION;
+  c->obs_dim = 58; c->act_dim = 12;
+  c->pi_hidden[0] = c->pi_hidden[1] = 64;
+  c->vf_hidden[0] = c->vf_hidden[1] = 64;
+  c->n_envs = 1; c->n_steps = 2048; c->batch_size = 64; c->n_epochs = 10;
+  c->gamma = 0.99; c->gae_lambda = 0.95; c->clip_range = 0.2; c->ent_coef = 0.0; c->vf_coef = 0.5;
+  c->max_grad_norm = 0.5; c->learning_rate = 3e-4; c->adam_beta1 = 0.9; c->adam_beta2 = 0.999; c->adam_eps = 1e-5;
+  c->action_low = -1.0; c->action_high = 1.0;
+  c->normalize_advantage = 1; c->seed = 0; c->device_id = 0; c->rank = 0; c->world_size = 1; c->fast_kernels = 1;
+}
+
+void* mobrob_ppo_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void mobrob_ppo_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int mobrob_ppo_create(const mobrob_ppo_config_t* cfg, mobrob_ppo_engine_t** out) {
+  if (!cfg || !out) return fail(MOBROB_ERR_INVALID, "null argument");
+  CHK(check_cfg(cfg));
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(MOBROB_ERR_NO_DEVICE, "no HIP device visible: libmobrob_ppo has no CPU fallback");
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(MOBROB_ERR_INVALID, "device_id %d out of range (%d devices)", cfg->device_id, ndev);
+  HIPC(hipSetDevice(cfg->device_id));
+  hipDeviceProp_t prop;
+  HIPC(hipGetDeviceProperties(&prop, cfg->device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(MOBROB_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", cfg->device_id, prop.gcnArchName);
+
+  auto* e = new mobrob_ppo_engine();
+  e->cfg = *cfg;
+  e->D = cfg->obs_dim; e->Dp = rup(cfg->obs_dim, 8); e->A = cfg->act_dim; e->Ap = rup(cfg->act_dim, 8);
+  e->H1 = cfg->pi_hidden[0]; e->H2 = cfg->pi_hidden[1]; e->G1 = cfg->vf_hidden[0]; e->G2 = cfg->vf_hidden[1];
+  e->N = cfg->n_envs; e->T = cfg->n_steps;
+  e->Bl = cfg->batch_size / cfg->world_size;
+  const int total = e->N * e->T;
+  e->nmb = cdiv(total, e->Bl);
+  e->rows_max = std::max(e->N, std::min(e->Bl, total));
+  const int sizes[T_COUNT] = {e->A, e->H1 * e->D, e->H1, e->H2 * e->H1, e->H2, e->G1 * e->D, e->G1, e->G2 * e->G1,
+                              e->G2, e->A * e->H2, e->A, e->G2, 1};
+  e->offs[0] = 0;
+  for (int i = 0; i < T_COUNT; ++i) e->offs[i + 1] = e->offs[i] + sizes[i];
+  e->P = e->offs[T_COUNT];
+  HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  e->own_stream = true;
+  *out = e;  // so that destroy() can clean up after a partial failure
+
+  const size_t P = e->P, N = e->N, T = e->T, Dp = e->Dp, A = e->A, Bl = std::min(e->Bl, total), R = e->rows_max;
+  CHK(dalloc(e, &e->params, P)); CHK(dalloc(e, &e->grads, P + 8)); CHK(dalloc(e, &e->m, P)); CHK(dalloc(e, &e->v, P));
+  CHK(dalloc(e, &e->offs_dev, T_COUNT + 1)); CHK(dalloc(e, &e->tensor_sq, T_COUNT));
+  CHK(dalloc(e, &e->pW1p, (size_t)e->H1 * Dp)); CHK(dalloc(e, &e->vW1p, (size_t)e->G1 * Dp));
+  CHK(dalloc(e, &e->aWp, (size_t)e->Ap * e->H2)); CHK(dalloc(e, &e->vWp, (size_t)8 * e->G2));
+  CHK(dalloc(e, &e->obs, (T + 1) * N * Dp)); CHK(dalloc(e, &e->actions, T * N * A));
+  CHK(dalloc(e, &e->rewards, T * N)); CHK(dalloc(e, &e->es, T * N)); CHK(dalloc(e, &e->values, T * N));
+  CHK(dalloc(e, &e->logp, T * N)); CHK(dalloc(e, &e->adv, T * N)); CHK(dalloc(e, &e->ret, T * N));
+  CHK(dalloc(e, &e->last_values, N)); CHK(dalloc(e, &e->last_dones, N)); CHK(dalloc(e, &e->prev_dones, N));
+  CHK(dalloc(e, &e->dones_tmp, N)); CHK(dalloc(e, &e->clip_act, N * A)); CHK(dalloc(e, &e->rew_tmp, N));
+  CHK(dalloc(e, &e->term_obs, N * Dp)); CHK(dalloc(e, &e->term_val, N)); CHK(dalloc(e, &e->eps_dev, R * A));
+  CHK(dalloc(e, &e->trunc_dev, N)); CHK(dalloc(e, &e->dones_u8, N)); CHK(dalloc(e, &e->ep_len, N));
+  CHK(dalloc(e, &e->rows, T * N)); CHK(dalloc(e, &e->perm_dev, T * N)); CHK(dalloc(e, &e->advstat, (size_t)e->nmb * 4));
+  e->stats_cap = std::max(64, 4 * e->nmb * cfg->n_epochs);
+  CHK(dalloc(e, &e->stats, (size_t)e->stats_cap * 8));
+  CHK(dalloc(e, &e->Xg, Bl * Dp)); CHK(dalloc(e, &e->actg, Bl * A)); CHK(dalloc(e, &e->lpg, Bl));
+  CHK(dalloc(e, &e->advg, Bl)); CHK(dalloc(e, &e->retg, Bl));
+  CHK(dalloc(e, &e->h1p, R * e->H1)); CHK(dalloc(e, &e->h2p, R * e->H2)); CHK(dalloc(e, &e->h1v, R * e->G1));
+  CHK(dalloc(e, &e->h2v, R * e->G2)); CHK(dalloc(e, &e->mu, R * e->Ap)); CHK(dalloc(e, &e->vout, R));
+  CHK(dalloc(e, &e->dmu, Bl * e->Ap)); CHK(dalloc(e, &e->dv, Bl * 8));
+  CHK(dalloc(e, &e->dz2p, Bl * e->H2)); CHK(dalloc(e, &e->dz1p, Bl * e->H1));
+  CHK(dalloc(e, &e->dz2v, Bl * e->G2)); CHK(dalloc(e, &e->dz1v, Bl * e->G1));
+  CHK(dalloc(e, &e->pred_obs, R * Dp)); CHK(dalloc(e, &e->pred_act, R * A));
+  HIPC(hipMemcpyAsync(e->offs_dev, e->offs, sizeof e->offs, hipMemcpyHostToDevice, e->stream));
+  // `_last_episode_starts` is all-True at _setup_learn (Appendix A.5)
+  std::vector<float> ones(N, 1.0f);
+  HIPC(hipMemcpyAsync(e->prev_dones, ones.data(), N * 4, hipMemcpyHostToDevice, e->stream));
+  HIPC(hipStreamSynchronize(e->stream));
+  repack(e);
+  HIPC(hipStreamSynchronize(e->stream));
+  return MOBROB_OK;
+}
+
+void mobrob_ppo_destroy(mobrob_ppo_engine_t* e) {
+  if (!e) return;
+  (void)hipStreamSynchronize(e->stream);
+  prof_resolve(e);
+  for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+  for (void* p : e->allocs) (void)hipFree(p);
+  if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int mobrob_ppo_set_stream(mobrob_ppo_engine_t* e, void* s) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  HIPC(hipStreamSynchronize(e->stream));
+  if (e->own_stream && e->stream) HIPC(hipStreamDestroy(e->stream));
+  if (s == nullptr) {
+    HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->own_stream = true;
+  } else {
+    e->stream = static_cast<hipStream_t>(s);
+    e->own_stream = false;
+  }
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_synchronize(mobrob_ppo_engine_t* e) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  HIPC(hipStreamSynchronize(e->stream));
+  return MOBROB_OK;
+}
+
+int64_t mobrob_ppo_param_count(const mobrob_ppo_engine_t* e) { return e ? e->P : -1; }
+
+int mobrob_ppo_get_params(mobrob_ppo_engine_t* e, float* out, int64_t n) {
+  if (!e || !out || n != e->P) return fail(MOBROB_ERR_INVALID, "get_params: n=%lld, expected %d", (long long)n, e ? e->P : -1);
+  HIPC(hipMemcpyAsync(out, e->params, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+  HIPC(hipStreamSynchronize(e->stream));
+  return MOBROB_OK;
+}
+int mobrob_ppo_set_params(mobrob_ppo_engine_t* e, const float* in, int64_t n) {
+  if (!e || !in || n != e->P) return fail(MOBROB_ERR_INVALID, "set_params: n=%lld, expected %d", (long long)n, e ? e->P : -1);
+  HIPC(hipMemcpyAsync(e->params, in, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+  repack(e);
+  HIPC(hipStreamSynchronize(e->stream));
+  return MOBROB_OK;
+}
+int mobrob_ppo_get_optimizer_state(mobrob_ppo_engine_t* e, float* m, float* v, int64_t n, int64_t* step) {
+  if (!e || n != e->P) return fail(MOBROB_ERR_INVALID, "get_optimizer_state: bad size");
+  if (m) HIPC(hipMemcpyAsync(m, e->m, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+  if (v) HIPC(hipMemcpyAsync(v, e->v, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+  HIPC(hipStreamSynchronize(e->stream));
+  if (step) *step = e->adam_step;
+  return MOBROB_OK;
+}
+int mobrob_ppo_set_optimizer_state(mobrob_ppo_engine_t* e, const float* m, const float* v, int64_t n, int64_t step) {
+  if (!e || !m || !v || n != e->P || step < 0) return fail(MOBROB_ERR_INVALID, "set_optimizer_state: bad argument");
+  HIPC(hipMemcpyAsync(e->m, m, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+  HIPC(hipMemcpyAsync(e->v, v, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+  HIPC(hipStreamSynchronize(e->stream));
+  e->adam_step = step;
+  return MOBROB_OK;
+}
+
+// ---- rollout ---------------------------------------------------------------------------------------
+int mobrob_ppo_rollout_begin(mobrob_ppo_engine_t* e) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  e->t = 0;
+  e->rollout_ready = false;
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_act(mobrob_ppo_engine_t* e, const float* obs, const float* eps, float* a_raw, float* a_clip,
+                   float* values, float* logp) {
+  if (!e || !obs) return fail(MOBROB_ERR_INVALID, "act: null argument");
+  if (e->t >= e->T) return fail(MOBROB_ERR_STATE, "act: rollout buffer full (t=%d, n_steps=%d)", e->t, e->T);
+  const size_t N = e->N, A = e->A;
+  CHK(upload_obs(e, obs, e->obs + (size_t)e->t * N * e->Dp, e->N));
+  if (eps) HIPC(hipMemcpyAsync(e->eps_dev, eps, N * A * 4, hipMemcpyHostToDevice, e->stream));
+  act_slot(e, e->t, eps ? e->eps_dev : nullptr);
+  if (a_raw) HIPC(hipMemcpyAsync(a_raw, e->actions + (size_t)e->t * N * A, N * A * 4, hipMemcpyDeviceToHost, e->stream));
+  if (a_clip) HIPC(hipMemcpyAsync(a_clip, e->clip_act, N * A * 4, hipMemcpyDeviceToHost, e->stream));
+  if (values) HIPC(hipMemcpyAsync(values, e->values + (size_t)e->t * N, N * 4, hipMemcpyDeviceToHost, e->stream));
+  if (logp) HIPC(hipMemcpyAsync(logp, e->logp + (size_t)e->t * N, N * 4, hipMemcpyDeviceToHost, e->stream));
+  HIPC(hipStreamSynchronize(e->stream));
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_store(mobrob_ppo_engine_t* e, const float* rewards, const uint8_t* dones, const uint8_t* truncated,
+                     const float* terminal_obs) {
+  if (!e || !rewards || !dones) return fail(MOBROB_ERR_INVALID, "store: null argument");
+  if (e->t >= e->T) return fail(MOBROB_ERR_STATE, "store: rollout buffer full");
+  const size_t N = e->N;
+  HIPC(hipMemcpyAsync(e->rew_tmp, rewards, N * 4, hipMemcpyHostToDevice, e->stream));
+  HIPC(hipMemcpyAsync(e->dones_u8, dones, N, hipMemcpyHostToDevice, e->stream));
+  bool any_trunc = false;
+  if (truncated && terminal_obs)
+    for (size_t i = 0; i < N; ++i) any_trunc |= truncated[i] != 0;
+  if (any_trunc) {
+    HIPC(hipMemcpyAsync(e->trunc_dev, truncated, N, hipMemcpyHostToDevice, e->stream));
+    CHK(upload_obs(e, terminal_obs, e->term_obs, e->N));
+    value_flagged(e, e->term_obs, e->trunc_dev, e->term_val);
+  }
+  hipLaunchKernelGGL(k_store_step, dim3(cdiv(e->N, 256)), dim3(256), 0, e->stream, e->rew_tmp, e->prev_dones,
+                     any_trunc ? e->trunc_dev : nullptr, e->term_val, (float)e->cfg.gamma, e->N,
+                     e->rewards + (size_t)e->t * N, e->es + (size_t)e->t * N);
+  hipLaunchKernelGGL(k_u8_to_f32, dim3(cdiv(e->N, 256)), dim3(256), 0, e->stream, e->dones_u8, e->prev_dones, e->N);
+  HIPC(hipStreamSynchronize(e->stream));  // host buffers may be reused by the caller
+  e->t++;
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_finish_rollout(mobrob_ppo_engine_t* e, const float* last_obs, const uint8_t* dones) {
+  if (!e || !last_obs || !dones) return fail(MOBROB_ERR_INVALID, "finish_rollout: null argument");
+  if (e->t != e->T) return fail(MOBROB_ERR_STATE, "finish_rollout: %d of %d steps stored", e->t, e->T);
+  const size_t N = e->N;
+  float* slot = e->obs + (size_t)e->T * N * e->Dp;
+  CHK(upload_obs(e, last_obs, slot, e->N));
+  HIPC(hipMemcpyAsync(e->dones_u8, dones, N, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_u8_to_f32, dim3(cdiv(e->N, 256)), dim3(256), 0, e->stream, e->dones_u8, e->last_dones, e->N);
+  forward(e, slot, e->N, false, nullptr, true, e->last_values);
+  run_gae(e);
+  HIPC(hipStreamSynchronize(e->stream));
+  e->rollout_ready = true;
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_compute_gae(mobrob_ppo_engine_t* e) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  run_gae(e);
+  HIPC(hipStreamSynchronize(e->stream));
+  e->rollout_ready = true;
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_mark_rollout_ready(mobrob_ppo_engine_t* e) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  e->rollout_ready = true;
+  e->t = e->T;
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_collect_synthetic(mobrob_ppo_engine_t* e, float p_term, int32_t time_limit) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  const int N = e->N, Dp = e->Dp, per = Dp / 4;
+  const size_t slot = (size_t)N * Dp;
+  const uint64_t env_seed = e->cfg.seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(e->cfg.rank + 1));
+  if (!e->env_started) {
+    hipLaunchKernelGGL(k_env_reset, dim3(cdiv(N * per, 256)), dim3(256), 0, e->stream, env_seed, N, e->D, Dp, e->obs,
+                       e->ep_len);
+    e->env_started = true;
+  } else {
+    HIPC(hipMemcpyAsync(e->obs, e->obs + (size_t)e->T * slot, slot * 4, hipMemcpyDeviceToDevice, e->stream));
+  }
+  e->rollout_ready = false;
+  for (int t = 0; t < e->T; ++t) {
+    act_slot(e, t, nullptr);
+    {
+      ProfScope ps(e, MOBROB_K_ENV);
+      hipLaunchKernelGGL(k_env_step, dim3(cdiv(N * per, 256)), dim3(256), 0, e->stream, env_seed, e->env_step_counter,
+                         N, e->D, Dp, p_term, time_limit, e->ep_len, e->obs + (size_t)(t + 1) * slot, e->term_obs,
+                         e->rew_tmp, e->dones_tmp, e->trunc_dev);
+      hipLaunchKernelGGL(k_env_advance, dim3(cdiv(N, 256)), dim3(256), 0, e->stream, N, e->dones_tmp, e->ep_len);
+    }
+    e->env_step_counter++;
+    value_flagged(e, e->term_obs, e->trunc_dev, e->term_val);
+    hipLaunchKernelGGL(k_store_step, dim3(cdiv(N, 256)), dim3(256), 0, e->stream, e->rew_tmp, e->prev_dones,
+                       e->trunc_dev, e->term_val, (float)e->cfg.gamma, N, e->rewards + (size_t)t * N,
+                       e->es + (size_t)t * N);
+    std::swap(e->prev_dones, e->dones_tmp);
+  }
+  HIPC(hipMemcpyAsync(e->last_dones, e->prev_dones, (size_t)N * 4, hipMemcpyDeviceToDevice, e->stream));
+  forward(e, e->obs + (size_t)e->T * slot, N, false, nullptr, true, e->last_values);
+  run_gae(e);
+  HIPC(hipGetLastError());
+  e->t = e->T;
+  e->rollout_ready = true;
+  return MOBROB_OK;
+}
+
+// ---- update ----------------------------------------------------------------------------------------
+int mobrob_ppo_num_minibatches(const mobrob_ppo_engine_t* e) { return e ? e->nmb : -1; }
+
+int mobrob_ppo_epoch_begin(mobrob_ppo_engine_t* e, const int64_t* perm) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  if (!e->rollout_ready) return fail(MOBROB_ERR_STATE, "epoch_begin: rollout not finished (finish_rollout / collect first)");
+  const int total = e->N * e->T;
+  if (perm) {
+    HIPC(hipMemcpyAsync(e->perm_dev, perm, (size_t)total * 8, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_perm_from_host, dim3(cdiv(total, 256)), dim3(256), 0, e->stream, e->perm_dev, total, e->T,
+                       e->N, e->rows);
+  } else {
+    const uint64_t key = (e->cfg.seed * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(e->cfg.rank + 1) << 48) ^ (e->perm_counter + 1);
+    e->perm_counter++;
+    hipLaunchKernelGGL(k_perm_feistel, dim3(cdiv(total, 256)), dim3(256), 0, e->stream, total, e->T, e->N,
+                       feistel_half_bits((uint64_t)total), (uint32_t)key, (uint32_t)(key >> 32), e->rows,
+                       (int64_t*)nullptr);
+  }
+  hipLaunchKernelGGL(k_adv_stats, dim3(e->nmb), dim3(1024), 0, e->stream, e->adv, e->rows, total, e->Bl, e->advstat);
+  HIPC(hipGetLastError());
+  e->epoch_open = true;
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  if (!e->epoch_open) return fail(MOBROB_ERR_STATE, "minibatch_grad before epoch_begin");
+  if (mb < 0 || mb >= e->nmb) return fail(MOBROB_ERR_INVALID, "minibatch %d out of range [0,%d)", mb, e->nmb);
+  ProfScope ps(e, MOBROB_K_TRAIN_GRAD);
+  const int total = e->N * e->T;
+  const int start = mb * e->Bl;
+  const int B = std::min(e->Bl, total - start);
+  const float inv_bg = 1.0f / (float)((int64_t)B * e->cfg.world_size);
+  e->cur_count = B;
+  HIPC(hipMemsetAsync(e->grads, 0, (size_t)(e->P + 8) * 4, e->stream));
+  float* sums = e->grads + e->P;
+  const int per = e->Dp / 4;
+  hipLaunchKernelGGL(k_gather, dim3(cdiv(B * per, 256)), dim3(256), 0, e->stream, e->rows + start, B, e->obs, e->Dp,
+                     e->actions, e->A, e->logp, e->adv, e->ret, e->Xg, e->actg, e->lpg, e->advg, e->retg);
+  forward_generic(e, e->Xg, B, true, e->mu, true, e->vout);
+  LossArgs L{};
+  L.mu = e->mu; L.ldmu = e->Ap; L.v = e->vout; L.actions = e->actg; L.old_logp = e->lpg; L.adv = e->advg;
+  L.ret = e->retg; L.log_std = Pp(e, T_LOGSTD); L.advstat = e->advstat + 4 * (size_t)mb; L.B = B; L.A = e->A;
+  L.normalize = e->cfg.normalize_advantage; L.clip = (float)e->cfg.clip_range; L.vf_coef = (float)e->cfg.vf_coef;
+  L.ent_coef = (float)e->cfg.ent_coef; L.inv_bg = inv_bg; L.dmu = e->dmu; L.lddmu = e->Ap; L.dv = e->dv; L.lddv = 8;
+  L.sums = sums; L.g_log_std = Gp(e, T_LOGSTD); L.g_b_action = Gp(e, T_AB); L.g_b_value = Gp(e, T_VB);
+  // padding columns of dmu/dv must be zero (K padding of the NN GEMM)
+  HIPC(hipMemsetAsync(e->dmu, 0, (size_t)B * e->Ap * 4, e->stream));
+  HIPC(hipMemsetAsync(e->dv, 0, (size_t)B * 8 * 4, e->stream));
+  hipLaunchKernelGGL(k_loss, dim3(cdiv(B, 256)), dim3(256), 0, e->stream, L);
+  hipLaunchKernelGGL(k_entropy_grad, dim3(1), dim3(64), 0, e->stream, Gp(e, T_LOGSTD), e->A, (float)e->cfg.ent_coef,
+                     (float)B, inv_bg);
+  // policy network backward
+  linear_bwd_weight(e, e->dmu, e->Ap, e->h2p, e->H2, Gp(e, T_AW), e->H2, e->A, e->H2, B);
+  linear_bwd_input(e, e->dmu, e->Ap, e->aWp, e->H2, e->h2p, e->H2, e->dz2p, e->H2, Gp(e, T_PB2), B, e->H2, e->Ap);
+  linear_bwd_weight(e, e->dz2p, e->H2, e->h1p, e->H1, Gp(e, T_PW2), e->H1, e->H2, e->H1, B);
+  linear_bwd_input(e, e->dz2p, e->H2, Pp(e, T_PW2), e->H1, e->h1p, e->H1, e->dz1p, e->H1, Gp(e, T_PB1), B, e->H1, e->H2);
+  linear_bwd_weight(e, e->dz1p, e->H1, e->Xg, e->Dp, Gp(e, T_PW1), e->D, e->H1, e->D, B);
+  // value network backward
+  linear_bwd_weight(e, e->dv, 8, e->h2v, e->G2, Gp(e, T_VW), e->G2, 1, e->G2, B);
+  linear_bwd_input(e, e->dv, 8, e->vWp, e->G2, e->h2v, e->G2, e->dz2v, e->G2, Gp(e, T_VB2), B, e->G2, 8);
+  linear_bwd_weight(e, e->dz2v, e->G2, e->h1v, e->G1, Gp(e, T_VW2), e->G1, e->G2, e->G1, B);
+  linear_bwd_input(e, e->dz2v, e->G2, Pp(e, T_VW2), e->G1, e->h1v, e->G1, e->dz1v, e->G1, Gp(e, T_VB1), B, e->G1, e->G2);
+  linear_bwd_weight(e, e->dz1v, e->G1, e->Xg, e->Dp, Gp(e, T_VW1), e->D, e->G1, e->D, B);
+  HIPC(hipGetLastError());
+  e->grad_pending = true;
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_minibatch_apply(mobrob_ppo_engine_t* e) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  if (!e->grad_pending) return fail(MOBROB_ERR_STATE, "minibatch_apply without a pending gradient");
+  ProfScope ps(e, MOBROB_K_APPLY);
+  hipLaunchKernelGGL(k_tensor_sqnorm, dim3(T_COUNT), dim3(1024), 0, e->stream, e->grads, e->offs_dev, (int)T_COUNT,
+                     e->tensor_sq);
+  e->adam_step++;
+  const double b1 = e->cfg.adam_beta1, b2 = e->cfg.adam_beta2;
+  const double bc1 = 1.0 - std::pow(b1, (double)e->adam_step);
+  const double bc2 = 1.0 - std::pow(b2, (double)e->adam_step);
+  AdamArgs a{};
+  a.p = e->params; a.g = e->grads; a.m = e->m; a.v = e->v; a.P = e->P; a.tensor_sq = e->tensor_sq; a.ntensors = T_COUNT;
+  a.max_norm = (float)e->cfg.max_grad_norm; a.step_size = (float)(e->cfg.learning_rate / bc1);
+  a.bc2_sqrt = (float)std::sqrt(bc2); a.beta1 = (float)b1; a.beta2 = (float)b2; a.eps = (float)e->cfg.adam_eps;
+  if (e->stats_n >= e->stats_cap) e->stats_n = 0;  // ring: oldest rows are dropped if nobody fetched them
+  a.stats_row = e->stats + (size_t)e->stats_n * 8;
+  e->stats_n++;
+  a.loss_sums = e->grads + e->P; a.ent_coef = (float)e->cfg.ent_coef; a.vf_coef = (float)e->cfg.vf_coef;
+  a.inv_bg = 1.0f / (float)((int64_t)e->cur_count * e->cfg.world_size);
+  a.log_std = Pp(e, T_LOGSTD); a.A = e->A;
+  hipLaunchKernelGGL(k_adam, dim3(cdiv(e->P, 256)), dim3(256), 0, e->stream, a);
+  repack(e);
+  HIPC(hipGetLastError());
+  e->grad_pending = false;
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_fetch_step_stats(mobrob_ppo_engine_t* e, float* out, int32_t max_rows) {
+  if (!e || !out || max_rows < 0) return fail(MOBROB_ERR_INVALID, "fetch_step_stats: bad argument");
+  const int n = std::min<int>(max_rows, e->stats_n);
+  if (n > 0) {
+    HIPC(hipMemcpyAsync(out, e->stats + (size_t)(e->stats_n - n) * 8, (size_t)n * 32, hipMemcpyDeviceToHost, e->stream));
+  }
+  HIPC(hipStreamSynchronize(e->stream));
+  e->stats_n = 0;
+  return n;
+}
+
+int mobrob_ppo_train(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_ppo_train_stats_t* st) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  if (e->cfg.world_size != 1)
+    return fail(MOBROB_ERR_STATE, "mobrob_ppo_train is the single-rank loop; data-parallel ranks drive epoch_begin/"
+                                  "minibatch_grad/[all-reduce]/minibatch_apply");
+  const size_t total = (size_t)e->N * e->T;
+  e->stats_n = 0;
+  for (int ep = 0; ep < e->cfg.n_epochs; ++ep) {
+    CHK(mobrob_ppo_epoch_begin(e, perms ? perms + (size_t)ep * total : nullptr));
+    if (ep == e->cfg.n_epochs - 1) e->stats_n = 0;
+    for (int mb = 0; mb < e->nmb; ++mb) {
+      CHK(mobrob_ppo_minibatch_grad(e, mb));
+      CHK(mobrob_ppo_minibatch_apply(e));
+    }
+  }
+  e->epoch_open = false;
+  if (st) {
+    std::vector<float> rows((size_t)e->nmb * 8);
+    const int n = mobrob_ppo_fetch_step_stats(e, rows.data(), e->nmb);
+    if (n < 0) return n;
+    double acc[7] = {0};
+    for (int i = 0; i < n; ++i)
+      for (int k = 0; k < 7; ++k) acc[k] += rows[(size_t)i * 8 + k];
+    const double d = n > 0 ? n : 1;
+    st->policy_loss = (float)(acc[0] / d); st->value_loss = (float)(acc[1] / d); st->entropy_loss = (float)(acc[2] / d);
+    st->loss = (float)(acc[3] / d); st->approx_kl = (float)(acc[4] / d); st->clip_fraction = (float)(acc[5] / d);
+    st->grad_norm = (float)(acc[6] / d); st->n_minibatches = e->cfg.n_epochs * e->nmb;
+  } else {
+    HIPC(hipStreamSynchronize(e->stream));
+  }
+  return MOBROB_OK;
+}
+
+// ---- inference --------------------------------------------------------------------------------------
+int mobrob_ppo_predict(mobrob_ppo_engine_t* e, const float* obs, int32_t n, int32_t deterministic, const float* eps,
+                       float* actions, float* values) {
+  if (!e || !obs || n < 1) return fail(MOBROB_ERR_INVALID, "predict: bad argument");
+  for (int s = 0; s < n; s += e->rows_max) {
+    const int c = std::min(e->rows_max, n - s);
+    CHK(upload_obs(e, obs + (size_t)s * e->D, e->pred_obs, c));
+    forward(e, e->pred_obs, c, actions != nullptr, e->mu, values != nullptr, e->vout);
+    if (actions) {
+      float* scratch = e->pred_act;
+      if (deterministic) {
+        hipLaunchKernelGGL(k_clip_mean, dim3(cdiv(c * e->A, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, c, e->A,
+                           (float)e->cfg.action_low, (float)e->cfg.action_high, scratch);
+      } else {
+        const float* epsd = nullptr;
+        if (eps) {
+          HIPC(hipMemcpyAsync(e->eps_dev, eps + (size_t)s * e->A, (size_t)c * e->A * 4, hipMemcpyHostToDevice, e->stream));
+          epsd = e->eps_dev;
+        }
+        hipLaunchKernelGGL(k_sample, dim3(cdiv(c, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, Pp(e, T_LOGSTD), epsd,
+                           c, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high, e->cfg.seed, e->draw_counter,
+                           (float*)nullptr, scratch, (float*)nullptr);
+        e->draw_counter++;
+      }
+      HIPC(hipMemcpyAsync(actions + (size_t)s * e->A, scratch, (size_t)c * e->A * 4, hipMemcpyDeviceToHost, e->stream));
+    }
+    if (values) HIPC(hipMemcpyAsync(values + s, e->vout, (size_t)c * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPC(hipStreamSynchronize(e->stream));
+  }
+  return MOBROB_OK;
+}
+
+// ---- buffers ----------------------------------------------------------------------------------------
+int mobrob_ppo_buffer_info(mobrob_ppo_engine_t* e, int32_t which, void** ptr, size_t* bytes) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  const size_t N = e->N, T = e->T;
+  void* p = nullptr;
+  size_t b = 0;
+  switch (which) {
+    case MOBROB_BUF_OBS: p = e->obs; b = (T + 1) * N * e->Dp * 4; break;
+    case MOBROB_BUF_ACTIONS: p = e->actions; b = T * N * e->A * 4; break;
+    case MOBROB_BUF_REWARDS: p = e->rewards; b = T * N * 4; break;
+    case MOBROB_BUF_EPISODE_STARTS: p = e->es; b = T * N * 4; break;
+    case MOBROB_BUF_VALUES: p = e->values; b = T * N * 4; break;
+    case MOBROB_BUF_LOG_PROBS: p = e->logp; b = T * N * 4; break;
+    case MOBROB_BUF_ADVANTAGES: p = e->adv; b = T * N * 4; break;
+    case MOBROB_BUF_RETURNS: p = e->ret; b = T * N * 4; break;
+    case MOBROB_BUF_PARAMS: p = e->params; b = (size_t)e->P * 4; break;
+    case MOBROB_BUF_GRADS: p = e->grads; b = (size_t)e->P * 4; break;
+    case MOBROB_BUF_ADVSTAT: p = e->advstat; b = (size_t)e->nmb * 4 * 8; break;
+    case MOBROB_BUF_LAST_VALUES: p = e->last_values; b = N * 4; break;
+    case MOBROB_BUF_LAST_DONES: p = e->last_dones; b = N * 4; break;
+    case MOBROB_BUF_CLIPPED_ACTIONS: p = e->clip_act; b = N * e->A * 4; break;
+    default: return fail(MOBROB_ERR_INVALID, "unknown buffer id %d", which);
+  }
+  if (ptr) *ptr = p;
+  if (bytes) *bytes = b;
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_read_buffer(mobrob_ppo_engine_t* e, int32_t which, void* host, size_t bytes) {
+  if (!e || !host) return fail(MOBROB_ERR_INVALID, "read_buffer: null argument");
+  void* p; size_t b;
+  CHK(mobrob_ppo_buffer_info(e, which, &p, &b));
+  if (which == MOBROB_BUF_OBS) {  // host layout [T+1][N][D]
+    const size_t rows = (size_t)(e->T + 1) * e->N;
+    if (bytes != rows * e->D * 4) return fail(MOBROB_ERR_INVALID, "read_buffer(OBS): expected %zu bytes", rows * e->D * 4);
+    HIPC(hipMemcpy2DAsync(host, (size_t)e->D * 4, p, (size_t)e->Dp * 4, (size_t)e->D * 4, rows, hipMemcpyDeviceToHost, e->stream));
+  } else {
+    if (bytes != b) return fail(MOBROB_ERR_INVALID, "read_buffer(%d): expected %zu bytes, got %zu", which, b, bytes);
+    HIPC(hipMemcpyAsync(host, p, b, hipMemcpyDeviceToHost, e->stream));
+  }
+  HIPC(hipStreamSynchronize(e->stream));
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_write_buffer(mobrob_ppo_engine_t* e, int32_t which, const void* host, size_t bytes) {
+  if (!e || !host) return fail(MOBROB_ERR_INVALID, "write_buffer: null argument");
+  void* p; size_t b;
+  CHK(mobrob_ppo_buffer_info(e, which, &p, &b));
+  if (which == MOBROB_BUF_OBS) {
+    const size_t rows = (size_t)(e->T + 1) * e->N;
+    if (bytes != rows * e->D * 4) return fail(MOBROB_ERR_INVALID, "write_buffer(OBS): expected %zu bytes", rows * e->D * 4);
+    HIPC(hipMemcpy2DAsync(p, (size_t)e->Dp * 4, host, (size_t)e->D * 4, (size_t)e->D * 4, rows, hipMemcpyHostToDevice, e->stream));
+  } else {
+    if (bytes != b) return fail(MOBROB_ERR_INVALID, "write_buffer(%d): expected %zu bytes, got %zu", which, b, bytes);
+    HIPC(hipMemcpyAsync(p, host, b, hipMemcpyHostToDevice, e->stream));
+    if (which == MOBROB_BUF_PARAMS) repack(e);
+  }
+  HIPC(hipStreamSynchronize(e->stream));
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_feistel_permutation(mobrob_ppo_engine_t* e, int64_t n, uint64_t key, int64_t* out) {
+  if (!e || !out || n < 1 || n > ((int64_t)1 << 30)) return fail(MOBROB_ERR_INVALID, "feistel_permutation: bad argument");
+  int64_t* d = nullptr;
+  HIPC(hipMalloc(&d, (size_t)n * 8));
+  hipLaunchKernelGGL(k_perm_feistel, dim3(cdiv((int)n, 256)), dim3(256), 0, e->stream, (int)n, 1, (int)n,
+                     feistel_half_bits((uint64_t)n), (uint32_t)key, (uint32_t)(key >> 32), (int*)nullptr, d);
+  hipError_t r = hipMemcpyAsync(out, d, (size_t)n * 8, hipMemcpyDeviceToHost, e->stream);
+  if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+  (void)hipFree(d);
+  if (r != hipSuccess) return fail(MOBROB_ERR_HIP, "feistel_permutation: %s", hipGetErrorString(r));
+  return MOBROB_OK;
+}
+
+// ---- profiling --------------------------------------------------------------------------------------
+int mobrob_ppo_profile_enable(mobrob_ppo_engine_t* e, int32_t on) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  HIPC(hipStreamSynchronize(e->stream));
+  prof_resolve(e);
+  e->prof_on = on != 0;
+  for (int i = 0; i < MOBROB_K_COUNT; ++i) { e->prof_ms[i] = 0; e->prof_calls[i] = 0; }
+  return MOBROB_OK;
+}
+int mobrob_ppo_profile_read(mobrob_ppo_engine_t* e, double* ms, int64_t* calls) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  HIPC(hipStreamSynchronize(e->stream));
+  prof_resolve(e);
+  for (int i = 0; i < MOBROB_K_COUNT; ++i) {
+    if (ms) ms[i] = e->prof_ms[i];
+    if (calls) calls[i] = e->prof_calls[i];
+  }
+  return MOBROB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,603 @@
+// Generic-shape kernels of the PPO hot path (any hidden width that is a multiple of 8).
+// The MLP contractions run on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact f32, bitwise
+// a k-ordered fmaf chain) with fragments loaded straight from L2/HBM; the fused fast path for the
+// benchmark shape lives in kernels_fused.h.  All kernels are gfx950-only (wave64).
+#pragma once
+#include "device_utils.h"
+
+namespace mobrob {
+
+// ------------------------------------------------------------------------------------------------
+// MFMA GEMM, one 32x32 output tile per wave, 4 waves per block stacked along M.
+//   MODE_NT: C[m][n] = sum_k A[m][k] * B[n][k]      (forward:  X . W^T)        K % 8 == 0
+//   MODE_NN: C[m][n] = sum_k A[m][k] * B[k][n]      (backward: dY . W)         K % 8 == 0
+//   MODE_TN: C[i][j] = sum_k A[k][i] * B[k][j]      (weight grad: dY^T . X), K = batch rows, split over
+//                                                    blockIdx.z, accumulated with float atomics
+// Fragment maps (cdna_hip_programming.md §3): A operand lane l holds A[i=l&31][k=l>>5], B operand lane l
+// holds B[k=l>>5][j=l&31]; C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// The k index inside a group of 8 is permuted (lane half h handles k = kk+4h+s at MFMA s) so that each
+// lane fetches its four k values with one 16-byte load; both operands use the same permutation.
+// Rows/cols beyond M/N are clamped for loads (they only pollute outputs that are never stored).
+// ------------------------------------------------------------------------------------------------
+enum { MODE_NT = 0, MODE_NN = 1, MODE_TN = 2 };
+enum { EPI_BIAS = 0, EPI_BIAS_TANH = 1, EPI_DTANH_COLSUM = 2, EPI_ATOMIC = 3 };
+
+struct GemmArgs {
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  const float* bias;    // EPI_BIAS / EPI_BIAS_TANH: [N] or nullptr
+  const float* Hact;    // EPI_DTANH_COLSUM: activation h (same shape as C), ld = ldh
+  int ldh;
+  float* colsum;        // EPI_DTANH_COLSUM: [N] += column sums of the stored tile (bias gradient)
+  int kchunk;           // MODE_TN: batch rows per blockIdx.z
+};
+
+template <int MODE, int EPI>
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int tm = blockIdx.x * 4 + wv, tn = blockIdx.y;
+  const int m0 = tm * 32, n0 = tn * 32;
+  if (m0 >= g.M) return;  // whole-wave exit (no block-level sync in this kernel)
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  if (MODE == MODE_NT) {
+    const int am = min(m0 + r, g.M - 1), bn = min(n0 + r, g.N - 1);
+    const float* ap = g.A + (size_t)am * g.lda + 4 * h;
+    const float* bp = g.B + (size_t)bn * g.ldb + 4 * h;
+#pragma unroll 2
+    for (int kk = 0; kk < g.K; kk += 8) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bp + kk);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+    }
+  } else if (MODE == MODE_NN) {
+    const int am = min(m0 + r, g.M - 1), bn = min(n0 + r, g.N - 1);
+    const float* ap = g.A + (size_t)am * g.lda + 4 * h;
+    const float* bp = g.B + (size_t)(4 * h) * g.ldb + bn;
+#pragma unroll 2
+    for (int kk = 0; kk < g.K; kk += 8) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk);
+      const float* bk = bp + (size_t)kk * g.ldb;
+      const float b0 = bk[0], b1 = bk[g.ldb], b2 = bk[2 * (size_t)g.ldb], b3 = bk[3 * (size_t)g.ldb];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b3, acc, 0, 0, 0);
+    }
+  } else {  // MODE_TN
+    const int ai = min(m0 + r, g.M - 1), bj = min(n0 + r, g.N - 1);
+    const int k0 = blockIdx.z * g.kchunk, k1 = min(k0 + g.kchunk, g.K);
+    for (int kk = k0; kk < k1; kk += 8) {
+      float a[4], b[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int k = kk + 2 * s + h;
+        const bool ok = k < k1;
+        const int kc = ok ? k : k0;
+        const float av = g.A[(size_t)kc * g.lda + ai];
+        a[s] = ok ? av : 0.f;
+        b[s] = g.B[(size_t)kc * g.ldb + bj];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    }
+  }
+
+  const int col = n0 + r;
+  const bool col_ok = col < g.N;
+  float csum = 0.f;
+  float bias = 0.f;
+  if ((EPI == EPI_BIAS || EPI == EPI_BIAS_TANH) && g.bias != nullptr && col_ok) bias = g.bias[col];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    if (row < g.M && col_ok) {
+      float v = acc[i];
+      if (EPI == EPI_BIAS) {
+        g.C[(size_t)row * g.ldc + col] = v + bias;
+      } else if (EPI == EPI_BIAS_TANH) {
+        g.C[(size_t)row * g.ldc + col] = tanhf(v + bias);
+      } else if (EPI == EPI_DTANH_COLSUM) {
+        const float hv = g.Hact[(size_t)row * g.ldh + col];
+        v = v * (1.0f - hv * hv);
+        g.C[(size_t)row * g.ldc + col] = v;
+        csum += v;
+      } else {
+        atomicAdd(&g.C[(size_t)row * g.ldc + col], v);
+      }
+    }
+  }
+  if (EPI == EPI_DTANH_COLSUM && g.colsum != nullptr) {
+    csum += __shfl_xor(csum, 32, 64);
+    if (h == 0 && col_ok) atomicAdd(&g.colsum[col], csum);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pack the canonical SB3-ordered parameter vector into zero-padded compute copies.
+//   W1 [H][D] -> [H][Dp];  head [A][H] -> [Ap][H] (extra rows zero)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pad_rows(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols,
+                           int rows_p, int cols_p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows_p * cols_p) return;
+  const int r = i / cols_p, c = i - r * cols_p;
+  dst[i] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rollout-time sampling epilogue: a = mu + exp(log_std) * eps ; logp = sum_a Normal.log_prob
+// [SB3 DiagGaussianDistribution.sample/log_prob; oracle act()].  One thread per env row.
+// eps == nullptr -> Philox4x32-10 counter (row, a/4, draw_counter, STREAM_EPS), key = seed.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kStreamEps = 0x45505331u;   // 'EPS1'
+constexpr uint32_t kStreamEnvObs = 0x4F425331u;
+constexpr uint32_t kStreamEnvTerm = 0x54524D31u;
+constexpr uint32_t kStreamEnvMisc = 0x4D495331u;
+constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
+
+__global__ void k_sample(const float* __restrict__ mu, int ldmu, const float* __restrict__ log_std,
+                         const float* __restrict__ eps, int n, int A, float lo, float hi, uint64_t seed,
+                         uint32_t draw, float* __restrict__ act_raw, float* __restrict__ act_clip,
+                         float* __restrict__ logp_out) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  float lp = 0.f;
+  float z[4];
+  for (int a = 0; a < A; ++a) {
+    float e;
+    if (eps != nullptr) {
+      e = eps[(size_t)row * A + a];
+    } else {
+      if ((a & 3) == 0) {
+        const Philox4 rr = philox4x32_10((uint32_t)row, (uint32_t)(a >> 2), draw, kStreamEps, (uint32_t)seed,
+                                         (uint32_t)(seed >> 32));
+        box_muller4(rr, z);
+      }
+      e = z[a & 3];
+    }
+    const float ls = log_std[a];
+    const float sd = expf(ls);
+    const float m = mu[(size_t)row * ldmu + a];
+    const float act = m + e * sd;
+    const float d = act - m;
+    lp += -(d * d) / (2.0f * (sd * sd)) - logf(sd) - kLogSqrt2Pi;
+    if (act_raw) act_raw[(size_t)row * A + a] = act;
+    if (act_clip) act_clip[(size_t)row * A + a] = fminf(fmaxf(act, lo), hi);
+  }
+  if (logp_out) logp_out[row] = lp;
+}
+
+// deterministic predict: clip(mu)
+__global__ void k_clip_mean(const float* __restrict__ mu, int ldmu, int n, int A, float lo, float hi,
+                            float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * A) return;
+  const int row = i / A, a = i - row * A;
+  out[i] = fminf(fmaxf(mu[(size_t)row * ldmu + a], lo), hi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rollout_buffer.add scalars: rewards (after time-limit bootstrap), episode_starts (= previous dones)
+// bootstrap: r = f32( f64(r) + f64( f32(gamma) * V(terminal_obs) ) )   [oracle bootstrap_reward]
+// ------------------------------------------------------------------------------------------------
+__global__ void k_store_step(const float* __restrict__ rew_in, const float* __restrict__ prev_dones,
+                             const uint8_t* __restrict__ trunc, const float* __restrict__ term_values,
+                             float gamma, int n, float* __restrict__ rew_out, float* __restrict__ es_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float r = rew_in[i];
+  if (trunc != nullptr && trunc[i]) {
+    const float gv = __fmul_rn(gamma, term_values[i]);
+    r = (float)((double)r + (double)gv);
+  }
+  rew_out[i] = r;
+  es_out[i] = prev_dones[i];
+}
+
+__global__ void k_u8_to_f32(const uint8_t* __restrict__ in, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] ? 1.f : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Value of flagged rows only (time-limit bootstrap is rare: one block per env, exits unless flagged).
+// V(x) = Wv . tanh(W2 tanh(W1 x + b1) + b2) + bv with the canonical (unpadded) parameter vector.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_value_flagged(const float* __restrict__ obs, int ldo,
+                                                       const uint8_t* __restrict__ flags,
+                                                       const float* __restrict__ W1, const float* __restrict__ b1,
+                                                       const float* __restrict__ W2, const float* __restrict__ b2,
+                                                       const float* __restrict__ Wv, const float* __restrict__ bv,
+                                                       int D, int G1, int G2, float* __restrict__ out) {
+  const int row = blockIdx.x;
+  if (!flags[row]) return;
+  extern __shared__ float sm[];  // x[D] | h1[G1] | h2[G2] | red[16]
+  float* x = sm;
+  float* h1 = x + D;
+  float* h2 = h1 + G1;
+  float* red = h2 + G2;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) x[i] = obs[(size_t)row * ldo + i];
+  __syncthreads();
+  for (int j = threadIdx.x; j < G1; j += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < D; ++k) s = fmaf(x[k], W1[(size_t)j * D + k], s);
+    h1[j] = tanhf(s + b1[j]);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < G2; j += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < G1; ++k) s = fmaf(h1[k], W2[(size_t)j * G1 + k], s);
+    h2[j] = tanhf(s + b2[j]);
+  }
+  __syncthreads();
+  float p = 0.f;
+  for (int k = threadIdx.x; k < G2; k += blockDim.x) p += h2[k] * Wv[k];
+  const float tot = block_sum(p, red);
+  if (threadIdx.x == 0) out[row] = tot + bv[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// GAE(lambda) reverse scan [SB3 RolloutBuffer.compute_returns_and_advantage; oracle gae()].
+// One lane per env, serial in t, [T][N] layout -> every wave load is 256 contiguous bytes.
+// Bit-exact vs the oracle: same operation order, explicit round-to-nearest ops (no fma contraction),
+// f64 carry.  Loads for the next kPF steps do not depend on the carry and are issued ahead.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_gae(const float* __restrict__ rewards, const float* __restrict__ values,
+                                            const float* __restrict__ episode_starts,
+                                            const float* __restrict__ last_values,
+                                            const float* __restrict__ last_dones, float gamma, double gl_d, int T,
+                                            int N, float* __restrict__ adv, float* __restrict__ ret) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float gl_f = (float)gl_d;  // python-float gamma*lambda meets a float32 array -> rounded to f32
+  // t = T-1: float64 arithmetic because `1.0 - dones` (bool) is float64 in SB3
+  double g;
+  {
+    const size_t o = (size_t)(T - 1) * N + n;
+    const double nnt = 1.0 - (double)last_dones[n];
+    const float gv = __fmul_rn(gamma, last_values[n]);
+    const double tmp = __dmul_rn((double)gv, nnt);
+    const float v = values[o];
+    const double delta = __dsub_rn(__dadd_rn((double)rewards[o], tmp), (double)v);
+    g = delta;  // + (gl * nnt) * 0
+    const float a = (float)g;
+    adv[o] = a;
+    ret[o] = __fadd_rn(a, v);
+  }
+  constexpr int kPF = 8;
+  int t = T - 2;
+  for (; t >= kPF - 1; t -= kPF) {
+    float r[kPF], v[kPF], vn[kPF], es[kPF];
+#pragma unroll
+    for (int j = 0; j < kPF; ++j) {
+      const size_t o = (size_t)(t - j) * N + n;
+      r[j] = rewards[o];
+      v[j] = values[o];
+      vn[j] = values[o + N];
+      es[j] = episode_starts[o + N];
+    }
+#pragma unroll
+    for (int j = 0; j < kPF; ++j) {
+      const size_t o = (size_t)(t - j) * N + n;
+      const float nnt = __fsub_rn(1.0f, es[j]);
+      const float delta = __fsub_rn(__fadd_rn(r[j], __fmul_rn(__fmul_rn(gamma, vn[j]), nnt)), v[j]);
+      const float coef = __fmul_rn(gl_f, nnt);
+      g = __dadd_rn((double)delta, __dmul_rn((double)coef, g));
+      const float a = (float)g;
+      adv[o] = a;
+      ret[o] = __fadd_rn(a, v[j]);
+    }
+  }
+  for (; t >= 0; --t) {
+    const size_t o = (size_t)t * N + n;
+    const float v = values[o];
+    const float nnt = __fsub_rn(1.0f, episode_starts[o + N]);
+    const float delta = __fsub_rn(__fadd_rn(rewards[o], __fmul_rn(__fmul_rn(gamma, values[o + N]), nnt)), v);
+    const float coef = __fmul_rn(gl_f, nnt);
+    g = __dadd_rn((double)delta, __dmul_rn((double)coef, g));
+    const float a = (float)g;
+    adv[o] = a;
+    ret[o] = __fadd_rn(a, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Minibatch index construction.  SB3 flat index is env-major (flat = n*T + t); device rows are t*N + n.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_perm_from_host(const int64_t* __restrict__ perm, int total, int T, int N,
+                                 int* __restrict__ rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t f = perm[i];
+  const int n = (int)(f / T), t = (int)(f - (int64_t)n * T);
+  rows[i] = t * N + n;
+}
+__global__ void k_perm_feistel(int total, int T, int N, int half_bits, uint32_t k0, uint32_t k1,
+                               int* __restrict__ rows, int64_t* __restrict__ flat_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint64_t f = feistel_perm((uint64_t)i, (uint64_t)total, half_bits, k0, k1);
+  if (flat_out) flat_out[i] = (int64_t)f;
+  if (rows) {
+    const int n = (int)(f / (uint64_t)T), t = (int)(f - (uint64_t)n * T);
+    rows[i] = t * N + n;
+  }
+}
+
+// per-minibatch (sum, sumsq, count) of the advantages in float64 (one block per minibatch)
+__global__ __launch_bounds__(1024) void k_adv_stats(const float* __restrict__ adv, const int* __restrict__ rows,
+                                                    int total, int bl, double* __restrict__ out) {
+  __shared__ double sc[16];
+  const int mb = blockIdx.x;
+  const int s = mb * bl, e = min(s + bl, total);
+  double a = 0.0, b = 0.0;
+  for (int i = s + threadIdx.x; i < e; i += blockDim.x) {
+    const double x = (double)adv[rows[i]];
+    a += x;
+    b += x * x;
+  }
+  const double sa = block_sum_d(a, sc);
+  const double sb = block_sum_d(b, sc);
+  if (threadIdx.x == 0) {
+    out[4 * mb + 0] = sa;
+    out[4 * mb + 1] = sb;
+    out[4 * mb + 2] = (double)(e - s);
+    out[4 * mb + 3] = 0.0;
+  }
+}
+
+// gather the minibatch rows into contiguous work arrays (generic path)
+__global__ void k_gather(const int* __restrict__ rows, int count, const float* __restrict__ obs, int Dp,
+                         const float* __restrict__ actions, int A, const float* __restrict__ logp,
+                         const float* __restrict__ adv, const float* __restrict__ ret, float* __restrict__ Xg,
+                         float* __restrict__ actg, float* __restrict__ lpg, float* __restrict__ advg,
+                         float* __restrict__ retg) {
+  const int per = Dp / 4;  // float4 chunks per row
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count * per) return;
+  const int b = i / per, c = i - b * per;
+  const int row = rows[b];
+  reinterpret_cast<f32x4*>(Xg)[(size_t)b * per + c] = reinterpret_cast<const f32x4*>(obs)[(size_t)row * per + c];
+  if (c == 0) {
+    lpg[b] = logp[row];
+    advg[b] = adv[row];
+    retg[b] = ret[row];
+  }
+  for (int a = c; a < A; a += per) actg[(size_t)b * A + a] = actions[(size_t)row * A + a];
+}
+
+// ------------------------------------------------------------------------------------------------
+// PPO loss forward + the gradient w.r.t. the network outputs [SB3 PPO.train; oracle loss_and_grads].
+// One thread per minibatch row.  inv_bg = 1 / GLOBAL batch size.  advstat = global (sum,sumsq,count).
+// Accumulates (atomics): sums[0..5] = sum min-surrogate, sum (ret-v)^2, sum kl-term, clip count,
+// rows; g_log_std[A]; g_bias_action[A]; g_bias_value.
+// ------------------------------------------------------------------------------------------------
+struct LossArgs {
+  const float* mu; int ldmu;
+  const float* v;             // [B]
+  const float* actions;       // [B][A]
+  const float* old_logp; const float* adv; const float* ret;
+  const float* log_std;
+  const double* advstat;      // 4 doubles of this minibatch
+  int B, A;
+  int normalize;
+  float clip, vf_coef, ent_coef, inv_bg;
+  float* dmu; int lddmu;      // [B][Ap]
+  float* dv; int lddv;        // [B][8]
+  float* sums;                // [8]
+  float* g_log_std; float* g_b_action; float* g_b_value;
+};
+
+__device__ __forceinline__ void adv_mean_std(const double* st, float* mean, float* sd, bool* on) {
+  const double n = st[2];
+  *on = n > 1.0;
+  const double m = st[0] / (n > 0 ? n : 1.0);
+  double var = (n > 1.0) ? (st[1] - n * m * m) / (n - 1.0) : 0.0;
+  if (var < 0.0) var = 0.0;
+  *mean = (float)m;
+  *sd = (float)sqrt(var);
+}
+
+__global__ __launch_bounds__(256) void k_loss(LossArgs L) {
+  __shared__ float red[16];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < L.B;
+  float s_pl = 0.f, s_vl = 0.f, s_kl = 0.f, s_cf = 0.f, g_logp = 0.f, dvv = 0.f;
+  if (live) {
+    float a = L.adv[i];
+    float mean, sd; bool on;
+    adv_mean_std(L.advstat, &mean, &sd, &on);
+    if (L.normalize && on) a = (a - mean) / (sd + 1e-8f);
+    float lp = 0.f;
+    for (int k = 0; k < L.A; ++k) {
+      const float sdv = expf(L.log_std[k]);
+      const float d = L.actions[(size_t)i * L.A + k] - L.mu[(size_t)i * L.ldmu + k];
+      lp += -(d * d) / (2.0f * (sdv * sdv)) - logf(sdv) - kLogSqrt2Pi;
+    }
+    const float log_ratio = lp - L.old_logp[i];
+    const float ratio = expf(log_ratio);
+    const float lo = 1.0f - L.clip, hi = 1.0f + L.clip;
+    const float s1 = a * ratio, s2 = a * fminf(fmaxf(ratio, lo), hi);
+    s_pl = fminf(s1, s2);
+    s_cf = (fabsf(ratio - 1.0f) > L.clip) ? 1.f : 0.f;
+    s_kl = (ratio - 1.0f) - log_ratio;
+    const float in_range = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+    const float w1 = (s1 < s2) ? 1.f : ((s1 > s2) ? 0.f : 0.5f);
+    const float d_ratio = -(w1 * a + (1.0f - w1) * a * in_range) * L.inv_bg;
+    g_logp = d_ratio * ratio;
+    const float vv = L.v[i], rr = L.ret[i];
+    s_vl = (rr - vv) * (rr - vv);
+    dvv = L.vf_coef * 2.0f * (vv - rr) * L.inv_bg;
+    L.dv[(size_t)i * L.lddv] = dvv;
+  }
+  // per-action pieces + block reductions
+  for (int k = 0; k < L.A; ++k) {
+    float gm = 0.f, gls = 0.f;
+    if (live) {
+      const float sdv = expf(L.log_std[k]);
+      const float var = sdv * sdv;
+      const float d = L.actions[(size_t)i * L.A + k] - L.mu[(size_t)i * L.ldmu + k];
+      gm = g_logp * d / var;
+      gls = g_logp * (d * d / var - 1.0f);
+      L.dmu[(size_t)i * L.lddmu + k] = gm;
+    }
+    const float t1 = block_sum(gm, red);
+    const float t2 = block_sum(gls, red);
+    if (threadIdx.x == 0) {
+      atomicAdd(&L.g_b_action[k], t1);
+      atomicAdd(&L.g_log_std[k], t2);
+    }
+  }
+  const float r0 = block_sum(s_pl, red), r1 = block_sum(s_vl, red), r2 = block_sum(s_kl, red);
+  const float r3 = block_sum(s_cf, red), r4 = block_sum(dvv, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&L.sums[0], r0);
+    atomicAdd(&L.sums[1], r1);
+    atomicAdd(&L.sums[2], r2);
+    atomicAdd(&L.sums[3], r3);
+    atomicAdd(&L.sums[4], (float)min(L.B - (int)(blockIdx.x * blockDim.x), (int)blockDim.x));
+    atomicAdd(L.g_b_value, r4);
+  }
+}
+
+// entropy term of the loss on log_std: d(-mean(entropy))/dlog_std_a = -(B_local/B_global) * ent_coef
+__global__ void k_entropy_grad(float* g_log_std, int A, float ent_coef, float b_local, float inv_bg) {
+  const int a = threadIdx.x;
+  if (a < A) g_log_std[a] += ent_coef * (-b_local) * inv_bg;
+}
+
+// ------------------------------------------------------------------------------------------------
+// clip_grad_norm_ + Adam [torch 2.0.1 single-tensor path; oracle clip_grad_norm / adam_step]
+// ------------------------------------------------------------------------------------------------
+// per-tensor sum of squares in f64: one block per tensor
+__global__ __launch_bounds__(1024) void k_tensor_sqnorm(const float* __restrict__ grads,
+                                                        const int* __restrict__ offsets, int ntensors,
+                                                        double* __restrict__ out) {
+  __shared__ double sc[16];
+  const int t = blockIdx.x;
+  const int s = offsets[t], e = offsets[t + 1];
+  double a = 0.0;
+  for (int i = s + threadIdx.x; i < e; i += blockDim.x) {
+    const double x = (double)grads[i];
+    a += x * x;
+  }
+  const double tot = block_sum_d(a, sc);
+  if (threadIdx.x == 0) out[t] = tot;
+}
+
+struct AdamArgs {
+  float* p; float* g; float* m; float* v;
+  int P;
+  const double* tensor_sq; int ntensors;
+  float max_norm;
+  float step_size;      // lr / (1 - beta1^t)
+  float bc2_sqrt;       // sqrt(1 - beta2^t)
+  float beta1, beta2, eps;
+  float* stats_row;     // [8] row of this step: [6] <- total grad norm ; finalised losses
+  const float* loss_sums; float ent_coef, vf_coef, inv_bg; const float* log_std; int A;
+};
+
+__global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
+  // total norm = norm of per-tensor norms (torch: torch.norm(torch.stack(norms)))
+  float tot_sq = 0.f;
+  for (int t = 0; t < a.ntensors; ++t) {
+    const float nt = (float)sqrt(a.tensor_sq[t]);
+    tot_sq += nt * nt;
+  }
+  const float total = sqrtf(tot_sq);
+  const float coef = fminf(a.max_norm / (total + 1e-6f), 1.0f);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && a.stats_row != nullptr) {
+    const float pl = -a.loss_sums[0] * a.inv_bg;
+    const float vl = a.loss_sums[1] * a.inv_bg;
+    float ent = 0.f;
+    for (int k = 0; k < a.A; ++k) ent += (0.5f + 0.91893853320467274178f) + logf(expf(a.log_std[k]));
+    const float el = -(ent * a.loss_sums[4]) * a.inv_bg;
+    a.stats_row[0] = pl;
+    a.stats_row[1] = vl;
+    a.stats_row[2] = el;
+    a.stats_row[3] = pl + a.ent_coef * el + a.vf_coef * vl;
+    a.stats_row[4] = a.loss_sums[2] * a.inv_bg;
+    a.stats_row[5] = a.loss_sums[3] * a.inv_bg;
+    a.stats_row[6] = total;
+    a.stats_row[7] = 0.f;
+  }
+  if (i >= a.P) return;
+  const float g = a.g[i] * coef;
+  const float m = a.m[i] * a.beta1 + (1.0f - a.beta1) * g;
+  const float v = a.v[i] * a.beta2 + (1.0f - a.beta2) * (g * g);
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  a.p[i] = a.p[i] - a.step_size * (m / denom);
+  a.m[i] = m;
+  a.v[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-resident synthetic env source.  One thread per (env, 4 obs features).
+// state: ep_len[N].  Writes next obs into rollout slot t+1, reward/done/trunc flags, terminal obs rows.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_env_step(uint64_t seed, uint32_t step, int N, int D, int Dp, float p_term, int time_limit,
+                           int* __restrict__ ep_len, float* __restrict__ obs_next, float* __restrict__ term_obs,
+                           float* __restrict__ rewards, float* __restrict__ dones_f, uint8_t* __restrict__ trunc) {
+  const int per = Dp / 4;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * per) return;
+  const int n = i / per, c = i - n * per;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  // env-level draws (identical for every chunk thread of the env)
+  const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, k0, k1);
+  const bool term = u32_to_unit_open(mr.x) < p_term;
+  const int len = ep_len[n] + 1;
+  const bool tr = (len >= time_limit) && !term;
+  const bool done = term || tr;
+  float z[4];
+  const Philox4 orr = philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, k0, k1);
+  box_muller4(orr, z);
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
+  if (tr) {  // the observation the episode ended on; the stored next obs is the post-reset one
+    reinterpret_cast<f32x4*>(term_obs)[(size_t)n * per + c] = o;
+    const Philox4 rr = philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, k0, k1);
+    box_muller4(rr, z);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
+  }
+  reinterpret_cast<f32x4*>(obs_next)[(size_t)n * per + c] = o;
+  if (c == 0) {
+    float zz[4];
+    box_muller4(Philox4{mr.y, mr.z, mr.w, mr.x ^ 0x9E3779B9u}, zz);
+    rewards[n] = 0.03f + 0.1f * zz[0] + (term ? 5.0f : 0.f);
+    dones_f[n] = done ? 1.f : 0.f;
+    trunc[n] = tr ? 1 : 0;
+  }
+}
+// ep_len update is a separate tiny kernel so that every chunk thread above sees the same old value
+__global__ void k_env_advance(int N, const float* __restrict__ dones_f, int* __restrict__ ep_len) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N) ep_len[n] = dones_f[n] != 0.f ? 0 : ep_len[n] + 1;
+}
+__global__ void k_env_reset(uint64_t seed, int N, int D, int Dp, float* __restrict__ obs0, int* __restrict__ ep_len) {
+  const int per = Dp / 4;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * per) return;
+  const int n = i / per, c = i - n * per;
+  float z[4];
+  box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, 0xFFFFFFFFu, kStreamEnvObs, (uint32_t)seed,
+                            (uint32_t)(seed >> 32)), z);
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
+  reinterpret_cast<f32x4*>(obs0)[(size_t)n * per + c] = o;
+  if (c == 0) ep_len[n] = 0;
+}
+
+}  // namespace mobrob

@@ -1,0 +1,276 @@
+"""NumPy-facing wrapper of the C ABI: one `PPOEngine` per GPU (one per process in data-parallel runs)."""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from ._lib import BUF, Config, TrainStats, check
+
+F32 = np.float32
+STAT_KEYS = ("policy_loss", "value_loss", "entropy_loss", "loss", "approx_kl", "clip_fraction", "grad_norm")
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u8(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _f32c(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=F32)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+def param_shapes(obs_dim, act_dim, pi, vf):
+    """SB3 `policy.state_dict()` key order and shapes (include/mobrob_ppo.h 'Conventions')."""
+    s = OrderedDict()
+    s["log_std"] = (act_dim,)
+    s["mlp_extractor.policy_net.0.weight"] = (pi[0], obs_dim)
+    s["mlp_extractor.policy_net.0.bias"] = (pi[0],)
+    s["mlp_extractor.policy_net.2.weight"] = (pi[1], pi[0])
+    s["mlp_extractor.policy_net.2.bias"] = (pi[1],)
+    s["mlp_extractor.value_net.0.weight"] = (vf[0], obs_dim)
+    s["mlp_extractor.value_net.0.bias"] = (vf[0],)
+    s["mlp_extractor.value_net.2.weight"] = (vf[1], vf[0])
+    s["mlp_extractor.value_net.2.bias"] = (vf[1],)
+    s["action_net.weight"] = (act_dim, pi[1])
+    s["action_net.bias"] = (act_dim,)
+    s["value_net.weight"] = (1, vf[1])
+    s["value_net.bias"] = (1,)
+    return s
+
+
+class PPOEngine:
+    def __init__(self, obs_dim, act_dim, n_envs, n_steps, batch_size=64, n_epochs=10, pi=(64, 64), vf=(64, 64),
+                 gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
+                 learning_rate=3e-4, adam_betas=(0.9, 0.999), adam_eps=1e-5, normalize_advantage=True,
+                 action_low=-1.0, action_high=1.0, seed=0, device_id=0, rank=0, world_size=1, fast_kernels=True):
+        self.lib = _lib.load()
+        if len(pi) != 2 or len(vf) != 2:
+            raise ValueError("net_arch must have exactly two hidden layers per network (pi=[h1,h2], vf=[h1,h2])")
+        cfg = Config()
+        self.lib.mobrob_ppo_default_config(C.byref(cfg))
+        cfg.obs_dim, cfg.act_dim = int(obs_dim), int(act_dim)
+        cfg.pi_hidden[0], cfg.pi_hidden[1] = int(pi[0]), int(pi[1])
+        cfg.vf_hidden[0], cfg.vf_hidden[1] = int(vf[0]), int(vf[1])
+        cfg.n_envs, cfg.n_steps, cfg.batch_size, cfg.n_epochs = int(n_envs), int(n_steps), int(batch_size), int(n_epochs)
+        cfg.gamma, cfg.gae_lambda, cfg.clip_range = float(gamma), float(gae_lambda), float(clip_range)
+        cfg.ent_coef, cfg.vf_coef, cfg.max_grad_norm = float(ent_coef), float(vf_coef), float(max_grad_norm)
+        cfg.learning_rate = float(learning_rate)
+        cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps = float(adam_betas[0]), float(adam_betas[1]), float(adam_eps)
+        cfg.action_low, cfg.action_high = float(action_low), float(action_high)
+        cfg.normalize_advantage = int(bool(normalize_advantage))
+        cfg.seed, cfg.device_id, cfg.rank, cfg.world_size = int(seed), int(device_id), int(rank), int(world_size)
+        cfg.fast_kernels = int(bool(fast_kernels))
+        self.cfg = cfg
+        self.D, self.A, self.N, self.T = int(obs_dim), int(act_dim), int(n_envs), int(n_steps)
+        self.shapes = param_shapes(self.D, self.A, tuple(pi), tuple(vf))
+        self._h = C.c_void_p()
+        check(self.lib.mobrob_ppo_create(C.byref(cfg), C.byref(self._h)))
+        self.P = int(self.lib.mobrob_ppo_param_count(self._h))
+        assert self.P == sum(int(np.prod(s)) for s in self.shapes.values())
+        self.n_minibatches = int(self.lib.mobrob_ppo_num_minibatches(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.mobrob_ppo_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters ---------------------------------------------------------------------------
+    def get_flat_params(self):
+        out = np.empty(self.P, F32)
+        check(self.lib.mobrob_ppo_get_params(self._h, _fp(out), self.P))
+        return out
+
+    def set_flat_params(self, flat):
+        flat = _f32c(flat, (self.P,))
+        check(self.lib.mobrob_ppo_set_params(self._h, _fp(flat), self.P))
+
+    def unflatten(self, flat):
+        out, o = OrderedDict(), 0
+        for k, s in self.shapes.items():
+            n = int(np.prod(s))
+            out[k] = np.array(flat[o:o + n], F32).reshape(s)
+            o += n
+        return out
+
+    def flatten(self, d):
+        parts = []
+        for k, s in self.shapes.items():
+            a = np.asarray(d[k], F32)
+            if a.shape != tuple(s):
+                raise ValueError(f"size mismatch for {k}: expected {tuple(s)}, got {a.shape}")
+            parts.append(a.ravel())
+        return np.concatenate(parts)
+
+    def get_params(self):
+        return self.unflatten(self.get_flat_params())
+
+    def set_params(self, d):
+        self.set_flat_params(self.flatten(d))
+
+    def get_optimizer_state(self):
+        m, v, step = np.empty(self.P, F32), np.empty(self.P, F32), C.c_int64()
+        check(self.lib.mobrob_ppo_get_optimizer_state(self._h, _fp(m), _fp(v), self.P, C.byref(step)))
+        return self.unflatten(m), self.unflatten(v), int(step.value)
+
+    def set_optimizer_state(self, exp_avg, exp_avg_sq, step):
+        m, v = _f32c(self.flatten(exp_avg)), _f32c(self.flatten(exp_avg_sq))
+        check(self.lib.mobrob_ppo_set_optimizer_state(self._h, _fp(m), _fp(v), self.P, int(step)))
+
+    # ---- rollout ------------------------------------------------------------------------------
+    def rollout_begin(self):
+        check(self.lib.mobrob_ppo_rollout_begin(self._h))
+
+    def act(self, obs, eps=None):
+        obs = _f32c(obs, (self.N, self.D))
+        eps = None if eps is None else _f32c(eps, (self.N, self.A))
+        a_raw, a_clip = np.empty((self.N, self.A), F32), np.empty((self.N, self.A), F32)
+        val, lp = np.empty(self.N, F32), np.empty(self.N, F32)
+        check(self.lib.mobrob_ppo_act(self._h, _fp(obs), _fp(eps), _fp(a_raw), _fp(a_clip), _fp(val), _fp(lp)))
+        return a_raw, a_clip, val, lp
+
+    def store(self, rewards, dones, truncated=None, terminal_obs=None):
+        rewards = _f32c(rewards, (self.N,))
+        dones = np.ascontiguousarray(dones, dtype=np.uint8)
+        tr = None if truncated is None else np.ascontiguousarray(truncated, dtype=np.uint8)
+        to = None if terminal_obs is None else _f32c(terminal_obs, (self.N, self.D))
+        check(self.lib.mobrob_ppo_store(self._h, _fp(rewards), _u8(dones), _u8(tr), _fp(to)))
+
+    def finish_rollout(self, last_obs, dones):
+        last_obs = _f32c(last_obs, (self.N, self.D))
+        dones = np.ascontiguousarray(dones, dtype=np.uint8)
+        check(self.lib.mobrob_ppo_finish_rollout(self._h, _fp(last_obs), _u8(dones)))
+
+    def collect_synthetic(self, p_term=1.0 / 107.0, time_limit=1000):
+        check(self.lib.mobrob_ppo_collect_synthetic(self._h, float(p_term), int(time_limit)))
+
+    def compute_gae(self):
+        check(self.lib.mobrob_ppo_compute_gae(self._h))
+
+    def mark_rollout_ready(self):
+        check(self.lib.mobrob_ppo_mark_rollout_ready(self._h))
+
+    # ---- update -------------------------------------------------------------------------------
+    def train(self, perms=None):
+        """Whole PPO.train().  perms: [n_epochs, T*N] int64 env-major permutations or None."""
+        p = None
+        if perms is not None:
+            perms = np.ascontiguousarray(perms, dtype=np.int64)
+            if perms.shape != (self.cfg.n_epochs, self.N * self.T):
+                raise ValueError(f"perms must be [{self.cfg.n_epochs}, {self.N * self.T}]")
+            p = perms.ctypes.data_as(C.POINTER(C.c_int64))
+        st = TrainStats()
+        check(self.lib.mobrob_ppo_train(self._h, p, C.byref(st)))
+        return {k: float(getattr(st, k)) for k in STAT_KEYS} | {"n_minibatches": int(st.n_minibatches)}
+
+    def epoch_begin(self, perm=None):
+        p = None
+        if perm is not None:
+            perm = np.ascontiguousarray(perm, dtype=np.int64)
+            if perm.shape != (self.N * self.T,):
+                raise ValueError("perm must have T*N entries")
+            p = perm.ctypes.data_as(C.POINTER(C.c_int64))
+        check(self.lib.mobrob_ppo_epoch_begin(self._h, p))
+
+    def minibatch_grad(self, mb):
+        check(self.lib.mobrob_ppo_minibatch_grad(self._h, int(mb)))
+
+    def minibatch_apply(self):
+        check(self.lib.mobrob_ppo_minibatch_apply(self._h))
+
+    def fetch_step_stats(self, max_rows=None):
+        max_rows = int(max_rows or (self.n_minibatches * self.cfg.n_epochs))
+        out = np.zeros((max_rows, 8), F32)
+        n = check(self.lib.mobrob_ppo_fetch_step_stats(self._h, _fp(out), max_rows))
+        return out[:n, :7]
+
+    # ---- inference ----------------------------------------------------------------------------
+    def predict(self, obs, deterministic=True, eps=None, want_values=False):
+        obs = np.asarray(obs)
+        single = obs.ndim == 1
+        x = _f32c(obs[None] if single else obs)
+        if x.ndim != 2 or x.shape[1] != self.D:
+            raise ValueError(f"Unexpected observation shape {obs.shape} for Box environment with shape ({self.D},)")
+        n = x.shape[0]
+        act = np.empty((n, self.A), F32)
+        val = np.empty(n, F32) if want_values else None
+        eps = None if eps is None else _f32c(eps, (n, self.A))
+        check(self.lib.mobrob_ppo_predict(self._h, _fp(x), n, int(bool(deterministic)), _fp(eps), _fp(act), _fp(val)))
+        act = act[0] if single else act
+        return (act, val) if want_values else act
+
+    # ---- buffers ------------------------------------------------------------------------------
+    def _buf_shape(self, name):
+        T, N = self.T, self.N
+        return {"obs": ((T + 1, N, self.D), F32), "actions": ((T, N, self.A), F32), "rewards": ((T, N), F32),
+                "episode_starts": ((T, N), F32), "values": ((T, N), F32), "log_probs": ((T, N), F32),
+                "advantages": ((T, N), F32), "returns": ((T, N), F32), "params": ((self.P,), F32),
+                "grads": ((self.P,), F32), "advstat": ((self.n_minibatches, 4), np.float64),
+                "last_values": ((N,), F32), "last_dones": ((N,), F32), "clipped_actions": ((N, self.A), F32)}[name]
+
+    def read(self, name):
+        shape, dt = self._buf_shape(name)
+        out = np.empty(shape, dt)
+        check(self.lib.mobrob_ppo_read_buffer(self._h, BUF[name], out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def write(self, name, arr):
+        shape, dt = self._buf_shape(name)
+        a = np.ascontiguousarray(arr, dtype=dt)
+        if a.shape != shape:
+            raise ValueError(f"{name}: expected {shape}, got {a.shape}")
+        check(self.lib.mobrob_ppo_write_buffer(self._h, BUF[name], a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def device_buffer(self, name):
+        """(device pointer, bytes) -- e.g. to wrap grads/advstat for a collective."""
+        p, b = C.c_void_p(), C.c_size_t()
+        check(self.lib.mobrob_ppo_buffer_info(self._h, BUF[name], C.byref(p), C.byref(b)))
+        return int(p.value), int(b.value)
+
+    def load_rollout(self, buf, last_values, dones):
+        """Inject a complete rollout (tests): dict of [T,N,..] arrays as in the oracle."""
+        obs = np.zeros((self.T + 1, self.N, self.D), F32)
+        obs[:self.T] = buf["obs"]
+        self.write("obs", obs)
+        for k in ("actions", "rewards", "episode_starts", "values", "log_probs"):
+            self.write(k, buf[k])
+        self.write("last_values", last_values)
+        self.write("last_dones", np.asarray(dones, F32))
+        if "advantages" in buf:
+            self.write("advantages", buf["advantages"])
+            self.write("returns", buf["returns"])
+            self.mark_rollout_ready()
+
+    def feistel_permutation(self, n, key):
+        out = np.empty(int(n), np.int64)
+        check(self.lib.mobrob_ppo_feistel_permutation(self._h, int(n), int(key) & (2 ** 64 - 1),
+                                                      out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+    def set_stream(self, stream_handle):
+        check(self.lib.mobrob_ppo_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        check(self.lib.mobrob_ppo_synchronize(self._h))
+
+    def profile(self, on=True):
+        check(self.lib.mobrob_ppo_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        ms, calls = (C.c_double * 5)(), (C.c_int64 * 5)()
+        check(self.lib.mobrob_ppo_profile_read(self._h, ms, calls))
+        return {k: (float(ms[i]), int(calls[i])) for k, i in _lib.KERNEL_IDS.items()}

@@ -1,0 +1,86 @@
+"""Synchronous data-parallel PPO update across the GPUs of one node.
+
+One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI; "gloo" in the CPU tests).
+Rank r owns its own vectorised envs and rollout shard [T, N, .]; nothing about the rollout or GAE is
+exchanged.  Per optimizer step there is exactly ONE gradient all-reduce (the flat P-float buffer, 645 KiB
+for 2x256) and, once per epoch, one tiny all-reduce of the per-minibatch advantage statistics
+(sum, sum of squares, count) so that advantage normalisation, the `mean()` losses and the global-norm
+clip equal single-process SB3 arithmetic on the union minibatch.  Every rank then applies the identical
+clip + Adam step -> replicas stay bit-identical without a parameter broadcast.
+
+The update loop is written against a small backend protocol so that the very same code is exercised
+with the HIP engine on GPUs and with a NumPy backend in the world_size-2 gloo tests:
+
+    backend.epoch_begin(perm_or_None)           -> local advantage partial sums ready
+    backend.advstat_tensor()                    -> torch tensor [n_mb, 4] float64 (in-place all-reduce target)
+    backend.minibatch_grad(mb)                  -> local gradient of the GLOBAL-mean loss
+    backend.grad_tensor()                       -> torch tensor [P] float32 (in-place all-reduce target)
+    backend.minibatch_apply()                   -> clip_grad_norm_ + Adam
+    backend.n_minibatches, backend.n_epochs
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class _DevArray:
+    """__cuda_array_interface__ view of an engine-owned device buffer (zero-copy into torch)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def device_tensor(ptr: int, shape, dtype: torch.dtype, device) -> torch.Tensor:
+    typestr = {torch.float32: "<f4", torch.float64: "<f8", torch.int32: "<i4"}[dtype]
+    return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device)
+
+
+class EngineBackend:
+    """Adapter: mobrob_amd.engine.PPOEngine -> the protocol above (device buffers exposed as torch tensors,
+    engine kernels enqueued on torch's current stream so that collectives are stream-ordered)."""
+
+    def __init__(self, engine, device=None):
+        self.e = engine
+        self.device = torch.device("cuda", engine.cfg.device_id) if device is None else device
+        torch.cuda.set_device(self.device)
+        self.e.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        gp, gb = engine.device_buffer("grads")
+        ap, ab = engine.device_buffer("advstat")
+        self._grad = device_tensor(gp, (gb // 4,), torch.float32, self.device)
+        self._adv = device_tensor(ap, (ab // 32, 4), torch.float64, self.device)
+        self.n_minibatches = engine.n_minibatches
+        self.n_epochs = int(engine.cfg.n_epochs)
+
+    def epoch_begin(self, perm=None):
+        self.e.epoch_begin(perm)
+
+    def advstat_tensor(self):
+        return self._adv
+
+    def minibatch_grad(self, mb):
+        self.e.minibatch_grad(mb)
+
+    def grad_tensor(self):
+        return self._grad
+
+    def minibatch_apply(self):
+        self.e.minibatch_apply()
+
+
+def train_data_parallel(backend, perms=None, group=None):
+    """PPO.train() across ranks.  perms: per-epoch LOCAL permutations ([n_epochs, T*N_local]) or None."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    for ep in range(backend.n_epochs):
+        backend.epoch_begin(None if perms is None else perms[ep])
+        if world > 1:
+            dist.all_reduce(backend.advstat_tensor(), op=dist.ReduceOp.SUM, group=group)
+        for mb in range(backend.n_minibatches):
+            backend.minibatch_grad(mb)
+            if world > 1:
+                dist.all_reduce(backend.grad_tensor(), op=dist.ReduceOp.SUM, group=group)
+            backend.minibatch_apply()

@@ -1,0 +1,238 @@
+"""GPU parity tests: HIP engine (through the C ABI) vs the CPU oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+from oracle import ppo_oracle as O
+from tests.util import (ENVS, golden_adam, golden_hyper, golden_minibatch, golden_params, load_golden, scaled_err,
+                        synthetic_rollout)
+
+pytestmark = pytest.mark.gpu
+
+
+def make_engine(g=None, **kw):
+    from mobrob_amd.engine import PPOEngine
+    if g is not None:
+        h = golden_hyper(g)
+        D, A = g["last_obs"].shape[1], g["p/log_std"].shape[0]
+        base = dict(obs_dim=D, act_dim=A, n_envs=g["last_obs"].shape[0], n_steps=4, batch_size=100, n_epochs=1,
+                    gamma=h.gamma, gae_lambda=h.gae_lambda, clip_range=h.clip_range, ent_coef=h.ent_coef,
+                    vf_coef=h.vf_coef, max_grad_norm=h.max_grad_norm, learning_rate=h.learning_rate,
+                    adam_betas=(h.beta1, h.beta2), adam_eps=h.adam_eps)
+        base.update(kw)
+        return PPOEngine(**base)
+    return PPOEngine(**kw)
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_act_matches_golden_and_oracle(env):
+    g = load_golden(env)
+    p = golden_params(g)
+    e = make_engine(g)
+    e.set_params(p)
+    a_raw, a_clip, val, lp = e.act(g["last_obs"], g["fwd/eps"])
+    o_raw, o_clip, o_val, o_lp = O.act(p, g["last_obs"], g["fwd/eps"])
+    # tolerance: north_star 1e-4 (fp32), relative to the magnitude of the compared tensor
+    assert scaled_err(a_raw, g["fwd/actions"]) < 1e-4 and scaled_err(a_raw, o_raw) < 1e-4
+    assert scaled_err(val, g["fwd/value"]) < 1e-4 and scaled_err(val, o_val) < 1e-4
+    assert np.allclose(lp, g["fwd/log_prob"], rtol=1e-4, atol=1e-3)
+    assert np.array_equal(a_clip, np.clip(a_raw, -1, 1))
+    det = e.predict(g["last_obs"], deterministic=True)
+    assert np.allclose(det, np.clip(g["fwd/mean"], -1, 1), atol=1e-4)
+    one = e.predict(g["last_obs"][0], deterministic=True)
+    assert one.shape == (p["log_std"].shape[0],) and np.allclose(one, det[0], atol=1e-6)
+    e.close()
+
+
+@pytest.mark.parametrize("T,N", [(1, 1), (2, 3), (37, 5), (64, 130), (257, 64)])
+def test_gae_bit_exact(T, N):
+    buf, lv, dones = synthetic_rollout(T, N, 4, 2, seed=T * 1000 + N, p_done=0.05)
+    e = make_engine(obs_dim=4, act_dim=2, n_envs=N, n_steps=T, batch_size=8, n_epochs=1, gamma=0.99, gae_lambda=0.95)
+    e.load_rollout(buf, lv, dones)
+    e.compute_gae()
+    adv, ret = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, 0.99, 0.95)
+    assert np.array_equal(e.read("advantages"), adv)
+    assert np.array_equal(e.read("returns"), ret)
+    e.close()
+
+
+@pytest.mark.parametrize("gamma,lam", [(0.99, 0.5), (0.999, 0.99), (1.0, 1.0), (0.9, 0.0)])
+def test_gae_bit_exact_hyper(gamma, lam):
+    buf, lv, dones = synthetic_rollout(100, 70, 4, 2, seed=7, p_done=0.03)
+    e = make_engine(obs_dim=4, act_dim=2, n_envs=70, n_steps=100, batch_size=8, n_epochs=1, gamma=gamma, gae_lambda=lam)
+    e.load_rollout(buf, lv, dones)
+    e.compute_gae()
+    adv, ret = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, gamma, lam)
+    assert np.array_equal(e.read("advantages"), adv) and np.array_equal(e.read("returns"), ret)
+    e.close()
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_minibatch_step_matches_golden(env):
+    """One optimizer step from the checkpoint's real weights + real Adam state on the golden minibatch."""
+    g = load_golden(env)
+    p, st, h = golden_params(g), golden_adam(g), golden_hyper(g)
+    obs, act, old_v, old_lp, adv, ret = golden_minibatch(g)
+    B, D, A = obs.shape[0], obs.shape[1], act.shape[1]
+    # inject the minibatch as a T=B, N=1 rollout; identity permutation -> the minibatch is rows 0..B-1
+    e = make_engine(g, n_envs=1, n_steps=B, batch_size=B, n_epochs=1)
+    e.set_params(p)
+    e.set_optimizer_state(st.exp_avg, st.exp_avg_sq, st.step)
+    buf = dict(obs=obs[:, None], actions=act[:, None], rewards=np.zeros((B, 1), np.float32),
+               episode_starts=np.zeros((B, 1), np.float32), values=old_v[:, None], log_probs=old_lp[:, None],
+               advantages=adv[:, None], returns=ret[:, None])
+    e.load_rollout(buf, np.zeros(1, np.float32), np.zeros(1, bool))
+    e.epoch_begin(np.arange(B))
+    e.minibatch_grad(0)
+    grads = e.unflatten(e.read("grads"))
+    for k, v in grads.items():
+        ref = g["step/grad/" + k]
+        assert np.max(np.abs(v - ref)) < 1e-4 * max(1.0, float(np.max(np.abs(ref)))), k
+    e.minibatch_apply()
+    stats = e.fetch_step_stats()[-1]
+    for i, k in enumerate(["policy_loss", "value_loss", "entropy_loss", "loss", "approx_kl", "clip_fraction",
+                           "grad_norm"]):
+        ref = float(g["step/" + k])
+        assert abs(stats[i] - ref) < 1e-4 * max(1.0, abs(ref)), (k, stats[i], ref)
+    newp = e.get_params()
+    m, v, step = e.get_optimizer_state()
+    assert step == int(g["adam_step"]) + 1
+    for k in newp:
+        assert np.max(np.abs(newp[k] - g["step/p/" + k])) < 1e-6 + 1e-5 * float(np.max(np.abs(g["step/p/" + k]))), k
+        assert np.allclose(m[k], g["step/m/" + k], rtol=1e-3, atol=1e-6), k
+        assert np.allclose(v[k], g["step/v/" + k], rtol=1e-3, atol=1e-8), k
+    e.close()
+
+
+@pytest.mark.parametrize("shape", [dict(D=14, A=2, H=64, T=40, N=5, B=50, E=2),
+                                   dict(D=58, A=12, H=64, T=25, N=16, B=100, E=2),
+                                   dict(D=58, A=12, H=256, T=16, N=24, B=128, E=1),
+                                   dict(D=43, A=2, H=64, T=30, N=7, B=64, E=2)])   # 210 = 3*64 + 18: short last batch
+def test_full_train_matches_oracle(shape):
+    """PPO.train over several epochs with supplied permutations (incl. a short final minibatch)."""
+    D, A, H, T, N, B, E = (shape[k] for k in "DAHTNBE")
+    rng = np.random.default_rng(11)
+    p = O.init_params(D, A, (H, H), (H, H), seed=2)
+    p["log_std"] = rng.normal(-0.3, 0.2, A).astype(np.float32)
+    p["action_net.weight"] *= 30
+    buf, lv, dones = synthetic_rollout(T, N, D, A, seed=5)
+    # make the stored actions/log-probs consistent with the policy so that ratios are O(1)
+    flat_obs = buf["obs"].reshape(T * N, D)
+    mean, val = O.policy_outputs(p, flat_obs)
+    acts = (mean + rng.standard_normal((T * N, A)).astype(np.float32) * np.exp(p["log_std"])).astype(np.float32)
+    buf["actions"] = acts.reshape(T, N, A)
+    buf["log_probs"] = (O.gaussian_log_prob(mean, p["log_std"], acts) + rng.normal(0, 0.1, T * N)).astype(np.float32).reshape(T, N)
+    buf["values"] = (val + rng.normal(0, 0.1, T * N)).astype(np.float32).reshape(T, N)
+    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=E, batch_size=B, learning_rate=3e-4)
+    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, h.gamma, h.gae_lambda)
+    perms = np.stack([rng.permutation(T * N) for _ in range(E)])
+
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H),
+                    gamma=h.gamma, gae_lambda=h.gae_lambda, ent_coef=h.ent_coef, learning_rate=h.learning_rate)
+    e.set_params(p)
+    e.load_rollout(buf, lv, dones)
+    e.compute_gae()
+    assert np.array_equal(e.read("advantages"), buf["advantages"])
+    stats = e.train(perms)
+    st = O.AdamState.zeros_like(p)
+    ostats = O.train(p, st, buf, h, perms)
+    nmb = -(-T * N // B)
+    assert stats["n_minibatches"] == E * nmb == len(ostats)
+    last = ostats[-nmb:]
+    for k in ["policy_loss", "value_loss", "loss", "approx_kl", "clip_fraction", "grad_norm"]:
+        ref = float(np.mean([float(s[k]) for s in last]))
+        assert abs(stats[k] - ref) < 2e-4 * max(1.0, abs(ref)), (k, stats[k], ref)
+    newp = e.get_params()
+    for k in p:
+        # after E*nmb Adam steps of size 3e-4 the trajectories must still agree to 1e-4 absolute
+        assert np.max(np.abs(newp[k] - p[k])) < 1e-4, (k, float(np.max(np.abs(newp[k] - p[k]))))
+    m, v, step = e.get_optimizer_state()
+    assert step == E * nmb
+    e.close()
+
+
+def test_feistel_bit_exact():
+    e = make_engine(obs_dim=4, act_dim=2, n_envs=2, n_steps=2, batch_size=2, n_epochs=1)
+    for n, key in [(1, 5), (7, 1), (100, 2 ** 40 + 17), (16000, 0xDEADBEEF12345), (65537, 3), (1 << 20, 99)]:
+        assert np.array_equal(e.feistel_permutation(n, key), O.feistel_permutation(n, key)), (n, key)
+    e.close()
+
+
+def test_host_rollout_matches_oracle():
+    """act/store/finish_rollout through the host path == oracle collect_rollout on the same env stream,
+    including a time-limit truncation with bootstrap."""
+    D, A, N, T = 14, 2, 6, 12
+    p = O.init_params(D, A, seed=4)
+    rng = np.random.default_rng(0)
+    eps = rng.standard_normal((T, N, A)).astype(np.float32)
+    h = O.Hyper(gamma=0.99, gae_lambda=0.9)
+    env_a = O.NumpySyntheticVecEnv(N, D, A, p_term=0.1, time_limit=5, seed=3)
+    obs0 = env_a.reset()
+    obuf, _, _ = O.collect_rollout({k: v.copy() for k, v in p.items()}, env_a, obs0, np.ones(N, bool), T, h,
+                                   lambda t: eps[t])
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=8, n_epochs=1, gamma=h.gamma,
+                    gae_lambda=h.gae_lambda)
+    e.set_params(p)
+    env_b = O.NumpySyntheticVecEnv(N, D, A, p_term=0.1, time_limit=5, seed=3)
+    obs = env_b.reset()
+    e.rollout_begin()
+    saw_trunc = False
+    for t in range(T):
+        a_raw, a_clip, val, lp = e.act(obs, eps[t])
+        obs, rew, done, trunc, term_obs = env_b.step(a_clip)
+        saw_trunc |= bool(trunc.any())
+        e.store(rew, done, trunc, term_obs)
+    e.finish_rollout(obs, done)
+    assert saw_trunc
+    got = {k: e.read(k) for k in ["actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns"]}
+    assert np.array_equal(e.read("obs")[:T], obuf["obs"])
+    assert np.array_equal(got["episode_starts"], obuf["episode_starts"])
+    for k in ["actions", "rewards", "values", "log_probs", "advantages", "returns"]:
+        assert scaled_err(got[k], obuf[k]) < 1e-4, k
+    e.close()
+
+
+def test_synthetic_collect_statistics_and_consistency():
+    """Device-resident env source: statistics of the generator and self-consistency of the stored rollout."""
+    D, A, N, T = 58, 12, 512, 64
+    p = O.init_params(D, A, seed=1)
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=4096, n_epochs=1, seed=123)
+    e.set_params(p)
+    e.collect_synthetic(p_term=1 / 20.0, time_limit=30)
+    e.synchronize()
+    obs = e.read("obs")
+    assert abs(obs.mean()) < 0.01 and abs(obs.std() - 1.0) < 0.01
+    es = e.read("episode_starts")
+    assert np.all(es[0] == 1.0)  # _last_episode_starts starts all-True
+    rate = es[1:].mean()
+    assert 0.03 < rate < 0.09  # p_term 0.05 (+ truncations)
+    rew = e.read("rewards")
+    assert 0.0 < np.median(rew) < 0.06
+    # stored values / log-probs are the policy's outputs on the stored observations and actions
+    flat = obs[:T].reshape(T * N, D)
+    mean, val = O.policy_outputs(p, flat)
+    acts = e.read("actions").reshape(T * N, A)
+    assert scaled_err(e.read("values").reshape(-1), val) < 1e-4
+    assert np.allclose(e.read("log_probs").reshape(-1), O.gaussian_log_prob(mean, p["log_std"], acts), rtol=1e-4, atol=1e-3)
+    z = (acts - mean) / np.exp(p["log_std"])
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01  # Philox + Box-Muller eps
+    adv, ret = O.gae(rew, e.read("values"), es, e.read("last_values"), e.read("last_dones") > 0, 0.99, 0.95)
+    assert np.array_equal(e.read("advantages"), adv)
+    # second rollout continues from the last observation of the first
+    last = obs[T].copy()
+    e.collect_synthetic(p_term=1 / 20.0, time_limit=30)
+    assert np.array_equal(e.read("obs")[0], last)
+    st = e.train(None)
+    assert np.isfinite(st["loss"]) and st["n_minibatches"] == e.n_minibatches
+    e.close()
+
+
+def test_error_paths():
+    from mobrob_amd.engine import PPOEngine
+    with pytest.raises(ValueError):
+        PPOEngine(obs_dim=4, act_dim=2, n_envs=2, n_steps=2, pi=(30, 30))
+    e = make_engine(obs_dim=4, act_dim=2, n_envs=2, n_steps=2, batch_size=2, n_epochs=1)
+    with pytest.raises(Exception):
+        e.epoch_begin(None)  # rollout not finished
+    with pytest.raises(ValueError):
+        e.set_flat_params(np.zeros(3, np.float32))
+    e.close()
