@@ -1,0 +1,261 @@
+"""stable-baselines3 2.0.0 zip checkpoint reader / writer (no SB3, no gymnasium needed).
+
+Format (SURVEY.md §5 "Checkpoint / resume", verified by unzipping /root/reference/data/policies/*.zip):
+an uncompressed (STORED) zip with
+    data                        JSON; non-JSON values as {":type:", ":serialized:" base64(cloudpickle), ...}
+    pytorch_variables.pth       torch.save({})
+    policy.pth                  torch.save(OrderedDict of the 13 tensors, SB3 key order)
+    policy.optimizer.pth        torch.save({"state": {i: {step, exp_avg, exp_avg_sq}}, "param_groups": [...]})
+    _stable_baselines3_version  "2.0.0"
+    system_info.txt
+Reference call sites: `PPO.save` via src/mobrob/rl_control/ppo.py:76-77 and examples/train.py:36-41,49;
+`PPO.load` via src/mobrob/utils.py:15-16 and examples/train.py:30-33.
+
+Writing blobs that real SB3 can unpickle without having SB3/gymnasium installed:
+  * policy_class          by-reference pickle of stable_baselines3.common.policies.ActorCriticPolicy (70 bytes)
+  * observation/action_space   by-value pickles of gymnasium.spaces.box.Box, emitted opcode-by-opcode in the
+                          same layout the reference blobs have (NEWOBJ + state dict), with ndarray payloads going
+                          through `numpy.core.numeric._frombuffer` so that NumPy 1.24 (the reference's) and 2.x
+                          both load them
+  * learning_rate / clip_range are written as plain JSON floats (SB3 turns floats into constant schedules in
+    `_setup_model`); `lr_schedule` is omitted (SB3 rebuilds it from `learning_rate` on load)
+"""
+from __future__ import annotations
+
+import base64
+import collections
+import io
+import json
+import pickle
+import struct
+import time
+import warnings
+import zipfile
+from collections import OrderedDict
+
+import numpy as np
+
+SB3_VERSION = "2.0.0"
+POLICY_KEYS = ["log_std",
+               "mlp_extractor.policy_net.0.weight", "mlp_extractor.policy_net.0.bias",
+               "mlp_extractor.policy_net.2.weight", "mlp_extractor.policy_net.2.bias",
+               "mlp_extractor.value_net.0.weight", "mlp_extractor.value_net.0.bias",
+               "mlp_extractor.value_net.2.weight", "mlp_extractor.value_net.2.bias",
+               "action_net.weight", "action_net.bias", "value_net.weight", "value_net.bias"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# tiny pickle assembler (protocol 5, same opcodes as the reference blobs; payloads are bytearrays)
+# ---------------------------------------------------------------------------------------------------
+def _s(x: str) -> bytes:  # SHORT_BINUNICODE
+    b = x.encode()
+    assert len(b) < 256
+    return b"\x8c" + bytes([len(b)]) + b
+
+
+def _glob(mod: str, name: str) -> bytes:  # STACK_GLOBAL
+    return _s(mod) + _s(name) + b"\x93"
+
+
+def _int(i: int) -> bytes:
+    if 0 <= i < 256:
+        return b"K" + bytes([i])
+    return b"J" + struct.pack("<i", i)
+
+
+def _dtype(code: str, byteorder: str) -> bytes:
+    # numpy.dtype(code, False, True) then BUILD with (3, byteorder, None, None, None, -1, -1, 0)
+    return (_glob("numpy", "dtype") + _s(code) + b"\x89\x88\x87R" + b"(" + _int(3) + _s(byteorder) + b"NNN" +
+            _int(-1) + _int(-1) + _int(0) + b"t" + b"b")
+
+
+def _ndarray(a: np.ndarray) -> bytes:
+    a = np.ascontiguousarray(a)
+    code = {"float32": ("f4", "<"), "float64": ("f8", "<"), "bool": ("b1", "|"), "int64": ("i8", "<")}[str(a.dtype)]
+    raw = a.tobytes()
+    shape = b"(" + b"".join(_int(int(s)) for s in a.shape) + b"t"
+    return (_glob("numpy.core.numeric", "_frombuffer") + b"(" + b"\x96" + struct.pack("<Q", len(raw)) + raw +
+            _dtype(*code) + shape + _s("C") + b"t" + b"R")
+
+
+def _wrap(body: bytes) -> bytes:
+    return b"\x80\x05" + body + b"."
+
+
+def pickle_ndarray(a) -> bytes:
+    return _wrap(_ndarray(np.asarray(a)))
+
+
+def pickle_box(low, high, dtype=np.float32) -> bytes:
+    """gymnasium.spaces.box.Box(low, high) by value: NEWOBJ + the 9-key state dict of gymnasium 0.28.1."""
+    low = np.asarray(low, dtype)
+    high = np.asarray(high, dtype)
+
+    def rep(x):
+        return str(float(x.flat[0])) if np.all(x == x.flat[0]) and np.isfinite(x.flat[0]) else \
+            (("-inf" if x.flat[0] < 0 else "inf") if np.all(x == x.flat[0]) else str(x))
+
+    items = [(_s("dtype"), _dtype("f4", "<")),
+             (_s("bounded_below"), _ndarray(np.isfinite(low))),
+             (_s("bounded_above"), _ndarray(np.isfinite(high))),
+             (_s("_shape"), b"(" + b"".join(_int(int(s)) for s in low.shape) + b"t"),
+             (_s("low"), _ndarray(low)), (_s("high"), _ndarray(high)),
+             (_s("low_repr"), _s(rep(low))), (_s("high_repr"), _s(rep(high))),
+             (_s("_np_random"), b"N")]
+    body = _glob("gymnasium.spaces.box", "Box") + b")\x81" + b"}" + b"(" + b"".join(k + v for k, v in items) + b"u" + b"b"
+    return _wrap(body)
+
+
+def pickle_policy_class() -> bytes:
+    return _wrap(_glob("stable_baselines3.common.policies", "ActorCriticPolicy"))
+
+
+def _blob(type_repr: str, payload: bytes, **extra) -> dict:
+    d = {":type:": type_repr, ":serialized:": base64.b64encode(payload).decode()}
+    d.update(extra)
+    return d
+
+
+def _unblob(entry):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return pickle.loads(base64.b64decode(entry[":serialized:"]))
+
+
+# ---------------------------------------------------------------------------------------------------
+# read
+# ---------------------------------------------------------------------------------------------------
+def load_zip(path):
+    """-> dict(data=<plain hyper-parameters + decoded arrays>, params=OrderedDict[str, np.ndarray],
+               optimizer=dict(exp_avg, exp_avg_sq, step, param_groups) | None)"""
+    import torch
+    if not str(path).endswith(".zip"):
+        path = str(path) + ".zip"
+    with zipfile.ZipFile(path) as z:
+        names = set(z.namelist())
+        raw = json.loads(z.read("data").decode())
+        data = {}
+        for k, v in raw.items():
+            if isinstance(v, dict) and ":serialized:" in v:
+                if k in ("_last_obs", "_last_episode_starts", "_last_original_obs", "ep_info_buffer", "ep_success_buffer"):
+                    try:
+                        data[k] = _unblob(v)
+                    except Exception:  # blobs that need gymnasium/SB3/py3.11 code objects are skipped, like SB3 does
+                        data[k] = None
+                elif k in ("observation_space", "action_space"):
+                    data[k] = {"shape": tuple(v.get("_shape", ())), "low_repr": v.get("low_repr"), "high_repr": v.get("high_repr")}
+                else:
+                    data[k] = None
+            else:
+                data[k] = v
+        sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)
+        params = OrderedDict((k, t.detach().cpu().numpy().astype(np.float32).copy()) for k, t in sd.items())
+        opt = None
+        if "policy.optimizer.pth" in names:
+            o = torch.load(io.BytesIO(z.read("policy.optimizer.pth")), map_location="cpu", weights_only=True)
+            if o.get("state"):
+                keys = list(params.keys())
+                opt = dict(exp_avg=OrderedDict((k, o["state"][i]["exp_avg"].numpy().copy()) for i, k in enumerate(keys)),
+                           exp_avg_sq=OrderedDict((k, o["state"][i]["exp_avg_sq"].numpy().copy()) for i, k in enumerate(keys)),
+                           step=int(float(o["state"][0]["step"])), param_groups=o["param_groups"])
+            else:
+                opt = dict(exp_avg=None, exp_avg_sq=None, step=0, param_groups=o.get("param_groups"))
+        version = z.read("_stable_baselines3_version").decode() if "_stable_baselines3_version" in names else None
+    data["_sb3_version"] = version
+    return dict(data=data, params=params, optimizer=opt)
+
+
+# ---------------------------------------------------------------------------------------------------
+# write
+# ---------------------------------------------------------------------------------------------------
+def save_zip(path, *, params, optimizer, hyper, obs_dim, act_dim, net_arch=None, counters=None, last_obs=None,
+             last_episode_starts=None, ep_info_buffer=None, action_low=-1.0, action_high=1.0, verbose=1, seed=0,
+             tensorboard_log=None):
+    """Write an SB3-2.0.0-layout zip.  `hyper` carries n_steps, batch_size, n_epochs, gamma, gae_lambda,
+    ent_coef, vf_coef, max_grad_norm, learning_rate, clip_range, n_envs; `optimizer` = dict(exp_avg, exp_avg_sq,
+    step, lr, betas, eps) with per-key arrays."""
+    import torch
+    if not str(path).endswith(".zip"):
+        path = str(path) + ".zip"
+    counters = dict(counters or {})
+    keys = list(params.keys())
+    assert keys == POLICY_KEYS, "parameters must be in SB3 registration order"
+    obs_low = np.full((obs_dim,), -np.inf, np.float32)
+    obs_high = np.full((obs_dim,), np.inf, np.float32)
+    act_low = np.full((act_dim,), action_low, np.float32)
+    act_high = np.full((act_dim,), action_high, np.float32)
+    n_envs = int(hyper["n_envs"])
+    if last_obs is None:
+        last_obs = np.zeros((n_envs, obs_dim), np.float32)
+    if last_episode_starts is None:
+        last_episode_starts = np.zeros((n_envs,), bool)
+    policy_kwargs = {} if net_arch is None else {"net_arch": {"pi": list(net_arch[0]), "vf": list(net_arch[1])}}
+    data = OrderedDict()
+    data["policy_class"] = _blob("<class 'abc.ABCMeta'>", pickle_policy_class(),
+                                 __module__="stable_baselines3.common.policies")
+    data["verbose"] = int(verbose)
+    data["policy_kwargs"] = policy_kwargs
+    data["num_timesteps"] = int(counters.get("num_timesteps", 0))
+    data["_total_timesteps"] = int(counters.get("_total_timesteps", 0))
+    data["_num_timesteps_at_start"] = int(counters.get("_num_timesteps_at_start", 0))
+    data["seed"] = seed
+    data["action_noise"] = None
+    data["start_time"] = int(counters.get("start_time", time.time_ns()))
+    data["learning_rate"] = float(hyper["learning_rate"])
+    data["tensorboard_log"] = tensorboard_log
+    data["_last_obs"] = _blob("<class 'numpy.ndarray'>", pickle_ndarray(np.asarray(last_obs, np.float32)))
+    data["_last_episode_starts"] = _blob("<class 'numpy.ndarray'>", pickle_ndarray(np.asarray(last_episode_starts, bool)))
+    data["_last_original_obs"] = None
+    data["_episode_num"] = int(counters.get("_episode_num", 0))
+    data["use_sde"] = False
+    data["sde_sample_freq"] = -1
+    data["_current_progress_remaining"] = float(counters.get("_current_progress_remaining", 1.0))
+    data["_stats_window_size"] = 100
+    buf = collections.deque(ep_info_buffer or [], maxlen=100)
+    data["ep_info_buffer"] = _blob("<class 'collections.deque'>", pickle.dumps(buf, protocol=4))
+    data["ep_success_buffer"] = _blob("<class 'collections.deque'>", pickle.dumps(collections.deque(maxlen=100), protocol=4))
+    data["_n_updates"] = int(counters.get("_n_updates", 0))
+    for k in ("n_steps", "gamma", "gae_lambda", "ent_coef", "vf_coef", "max_grad_norm", "batch_size", "n_epochs"):
+        data[k] = hyper[k]
+    data["clip_range"] = float(hyper["clip_range"])
+    data["clip_range_vf"] = None
+    data["normalize_advantage"] = bool(hyper.get("normalize_advantage", True))
+    data["target_kl"] = None
+    data["observation_space"] = _blob("<class 'gymnasium.spaces.box.Box'>", pickle_box(obs_low, obs_high),
+                                      dtype="float32", _shape=[obs_dim], low_repr="-inf", high_repr="inf", _np_random=None)
+    data["action_space"] = _blob("<class 'gymnasium.spaces.box.Box'>", pickle_box(act_low, act_high), dtype="float32",
+                                 _shape=[act_dim], low_repr=str(float(action_low)), high_repr=str(float(action_high)),
+                                 _np_random=None)
+    data["n_envs"] = n_envs
+
+    sd = OrderedDict((k, torch.from_numpy(np.ascontiguousarray(params[k], dtype=np.float32)).clone()) for k in keys)
+    state = {}
+    if optimizer.get("exp_avg") is not None and int(optimizer.get("step", 0)) > 0:
+        for i, k in enumerate(keys):
+            state[i] = {"step": torch.tensor(float(optimizer["step"])),
+                        "exp_avg": torch.from_numpy(np.ascontiguousarray(optimizer["exp_avg"][k], np.float32)).clone(),
+                        "exp_avg_sq": torch.from_numpy(np.ascontiguousarray(optimizer["exp_avg_sq"][k], np.float32)).clone()}
+    opt_sd = {"state": state,
+              "param_groups": [{"lr": float(optimizer.get("lr", hyper["learning_rate"])),
+                                "betas": tuple(optimizer.get("betas", (0.9, 0.999))), "eps": float(optimizer.get("eps", 1e-5)),
+                                "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None,
+                                "capturable": False, "differentiable": False, "fused": None,
+                                "params": list(range(len(keys)))}]}
+
+    def tsave(obj):
+        b = io.BytesIO()
+        torch.save(obj, b)
+        return b.getvalue()
+
+    import platform
+    info = (f"- OS: {platform.platform()}\n- Python: {platform.python_version()}\n- Stable-Baselines3: {SB3_VERSION} "
+            f"(written by mobrob_amd, MI355X-native engine)\n- PyTorch: {torch.__version__}\n- GPU Enabled: True\n"
+            f"- Numpy: {np.__version__}\n")
+    with zipfile.ZipFile(path, "w", compression=zipfile.ZIP_STORED) as z:
+        z.writestr("data", json.dumps(data, indent=4))
+        z.writestr("pytorch_variables.pth", tsave({}))
+        z.writestr("policy.pth", tsave(sd))
+        z.writestr("policy.optimizer.pth", tsave(opt_sd))
+        z.writestr("_stable_baselines3_version", SB3_VERSION)
+        z.writestr("system_info.txt", info)
+    return path
