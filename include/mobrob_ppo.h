@@ -184,7 +184,8 @@ enum {
   MOBROB_BUF_LAST_VALUES = 11, /* f32 [N]                                                        */
   MOBROB_BUF_LAST_DONES = 12,  /* f32 [N] (0/1)                                                  */
   MOBROB_BUF_CLIPPED_ACTIONS = 13, /* f32 [N][A] of the most recent act                          */
-  MOBROB_BUF_COUNT = 14
+  MOBROB_BUF_EPISODE_START_STATE = 14, /* f32 [N] `_last_episode_starts` carried between rollouts   */
+  MOBROB_BUF_COUNT = 15
 };
 int mobrob_ppo_buffer_info(mobrob_ppo_engine_t* e, int32_t which, void** ptr_dev, size_t* bytes);
 /* copy with host layout [..][D] <-> device layout [..][Dp] handled for MOBROB_BUF_OBS */

@@ -739,6 +739,7 @@ int mobrob_ppo_buffer_info(mobrob_ppo_engine_t* e, int32_t which, void** ptr, si
     case MOBROB_BUF_LAST_VALUES: p = e->last_values; b = N * 4; break;
     case MOBROB_BUF_LAST_DONES: p = e->last_dones; b = N * 4; break;
     case MOBROB_BUF_CLIPPED_ACTIONS: p = e->clip_act; b = N * e->A * 4; break;
+    case MOBROB_BUF_EPISODE_START_STATE: p = e->prev_dones; b = N * 4; break;
     default: return fail(MOBROB_ERR_INVALID, "unknown buffer id %d", which);
   }
   if (ptr) *ptr = p;

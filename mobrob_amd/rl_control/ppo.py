@@ -1,0 +1,457 @@
+"""PPO controller -- mirror of the reference's `PPOCtrl` (/root/reference/src/mobrob/rl_control/ppo.py:14-77)
+and of the slice of `stable_baselines3.PPO` that the reference touches:
+
+    PPO(env=..., seed=..., tensorboard_log=..., **ppo_kwargs)         ppo.py:50-59
+    .learn(total_timesteps, callback, progress_bar)                   ppo.py:73-74, examples/train.py:42-46
+    .save(path) / PPO.load(path)                                      ppo.py:76-77, utils.py:15-16, train.py:30-33
+    .policy.state_dict() / .policy.load_state_dict(...)               train.py:31-33
+    .predict(obs, deterministic=True) -> (action, None)               examples/control.py:39
+    CheckpointCallback(save_freq, save_path, name_prefix, verbose)    train.py:36-41
+
+All arithmetic runs in the HIP engine (libmobrob_ppo.so) on an MI355X; there is no CPU fallback.  The YAML's
+`device: cpu` is accepted (schema compatibility) and ignored.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from collections import OrderedDict, deque
+
+import numpy as np
+
+from ..checkpoint import load_zip, save_zip
+from ..engine import PPOEngine
+from ..envs.vec_env import DeviceSyntheticVecEnv, HostVecEnv, SyntheticVecEnv, make_vec_env
+from ..envs.wrapper import get_env
+from ..utils import DATA_DIR
+from .init import orthogonal_policy_init
+
+try:
+    import tensorboard  # noqa: F401
+except ImportError:
+    tensorboard = None
+
+DummyVecEnv = HostVecEnv  # both reference choices (ppo.py:30-33) map to the in-process batched VecEnv
+SubprocVecEnv = HostVecEnv
+
+
+# --------------------------------------------------------------------------------------------------
+# callbacks (SB3 BaseCallback protocol, the part CheckpointCallback needs)
+# --------------------------------------------------------------------------------------------------
+class BaseCallback:
+    def __init__(self, verbose: int = 0):
+        self.verbose, self.model, self.n_calls, self.num_timesteps = verbose, None, 0, 0
+
+    def init_callback(self, model):
+        self.model = model
+
+    def on_training_start(self, locals_=None, globals_=None):
+        pass
+
+    def on_rollout_start(self):
+        pass
+
+    def on_step(self) -> bool:
+        self.n_calls += 1
+        self.num_timesteps = self.model.num_timesteps
+        return self._on_step()
+
+    def _on_step(self) -> bool:
+        return True
+
+    def on_rollout_end(self):
+        pass
+
+    def on_training_end(self):
+        pass
+
+
+class CheckpointCallback(BaseCallback):
+    """Saves `<save_path>/<name_prefix>_<num_timesteps>_steps.zip` every `save_freq` calls (Appendix A.9)."""
+
+    def __init__(self, save_freq: int, save_path: str, name_prefix: str = "rl_model", verbose: int = 0):
+        super().__init__(verbose)
+        self.save_freq, self.save_path, self.name_prefix = max(int(save_freq), 1), save_path, name_prefix
+
+    def init_callback(self, model):
+        super().init_callback(model)
+        if self.save_path is not None:
+            os.makedirs(self.save_path, exist_ok=True)
+
+    def _on_step(self) -> bool:
+        if self.n_calls % self.save_freq == 0:
+            path = os.path.join(self.save_path, f"{self.name_prefix}_{self.num_timesteps}_steps.zip")
+            self.model.save(path)
+            if self.verbose >= 2:
+                print(f"Saving model checkpoint to {path}")
+        return True
+
+
+class _CallbackList(BaseCallback):
+    def __init__(self, cbs):
+        super().__init__()
+        self.cbs = cbs
+
+    def init_callback(self, model):
+        super().init_callback(model)
+        for c in self.cbs:
+            c.init_callback(model)
+
+    def on_training_start(self, l=None, g=None):
+        for c in self.cbs:
+            c.on_training_start(l, g)
+
+    def on_rollout_start(self):
+        for c in self.cbs:
+            c.on_rollout_start()
+
+    def _on_step(self):
+        ok = True
+        for c in self.cbs:
+            ok = c.on_step() and ok
+        return ok
+
+    def on_rollout_end(self):
+        for c in self.cbs:
+            c.on_rollout_end()
+
+    def on_training_end(self):
+        for c in self.cbs:
+            c.on_training_end()
+
+
+# --------------------------------------------------------------------------------------------------
+# policy handle
+# --------------------------------------------------------------------------------------------------
+class ActorCriticPolicyHandle:
+    """`ppo.policy`: state_dict()/load_state_dict() with SB3's 13 keys; tensors are torch CPU tensors."""
+
+    def __init__(self, model):
+        self._m = model
+
+    def state_dict(self):
+        import torch
+        return OrderedDict((k, torch.from_numpy(v.copy())) for k, v in self._m.engine.get_params().items())
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        cur = self._m.engine.get_params()
+        missing = [k for k in cur if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in cur]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing keys {missing}, unexpected keys {unexpected}")
+        for k in cur:
+            if k in state_dict:
+                v = state_dict[k]
+                v = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+                if v.shape != cur[k].shape:
+                    raise RuntimeError(f"size mismatch for {k}: copying a param with shape {tuple(v.shape)} from "
+                                       f"checkpoint, the shape in current model is {tuple(cur[k].shape)}")
+                cur[k] = v.astype(np.float32)
+        self._m.engine.set_params(cur)
+
+    def predict(self, observation, state=None, episode_start=None, deterministic: bool = False):
+        return self._m.predict(observation, state, episode_start, deterministic)
+
+    def set_training_mode(self, mode: bool):
+        pass
+
+
+_SB3_DEFAULTS = dict(learning_rate=3e-4, n_steps=2048, batch_size=64, n_epochs=10, gamma=0.99, gae_lambda=0.95,
+                     clip_range=0.2, clip_range_vf=None, normalize_advantage=True, ent_coef=0.0, vf_coef=0.5,
+                     max_grad_norm=0.5, use_sde=False, sde_sample_freq=-1, target_kl=None, stats_window_size=100)
+
+
+class PPO:
+    def __init__(self, policy="MlpPolicy", env=None, learning_rate=3e-4, n_steps=2048, batch_size=64, n_epochs=10,
+                 gamma=0.99, gae_lambda=0.95, clip_range=0.2, clip_range_vf=None, normalize_advantage=True,
+                 ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, use_sde=False, sde_sample_freq=-1, target_kl=None,
+                 stats_window_size=100, tensorboard_log=None, policy_kwargs=None, verbose=0, seed=None, device="auto",
+                 _init_setup_model=True, _dims=None, _engine_kwargs=None):
+        if policy not in ("MlpPolicy",) and getattr(policy, "__name__", "") != "ActorCriticPolicy":
+            raise ValueError(f"Policy {policy} unknown")
+        if callable(learning_rate) or callable(clip_range):
+            raise NotImplementedError("only constant learning_rate / clip_range schedules (all reference configs)")
+        if clip_range_vf is not None or use_sde or target_kl is not None:
+            raise NotImplementedError("clip_range_vf, use_sde and target_kl are not used by the reference configs "
+                                      "and are not implemented by the HIP engine")
+        self.policy_class = "MlpPolicy"
+        self.env = env
+        self.learning_rate, self.n_steps, self.batch_size, self.n_epochs = float(learning_rate), int(n_steps), int(batch_size), int(n_epochs)
+        self.gamma, self.gae_lambda, self.clip_range = float(gamma), float(gae_lambda), float(clip_range)
+        self.clip_range_vf, self.normalize_advantage = None, bool(normalize_advantage)
+        self.ent_coef, self.vf_coef, self.max_grad_norm = float(ent_coef), float(vf_coef), float(max_grad_norm)
+        self.use_sde, self.sde_sample_freq, self.target_kl = False, -1, None
+        self.tensorboard_log, self.verbose, self.seed, self.device = tensorboard_log, int(verbose), seed, device
+        self.policy_kwargs = dict(policy_kwargs or {})
+        net_arch = self.policy_kwargs.get("net_arch", dict(pi=[64, 64], vf=[64, 64]))
+        if isinstance(net_arch, (list, tuple)):
+            net_arch = dict(pi=list(net_arch), vf=list(net_arch))
+        self.net_arch = (tuple(net_arch.get("pi", [64, 64])), tuple(net_arch.get("vf", [64, 64])))
+        unknown = set(self.policy_kwargs) - {"net_arch"}
+        if unknown:
+            raise NotImplementedError(f"policy_kwargs {sorted(unknown)} are not supported (MlpPolicy with tanh, "
+                                      "ortho_init, two hidden layers per network)")
+        self.num_timesteps = 0
+        self._total_timesteps = 0
+        self._num_timesteps_at_start = 0
+        self._n_updates = 0
+        self._episode_num = 0
+        self._current_progress_remaining = 1.0
+        self._last_obs = None
+        self._last_episode_starts = None
+        self.start_time = None
+        self.ep_info_buffer = deque(maxlen=stats_window_size)
+        self._stats_window_size = stats_window_size
+        self._engine_kwargs = dict(_engine_kwargs or {})
+        if env is not None:
+            self.n_envs, self.obs_dim, self.act_dim = env.num_envs, env.obs_dim, env.act_dim
+        elif _dims is not None:
+            self.n_envs, self.obs_dim, self.act_dim = _dims
+        else:
+            raise ValueError("PPO needs an environment (or load a checkpoint with PPO.load)")
+        self.engine = None
+        self.policy = None
+        if _init_setup_model:
+            self._setup_model()
+
+    # ---------------------------------------------------------------------------------------------
+    def _setup_model(self):
+        if self.n_steps * self.n_envs <= 1:
+            raise AssertionError("`n_steps * n_envs` must be greater than 1")
+        kw = dict(obs_dim=self.obs_dim, act_dim=self.act_dim, n_envs=self.n_envs, n_steps=self.n_steps,
+                  batch_size=self.batch_size, n_epochs=self.n_epochs, pi=self.net_arch[0], vf=self.net_arch[1],
+                  gamma=self.gamma, gae_lambda=self.gae_lambda, clip_range=self.clip_range, ent_coef=self.ent_coef,
+                  vf_coef=self.vf_coef, max_grad_norm=self.max_grad_norm, learning_rate=self.learning_rate,
+                  normalize_advantage=self.normalize_advantage, seed=0 if self.seed is None else int(self.seed))
+        kw.update(self._engine_kwargs)
+        self.engine = PPOEngine(**kw)
+        self.engine.set_params(orthogonal_policy_init(self.obs_dim, self.act_dim, self.net_arch[0], self.net_arch[1],
+                                                      seed=0 if self.seed is None else int(self.seed)))
+        self.policy = ActorCriticPolicyHandle(self)
+
+    def get_env(self):
+        return self.env
+
+    def set_env(self, env):
+        if (env.num_envs, env.obs_dim, env.act_dim) != (self.n_envs, self.obs_dim, self.act_dim):
+            raise ValueError("environment does not match the model's (n_envs, obs_dim, act_dim)")
+        self.env = env
+        self._last_obs = None
+
+    # ---------------------------------------------------------------------------------------------
+    def predict(self, observation, state=None, episode_start=None, deterministic: bool = False):
+        """-> (actions clipped to the Box, None) like SB3's BasePolicy.predict (Appendix A.10)."""
+        act = self.engine.predict(np.asarray(observation, dtype=np.float32), deterministic=deterministic)
+        return act, None
+
+    # ---------------------------------------------------------------------------------------------
+    def _collect_rollouts(self, callback) -> bool:
+        e, env, N = self.engine, self.env, self.n_envs
+        callback.on_rollout_start()
+        if isinstance(env, DeviceSyntheticVecEnv):
+            e.collect_synthetic(env.p_term, env.time_limit)
+            for _ in range(self.n_steps):
+                self.num_timesteps += N
+                if not callback.on_step():
+                    return False
+            callback.on_rollout_end()
+            return True
+        e.rollout_begin()
+        dones = np.zeros(N, bool)
+        for _ in range(self.n_steps):
+            _, clipped, _, _ = e.act(self._last_obs)
+            new_obs, rewards, dones, infos = env.step(clipped)
+            self.num_timesteps += N
+            if not callback.on_step():
+                return False
+            trunc, term_obs = None, None
+            for i, info in enumerate(infos):
+                ep = info.get("episode")
+                if ep is not None:
+                    self.ep_info_buffer.append(ep)
+                if dones[i] and info.get("terminal_observation") is not None and info.get("TimeLimit.truncated", False):
+                    if trunc is None:
+                        trunc, term_obs = np.zeros(N, np.uint8), np.zeros((N, self.obs_dim), np.float32)
+                    trunc[i], term_obs[i] = 1, info["terminal_observation"]
+            e.store(rewards, dones, trunc, term_obs)
+            self._last_obs, self._last_episode_starts = new_obs, dones
+        e.finish_rollout(self._last_obs, dones)
+        callback.on_rollout_end()
+        return True
+
+    def train(self):
+        stats = self.engine.train(None)
+        self._n_updates += self.n_epochs
+        return stats
+
+    def learn(self, total_timesteps, callback=None, log_interval=1, tb_log_name="PPO", reset_num_timesteps=True,
+              progress_bar=False):
+        if self.env is None:
+            raise ValueError("learn() needs an environment: PPO.load(path, env=...) or set_env()")
+        total_timesteps = int(total_timesteps)
+        self.start_time = time.time_ns()
+        if reset_num_timesteps:
+            self.num_timesteps, self._episode_num = 0, 0
+        else:
+            total_timesteps += self.num_timesteps
+        self._total_timesteps, self._num_timesteps_at_start = total_timesteps, self.num_timesteps
+        host_env = not isinstance(self.env, DeviceSyntheticVecEnv)
+        if host_env and (reset_num_timesteps or self._last_obs is None):
+            self._last_obs = self.env.reset()
+            self._last_episode_starts = np.ones(self.n_envs, bool)
+            self.engine.write("episode_start_state", np.ones(self.n_envs, np.float32))
+        if callback is None:
+            callback = BaseCallback()
+        elif isinstance(callback, (list, tuple)):
+            callback = _CallbackList(list(callback))
+        callback.init_callback(self)
+        callback.on_training_start(locals(), globals())
+        bar = None
+        if progress_bar:
+            try:
+                from tqdm import tqdm
+                bar = tqdm(total=total_timesteps - self.num_timesteps, file=sys.stderr)
+            except ImportError:
+                bar = None
+        iteration = 0
+        while self.num_timesteps < total_timesteps:
+            before = self.num_timesteps
+            if not self._collect_rollouts(callback):
+                break
+            iteration += 1
+            self._current_progress_remaining = 1.0 - float(self.num_timesteps) / float(total_timesteps)
+            stats = self.train()
+            if bar is not None:
+                bar.update(self.num_timesteps - before)
+            if self.verbose >= 1 and log_interval is not None and iteration % log_interval == 0:
+                self._log(iteration, stats)
+        if bar is not None:
+            bar.close()
+        callback.on_training_end()
+        return self
+
+    def _log(self, iteration, stats):
+        elapsed = max((time.time_ns() - self.start_time) / 1e9, sys.float_info.epsilon)
+        fps = int((self.num_timesteps - self._num_timesteps_at_start) / elapsed)
+        rows = []
+        if len(self.ep_info_buffer) > 0:
+            rows += [("rollout/ep_len_mean", float(np.mean([e["l"] for e in self.ep_info_buffer]))),
+                     ("rollout/ep_rew_mean", float(np.mean([e["r"] for e in self.ep_info_buffer])))]
+        rows += [("time/fps", fps), ("time/iterations", iteration), ("time/time_elapsed", int(elapsed)),
+                 ("time/total_timesteps", self.num_timesteps), ("train/approx_kl", stats["approx_kl"]),
+                 ("train/clip_fraction", stats["clip_fraction"]), ("train/clip_range", self.clip_range),
+                 ("train/entropy_loss", stats["entropy_loss"]), ("train/learning_rate", self.learning_rate),
+                 ("train/loss", stats["loss"]), ("train/n_updates", self._n_updates),
+                 ("train/policy_gradient_loss", stats["policy_loss"]), ("train/value_loss", stats["value_loss"])]
+        w = max(len(k) for k, _ in rows)
+        print("-" * (w + 20))
+        for k, v in rows:
+            print(f"| {k:<{w}} | {v:<13.6g} |" if isinstance(v, float) else f"| {k:<{w}} | {v:<13} |")
+        print("-" * (w + 20), flush=True)
+
+    # ---------------------------------------------------------------------------------------------
+    def _hyper(self):
+        return dict(n_steps=self.n_steps, batch_size=self.batch_size, n_epochs=self.n_epochs, gamma=self.gamma,
+                    gae_lambda=self.gae_lambda, ent_coef=self.ent_coef, vf_coef=self.vf_coef,
+                    max_grad_norm=self.max_grad_norm, learning_rate=self.learning_rate, clip_range=self.clip_range,
+                    normalize_advantage=self.normalize_advantage, n_envs=self.n_envs)
+
+    def save(self, path):
+        """SB3-layout zip (checkpoint.py); appends .zip like SB3 when the suffix is missing."""
+        m, v, step = self.engine.get_optimizer_state()
+        d = os.path.dirname(str(path))
+        if d:
+            os.makedirs(d, exist_ok=True)
+        explicit_arch = "net_arch" in self.policy_kwargs
+        save_zip(path, params=self.engine.get_params(),
+                 optimizer=dict(exp_avg=m, exp_avg_sq=v, step=step, lr=self.learning_rate, betas=(0.9, 0.999), eps=1e-5),
+                 hyper=self._hyper(), obs_dim=self.obs_dim, act_dim=self.act_dim,
+                 net_arch=self.net_arch if explicit_arch else None,
+                 counters=dict(num_timesteps=self.num_timesteps, _total_timesteps=self._total_timesteps,
+                               _num_timesteps_at_start=self._num_timesteps_at_start, _n_updates=self._n_updates,
+                               _episode_num=self._episode_num, start_time=self.start_time or time.time_ns(),
+                               _current_progress_remaining=self._current_progress_remaining),
+                 last_obs=self._last_obs, last_episode_starts=self._last_episode_starts,
+                 ep_info_buffer=list(self.ep_info_buffer), verbose=self.verbose, seed=self.seed,
+                 tensorboard_log=self.tensorboard_log)
+
+    @classmethod
+    def load(cls, path, env=None, device="auto", custom_objects=None, print_system_info=False, force_reset=True,
+             **kwargs):
+        ck = load_zip(path)
+        d, params = ck["data"], ck["params"]
+        D = params["mlp_extractor.policy_net.0.weight"].shape[1]
+        A = params["log_std"].shape[0]
+        pi = (params["mlp_extractor.policy_net.0.weight"].shape[0], params["mlp_extractor.policy_net.2.weight"].shape[0])
+        vf = (params["mlp_extractor.value_net.0.weight"].shape[0], params["mlp_extractor.value_net.2.weight"].shape[0])
+        pk = dict(d.get("policy_kwargs") or {})
+        pk.setdefault("net_arch", dict(pi=list(pi), vf=list(vf)))
+        explicit_arch = "net_arch" in (d.get("policy_kwargs") or {})
+        n_envs = int(d.get("n_envs", 1)) if env is None else env.num_envs
+        if env is not None and (env.obs_dim, env.act_dim) != (D, A):
+            raise ValueError(f"Observation/action spaces do not match: checkpoint ({D},{A}) vs env ({env.obs_dim},{env.act_dim})")
+        clip = d.get("clip_range")
+        model = cls(policy="MlpPolicy", env=env, learning_rate=float(d.get("learning_rate", 3e-4)),
+                    n_steps=int(d.get("n_steps", 2048)), batch_size=int(d.get("batch_size", 64)),
+                    n_epochs=int(d.get("n_epochs", 10)), gamma=float(d.get("gamma", 0.99)),
+                    gae_lambda=float(d.get("gae_lambda", 0.95)), clip_range=float(clip) if isinstance(clip, (int, float)) else 0.2,
+                    normalize_advantage=bool(d.get("normalize_advantage", True)), ent_coef=float(d.get("ent_coef", 0.0)),
+                    vf_coef=float(d.get("vf_coef", 0.5)), max_grad_norm=float(d.get("max_grad_norm", 0.5)),
+                    tensorboard_log=d.get("tensorboard_log"), policy_kwargs=pk, verbose=int(d.get("verbose", 0)),
+                    seed=d.get("seed"), device=device, _dims=(n_envs, D, A), **kwargs)
+        if not explicit_arch:
+            model.policy_kwargs.pop("net_arch", None)
+        model.engine.set_params(params)
+        opt = ck["optimizer"]
+        if opt is not None and opt.get("exp_avg") is not None:
+            model.engine.set_optimizer_state(opt["exp_avg"], opt["exp_avg_sq"], opt["step"])
+        for k in ("num_timesteps", "_total_timesteps", "_num_timesteps_at_start", "_n_updates", "_episode_num",
+                  "_current_progress_remaining", "start_time"):
+            if d.get(k) is not None:
+                setattr(model, k, d[k])
+        if d.get("ep_info_buffer") is not None:
+            model.ep_info_buffer = deque(d["ep_info_buffer"], maxlen=model._stats_window_size)
+        if not force_reset and d.get("_last_obs") is not None:
+            model._last_obs = np.asarray(d["_last_obs"], np.float32)
+        return model
+
+
+class PPOCtrl:
+    """Same constructor, `from_config`, `learn`, `save_model` and `.ppo` attribute as the reference class
+    (src/mobrob/rl_control/ppo.py:14-77).  `vec_env_type` accepts the reference values "subproc" and "dummy"
+    (ValueError otherwise, ppo.py:35) -- both run the in-process batched VecEnv -- plus two build extensions:
+    "synthetic" (host NumPy env source) and "device" (device-resident synthetic source)."""
+
+    def __init__(self, ppo_kwargs: dict, env_name: str, time_limit: int, n_env: int, vec_env_type: str = "dummy",
+                 enable_gui: bool = False, seed: int = 0) -> None:
+        self.ppo_kwargs = ppo_kwargs
+        self.env_name = env_name
+        self.time_limit = time_limit
+        self.n_env = n_env
+        if vec_env_type in ("subproc", "dummy"):
+            vec_env = make_vec_env(get_env, n_envs=n_env,
+                                   env_kwargs={"env_name": env_name, "enable_gui": enable_gui,
+                                               "terminate_on_goal": True, "time_limit": time_limit},
+                                   vec_env_cls=HostVecEnv, seed=seed)
+        elif vec_env_type == "synthetic":
+            vec_env = SyntheticVecEnv.for_robot(env_name, n_env, time_limit, seed)
+        elif vec_env_type == "device":
+            vec_env = DeviceSyntheticVecEnv.for_robot(env_name, n_env, time_limit, seed)
+        else:
+            raise ValueError(f"Unknown vec_env_type: {vec_env_type}")
+        self.ppo = PPO(env=vec_env, seed=seed,
+                       tensorboard_log=(f"{DATA_DIR}/policies/tmp/{env_name}-ppo/tensorboard" if tensorboard is not None else None),
+                       **ppo_kwargs)
+
+    @classmethod
+    def from_config(cls, config: dict) -> "PPOCtrl":
+        return cls(ppo_kwargs=config["ppo_kwargs"], env_name=config["env_name"], time_limit=config["time_limit"],
+                   n_env=config["n_envs"], vec_env_type=config["vec_env_type"], enable_gui=config["enable_gui"],
+                   seed=config["seed"])
+
+    def learn(self, *args, **kwargs) -> None:
+        self.ppo.learn(*args, **kwargs)
+
+    def save_model(self, save_path: str) -> None:
+        self.ppo.save(save_path)
