@@ -250,6 +250,16 @@ void run_gae(mobrob_ppo_engine* e) {
 void act_slot(mobrob_ppo_engine* e, int t, const float* eps_dev_or_null) {
   ProfScope ps(e, MOBROB_K_ACT);
   const float* X = e->obs + (size_t)t * e->N * e->Dp;
+  if (e->fused.enabled) {
+    FusedActArgs a{};
+    a.X = X; a.rows = e->N; a.want_pi = 1; a.want_v = 1; a.mu = nullptr; a.ldmu = e->Ap;
+    a.v = e->values + (size_t)t * e->N; a.sample = 1; a.A = e->A; a.log_std = Pp(e, T_LOGSTD); a.eps = eps_dev_or_null;
+    a.seed = e->cfg.seed; a.draw = e->draw_counter; a.lo = (float)e->cfg.action_low; a.hi = (float)e->cfg.action_high;
+    a.act_raw = e->actions + (size_t)t * e->N * e->A; a.act_clip = e->clip_act; a.logp = e->logp + (size_t)t * e->N;
+    fused_launch_act(e->fused, a, e->stream);
+    e->draw_counter++;
+    return;
+  }
   forward(e, X, e->N, true, e->mu, true, e->values + (size_t)t * e->N);
   hipLaunchKernelGGL(k_sample, dim3(cdiv(e->N, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, Pp(e, T_LOGSTD),
                      eps_dev_or_null, e->N, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high, e->cfg.seed,
@@ -261,6 +271,59 @@ int upload_obs(mobrob_ppo_engine* e, const float* host, float* dev_rows, int row
   HIPC(hipMemcpy2DAsync(dev_rows, (size_t)e->Dp * 4, host, (size_t)e->D * 4, (size_t)e->D * 4, rows,
                         hipMemcpyHostToDevice, e->stream));
   return MOBROB_OK;
+}
+
+int fused_init(mobrob_ppo_engine* e) {
+  FusedState& f = e->fused;
+  f.enabled = e->cfg.fast_kernels && fused_shape_ok(e->D, e->A, e->H1, e->H2, e->G1, e->G2);
+  if (!f.enabled) return MOBROB_OK;
+  f.D = e->D; f.Dp = e->Dp; f.A = e->A;
+  const size_t nW1 = (size_t)(FH / 32) * (e->Dp / 8) * 256, nW2 = (size_t)(FH / 32) * (FH / 8) * 256;
+  const size_t nW3f = (size_t)(FH / 8) * 256, nW3b = (size_t)(FH / 32) * 4 * 256;
+  const size_t per_net = nW1 + 2 * nW2 + nW3f + nW3b;
+  f.packed_floats = 2 * per_net;
+  CHK(dalloc(e, &f.packed, f.packed_floats));
+  const int bias_ids[2][3] = {{T_PB1, T_PB2, T_AB}, {T_VB1, T_VB2, T_VB}};
+  for (int n = 0; n < 2; ++n) {
+    float* p = f.packed + n * per_net;
+    f.net[n].W1f = reinterpret_cast<const f32x4*>(p); p += nW1;
+    f.net[n].W2f = reinterpret_cast<const f32x4*>(p); p += nW2;
+    f.net[n].W3f = reinterpret_cast<const f32x4*>(p); p += nW3f;
+    f.net[n].W2b = reinterpret_cast<const f32x4*>(p); p += nW2;
+    f.net[n].W3b = reinterpret_cast<const f32x4*>(p); p += nW3b;
+    f.net[n].b1 = e->params + e->offs[bias_ids[n][0]];
+    f.net[n].b2 = e->params + e->offs[bias_ids[n][1]];
+    f.net[n].b3 = e->params + e->offs[bias_ids[n][2]];
+    f.net[n].head = n == 0 ? e->A : 1;
+  }
+  f.slab_floats = slab_size(e->Dp);
+  f.max_grid = 256;
+  CHK(dalloc(e, &f.slabs, (size_t)f.max_grid * f.slab_floats));
+  f.lds_bytes = fused_lds_bytes(e->Dp);
+  HIPC(fused_set_lds_attr(f));
+  return MOBROB_OK;
+}
+
+// fused minibatch gradient: one persistent kernel + the deterministic slab reduction
+void fused_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, float inv_bg) {
+  FusedState& f = e->fused;
+  FusedTrainArgs a{};
+  a.net[0] = f.net[0]; a.net[1] = f.net[1];
+  a.obs = e->obs; a.Dp = e->Dp; a.actions = e->actions; a.A = e->A; a.old_logp = e->logp; a.adv = e->adv; a.ret = e->ret;
+  a.rows = e->rows + start; a.count = B; a.log_std = e->params + e->offs[T_LOGSTD];
+  a.advstat = e->advstat + 4 * (size_t)mb; a.normalize = e->cfg.normalize_advantage;
+  a.clip = (float)e->cfg.clip_range; a.vf_coef = (float)e->cfg.vf_coef; a.ent_coef = (float)e->cfg.ent_coef;
+  a.inv_bg = inv_bg; a.slabs = f.slabs; a.slab_floats = f.slab_floats; a.sums = e->grads + e->P;
+  const int ntiles = cdiv(B, FR);
+  const int grid = 2 * std::min(f.max_grid / 2, ntiles);
+  (void)hipMemsetAsync(e->grads + e->P, 0, 8 * sizeof(float), e->stream);
+  fused_launch_train(f, a, grid, e->stream);
+  SlabReduceArgs s{};
+  s.slabs = f.slabs; s.slab_floats = f.slab_floats; s.nslabs = grid; s.grads = e->grads; s.P = e->P;
+  for (int i = 0; i < 14; ++i) s.offs[i] = e->offs[i];
+  s.D = e->D; s.Dp = e->Dp; s.A = e->A; s.ent_coef = (float)e->cfg.ent_coef; s.b_local = (float)B; s.inv_bg = inv_bg;
+  s.sums = e->grads + e->P;
+  hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(e->P, 256)), dim3(256), 0, e->stream, s);
 }
 
 int check_cfg(const mobrob_ppo_config_t* c) {
@@ -359,6 +422,7 @@ int mobrob_ppo_create(const mobrob_ppo_config_t* cfg, mobrob_ppo_engine_t** out)
   CHK(dalloc(e, &e->dz2v, Bl * e->G2)); CHK(dalloc(e, &e->dz1v, Bl * e->G1));
   CHK(dalloc(e, &e->pred_obs, R * Dp)); CHK(dalloc(e, &e->pred_act, R * A));
   HIPC(hipMemcpyAsync(e->offs_dev, e->offs, sizeof e->offs, hipMemcpyHostToDevice, e->stream));
+  CHK(fused_init(e));
   // `_last_episode_starts` is all-True at _setup_learn (Appendix A.5)
   std::vector<float> ones(N, 1.0f);
   HIPC(hipMemcpyAsync(e->prev_dones, ones.data(), N * 4, hipMemcpyHostToDevice, e->stream));
@@ -580,6 +644,12 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
   const int B = std::min(e->Bl, total - start);
   const float inv_bg = 1.0f / (float)((int64_t)B * e->cfg.world_size);
   e->cur_count = B;
+  if (e->fused.enabled) {
+    fused_minibatch_grad(e, mb, start, B, inv_bg);
+    HIPC(hipGetLastError());
+    e->grad_pending = true;
+    return MOBROB_OK;
+  }
   HIPC(hipMemsetAsync(e->grads, 0, (size_t)(e->P + 8) * 4, e->stream));
   float* sums = e->grads + e->P;
   const int per = e->Dp / 4;

@@ -236,3 +236,113 @@ def test_error_paths():
     with pytest.raises(ValueError):
         e.set_flat_params(np.zeros(3, np.float32))
     e.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# fused fast path (hidden width 256): same oracle, plus a differential check against the generic kernels
+# ------------------------------------------------------------------------------------------------
+def _consistent_rollout(p, T, N, D, A, seed):
+    rng = np.random.default_rng(seed)
+    buf, lv, dones = synthetic_rollout(T, N, D, A, seed=seed)
+    flat_obs = buf["obs"].reshape(T * N, D)
+    mean, val = O.policy_outputs(p, flat_obs)
+    acts = (mean + rng.standard_normal((T * N, A)).astype(np.float32) * np.exp(p["log_std"])).astype(np.float32)
+    buf["actions"] = acts.reshape(T, N, A)
+    buf["log_probs"] = (O.gaussian_log_prob(mean, p["log_std"], acts) + rng.normal(0, 0.1, T * N)).astype(np.float32).reshape(T, N)
+    buf["values"] = (val + rng.normal(0, 0.1, T * N)).astype(np.float32).reshape(T, N)
+    return buf, lv, dones
+
+
+@pytest.mark.parametrize("D,A", [(58, 12), (14, 2), (26, 2), (12, 18), (43, 2)])
+def test_fused_act_matches_oracle(D, A):
+    N, H = 200, 256  # 200 rows: 3 full tiles + a partial one
+    rng = np.random.default_rng(D)
+    p = O.init_params(D, A, (H, H), (H, H), seed=D)
+    p["log_std"] = rng.normal(0.2, 0.3, A).astype(np.float32)
+    for k in p:
+        if k.endswith("bias"):
+            p[k] = rng.normal(0, 0.1, p[k].shape).astype(np.float32)
+    obs = rng.standard_normal((N, D)).astype(np.float32) * 2
+    eps = rng.standard_normal((N, A)).astype(np.float32)
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=2, batch_size=64, n_epochs=1, pi=(H, H), vf=(H, H))
+    e.set_params(p)
+    a_raw, a_clip, val, lp = e.act(obs, eps)
+    o_raw, o_clip, o_val, o_lp = O.act(p, obs, eps)
+    assert scaled_err(a_raw, o_raw) < 1e-4 and scaled_err(val, o_val) < 1e-4
+    assert np.allclose(lp, o_lp, rtol=1e-4, atol=1e-3)
+    assert np.array_equal(a_clip, np.clip(a_raw, -1, 1))
+    det, v2 = e.predict(obs, deterministic=True, want_values=True)
+    assert np.allclose(det, np.clip(O.policy_outputs(p, obs)[0], -1, 1), atol=1e-4) and scaled_err(v2, o_val) < 1e-4
+    e.close()
+
+
+@pytest.mark.parametrize("cfg", [dict(D=58, A=12, T=8, N=13, B=104, E=1),        # one partial-tile minibatch (104 = 64+40)
+                                 dict(D=58, A=12, T=50, N=200, B=10000, E=1),    # 157 tiles -> 128 WGs, some with 2 tiles
+                                 dict(D=14, A=2, T=30, N=100, B=1000, E=2),      # 3 minibatches, DP=16
+                                 dict(D=43, A=2, T=20, N=64, B=512, E=1),        # DP=48
+                                 dict(D=26, A=2, T=9, N=7, B=63, E=2)])          # DP=32, single tile, count < 64
+def test_fused_train_matches_oracle_and_generic(cfg):
+    D, A, T, N, B, E = (cfg[k] for k in "DATNBE")
+    H = 256
+    rng = np.random.default_rng(17)
+    p0 = O.init_params(D, A, (H, H), (H, H), seed=3)
+    p0["log_std"] = rng.normal(-0.3, 0.2, A).astype(np.float32)
+    p0["action_net.weight"] *= 30
+    buf, lv, dones = _consistent_rollout(p0, T, N, D, A, seed=9)
+    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=E, batch_size=B, learning_rate=3e-4)
+    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, h.gamma, h.gae_lambda)
+    perms = np.stack([rng.permutation(T * N) for _ in range(E)])
+    results = {}
+    for fast in (True, False):
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H),
+                        gamma=h.gamma, gae_lambda=h.gae_lambda, ent_coef=h.ent_coef, learning_rate=h.learning_rate,
+                        fast_kernels=fast)
+        e.set_params(p0)
+        e.load_rollout(buf, lv, dones)
+        # first-minibatch gradient
+        e.epoch_begin(perms[0])
+        e.minibatch_grad(0)
+        g0 = e.read("grads")
+        e.minibatch_apply()
+        e.fetch_step_stats()
+        # then the full update from scratch
+        e.set_params(p0)
+        z = {k: np.zeros_like(v) for k, v in p0.items()}
+        e.set_optimizer_state(z, z, 0)
+        stats = e.train(perms)
+        results[fast] = (g0, e.get_params(), stats)
+        e.close()
+    p = {k: v.copy() for k, v in p0.items()}
+    idx = perms[0][:B]
+    _, og, _ = O.loss_and_grads(p, *O.gather_minibatch(buf, idx), h)
+    og = O.flatten_params(og)
+    scale = float(np.max(np.abs(og)))
+    for fast in (True, False):
+        assert np.max(np.abs(results[fast][0] - og)) < 1e-4 * max(1.0, scale), fast
+    st = O.AdamState.zeros_like(p)
+    ostats = O.train(p, st, buf, h, perms)
+    nmb = -(-T * N // B)
+    for fast in (True, False):
+        newp, stats = results[fast][1], results[fast][2]
+        for k in p:
+            assert np.max(np.abs(newp[k] - p[k])) < 1e-4, (fast, k, float(np.max(np.abs(newp[k] - p[k]))))
+        for k in ["policy_loss", "value_loss", "loss", "approx_kl", "clip_fraction", "grad_norm"]:
+            ref = float(np.mean([float(s[k]) for s in ostats[-nmb:]]))
+            assert abs(stats[k] - ref) < 2e-4 * max(1.0, abs(ref)), (fast, k, stats[k], ref)
+
+
+def test_fused_gradients_are_run_to_run_deterministic():
+    D, A, T, N, B, H = 58, 12, 40, 128, 5120, 256
+    p = O.init_params(D, A, (H, H), (H, H), seed=1)
+    buf, lv, dones = _consistent_rollout(p, T, N, D, A, seed=2)
+    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, 0.99, 0.95)
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=1, pi=(H, H), vf=(H, H))
+    e.set_params(p)
+    e.load_rollout(buf, lv, dones)
+    e.epoch_begin(np.arange(T * N))
+    e.minibatch_grad(0)
+    g1 = e.read("grads")
+    e.minibatch_grad(0)
+    g2 = e.read("grads")
+    assert np.array_equal(g1, g2)  # slab reduction, no float atomics
+    e.close()
