@@ -122,69 +122,25 @@ __device__ __forceinline__ void gemm_lds_packed(int a_off, const f32x4* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// dW2 accumulators in hand-managed accumulator registers a[0:255] (cdna_hip_programming.md §5.7 item 4).
-// The library is compiled with -mllvm -amdgpu-mfma-vgpr-form, so every compiler-generated MFMA keeps its
-// accumulator in arch VGPRs and the compiler never allocates an AGPR itself; the 256 AGPRs then belong to the
-// statements below.  Tile (ib, jb) of the wave's [2][8] block grid lives in a[(ib*8+jb)*16 .. +15].
-// build() audits the generated code: no spills, no compiler v_accvgpr_* (see __graft_entry__.py).
+// dW2 accumulators: 16 tiles of 32x32 (this wave's 64 neurons x 256 inputs) pinned to the accumulator
+// register file for the whole kernel.  The library is compiled with -mllvm -amdgpu-mfma-vgpr-form, so every
+// compiler-selected MFMA keeps its accumulator in arch VGPRs (work tiles, <= 64 registers); the persistent
+// tiles are only ever touched by the statement below, whose "+a" constraints make the register allocator keep
+// all 256 AGPRs occupied by them (so it cannot park anything else there).  Tile t = ib*8 + jb.
 // ------------------------------------------------------------------------------------------------
-#define ACC_CLOBBER_16(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
-#define ACC_CLOBBERS                                                                                                   \
-  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", ACC_CLOBBER_16(1), ACC_CLOBBER_16(2), ACC_CLOBBER_16(3), \
-      ACC_CLOBBER_16(4), ACC_CLOBBER_16(5), ACC_CLOBBER_16(6), ACC_CLOBBER_16(7), ACC_CLOBBER_16(8), ACC_CLOBBER_16(9), \
-      ACC_CLOBBER_16(10), ACC_CLOBBER_16(11), ACC_CLOBBER_16(12), ACC_CLOBBER_16(13), ACC_CLOBBER_16(14),              \
-      ACC_CLOBBER_16(15), ACC_CLOBBER_16(16), ACC_CLOBBER_16(17), ACC_CLOBBER_16(18), ACC_CLOBBER_16(19),              \
-      ACC_CLOBBER_16(20), ACC_CLOBBER_16(21), ACC_CLOBBER_16(22), ACC_CLOBBER_16(23), ACC_CLOBBER_16(24), "a250",      \
-      "a251", "a252", "a253", "a254", "a255"
-
-template <int N>
-__device__ __forceinline__ void acc_zero_range() {
-  if constexpr (N < 256) {
-    asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(N));
-    acc_zero_range<N + 1>();
-  }
-}
-template <int N>
-__device__ __forceinline__ float acc_read() {
-  float v;
-  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(N));
-  return v;
-}
-// one k-step (two batch rows) of dW2 += dz2^T . h1 for the wave's 64 x 256 block: 16 MFMAs
-#define MF(acc, A, B) "v_mfma_f32_32x32x2_f32 " acc ", " A ", " B ", " acc "\n\t"
-__device__ __forceinline__ void dw2_kstep(float x0, float x1, float y0, float y1, float y2, float y3, float y4,
-                                          float y5, float y6, float y7) {
+#define MFA(t, x, y) "v_mfma_f32_32x32x2_f32 %" #t ", %" #x ", %" #y ", %" #t "\n\t"
+// one k-step (two batch rows) of dW2 += dz2^T . h1: 16 MFMAs; x = A operands (2 neuron blocks), y = B operands
+__device__ __forceinline__ void dw2_kstep(f32x16 (&g)[16], float x0, float x1, float y0, float y1, float y2,
+                                          float y3, float y4, float y5, float y6, float y7) {
   asm volatile(
-      "s_nop 1\n\t"
-      MF("a[0:15]", "%0", "%2")    MF("a[128:143]", "%1", "%2")
-      MF("a[16:31]", "%0", "%3")   MF("a[144:159]", "%1", "%3")
-      MF("a[32:47]", "%0", "%4")   MF("a[160:175]", "%1", "%4")
-      MF("a[48:63]", "%0", "%5")   MF("a[176:191]", "%1", "%5")
-      MF("a[64:79]", "%0", "%6")   MF("a[192:207]", "%1", "%6")
-      MF("a[80:95]", "%0", "%7")   MF("a[208:223]", "%1", "%7")
-      MF("a[96:111]", "%0", "%8")  MF("a[224:239]", "%1", "%8")
-      MF("a[112:127]", "%0", "%9") MF("a[240:255]", "%1", "%9")
+      "s_nop 1\n\t"  // VALU-written operand -> MFMA
+      MFA(0, 16, 18) MFA(8, 17, 18) MFA(1, 16, 19) MFA(9, 17, 19) MFA(2, 16, 20) MFA(10, 17, 20)
+      MFA(3, 16, 21) MFA(11, 17, 21) MFA(4, 16, 22) MFA(12, 17, 22) MFA(5, 16, 23) MFA(13, 17, 23)
+      MFA(6, 16, 24) MFA(14, 17, 24) MFA(7, 16, 25) MFA(15, 17, 25)
       "s_nop 1"
-      :
-      : "v"(x0), "v"(x1), "v"(y0), "v"(y1), "v"(y2), "v"(y3), "v"(y4), "v"(y5), "v"(y6), "v"(y7)
-      : ACC_CLOBBERS);
-}
-// store the 16 tiles to the slab (C layout); w2 already points at this lane's (4h, r) element of the wave block
-template <int T, int I>
-__device__ __forceinline__ void acc_store_tile(float* w2) {
-  if constexpr (I < 16) {
-    constexpr int ib = T / 8, jb = T % 8;
-    w2[(32 * ib + crc(I)) * FH + 32 * jb] = acc_read<T * 16 + I>();
-    acc_store_tile<T, I + 1>(w2);
-  }
-}
-template <int T>
-__device__ __forceinline__ void acc_store_all(float* w2) {
-  if constexpr (T < 16) {
-    acc_store_tile<T, 0>(w2);
-    __builtin_amdgcn_sched_barrier(0);  // keep at most one tile (16 registers) of read-backs live
-    acc_store_all<T + 1>(w2);
-  }
+      : "+a"(g[0]), "+a"(g[1]), "+a"(g[2]), "+a"(g[3]), "+a"(g[4]), "+a"(g[5]), "+a"(g[6]), "+a"(g[7]), "+a"(g[8]),
+        "+a"(g[9]), "+a"(g[10]), "+a"(g[11]), "+a"(g[12]), "+a"(g[13]), "+a"(g[14]), "+a"(g[15])
+      : "v"(x0), "v"(x1), "v"(y0), "v"(y1), "v"(y2), "v"(y3), "v"(y4), "v"(y5), "v"(y6), "v"(y7));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -300,7 +256,9 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
 
   // dW2 lives in the 256 accumulator registers for the whole kernel; dW1 / dW3 are small and are accumulated
   // per tile into the workgroup's private slab (read-modify-write by the owning lane, L2 resident).
-  acc_zero_range<0>();
+  f32x16 gW2[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) gW2[t] = zero16();
   float* slab = a.slabs + (size_t)blockIdx.x * a.slab_floats;
   float* slab_w1 = slab + slab_off_w1();
   float* slab_w3 = slab + slab_off_w3(DP);
@@ -430,7 +388,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
 #pragma unroll 2
       for (int k = 0; k < FR; k += 2) {
         const float* bk = &lds[bo + k * FLDH];
-        dw2_kstep(lds[ao + k * FLDH], lds[ao + k * FLDH + 32], bk[0], bk[32], bk[64], bk[96], bk[128], bk[160], bk[192],
+        dw2_kstep(gW2, lds[ao + k * FLDH], lds[ao + k * FLDH + 32], bk[0], bk[32], bk[64], bk[96], bk[128], bk[160], bk[192],
                   bk[224]);
       }
     }
@@ -485,8 +443,14 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
 
   // ---- store this workgroup's partial gradients to its slab ----
   {
-    asm volatile("s_nop 15\n\ts_nop 3");  // last MFMA's D -> v_accvgpr_read (16-pass XDL)
-    acc_store_all<0>(slab + slab_off_w2() + (64 * wave + 4 * h) * FH + r);
+    asm volatile("s_nop 15\n\ts_nop 3");  // last asm MFMA's D -> v_accvgpr_read (16-pass XDL)
+    float* w2 = slab + slab_off_w2() + (64 * wave + 4 * h) * FH + r;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) w2[(32 * (t / 8) + crc(i)) * FH + 32 * (t % 8)] = gW2[t][i];
+      __builtin_amdgcn_sched_barrier(0);  // keep at most one tile of read-backs live
+    }
     const float b2a = gb2a + __shfl_xor(gb2a, 32, 64), b2b = gb2b + __shfl_xor(gb2b, 32, 64);
     const float b1a = gb1a + __shfl_xor(gb1a, 32, 64), b1b = gb1b + __shfl_xor(gb1b, 32, 64);
     if (h == 0) {
