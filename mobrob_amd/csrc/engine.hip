@@ -299,6 +299,7 @@ int fused_init(mobrob_ppo_engine* e) {
   f.slab_floats = slab_size(e->Dp);
   f.max_grid = 256;
   CHK(dalloc(e, &f.slabs, (size_t)f.max_grid * f.slab_floats));
+  CHK(dalloc(e, &f.stamps, 32));
   f.lds_bytes = fused_lds_bytes(e->Dp);
   HIPC(fused_set_lds_attr(f));
   return MOBROB_OK;
@@ -314,6 +315,7 @@ void fused_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, float 
   a.advstat = e->advstat + 4 * (size_t)mb; a.normalize = e->cfg.normalize_advantage;
   a.clip = (float)e->cfg.clip_range; a.vf_coef = (float)e->cfg.vf_coef; a.ent_coef = (float)e->cfg.ent_coef;
   a.inv_bg = inv_bg; a.slabs = f.slabs; a.slab_floats = f.slab_floats; a.sums = e->grads + e->P;
+  a.stamps = f.stamps;
   const int ntiles = cdiv(B, FR);
   const int grid = 2 * std::min(f.max_grid / 2, ntiles);
   (void)hipMemsetAsync(e->grads + e->P, 0, 8 * sizeof(float), e->stream);
@@ -882,5 +884,15 @@ int mobrob_ppo_profile_read(mobrob_ppo_engine_t* e, double* ms, int64_t* calls) 
   }
   return MOBROB_OK;
 }
+
+#ifdef MOBROB_STAMPS
+// diagnostic build only (not part of include/mobrob_ppo.h)
+int mobrob_dbg_read_stamps(mobrob_ppo_engine_t* e, unsigned long long* out32, int reset) {
+  HIPC(hipStreamSynchronize(e->stream));
+  HIPC(hipMemcpy(out32, e->fused.stamps, 32 * 8, hipMemcpyDeviceToHost));
+  if (reset) HIPC(hipMemset(e->fused.stamps, 0, 32 * 8));
+  return 0;
+}
+#endif
 
 }  // extern "C"

@@ -47,12 +47,27 @@ struct FusedTrainArgs {
   float* slabs;                  // [gridDim.x][slab_floats]
   int slab_floats;
   float* sums;                   // [8] loss statistics (float atomics; diagnostics only)
+  unsigned long long* stamps;    // diagnostic build only (MOBROB_STAMPS): per-phase cycle sums
 };
 
-// slab layout (floats): dW2 [H][H] | dW1 [H][Dp] | dW3 [32][H] | db2 [H] | db1 [H] | db3 [32] | dls [32]
+// slab layout (floats): dW2 [H][H] | dW1 [H][64] | dW3 [32][H] | db2 [H] | db1 [H] | db3 [32] | dls [32]
+// The three weight regions are stored in MFMA *fragment order* (the slab is private scratch, only k_slab_reduce
+// reads it): wave w, 32x32 tile t, accumulator register i, lane l  ->  ((w*NT + t)*4 + i/4)*256 + l*4 + i%4,
+// so that every lane moves its 16 registers of a tile with four coalesced 16-byte accesses.
+//   dW2: NT = 16, t = ib*8 + jb   (neuron block ib of the wave's 64, input block jb of 8)
+//   dW1: NT = 4,  t = ib*2 + jb   (input block jb of 2; columns >= Dp hold junk and are never read)
+//   dW3: NT = 2,  t = jb          (rows = 32 head outputs, columns 64w + 32jb + r)
+__host__ __device__ inline int frag_off(int w, int nt, int t, int i, int lane) {
+  return ((w * nt + t) * 4 + (i >> 2)) * 256 + lane * 4 + (i & 3);
+}
+// inverse C-layout map: row within a 32x32 tile -> (accumulator register i, lane half h)
+__host__ __device__ inline void row_to_ih(int row, int* i, int* h) {
+  *h = (row >> 2) & 1;
+  *i = (row & 3) + 4 * (row >> 3);
+}
 __host__ __device__ inline int slab_off_w2() { return 0; }
 __host__ __device__ inline int slab_off_w1() { return FH * FH; }
-__host__ __device__ inline int slab_off_w3(int Dp) { return FH * FH + FH * Dp; }
+__host__ __device__ inline int slab_off_w3(int) { return FH * FH + FH * 64; }
 __host__ __device__ inline int slab_off_b2(int Dp) { return slab_off_w3(Dp) + 32 * FH; }
 __host__ __device__ inline int slab_off_b1(int Dp) { return slab_off_b2(Dp) + FH; }
 __host__ __device__ inline int slab_off_b3(int Dp) { return slab_off_b1(Dp) + FH; }
@@ -84,41 +99,67 @@ __device__ __forceinline__ int opaque(int x) {
   asm volatile("" : "+v"(x));
   return x;
 }
+// Global accesses as "uniform base (SGPR pair) + 32-bit unsigned byte offset (one VGPR)": keeps per-lane 64-bit
+// pointers (two VGPRs each, hoisted out of the tile loop and spilled) out of the register file.
+__device__ __forceinline__ unsigned opaque_u(unsigned x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+__device__ __forceinline__ f32x4 ldg16(const void* base, unsigned byte_off) {
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void stg16(void* base, unsigned byte_off, const f32x4& v) {
+  *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
 // C layout: element i of a 32x32 accumulator sits at row crc(i) + 4*h, column r of the tile
 __device__ __forceinline__ constexpr int crc(int i) { return (i & 3) + 8 * (i >> 2); }
 
 // acc[cb][rb] += A[rb*32 + 0..31][0..8*nkg) . Bpacked[cb]  for this wave's two 32-column blocks.
 // a_off: LDS offset of the A tile (row stride lda floats); Bp0/Bp1: packed fragments [nkg][64] of the two blocks.
 // B fragments are prefetched two k-groups ahead (global/L2 latency); A fragments one k-group ahead (LDS).
+#define MFMA_KG(u, v, p, q)                     \
+  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) { \
+    c00 = MFMA32(u[s_], p[s_], c00);            \
+    c01 = MFMA32(v[s_], p[s_], c01);            \
+    c10 = MFMA32(u[s_], q[s_], c10);            \
+    c11 = MFMA32(v[s_], q[s_], c11);            \
+  }
+// nkg must be even.  The k-group loop is unrolled by two with ping-pong operand buffers (no register rotation:
+// a rotation makes the compiler copy -- and therefore wait for -- loads that were only just issued).
 template <int LDA>
 __device__ __forceinline__ void gemm_lds_packed(int a_off, const f32x4* __restrict__ Bp0,
                                                 const f32x4* __restrict__ Bp1, int nkg, f32x16& c00, f32x16& c01,
                                                 f32x16& c10, f32x16& c11, int lane) {
   const int r = lane & 31, h = lane >> 5;
   const int ab = opaque(a_off + r * LDA + 4 * h);
-  Bp0 += lane;
-  Bp1 += lane;
-  f32x4 b0 = Bp0[0], b1 = Bp1[0];
-  f32x4 b0n = nkg > 1 ? Bp0[64] : b0, b1n = nkg > 1 ? Bp1[64] : b1;
-  f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[ab]);
-  f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA]);
-#pragma unroll 2
-  for (int kg = 0; kg < nkg; ++kg) {
-    const f32x4 p = b0, q = b1, u = a0, v = a1;
-    b0 = b0n; b1 = b1n;
-    if (kg + 2 < nkg) { b0n = Bp0[(kg + 2) * 64]; b1n = Bp1[(kg + 2) * 64]; }
-    if (kg + 1 < nkg) {
-      a0 = *reinterpret_cast<const f32x4*>(&lds[ab + (kg + 1) * 8]);
-      a1 = *reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA + (kg + 1) * 8]);
-    }
-#pragma unroll
-    for (int s_ = 0; s_ < 4; ++s_) {
-      c00 = MFMA32(u[s_], p[s_], c00);
-      c01 = MFMA32(v[s_], p[s_], c01);
-      c10 = MFMA32(u[s_], q[s_], c10);
-      c11 = MFMA32(v[s_], q[s_], c11);
-    }
+  unsigned bo = opaque_u((unsigned)lane * 16u);  // byte offset of this lane's fragment; +1024 per k-group
+  f32x4 pA = ldg16(Bp0, bo), qA = ldg16(Bp1, bo), pB, qB;
+  f32x4 uA = *reinterpret_cast<const f32x4*>(&lds[ab]);
+  f32x4 vA = *reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA]);
+  f32x4 uB, vB;
+  int ao = ab;
+  // branch-free steady state (exact counted waits), last pair peeled
+#pragma unroll 1
+  for (int kg = 0; kg < nkg - 2; kg += 2) {
+    pB = ldg16(Bp0, bo + 1024u);
+    qB = ldg16(Bp1, bo + 1024u);
+    uB = *reinterpret_cast<const f32x4*>(&lds[ao + 8]);
+    vB = *reinterpret_cast<const f32x4*>(&lds[ao + 32 * LDA + 8]);
+    MFMA_KG(uA, vA, pA, qA)
+    pA = ldg16(Bp0, bo + 2048u);
+    qA = ldg16(Bp1, bo + 2048u);
+    uA = *reinterpret_cast<const f32x4*>(&lds[ao + 16]);
+    vA = *reinterpret_cast<const f32x4*>(&lds[ao + 32 * LDA + 16]);
+    MFMA_KG(uB, vB, pB, qB)
+    bo += 2048u;
+    ao += 16;
   }
+  pB = ldg16(Bp0, bo + 1024u);
+  qB = ldg16(Bp1, bo + 1024u);
+  uB = *reinterpret_cast<const f32x4*>(&lds[ao + 8]);
+  vB = *reinterpret_cast<const f32x4*>(&lds[ao + 32 * LDA + 8]);
+  MFMA_KG(uA, vA, pA, qA)
+  MFMA_KG(uB, vB, pB, qB)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -161,19 +202,32 @@ __device__ __forceinline__ void store_tanh(int dst_off, const float* __restrict_
     lds[o + (32 + crc(i)) * FLDH + 32] = fast_tanh(c11[i] + bz1);
   }
 }
-// lds[hs][row][col] <- acc * (1 - hs^2) in place; accumulates the column sums (both lane halves hold partials)
+// lds[hs][row][col] <- acc * (1 - hs^2) in place
 __device__ __forceinline__ void dtanh_inplace(int hs_off, int wave, int lane, const f32x16& c00, const f32x16& c01,
-                                              const f32x16& c10, const f32x16& c11, float& cs0, float& cs1) {
+                                              const f32x16& c10, const f32x16& c11) {
   const int r = lane & 31, h = lane >> 5;
   const int o = opaque(hs_off + 4 * h * FLDH + 64 * wave + r);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    float hv, z;
-    hv = lds[o + crc(i) * FLDH];             z = c00[i] * (1.0f - hv * hv); lds[o + crc(i) * FLDH] = z;             cs0 += z;
-    hv = lds[o + (32 + crc(i)) * FLDH];      z = c01[i] * (1.0f - hv * hv); lds[o + (32 + crc(i)) * FLDH] = z;      cs0 += z;
-    hv = lds[o + crc(i) * FLDH + 32];        z = c10[i] * (1.0f - hv * hv); lds[o + crc(i) * FLDH + 32] = z;        cs1 += z;
-    hv = lds[o + (32 + crc(i)) * FLDH + 32]; z = c11[i] * (1.0f - hv * hv); lds[o + (32 + crc(i)) * FLDH + 32] = z; cs1 += z;
+    float hv;
+    hv = lds[o + crc(i) * FLDH];             lds[o + crc(i) * FLDH] = c00[i] * (1.0f - hv * hv);
+    hv = lds[o + (32 + crc(i)) * FLDH];      lds[o + (32 + crc(i)) * FLDH] = c01[i] * (1.0f - hv * hv);
+    hv = lds[o + crc(i) * FLDH + 32];        lds[o + crc(i) * FLDH + 32] = c10[i] * (1.0f - hv * hv);
+    hv = lds[o + (32 + crc(i)) * FLDH + 32]; lds[o + (32 + crc(i)) * FLDH + 32] = c11[i] * (1.0f - hv * hv);
   }
+}
+// sum of column `tid` of a [64][FLDH] LDS tile over its 64 rows, fixed order (bias gradients)
+__device__ __forceinline__ float column_sum(int hs_off, int tid) {
+  const int o = opaque(hs_off + tid);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 2
+  for (int rr = 0; rr < FR; rr += 4) {
+    s0 += lds[o + rr * FLDH];
+    s1 += lds[o + (rr + 1) * FLDH];
+    s2 += lds[o + (rr + 2) * FLDH];
+    s3 += lds[o + (rr + 3) * FLDH];
+  }
+  return (s0 + s1) + (s2 + s3);
 }
 
 // LDS carve-up (float offsets) for a given padded observation width
@@ -184,15 +238,43 @@ struct Lay {
   static constexpr int H1 = X + FR * LDX;
   static constexpr int H2 = H1 + FR * FLDH;
   static constexpr int DO = H2 + FR * FLDH;
-  static constexpr int END = DO + FR * FLDO;
+  static constexpr int CST = DO + FR * FLDO;  // [3][32]: 1/var, log(sd)+log(sqrt(2pi)), head bias
+  static constexpr int GACC = CST + 96;       // [4 waves][2][32]: per-wave head-bias / log_std gradient sums
+  static constexpr int END = GACC + 256;
 };
+
+// ------------------------------------------------------------------------------------------------
+// Diagnostic build (-DMOBROB_STAMPS): s_memtime stamps at phase boundaries, summed over waves into
+// a.stamps[phase] (cdna_hip_programming.md §7 'In-kernel stamps').  Never compiled into the product library.
+// ------------------------------------------------------------------------------------------------
+#ifdef MOBROB_STAMPS
+#define STAMP(id)                                                                                  \
+  {                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    unsigned long long t_;                                                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    if (lane == 0) atomicAdd(&stamps_[id], t_ - tprev_);                                          \
+    tprev_ = t_;                                                                                   \
+  }
+#define STAMP_INIT()                                                                               \
+  unsigned long long tprev_;                                                                       \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev_)::"memory");
+#define STAMP_PARAMS , unsigned long long *stamps_, unsigned long long &tprev_
+#define STAMP_ARGS , stamps_, tprev_
+#else
+#define STAMP(id)
+#define STAMP_INIT()
+#define STAMP_PARAMS
+#define STAMP_ARGS
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // forward of one 64-row tile through one network; leaves h1, h2 in LDS and the raw head tile
 // (without bias) in the head tile [64][FLDO].  All 4 waves participate; ends with a barrier.
 // ------------------------------------------------------------------------------------------------
 template <int DP>
-__device__ __forceinline__ void tile_forward(const FusedNet& W, int wave, int lane) {
+__device__ __forceinline__ void tile_forward(const FusedNet& W, int wave, int lane STAMP_PARAMS) {
   using L = Lay<DP>;
   const int r = lane & 31, h = lane >> 5;
   {  // layer 1: K = DP
@@ -200,31 +282,55 @@ __device__ __forceinline__ void tile_forward(const FusedNet& W, int wave, int la
     constexpr int nkg = DP / 8;
     gemm_lds_packed<L::LDX>(L::X, W.W1f + (size_t)(2 * wave) * nkg * 64, W.W1f + (size_t)(2 * wave + 1) * nkg * 64,
                             nkg, c00, c01, c10, c11, lane);
+    STAMP(1)
     store_tanh(L::H1, W.b1, wave, lane, c00, c01, c10, c11);
+    STAMP(2)
   }
   __syncthreads();
+  STAMP(3)
   {  // layer 2: K = H
     f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
     constexpr int nkg = FH / 8;
     gemm_lds_packed<FLDH>(L::H1, W.W2f + (size_t)(2 * wave) * nkg * 64, W.W2f + (size_t)(2 * wave + 1) * nkg * 64, nkg,
                           c00, c01, c10, c11, lane);
+    STAMP(4)
     store_tanh(L::H2, W.b2, wave, lane, c00, c01, c10, c11);
+    STAMP(5)
   }
   __syncthreads();
+  STAMP(6)
   {  // head: [64 x 32] = h2 . W3^T, K split in two halves; wave = (khalf << 1) | rowblock
     const int rb = wave & 1, ks = wave >> 1;
-    f32x16 acc = zero16();
+    f32x16 acc = zero16(), acc2 = zero16();  // two independent chains (even / odd k-groups)
     const int ab = opaque(L::H2 + (rb * 32 + r) * FLDH + ks * 128 + 4 * h);
-    const f32x4* bp = W.W3f + (size_t)(ks * 16) * 64 + lane;
-#pragma unroll 4
-    for (int kg = 0; kg < 16; ++kg) {
-      const f32x4 b = bp[kg * 64];
-      const f32x4 a = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8]);
-      acc = MFMA32(a[0], b[0], acc);
-      acc = MFMA32(a[1], b[1], acc);
-      acc = MFMA32(a[2], b[2], acc);
-      acc = MFMA32(a[3], b[3], acc);
+    const f32x4* bp = W.W3f + (size_t)(ks * 16) * 64;
+    unsigned bo = opaque_u((unsigned)lane * 16u);
+    f32x4 bA = ldg16(bp, bo), bB = ldg16(bp, bo + 1024u);
+    f32x4 aA = *reinterpret_cast<const f32x4*>(&lds[ab]), aB = *reinterpret_cast<const f32x4*>(&lds[ab + 8]);
+    int ao = ab;
+#pragma unroll 1
+    for (int kg = 0; kg < 14; kg += 2) {
+      const f32x4 b0 = bA, b1 = bB, a0 = aA, a1 = aB;
+      bA = ldg16(bp, bo + 2048u);
+      bB = ldg16(bp, bo + 3072u);
+      aA = *reinterpret_cast<const f32x4*>(&lds[ao + 16]);
+      aB = *reinterpret_cast<const f32x4*>(&lds[ao + 24]);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        acc = MFMA32(a0[s_], b0[s_], acc);
+        acc2 = MFMA32(a1[s_], b1[s_], acc2);
+      }
+      bo += 2048u;
+      ao += 16;
     }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      acc = MFMA32(aA[s_], bA[s_], acc);
+      acc2 = MFMA32(aB[s_], bB[s_], acc2);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
+    STAMP(7)
     // deterministic cross-wave reduction through the head tile: one K-half per round
     const int o = opaque(L::DO + (rb * 32 + 4 * h) * FLDO + r);
 #pragma unroll
@@ -248,7 +354,8 @@ template <int DP>
 __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   using L = Lay<DP>;
   constexpr int ldx = L::LDX, per = DP / 4;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> SGPR addressing of weights/slabs
   const int r = lane & 31, h = lane >> 5;
   const int net = blockIdx.x & 1, wg = blockIdx.x >> 1, nwg = gridDim.x >> 1;
   const FusedNet W = a.net[net];
@@ -263,9 +370,23 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   float* slab_w1 = slab + slab_off_w1();
   float* slab_w3 = slab + slab_off_w3(DP);
   bool first = true;
-  float gb2a = 0.f, gb2b = 0.f, gb1a = 0.f, gb1b = 0.f;  // bias-gradient partials for cols 64w+r, 64w+32+r
-  float gb3 = 0.f, gls = 0.f;                            // wave 0, lane < head
-  float s_pl = 0.f, s_vl = 0.f, s_kl = 0.f, s_cf = 0.f;  // wave 0 loss statistics
+  float gb2 = 0.f, gb1 = 0.f;  // bias gradients of hidden column `tid`
+  float s_pl = 0.f, s_vl = 0.f, s_kl = 0.f, s_cf = 0.f;  // loss statistics (lanes with q == 0)
+  // per-action constants of the Gaussian head and the per-wave head-gradient accumulators
+  if (tid < 32) {
+    const int k = tid;
+    float iv = 0.f, lc = 0.f, bb = 0.f;
+    if (net == 0 && k < a.A) {
+      const float sd = expf(a.log_std[k]);
+      iv = 1.0f / (sd * sd);
+      lc = logf(sd) + 0.91893853320467274178f;
+    }
+    if (k < W.head) bb = W.b3[k];
+    lds[L::CST + k] = iv;
+    lds[L::CST + 32 + k] = lc;
+    lds[L::CST + 64 + k] = bb;
+  }
+  lds[L::GACC + tid] = 0.f;
 
   float adv_mean = 0.f, adv_sd = 1.f;
   bool adv_on = false;
@@ -279,6 +400,10 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     adv_sd = (float)sqrt(var);
   }
 
+#ifdef MOBROB_STAMPS
+  unsigned long long* stamps_ = a.stamps;
+#endif
+  STAMP_INIT()
   for (int tile = wg; tile < ntiles; tile += nwg) {
     const int row0 = tile * FR;
     // ---- gather the observation rows of this tile (zero rows beyond the minibatch) ----
@@ -287,74 +412,102 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
       const int rr = i / per, c = i - rr * per;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row0 + rr < a.count) {
-        const int src = a.rows[row0 + rr];
-        v = reinterpret_cast<const f32x4*>(a.obs)[(size_t)src * per + c];
+        const unsigned src = (unsigned)a.rows[row0 + rr];
+        v = ldg16(a.obs, src * (unsigned)(DP * 4) + (unsigned)(c * 16));
       }
       *reinterpret_cast<f32x4*>(&lds[L::X + rr * ldx + 4 * c]) = v;
     }
     __syncthreads();
-    tile_forward<DP>(W, wave, lane);
+    STAMP(0)
+    tile_forward<DP>(W, wave, lane STAMP_ARGS);
+    STAMP(8)
 
-    // ---- loss: one lane per row (wave 0); writes dL/d(head output) into the head tile, zero padded ----
-    if (wave == 0) {
-      const int rr = lane;
+    // ---- loss: 4 lanes per row (q = action residue mod 4), all waves; writes dL/d(head output) into the
+    //      head tile (zero padded) and accumulates the head-bias / log_std gradient sums per wave ----
+    {
+      const int rr = tid >> 2, q = tid & 3;
       const bool live = row0 + rr < a.count;
       const int src = live ? a.rows[row0 + rr] : 0;
-      float* drow = &lds[L::DO + rr * FLDO];
+      const int db = opaque(L::DO + rr * FLDO + q);  // head tile row, this lane's action residue
+      const int cb = opaque(L::CST + q);             // per-action constants: [0]=1/var [32]=log terms [64]=bias
+      const int gb = opaque(L::GACC + wave * 64 + q);
+      const int A = a.A;
       if (net == 0) {
+        float lp = 0.f;
+        float dk[8];
+        const unsigned aoff = ((unsigned)src * (unsigned)A + (unsigned)q) * 4u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float d = 0.f;
+          if (4 * j + q < A && live) {
+            d = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.actions) + (aoff + 16u * j)) -
+                (lds[db + 4 * j] + lds[cb + 64 + 4 * j]);
+            lp += -(d * d) * (0.5f * lds[cb + 4 * j]) - lds[cb + 32 + 4 * j];
+          }
+          dk[j] = d;
+        }
+        lp += __shfl_xor(lp, 1, 64);
+        lp += __shfl_xor(lp, 2, 64);
         float g_logp = 0.f;
         if (live) {
           float adv = a.adv[src];
           if (a.normalize && adv_on) adv = (adv - adv_mean) / (adv_sd + 1e-8f);
-          float lp = 0.f;
-          for (int k = 0; k < a.A; ++k) {
-            const float sd = expf(a.log_std[k]);
-            const float d = a.actions[(size_t)src * a.A + k] - (drow[k] + W.b3[k]);
-            lp += -(d * d) / (2.0f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
-          }
           const float log_ratio = lp - a.old_logp[src];
           const float ratio = expf(log_ratio);
           const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
           const float s1 = adv * ratio, s2 = adv * fminf(fmaxf(ratio, lo), hi);
-          s_pl += fminf(s1, s2);
-          s_cf += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
-          s_kl += (ratio - 1.0f) - log_ratio;
+          if (q == 0) {
+            s_pl += fminf(s1, s2);
+            s_cf += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
+            s_kl += (ratio - 1.0f) - log_ratio;
+          }
           const float in_range = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
           const float w1 = (s1 < s2) ? 1.f : ((s1 > s2) ? 0.f : 0.5f);
           g_logp = -(w1 * adv + (1.0f - w1) * adv * in_range) * a.inv_bg * ratio;
         }
-        for (int k = 0; k < 32; ++k) {
-          float gm = 0.f, gl = 0.f;
-          if (k < a.A && live) {
-            const float sd = expf(a.log_std[k]);
-            const float var = sd * sd;
-            const float d = a.actions[(size_t)src * a.A + k] - (drow[k] + W.b3[k]);
-            gm = g_logp * d / var;
-            gl = g_logp * (d * d / var - 1.0f);
-          }
-          drow[k] = gm;
-          if (k < a.A) {  // wave-uniform
-            const float t1 = wave_sum(gm), t2 = wave_sum(gl);
-            if (lane == k) { gb3 += t1; gls += t2; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float iv = lds[cb + 4 * j];
+          float gm = g_logp * dk[j] * iv;  // zero for k >= A (dk = 0, iv = 0)
+          float gl = (4 * j + q < A) ? g_logp * (dk[j] * dk[j] * iv - 1.0f) : 0.f;
+          lds[db + 4 * j] = gm;
+          if (4 * j < A) {  // wave-uniform: sum over the 16 rows of this wave (lanes with equal q)
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) {
+              gm += __shfl_xor(gm, o, 64);
+              gl += __shfl_xor(gl, o, 64);
+            }
+            if (lane < 4) {
+              lds[gb + 4 * j] += gm;
+              lds[gb + 32 + 4 * j] += gl;
+            }
           }
         }
       } else {
         float dv = 0.f;
-        if (live) {
-          const float v = drow[0] + W.b3[0], rt = a.ret[src];
+        if (live && q == 0) {
+          const float v = lds[db] + lds[cb + 64], rt = a.ret[src];
           s_vl += (rt - v) * (rt - v);
           dv = a.vf_coef * 2.0f * (v - rt) * a.inv_bg;
         }
-        drow[0] = dv;
-        for (int k = 1; k < 32; ++k) drow[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lds[db + 4 * j] = (j == 0) ? dv : 0.f;  // q != 0 lanes hold dv = 0
         const float t = wave_sum(dv);
-        if (lane == 0) gb3 += t;
+        if (lane == 0) lds[gb] += t;
       }
     }
     __syncthreads();
+    STAMP(9)
 
     // ---- dW3 (+)= dout^T . h2  (M = 32 head rows, this wave's 64 columns, K = 64 rows) ----
     {
+      const unsigned s3 = opaque_u((unsigned)(wave * 2 * 4 * 64 + lane) * 16u);  // [w][jb][quad][lane] x 16 B
+      f32x4 o0[4], o1[4];  // running slab values, fetched while the MFMAs run
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        o0[qd] = ldg16(slab_w3, s3 + qd * 1024u);
+        o1[qd] = ldg16(slab_w3, s3 + (4 + qd) * 1024u);
+      }
       f32x16 t0 = zero16(), t1 = zero16();
       const int ao = opaque(L::DO + h * FLDO + r);              // A[i=a][k=row] = dout[row][a]
       const int bo = opaque(L::H2 + h * FLDH + 64 * wave + r);  // B[k=row][j]  = h2[row][j]
@@ -364,24 +517,34 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
         t0 = MFMA32(x, lds[bo + k * FLDH], t0);
         t1 = MFMA32(x, lds[bo + k * FLDH + 32], t1);
       }
-      const int so = opaque(4 * h * FH + 64 * wave + r);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float* p = slab_w3 + so + crc(i) * FH;
-        p[0] = first ? t0[i] : p[0] + t0[i];
-        p[32] = first ? t1[i] : p[32] + t1[i];
+      for (int qd = 0; qd < 4; ++qd) {
+        f32x4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v0[e] = (first ? 0.f : o0[qd][e]) + t0[4 * qd + e];
+          v1[e] = (first ? 0.f : o1[qd][e]) + t1[4 * qd + e];
+        }
+        stg16(slab_w3, s3 + qd * 1024u, v0);
+        stg16(slab_w3, s3 + (4 + qd) * 1024u, v1);
       }
     }
+    STAMP(10)
     // ---- dh2 = dout . W3 (K = 32), then dz2 = dh2 * (1 - h2^2) in place ----
     {
       f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
       gemm_lds_packed<FLDO>(L::DO, W.W3b + (size_t)(2 * wave) * 4 * 64, W.W3b + (size_t)(2 * wave + 1) * 4 * 64, 4, c00,
                             c01, c10, c11, lane);
+      STAMP(11)
       __syncthreads();  // every wave is done reading h2 (dW3) before it is overwritten
-      dtanh_inplace(L::H2, wave, lane, c00, c01, c10, c11, gb2a, gb2b);
+      STAMP(12)
+      dtanh_inplace(L::H2, wave, lane, c00, c01, c10, c11);
+      STAMP(13)
     }
     __syncthreads();
+    STAMP(14)
     // ---- dW2 += dz2^T . h1  (this wave: 64 neurons x 256 inputs, K = 64 rows) ----
+    gb2 += column_sum(L::H2, tid);
     {
       const int ao = opaque(L::H2 + h * FLDH + 64 * wave + r);
       const int bo = opaque(L::H1 + h * FLDH + r);
@@ -392,21 +555,38 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
                   bk[224]);
       }
     }
+    STAMP(15)
     // ---- dh1 = dz2 . W2 (K = 256), then dz1 = dh1 * (1 - h1^2) in place ----
     {
       f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
       constexpr int nkg = FH / 8;
       gemm_lds_packed<FLDH>(L::H2, W.W2b + (size_t)(2 * wave) * nkg * 64, W.W2b + (size_t)(2 * wave + 1) * nkg * 64, nkg,
                             c00, c01, c10, c11, lane);
+      STAMP(16)
       __syncthreads();  // dW2 reads of h1 complete everywhere
-      dtanh_inplace(L::H1, wave, lane, c00, c01, c10, c11, gb1a, gb1b);
+      STAMP(17)
+      dtanh_inplace(L::H1, wave, lane, c00, c01, c10, c11);
+      STAMP(18)
     }
     __syncthreads();
+    STAMP(19)
     // ---- dW1 (+)= dz1^T . X  (this wave: 64 neurons x DP inputs, K = 64 rows) ----
+    gb1 += column_sum(L::H1, tid);
     {
+      constexpr bool two = DP > 32;
+      const unsigned s1 = opaque_u((unsigned)(wave * 4 * 4 * 64 + lane) * 16u);  // [w][ib*2+jb][quad][lane] x 16 B
+      f32x4 o00[4], o10[4], o01[4], o11[4];  // running slab values, fetched while the MFMAs run
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        o00[qd] = ldg16(slab_w1, s1 + (0 * 4 + qd) * 1024u);
+        o10[qd] = ldg16(slab_w1, s1 + (2 * 4 + qd) * 1024u);
+        if (two) {
+          o01[qd] = ldg16(slab_w1, s1 + (1 * 4 + qd) * 1024u);
+          o11[qd] = ldg16(slab_w1, s1 + (3 * 4 + qd) * 1024u);
+        }
+      }
       f32x16 t00 = zero16(), t10 = zero16(), t01 = zero16(), t11 = zero16();
       const int ao = opaque(L::H1 + h * FLDH + 64 * wave + r);
-      constexpr bool two = DP > 32;
       const int c0 = (r < DP) ? r : 0;
       const int c1 = (32 + r < DP) ? 32 + r : c0;  // clamped columns are never stored
       const int b0o = opaque(L::X + h * ldx + c0), b1o = opaque(L::X + h * ldx + c1);
@@ -422,49 +602,63 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
           t11 = MFMA32(x1, y1, t11);
         }
       }
-      const int so = opaque((64 * wave + 4 * h) * DP + r);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float* p0 = slab_w1 + so + crc(i) * DP;
-        float* p1 = p0 + 32 * DP;
-        if (r < DP) {
-          p0[0] = first ? t00[i] : p0[0] + t00[i];
-          p1[0] = first ? t10[i] : p1[0] + t10[i];
+      for (int qd = 0; qd < 4; ++qd) {
+        f32x4 v00, v10, v01, v11;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v00[e] = (first ? 0.f : o00[qd][e]) + t00[4 * qd + e];
+          v10[e] = (first ? 0.f : o10[qd][e]) + t10[4 * qd + e];
+          if (two) {
+            v01[e] = (first ? 0.f : o01[qd][e]) + t01[4 * qd + e];
+            v11[e] = (first ? 0.f : o11[qd][e]) + t11[4 * qd + e];
+          }
         }
-        if (two && 32 + r < DP) {
-          p0[32] = first ? t01[i] : p0[32] + t01[i];
-          p1[32] = first ? t11[i] : p1[32] + t11[i];
+        stg16(slab_w1, s1 + (0 * 4 + qd) * 1024u, v00);
+        stg16(slab_w1, s1 + (2 * 4 + qd) * 1024u, v10);
+        if (two) {
+          stg16(slab_w1, s1 + (1 * 4 + qd) * 1024u, v01);
+          stg16(slab_w1, s1 + (3 * 4 + qd) * 1024u, v11);
         }
       }
     }
     first = false;
+    STAMP(20)
     __syncthreads();  // X / h1 / h2 are rewritten by the next tile
+    STAMP(21)
   }
 
   // ---- store this workgroup's partial gradients to its slab ----
+  STAMP(22)
   {
     asm volatile("s_nop 15\n\ts_nop 3");  // last asm MFMA's D -> v_accvgpr_read (16-pass XDL)
-    float* w2 = slab + slab_off_w2() + (64 * wave + 4 * h) * FH + r;
+    float* w2base = slab + slab_off_w2();
+    const unsigned s2 = (unsigned)(wave * 16 * 4 * 64 + lane) * 16u;  // [w][t][quad][lane] x 16 B
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) w2[(32 * (t / 8) + crc(i)) * FH + 32 * (t % 8)] = gW2[t][i];
+      for (int qd = 0; qd < 4; ++qd) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gW2[t][4 * qd + e];
+        stg16(w2base, s2 + (unsigned)(t * 4 + qd) * 1024u, v);
+      }
       __builtin_amdgcn_sched_barrier(0);  // keep at most one tile of read-backs live
     }
-    const float b2a = gb2a + __shfl_xor(gb2a, 32, 64), b2b = gb2b + __shfl_xor(gb2b, 32, 64);
-    const float b1a = gb1a + __shfl_xor(gb1a, 32, 64), b1b = gb1b + __shfl_xor(gb1b, 32, 64);
-    if (h == 0) {
-      slab[slab_off_b2(DP) + 64 * wave + r] = b2a;
-      slab[slab_off_b2(DP) + 64 * wave + 32 + r] = b2b;
-      slab[slab_off_b1(DP) + 64 * wave + r] = b1a;
-      slab[slab_off_b1(DP) + 64 * wave + 32 + r] = b1b;
-    }
-    if (wave == 0 && lane < 32) {
-      slab[slab_off_b3(DP) + lane] = gb3;
-      slab[slab_off_ls(DP) + lane] = gls;
+    slab[slab_off_b2(DP) + tid] = gb2;
+    slab[slab_off_b1(DP) + tid] = gb1;
+    if (tid < 32) {  // fixed-order sum of the four per-wave partials (the loop-end barrier made them visible)
+      float b3s = 0.f, lss = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        b3s += lds[L::GACC + w * 64 + tid];
+        lss += lds[L::GACC + w * 64 + 32 + tid];
+      }
+      slab[slab_off_b3(DP) + tid] = b3s;
+      slab[slab_off_ls(DP) + tid] = lss;
     }
   }
-  if (wave == 0) {
+  {
     const float t0 = wave_sum(s_pl), t1 = wave_sum(s_vl), t2 = wave_sum(s_kl), t3 = wave_sum(s_cf);
     if (lane == 0) {
       if (net == 0) {
@@ -501,19 +695,34 @@ __global__ __launch_bounds__(256) void k_slab_reduce(SlabReduceArgs s) {
   for (int k = 1; k < 13; ++k) t += (i >= s.offs[k]) ? 1 : 0;
   const int e = i - s.offs[t];
   int net, off;
+  auto w2_off = [&](int n, int j) {  // dW2[n][j]
+    int i, h;
+    row_to_ih(n & 31, &i, &h);
+    return slab_off_w2() + frag_off(n >> 6, 16, ((n >> 5) & 1) * 8 + (j >> 5), i, (j & 31) + 32 * h);
+  };
+  auto w1_off = [&](int n, int j) {  // dW1[n][j], j < D
+    int i, h;
+    row_to_ih(n & 31, &i, &h);
+    return slab_off_w1() + frag_off(n >> 6, 4, ((n >> 5) & 1) * 2 + (j >> 5), i, (j & 31) + 32 * h);
+  };
+  auto w3_off = [&](int a_, int j) {  // dW3[a][j]
+    int i, h;
+    row_to_ih(a_, &i, &h);
+    return slab_off_w3(s.Dp) + frag_off(j >> 6, 2, (j >> 5) & 1, i, (j & 31) + 32 * h);
+  };
   switch (t) {
-    case 0: net = 0; off = slab_off_ls(s.Dp) + e; break;                                   // log_std
-    case 1: net = 0; off = slab_off_w1() + (e / s.D) * s.Dp + (e % s.D); break;            // pi W1 [H][D]
+    case 0: net = 0; off = slab_off_ls(s.Dp) + e; break;           // log_std
+    case 1: net = 0; off = w1_off(e / s.D, e % s.D); break;        // pi W1 [H][D]
     case 2: net = 0; off = slab_off_b1(s.Dp) + e; break;
-    case 3: net = 0; off = slab_off_w2() + e; break;
+    case 3: net = 0; off = w2_off(e / FH, e % FH); break;
     case 4: net = 0; off = slab_off_b2(s.Dp) + e; break;
-    case 5: net = 1; off = slab_off_w1() + (e / s.D) * s.Dp + (e % s.D); break;            // vf W1
+    case 5: net = 1; off = w1_off(e / s.D, e % s.D); break;        // vf W1
     case 6: net = 1; off = slab_off_b1(s.Dp) + e; break;
-    case 7: net = 1; off = slab_off_w2() + e; break;
+    case 7: net = 1; off = w2_off(e / FH, e % FH); break;
     case 8: net = 1; off = slab_off_b2(s.Dp) + e; break;
-    case 9: net = 0; off = slab_off_w3(s.Dp) + e; break;                                   // action_net.weight [A][H]
+    case 9: net = 0; off = w3_off(e / FH, e % FH); break;          // action_net.weight [A][H]
     case 10: net = 0; off = slab_off_b3(s.Dp) + e; break;
-    case 11: net = 1; off = slab_off_w3(s.Dp) + e; break;                                  // value_net.weight [1][H]
+    case 11: net = 1; off = w3_off(0, e); break;                   // value_net.weight [1][H]
     default: net = 1; off = slab_off_b3(s.Dp) + e; break;
   }
   float acc = 0.f;
@@ -566,7 +775,8 @@ template <int DP>
 __global__ __launch_bounds__(FTHREADS, 1) void k_fused_act(FusedActArgs a) {
   using L = Lay<DP>;
   constexpr int ldx = L::LDX, per = DP / 4;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> SGPR addressing of weights/slabs
   const int net = blockIdx.x & 1, tile = blockIdx.x >> 1;
   if ((net == 0 && !a.want_pi) || (net == 1 && !a.want_v)) return;
   const FusedNet W = a.net[net];
@@ -579,7 +789,12 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_act(FusedActArgs a) {
     *reinterpret_cast<f32x4*>(&lds[L::X + rr * ldx + 4 * c]) = v;
   }
   __syncthreads();
-  tile_forward<DP>(W, wave, lane);
+#ifdef MOBROB_STAMPS
+  unsigned long long dummy_[32];
+  unsigned long long* stamps_ = dummy_;
+  STAMP_INIT()
+#endif
+  tile_forward<DP>(W, wave, lane STAMP_ARGS);
   if (wave != 0) return;
   const int row = row0 + lane;
   if (row >= a.rows) return;
@@ -628,11 +843,12 @@ struct FusedState {
   size_t packed_floats = 0;
   FusedNet net[2];
   float* slabs = nullptr;
+  unsigned long long* stamps = nullptr;  // diagnostic build only
   int slab_floats = 0, max_grid = 0;
   size_t lds_bytes = 0;
 };
 
-inline size_t fused_lds_bytes(int Dp) { return (size_t)(FR * (Dp + 4) + 2 * FR * FLDH + FR * FLDO) * sizeof(float); }
+inline size_t fused_lds_bytes(int Dp) { return (size_t)(FR * (Dp + 4) + 2 * FR * FLDH + FR * FLDO + 96 + 256) * sizeof(float); }
 
 inline bool fused_shape_ok(int D, int A, int H1, int H2, int G1, int G2) {
   const int Dp = (D + 7) / 8 * 8;
