@@ -76,7 +76,7 @@ struct mobrob_ppo_engine {
   float *last_values = nullptr, *last_dones = nullptr, *prev_dones = nullptr, *dones_tmp = nullptr;
   float *clip_act = nullptr, *rew_tmp = nullptr, *term_obs = nullptr, *term_val = nullptr, *eps_dev = nullptr;
   uint8_t *trunc_dev = nullptr, *dones_u8 = nullptr;
-  int* ep_len = nullptr;
+  int *ep_len = nullptr, *ep_len2 = nullptr;
   bool env_started = false;
   uint32_t draw_counter = 0;  // Philox draw index for eps
   uint32_t env_step_counter = 0;
@@ -233,10 +233,12 @@ void forward(mobrob_ppo_engine* e, const float* X, int rows, bool want_pi, float
   forward_generic(e, X, rows, want_pi, mu_out, want_v, v_out);
 }
 
-void value_flagged(mobrob_ppo_engine* e, const float* obs_rows, const uint8_t* flags, float* out) {
+void value_flagged(mobrob_ppo_engine* e, const float* obs_rows, const uint8_t* flags, float* out,
+                   float* bootstrap_rewards = nullptr) {
   const size_t sm = (size_t)(e->D + e->G1 + e->G2 + 16) * sizeof(float);
   hipLaunchKernelGGL(k_value_flagged, dim3(e->N), dim3(256), sm, e->stream, obs_rows, e->Dp, flags, Pp(e, T_VW1),
-                     Pp(e, T_VB1), Pp(e, T_VW2), Pp(e, T_VB2), Pp(e, T_VW), Pp(e, T_VB), e->D, e->G1, e->G2, out);
+                     Pp(e, T_VB1), Pp(e, T_VW2), Pp(e, T_VB2), Pp(e, T_VW), Pp(e, T_VB), e->D, e->G1, e->G2, out,
+                     bootstrap_rewards, (float)e->cfg.gamma);
 }
 
 void run_gae(mobrob_ppo_engine* e) {
@@ -301,6 +303,7 @@ int fused_init(mobrob_ppo_engine* e) {
   CHK(dalloc(e, &f.slabs, (size_t)f.max_grid * f.slab_floats));
   CHK(dalloc(e, &f.stamps, 32));
   f.lds_bytes = fused_lds_bytes(e->Dp);
+  f.lds_act_bytes = fused_lds_act_bytes(e->Dp);
   HIPC(fused_set_lds_attr(f));
   return MOBROB_OK;
 }
@@ -325,7 +328,7 @@ void fused_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, float 
   for (int i = 0; i < 14; ++i) s.offs[i] = e->offs[i];
   s.D = e->D; s.Dp = e->Dp; s.A = e->A; s.ent_coef = (float)e->cfg.ent_coef; s.b_local = (float)B; s.inv_bg = inv_bg;
   s.sums = e->grads + e->P;
-  hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(e->P, 256)), dim3(256), 0, e->stream, s);
+  hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(f.slab_floats, 256), 2), dim3(256), 0, e->stream, s);
 }
 
 int check_cfg(const mobrob_ppo_config_t* c) {
@@ -411,7 +414,7 @@ int mobrob_ppo_create(const mobrob_ppo_config_t* cfg, mobrob_ppo_engine_t** out)
   CHK(dalloc(e, &e->last_values, N)); CHK(dalloc(e, &e->last_dones, N)); CHK(dalloc(e, &e->prev_dones, N));
   CHK(dalloc(e, &e->dones_tmp, N)); CHK(dalloc(e, &e->clip_act, N * A)); CHK(dalloc(e, &e->rew_tmp, N));
   CHK(dalloc(e, &e->term_obs, N * Dp)); CHK(dalloc(e, &e->term_val, N)); CHK(dalloc(e, &e->eps_dev, R * A));
-  CHK(dalloc(e, &e->trunc_dev, N)); CHK(dalloc(e, &e->dones_u8, N)); CHK(dalloc(e, &e->ep_len, N));
+  CHK(dalloc(e, &e->trunc_dev, N)); CHK(dalloc(e, &e->dones_u8, N)); CHK(dalloc(e, &e->ep_len, N)); CHK(dalloc(e, &e->ep_len2, N));
   CHK(dalloc(e, &e->rows, T * N)); CHK(dalloc(e, &e->perm_dev, T * N)); CHK(dalloc(e, &e->advstat, (size_t)e->nmb * 4));
   e->stats_cap = std::max(64, 4 * e->nmb * cfg->n_epochs);
   CHK(dalloc(e, &e->stats, (size_t)e->stats_cap * 8));
@@ -591,17 +594,16 @@ int mobrob_ppo_collect_synthetic(mobrob_ppo_engine_t* e, float p_term, int32_t t
     act_slot(e, t, nullptr);
     {
       ProfScope ps(e, MOBROB_K_ENV);
-      hipLaunchKernelGGL(k_env_step, dim3(cdiv(N * per, 256)), dim3(256), 0, e->stream, env_seed, e->env_step_counter,
-                         N, e->D, Dp, p_term, time_limit, e->ep_len, e->obs + (size_t)(t + 1) * slot, e->term_obs,
-                         e->rew_tmp, e->dones_tmp, e->trunc_dev);
-      hipLaunchKernelGGL(k_env_advance, dim3(cdiv(N, 256)), dim3(256), 0, e->stream, N, e->dones_tmp, e->ep_len);
+      hipLaunchKernelGGL(k_env_step_store, dim3(cdiv(N * per, 256)), dim3(256), 0, e->stream, env_seed,
+                         e->env_step_counter, N, e->D, Dp, p_term, time_limit, e->ep_len, e->ep_len2,
+                         e->obs + (size_t)(t + 1) * slot, e->term_obs, e->prev_dones, e->dones_tmp, e->trunc_dev,
+                         e->rewards + (size_t)t * N, e->es + (size_t)t * N);
+      // time-limit bootstrap of the (rare) truncated rows, in place: rewards += gamma * V(terminal_obs)
+      value_flagged(e, e->term_obs, e->trunc_dev, e->term_val, e->rewards + (size_t)t * N);
     }
     e->env_step_counter++;
-    value_flagged(e, e->term_obs, e->trunc_dev, e->term_val);
-    hipLaunchKernelGGL(k_store_step, dim3(cdiv(N, 256)), dim3(256), 0, e->stream, e->rew_tmp, e->prev_dones,
-                       e->trunc_dev, e->term_val, (float)e->cfg.gamma, N, e->rewards + (size_t)t * N,
-                       e->es + (size_t)t * N);
     std::swap(e->prev_dones, e->dones_tmp);
+    std::swap(e->ep_len, e->ep_len2);
   }
   HIPC(hipMemcpyAsync(e->last_dones, e->prev_dones, (size_t)N * 4, hipMemcpyDeviceToDevice, e->stream));
   forward(e, e->obs + (size_t)e->T * slot, N, false, nullptr, true, e->last_values);

@@ -131,7 +131,7 @@ __device__ __forceinline__ void gemm_lds_packed(int a_off, const f32x4* __restri
                                                 const f32x4* __restrict__ Bp1, int nkg, f32x16& c00, f32x16& c01,
                                                 f32x16& c10, f32x16& c11, int lane) {
   const int r = lane & 31, h = lane >> 5;
-  const int ab = opaque(a_off + r * LDA + 4 * h);
+  const int ab = 4 * opaque((a_off + r * LDA + 4 * h) >> 2);  // provably 16-byte aligned -> ds_read_b128
   unsigned bo = opaque_u((unsigned)lane * 16u);  // byte offset of this lane's fragment; +1024 per k-group
   f32x4 pA = ldg16(Bp0, bo), qA = ldg16(Bp1, bo), pB, qB;
   f32x4 uA = *reinterpret_cast<const f32x4*>(&lds[ab]);
@@ -302,7 +302,7 @@ __device__ __forceinline__ void tile_forward(const FusedNet& W, int wave, int la
   {  // head: [64 x 32] = h2 . W3^T, K split in two halves; wave = (khalf << 1) | rowblock
     const int rb = wave & 1, ks = wave >> 1;
     f32x16 acc = zero16(), acc2 = zero16();  // two independent chains (even / odd k-groups)
-    const int ab = opaque(L::H2 + (rb * 32 + r) * FLDH + ks * 128 + 4 * h);
+    const int ab = 4 * opaque((L::H2 + (rb * 32 + r) * FLDH + ks * 128 + 4 * h) >> 2);
     const f32x4* bp = W.W3f + (size_t)(ks * 16) * 64;
     unsigned bo = opaque_u((unsigned)lane * 16u);
     f32x4 bA = ldg16(bp, bo), bB = ldg16(bp, bo + 1024u);
@@ -685,50 +685,68 @@ struct SlabReduceArgs {
   float* sums;    // sums[4] = rows (for the stats finaliser)
 };
 
-__global__ __launch_bounds__(256) void k_slab_reduce(SlabReduceArgs s) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) s.sums[4] = s.b_local;
-  if (i >= s.P) return;
-  // locate tensor
-  int t = 0;
-#pragma unroll
-  for (int k = 1; k < 13; ++k) t += (i >= s.offs[k]) ? 1 : 0;
-  const int e = i - s.offs[t];
-  int net, off;
-  auto w2_off = [&](int n, int j) {  // dW2[n][j]
-    int i, h;
-    row_to_ih(n & 31, &i, &h);
-    return slab_off_w2() + frag_off(n >> 6, 16, ((n >> 5) & 1) * 8 + (j >> 5), i, (j & 31) + 32 * h);
+// slab position -> canonical gradient index of network `net` (or -1 for padding / unused positions)
+__device__ __forceinline__ int slab_to_canonical(const SlabReduceArgs& s, int net, int p) {
+  const int T_W1 = net == 0 ? 1 : 5, T_B1 = net == 0 ? 2 : 6, T_W2 = net == 0 ? 3 : 7, T_B2 = net == 0 ? 4 : 8;
+  const int T_W3 = net == 0 ? 9 : 11, T_B3 = net == 0 ? 10 : 12;
+  const int head = net == 0 ? s.A : 1;
+  auto frag = [](int q, int nt, int* w, int* t, int* i, int* lane) {
+    *lane = (q >> 2) & 63;
+    *i = (q & 3) + 4 * ((q >> 8) & 3);
+    const int wt = q >> 10;
+    *t = wt % nt;
+    *w = wt / nt;
   };
-  auto w1_off = [&](int n, int j) {  // dW1[n][j], j < D
-    int i, h;
-    row_to_ih(n & 31, &i, &h);
-    return slab_off_w1() + frag_off(n >> 6, 4, ((n >> 5) & 1) * 2 + (j >> 5), i, (j & 31) + 32 * h);
-  };
-  auto w3_off = [&](int a_, int j) {  // dW3[a][j]
-    int i, h;
-    row_to_ih(a_, &i, &h);
-    return slab_off_w3(s.Dp) + frag_off(j >> 6, 2, (j >> 5) & 1, i, (j & 31) + 32 * h);
-  };
-  switch (t) {
-    case 0: net = 0; off = slab_off_ls(s.Dp) + e; break;           // log_std
-    case 1: net = 0; off = w1_off(e / s.D, e % s.D); break;        // pi W1 [H][D]
-    case 2: net = 0; off = slab_off_b1(s.Dp) + e; break;
-    case 3: net = 0; off = w2_off(e / FH, e % FH); break;
-    case 4: net = 0; off = slab_off_b2(s.Dp) + e; break;
-    case 5: net = 1; off = w1_off(e / s.D, e % s.D); break;        // vf W1
-    case 6: net = 1; off = slab_off_b1(s.Dp) + e; break;
-    case 7: net = 1; off = w2_off(e / FH, e % FH); break;
-    case 8: net = 1; off = slab_off_b2(s.Dp) + e; break;
-    case 9: net = 0; off = w3_off(e / FH, e % FH); break;          // action_net.weight [A][H]
-    case 10: net = 0; off = slab_off_b3(s.Dp) + e; break;
-    case 11: net = 1; off = w3_off(0, e); break;                   // value_net.weight [1][H]
-    default: net = 1; off = slab_off_b3(s.Dp) + e; break;
+  int w, t, i, lane;
+  if (p < slab_off_w1()) {  // dW2
+    frag(p, 16, &w, &t, &i, &lane);
+    const int n = 64 * w + 32 * (t >> 3) + crc(i) + 4 * (lane >> 5), j = 32 * (t & 7) + (lane & 31);
+    return s.offs[T_W2] + n * FH + j;
   }
-  float acc = 0.f;
-  for (int w = net; w < s.nslabs; w += 2) acc += s.slabs[(size_t)w * s.slab_floats + off];
-  if (t == 0) acc += s.ent_coef * (-s.b_local) * s.inv_bg;  // entropy bonus gradient on log_std
-  s.grads[i] = acc;
+  if (p < slab_off_w3(s.Dp)) {  // dW1
+    frag(p - slab_off_w1(), 4, &w, &t, &i, &lane);
+    const int n = 64 * w + 32 * (t >> 1) + crc(i) + 4 * (lane >> 5), j = 32 * (t & 1) + (lane & 31);
+    return j < s.D ? s.offs[T_W1] + n * s.D + j : -1;
+  }
+  if (p < slab_off_b2(s.Dp)) {  // dW3
+    frag(p - slab_off_w3(s.Dp), 2, &w, &t, &i, &lane);
+    const int a_ = crc(i) + 4 * (lane >> 5), j = 64 * w + 32 * t + (lane & 31);
+    return a_ < head ? s.offs[T_W3] + a_ * FH + j : -1;
+  }
+  if (p < slab_off_b1(s.Dp)) return s.offs[T_B2] + (p - slab_off_b2(s.Dp));
+  if (p < slab_off_b3(s.Dp)) return s.offs[T_B1] + (p - slab_off_b1(s.Dp));
+  if (p < slab_off_ls(s.Dp)) {
+    const int k = p - slab_off_b3(s.Dp);
+    return k < head ? s.offs[T_B3] + k : -1;
+  }
+  const int k = p - slab_off_ls(s.Dp);
+  return (net == 0 && k < s.A) ? s.offs[0] + k : -1;
+}
+
+// grid = (ceil(slab_floats / 256), 2 networks): thread p sums slab position p over the slabs of its network
+// (coalesced reads, fixed order) and scatters the total to the canonical gradient vector.
+__global__ __launch_bounds__(256) void k_slab_reduce(SlabReduceArgs s) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int net = blockIdx.y;
+  if (p == 0 && net == 0) s.sums[4] = s.b_local;
+  if (p >= s.slab_floats) return;
+  const int dst = slab_to_canonical(s, net, p);
+  if (dst < 0) return;
+  const float* src = s.slabs + (size_t)net * s.slab_floats + p;
+  const size_t stride = 2 * (size_t)s.slab_floats;
+  const int n = (s.nslabs - net + 1) / 2;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int w = 0;
+  for (; w + 4 <= n; w += 4) {
+    a0 += src[(size_t)w * stride];
+    a1 += src[(size_t)(w + 1) * stride];
+    a2 += src[(size_t)(w + 2) * stride];
+    a3 += src[(size_t)(w + 3) * stride];
+  }
+  for (; w < n; ++w) a0 += src[(size_t)w * stride];
+  float acc = (a0 + a1) + (a2 + a3);
+  if (dst < s.offs[1]) acc += s.ent_coef * (-s.b_local) * s.inv_bg;  // entropy bonus gradient on log_std
+  s.grads[dst] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -771,42 +789,138 @@ struct FusedActArgs {
   float* act_raw; float* act_clip; float* logp;
 };
 
+// 32-row variant of the packed GEMM: one row block, two column blocks per wave (8 MFMAs per k-group)
+#define MFMA_KG1(u, p, q)                            \
+  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) { \
+    c0 = MFMA32(u[s_], p[s_], c0);                   \
+    c1 = MFMA32(u[s_], q[s_], c1);                   \
+  }
+template <int LDA>
+__device__ __forceinline__ void gemm_lds_packed_r32(int a_off, const f32x4* __restrict__ Bp0,
+                                                    const f32x4* __restrict__ Bp1, int nkg, f32x16& c0, f32x16& c1,
+                                                    int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int ab = 4 * opaque((a_off + r * LDA + 4 * h) >> 2);
+  unsigned bo = opaque_u((unsigned)lane * 16u);
+  f32x4 pA = ldg16(Bp0, bo), qA = ldg16(Bp1, bo), pB, qB;
+  f32x4 uA = *reinterpret_cast<const f32x4*>(&lds[ab]), uB;
+  int ao = ab;
+#pragma unroll 1
+  for (int kg = 0; kg < nkg - 2; kg += 2) {
+    pB = ldg16(Bp0, bo + 1024u);
+    qB = ldg16(Bp1, bo + 1024u);
+    uB = *reinterpret_cast<const f32x4*>(&lds[ao + 8]);
+    MFMA_KG1(uA, pA, qA)
+    pA = ldg16(Bp0, bo + 2048u);
+    qA = ldg16(Bp1, bo + 2048u);
+    uA = *reinterpret_cast<const f32x4*>(&lds[ao + 16]);
+    MFMA_KG1(uB, pB, qB)
+    bo += 2048u;
+    ao += 16;
+  }
+  pB = ldg16(Bp0, bo + 1024u);
+  qB = ldg16(Bp1, bo + 1024u);
+  uB = *reinterpret_cast<const f32x4*>(&lds[ao + 8]);
+  MFMA_KG1(uA, pA, qA)
+  MFMA_KG1(uB, pB, qB)
+}
+
+// LDS carve-up of the 32-row rollout kernel
 template <int DP>
-__global__ __launch_bounds__(FTHREADS, 1) void k_fused_act(FusedActArgs a) {
-  using L = Lay<DP>;
-  constexpr int ldx = L::LDX, per = DP / 4;
+struct Lay32 {
+  static constexpr int R = 32;
+  static constexpr int LDX = DP + 4;
+  static constexpr int X = 0;
+  static constexpr int H1 = X + R * LDX;
+  static constexpr int H2 = H1 + R * FLDH;
+  static constexpr int DO = H2 + R * FLDH;   // [4 K-slices][32][FLDO] partial head tiles
+  static constexpr int END = DO + 4 * R * FLDO;
+};
+
+// grid = 2 * ceil(rows / 32); block b: net = b & 1, tile = b >> 1.  ~76 KB of LDS -> two blocks per CU.
+template <int DP>
+__global__ __launch_bounds__(FTHREADS, 2) void k_fused_act(FusedActArgs a) {
+  using L = Lay32<DP>;
+  constexpr int ldx = L::LDX, per = DP / 4, R = 32;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> SGPR addressing of weights/slabs
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
   const int net = blockIdx.x & 1, tile = blockIdx.x >> 1;
   if ((net == 0 && !a.want_pi) || (net == 1 && !a.want_v)) return;
   const FusedNet W = a.net[net];
-  const int row0 = tile * FR;
+  const int row0 = tile * R;
 #pragma unroll
-  for (int i = tid; i < FR * per; i += FTHREADS) {
+  for (int i = tid; i < R * per; i += FTHREADS) {
     const int rr = i / per, c = i - rr * per;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row0 + rr < a.rows) v = reinterpret_cast<const f32x4*>(a.X)[(size_t)(row0 + rr) * per + c];
+    if (row0 + rr < a.rows) v = ldg16(a.X, (unsigned)(row0 + rr) * (unsigned)(DP * 4) + (unsigned)(c * 16));
     *reinterpret_cast<f32x4*>(&lds[L::X + rr * ldx + 4 * c]) = v;
   }
   __syncthreads();
-#ifdef MOBROB_STAMPS
-  unsigned long long dummy_[32];
-  unsigned long long* stamps_ = dummy_;
-  STAMP_INIT()
-#endif
-  tile_forward<DP>(W, wave, lane STAMP_ARGS);
-  if (wave != 0) return;
+  {  // layer 1
+    f32x16 c0 = zero16(), c1 = zero16();
+    constexpr int nkg = DP / 8;
+    gemm_lds_packed_r32<ldx>(L::X, W.W1f + (size_t)(2 * wave) * nkg * 64, W.W1f + (size_t)(2 * wave + 1) * nkg * 64, nkg,
+                             c0, c1, lane);
+    const float bz0 = W.b1[64 * wave + r], bz1 = W.b1[64 * wave + 32 + r];
+    const int o = opaque(L::H1 + 4 * h * FLDH + 64 * wave + r);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      lds[o + crc(i) * FLDH] = fast_tanh(c0[i] + bz0);
+      lds[o + crc(i) * FLDH + 32] = fast_tanh(c1[i] + bz1);
+    }
+  }
+  __syncthreads();
+  {  // layer 2
+    f32x16 c0 = zero16(), c1 = zero16();
+    constexpr int nkg = FH / 8;
+    gemm_lds_packed_r32<FLDH>(L::H1, W.W2f + (size_t)(2 * wave) * nkg * 64, W.W2f + (size_t)(2 * wave + 1) * nkg * 64,
+                              nkg, c0, c1, lane);
+    const float bz0 = W.b2[64 * wave + r], bz1 = W.b2[64 * wave + 32 + r];
+    const int o = opaque(L::H2 + 4 * h * FLDH + 64 * wave + r);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      lds[o + crc(i) * FLDH] = fast_tanh(c0[i] + bz0);
+      lds[o + crc(i) * FLDH + 32] = fast_tanh(c1[i] + bz1);
+    }
+  }
+  __syncthreads();
+  {  // head: K split over the 4 waves (64 each); partial tiles side by side, summed in the epilogue
+    f32x16 acc = zero16(), acc2 = zero16();
+    const int ab = 4 * opaque((L::H2 + r * FLDH + wave * 64 + 4 * h) >> 2);
+    const f32x4* bp = W.W3f + (size_t)(wave * 8) * 64;
+    const unsigned bo = opaque_u((unsigned)lane * 16u);
+#pragma unroll
+    for (int kg = 0; kg < 8; kg += 2) {
+      const f32x4 b0 = ldg16(bp, bo + kg * 1024u), b1 = ldg16(bp, bo + (kg + 1) * 1024u);
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8]);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8 + 8]);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        acc = MFMA32(a0[s_], b0[s_], acc);
+        acc2 = MFMA32(a1[s_], b1[s_], acc2);
+      }
+    }
+    const int o = opaque(L::DO + wave * R * FLDO + 4 * h * FLDO + r);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lds[o + crc(i) * FLDO] = acc[i] + acc2[i];
+  }
+  __syncthreads();
+  if (wave != 0 || lane >= R) return;
   const int row = row0 + lane;
   if (row >= a.rows) return;
-  const float* drow = &lds[L::DO + lane * FLDO];
+  const int db = opaque(L::DO + lane * FLDO);
+  auto head = [&](int k) {  // fixed-order sum of the four K-slices + bias
+    return ((lds[db + k] + lds[db + R * FLDO + k]) + (lds[db + 2 * R * FLDO + k] + lds[db + 3 * R * FLDO + k])) + W.b3[k];
+  };
   if (net == 1) {
-    a.v[row] = drow[0] + W.b3[0];
+    a.v[row] = head(0);
     return;
   }
   float lp = 0.f;
   float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
   for (int k = 0; k < a.A; ++k) {
-    const float m = drow[k] + W.b3[k];
+    const float m = head(k);
     if (a.mu) a.mu[(size_t)row * a.ldmu + k] = m;
     if (a.sample) {
       float e;
@@ -845,10 +959,12 @@ struct FusedState {
   float* slabs = nullptr;
   unsigned long long* stamps = nullptr;  // diagnostic build only
   int slab_floats = 0, max_grid = 0;
-  size_t lds_bytes = 0;
+  size_t lds_bytes = 0, lds_act_bytes = 0;
 };
 
 inline size_t fused_lds_bytes(int Dp) { return (size_t)(FR * (Dp + 4) + 2 * FR * FLDH + FR * FLDO + 96 + 256) * sizeof(float); }
+
+inline size_t fused_lds_act_bytes(int Dp) { return (size_t)(32 * (Dp + 4) + 2 * 32 * FLDH + 4 * 32 * FLDO) * sizeof(float); }
 
 inline bool fused_shape_ok(int D, int A, int H1, int H2, int G1, int G2) {
   const int Dp = (D + 7) / 8 * 8;
@@ -888,8 +1004,8 @@ inline void fused_launch_act(FusedState& f, FusedActArgs& a, hipStream_t st) {
   a.net[0] = f.net[0];
   a.net[1] = f.net[1];
   a.Dp = f.Dp;
-  const int tiles = (a.rows + FR - 1) / FR;
-  FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused_act<DPc>), dim3(2 * tiles), dim3(FTHREADS), f.lds_bytes, st, a));
+  const int tiles = (a.rows + 31) / 32;
+  FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused_act<DPc>), dim3(2 * tiles), dim3(FTHREADS), f.lds_act_bytes, st, a));
 }
 inline void fused_launch_train(FusedState& f, FusedTrainArgs& a, int grid, hipStream_t st) {
   FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused_train<DPc>), dim3(grid), dim3(FTHREADS), f.lds_bytes, st, a));
@@ -899,7 +1015,7 @@ inline hipError_t fused_set_lds_attr(FusedState& f) {
   FUSED_DISPATCH_DP(f.Dp, {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_train<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_act<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_act<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_act_bytes);
   });
   return e;
 }

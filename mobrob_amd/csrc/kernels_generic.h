@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void k_value_flagged(const float* __restrict__
                                                        const float* __restrict__ W1, const float* __restrict__ b1,
                                                        const float* __restrict__ W2, const float* __restrict__ b2,
                                                        const float* __restrict__ Wv, const float* __restrict__ bv,
-                                                       int D, int G1, int G2, float* __restrict__ out) {
+                                                       int D, int G1, int G2, float* __restrict__ out,
+                                                       float* __restrict__ rew_inout, float gamma) {
   const int row = blockIdx.x;
   if (!flags[row]) return;
   extern __shared__ float sm[];  // x[D] | h1[G1] | h2[G2] | red[16]
@@ -241,7 +242,12 @@ __global__ __launch_bounds__(256) void k_value_flagged(const float* __restrict__
   float p = 0.f;
   for (int k = threadIdx.x; k < G2; k += blockDim.x) p += h2[k] * Wv[k];
   const float tot = block_sum(p, red);
-  if (threadIdx.x == 0) out[row] = tot + bv[0];
+  if (threadIdx.x == 0) {
+    const float v = tot + bv[0];
+    out[row] = v;
+    if (rew_inout != nullptr)  // rewards[idx] += gamma * V(terminal_obs)  [oracle bootstrap_reward]
+      rew_inout[row] = (float)((double)rew_inout[row] + (double)__fmul_rn(gamma, v));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -578,6 +584,46 @@ __global__ void k_env_step(uint64_t seed, uint32_t step, int N, int D, int Dp, f
     rewards[n] = 0.03f + 0.1f * zz[0] + (term ? 5.0f : 0.f);
     dones_f[n] = done ? 1.f : 0.f;
     trunc[n] = tr ? 1 : 0;
+  }
+}
+// One-launch variant used by the device-resident rollout: env draw + rollout_buffer.add scalars.
+// ep_len is double buffered (every chunk thread of an env must see the OLD value); the time-limit
+// bootstrap of the (rare) truncated rows is applied afterwards by k_value_flagged in place.
+__global__ void k_env_step_store(uint64_t seed, uint32_t step, int N, int D, int Dp, float p_term, int time_limit,
+                                 const int* __restrict__ ep_len_in, int* __restrict__ ep_len_out,
+                                 float* __restrict__ obs_next, float* __restrict__ term_obs,
+                                 const float* __restrict__ prev_dones, float* __restrict__ next_dones,
+                                 uint8_t* __restrict__ trunc, float* __restrict__ rew_out, float* __restrict__ es_out) {
+  const int per = Dp / 4;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * per) return;
+  const int n = i / per, c = i - n * per;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, k0, k1);
+  const bool term = u32_to_unit_open(mr.x) < p_term;
+  const int len = ep_len_in[n] + 1;
+  const bool tr = (len >= time_limit) && !term;
+  const bool done = term || tr;
+  float z[4];
+  box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, k0, k1), z);
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
+  if (tr) {
+    reinterpret_cast<f32x4*>(term_obs)[(size_t)n * per + c] = o;
+    box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, k0, k1), z);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
+  }
+  reinterpret_cast<f32x4*>(obs_next)[(size_t)n * per + c] = o;
+  if (c == 0) {
+    float zz[4];
+    box_muller4(Philox4{mr.y, mr.z, mr.w, mr.x ^ 0x9E3779B9u}, zz);
+    rew_out[n] = 0.03f + 0.1f * zz[0] + (term ? 5.0f : 0.f);
+    es_out[n] = prev_dones[n];
+    next_dones[n] = done ? 1.f : 0.f;
+    trunc[n] = tr ? 1 : 0;
+    ep_len_out[n] = done ? 0 : len;
   }
 }
 // ep_len update is a separate tiny kernel so that every chunk thread above sees the same old value
