@@ -68,6 +68,9 @@ struct mobrob_ppo_engine {
   float *params = nullptr, *grads = nullptr /* [P] + 8 loss sums */, *m = nullptr, *v = nullptr;
   int* offs_dev = nullptr;
   double* tensor_sq = nullptr;  // [13]
+  NormChunk* chunks_dev = nullptr;
+  double* chunk_partial = nullptr;
+  int nchunks = 0;
   float *pW1p = nullptr, *vW1p = nullptr, *aWp = nullptr, *vWp = nullptr;  // zero-padded compute copies
   int64_t adam_step = 0;
   // rollout storage
@@ -428,6 +431,17 @@ int mobrob_ppo_create(const mobrob_ppo_config_t* cfg, mobrob_ppo_engine_t** out)
   CHK(dalloc(e, &e->pred_obs, R * Dp)); CHK(dalloc(e, &e->pred_act, R * A));
   HIPC(hipMemcpyAsync(e->offs_dev, e->offs, sizeof e->offs, hipMemcpyHostToDevice, e->stream));
   CHK(fused_init(e));
+  {  // chunk table for the gradient-norm reduction: <= 4096 elements per block, chunks sorted by tensor
+    std::vector<NormChunk> ch;
+    for (int tt = 0; tt < T_COUNT; ++tt)
+      for (int s0 = e->offs[tt]; s0 < e->offs[tt + 1]; s0 += 4096) ch.push_back(NormChunk{tt, s0, std::min(s0 + 4096, e->offs[tt + 1]), 0});
+    e->nchunks = (int)ch.size();
+    if (e->nchunks > 256) return fail(MOBROB_ERR_INVALID, "parameter vector too large for the norm chunk table (%d chunks)", e->nchunks);
+    CHK(dalloc(e, &e->chunks_dev, ch.size()));
+    CHK(dalloc(e, &e->chunk_partial, ch.size()));
+    HIPC(hipMemcpyAsync(e->chunks_dev, ch.data(), ch.size() * sizeof(NormChunk), hipMemcpyHostToDevice, e->stream));
+    HIPC(hipStreamSynchronize(e->stream));
+  }
   // `_last_episode_starts` is all-True at _setup_learn (Appendix A.5)
   std::vector<float> ones(N, 1.0f);
   HIPC(hipMemcpyAsync(e->prev_dones, ones.data(), N * 4, hipMemcpyHostToDevice, e->stream));
@@ -693,24 +707,37 @@ int mobrob_ppo_minibatch_apply(mobrob_ppo_engine_t* e) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   if (!e->grad_pending) return fail(MOBROB_ERR_STATE, "minibatch_apply without a pending gradient");
   ProfScope ps(e, MOBROB_K_APPLY);
-  hipLaunchKernelGGL(k_tensor_sqnorm, dim3(T_COUNT), dim3(1024), 0, e->stream, e->grads, e->offs_dev, (int)T_COUNT,
-                     e->tensor_sq);
   e->adam_step++;
   const double b1 = e->cfg.adam_beta1, b2 = e->cfg.adam_beta2;
   const double bc1 = 1.0 - std::pow(b1, (double)e->adam_step);
   const double bc2 = 1.0 - std::pow(b2, (double)e->adam_step);
-  AdamArgs a{};
-  a.p = e->params; a.g = e->grads; a.m = e->m; a.v = e->v; a.P = e->P; a.tensor_sq = e->tensor_sq; a.ntensors = T_COUNT;
+  if (e->stats_n >= e->stats_cap) e->stats_n = 0;  // ring: oldest rows are dropped if nobody fetched them
+  float* stats_row = e->stats + (size_t)e->stats_n * 8;
+  e->stats_n++;
+  StatsArgs st{};
+  st.stats_row = stats_row; st.loss_sums = e->grads + e->P; st.log_std = Pp(e, T_LOGSTD);
+  st.ent_coef = (float)e->cfg.ent_coef; st.vf_coef = (float)e->cfg.vf_coef;
+  st.inv_bg = 1.0f / (float)((int64_t)e->cur_count * e->cfg.world_size); st.n_act = e->A;
+  hipLaunchKernelGGL(k_sqnorm_chunks, dim3(e->nchunks), dim3(256), 0, e->stream, e->grads, e->chunks_dev,
+                     e->chunk_partial, st);
+  AdamPackArgs a{};
+  a.p = e->params; a.g = e->grads; a.m = e->m; a.v = e->v; a.P = e->P;
+  a.chunks = e->chunks_dev; a.partial = e->chunk_partial; a.nchunks = e->nchunks;
   a.max_norm = (float)e->cfg.max_grad_norm; a.step_size = (float)(e->cfg.learning_rate / bc1);
   a.bc2_sqrt = (float)std::sqrt(bc2); a.beta1 = (float)b1; a.beta2 = (float)b2; a.eps = (float)e->cfg.adam_eps;
-  if (e->stats_n >= e->stats_cap) e->stats_n = 0;  // ring: oldest rows are dropped if nobody fetched them
-  a.stats_row = e->stats + (size_t)e->stats_n * 8;
-  e->stats_n++;
-  a.loss_sums = e->grads + e->P; a.ent_coef = (float)e->cfg.ent_coef; a.vf_coef = (float)e->cfg.vf_coef;
-  a.inv_bg = 1.0f / (float)((int64_t)e->cur_count * e->cfg.world_size);
-  a.log_std = Pp(e, T_LOGSTD); a.A = e->A;
-  hipLaunchKernelGGL(k_adam, dim3(cdiv(e->P, 256)), dim3(256), 0, e->stream, a);
-  repack(e);
+  for (int i = 0; i < 14; ++i) a.offs[i] = e->offs[i];
+  a.D = e->D; a.Dp = e->Dp; a.A = e->A; a.Ap = e->Ap; a.H1 = e->H1; a.H2 = e->H2; a.G1 = e->G1; a.G2 = e->G2;
+  a.pW1p = e->pW1p; a.vW1p = e->vW1p; a.aWp = e->aWp; a.vWp = e->vWp;
+  for (int n = 0; n < 2; ++n) {
+    const bool on = e->fused.enabled;
+    a.fW1f[n] = on ? (float*)e->fused.net[n].W1f : nullptr;
+    a.fW2f[n] = on ? (float*)e->fused.net[n].W2f : nullptr;
+    a.fW3f[n] = on ? (float*)e->fused.net[n].W3f : nullptr;
+    a.fW2b[n] = on ? (float*)e->fused.net[n].W2b : nullptr;
+    a.fW3b[n] = on ? (float*)e->fused.net[n].W3b : nullptr;
+  }
+  a.stats_row = stats_row;
+  hipLaunchKernelGGL(k_adam_pack, dim3(cdiv(e->P, 256)), dim3(256), 0, e->stream, a);
   HIPC(hipGetLastError());
   e->grad_pending = false;
   return MOBROB_OK;

@@ -948,6 +948,127 @@ __global__ __launch_bounds__(FTHREADS, 2) void k_fused_act(FusedActArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// clip_grad_norm_ + Adam + re-packing in three small launches [torch 2.0.1 semantics; oracle clip_grad_norm /
+// adam_step]:
+//   k_sqnorm_chunks : per-(tensor, chunk) sum of squares in f64 (many blocks; chunk table built on the host)
+//   k_adam_pack     : every block re-derives the clip coefficient from the chunk partials (fixed order), then
+//                     each thread updates one canonical parameter and scatters it into the zero-padded copies
+//                     (generic path) and the MFMA-fragment packs (fused path) -- no separate pack launches.
+// ------------------------------------------------------------------------------------------------
+struct NormChunk { int tensor, start, end, pad; };
+
+struct StatsArgs {
+  float* stats_row; const float* loss_sums; const float* log_std; float ent_coef, vf_coef, inv_bg; int n_act;
+};
+__global__ __launch_bounds__(256) void k_sqnorm_chunks(const float* __restrict__ g, const NormChunk* __restrict__ chunks,
+                                                       double* __restrict__ partial, StatsArgs st) {
+  __shared__ double sc[16];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && st.stats_row != nullptr) {  // loss statistics (pre-update log_std)
+    const float pl = -st.loss_sums[0] * st.inv_bg;
+    const float vl = st.loss_sums[1] * st.inv_bg;
+    float ent = 0.f;
+    for (int k = 0; k < st.n_act; ++k) ent += (0.5f + 0.91893853320467274178f) + logf(expf(st.log_std[k]));
+    const float el = -(ent * st.loss_sums[4]) * st.inv_bg;
+    st.stats_row[0] = pl; st.stats_row[1] = vl; st.stats_row[2] = el;
+    st.stats_row[3] = pl + st.ent_coef * el + st.vf_coef * vl;
+    st.stats_row[4] = st.loss_sums[2] * st.inv_bg;
+    st.stats_row[5] = st.loss_sums[3] * st.inv_bg;
+    st.stats_row[7] = 0.f;
+  }
+  const NormChunk c = chunks[blockIdx.x];
+  double a = 0.0;
+  for (int i = c.start + threadIdx.x; i < c.end; i += blockDim.x) {
+    const double x = (double)g[i];
+    a += x * x;
+  }
+  const double tot = block_sum_d(a, sc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+struct AdamPackArgs {
+  float* p; const float* g; float* m; float* v; int P;
+  const NormChunk* chunks; const double* partial; int nchunks;
+  float max_norm, step_size, bc2_sqrt, beta1, beta2, eps;
+  int offs[14];
+  int D, Dp, A, Ap, H1, H2, G1, G2;
+  // generic-path padded copies (always maintained: cheap, and k_value_flagged/predict fallbacks use canonical)
+  float* pW1p; float* vW1p; float* aWp; float* vWp;
+  // fused-path packs (null when the fused path is disabled)
+  float* fW1f[2]; float* fW2f[2]; float* fW3f[2]; float* fW2b[2]; float* fW3b[2];
+  float* stats_row;  // [6] <- total gradient norm
+};
+
+__device__ __forceinline__ int pack_fwd_idx(int n, int k, int KG) {
+  return (((n >> 5) * KG + (k >> 3)) * 64 + (n & 31) + 32 * ((k >> 2) & 1)) * 4 + (k & 3);
+}
+__device__ __forceinline__ int pack_bwd_idx(int krow, int j, int KG) {
+  return (((j >> 5) * KG + (krow >> 3)) * 64 + (j & 31) + 32 * ((krow >> 2) & 1)) * 4 + (krow & 3);
+}
+
+__global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
+  __shared__ double part[256];
+  __shared__ float coef_s, total_s;
+  for (int c = threadIdx.x; c < a.nchunks; c += blockDim.x) part[c] = a.partial[c];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // total norm = norm of per-tensor norms (torch.norm(torch.stack(norms))), chunks are sorted by tensor
+    float tot_sq = 0.f;
+    int c = 0;
+    while (c < a.nchunks) {
+      const int t = a.chunks[c].tensor;
+      double ts = 0.0;
+      while (c < a.nchunks && a.chunks[c].tensor == t) ts += part[c++];
+      const float nt = (float)sqrt(ts);
+      tot_sq += nt * nt;
+    }
+    const float total = sqrtf(tot_sq);
+    total_s = total;
+    coef_s = fminf(a.max_norm / (total + 1e-6f), 1.0f);
+  }
+  __syncthreads();
+  const float coef = coef_s;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && a.stats_row != nullptr) a.stats_row[6] = total_s;
+  if (i >= a.P) return;
+  const float g = a.g[i] * coef;
+  const float m = a.m[i] * a.beta1 + (1.0f - a.beta1) * g;
+  const float v = a.v[i] * a.beta2 + (1.0f - a.beta2) * (g * g);
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  const float pn = a.p[i] - a.step_size * (m / denom);
+  a.m[i] = m;
+  a.v[i] = v;
+  a.p[i] = pn;
+  int t = 0;
+#pragma unroll
+  for (int k = 1; k < 13; ++k) t += (i >= a.offs[k]) ? 1 : 0;
+  const int e = i - a.offs[t];
+  switch (t) {
+    case 1: case 5: {  // W1 [H][D]
+      const int net = t == 5, n = e / a.D, k = e - n * a.D;
+      (net ? a.vW1p : a.pW1p)[n * a.Dp + k] = pn;
+      if (a.fW1f[net]) a.fW1f[net][pack_fwd_idx(n, k, a.Dp / 8)] = pn;
+    } break;
+    case 3: case 7: {  // W2 [H2][H1]
+      const int net = t == 7;
+      if (a.fW2f[net]) {
+        const int K = net ? a.G1 : a.H1, n = e / K, k = e - n * K;
+        a.fW2f[net][pack_fwd_idx(n, k, K / 8)] = pn;
+        a.fW2b[net][pack_bwd_idx(n, k, (net ? a.G2 : a.H2) / 8)] = pn;
+      }
+    } break;
+    case 9: case 11: {  // head [A or 1][H2]
+      const int net = t == 11, K = net ? a.G2 : a.H2, n = e / K, k = e - n * K;
+      (net ? a.vWp : a.aWp)[e] = pn;
+      if (a.fW3f[net]) {
+        a.fW3f[net][pack_fwd_idx(n, k, K / 8)] = pn;
+        a.fW3b[net][pack_bwd_idx(n, k, 4)] = pn;
+      }
+    } break;
+    default: break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-side state of the fused path
 // ------------------------------------------------------------------------------------------------
 struct FusedState {
