@@ -126,14 +126,23 @@ __device__ __forceinline__ constexpr int crc(int i) { return (i & 3) + 8 * (i >>
   }
 // nkg must be even.  The k-group loop is unrolled by two with ping-pong operand buffers (no register rotation:
 // a rotation makes the compiler copy -- and therefore wait for -- loads that were only just issued).
+// first k-group's weight fragments of a GEMM phase, fetched one phase early (hides the L2 latency that a
+// single wave per SIMD cannot cover otherwise)
+struct Frag2 {
+  f32x4 p, q;
+};
+__device__ __forceinline__ Frag2 prefetch_frag(const f32x4* __restrict__ Bp0, const f32x4* __restrict__ Bp1, int lane) {
+  const unsigned bo = opaque_u((unsigned)lane * 16u);
+  return Frag2{ldg16(Bp0, bo), ldg16(Bp1, bo)};
+}
 template <int LDA>
 __device__ __forceinline__ void gemm_lds_packed(int a_off, const f32x4* __restrict__ Bp0,
                                                 const f32x4* __restrict__ Bp1, int nkg, f32x16& c00, f32x16& c01,
-                                                f32x16& c10, f32x16& c11, int lane) {
+                                                f32x16& c10, f32x16& c11, int lane, const Frag2& first) {
   const int r = lane & 31, h = lane >> 5;
   const int ab = 4 * opaque((a_off + r * LDA + 4 * h) >> 2);  // provably 16-byte aligned -> ds_read_b128
   unsigned bo = opaque_u((unsigned)lane * 16u);  // byte offset of this lane's fragment; +1024 per k-group
-  f32x4 pA = ldg16(Bp0, bo), qA = ldg16(Bp1, bo), pB, qB;
+  f32x4 pA = first.p, qA = first.q, pB, qB;
   f32x4 uA = *reinterpret_cast<const f32x4*>(&lds[ab]);
   f32x4 vA = *reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA]);
   f32x4 uB, vB;
@@ -274,38 +283,50 @@ struct Lay {
 // (without bias) in the head tile [64][FLDO].  All 4 waves participate; ends with a barrier.
 // ------------------------------------------------------------------------------------------------
 template <int DP>
-__device__ __forceinline__ void tile_forward(const FusedNet& W, int wave, int lane STAMP_PARAMS) {
+__device__ __forceinline__ Frag2 tile_layers(const FusedNet& W, int wave, int lane, const Frag2& f1 STAMP_PARAMS) {
   using L = Lay<DP>;
-  const int r = lane & 31, h = lane >> 5;
+  constexpr int nkg2 = FH / 8;
+  const f32x4* w2a = W.W2f + (size_t)(2 * wave) * nkg2 * 64;
+  const f32x4* w2b = W.W2f + (size_t)(2 * wave + 1) * nkg2 * 64;
+  Frag2 f2;
   {  // layer 1: K = DP
     f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
     constexpr int nkg = DP / 8;
     gemm_lds_packed<L::LDX>(L::X, W.W1f + (size_t)(2 * wave) * nkg * 64, W.W1f + (size_t)(2 * wave + 1) * nkg * 64,
-                            nkg, c00, c01, c10, c11, lane);
+                            nkg, c00, c01, c10, c11, lane, f1);
+    f2 = prefetch_frag(w2a, w2b, lane);
     STAMP(1)
     store_tanh(L::H1, W.b1, wave, lane, c00, c01, c10, c11);
     STAMP(2)
   }
   __syncthreads();
   STAMP(3)
+  // head GEMM operands: K split in two halves; wave = (khalf << 1) | rowblock
+  const f32x4* bp = W.W3f + (size_t)((wave >> 1) * 16) * 64;
+  Frag2 f3;
   {  // layer 2: K = H
     f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
-    constexpr int nkg = FH / 8;
-    gemm_lds_packed<FLDH>(L::H1, W.W2f + (size_t)(2 * wave) * nkg * 64, W.W2f + (size_t)(2 * wave + 1) * nkg * 64, nkg,
-                          c00, c01, c10, c11, lane);
+    gemm_lds_packed<FLDH>(L::H1, w2a, w2b, nkg2, c00, c01, c10, c11, lane, f2);
+    f3 = prefetch_frag(bp, bp + 64, lane);
     STAMP(4)
     store_tanh(L::H2, W.b2, wave, lane, c00, c01, c10, c11);
     STAMP(5)
   }
   __syncthreads();
   STAMP(6)
-  {  // head: [64 x 32] = h2 . W3^T, K split in two halves; wave = (khalf << 1) | rowblock
-    const int rb = wave & 1, ks = wave >> 1;
+  return f3;
+}
+template <int DP>
+__device__ __forceinline__ void tile_head(const FusedNet& W, int wave, int lane, const Frag2& f3 STAMP_PARAMS) {
+  using L = Lay<DP>;
+  const int r = lane & 31, h = lane >> 5;
+  const int rb = wave & 1, ks = wave >> 1;
+  const f32x4* bp = W.W3f + (size_t)(ks * 16) * 64;
+  {  // head: [64 x 32] = h2 . W3^T
     f32x16 acc = zero16(), acc2 = zero16();  // two independent chains (even / odd k-groups)
     const int ab = 4 * opaque((L::H2 + (rb * 32 + r) * FLDH + ks * 128 + 4 * h) >> 2);
-    const f32x4* bp = W.W3f + (size_t)(ks * 16) * 64;
     unsigned bo = opaque_u((unsigned)lane * 16u);
-    f32x4 bA = ldg16(bp, bo), bB = ldg16(bp, bo + 1024u);
+    f32x4 bA = f3.p, bB = f3.q;
     f32x4 aA = *reinterpret_cast<const f32x4*>(&lds[ab]), aB = *reinterpret_cast<const f32x4*>(&lds[ab + 8]);
     int ao = ab;
 #pragma unroll 1
@@ -406,6 +427,8 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   STAMP_INIT()
   for (int tile = wg; tile < ntiles; tile += nwg) {
     const int row0 = tile * FR;
+    const Frag2 f1 = prefetch_frag(W.W1f + (size_t)(2 * wave) * (DP / 8) * 64,
+                                   W.W1f + (size_t)(2 * wave + 1) * (DP / 8) * 64, lane);
     // ---- gather the observation rows of this tile (zero rows beyond the minibatch) ----
 #pragma unroll
     for (int i = tid; i < FR * per; i += FTHREADS) {
@@ -419,15 +442,36 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     }
     __syncthreads();
     STAMP(0)
-    tile_forward<DP>(W, wave, lane STAMP_ARGS);
+    const Frag2 f3 = tile_layers<DP>(W, wave, lane, f1 STAMP_ARGS);
+    // operands of the loss stage, fetched while the head GEMM runs (4 lanes per row, q = action residue mod 4)
+    const int lrr = tid >> 2, lq = tid & 3;
+    const bool llive = row0 + lrr < a.count;
+    float l_adv = 0.f, l_old = 0.f, l_act[8];
+    {
+      const unsigned src = llive ? (unsigned)a.rows[row0 + lrr] : 0u;
+      if (net == 0) {
+        const unsigned aoff = (src * (unsigned)a.A + (unsigned)lq) * 4u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          l_act[j] = (4 * j + lq < a.A && llive)
+                         ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.actions) + (aoff + 16u * j))
+                         : 0.f;
+        if (llive) { l_adv = a.adv[src]; l_old = a.old_logp[src]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) l_act[j] = 0.f;
+        if (llive) l_old = a.ret[src];
+      }
+    }
+    tile_head<DP>(W, wave, lane, f3 STAMP_ARGS);
     STAMP(8)
 
+    const Frag2 fh2 = prefetch_frag(W.W3b + (size_t)(2 * wave) * 4 * 64, W.W3b + (size_t)(2 * wave + 1) * 4 * 64, lane);
     // ---- loss: 4 lanes per row (q = action residue mod 4), all waves; writes dL/d(head output) into the
     //      head tile (zero padded) and accumulates the head-bias / log_std gradient sums per wave ----
     {
-      const int rr = tid >> 2, q = tid & 3;
-      const bool live = row0 + rr < a.count;
-      const int src = live ? a.rows[row0 + rr] : 0;
+      const int rr = lrr, q = lq;
+      const bool live = llive;
       const int db = opaque(L::DO + rr * FLDO + q);  // head tile row, this lane's action residue
       const int cb = opaque(L::CST + q);             // per-action constants: [0]=1/var [32]=log terms [64]=bias
       const int gb = opaque(L::GACC + wave * 64 + q);
@@ -435,13 +479,11 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
       if (net == 0) {
         float lp = 0.f;
         float dk[8];
-        const unsigned aoff = ((unsigned)src * (unsigned)A + (unsigned)q) * 4u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float d = 0.f;
           if (4 * j + q < A && live) {
-            d = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.actions) + (aoff + 16u * j)) -
-                (lds[db + 4 * j] + lds[cb + 64 + 4 * j]);
+            d = l_act[j] - (lds[db + 4 * j] + lds[cb + 64 + 4 * j]);
             lp += -(d * d) * (0.5f * lds[cb + 4 * j]) - lds[cb + 32 + 4 * j];
           }
           dk[j] = d;
@@ -450,9 +492,9 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
         lp += __shfl_xor(lp, 2, 64);
         float g_logp = 0.f;
         if (live) {
-          float adv = a.adv[src];
+          float adv = l_adv;
           if (a.normalize && adv_on) adv = (adv - adv_mean) / (adv_sd + 1e-8f);
-          const float log_ratio = lp - a.old_logp[src];
+          const float log_ratio = lp - l_old;
           const float ratio = expf(log_ratio);
           const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
           const float s1 = adv * ratio, s2 = adv * fminf(fmaxf(ratio, lo), hi);
@@ -486,7 +528,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
       } else {
         float dv = 0.f;
         if (live && q == 0) {
-          const float v = lds[db] + lds[cb + 64], rt = a.ret[src];
+          const float v = lds[db] + lds[cb + 64], rt = l_old;
           s_vl += (rt - v) * (rt - v);
           dv = a.vf_coef * 2.0f * (v - rt) * a.inv_bg;
         }
@@ -534,7 +576,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     {
       f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
       gemm_lds_packed<FLDO>(L::DO, W.W3b + (size_t)(2 * wave) * 4 * 64, W.W3b + (size_t)(2 * wave + 1) * 4 * 64, 4, c00,
-                            c01, c10, c11, lane);
+                            c01, c10, c11, lane, fh2);
       STAMP(11)
       __syncthreads();  // every wave is done reading h2 (dW3) before it is overwritten
       STAMP(12)
@@ -544,6 +586,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     __syncthreads();
     STAMP(14)
     // ---- dW2 += dz2^T . h1  (this wave: 64 neurons x 256 inputs, K = 64 rows) ----
+    const Frag2 fh1 = prefetch_frag(W.W2b + (size_t)(2 * wave) * (FH / 8) * 64, W.W2b + (size_t)(2 * wave + 1) * (FH / 8) * 64, lane);
     gb2 += column_sum(L::H2, tid);
     {
       const int ao = opaque(L::H2 + h * FLDH + 64 * wave + r);
@@ -561,7 +604,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
       f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
       constexpr int nkg = FH / 8;
       gemm_lds_packed<FLDH>(L::H2, W.W2b + (size_t)(2 * wave) * nkg * 64, W.W2b + (size_t)(2 * wave + 1) * nkg * 64, nkg,
-                            c00, c01, c10, c11, lane);
+                            c00, c01, c10, c11, lane, fh1);
       STAMP(16)
       __syncthreads();  // dW2 reads of h1 complete everywhere
       STAMP(17)
