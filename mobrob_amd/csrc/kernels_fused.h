@@ -256,6 +256,12 @@ struct Lay {
 // Diagnostic build (-DMOBROB_STAMPS): s_memtime stamps at phase boundaries, summed over waves into
 // a.stamps[phase] (cdna_hip_programming.md §7 'In-kernel stamps').  Never compiled into the product library.
 // ------------------------------------------------------------------------------------------------
+// Timing-only ablation builds (-DMOBROB_SKIP=<mask>): skip one phase of k_fused_train to price it in situ
+// (outputs are wrong by construction; never compiled into the product library).
+#ifndef MOBROB_SKIP
+#define MOBROB_SKIP 0
+#endif
+#define PHASE_ON(bit) (!((MOBROB_SKIP) & (bit)))
 #ifdef MOBROB_STAMPS
 #define STAMP(id)                                                                                  \
   {                                                                                                \
@@ -292,11 +298,13 @@ __device__ __forceinline__ Frag2 tile_layers(const FusedNet& W, int wave, int la
   {  // layer 1: K = DP
     f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
     constexpr int nkg = DP / 8;
-    gemm_lds_packed<L::LDX>(L::X, W.W1f + (size_t)(2 * wave) * nkg * 64, W.W1f + (size_t)(2 * wave + 1) * nkg * 64,
-                            nkg, c00, c01, c10, c11, lane, f1);
+    if (PHASE_ON(2))
+      gemm_lds_packed<L::LDX>(L::X, W.W1f + (size_t)(2 * wave) * nkg * 64, W.W1f + (size_t)(2 * wave + 1) * nkg * 64,
+                              nkg, c00, c01, c10, c11, lane, f1);
     f2 = prefetch_frag(w2a, w2b, lane);
     STAMP(1)
-    store_tanh(L::H1, W.b1, wave, lane, c00, c01, c10, c11);
+    if (PHASE_ON(1024)) store_tanh(L::H1, W.b1, wave, lane, c00, c01, c10, c11);
+    else asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
     STAMP(2)
   }
   __syncthreads();
@@ -306,10 +314,11 @@ __device__ __forceinline__ Frag2 tile_layers(const FusedNet& W, int wave, int la
   Frag2 f3;
   {  // layer 2: K = H
     f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
-    gemm_lds_packed<FLDH>(L::H1, w2a, w2b, nkg2, c00, c01, c10, c11, lane, f2);
+    if (PHASE_ON(4)) gemm_lds_packed<FLDH>(L::H1, w2a, w2b, nkg2, c00, c01, c10, c11, lane, f2);
     f3 = prefetch_frag(bp, bp + 64, lane);
     STAMP(4)
-    store_tanh(L::H2, W.b2, wave, lane, c00, c01, c10, c11);
+    if (PHASE_ON(1024)) store_tanh(L::H2, W.b2, wave, lane, c00, c01, c10, c11);
+    else asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
     STAMP(5)
   }
   __syncthreads();
@@ -434,7 +443,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     for (int i = tid; i < FR * per; i += FTHREADS) {
       const int rr = i / per, c = i - rr * per;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row0 + rr < a.count) {
+      if (PHASE_ON(1) && row0 + rr < a.count) {
         const unsigned src = (unsigned)a.rows[row0 + rr];
         v = ldg16(a.obs, src * (unsigned)(DP * 4) + (unsigned)(c * 16));
       }
@@ -463,13 +472,13 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
         if (llive) l_old = a.ret[src];
       }
     }
-    tile_head<DP>(W, wave, lane, f3 STAMP_ARGS);
+    if (PHASE_ON(8)) tile_head<DP>(W, wave, lane, f3 STAMP_ARGS);
     STAMP(8)
 
     const Frag2 fh2 = prefetch_frag(W.W3b + (size_t)(2 * wave) * 4 * 64, W.W3b + (size_t)(2 * wave + 1) * 4 * 64, lane);
     // ---- loss: 4 lanes per row (q = action residue mod 4), all waves; writes dL/d(head output) into the
     //      head tile (zero padded) and accumulates the head-bias / log_std gradient sums per wave ----
-    {
+    if (PHASE_ON(16)) {
       const int rr = lrr, q = lq;
       const bool live = llive;
       const int db = opaque(L::DO + rr * FLDO + q);  // head tile row, this lane's action residue
@@ -542,7 +551,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     STAMP(9)
 
     // ---- dW3 (+)= dout^T . h2  (M = 32 head rows, this wave's 64 columns, K = 64 rows) ----
-    {
+    if (PHASE_ON(32)) {
       const unsigned s3 = opaque_u((unsigned)(wave * 2 * 4 * 64 + lane) * 16u);  // [w][jb][quad][lane] x 16 B
       f32x4 o0[4], o1[4];  // running slab values, fetched while the MFMAs run
 #pragma unroll
@@ -575,20 +584,22 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     // ---- dh2 = dout . W3 (K = 32), then dz2 = dh2 * (1 - h2^2) in place ----
     {
       f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
-      gemm_lds_packed<FLDO>(L::DO, W.W3b + (size_t)(2 * wave) * 4 * 64, W.W3b + (size_t)(2 * wave + 1) * 4 * 64, 4, c00,
-                            c01, c10, c11, lane, fh2);
+      if (PHASE_ON(64))
+        gemm_lds_packed<FLDO>(L::DO, W.W3b + (size_t)(2 * wave) * 4 * 64, W.W3b + (size_t)(2 * wave + 1) * 4 * 64, 4,
+                              c00, c01, c10, c11, lane, fh2);
       STAMP(11)
       __syncthreads();  // every wave is done reading h2 (dW3) before it is overwritten
       STAMP(12)
-      dtanh_inplace(L::H2, wave, lane, c00, c01, c10, c11);
+      if (PHASE_ON(1024)) dtanh_inplace(L::H2, wave, lane, c00, c01, c10, c11);
+      else asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
       STAMP(13)
     }
     __syncthreads();
     STAMP(14)
     // ---- dW2 += dz2^T . h1  (this wave: 64 neurons x 256 inputs, K = 64 rows) ----
     const Frag2 fh1 = prefetch_frag(W.W2b + (size_t)(2 * wave) * (FH / 8) * 64, W.W2b + (size_t)(2 * wave + 1) * (FH / 8) * 64, lane);
-    gb2 += column_sum(L::H2, tid);
-    {
+    if (PHASE_ON(2048)) gb2 += column_sum(L::H2, tid);
+    if (PHASE_ON(128)) {
       const int ao = opaque(L::H2 + h * FLDH + 64 * wave + r);
       const int bo = opaque(L::H1 + h * FLDH + r);
 #pragma unroll 2
@@ -603,30 +614,34 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     {
       f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
       constexpr int nkg = FH / 8;
-      gemm_lds_packed<FLDH>(L::H2, W.W2b + (size_t)(2 * wave) * nkg * 64, W.W2b + (size_t)(2 * wave + 1) * nkg * 64, nkg,
-                            c00, c01, c10, c11, lane, fh1);
+      if (PHASE_ON(256))
+        gemm_lds_packed<FLDH>(L::H2, W.W2b + (size_t)(2 * wave) * nkg * 64, W.W2b + (size_t)(2 * wave + 1) * nkg * 64,
+                              nkg, c00, c01, c10, c11, lane, fh1);
       STAMP(16)
       __syncthreads();  // dW2 reads of h1 complete everywhere
       STAMP(17)
-      dtanh_inplace(L::H1, wave, lane, c00, c01, c10, c11);
+      if (PHASE_ON(1024)) dtanh_inplace(L::H1, wave, lane, c00, c01, c10, c11);
+      else asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
       STAMP(18)
     }
     __syncthreads();
     STAMP(19)
     // ---- dW1 (+)= dz1^T . X  (this wave: 64 neurons x DP inputs, K = 64 rows) ----
-    gb1 += column_sum(L::H1, tid);
-    {
+    if (PHASE_ON(2048)) gb1 += column_sum(L::H1, tid);
+    if (PHASE_ON(512)) {
       constexpr bool two = DP > 32;
       const unsigned s1 = opaque_u((unsigned)(wave * 4 * 4 * 64 + lane) * 16u);  // [w][ib*2+jb][quad][lane] x 16 B
       f32x4 o00[4], o10[4], o01[4], o11[4];  // running slab values, fetched while the MFMAs run
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
+        if (PHASE_ON(4096)) {
         o00[qd] = ldg16(slab_w1, s1 + (0 * 4 + qd) * 1024u);
         o10[qd] = ldg16(slab_w1, s1 + (2 * 4 + qd) * 1024u);
         if (two) {
           o01[qd] = ldg16(slab_w1, s1 + (1 * 4 + qd) * 1024u);
           o11[qd] = ldg16(slab_w1, s1 + (3 * 4 + qd) * 1024u);
         }
+        } else { o00[qd] = o10[qd] = o01[qd] = o11[qd] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       }
       f32x16 t00 = zero16(), t10 = zero16(), t01 = zero16(), t11 = zero16();
       const int ao = opaque(L::H1 + h * FLDH + 64 * wave + r);
@@ -657,12 +672,14 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
             v11[e] = (first ? 0.f : o11[qd][e]) + t11[4 * qd + e];
           }
         }
+        if (PHASE_ON(8192)) {
         stg16(slab_w1, s1 + (0 * 4 + qd) * 1024u, v00);
         stg16(slab_w1, s1 + (2 * 4 + qd) * 1024u, v10);
         if (two) {
           stg16(slab_w1, s1 + (1 * 4 + qd) * 1024u, v01);
           stg16(slab_w1, s1 + (3 * 4 + qd) * 1024u, v11);
         }
+        } else { asm volatile("" ::"v"(v00), "v"(v10), "v"(v01), "v"(v11)); }
       }
     }
     first = false;
