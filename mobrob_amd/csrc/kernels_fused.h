@@ -384,9 +384,8 @@ template <int DP>
 __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   using L = Lay<DP>;
   constexpr int ldx = L::LDX, per = DP / 4;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> SGPR addressing of weights/slabs
-  const int r = lane & 31, h = lane >> 5;
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);  // wave-uniform -> SGPR addressing of weights/slabs
   const int net = blockIdx.x & 1, wg = blockIdx.x >> 1, nwg = gridDim.x >> 1;
   const FusedNet W = a.net[net];
   const int ntiles = (a.count + FR - 1) / FR;
@@ -396,15 +395,18 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   f32x16 gW2[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t) gW2[t] = zero16();
+  // dW1 (4 tiles) and dW3 (2 tiles) accumulate in arch VGPRs across all tiles of the workgroup (96 registers):
+  // the hot GEMM loops need ~100 VGPRs, so everything fits without spilling and no per-tile slab traffic remains.
+  f32x16 gW1a = zero16(), gW1b = zero16(), gW1c = zero16(), gW1d = zero16();  // [ib][jb] = 00, 10, 01, 11
+  f32x16 gW3a = zero16(), gW3b = zero16();
   float* slab = a.slabs + (size_t)blockIdx.x * a.slab_floats;
   float* slab_w1 = slab + slab_off_w1();
   float* slab_w3 = slab + slab_off_w3(DP);
-  bool first = true;
   float gb2 = 0.f, gb1 = 0.f;  // bias gradients of hidden column `tid`
   float s_pl = 0.f, s_vl = 0.f, s_kl = 0.f, s_cf = 0.f;  // loss statistics (lanes with q == 0)
   // per-action constants of the Gaussian head and the per-wave head-gradient accumulators
-  if (tid < 32) {
-    const int k = tid;
+  if (tid0 < 32) {
+    const int k = tid0;
     float iv = 0.f, lc = 0.f, bb = 0.f;
     if (net == 0 && k < a.A) {
       const float sd = expf(a.log_std[k]);
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     lds[L::CST + 32 + k] = lc;
     lds[L::CST + 64 + k] = bb;
   }
-  lds[L::GACC + tid] = 0.f;
+  lds[L::GACC + tid0] = 0.f;
 
   float adv_mean = 0.f, adv_sd = 1.f;
   bool adv_on = false;
@@ -435,6 +437,10 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
 #endif
   STAMP_INIT()
   for (int tile = wg; tile < ntiles; tile += nwg) {
+    // Per-lane indices are re-derived from an opaque copy of the thread id in every tile: otherwise LLVM hoists
+    // every address base that depends only on the lane out of this loop and keeps ~40 of them live (and spilled).
+    const int tid = opaque(tid0), lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
     const int row0 = tile * FR;
     const Frag2 f1 = prefetch_frag(W.W1f + (size_t)(2 * wave) * (DP / 8) * 64,
                                    W.W1f + (size_t)(2 * wave + 1) * (DP / 8) * 64, lane);
@@ -550,35 +556,20 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     __syncthreads();
     STAMP(9)
 
-    // ---- dW3 (+)= dout^T . h2  (M = 32 head rows, this wave's 64 columns, K = 64 rows) ----
+    // ---- dW3 += dout^T . h2  (M = 32 head rows, this wave's 64 columns, K = 64 rows) ----
     if (PHASE_ON(32)) {
-      const unsigned s3 = opaque_u((unsigned)(wave * 2 * 4 * 64 + lane) * 16u);  // [w][jb][quad][lane] x 16 B
-      f32x4 o0[4], o1[4];  // running slab values, fetched while the MFMAs run
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        o0[qd] = ldg16(slab_w3, s3 + qd * 1024u);
-        o1[qd] = ldg16(slab_w3, s3 + (4 + qd) * 1024u);
-      }
-      f32x16 t0 = zero16(), t1 = zero16();
       const int ao = opaque(L::DO + h * FLDO + r);              // A[i=a][k=row] = dout[row][a]
       const int bo = opaque(L::H2 + h * FLDH + 64 * wave + r);  // B[k=row][j]  = h2[row][j]
+      float x = lds[ao], y0 = lds[bo], y1 = lds[bo + 32];
 #pragma unroll 4
-      for (int k = 0; k < FR; k += 2) {
-        const float x = lds[ao + k * FLDO];
-        t0 = MFMA32(x, lds[bo + k * FLDH], t0);
-        t1 = MFMA32(x, lds[bo + k * FLDH + 32], t1);
+      for (int k = 0; k < FR - 2; k += 2) {
+        const float xn = lds[ao + (k + 2) * FLDO], y0n = lds[bo + (k + 2) * FLDH], y1n = lds[bo + (k + 2) * FLDH + 32];
+        gW3a = MFMA32(x, y0, gW3a);
+        gW3b = MFMA32(x, y1, gW3b);
+        x = xn; y0 = y0n; y1 = y1n;
       }
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        f32x4 v0, v1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v0[e] = (first ? 0.f : o0[qd][e]) + t0[4 * qd + e];
-          v1[e] = (first ? 0.f : o1[qd][e]) + t1[4 * qd + e];
-        }
-        stg16(slab_w3, s3 + qd * 1024u, v0);
-        stg16(slab_w3, s3 + (4 + qd) * 1024u, v1);
-      }
+      gW3a = MFMA32(x, y0, gW3a);
+      gW3b = MFMA32(x, y1, gW3b);
     }
     STAMP(10)
     // ---- dh2 = dout . W3 (K = 32), then dz2 = dh2 * (1 - h2^2) in place ----
@@ -626,72 +617,71 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     }
     __syncthreads();
     STAMP(19)
-    // ---- dW1 (+)= dz1^T . X  (this wave: 64 neurons x DP inputs, K = 64 rows) ----
+    // ---- dW1 += dz1^T . X  (this wave: 64 neurons x DP inputs, K = 64 rows) ----
     if (PHASE_ON(2048)) gb1 += column_sum(L::H1, tid);
     if (PHASE_ON(512)) {
       constexpr bool two = DP > 32;
-      const unsigned s1 = opaque_u((unsigned)(wave * 4 * 4 * 64 + lane) * 16u);  // [w][ib*2+jb][quad][lane] x 16 B
-      f32x4 o00[4], o10[4], o01[4], o11[4];  // running slab values, fetched while the MFMAs run
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        if (PHASE_ON(4096)) {
-        o00[qd] = ldg16(slab_w1, s1 + (0 * 4 + qd) * 1024u);
-        o10[qd] = ldg16(slab_w1, s1 + (2 * 4 + qd) * 1024u);
-        if (two) {
-          o01[qd] = ldg16(slab_w1, s1 + (1 * 4 + qd) * 1024u);
-          o11[qd] = ldg16(slab_w1, s1 + (3 * 4 + qd) * 1024u);
-        }
-        } else { o00[qd] = o10[qd] = o01[qd] = o11[qd] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      }
-      f32x16 t00 = zero16(), t10 = zero16(), t01 = zero16(), t11 = zero16();
       const int ao = opaque(L::H1 + h * FLDH + 64 * wave + r);
       const int c0 = (r < DP) ? r : 0;
-      const int c1 = (32 + r < DP) ? 32 + r : c0;  // clamped columns are never stored
+      const int c1 = (32 + r < DP) ? 32 + r : c0;  // clamped columns are never read back
       const int b0o = opaque(L::X + h * ldx + c0), b1o = opaque(L::X + h * ldx + c1);
+      float x0 = lds[ao], x1 = lds[ao + 32], y0 = lds[b0o], y1 = two ? lds[b1o] : 0.f;
 #pragma unroll 4
-      for (int k = 0; k < FR; k += 2) {
-        const float x0 = lds[ao + k * FLDH], x1 = lds[ao + k * FLDH + 32];
-        const float y0 = lds[b0o + k * ldx];
-        t00 = MFMA32(x0, y0, t00);
-        t10 = MFMA32(x1, y0, t10);
+      for (int k = 0; k < FR - 2; k += 2) {  // operands of step k+2 are fetched before the MFMAs of step k
+        const float x0n = lds[ao + (k + 2) * FLDH], x1n = lds[ao + (k + 2) * FLDH + 32];
+        const float y0n = lds[b0o + (k + 2) * ldx], y1n = two ? lds[b1o + (k + 2) * ldx] : 0.f;
+        gW1a = MFMA32(x0, y0, gW1a);
+        gW1b = MFMA32(x1, y0, gW1b);
         if (two) {
-          const float y1 = lds[b1o + k * ldx];
-          t01 = MFMA32(x0, y1, t01);
-          t11 = MFMA32(x1, y1, t11);
+          gW1c = MFMA32(x0, y1, gW1c);
+          gW1d = MFMA32(x1, y1, gW1d);
         }
+        x0 = x0n; x1 = x1n; y0 = y0n; y1 = y1n;
       }
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        f32x4 v00, v10, v01, v11;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v00[e] = (first ? 0.f : o00[qd][e]) + t00[4 * qd + e];
-          v10[e] = (first ? 0.f : o10[qd][e]) + t10[4 * qd + e];
-          if (two) {
-            v01[e] = (first ? 0.f : o01[qd][e]) + t01[4 * qd + e];
-            v11[e] = (first ? 0.f : o11[qd][e]) + t11[4 * qd + e];
-          }
-        }
-        if (PHASE_ON(8192)) {
-        stg16(slab_w1, s1 + (0 * 4 + qd) * 1024u, v00);
-        stg16(slab_w1, s1 + (2 * 4 + qd) * 1024u, v10);
-        if (two) {
-          stg16(slab_w1, s1 + (1 * 4 + qd) * 1024u, v01);
-          stg16(slab_w1, s1 + (3 * 4 + qd) * 1024u, v11);
-        }
-        } else { asm volatile("" ::"v"(v00), "v"(v10), "v"(v01), "v"(v11)); }
+      gW1a = MFMA32(x0, y0, gW1a);
+      gW1b = MFMA32(x1, y0, gW1b);
+      if (two) {
+        gW1c = MFMA32(x0, y1, gW1c);
+        gW1d = MFMA32(x1, y1, gW1d);
       }
     }
-    first = false;
     STAMP(20)
     __syncthreads();  // X / h1 / h2 are rewritten by the next tile
     STAMP(21)
   }
 
+  const int tid = tid0, lane = tid & 63;
   // ---- store this workgroup's partial gradients to its slab ----
   STAMP(22)
   {
     asm volatile("s_nop 15\n\ts_nop 3");  // last asm MFMA's D -> v_accvgpr_read (16-pass XDL)
+    {  // dW1 / dW3 tiles, fragment order: [w][tile][quad][lane] x 16 B
+      const unsigned s1 = (unsigned)(wave * 4 * 4 * 64 + lane) * 16u, s3 = (unsigned)(wave * 2 * 4 * 64 + lane) * 16u;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gW1a[4 * qd + e];
+        stg16(slab_w1, s1 + (0 * 4 + qd) * 1024u, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gW1b[4 * qd + e];
+        stg16(slab_w1, s1 + (2 * 4 + qd) * 1024u, v);
+        if (DP > 32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gW1c[4 * qd + e];
+          stg16(slab_w1, s1 + (1 * 4 + qd) * 1024u, v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gW1d[4 * qd + e];
+          stg16(slab_w1, s1 + (3 * 4 + qd) * 1024u, v);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gW3a[4 * qd + e];
+        stg16(slab_w3, s3 + qd * 1024u, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gW3b[4 * qd + e];
+        stg16(slab_w3, s3 + (4 + qd) * 1024u, v);
+      }
+    }
     float* w2base = slab + slab_off_w2();
     const unsigned s2 = (unsigned)(wave * 16 * 4 * 64 + lane) * 16u;  // [w][t][quad][lane] x 16 B
 #pragma unroll
