@@ -193,6 +193,34 @@ __device__ __forceinline__ void dw2_kstep(f32x16 (&g)[16], float x0, float x1, f
       : "v"(x0), "v"(x1), "v"(y0), "v"(y1), "v"(y2), "v"(y3), "v"(y4), "v"(y5), "v"(y6), "v"(y7));
 }
 
+// Small TN phases (dW3, dW1) keep their accumulators in arch VGPRs; the MFMAs of one k-step are issued as one
+// opaque statement so that the compiler cannot split the interleaved chains into separate passes (it did, spilling
+// every second operand).  "s_nop 1": VALU-written operand -> MFMA.  The accumulators are only read at kernel end.
+__device__ __forceinline__ void mfma_x1y2(f32x16& c0, f32x16& c1, float x, float y0, float y1) {
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f32_32x32x2_f32 %0, %2, %3, %0\n\t"
+               "v_mfma_f32_32x32x2_f32 %1, %2, %4, %1"
+               : "+v"(c0), "+v"(c1)
+               : "v"(x), "v"(y0), "v"(y1));
+}
+__device__ __forceinline__ void mfma_x2y1(f32x16& c0, f32x16& c1, float x0, float x1, float y) {
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f32_32x32x2_f32 %0, %2, %4, %0\n\t"
+               "v_mfma_f32_32x32x2_f32 %1, %3, %4, %1"
+               : "+v"(c0), "+v"(c1)
+               : "v"(x0), "v"(x1), "v"(y));
+}
+__device__ __forceinline__ void mfma_x2y2(f32x16& c00, f32x16& c10, f32x16& c01, f32x16& c11, float x0, float x1,
+                                          float y0, float y1) {
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f32_32x32x2_f32 %0, %4, %6, %0\n\t"
+               "v_mfma_f32_32x32x2_f32 %1, %5, %6, %1\n\t"
+               "v_mfma_f32_32x32x2_f32 %2, %4, %7, %2\n\t"
+               "v_mfma_f32_32x32x2_f32 %3, %5, %7, %3"
+               : "+v"(c00), "+v"(c10), "+v"(c01), "+v"(c11)
+               : "v"(x0), "v"(x1), "v"(y0), "v"(y1));
+}
+
 // ------------------------------------------------------------------------------------------------
 // epilogue helpers for the wave's 64x64 output block (2 column blocks x 2 row blocks, C layout)
 // ------------------------------------------------------------------------------------------------
@@ -564,12 +592,10 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
 #pragma unroll 4
       for (int k = 0; k < FR - 2; k += 2) {
         const float xn = lds[ao + (k + 2) * FLDO], y0n = lds[bo + (k + 2) * FLDH], y1n = lds[bo + (k + 2) * FLDH + 32];
-        gW3a = MFMA32(x, y0, gW3a);
-        gW3b = MFMA32(x, y1, gW3b);
+        mfma_x1y2(gW3a, gW3b, x, y0, y1);
         x = xn; y0 = y0n; y1 = y1n;
       }
-      gW3a = MFMA32(x, y0, gW3a);
-      gW3b = MFMA32(x, y1, gW3b);
+      mfma_x1y2(gW3a, gW3b, x, y0, y1);
     }
     STAMP(10)
     // ---- dh2 = dout . W3 (K = 32), then dz2 = dh2 * (1 - h2^2) in place ----
@@ -630,20 +656,12 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
       for (int k = 0; k < FR - 2; k += 2) {  // operands of step k+2 are fetched before the MFMAs of step k
         const float x0n = lds[ao + (k + 2) * FLDH], x1n = lds[ao + (k + 2) * FLDH + 32];
         const float y0n = lds[b0o + (k + 2) * ldx], y1n = two ? lds[b1o + (k + 2) * ldx] : 0.f;
-        gW1a = MFMA32(x0, y0, gW1a);
-        gW1b = MFMA32(x1, y0, gW1b);
-        if (two) {
-          gW1c = MFMA32(x0, y1, gW1c);
-          gW1d = MFMA32(x1, y1, gW1d);
-        }
+        if (two) mfma_x2y2(gW1a, gW1b, gW1c, gW1d, x0, x1, y0, y1);
+        else mfma_x2y1(gW1a, gW1b, x0, x1, y0);
         x0 = x0n; x1 = x1n; y0 = y0n; y1 = y1n;
       }
-      gW1a = MFMA32(x0, y0, gW1a);
-      gW1b = MFMA32(x1, y0, gW1b);
-      if (two) {
-        gW1c = MFMA32(x0, y1, gW1c);
-        gW1d = MFMA32(x1, y1, gW1d);
-      }
+      if (two) mfma_x2y2(gW1a, gW1b, gW1c, gW1d, x0, x1, y0, y1);
+      else mfma_x2y1(gW1a, gW1b, x0, x1, y0);
     }
     STAMP(20)
     __syncthreads();  // X / h1 / h2 are rewritten by the next tile
