@@ -20,7 +20,7 @@ else:
     base = None
     names = {0: "full", 1: "gather loads", 2: "L1 gemm", 4: "L2 gemm", 8: "head gemm+reduce", 16: "loss stage", 32: "dW3+RMW",
              64: "dh2 gemm", 128: "dW2", 256: "dh1 gemm", 512: "dW1+RMW", 1024: "all epilogues", 2048: "column sums", 4096: "dW1 slab loads", 8192: "dW1 slab stores", 12288: "dW1 slab ld+st"}
-    for m in [0, 512, 4096, 8192, 12288]:
+    for m in [0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048]:
         out = subprocess.run([sys.executable, __file__, str(m)], capture_output=True, text=True).stdout.strip().splitlines()[-1]
         v = json.loads(out)["ms_per_launch"]
         if m == 0:
