@@ -150,8 +150,16 @@ def main():
         env_steps = N * T * world * args.steps
         nmb = eng.n_minibatches
         ms, calls = prof["train_grad"]
-        flops_per_launch = 3.0 * f_fwd(D, H, A) * B  # forward + 2x backward over one minibatch
+        # ALGORITHMIC flops of the dominant kernel: forward + 2x backward = 3*F_fwd per sample, times
+        # the samples one launch processes (T*N*E samples per iteration spread over its launches; the last
+        # minibatch of an epoch is short when batch does not divide T*N)
+        flops_per_launch = 3.0 * f_fwd(D, H, A) * (float(N) * T * E * args.steps) / max(calls, 1)
         achieved = (flops_per_launch * calls / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r1", "hbm_traffic_pmc.json")
+        if os.path.exists(tj) and not args.generic and args.workload == "doggo-4096env-2x256":
+            k = json.load(open(tj))["kernels"].get("void mobrob::k_fused_train<64>")
+            traffic = k["hbm_bytes_per_launch_corrected"] if k else None
         out = {
             "metric": "env-steps/sec (whole node), doggo PPO" if "doggo" in args.workload else "env-steps/sec (whole node)",
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -161,9 +169,10 @@ def main():
                        "n_steps": T, "n_epochs": E, "minibatch_per_gpu": B, "minibatches_per_epoch": nmb,
                        "env_source": "device-resident synthetic (Philox)", "parallelism": f"dp{world}",
                        "kernels": "generic" if args.generic else "fused"},
-            "roofline": {"bound": "mfma", "kernel": "minibatch forward+loss+backward (train_grad)",
+            "roofline": {"bound": "mfma", "kernel": "k_fused_train (minibatch forward+loss+backward)" if not args.generic else "generic GEMM chain",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/r1/hbm_traffic_pmc.json)",
                          "avg_launch_ms": ms / max(calls, 1), "launches": calls,
                          "flops_per_launch": flops_per_launch},
             "phase_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},

@@ -205,10 +205,11 @@ int mobrob_ppo_feistel_permutation(mobrob_ppo_engine_t* e, int64_t n, uint64_t k
 enum {
   MOBROB_K_ACT = 0,          /* rollout policy/value forward + sample                           */
   MOBROB_K_GAE = 1,          /* GAE(lambda) scan                                                */
-  MOBROB_K_TRAIN_GRAD = 2,   /* minibatch forward + loss + backward (dominant)                  */
+  MOBROB_K_TRAIN_GRAD = 2,   /* minibatch forward + loss + backward (dominant kernel)           */
   MOBROB_K_APPLY = 3,        /* grad-norm + clip + Adam                                         */
-  MOBROB_K_ENV = 4,          /* synthetic env source                                            */
-  MOBROB_K_COUNT = 5
+  MOBROB_K_ENV = 4,          /* synthetic env source (+ time-limit bootstrap)                   */
+  MOBROB_K_GRAD_REDUCE = 5,  /* deterministic reduction of the per-workgroup gradient slabs     */
+  MOBROB_K_COUNT = 6
 };
 int mobrob_ppo_profile_enable(mobrob_ppo_engine_t* e, int32_t on);
 /* accumulated since enable: total milliseconds and launch-group count per id */

@@ -325,7 +325,11 @@ void fused_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, float 
   const int ntiles = cdiv(B, FR);
   const int grid = 2 * std::min(f.max_grid / 2, ntiles);
   (void)hipMemsetAsync(e->grads + e->P, 0, 8 * sizeof(float), e->stream);
-  fused_launch_train(f, a, grid, e->stream);
+  {
+    ProfScope ps(e, MOBROB_K_TRAIN_GRAD);
+    fused_launch_train(f, a, grid, e->stream);
+  }
+  ProfScope pr(e, MOBROB_K_GRAD_REDUCE);
   SlabReduceArgs s{};
   s.slabs = f.slabs; s.slab_floats = f.slab_floats; s.nslabs = grid; s.grads = e->grads; s.P = e->P;
   for (int i = 0; i < 14; ++i) s.offs[i] = e->offs[i];
@@ -656,7 +660,6 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   if (!e->epoch_open) return fail(MOBROB_ERR_STATE, "minibatch_grad before epoch_begin");
   if (mb < 0 || mb >= e->nmb) return fail(MOBROB_ERR_INVALID, "minibatch %d out of range [0,%d)", mb, e->nmb);
-  ProfScope ps(e, MOBROB_K_TRAIN_GRAD);
   const int total = e->N * e->T;
   const int start = mb * e->Bl;
   const int B = std::min(e->Bl, total - start);
@@ -668,6 +671,7 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
     e->grad_pending = true;
     return MOBROB_OK;
   }
+  ProfScope ps(e, MOBROB_K_TRAIN_GRAD);
   HIPC(hipMemsetAsync(e->grads, 0, (size_t)(e->P + 8) * 4, e->stream));
   float* sums = e->grads + e->P;
   const int per = e->Dp / 4;

@@ -271,6 +271,6 @@ class PPOEngine:
         check(self.lib.mobrob_ppo_profile_enable(self._h, int(on)))
 
     def profile_read(self):
-        ms, calls = (C.c_double * 5)(), (C.c_int64 * 5)()
+        ms, calls = (C.c_double * 6)(), (C.c_int64 * 6)()
         check(self.lib.mobrob_ppo_profile_read(self._h, ms, calls))
         return {k: (float(ms[i]), int(calls[i])) for k, i in _lib.KERNEL_IDS.items()}
