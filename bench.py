@@ -97,14 +97,21 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # MOBROB_FORCE_DP=1 runs the data-parallel code path (process group, zero-copy tensor views, all-reduces) even
+    # at world size 1 -- used to validate the multi-GPU plumbing on a single-GPU box.
+    force_dp = os.environ.get("MOBROB_FORCE_DP", "0") == "1"
+    use_dp = world > 1 or force_dp
+    if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__
     if rank == 0:
         __graft_entry__.build()
-    if world > 1:
+    if use_dp:
         dist.barrier()
     from mobrob_amd.engine import PPOEngine
     from mobrob_amd.parallel import EngineBackend, train_data_parallel
@@ -114,19 +121,19 @@ def main():
                     gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.01, seed=0, device_id=local_rank,
                     rank=rank, world_size=world, fast_kernels=not args.generic)
     eng.set_params(init_params(D, A, H, seed=0))  # identical replicas on every rank
-    backend = EngineBackend(eng) if world > 1 else None
+    backend = EngineBackend(eng) if use_dp else None
 
     def iteration():
         eng.collect_synthetic(p_term=w["p_term"], time_limit=w["tl"])
-        if world > 1:
-            train_data_parallel(backend)
+        if use_dp:
+            train_data_parallel(backend, force_collectives=force_dp)
         else:
             eng.train(None)
 
     def fence():
         eng.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dp:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -141,7 +148,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile(False)
-    if world > 1:
+    if use_dp:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -180,7 +187,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dp:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

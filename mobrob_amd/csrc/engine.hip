@@ -244,6 +244,9 @@ void value_flagged(mobrob_ppo_engine* e, const float* obs_rows, const uint8_t* f
                      bootstrap_rewards, (float)e->cfg.gamma);
 }
 
+// Philox key of the action-noise stream: data-parallel ranks must not share it
+uint64_t eps_seed(const mobrob_ppo_engine* e) { return e->cfg.seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(e->cfg.rank + 1)); }
+
 void run_gae(mobrob_ppo_engine* e) {
   ProfScope ps(e, MOBROB_K_GAE);
   const double gl = e->cfg.gamma * e->cfg.gae_lambda;  // python: self.gamma * self.gae_lambda (float64)
@@ -259,7 +262,7 @@ void act_slot(mobrob_ppo_engine* e, int t, const float* eps_dev_or_null) {
     FusedActArgs a{};
     a.X = X; a.rows = e->N; a.want_pi = 1; a.want_v = 1; a.mu = nullptr; a.ldmu = e->Ap;
     a.v = e->values + (size_t)t * e->N; a.sample = 1; a.A = e->A; a.log_std = Pp(e, T_LOGSTD); a.eps = eps_dev_or_null;
-    a.seed = e->cfg.seed; a.draw = e->draw_counter; a.lo = (float)e->cfg.action_low; a.hi = (float)e->cfg.action_high;
+    a.seed = eps_seed(e); a.draw = e->draw_counter; a.lo = (float)e->cfg.action_low; a.hi = (float)e->cfg.action_high;
     a.act_raw = e->actions + (size_t)t * e->N * e->A; a.act_clip = e->clip_act; a.logp = e->logp + (size_t)t * e->N;
     fused_launch_act(e->fused, a, e->stream);
     e->draw_counter++;
@@ -267,7 +270,7 @@ void act_slot(mobrob_ppo_engine* e, int t, const float* eps_dev_or_null) {
   }
   forward(e, X, e->N, true, e->mu, true, e->values + (size_t)t * e->N);
   hipLaunchKernelGGL(k_sample, dim3(cdiv(e->N, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, Pp(e, T_LOGSTD),
-                     eps_dev_or_null, e->N, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high, e->cfg.seed,
+                     eps_dev_or_null, e->N, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high, eps_seed(e),
                      e->draw_counter, e->actions + (size_t)t * e->N * e->A, e->clip_act, e->logp + (size_t)t * e->N);
   e->draw_counter++;
 }
@@ -811,7 +814,7 @@ int mobrob_ppo_predict(mobrob_ppo_engine_t* e, const float* obs, int32_t n, int3
           epsd = e->eps_dev;
         }
         hipLaunchKernelGGL(k_sample, dim3(cdiv(c, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, Pp(e, T_LOGSTD), epsd,
-                           c, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high, e->cfg.seed, e->draw_counter,
+                           c, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high, eps_seed(e), e->draw_counter,
                            (float*)nullptr, scratch, (float*)nullptr);
         e->draw_counter++;
       }

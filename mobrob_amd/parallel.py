@@ -72,15 +72,17 @@ class EngineBackend:
         self.e.minibatch_apply()
 
 
-def train_data_parallel(backend, perms=None, group=None):
-    """PPO.train() across ranks.  perms: per-epoch LOCAL permutations ([n_epochs, T*N_local]) or None."""
+def train_data_parallel(backend, perms=None, group=None, force_collectives=False):
+    """PPO.train() across ranks.  perms: per-epoch LOCAL permutations ([n_epochs, T*N_local]) or None.
+    force_collectives issues the all-reduces even at world size 1 (plumbing self-test)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    comm = world > 1 or (force_collectives and dist.is_initialized())
     for ep in range(backend.n_epochs):
         backend.epoch_begin(None if perms is None else perms[ep])
-        if world > 1:
+        if comm:
             dist.all_reduce(backend.advstat_tensor(), op=dist.ReduceOp.SUM, group=group)
         for mb in range(backend.n_minibatches):
             backend.minibatch_grad(mb)
-            if world > 1:
+            if comm:
                 dist.all_reduce(backend.grad_tensor(), op=dist.ReduceOp.SUM, group=group)
             backend.minibatch_apply()
