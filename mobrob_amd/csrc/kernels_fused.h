@@ -464,6 +464,18 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   unsigned long long* stamps_ = a.stamps;
 #endif
   STAMP_INIT()
+  // software-pipelined gather: xr holds the X rows of the tile about to be processed (zero beyond the minibatch)
+  constexpr int NG = (FR * per + FTHREADS - 1) / FTHREADS;
+  static_assert((FR * per) % FTHREADS == 0, "gather assumes a whole number of 16-byte chunks per thread");
+  f32x4 xr[NG];
+  int nsrc[NG];
+#pragma unroll
+  for (int u = 0; u < NG; ++u) {
+    const int i = tid0 + u * FTHREADS, rr = i / per, c = i - rr * per;
+    xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (PHASE_ON(1) && wg < ntiles && wg * FR + rr < a.count)
+      xr[u] = ldg16(a.obs, (unsigned)a.rows[wg * FR + rr] * (unsigned)(DP * 4) + (unsigned)(c * 16));
+  }
   for (int tile = wg; tile < ntiles; tile += nwg) {
     // Per-lane indices are re-derived from an opaque copy of the thread id in every tile: otherwise LLVM hoists
     // every address base that depends only on the lane out of this loop and keeps ~40 of them live (and spilled).
@@ -472,16 +484,18 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     const int row0 = tile * FR;
     const Frag2 f1 = prefetch_frag(W.W1f + (size_t)(2 * wave) * (DP / 8) * 64,
                                    W.W1f + (size_t)(2 * wave + 1) * (DP / 8) * 64, lane);
-    // ---- gather the observation rows of this tile (zero rows beyond the minibatch) ----
+    // ---- the observation rows of this tile were fetched during the previous tile's dW1 phase ----
 #pragma unroll
-    for (int i = tid; i < FR * per; i += FTHREADS) {
-      const int rr = i / per, c = i - rr * per;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (PHASE_ON(1) && row0 + rr < a.count) {
-        const unsigned src = (unsigned)a.rows[row0 + rr];
-        v = ldg16(a.obs, src * (unsigned)(DP * 4) + (unsigned)(c * 16));
-      }
-      *reinterpret_cast<f32x4*>(&lds[L::X + rr * ldx + 4 * c]) = v;
+    for (int u = 0; u < NG; ++u) {
+      const int i = tid + u * FTHREADS, rr = i / per, c = i - rr * per;
+      *reinterpret_cast<f32x4*>(&lds[L::X + rr * ldx + 4 * c]) = xr[u];
+    }
+    // row indices of the NEXT tile (their observation loads are issued before this tile's dW1 phase)
+    const int nrow0 = (tile + nwg) * FR;
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int rr = (tid + u * FTHREADS) / per;
+      nsrc[u] = (PHASE_ON(1) && tile + nwg < ntiles && nrow0 + rr < a.count) ? a.rows[nrow0 + rr] : -1;
     }
     __syncthreads();
     STAMP(0)
@@ -644,6 +658,12 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     __syncthreads();
     STAMP(19)
     // ---- dW1 += dz1^T . X  (this wave: 64 neurons x DP inputs, K = 64 rows) ----
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {  // next tile's X rows: in flight during dW1, written to LDS at the loop top
+      const int c = (tid + u * FTHREADS) % per;
+      xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (nsrc[u] >= 0) xr[u] = ldg16(a.obs, (unsigned)nsrc[u] * (unsigned)(DP * 4) + (unsigned)(c * 16));
+    }
     if (PHASE_ON(2048)) gb1 += column_sum(L::H1, tid);
     if (PHASE_ON(512)) {
       constexpr bool two = DP > 32;
