@@ -288,7 +288,7 @@ int fused_init(mobrob_ppo_engine* e) {
   f.D = e->D; f.Dp = e->Dp; f.A = e->A;
   const size_t nW1 = (size_t)(FH / 32) * (e->Dp / 8) * 256, nW2 = (size_t)(FH / 32) * (FH / 8) * 256;
   const size_t nW3f = (size_t)(FH / 8) * 256, nW3b = (size_t)(FH / 32) * 4 * 256;
-  const size_t per_net = nW1 + 2 * nW2 + nW3f + nW3b;
+  const size_t per_net = nW1 + 2 * nW2 + nW3f + nW3b + 2 * FH;
   f.packed_floats = 2 * per_net;
   CHK(dalloc(e, &f.packed, f.packed_floats));
   const int bias_ids[2][3] = {{T_PB1, T_PB2, T_AB}, {T_VB1, T_VB2, T_VB}};
@@ -299,8 +299,8 @@ int fused_init(mobrob_ppo_engine* e) {
     f.net[n].W3f = reinterpret_cast<const f32x4*>(p); p += nW3f;
     f.net[n].W2b = reinterpret_cast<const f32x4*>(p); p += nW2;
     f.net[n].W3b = reinterpret_cast<const f32x4*>(p); p += nW3b;
-    f.net[n].b1 = e->params + e->offs[bias_ids[n][0]];
-    f.net[n].b2 = e->params + e->offs[bias_ids[n][1]];
+    f.net[n].b1s = p; p += FH;
+    f.net[n].b2s = p; p += FH;
     f.net[n].b3 = e->params + e->offs[bias_ids[n][2]];
     f.net[n].head = n == 0 ? e->A : 1;
   }
@@ -742,6 +742,8 @@ int mobrob_ppo_minibatch_apply(mobrob_ppo_engine_t* e) {
     a.fW3f[n] = on ? (float*)e->fused.net[n].W3f : nullptr;
     a.fW2b[n] = on ? (float*)e->fused.net[n].W2b : nullptr;
     a.fW3b[n] = on ? (float*)e->fused.net[n].W3b : nullptr;
+    a.fb1s[n] = on ? (float*)e->fused.net[n].b1s : nullptr;
+    a.fb2s[n] = on ? (float*)e->fused.net[n].b2s : nullptr;
   }
   a.stats_row = stats_row;
   hipLaunchKernelGGL(k_adam_pack, dim3(cdiv(e->P, 256)), dim3(256), 0, e->stream, a);

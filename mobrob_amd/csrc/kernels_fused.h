@@ -28,7 +28,8 @@ struct FusedNet {
   const f32x4* W3f;  // [1][H/8][64]       fwd pack of head [32 (zero padded)][H]
   const f32x4* W2b;  // [H/32][H/8][64]    bwd pack: B[k=n][j] = W2[n][j]
   const f32x4* W3b;  // [H/32][32/8][64]   bwd pack: B[k=a][j] = head[a][j], a < 32 zero padded
-  const float* b1; const float* b2; const float* b3;  // canonical biases
+  const float* b1s; const float* b2s;  // hidden biases pre-multiplied by kTanhScale (see fast_tanh_scaled)
+  const float* b3;                     // canonical head bias
   int head;          // A for the policy net, 1 for the value net
 };
 
@@ -88,6 +89,19 @@ __device__ __forceinline__ f32x16 zero16() {
 __device__ __forceinline__ float fast_tanh(float x) {
   const float t = __builtin_amdgcn_exp2f(x * 2.88539008177792681472f);  // exp(2x)
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+// The forward weight packs of the hidden layers and their biases are stored pre-multiplied by 2*log2(e), and the
+// GEMM accumulators start from the (scaled) bias, so the layer epilogue is exp2 / add / rcp / fma per value.
+constexpr float kTanhScale = 2.88539008177792681472f;
+__device__ __forceinline__ float fast_tanh_scaled(float xs) {  // xs = 2*log2(e) * x
+  const float t = __builtin_amdgcn_exp2f(xs);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+__device__ __forceinline__ f32x16 splat16(float v) {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = v;
+  return z;
 }
 
 // All LDS accesses go through ONE extern array with integer (float-unit) offsets, so that every address is
@@ -224,19 +238,17 @@ __device__ __forceinline__ void mfma_x2y2(f32x16& c00, f32x16& c10, f32x16& c01,
 // ------------------------------------------------------------------------------------------------
 // epilogue helpers for the wave's 64x64 output block (2 column blocks x 2 row blocks, C layout)
 // ------------------------------------------------------------------------------------------------
-// lds[dst][row][col] = tanh(acc + bias[col])
-__device__ __forceinline__ void store_tanh(int dst_off, const float* __restrict__ bias, int wave, int lane,
-                                           const f32x16& c00, const f32x16& c01, const f32x16& c10,
-                                           const f32x16& c11) {
+// lds[dst][row][col] = tanh(acc / kTanhScale)   (acc already holds kTanhScale * (x.W^T + b))
+__device__ __forceinline__ void store_tanh(int dst_off, int wave, int lane, const f32x16& c00, const f32x16& c01,
+                                           const f32x16& c10, const f32x16& c11) {
   const int r = lane & 31, h = lane >> 5;
-  const float bz0 = bias[64 * wave + r], bz1 = bias[64 * wave + 32 + r];
   const int o = opaque(dst_off + 4 * h * FLDH + 64 * wave + r);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    lds[o + crc(i) * FLDH] = fast_tanh(c00[i] + bz0);
-    lds[o + (32 + crc(i)) * FLDH] = fast_tanh(c01[i] + bz0);
-    lds[o + crc(i) * FLDH + 32] = fast_tanh(c10[i] + bz1);
-    lds[o + (32 + crc(i)) * FLDH + 32] = fast_tanh(c11[i] + bz1);
+    lds[o + crc(i) * FLDH] = fast_tanh_scaled(c00[i]);
+    lds[o + (32 + crc(i)) * FLDH] = fast_tanh_scaled(c01[i]);
+    lds[o + crc(i) * FLDH + 32] = fast_tanh_scaled(c10[i]);
+    lds[o + (32 + crc(i)) * FLDH + 32] = fast_tanh_scaled(c11[i]);
   }
 }
 // lds[hs][row][col] <- acc * (1 - hs^2) in place
@@ -323,15 +335,17 @@ __device__ __forceinline__ Frag2 tile_layers(const FusedNet& W, int wave, int la
   const f32x4* w2a = W.W2f + (size_t)(2 * wave) * nkg2 * 64;
   const f32x4* w2b = W.W2f + (size_t)(2 * wave + 1) * nkg2 * 64;
   Frag2 f2;
+  const int r_ = lane & 31;
   {  // layer 1: K = DP
-    f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
+    const float bz0 = W.b1s[64 * wave + r_], bz1 = W.b1s[64 * wave + 32 + r_];
+    f32x16 c00 = splat16(bz0), c01 = splat16(bz0), c10 = splat16(bz1), c11 = splat16(bz1);
     constexpr int nkg = DP / 8;
     if (PHASE_ON(2))
       gemm_lds_packed<L::LDX>(L::X, W.W1f + (size_t)(2 * wave) * nkg * 64, W.W1f + (size_t)(2 * wave + 1) * nkg * 64,
                               nkg, c00, c01, c10, c11, lane, f1);
     f2 = prefetch_frag(w2a, w2b, lane);
     STAMP(1)
-    if (PHASE_ON(1024)) store_tanh(L::H1, W.b1, wave, lane, c00, c01, c10, c11);
+    if (PHASE_ON(1024)) store_tanh(L::H1, wave, lane, c00, c01, c10, c11);
     else asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
     STAMP(2)
   }
@@ -341,11 +355,12 @@ __device__ __forceinline__ Frag2 tile_layers(const FusedNet& W, int wave, int la
   const f32x4* bp = W.W3f + (size_t)((wave >> 1) * 16) * 64;
   Frag2 f3;
   {  // layer 2: K = H
-    f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
+    const float bz0 = W.b2s[64 * wave + r_], bz1 = W.b2s[64 * wave + 32 + r_];
+    f32x16 c00 = splat16(bz0), c01 = splat16(bz0), c10 = splat16(bz1), c11 = splat16(bz1);
     if (PHASE_ON(4)) gemm_lds_packed<FLDH>(L::H1, w2a, w2b, nkg2, c00, c01, c10, c11, lane, f2);
     f3 = prefetch_frag(bp, bp + 64, lane);
     STAMP(4)
-    if (PHASE_ON(1024)) store_tanh(L::H2, W.b2, wave, lane, c00, c01, c10, c11);
+    if (PHASE_ON(1024)) store_tanh(L::H2, wave, lane, c00, c01, c10, c11);
     else asm volatile("" ::"v"(c00), "v"(c01), "v"(c10), "v"(c11));
     STAMP(5)
   }
@@ -844,12 +859,16 @@ __global__ __launch_bounds__(256) void k_slab_reduce(SlabReduceArgs s) {
 // rows/cols outside the source matrix are zero.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_pack_fwd(const float* __restrict__ W, int N, int K, int ld, float* __restrict__ out, int NB,
-                           int KG) {
+                           int KG, float scale) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= NB * KG * 256) return;
   const int s = i & 3, lane = (i >> 2) & 63, kg = (i >> 8) % KG, nb = (i >> 8) / KG;
   const int n = nb * 32 + (lane & 31), k = kg * 8 + 4 * (lane >> 5) + s;
-  out[i] = (n < N && k < K) ? W[(size_t)n * ld + k] : 0.f;
+  out[i] = (n < N && k < K) ? scale * W[(size_t)n * ld + k] : 0.f;
+}
+__global__ void k_scale_copy(const float* __restrict__ src, float* __restrict__ dst, int n, float scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = scale * src[i];
 }
 __global__ void k_pack_bwd(const float* __restrict__ W, int N, int K, int ld, float* __restrict__ out, int JB,
                            int KG) {
@@ -946,30 +965,28 @@ __global__ __launch_bounds__(FTHREADS, 2) void k_fused_act(FusedActArgs a) {
   }
   __syncthreads();
   {  // layer 1
-    f32x16 c0 = zero16(), c1 = zero16();
+    f32x16 c0 = splat16(W.b1s[64 * wave + r]), c1 = splat16(W.b1s[64 * wave + 32 + r]);
     constexpr int nkg = DP / 8;
     gemm_lds_packed_r32<ldx>(L::X, W.W1f + (size_t)(2 * wave) * nkg * 64, W.W1f + (size_t)(2 * wave + 1) * nkg * 64, nkg,
                              c0, c1, lane);
-    const float bz0 = W.b1[64 * wave + r], bz1 = W.b1[64 * wave + 32 + r];
     const int o = opaque(L::H1 + 4 * h * FLDH + 64 * wave + r);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      lds[o + crc(i) * FLDH] = fast_tanh(c0[i] + bz0);
-      lds[o + crc(i) * FLDH + 32] = fast_tanh(c1[i] + bz1);
+      lds[o + crc(i) * FLDH] = fast_tanh_scaled(c0[i]);
+      lds[o + crc(i) * FLDH + 32] = fast_tanh_scaled(c1[i]);
     }
   }
   __syncthreads();
   {  // layer 2
-    f32x16 c0 = zero16(), c1 = zero16();
+    f32x16 c0 = splat16(W.b2s[64 * wave + r]), c1 = splat16(W.b2s[64 * wave + 32 + r]);
     constexpr int nkg = FH / 8;
     gemm_lds_packed_r32<FLDH>(L::H1, W.W2f + (size_t)(2 * wave) * nkg * 64, W.W2f + (size_t)(2 * wave + 1) * nkg * 64,
                               nkg, c0, c1, lane);
-    const float bz0 = W.b2[64 * wave + r], bz1 = W.b2[64 * wave + 32 + r];
     const int o = opaque(L::H2 + 4 * h * FLDH + 64 * wave + r);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      lds[o + crc(i) * FLDH] = fast_tanh(c0[i] + bz0);
-      lds[o + crc(i) * FLDH + 32] = fast_tanh(c1[i] + bz1);
+      lds[o + crc(i) * FLDH] = fast_tanh_scaled(c0[i]);
+      lds[o + crc(i) * FLDH + 32] = fast_tanh_scaled(c1[i]);
     }
   }
   __syncthreads();
@@ -1082,7 +1099,7 @@ struct AdamPackArgs {
   // generic-path padded copies (always maintained: cheap, and k_value_flagged/predict fallbacks use canonical)
   float* pW1p; float* vW1p; float* aWp; float* vWp;
   // fused-path packs (null when the fused path is disabled)
-  float* fW1f[2]; float* fW2f[2]; float* fW3f[2]; float* fW2b[2]; float* fW3b[2];
+  float* fW1f[2]; float* fW2f[2]; float* fW3f[2]; float* fW2b[2]; float* fW3b[2]; float* fb1s[2]; float* fb2s[2];
   float* stats_row;  // [6] <- total gradient norm
 };
 
@@ -1134,13 +1151,13 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
     case 1: case 5: {  // W1 [H][D]
       const int net = t == 5, n = e / a.D, k = e - n * a.D;
       (net ? a.vW1p : a.pW1p)[n * a.Dp + k] = pn;
-      if (a.fW1f[net]) a.fW1f[net][pack_fwd_idx(n, k, a.Dp / 8)] = pn;
+      if (a.fW1f[net]) a.fW1f[net][pack_fwd_idx(n, k, a.Dp / 8)] = kTanhScale * pn;
     } break;
     case 3: case 7: {  // W2 [H2][H1]
       const int net = t == 7;
       if (a.fW2f[net]) {
         const int K = net ? a.G1 : a.H1, n = e / K, k = e - n * K;
-        a.fW2f[net][pack_fwd_idx(n, k, K / 8)] = pn;
+        a.fW2f[net][pack_fwd_idx(n, k, K / 8)] = kTanhScale * pn;
         a.fW2b[net][pack_bwd_idx(n, k, (net ? a.G2 : a.H2) / 8)] = pn;
       }
     } break;
@@ -1152,6 +1169,8 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
         a.fW3b[net][pack_bwd_idx(n, k, 4)] = pn;
       }
     } break;
+    case 2: case 6: if (a.fb1s[t == 6]) a.fb1s[t == 6][e] = kTanhScale * pn; break;  // hidden biases (scaled copies)
+    case 4: case 8: if (a.fb2s[t == 8]) a.fb2s[t == 8][e] = kTanhScale * pn; break;
     default: break;
   }
 }
@@ -1184,8 +1203,9 @@ inline bool fused_shape_ok(int D, int A, int H1, int H2, int G1, int G2) {
 inline void fused_repack(FusedState& f, const float* params, const int* offs, hipStream_t st) {
   if (!f.enabled) return;
   const int Dp = f.Dp, D = f.D, A = f.A;
-  auto fwd = [&](const float* W, int N, int K, int ld, const f32x4* out, int NB, int KG) {
-    hipLaunchKernelGGL(k_pack_fwd, dim3((NB * KG * 256 + 255) / 256), dim3(256), 0, st, W, N, K, ld, (float*)out, NB, KG);
+  auto fwd = [&](const float* W, int N, int K, int ld, const f32x4* out, int NB, int KG, float scale) {
+    hipLaunchKernelGGL(k_pack_fwd, dim3((NB * KG * 256 + 255) / 256), dim3(256), 0, st, W, N, K, ld, (float*)out, NB, KG,
+                       scale);
   };
   auto bwd = [&](const float* W, int N, int K, int ld, const f32x4* out, int JB, int KG) {
     hipLaunchKernelGGL(k_pack_bwd, dim3((JB * KG * 256 + 255) / 256), dim3(256), 0, st, W, N, K, ld, (float*)out, JB, KG);
@@ -1193,9 +1213,11 @@ inline void fused_repack(FusedState& f, const float* params, const int* offs, hi
   // tensor ids: 0 log_std, 1 pW1, 2 pb1, 3 pW2, 4 pb2, 5 vW1, 6 vb1, 7 vW2, 8 vb2, 9 aW, 10 ab, 11 vW, 12 vb
   const int w1[2] = {1, 5}, w2[2] = {3, 7}, w3[2] = {9, 11}, heads[2] = {A, 1};
   for (int n = 0; n < 2; ++n) {
-    fwd(params + offs[w1[n]], FH, D, D, f.net[n].W1f, FH / 32, Dp / 8);
-    fwd(params + offs[w2[n]], FH, FH, FH, f.net[n].W2f, FH / 32, FH / 8);
-    fwd(params + offs[w3[n]], heads[n], FH, FH, f.net[n].W3f, 1, FH / 8);
+    fwd(params + offs[w1[n]], FH, D, D, f.net[n].W1f, FH / 32, Dp / 8, kTanhScale);
+    fwd(params + offs[w2[n]], FH, FH, FH, f.net[n].W2f, FH / 32, FH / 8, kTanhScale);
+    fwd(params + offs[w3[n]], heads[n], FH, FH, f.net[n].W3f, 1, FH / 8, 1.0f);
+    hipLaunchKernelGGL(k_scale_copy, dim3(1), dim3(256), 0, st, params + offs[w1[n] + 1], (float*)f.net[n].b1s, FH, kTanhScale);
+    hipLaunchKernelGGL(k_scale_copy, dim3(1), dim3(256), 0, st, params + offs[w2[n] + 1], (float*)f.net[n].b2s, FH, kTanhScale);
     bwd(params + offs[w2[n]], FH, FH, FH, f.net[n].W2b, FH / 32, FH / 8);
     bwd(params + offs[w3[n]], heads[n], FH, FH, f.net[n].W3b, FH / 32, 4);
   }
