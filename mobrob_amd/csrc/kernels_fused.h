@@ -185,6 +185,56 @@ __device__ __forceinline__ void gemm_lds_packed(int a_off, const f32x4* __restri
   MFMA_KG(uB, vB, pB, qB)
 }
 
+// Deep-pipelined variant for the K = 256 contractions (nkg % 4 == 0, nkg >= 8): weight fragments are fetched THREE
+// k-groups (~3 us of MFMA work) ahead through a 4-deep register ring -- one k-group of lookahead does not cover
+// the L2 latency when all 256 CUs stream weights -- A fragments one k-group ahead from LDS.
+template <int LDA>
+__device__ __forceinline__ void gemm_lds_packed_deep(int a_off, const f32x4* __restrict__ Bp0,
+                                                     const f32x4* __restrict__ Bp1, int nkg, f32x16& c00,
+                                                     f32x16& c01, f32x16& c10, f32x16& c11, int lane,
+                                                     const Frag2& first) {
+  const int r = lane & 31, h = lane >> 5;
+  const int ab = 4 * opaque((a_off + r * LDA + 4 * h) >> 2);
+  unsigned bo = opaque_u((unsigned)lane * 16u);
+  f32x4 p0 = first.p, q0 = first.q;
+  f32x4 p1 = ldg16(Bp0, bo + 1024u), q1 = ldg16(Bp1, bo + 1024u);
+  f32x4 p2 = ldg16(Bp0, bo + 2048u), q2 = ldg16(Bp1, bo + 2048u);
+  f32x4 p3, q3;
+  f32x4 uA = *reinterpret_cast<const f32x4*>(&lds[ab]);
+  f32x4 vA = *reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA]);
+  f32x4 uB, vB;
+  int ao = ab;
+#define LDA_NEXT(U, V, off)                                             \
+  U = *reinterpret_cast<const f32x4*>(&lds[ao + (off)]);                \
+  V = *reinterpret_cast<const f32x4*>(&lds[ao + 32 * LDA + (off)]);
+#pragma unroll 1
+  for (int kg = 0; kg < nkg - 4; kg += 4) {
+    p3 = ldg16(Bp0, bo + 3072u); q3 = ldg16(Bp1, bo + 3072u);
+    LDA_NEXT(uB, vB, 8)
+    MFMA_KG(uA, vA, p0, q0)
+    p0 = ldg16(Bp0, bo + 4096u); q0 = ldg16(Bp1, bo + 4096u);
+    LDA_NEXT(uA, vA, 16)
+    MFMA_KG(uB, vB, p1, q1)
+    p1 = ldg16(Bp0, bo + 5120u); q1 = ldg16(Bp1, bo + 5120u);
+    LDA_NEXT(uB, vB, 24)
+    MFMA_KG(uA, vA, p2, q2)
+    p2 = ldg16(Bp0, bo + 6144u); q2 = ldg16(Bp1, bo + 6144u);
+    LDA_NEXT(uA, vA, 32)
+    MFMA_KG(uB, vB, p3, q3)
+    bo += 4096u;
+    ao += 32;
+  }
+  p3 = ldg16(Bp0, bo + 3072u); q3 = ldg16(Bp1, bo + 3072u);
+  LDA_NEXT(uB, vB, 8)
+  MFMA_KG(uA, vA, p0, q0)
+  LDA_NEXT(uA, vA, 16)
+  MFMA_KG(uB, vB, p1, q1)
+  LDA_NEXT(uB, vB, 24)
+  MFMA_KG(uA, vA, p2, q2)
+  MFMA_KG(uB, vB, p3, q3)
+#undef LDA_NEXT
+}
+
 // ------------------------------------------------------------------------------------------------
 // dW2 accumulators: 16 tiles of 32x32 (this wave's 64 neurons x 256 inputs) pinned to the accumulator
 // register file for the whole kernel.  The library is compiled with -mllvm -amdgpu-mfma-vgpr-form, so every
@@ -357,7 +407,7 @@ __device__ __forceinline__ Frag2 tile_layers(const FusedNet& W, int wave, int la
   {  // layer 2: K = H
     const float bz0 = W.b2s[64 * wave + r_], bz1 = W.b2s[64 * wave + 32 + r_];
     f32x16 c00 = splat16(bz0), c01 = splat16(bz0), c10 = splat16(bz1), c11 = splat16(bz1);
-    if (PHASE_ON(4)) gemm_lds_packed<FLDH>(L::H1, w2a, w2b, nkg2, c00, c01, c10, c11, lane, f2);
+    if (PHASE_ON(4)) gemm_lds_packed_deep<FLDH>(L::H1, w2a, w2b, nkg2, c00, c01, c10, c11, lane, f2);
     f3 = prefetch_frag(bp, bp + 64, lane);
     STAMP(4)
     if (PHASE_ON(1024)) store_tanh(L::H2, wave, lane, c00, c01, c10, c11);
@@ -661,8 +711,8 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
       f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
       constexpr int nkg = FH / 8;
       if (PHASE_ON(256))
-        gemm_lds_packed<FLDH>(L::H2, W.W2b + (size_t)(2 * wave) * nkg * 64, W.W2b + (size_t)(2 * wave + 1) * nkg * 64,
-                              nkg, c00, c01, c10, c11, lane, fh1);
+        gemm_lds_packed_deep<FLDH>(L::H2, W.W2b + (size_t)(2 * wave) * nkg * 64,
+                                   W.W2b + (size_t)(2 * wave + 1) * nkg * 64, nkg, c00, c01, c10, c11, lane, fh1);
       STAMP(16)
       __syncthreads();  // dW2 reads of h1 complete everywhere
       STAMP(17)
