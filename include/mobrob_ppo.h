@@ -75,7 +75,8 @@ typedef struct mobrob_ppo_config {
   int32_t device_id;          /* HIP device ordinal                                              */
   int32_t rank, world_size;   /* data-parallel position; batch_size is split batch_size/world    */
   int32_t fast_kernels;       /* 1: use the fused MFMA kernels when the shape allows; 0: generic */
-  int32_t reserved[7];
+  int32_t rollout_graph;      /* 1: replay the device-resident rollout as one captured hipGraph  */
+  int32_t reserved[6];
 } mobrob_ppo_config_t;
 
 /* Fill `cfg` with SB3 2.0.0 defaults (Appendix A.1).  Replaces PPO.__init__'s default kwargs. */

@@ -29,7 +29,7 @@ class Config(C.Structure):
         ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
         ("action_low", C.c_double), ("action_high", C.c_double),
         ("normalize_advantage", C.c_int32), ("seed", C.c_uint64), ("device_id", C.c_int32),
-        ("rank", C.c_int32), ("world_size", C.c_int32), ("fast_kernels", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("rank", C.c_int32), ("world_size", C.c_int32), ("fast_kernels", C.c_int32), ("rollout_graph", C.c_int32), ("reserved", C.c_int32 * 6),
     ]
 
 

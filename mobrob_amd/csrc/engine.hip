@@ -80,6 +80,11 @@ struct mobrob_ppo_engine {
   float *clip_act = nullptr, *rew_tmp = nullptr, *term_obs = nullptr, *term_val = nullptr, *eps_dev = nullptr;
   uint8_t *trunc_dev = nullptr, *dones_u8 = nullptr;
   int *ep_len = nullptr, *ep_len2 = nullptr;
+  uint32_t* ctr_dev = nullptr;  // [0] eps draw base, [1] env step base (device-resident: graph replays advance them)
+  hipGraph_t ro_graph = nullptr;
+  hipGraphExec_t ro_exec = nullptr;
+  float ro_p_term = -1.f;
+  int ro_time_limit = -1;
   bool env_started = false;
   uint32_t draw_counter = 0;  // Philox draw index for eps
   uint32_t env_step_counter = 0;
@@ -255,24 +260,26 @@ void run_gae(mobrob_ppo_engine* e) {
 }
 
 // policy forward + sample for rollout slot t (observations already in the slot)
-void act_slot(mobrob_ppo_engine* e, int t, const float* eps_dev_or_null) {
+void act_slot(mobrob_ppo_engine* e, int t, const float* eps_dev_or_null, bool device_counter = false) {
+  const uint32_t draw = device_counter ? (uint32_t)t : e->draw_counter;
+  const uint32_t* draw_base = device_counter ? e->ctr_dev : nullptr;
   ProfScope ps(e, MOBROB_K_ACT);
   const float* X = e->obs + (size_t)t * e->N * e->Dp;
   if (e->fused.enabled) {
     FusedActArgs a{};
     a.X = X; a.rows = e->N; a.want_pi = 1; a.want_v = 1; a.mu = nullptr; a.ldmu = e->Ap;
     a.v = e->values + (size_t)t * e->N; a.sample = 1; a.A = e->A; a.log_std = Pp(e, T_LOGSTD); a.eps = eps_dev_or_null;
-    a.seed = eps_seed(e); a.draw = e->draw_counter; a.lo = (float)e->cfg.action_low; a.hi = (float)e->cfg.action_high;
+    a.seed = eps_seed(e); a.draw = draw; a.draw_base = draw_base; a.lo = (float)e->cfg.action_low; a.hi = (float)e->cfg.action_high;
     a.act_raw = e->actions + (size_t)t * e->N * e->A; a.act_clip = e->clip_act; a.logp = e->logp + (size_t)t * e->N;
     fused_launch_act(e->fused, a, e->stream);
-    e->draw_counter++;
+    if (!device_counter) e->draw_counter++;
     return;
   }
   forward(e, X, e->N, true, e->mu, true, e->values + (size_t)t * e->N);
   hipLaunchKernelGGL(k_sample, dim3(cdiv(e->N, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, Pp(e, T_LOGSTD),
                      eps_dev_or_null, e->N, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high, eps_seed(e),
-                     e->draw_counter, e->actions + (size_t)t * e->N * e->A, e->clip_act, e->logp + (size_t)t * e->N);
-  e->draw_counter++;
+                     draw, draw_base, e->actions + (size_t)t * e->N * e->A, e->clip_act, e->logp + (size_t)t * e->N);
+  if (!device_counter) e->draw_counter++;
 }
 
 int upload_obs(mobrob_ppo_engine* e, const float* host, float* dev_rows, int rows) {
@@ -373,6 +380,7 @@ void mobrob_ppo_default_config(mobrob_ppo_config_t* c) {
   c->max_grad_norm = 0.5; c->learning_rate = 3e-4; c->adam_beta1 = 0.9; c->adam_beta2 = 0.999; c->adam_eps = 1e-5;
   c->action_low = -1.0; c->action_high = 1.0;
   c->normalize_advantage = 1; c->seed = 0; c->device_id = 0; c->rank = 0; c->world_size = 1; c->fast_kernels = 1;
+  c->rollout_graph = 1;
 }
 
 void* mobrob_ppo_host_alloc(size_t bytes) {
@@ -424,7 +432,7 @@ int mobrob_ppo_create(const mobrob_ppo_config_t* cfg, mobrob_ppo_engine_t** out)
   CHK(dalloc(e, &e->last_values, N)); CHK(dalloc(e, &e->last_dones, N)); CHK(dalloc(e, &e->prev_dones, N));
   CHK(dalloc(e, &e->dones_tmp, N)); CHK(dalloc(e, &e->clip_act, N * A)); CHK(dalloc(e, &e->rew_tmp, N));
   CHK(dalloc(e, &e->term_obs, N * Dp)); CHK(dalloc(e, &e->term_val, N)); CHK(dalloc(e, &e->eps_dev, R * A));
-  CHK(dalloc(e, &e->trunc_dev, N)); CHK(dalloc(e, &e->dones_u8, N)); CHK(dalloc(e, &e->ep_len, N)); CHK(dalloc(e, &e->ep_len2, N));
+  CHK(dalloc(e, &e->trunc_dev, N)); CHK(dalloc(e, &e->dones_u8, N)); CHK(dalloc(e, &e->ep_len, N)); CHK(dalloc(e, &e->ep_len2, N)); CHK(dalloc(e, &e->ctr_dev, 2));
   CHK(dalloc(e, &e->rows, T * N)); CHK(dalloc(e, &e->perm_dev, T * N)); CHK(dalloc(e, &e->advstat, (size_t)e->nmb * 4));
   e->stats_cap = std::max(64, 4 * e->nmb * cfg->n_epochs);
   CHK(dalloc(e, &e->stats, (size_t)e->stats_cap * 8));
@@ -462,6 +470,8 @@ void mobrob_ppo_destroy(mobrob_ppo_engine_t* e) {
   if (!e) return;
   (void)hipStreamSynchronize(e->stream);
   prof_resolve(e);
+  if (e->ro_exec) (void)hipGraphExecDestroy(e->ro_exec);
+  if (e->ro_graph) (void)hipGraphDestroy(e->ro_graph);
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -471,6 +481,8 @@ void mobrob_ppo_destroy(mobrob_ppo_engine_t* e) {
 int mobrob_ppo_set_stream(mobrob_ppo_engine_t* e, void* s) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   HIPC(hipStreamSynchronize(e->stream));
+  if (e->ro_exec) { (void)hipGraphExecDestroy(e->ro_exec); e->ro_exec = nullptr; }
+  if (e->ro_graph) { (void)hipGraphDestroy(e->ro_graph); e->ro_graph = nullptr; }
   if (e->own_stream && e->stream) HIPC(hipStreamDestroy(e->stream));
   if (s == nullptr) {
     HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -598,37 +610,72 @@ int mobrob_ppo_mark_rollout_ready(mobrob_ppo_engine_t* e) {
   return MOBROB_OK;
 }
 
-int mobrob_ppo_collect_synthetic(mobrob_ppo_engine_t* e, float p_term, int32_t time_limit) {
-  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+namespace {
+// enqueue one whole device-resident rollout (T steps + last values + GAE) on the engine stream
+int enqueue_rollout(mobrob_ppo_engine* e, float p_term, int time_limit) {
   const int N = e->N, Dp = e->Dp, per = Dp / 4;
   const size_t slot = (size_t)N * Dp;
   const uint64_t env_seed = e->cfg.seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(e->cfg.rank + 1));
-  if (!e->env_started) {
-    hipLaunchKernelGGL(k_env_reset, dim3(cdiv(N * per, 256)), dim3(256), 0, e->stream, env_seed, N, e->D, Dp, e->obs,
-                       e->ep_len);
-    e->env_started = true;
-  } else {
-    HIPC(hipMemcpyAsync(e->obs, e->obs + (size_t)e->T * slot, slot * 4, hipMemcpyDeviceToDevice, e->stream));
-  }
-  e->rollout_ready = false;
+  // the previous rollout's last observation is this rollout's first
+  HIPC(hipMemcpyAsync(e->obs, e->obs + (size_t)e->T * slot, slot * 4, hipMemcpyDeviceToDevice, e->stream));
   for (int t = 0; t < e->T; ++t) {
-    act_slot(e, t, nullptr);
+    act_slot(e, t, nullptr, true);
     {
       ProfScope ps(e, MOBROB_K_ENV);
-      hipLaunchKernelGGL(k_env_step_store, dim3(cdiv(N * per, 256)), dim3(256), 0, e->stream, env_seed,
-                         e->env_step_counter, N, e->D, Dp, p_term, time_limit, e->ep_len, e->ep_len2,
+      hipLaunchKernelGGL(k_env_step_store, dim3(cdiv(N * per, 256)), dim3(256), 0, e->stream, env_seed, (uint32_t)t,
+                         e->ctr_dev + 1, N, e->D, Dp, p_term, time_limit, e->ep_len, e->ep_len2,
                          e->obs + (size_t)(t + 1) * slot, e->term_obs, e->prev_dones, e->dones_tmp, e->trunc_dev,
                          e->rewards + (size_t)t * N, e->es + (size_t)t * N);
       // time-limit bootstrap of the (rare) truncated rows, in place: rewards += gamma * V(terminal_obs)
       value_flagged(e, e->term_obs, e->trunc_dev, e->term_val, e->rewards + (size_t)t * N);
     }
-    e->env_step_counter++;
     std::swap(e->prev_dones, e->dones_tmp);
     std::swap(e->ep_len, e->ep_len2);
   }
+  hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, e->stream, e->ctr_dev, (uint32_t)e->T, (uint32_t)e->T);
   HIPC(hipMemcpyAsync(e->last_dones, e->prev_dones, (size_t)N * 4, hipMemcpyDeviceToDevice, e->stream));
   forward(e, e->obs + (size_t)e->T * slot, N, false, nullptr, true, e->last_values);
   run_gae(e);
+  return MOBROB_OK;
+}
+}  // namespace
+
+int mobrob_ppo_collect_synthetic(mobrob_ppo_engine_t* e, float p_term, int32_t time_limit) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  const int N = e->N, Dp = e->Dp, per = Dp / 4;
+  const size_t slot = (size_t)N * Dp;
+  if (!e->env_started) {
+    const uint64_t env_seed = e->cfg.seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(e->cfg.rank + 1));
+    float* last = e->obs + (size_t)e->T * slot;  // reset writes the "previous last observation"
+    hipLaunchKernelGGL(k_env_reset, dim3(cdiv(N * per, 256)), dim3(256), 0, e->stream, env_seed, N, e->D, Dp, last,
+                       e->ep_len);
+    e->env_started = true;
+  }
+  e->rollout_ready = false;
+  // Graph replay: every kernel argument of the T-step loop is fixed (slot pointers, ping-pong buffers with even T,
+  // counters relative to device-resident bases), so the loop is captured once and replayed per rollout.
+  const bool use_graph = e->cfg.rollout_graph && (e->T % 2 == 0);
+  if (!use_graph) {
+    CHK(enqueue_rollout(e, p_term, time_limit));
+  } else {
+    if (e->ro_exec == nullptr || e->ro_p_term != p_term || e->ro_time_limit != time_limit) {
+      if (e->ro_exec) { (void)hipGraphExecDestroy(e->ro_exec); e->ro_exec = nullptr; }
+      if (e->ro_graph) { (void)hipGraphDestroy(e->ro_graph); e->ro_graph = nullptr; }
+      const bool prof = e->prof_on;
+      e->prof_on = false;  // event records cannot be part of the captured graph
+      HIPC(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+      const int rc = enqueue_rollout(e, p_term, time_limit);
+      hipError_t ce = hipStreamEndCapture(e->stream, &e->ro_graph);
+      e->prof_on = prof;
+      if (rc != MOBROB_OK) return rc;
+      if (ce != hipSuccess) return fail(MOBROB_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+      HIPC(hipGraphInstantiate(&e->ro_exec, e->ro_graph, nullptr, nullptr, 0));
+      e->ro_p_term = p_term;
+      e->ro_time_limit = time_limit;
+    }
+    ProfScope ps(e, MOBROB_K_ACT);  // with graph replay the ACT scope covers the whole rollout (forward+env+GAE)
+    HIPC(hipGraphLaunch(e->ro_exec, e->stream));
+  }
   HIPC(hipGetLastError());
   e->t = e->T;
   e->rollout_ready = true;
@@ -817,7 +864,7 @@ int mobrob_ppo_predict(mobrob_ppo_engine_t* e, const float* obs, int32_t n, int3
         }
         hipLaunchKernelGGL(k_sample, dim3(cdiv(c, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, Pp(e, T_LOGSTD), epsd,
                            c, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high, eps_seed(e), e->draw_counter,
-                           (float*)nullptr, scratch, (float*)nullptr);
+                           (const uint32_t*)nullptr, (float*)nullptr, scratch, (float*)nullptr);
         e->draw_counter++;
       }
       HIPC(hipMemcpyAsync(actions + (size_t)s * e->A, scratch, (size_t)c * e->A * 4, hipMemcpyDeviceToHost, e->stream));

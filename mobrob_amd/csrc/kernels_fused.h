@@ -942,7 +942,7 @@ struct FusedActArgs {
   float* v;                // [rows]
   // sampling (policy net) -- any of the outputs may be null
   int sample; int A;
-  const float* log_std; const float* eps; uint64_t seed; uint32_t draw; float lo, hi;
+  const float* log_std; const float* eps; uint64_t seed; uint32_t draw; const uint32_t* draw_base; float lo, hi;
   float* act_raw; float* act_clip; float* logp;
 };
 
@@ -1084,7 +1084,8 @@ __global__ __launch_bounds__(FTHREADS, 2) void k_fused_act(FusedActArgs a) {
       } else {
         if ((k & 3) == 0) {
           float z[4];
-          box_muller4(philox4x32_10((uint32_t)row, (uint32_t)(k >> 2), a.draw, 0x45505331u, (uint32_t)a.seed,
+          box_muller4(philox4x32_10((uint32_t)row, (uint32_t)(k >> 2), a.draw + (a.draw_base ? *a.draw_base : 0u),
+                                    0x45505331u, (uint32_t)a.seed,
                                     (uint32_t)(a.seed >> 32)), z);
           z0 = z[0]; z1 = z[1]; z2 = z[2]; z3 = z[3];
         }

@@ -145,10 +145,11 @@ constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
 
 __global__ void k_sample(const float* __restrict__ mu, int ldmu, const float* __restrict__ log_std,
                          const float* __restrict__ eps, int n, int A, float lo, float hi, uint64_t seed,
-                         uint32_t draw, float* __restrict__ act_raw, float* __restrict__ act_clip,
-                         float* __restrict__ logp_out) {
+                         uint32_t draw_rel, const uint32_t* __restrict__ draw_base, float* __restrict__ act_raw,
+                         float* __restrict__ act_clip, float* __restrict__ logp_out) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n) return;
+  const uint32_t draw = draw_rel + (draw_base ? *draw_base : 0u);
   float lp = 0.f;
   float z[4];
   for (int a = 0; a < A; ++a) {
@@ -589,7 +590,11 @@ __global__ void k_env_step(uint64_t seed, uint32_t step, int N, int D, int Dp, f
 // One-launch variant used by the device-resident rollout: env draw + rollout_buffer.add scalars.
 // ep_len is double buffered (every chunk thread of an env must see the OLD value); the time-limit
 // bootstrap of the (rare) truncated rows is applied afterwards by k_value_flagged in place.
-__global__ void k_env_step_store(uint64_t seed, uint32_t step, int N, int D, int Dp, float p_term, int time_limit,
+__global__ void k_add_counters(uint32_t* ctr, uint32_t d0, uint32_t d1) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { ctr[0] += d0; ctr[1] += d1; }
+}
+__global__ void k_env_step_store(uint64_t seed, uint32_t step_rel, const uint32_t* __restrict__ step_base, int N, int D,
+                                 int Dp, float p_term, int time_limit,
                                  const int* __restrict__ ep_len_in, int* __restrict__ ep_len_out,
                                  float* __restrict__ obs_next, float* __restrict__ term_obs,
                                  const float* __restrict__ prev_dones, float* __restrict__ next_dones,
@@ -599,6 +604,7 @@ __global__ void k_env_step_store(uint64_t seed, uint32_t step, int N, int D, int
   if (i >= N * per) return;
   const int n = i / per, c = i - n * per;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const uint32_t step = step_rel + (step_base ? *step_base : 0u);  // device-resident base: graph replays advance it
   const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, k0, k1);
   const bool term = u32_to_unit_open(mr.x) < p_term;
   const int len = ep_len_in[n] + 1;

@@ -51,7 +51,8 @@ class PPOEngine:
     def __init__(self, obs_dim, act_dim, n_envs, n_steps, batch_size=64, n_epochs=10, pi=(64, 64), vf=(64, 64),
                  gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
                  learning_rate=3e-4, adam_betas=(0.9, 0.999), adam_eps=1e-5, normalize_advantage=True,
-                 action_low=-1.0, action_high=1.0, seed=0, device_id=0, rank=0, world_size=1, fast_kernels=True):
+                 action_low=-1.0, action_high=1.0, seed=0, device_id=0, rank=0, world_size=1, fast_kernels=True,
+                 rollout_graph=True):
         self.lib = _lib.load()
         if len(pi) != 2 or len(vf) != 2:
             raise ValueError("net_arch must have exactly two hidden layers per network (pi=[h1,h2], vf=[h1,h2])")
@@ -69,6 +70,7 @@ class PPOEngine:
         cfg.normalize_advantage = int(bool(normalize_advantage))
         cfg.seed, cfg.device_id, cfg.rank, cfg.world_size = int(seed), int(device_id), int(rank), int(world_size)
         cfg.fast_kernels = int(bool(fast_kernels))
+        cfg.rollout_graph = int(bool(rollout_graph))
         self.cfg = cfg
         self.D, self.A, self.N, self.T = int(obs_dim), int(act_dim), int(n_envs), int(n_steps)
         self.shapes = param_shapes(self.D, self.A, tuple(pi), tuple(vf))
