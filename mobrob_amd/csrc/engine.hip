@@ -334,7 +334,7 @@ void fused_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, float 
   a.stamps = f.stamps;
   const int ntiles = cdiv(B, FR);
   const int grid = 2 * std::min(f.max_grid / 2, ntiles);
-  (void)hipMemsetAsync(e->grads + e->P, 0, 8 * sizeof(float), e->stream);
+  // the 8 loss accumulators behind the gradient vector were zeroed by the previous k_adam_pack (or at allocation)
   {
     ProfScope ps(e, MOBROB_K_TRAIN_GRAD);
     fused_launch_train(f, a, grid, e->stream);
@@ -793,6 +793,7 @@ int mobrob_ppo_minibatch_apply(mobrob_ppo_engine_t* e) {
     a.fb2s[n] = on ? (float*)e->fused.net[n].b2s : nullptr;
   }
   a.stats_row = stats_row;
+  a.loss_sums_zero = e->fused.enabled ? e->grads + e->P : nullptr;
   hipLaunchKernelGGL(k_adam_pack, dim3(cdiv(e->P, 256)), dim3(256), 0, e->stream, a);
   HIPC(hipGetLastError());
   e->grad_pending = false;

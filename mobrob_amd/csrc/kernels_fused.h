@@ -1152,6 +1152,7 @@ struct AdamPackArgs {
   // fused-path packs (null when the fused path is disabled)
   float* fW1f[2]; float* fW2f[2]; float* fW3f[2]; float* fW2b[2]; float* fW3b[2]; float* fb1s[2]; float* fb2s[2];
   float* stats_row;  // [6] <- total gradient norm
+  float* loss_sums_zero;  // fused path: the 8 loss accumulators are re-zeroed here instead of by a memset launch
 };
 
 __device__ __forceinline__ int pack_fwd_idx(int n, int k, int KG) {
@@ -1185,6 +1186,7 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
   const float coef = coef_s;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0 && a.stats_row != nullptr) a.stats_row[6] = total_s;
+  if (i < 8 && a.loss_sums_zero != nullptr) a.loss_sums_zero[i] = 0.f;  // consumed by k_sqnorm_chunks; ready for the next step
   if (i >= a.P) return;
   const float g = a.g[i] * coef;
   const float m = a.m[i] * a.beta1 + (1.0f - a.beta1) * g;
