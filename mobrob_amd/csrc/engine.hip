@@ -14,6 +14,7 @@
 #include "../../include/mobrob_ppo.h"
 #include "kernels_generic.h"
 #include "kernels_fused.h"
+#include "fused_dispatch.h"
 
 using namespace mobrob;
 
@@ -292,10 +293,15 @@ int fused_init(mobrob_ppo_engine* e) {
   FusedState& f = e->fused;
   f.enabled = e->cfg.fast_kernels && fused_shape_ok(e->D, e->A, e->H1, e->H2, e->G1, e->G2);
   if (!f.enabled) return MOBROB_OK;
-  f.D = e->D; f.Dp = e->Dp; f.A = e->A;
-  const size_t nW1 = (size_t)(FH / 32) * (e->Dp / 8) * 256, nW2 = (size_t)(FH / 32) * (FH / 8) * 256;
-  const size_t nW3f = (size_t)(FH / 8) * 256, nW3b = (size_t)(FH / 32) * 4 * 256;
-  const size_t per_net = nW1 + 2 * nW2 + nW3f + nW3b + 2 * FH;
+  f.D = e->D; f.Dp = e->Dp; f.A = e->A; f.H = e->H1;
+  if ((uint64_t)(e->T + 1) * e->N * e->Dp * 4ull >= (1ull << 32) || (uint64_t)e->T * e->N * e->A * 4ull >= (1ull << 32)) {
+    f.enabled = false;  // the fused kernels address rollout rows with 32-bit byte offsets
+    return MOBROB_OK;
+  }
+  const int H = f.H;
+  const size_t nW1 = (size_t)(H / 32) * (e->Dp / 8) * 256, nW2 = (size_t)(H / 32) * (H / 8) * 256;
+  const size_t nW3f = (size_t)(H / 8) * 256, nW3b = (size_t)(H / 32) * 4 * 256;
+  const size_t per_net = nW1 + 2 * nW2 + nW3f + nW3b + 2 * H;
   f.packed_floats = 2 * per_net;
   CHK(dalloc(e, &f.packed, f.packed_floats));
   const int bias_ids[2][3] = {{T_PB1, T_PB2, T_AB}, {T_VB1, T_VB2, T_VB}};
@@ -306,19 +312,51 @@ int fused_init(mobrob_ppo_engine* e) {
     f.net[n].W3f = reinterpret_cast<const f32x4*>(p); p += nW3f;
     f.net[n].W2b = reinterpret_cast<const f32x4*>(p); p += nW2;
     f.net[n].W3b = reinterpret_cast<const f32x4*>(p); p += nW3b;
-    f.net[n].b1s = p; p += FH;
-    f.net[n].b2s = p; p += FH;
+    f.net[n].b1s = p; p += H;
+    f.net[n].b2s = p; p += H;
     f.net[n].b3 = e->params + e->offs[bias_ids[n][2]];
     f.net[n].head = n == 0 ? e->A : 1;
   }
-  f.slab_floats = slab_size(e->Dp);
   f.max_grid = 256;
-  CHK(dalloc(e, &f.slabs, (size_t)f.max_grid * f.slab_floats));
+  if (H == 64) {
+    f.slab_floats = s64_size();
+    CHK(dalloc(e, &f.slabs, (size_t)f.max_grid * 4 * f.slab_floats));  // one slab per wave
+    f.lds_bytes = fused64_lds_bytes(e->Dp);
+    f.lds_act_bytes = f.lds_bytes;
+  } else {
+    f.slab_floats = slab_size(e->Dp);
+    CHK(dalloc(e, &f.slabs, (size_t)f.max_grid * f.slab_floats));
+    f.lds_bytes = fused_lds_bytes(e->Dp);
+    f.lds_act_bytes = fused_lds_act_bytes(e->Dp);
+  }
   CHK(dalloc(e, &f.stamps, 32));
-  f.lds_bytes = fused_lds_bytes(e->Dp);
-  f.lds_act_bytes = fused_lds_act_bytes(e->Dp);
   HIPC(fused_set_lds_attr(f));
   return MOBROB_OK;
+}
+
+// 64-wide networks: one independent wave per 32-row tile (kernels_fused64.h)
+void fused64_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, float inv_bg) {
+  FusedState& f = e->fused;
+  Fused64TrainArgs a{};
+  a.net[0] = f.net[0]; a.net[1] = f.net[1];
+  a.obs = e->obs; a.actions = e->actions; a.A = e->A; a.old_logp = e->logp; a.adv = e->adv; a.ret = e->ret;
+  a.rows = e->rows + start; a.count = B; a.log_std = e->params + e->offs[T_LOGSTD];
+  a.advstat = e->advstat + 4 * (size_t)mb; a.normalize = e->cfg.normalize_advantage;
+  a.clip = (float)e->cfg.clip_range; a.vf_coef = (float)e->cfg.vf_coef; a.ent_coef = (float)e->cfg.ent_coef;
+  a.inv_bg = inv_bg; a.slabs = f.slabs; a.sums = e->grads + e->P;
+  const int ntiles = cdiv(B, GR);
+  const int grid = 2 * std::min(f.max_grid / 2, cdiv(ntiles, 4));
+  {
+    ProfScope ps(e, MOBROB_K_TRAIN_GRAD);
+    fused64_launch_train(f, a, grid, e->stream);
+  }
+  ProfScope pr(e, MOBROB_K_GRAD_REDUCE);
+  Slab64ReduceArgs s{};
+  s.slabs = f.slabs; s.nblocks = grid; s.grads = e->grads;
+  for (int i = 0; i < 14; ++i) s.offs[i] = e->offs[i];
+  s.D = e->D; s.A = e->A; s.ent_coef = (float)e->cfg.ent_coef; s.b_local = (float)B; s.inv_bg = inv_bg;
+  s.sums = e->grads + e->P;
+  hipLaunchKernelGGL(k_slab64_reduce, dim3(cdiv(s64_size(), 256), 2), dim3(256), 0, e->stream, s);
 }
 
 // fused minibatch gradient: one persistent kernel + the deterministic slab reduction
@@ -716,7 +754,8 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
   const float inv_bg = 1.0f / (float)((int64_t)B * e->cfg.world_size);
   e->cur_count = B;
   if (e->fused.enabled) {
-    fused_minibatch_grad(e, mb, start, B, inv_bg);
+    if (e->fused.H == 64) fused64_minibatch_grad(e, mb, start, B, inv_bg);
+    else fused_minibatch_grad(e, mb, start, B, inv_bg);
     HIPC(hipGetLastError());
     e->grad_pending = true;
     return MOBROB_OK;

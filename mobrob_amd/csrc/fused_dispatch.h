@@ -1,0 +1,51 @@
+// Host-side dispatch of the fused kernel families (hidden width 256: kernels_fused.h, 64: kernels_fused64.h).
+#pragma once
+#include "kernels_fused.h"
+#include "kernels_fused64.h"
+
+namespace mobrob {
+
+#define FUSED_DISPATCH_DP(dp, CALL)                   \
+  switch (dp) {                                       \
+    case 16: { constexpr int DPc = 16; CALL; } break; \
+    case 32: { constexpr int DPc = 32; CALL; } break; \
+    case 48: { constexpr int DPc = 48; CALL; } break; \
+    default: { constexpr int DPc = 64; CALL; } break; \
+  }
+
+inline void fused_launch_act(FusedState& f, FusedActArgs& a, hipStream_t st) {
+  a.net[0] = f.net[0];
+  a.net[1] = f.net[1];
+  a.Dp = f.Dp;
+  const int tiles = (a.rows + 31) / 32;
+  if (f.H == 64) {
+    FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused64_act<DPc>), dim3((2 * tiles + 3) / 4), dim3(GTHREADS), f.lds_act_bytes, st, a));
+  } else {
+    FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused_act<DPc>), dim3(2 * tiles), dim3(FTHREADS), f.lds_act_bytes, st, a));
+  }
+}
+inline void fused_launch_train(FusedState& f, FusedTrainArgs& a, int grid, hipStream_t st) {
+  FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused_train<DPc>), dim3(grid), dim3(FTHREADS), f.lds_bytes, st, a));
+}
+inline void fused64_launch_train(FusedState& f, Fused64TrainArgs& a, int grid, hipStream_t st) {
+  FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused64_train<DPc>), dim3(grid), dim3(GTHREADS), f.lds_bytes, st, a));
+}
+inline hipError_t fused_set_lds_attr(FusedState& f) {
+  hipError_t e = hipSuccess;
+  if (f.H == 64) {
+    FUSED_DISPATCH_DP(f.Dp, {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused64_train<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused64_act<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_act_bytes);
+    });
+  } else {
+    FUSED_DISPATCH_DP(f.Dp, {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_train<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_act<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_act_bytes);
+    });
+  }
+  return e;
+}
+
+}  // namespace mobrob

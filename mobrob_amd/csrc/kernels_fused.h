@@ -1233,6 +1233,7 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
 // ------------------------------------------------------------------------------------------------
 struct FusedState {
   bool enabled = false;
+  int H = 0;  // hidden width served by the fused kernels: 256 (kernels_fused.h) or 64 (kernels_fused64.h)
   int D = 0, Dp = 0, A = 0;
   float* packed = nullptr;      // all packed weights
   size_t packed_floats = 0;
@@ -1249,7 +1250,8 @@ inline size_t fused_lds_act_bytes(int Dp) { return (size_t)(32 * (Dp + 4) + 2 * 
 
 inline bool fused_shape_ok(int D, int A, int H1, int H2, int G1, int G2) {
   const int Dp = (D + 7) / 8 * 8;
-  return H1 == FH && H2 == FH && G1 == FH && G2 == FH && A <= 32 && (Dp == 16 || Dp == 32 || Dp == 48 || Dp == 64);
+  const bool same = H1 == H2 && H1 == G1 && H1 == G2 && (H1 == FH || H1 == 64);
+  return same && A <= 32 && (Dp == 16 || Dp == 32 || Dp == 48 || Dp == 64);
 }
 
 // (re)build the packed weight copies from the canonical parameter vector
@@ -1265,44 +1267,19 @@ inline void fused_repack(FusedState& f, const float* params, const int* offs, hi
   };
   // tensor ids: 0 log_std, 1 pW1, 2 pb1, 3 pW2, 4 pb2, 5 vW1, 6 vb1, 7 vW2, 8 vb2, 9 aW, 10 ab, 11 vW, 12 vb
   const int w1[2] = {1, 5}, w2[2] = {3, 7}, w3[2] = {9, 11}, heads[2] = {A, 1};
+  const int H = f.H;
   for (int n = 0; n < 2; ++n) {
-    fwd(params + offs[w1[n]], FH, D, D, f.net[n].W1f, FH / 32, Dp / 8, kTanhScale);
-    fwd(params + offs[w2[n]], FH, FH, FH, f.net[n].W2f, FH / 32, FH / 8, kTanhScale);
-    fwd(params + offs[w3[n]], heads[n], FH, FH, f.net[n].W3f, 1, FH / 8, 1.0f);
-    hipLaunchKernelGGL(k_scale_copy, dim3(1), dim3(256), 0, st, params + offs[w1[n] + 1], (float*)f.net[n].b1s, FH, kTanhScale);
-    hipLaunchKernelGGL(k_scale_copy, dim3(1), dim3(256), 0, st, params + offs[w2[n] + 1], (float*)f.net[n].b2s, FH, kTanhScale);
-    bwd(params + offs[w2[n]], FH, FH, FH, f.net[n].W2b, FH / 32, FH / 8);
-    bwd(params + offs[w3[n]], heads[n], FH, FH, f.net[n].W3b, FH / 32, 4);
+    fwd(params + offs[w1[n]], H, D, D, f.net[n].W1f, H / 32, Dp / 8, kTanhScale);
+    fwd(params + offs[w2[n]], H, H, H, f.net[n].W2f, H / 32, H / 8, kTanhScale);
+    fwd(params + offs[w3[n]], heads[n], H, H, f.net[n].W3f, 1, H / 8, 1.0f);
+    hipLaunchKernelGGL(k_scale_copy, dim3(1), dim3(256), 0, st, params + offs[w1[n] + 1], (float*)f.net[n].b1s, H, kTanhScale);
+    hipLaunchKernelGGL(k_scale_copy, dim3(1), dim3(256), 0, st, params + offs[w2[n] + 1], (float*)f.net[n].b2s, H, kTanhScale);
+    bwd(params + offs[w2[n]], H, H, H, f.net[n].W2b, H / 32, H / 8);
+    bwd(params + offs[w3[n]], heads[n], H, H, f.net[n].W3b, H / 32, 4);
   }
 }
 
-#define FUSED_DISPATCH_DP(dp, CALL)                 \
-  switch (dp) {                                     \
-    case 16: { constexpr int DPc = 16; CALL; } break; \
-    case 32: { constexpr int DPc = 32; CALL; } break; \
-    case 48: { constexpr int DPc = 48; CALL; } break; \
-    default: { constexpr int DPc = 64; CALL; } break; \
-  }
-
-inline void fused_launch_act(FusedState& f, FusedActArgs& a, hipStream_t st) {
-  a.net[0] = f.net[0];
-  a.net[1] = f.net[1];
-  a.Dp = f.Dp;
-  const int tiles = (a.rows + 31) / 32;
-  FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused_act<DPc>), dim3(2 * tiles), dim3(FTHREADS), f.lds_act_bytes, st, a));
-}
-inline void fused_launch_train(FusedState& f, FusedTrainArgs& a, int grid, hipStream_t st) {
-  FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused_train<DPc>), dim3(grid), dim3(FTHREADS), f.lds_bytes, st, a));
-}
-inline hipError_t fused_set_lds_attr(FusedState& f) {
-  hipError_t e = hipSuccess;
-  FUSED_DISPATCH_DP(f.Dp, {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_train<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_act<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_act_bytes);
-  });
-  return e;
-}
+inline void fused_launch_act(FusedState& f, FusedActArgs& a, hipStream_t st);
 
 inline bool fused_forward(FusedState& f, const float* X, int rows, bool want_pi, float* mu_out, int ldmu, bool want_v,
                           float* v_out, hipStream_t st) {

@@ -1,0 +1,479 @@
+// Fused fast path for hidden width 64 -- the shape of every reference config (data/configs/*.yaml: net_arch
+// pi=[64,64], vf=[64,64]; SB3 default) and of BASELINE config 2 (point, 1024 envs, 2x64).
+//
+// With 64-wide layers a whole network tile fits one wave: every wave owns a private 32-row tile in LDS and runs
+// the complete forward -> loss -> backward chain by itself.  There is NO workgroup barrier in the tile loop: the
+// LDS round trips between layers (C layout -> A-operand layout) are ordered by the in-order DS queue of the
+// wave.  Weights (<= 64 KB per network, fragment-packed as in kernels_fused.h) stream from L2; all weight
+// gradients (dW2 4 tiles, dW1 <= 4 tiles, dW3 2 tiles = 160 registers) stay in registers for every tile of the
+// wave and are written once, as a per-wave slab, for the deterministic reduction kernel.
+#pragma once
+#include "kernels_fused.h"
+
+namespace mobrob {
+
+constexpr int GH = 64;         // hidden width
+constexpr int GR = 32;         // rows per tile = one MFMA row block
+constexpr int GLDH = GH + 4;   // 68 floats: conflict-free ds_read_b128 (68 % 64 == 4)
+constexpr int GTHREADS = 256;  // 4 independent waves per block
+
+template <int DP>
+struct Lay64 {
+  static constexpr int LDX = DP + 4;
+  static constexpr int X = 0;
+  static constexpr int H1 = X + GR * LDX;
+  static constexpr int H2 = H1 + GR * GLDH;
+  static constexpr int DO = H2 + GR * GLDH;    // head tile [32][FLDO]
+  static constexpr int GACC = DO + GR * FLDO;  // [2][32] head-bias / log_std gradient sums of this wave
+  static constexpr int WAVE = GACC + 64;       // floats per wave
+  static constexpr int CST = 4 * WAVE;         // block-level [3][32] per-action constants
+  static constexpr int END = CST + 96;
+};
+inline size_t fused64_lds_bytes(int Dp) {
+  return (size_t)(4 * (GR * (Dp + 4) + 2 * GR * GLDH + GR * FLDO + 64) + 96) * sizeof(float);
+}
+
+// per-wave slab (floats), fragment order: dW2 [4 tiles: ib*2+jb] | dW1 [4 tiles: ib*2+jb] | dW3 [2 tiles: jb]
+//                                         | db2 [64] | db1 [64] | db3 [32] | dls [32]
+__host__ __device__ inline int s64_w2() { return 0; }
+__host__ __device__ inline int s64_w1() { return 4 * 1024; }
+__host__ __device__ inline int s64_w3() { return 8 * 1024; }
+__host__ __device__ inline int s64_b2() { return 10 * 1024; }
+__host__ __device__ inline int s64_b1() { return s64_b2() + 64; }
+__host__ __device__ inline int s64_b3() { return s64_b1() + 64; }
+__host__ __device__ inline int s64_ls() { return s64_b3() + 32; }
+__host__ __device__ inline int s64_size() { return s64_ls() + 32; }
+
+// forward layers of one 32-row tile held at LDS offset wb (per-wave region); leaves h1, h2 and the raw head tile
+template <int DP>
+__device__ __forceinline__ void tile64_forward(const FusedNet& W, int wb, int lane) {
+  using L = Lay64<DP>;
+  const int r = lane & 31, h = lane >> 5;
+  {  // layer 1
+    f32x16 c0 = splat16(W.b1s[r]), c1 = splat16(W.b1s[32 + r]);
+    constexpr int nkg = DP / 8;
+    gemm_lds_packed_r32<L::LDX>(wb + L::X, W.W1f, W.W1f + (size_t)nkg * 64, nkg, c0, c1, lane);
+    const int o = opaque(wb + L::H1 + 4 * h * GLDH + r);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      lds[o + crc(i) * GLDH] = fast_tanh_scaled(c0[i]);
+      lds[o + crc(i) * GLDH + 32] = fast_tanh_scaled(c1[i]);
+    }
+  }
+  {  // layer 2
+    f32x16 c0 = splat16(W.b2s[r]), c1 = splat16(W.b2s[32 + r]);
+    constexpr int nkg = GH / 8;
+    gemm_lds_packed_r32<GLDH>(wb + L::H1, W.W2f, W.W2f + (size_t)nkg * 64, nkg, c0, c1, lane);
+    const int o = opaque(wb + L::H2 + 4 * h * GLDH + r);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      lds[o + crc(i) * GLDH] = fast_tanh_scaled(c0[i]);
+      lds[o + crc(i) * GLDH + 32] = fast_tanh_scaled(c1[i]);
+    }
+  }
+  {  // head: [32 x 32] = h2 . W3^T, K = 64, two independent accumulation chains
+    f32x16 acc = zero16(), acc2 = zero16();
+    const int ab = 4 * opaque((wb + L::H2 + r * GLDH + 4 * h) >> 2);
+    const unsigned bo = opaque_u((unsigned)lane * 16u);
+#pragma unroll
+    for (int kg = 0; kg < 8; kg += 2) {
+      const f32x4 b0 = ldg16(W.W3f, bo + kg * 1024u), b1 = ldg16(W.W3f, bo + (kg + 1) * 1024u);
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8]);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8 + 8]);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        acc = MFMA32(a0[s_], b0[s_], acc);
+        acc2 = MFMA32(a1[s_], b1[s_], acc2);
+      }
+    }
+    const int o = opaque(wb + L::DO + 4 * h * FLDO + r);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lds[o + crc(i) * FLDO] = acc[i] + acc2[i];
+  }
+}
+
+struct Fused64TrainArgs {
+  FusedNet net[2];
+  const float* obs;
+  const float* actions; int A;
+  const float* old_logp; const float* adv; const float* ret;
+  const int* rows; int count;
+  const float* log_std;
+  const double* advstat;
+  int normalize;
+  float clip, vf_coef, ent_coef, inv_bg;
+  float* slabs;   // [gridDim.x * 4 waves][s64_size()]
+  float* sums;
+};
+
+// grid: even number of blocks; block b works for network b & 1; its 4 waves take tiles (b>>1)*4 + wave, stride.
+template <int DP>
+__global__ __launch_bounds__(GTHREADS, 1) void k_fused64_train(Fused64TrainArgs a) {
+  using L = Lay64<DP>;
+  constexpr int ldx = L::LDX, per = DP / 4;
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int net = blockIdx.x & 1;
+  const int widx = (blockIdx.x >> 1) * 4 + wave, nw = (gridDim.x >> 1) * 4;
+  const int wb = wave * L::WAVE;
+  const FusedNet W = a.net[net];
+  const int ntiles = (a.count + GR - 1) / GR;
+
+  f32x16 gW2a = zero16(), gW2b = zero16(), gW2c = zero16(), gW2d = zero16();  // [ib][jb] = 00, 10, 01, 11
+  f32x16 gW1a = zero16(), gW1b = zero16(), gW1c = zero16(), gW1d = zero16();
+  f32x16 gW3a = zero16(), gW3b = zero16();
+  float gb2 = 0.f, gb1 = 0.f;  // lane c: bias gradient of hidden column c
+  float s_pl = 0.f, s_vl = 0.f, s_kl = 0.f, s_cf = 0.f;
+
+  if (tid0 < 32) {  // per-action constants (block level)
+    const int k = tid0;
+    float iv = 0.f, lc = 0.f, bb = 0.f;
+    if (net == 0 && k < a.A) {
+      const float sd = expf(a.log_std[k]);
+      iv = 1.0f / (sd * sd);
+      lc = logf(sd) + 0.91893853320467274178f;
+    }
+    if (k < W.head) bb = W.b3[k];
+    lds[L::CST + k] = iv;
+    lds[L::CST + 32 + k] = lc;
+    lds[L::CST + 64 + k] = bb;
+  }
+  lds[wb + L::GACC + (tid0 & 63)] = 0.f;
+  __syncthreads();  // the only workgroup barrier: constants visible to the four waves
+
+  float adv_mean = 0.f, adv_sd = 1.f;
+  bool adv_on = false;
+  {
+    const double n = a.advstat[2];
+    adv_on = n > 1.0;
+    const double m = a.advstat[0] / (n > 0 ? n : 1.0);
+    double var = adv_on ? (a.advstat[1] - n * m * m) / (n - 1.0) : 0.0;
+    if (var < 0.0) var = 0.0;
+    adv_mean = (float)m;
+    adv_sd = (float)sqrt(var);
+  }
+
+  for (int tile = widx; tile < ntiles; tile += nw) {
+    const int lane = opaque(tid0) & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int row0 = tile * GR;
+    // ---- gather 32 observation rows (zero beyond the minibatch) ----
+#pragma unroll
+    for (int i = lane; i < GR * per; i += 64) {
+      const int rr = i / per, c = i - rr * per;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row0 + rr < a.count)
+        v = ldg16(a.obs, (unsigned)a.rows[row0 + rr] * (unsigned)(DP * 4) + (unsigned)(c * 16));
+      *reinterpret_cast<f32x4*>(&lds[wb + L::X + rr * ldx + 4 * c]) = v;
+    }
+    tile64_forward<DP>(W, wb, lane);
+
+    // ---- loss: two lanes per row (q = action parity); dL/d(head) -> head tile, zero padded ----
+    {
+      const int rr = r, q = h;
+      const bool live = row0 + rr < a.count;
+      const unsigned src = live ? (unsigned)a.rows[row0 + rr] : 0u;
+      const int db = opaque(wb + L::DO + rr * FLDO + q);
+      const int cb = opaque(L::CST + q);
+      const int gb = opaque(wb + L::GACC + q);
+      const int A = a.A;
+      if (net == 0) {
+        const float* arow = a.actions + (size_t)src * A + q;
+        float lp = 0.f;
+        if (live)
+          for (int j = 0; 2 * j + q < A; ++j) {
+            const float d = arow[2 * j] - (lds[db + 2 * j] + lds[cb + 64 + 2 * j]);
+            lp += -(d * d) * (0.5f * lds[cb + 2 * j]) - lds[cb + 32 + 2 * j];
+          }
+        lp += __shfl_xor(lp, 32, 64);
+        float g_logp = 0.f;
+        if (live) {
+          float adv = a.adv[src];
+          if (a.normalize && adv_on) adv = (adv - adv_mean) / (adv_sd + 1e-8f);
+          const float log_ratio = lp - a.old_logp[src];
+          const float ratio = expf(log_ratio);
+          const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
+          const float s1 = adv * ratio, s2 = adv * fminf(fmaxf(ratio, lo), hi);
+          if (q == 0) {
+            s_pl += fminf(s1, s2);
+            s_cf += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
+            s_kl += (ratio - 1.0f) - log_ratio;
+          }
+          const float in_range = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+          const float w1 = (s1 < s2) ? 1.f : ((s1 > s2) ? 0.f : 0.5f);
+          g_logp = -(w1 * adv + (1.0f - w1) * adv * in_range) * a.inv_bg * ratio;
+        }
+        for (int j = 0; j < 16; ++j) {  // k = 2j + q; wave-uniform trip count
+          const int k = 2 * j + q;
+          float gm = 0.f, gl = 0.f;
+          if (k < A && live) {
+            const float iv = lds[cb + 2 * j];
+            const float d = arow[2 * j] - (lds[db + 2 * j] + lds[cb + 64 + 2 * j]);
+            gm = g_logp * d * iv;
+            gl = g_logp * (d * d * iv - 1.0f);
+          }
+          lds[db + 2 * j] = gm;
+          if (2 * j < A) {  // wave-uniform: sum over the 32 rows (lanes with equal q)
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+              gm += __shfl_xor(gm, o, 64);
+              gl += __shfl_xor(gl, o, 64);
+            }
+            if (r == 0) {
+              lds[gb + 2 * j] += gm;
+              lds[gb + 32 + 2 * j] += gl;
+            }
+          }
+        }
+      } else {
+        float dv = 0.f;
+        if (live && q == 0) {
+          const float v = lds[db] + lds[cb + 64], rt = a.ret[src];
+          s_vl += (rt - v) * (rt - v);
+          dv = a.vf_coef * 2.0f * (v - rt) * a.inv_bg;
+        }
+        for (int j = 0; j < 16; ++j) lds[db + 2 * j] = (j == 0) ? dv : 0.f;
+        const float t = wave_sum(dv);
+        if (lane == 0) lds[gb] += t;
+      }
+    }
+
+    // ---- dW3 += dout^T . h2  (K = 32 rows) ----
+    {
+      const int ao = opaque(wb + L::DO + h * FLDO + r);
+      const int bo = opaque(wb + L::H2 + h * GLDH + r);
+#pragma unroll 4
+      for (int k = 0; k < GR; k += 2)
+        mfma_x1y2(gW3a, gW3b, lds[ao + k * FLDO], lds[bo + k * GLDH], lds[bo + k * GLDH + 32]);
+    }
+    // ---- dh2 = dout . W3 (K = 32) ; dz2 = dh2 * (1 - h2^2) in place ----
+    {
+      f32x16 c0 = zero16(), c1 = zero16();
+      gemm_lds_packed_r32<FLDO>(wb + L::DO, W.W3b, W.W3b + 4 * 64, 4, c0, c1, lane);
+      const int o = opaque(wb + L::H2 + 4 * h * GLDH + r);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float hv;
+        hv = lds[o + crc(i) * GLDH];      lds[o + crc(i) * GLDH] = c0[i] * (1.0f - hv * hv);
+        hv = lds[o + crc(i) * GLDH + 32]; lds[o + crc(i) * GLDH + 32] = c1[i] * (1.0f - hv * hv);
+      }
+    }
+    // ---- bias gradient of layer 2: column sums of dz2 (lane c <-> column c) ----
+    {
+      const int o = opaque(wb + L::H2 + lane);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
+      for (int rr = 0; rr < GR; rr += 2) {
+        s0 += lds[o + rr * GLDH];
+        s1 += lds[o + (rr + 1) * GLDH];
+      }
+      gb2 += s0 + s1;
+    }
+    // ---- dW2 += dz2^T . h1  (64 x 64, K = 32 rows) ----
+    {
+      const int ao = opaque(wb + L::H2 + h * GLDH + r);
+      const int bo = opaque(wb + L::H1 + h * GLDH + r);
+#pragma unroll 4
+      for (int k = 0; k < GR; k += 2)
+        mfma_x2y2(gW2a, gW2b, gW2c, gW2d, lds[ao + k * GLDH], lds[ao + k * GLDH + 32], lds[bo + k * GLDH],
+                  lds[bo + k * GLDH + 32]);
+    }
+    // ---- dh1 = dz2 . W2 (K = 64) ; dz1 = dh1 * (1 - h1^2) in place ----
+    {
+      f32x16 c0 = zero16(), c1 = zero16();
+      constexpr int nkg = GH / 8;
+      gemm_lds_packed_r32<GLDH>(wb + L::H2, W.W2b, W.W2b + (size_t)nkg * 64, nkg, c0, c1, lane);
+      const int o = opaque(wb + L::H1 + 4 * h * GLDH + r);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float hv;
+        hv = lds[o + crc(i) * GLDH];      lds[o + crc(i) * GLDH] = c0[i] * (1.0f - hv * hv);
+        hv = lds[o + crc(i) * GLDH + 32]; lds[o + crc(i) * GLDH + 32] = c1[i] * (1.0f - hv * hv);
+      }
+    }
+    {
+      const int o = opaque(wb + L::H1 + lane);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
+      for (int rr = 0; rr < GR; rr += 2) {
+        s0 += lds[o + rr * GLDH];
+        s1 += lds[o + (rr + 1) * GLDH];
+      }
+      gb1 += s0 + s1;
+    }
+    // ---- dW1 += dz1^T . X  (64 x DP, K = 32 rows) ----
+    {
+      constexpr bool two = DP > 32;
+      const int ao = opaque(wb + L::H1 + h * GLDH + r);
+      const int c0 = (r < DP) ? r : 0;
+      const int c1 = (32 + r < DP) ? 32 + r : c0;
+      const int b0o = opaque(wb + L::X + h * ldx + c0), b1o = opaque(wb + L::X + h * ldx + c1);
+#pragma unroll 4
+      for (int k = 0; k < GR; k += 2) {
+        if (two)
+          mfma_x2y2(gW1a, gW1b, gW1c, gW1d, lds[ao + k * GLDH], lds[ao + k * GLDH + 32], lds[b0o + k * ldx],
+                    lds[b1o + k * ldx]);
+        else
+          mfma_x2y1(gW1a, gW1b, lds[ao + k * GLDH], lds[ao + k * GLDH + 32], lds[b0o + k * ldx]);
+      }
+    }
+  }
+
+  // ---- per-wave slab ----
+  const int lane = tid0 & 63;
+  float* slab = a.slabs + (size_t)(blockIdx.x * 4 + wave) * s64_size();
+  asm volatile("s_nop 15\n\ts_nop 3");  // last asm MFMA's D -> VALU/VMEM read
+  auto put = [&](int region, int t, const f32x16& g) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = g[4 * qd + e];
+      stg16(slab + region, (unsigned)((t * 4 + qd) * 64 + lane) * 16u, v);
+    }
+  };
+  put(s64_w2(), 0, gW2a); put(s64_w2(), 2, gW2b); put(s64_w2(), 1, gW2c); put(s64_w2(), 3, gW2d);  // t = ib*2 + jb
+  put(s64_w1(), 0, gW1a); put(s64_w1(), 2, gW1b);
+  if (DP > 32) { put(s64_w1(), 1, gW1c); put(s64_w1(), 3, gW1d); }
+  put(s64_w3(), 0, gW3a); put(s64_w3(), 1, gW3b);
+  slab[s64_b2() + lane] = gb2;
+  slab[s64_b1() + lane] = gb1;
+  if (lane < 32) {
+    slab[s64_b3() + lane] = lds[wb + L::GACC + lane];
+    slab[s64_ls() + lane] = lds[wb + L::GACC + 32 + lane];
+  }
+  const float t0 = wave_sum(s_pl), t1 = wave_sum(s_vl), t2 = wave_sum(s_kl), t3 = wave_sum(s_cf);
+  if (lane == 0) {
+    if (net == 0) {
+      atomicAdd(&a.sums[0], t0);
+      atomicAdd(&a.sums[2], t2);
+      atomicAdd(&a.sums[3], t3);
+    } else {
+      atomicAdd(&a.sums[1], t1);
+    }
+  }
+}
+
+// ---- slab reduction for the 64-wide path: thread p sums slab position p over the waves of its network ----
+struct Slab64ReduceArgs {
+  const float* slabs; int nblocks;  // train grid size; slab index = block*4 + wave, network = block & 1
+  float* grads;
+  int offs[14];
+  int D, A;
+  float ent_coef, b_local, inv_bg;
+  float* sums;
+};
+__device__ __forceinline__ int slab64_to_canonical(const Slab64ReduceArgs& s, int net, int p) {
+  const int T_W1 = net == 0 ? 1 : 5, T_B1 = net == 0 ? 2 : 6, T_W2 = net == 0 ? 3 : 7, T_B2 = net == 0 ? 4 : 8;
+  const int T_W3 = net == 0 ? 9 : 11, T_B3 = net == 0 ? 10 : 12;
+  const int head = net == 0 ? s.A : 1;
+  auto frag = [](int q, int* t, int* i, int* lane) {
+    *lane = (q >> 2) & 63;
+    *i = (q & 3) + 4 * ((q >> 8) & 3);
+    *t = q >> 10;
+  };
+  int t, i, lane;
+  if (p < s64_w1()) {  // dW2[n][j]
+    frag(p, &t, &i, &lane);
+    return s.offs[T_W2] + (32 * (t >> 1) + crc(i) + 4 * (lane >> 5)) * GH + 32 * (t & 1) + (lane & 31);
+  }
+  if (p < s64_w3()) {  // dW1[n][j]
+    frag(p - s64_w1(), &t, &i, &lane);
+    const int j = 32 * (t & 1) + (lane & 31);
+    return j < s.D ? s.offs[T_W1] + (32 * (t >> 1) + crc(i) + 4 * (lane >> 5)) * s.D + j : -1;
+  }
+  if (p < s64_b2()) {  // dW3[a][j]
+    frag(p - s64_w3(), &t, &i, &lane);
+    const int a_ = crc(i) + 4 * (lane >> 5);
+    return a_ < head ? s.offs[T_W3] + a_ * GH + 32 * t + (lane & 31) : -1;
+  }
+  if (p < s64_b1()) return s.offs[T_B2] + (p - s64_b2());
+  if (p < s64_b3()) return s.offs[T_B1] + (p - s64_b1());
+  if (p < s64_ls()) {
+    const int k = p - s64_b3();
+    return k < head ? s.offs[T_B3] + k : -1;
+  }
+  const int k = p - s64_ls();
+  return (net == 0 && k < s.A) ? s.offs[0] + k : -1;
+}
+__global__ __launch_bounds__(256) void k_slab64_reduce(Slab64ReduceArgs s) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int net = blockIdx.y;
+  if (p == 0 && net == 0) s.sums[4] = s.b_local;
+  if (p >= s64_size()) return;
+  const int dst = slab64_to_canonical(s, net, p);
+  if (dst < 0) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // blocks of this network: net, net+2, ...; 4 waves each
+  for (int b = net; b < s.nblocks; b += 2) {
+    const float* src = s.slabs + (size_t)(b * 4) * s64_size() + p;
+    a0 += src[0];
+    a1 += src[s64_size()];
+    a2 += src[2 * (size_t)s64_size()];
+    a3 += src[3 * (size_t)s64_size()];
+  }
+  float acc = (a0 + a1) + (a2 + a3);
+  if (dst < s.offs[1]) acc += s.ent_coef * (-s.b_local) * s.inv_bg;
+  s.grads[dst] = acc;
+}
+
+// ---- rollout-time forward + sampling for 64-wide nets: one wave per 32-row tile and network ----
+template <int DP>
+__global__ __launch_bounds__(GTHREADS, 1) void k_fused64_act(FusedActArgs a) {
+  using L = Lay64<DP>;
+  constexpr int ldx = L::LDX, per = DP / 4;
+  const int tid0 = threadIdx.x, lane = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int gw = blockIdx.x * 4 + wave;  // global wave: network = gw & 1, tile = gw >> 1
+  const int net = gw & 1, tile = gw >> 1;
+  const int wb = wave * L::WAVE;
+  const int row0 = tile * GR;
+  if (row0 >= a.rows) return;
+  if ((net == 0 && !a.want_pi) || (net == 1 && !a.want_v)) return;
+  const FusedNet W = a.net[net];
+#pragma unroll
+  for (int i = lane; i < GR * per; i += 64) {
+    const int rr = i / per, c = i - rr * per;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row0 + rr < a.rows) v = ldg16(a.X, (unsigned)(row0 + rr) * (unsigned)(DP * 4) + (unsigned)(c * 16));
+    *reinterpret_cast<f32x4*>(&lds[wb + L::X + rr * ldx + 4 * c]) = v;
+  }
+  tile64_forward<DP>(W, wb, lane);
+  if (lane >= GR) return;
+  const int row = row0 + lane;
+  if (row >= a.rows) return;
+  const int db = opaque(wb + L::DO + lane * FLDO);
+  if (net == 1) {
+    a.v[row] = lds[db] + W.b3[0];
+    return;
+  }
+  float lp = 0.f;
+  float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
+  for (int k = 0; k < a.A; ++k) {
+    const float m = lds[db + k] + W.b3[k];
+    if (a.mu) a.mu[(size_t)row * a.ldmu + k] = m;
+    if (a.sample) {
+      float e;
+      if (a.eps != nullptr) {
+        e = a.eps[(size_t)row * a.A + k];
+      } else {
+        if ((k & 3) == 0) {
+          float z[4];
+          box_muller4(philox4x32_10((uint32_t)row, (uint32_t)(k >> 2), a.draw + (a.draw_base ? *a.draw_base : 0u),
+                                    0x45505331u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32)), z);
+          z0 = z[0]; z1 = z[1]; z2 = z[2]; z3 = z[3];
+        }
+        const int q = k & 3;
+        e = q == 0 ? z0 : (q == 1 ? z1 : (q == 2 ? z2 : z3));
+      }
+      const float sd = expf(a.log_std[k]);
+      const float act = m + e * sd;
+      const float d = act - m;
+      lp += -(d * d) / (2.0f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
+      if (a.act_raw) a.act_raw[(size_t)row * a.A + k] = act;
+      if (a.act_clip) a.act_clip[(size_t)row * a.A + k] = fminf(fmaxf(act, a.lo), a.hi);
+    }
+  }
+  if (a.sample && a.logp) a.logp[row] = lp;
+}
+
+}  // namespace mobrob

@@ -23,11 +23,12 @@ def make_engine(g=None, **kw):
     return PPOEngine(**kw)
 
 
+@pytest.mark.parametrize("fast", [True, False])  # fused 64-wide kernels / generic GEMM chain
 @pytest.mark.parametrize("env", ENVS)
-def test_act_matches_golden_and_oracle(env):
+def test_act_matches_golden_and_oracle(env, fast):
     g = load_golden(env)
     p = golden_params(g)
-    e = make_engine(g)
+    e = make_engine(g, fast_kernels=fast)
     e.set_params(p)
     a_raw, a_clip, val, lp = e.act(g["last_obs"], g["fwd/eps"])
     o_raw, o_clip, o_val, o_lp = O.act(p, g["last_obs"], g["fwd/eps"])
@@ -66,15 +67,16 @@ def test_gae_bit_exact_hyper(gamma, lam):
     e.close()
 
 
+@pytest.mark.parametrize("fast", [True, False])
 @pytest.mark.parametrize("env", ENVS)
-def test_minibatch_step_matches_golden(env):
+def test_minibatch_step_matches_golden(env, fast):
     """One optimizer step from the checkpoint's real weights + real Adam state on the golden minibatch."""
     g = load_golden(env)
     p, st, h = golden_params(g), golden_adam(g), golden_hyper(g)
     obs, act, old_v, old_lp, adv, ret = golden_minibatch(g)
     B, D, A = obs.shape[0], obs.shape[1], act.shape[1]
     # inject the minibatch as a T=B, N=1 rollout; identity permutation -> the minibatch is rows 0..B-1
-    e = make_engine(g, n_envs=1, n_steps=B, batch_size=B, n_epochs=1)
+    e = make_engine(g, n_envs=1, n_steps=B, batch_size=B, n_epochs=1, fast_kernels=fast)
     e.set_params(p)
     e.set_optimizer_state(st.exp_avg, st.exp_avg_sq, st.step)
     buf = dict(obs=obs[:, None], actions=act[:, None], rewards=np.zeros((B, 1), np.float32),
@@ -106,7 +108,9 @@ def test_minibatch_step_matches_golden(env):
 @pytest.mark.parametrize("shape", [dict(D=14, A=2, H=64, T=40, N=5, B=50, E=2),
                                    dict(D=58, A=12, H=64, T=25, N=16, B=100, E=2),
                                    dict(D=58, A=12, H=256, T=16, N=24, B=128, E=1),
-                                   dict(D=43, A=2, H=64, T=30, N=7, B=64, E=2)])   # 210 = 3*64 + 18: short last batch
+                                   dict(D=43, A=2, H=64, T=30, N=7, B=64, E=2),    # 210 = 3*64 + 18: short last batch
+                                   dict(D=12, A=18, H=64, T=64, N=300, B=6000, E=1),  # many tiles per wave
+                                   dict(D=58, A=12, H=64, T=25, N=16, B=100, E=2, fast=False)])
 def test_full_train_matches_oracle(shape):
     """PPO.train over several epochs with supplied permutations (incl. a short final minibatch)."""
     D, A, H, T, N, B, E = (shape[k] for k in "DAHTNBE")
@@ -127,7 +131,8 @@ def test_full_train_matches_oracle(shape):
     perms = np.stack([rng.permutation(T * N) for _ in range(E)])
 
     e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H),
-                    gamma=h.gamma, gae_lambda=h.gae_lambda, ent_coef=h.ent_coef, learning_rate=h.learning_rate)
+                    gamma=h.gamma, gae_lambda=h.gae_lambda, ent_coef=h.ent_coef, learning_rate=h.learning_rate,
+                    fast_kernels=shape.get("fast", True))
     e.set_params(p)
     e.load_rollout(buf, lv, dones)
     e.compute_gae()
