@@ -320,7 +320,7 @@ int fused_init(mobrob_ppo_engine* e) {
   f.max_grid = 256;
   if (H == 64) {
     f.slab_floats = s64_size();
-    CHK(dalloc(e, &f.slabs, (size_t)f.max_grid * 4 * f.slab_floats));  // one slab per wave
+    CHK(dalloc(e, &f.slabs, (size_t)f.max_grid * f.slab_floats));  // one slab per block
     f.lds_bytes = fused64_lds_bytes(e->Dp);
     f.lds_act_bytes = f.lds_bytes;
   } else {
@@ -345,7 +345,7 @@ void fused64_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, floa
   a.clip = (float)e->cfg.clip_range; a.vf_coef = (float)e->cfg.vf_coef; a.ent_coef = (float)e->cfg.ent_coef;
   a.inv_bg = inv_bg; a.slabs = f.slabs; a.sums = e->grads + e->P;
   const int ntiles = cdiv(B, GR);
-  const int grid = 2 * std::min(f.max_grid / 2, cdiv(ntiles, 4));
+  const int grid = 2 * std::min(f.max_grid / 2, cdiv(ntiles, g_waves(e->Dp)));
   {
     ProfScope ps(e, MOBROB_K_TRAIN_GRAD);
     fused64_launch_train(f, a, grid, e->stream);

@@ -19,7 +19,7 @@ inline void fused_launch_act(FusedState& f, FusedActArgs& a, hipStream_t st) {
   a.Dp = f.Dp;
   const int tiles = (a.rows + 31) / 32;
   if (f.H == 64) {
-    FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused64_act<DPc>), dim3((2 * tiles + 3) / 4), dim3(GTHREADS), f.lds_act_bytes, st, a));
+    FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused64_act<DPc>), dim3((2 * tiles + g_waves(DPc) - 1) / g_waves(DPc)), dim3(g_waves(DPc) * 64), f.lds_act_bytes, st, a));
   } else {
     FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused_act<DPc>), dim3(2 * tiles), dim3(FTHREADS), f.lds_act_bytes, st, a));
   }
@@ -28,7 +28,7 @@ inline void fused_launch_train(FusedState& f, FusedTrainArgs& a, int grid, hipSt
   FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused_train<DPc>), dim3(grid), dim3(FTHREADS), f.lds_bytes, st, a));
 }
 inline void fused64_launch_train(FusedState& f, Fused64TrainArgs& a, int grid, hipStream_t st) {
-  FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused64_train<DPc>), dim3(grid), dim3(GTHREADS), f.lds_bytes, st, a));
+  FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused64_train<DPc>), dim3(grid), dim3(g_waves(DPc) * 64), f.lds_bytes, st, a));
 }
 inline hipError_t fused_set_lds_attr(FusedState& f) {
   hipError_t e = hipSuccess;

@@ -15,7 +15,9 @@ namespace mobrob {
 constexpr int GH = 64;         // hidden width
 constexpr int GR = 32;         // rows per tile = one MFMA row block
 constexpr int GLDH = GH + 4;   // 68 floats: conflict-free ds_read_b128 (68 % 64 == 4)
-constexpr int GTHREADS = 256;  // 4 independent waves per block
+// independent waves per block: as many as fit 160 KB of LDS -> 5 or 6 waves per CU, i.e. two waves on some SIMDs
+// (each wave needs <= 256 registers), which hides most of the phase-boundary latency of a lone wave
+__host__ __device__ constexpr int g_waves(int DP) { return DP <= 32 ? 6 : 5; }
 
 template <int DP>
 struct Lay64 {
@@ -26,14 +28,15 @@ struct Lay64 {
   static constexpr int DO = H2 + GR * GLDH;    // head tile [32][FLDO]
   static constexpr int GACC = DO + GR * FLDO;  // [2][32] head-bias / log_std gradient sums of this wave
   static constexpr int WAVE = GACC + 64;       // floats per wave
-  static constexpr int CST = 4 * WAVE;         // block-level [3][32] per-action constants
+  static constexpr int NWV = g_waves(DP);
+  static constexpr int CST = NWV * WAVE;       // block-level [3][32] per-action constants
   static constexpr int END = CST + 96;
 };
 inline size_t fused64_lds_bytes(int Dp) {
-  return (size_t)(4 * (GR * (Dp + 4) + 2 * GR * GLDH + GR * FLDO + 64) + 96) * sizeof(float);
+  return (size_t)(g_waves(Dp) * (GR * (Dp + 4) + 2 * GR * GLDH + GR * FLDO + 64) + 96) * sizeof(float);
 }
 
-// per-wave slab (floats), fragment order: dW2 [4 tiles: ib*2+jb] | dW1 [4 tiles: ib*2+jb] | dW3 [2 tiles: jb]
+// per-BLOCK slab (floats; the waves of a block are summed through LDS at kernel end), fragment order: dW2 [4 tiles: ib*2+jb] | dW1 [4 tiles: ib*2+jb] | dW3 [2 tiles: jb]
 //                                         | db2 [64] | db1 [64] | db3 [32] | dls [32]
 __host__ __device__ inline int s64_w2() { return 0; }
 __host__ __device__ inline int s64_w1() { return 4 * 1024; }
@@ -102,19 +105,19 @@ struct Fused64TrainArgs {
   const double* advstat;
   int normalize;
   float clip, vf_coef, ent_coef, inv_bg;
-  float* slabs;   // [gridDim.x * 4 waves][s64_size()]
+  float* slabs;   // [gridDim.x][s64_size()]
   float* sums;
 };
 
-// grid: even number of blocks; block b works for network b & 1; its 4 waves take tiles (b>>1)*4 + wave, stride.
+// grid: even number of blocks; block b works for network b & 1; its NWV waves take tiles (b>>1)*NWV + wave, stride.
 template <int DP>
-__global__ __launch_bounds__(GTHREADS, 1) void k_fused64_train(Fused64TrainArgs a) {
+__global__ __launch_bounds__(g_waves(DP) * 64, 2) void k_fused64_train(Fused64TrainArgs a) {
   using L = Lay64<DP>;
-  constexpr int ldx = L::LDX, per = DP / 4;
+  constexpr int ldx = L::LDX, per = DP / 4, NWV = L::NWV;
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int net = blockIdx.x & 1;
-  const int widx = (blockIdx.x >> 1) * 4 + wave, nw = (gridDim.x >> 1) * 4;
+  const int widx = (blockIdx.x >> 1) * NWV + wave, nw = (gridDim.x >> 1) * NWV;
   const int wb = wave * L::WAVE;
   const FusedNet W = a.net[net];
   const int ntiles = (a.count + GR - 1) / GR;
@@ -319,10 +322,57 @@ __global__ __launch_bounds__(GTHREADS, 1) void k_fused64_train(Fused64TrainArgs 
     }
   }
 
-  // ---- per-wave slab ----
+  // ---- sum the block's waves through LDS (fixed order), then wave 0 writes the block slab ----
   const int lane = tid0 & 63;
-  float* slab = a.slabs + (size_t)(blockIdx.x * 4 + wave) * s64_size();
-  asm volatile("s_nop 15\n\ts_nop 3");  // last asm MFMA's D -> VALU/VMEM read
+  asm volatile("s_nop 15\n\ts_nop 3");  // last asm MFMA's D -> VALU read
+  __syncthreads();                          // every wave has left its tile loop: the tile regions are free
+  auto block_sum16 = [&](f32x16& g) {
+    if (wave > 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) lds[(wave - 1) * 1024 + i * 64 + lane] = g[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float v = g[i];
+#pragma unroll
+        for (int w = 0; w < NWV - 1; ++w) v += lds[w * 1024 + i * 64 + lane];
+        g[i] = v;
+      }
+    }
+    __syncthreads();
+  };
+  block_sum16(gW2a); block_sum16(gW2b); block_sum16(gW2c); block_sum16(gW2d);
+  block_sum16(gW1a); block_sum16(gW1b);
+  if (DP > 32) { block_sum16(gW1c); block_sum16(gW1d); }
+  block_sum16(gW3a); block_sum16(gW3b);
+  {
+    if (wave > 0) {
+      lds[(wave - 1) * 128 + lane] = gb2;
+      lds[(wave - 1) * 128 + 64 + lane] = gb1;
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int w = 0; w < NWV - 1; ++w) {
+        gb2 += lds[w * 128 + lane];
+        gb1 += lds[w * 128 + 64 + lane];
+      }
+    }
+  }
+  const float t0 = wave_sum(s_pl), t1 = wave_sum(s_vl), t2 = wave_sum(s_kl), t3 = wave_sum(s_cf);
+  if (lane == 0) {
+    if (net == 0) {
+      atomicAdd(&a.sums[0], t0);
+      atomicAdd(&a.sums[2], t2);
+      atomicAdd(&a.sums[3], t3);
+    } else {
+      atomicAdd(&a.sums[1], t1);
+    }
+  }
+  if (wave != 0) return;
+  float* slab = a.slabs + (size_t)blockIdx.x * s64_size();
   auto put = [&](int region, int t, const f32x16& g) {
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
@@ -338,25 +388,21 @@ __global__ __launch_bounds__(GTHREADS, 1) void k_fused64_train(Fused64TrainArgs 
   put(s64_w3(), 0, gW3a); put(s64_w3(), 1, gW3b);
   slab[s64_b2() + lane] = gb2;
   slab[s64_b1() + lane] = gb1;
-  if (lane < 32) {
-    slab[s64_b3() + lane] = lds[wb + L::GACC + lane];
-    slab[s64_ls() + lane] = lds[wb + L::GACC + 32 + lane];
-  }
-  const float t0 = wave_sum(s_pl), t1 = wave_sum(s_vl), t2 = wave_sum(s_kl), t3 = wave_sum(s_cf);
-  if (lane == 0) {
-    if (net == 0) {
-      atomicAdd(&a.sums[0], t0);
-      atomicAdd(&a.sums[2], t2);
-      atomicAdd(&a.sums[3], t3);
-    } else {
-      atomicAdd(&a.sums[1], t1);
+  if (lane < 32) {  // head-bias / log_std sums of all waves (their GACC regions were not touched by the reduction)
+    float b3s = 0.f, lss = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+      b3s += lds[w * L::WAVE + L::GACC + lane];
+      lss += lds[w * L::WAVE + L::GACC + 32 + lane];
     }
+    slab[s64_b3() + lane] = b3s;
+    slab[s64_ls() + lane] = lss;
   }
 }
 
 // ---- slab reduction for the 64-wide path: thread p sums slab position p over the waves of its network ----
 struct Slab64ReduceArgs {
-  const float* slabs; int nblocks;  // train grid size; slab index = block*4 + wave, network = block & 1
+  const float* slabs; int nblocks;  // train grid size; slab index = block, network = block & 1
   float* grads;
   int offs[14];
   int D, A;
@@ -403,14 +449,18 @@ __global__ __launch_bounds__(256) void k_slab64_reduce(Slab64ReduceArgs s) {
   if (p >= s64_size()) return;
   const int dst = slab64_to_canonical(s, net, p);
   if (dst < 0) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // blocks of this network: net, net+2, ...; 4 waves each
-  for (int b = net; b < s.nblocks; b += 2) {
-    const float* src = s.slabs + (size_t)(b * 4) * s64_size() + p;
-    a0 += src[0];
-    a1 += src[s64_size()];
-    a2 += src[2 * (size_t)s64_size()];
-    a3 += src[3 * (size_t)s64_size()];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // blocks of this network: net, net+2, ...
+  const float* src = s.slabs + (size_t)net * s64_size() + p;
+  const size_t stride = 2 * (size_t)s64_size();
+  const int n = (s.nblocks - net + 1) / 2;
+  int w = 0;
+  for (; w + 4 <= n; w += 4) {
+    a0 += src[(size_t)w * stride];
+    a1 += src[(size_t)(w + 1) * stride];
+    a2 += src[(size_t)(w + 2) * stride];
+    a3 += src[(size_t)(w + 3) * stride];
   }
+  for (; w < n; ++w) a0 += src[(size_t)w * stride];
   float acc = (a0 + a1) + (a2 + a3);
   if (dst < s.offs[1]) acc += s.ent_coef * (-s.b_local) * s.inv_bg;
   s.grads[dst] = acc;
@@ -418,12 +468,12 @@ __global__ __launch_bounds__(256) void k_slab64_reduce(Slab64ReduceArgs s) {
 
 // ---- rollout-time forward + sampling for 64-wide nets: one wave per 32-row tile and network ----
 template <int DP>
-__global__ __launch_bounds__(GTHREADS, 1) void k_fused64_act(FusedActArgs a) {
+__global__ __launch_bounds__(g_waves(DP) * 64, 2) void k_fused64_act(FusedActArgs a) {
   using L = Lay64<DP>;
   constexpr int ldx = L::LDX, per = DP / 4;
   const int tid0 = threadIdx.x, lane = tid0 & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-  const int gw = blockIdx.x * 4 + wave;  // global wave: network = gw & 1, tile = gw >> 1
+  const int gw = blockIdx.x * L::NWV + wave;  // global wave: network = gw & 1, tile = gw >> 1
   const int net = gw & 1, tile = gw >> 1;
   const int wb = wave * L::WAVE;
   const int row0 = tile * GR;
