@@ -321,8 +321,8 @@ int fused_init(mobrob_ppo_engine* e) {
   if (H == 64) {
     f.slab_floats = s64_size();
     CHK(dalloc(e, &f.slabs, (size_t)f.max_grid * f.slab_floats));  // one slab per block
-    f.lds_bytes = fused64_lds_bytes(e->Dp);
-    f.lds_act_bytes = f.lds_bytes;
+    f.lds_bytes = fused64_train_lds_bytes(e->Dp);
+    f.lds_act_bytes = fused64_lds_bytes(e->Dp);
   } else {
     f.slab_floats = slab_size(e->Dp);
     CHK(dalloc(e, &f.slabs, (size_t)f.max_grid * f.slab_floats));
@@ -345,7 +345,9 @@ void fused64_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, floa
   a.clip = (float)e->cfg.clip_range; a.vf_coef = (float)e->cfg.vf_coef; a.ent_coef = (float)e->cfg.ent_coef;
   a.inv_bg = inv_bg; a.slabs = f.slabs; a.sums = e->grads + e->P;
   const int ntiles = cdiv(B, GR);
-  const int grid = 2 * std::min(f.max_grid / 2, cdiv(ntiles, g_waves(e->Dp)));
+  const int grid = 2 * std::min(f.max_grid / 2, cdiv(ntiles, g_train_waves(e->Dp)));
+  a.wpack[0] = reinterpret_cast<const float*>(f.net[0].W1f);
+  a.wpack[1] = reinterpret_cast<const float*>(f.net[1].W1f);
   {
     ProfScope ps(e, MOBROB_K_TRAIN_GRAD);
     fused64_launch_train(f, a, grid, e->stream);

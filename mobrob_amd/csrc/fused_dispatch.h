@@ -28,7 +28,7 @@ inline void fused_launch_train(FusedState& f, FusedTrainArgs& a, int grid, hipSt
   FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused_train<DPc>), dim3(grid), dim3(FTHREADS), f.lds_bytes, st, a));
 }
 inline void fused64_launch_train(FusedState& f, Fused64TrainArgs& a, int grid, hipStream_t st) {
-  FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused64_train<DPc>), dim3(grid), dim3(g_waves(DPc) * 64), f.lds_bytes, st, a));
+  FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused64_train<DPc>), dim3(grid), dim3(Lay64<DPc>::TNWV * 64), f.lds_bytes, st, a));
 }
 inline hipError_t fused_set_lds_attr(FusedState& f) {
   hipError_t e = hipSuccess;

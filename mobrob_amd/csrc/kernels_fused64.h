@@ -19,6 +19,18 @@ constexpr int GLDH = GH + 4;   // 68 floats: conflict-free ds_read_b128 (68 % 64
 // (each wave needs <= 256 registers), which hides most of the phase-boundary latency of a lone wave
 __host__ __device__ constexpr int g_waves(int DP) { return DP <= 32 ? 6 : 5; }
 
+// packed weights of ONE network as laid out in FusedState::packed (and mirrored into LDS by the train kernel)
+template <int DP>
+struct Wts64 {
+  static constexpr int W1F = 0;
+  static constexpr int W2F = W1F + 2 * (DP / 8) * 256;
+  static constexpr int W3F = W2F + 2 * 8 * 256;
+  static constexpr int W2B = W3F + 8 * 256;
+  static constexpr int W3B = W2B + 2 * 8 * 256;
+  static constexpr int B1S = W3B + 2 * 4 * 256;
+  static constexpr int B2S = B1S + 64;
+  static constexpr int TOTAL = B2S + 64;
+};
 template <int DP>
 struct Lay64 {
   static constexpr int LDX = DP + 4;
@@ -31,7 +43,19 @@ struct Lay64 {
   static constexpr int NWV = g_waves(DP);
   static constexpr int CST = NWV * WAVE;       // block-level [3][32] per-action constants
   static constexpr int END = CST + 96;
+  // training kernel: the network's packed weights are LDS resident in front of the wave regions
+  static constexpr int TW = Wts64<DP>::TOTAL;
+  static constexpr int TNWV = (40960 - TW - 96) / WAVE;   // waves per block that fit 160 KB (4 for DP=16, else 3)
+  static constexpr int TCST = TW + TNWV * WAVE;
+  static constexpr int TEND = TCST + 96;
 };
+__host__ __device__ constexpr int g_train_waves(int DP) {
+  return (40960 - (2 * (DP / 8) * 256 + 2 * 4096 + 2048 + 4096 / 2 + 128) - 96) / (GR * (DP + 4) + 2 * GR * GLDH + GR * FLDO + 64);
+}
+inline size_t fused64_train_lds_bytes(int Dp) {
+  const int tw = 2 * (Dp / 8) * 256 + 2 * 4096 + 2048 + 2048 + 128;
+  return (size_t)(tw + g_train_waves(Dp) * (GR * (Dp + 4) + 2 * GR * GLDH + GR * FLDO + 64) + 96) * sizeof(float);
+}
 inline size_t fused64_lds_bytes(int Dp) {
   return (size_t)(g_waves(Dp) * (GR * (Dp + 4) + 2 * GR * GLDH + GR * FLDO + 64) + 96) * sizeof(float);
 }
@@ -46,6 +70,37 @@ __host__ __device__ inline int s64_b1() { return s64_b2() + 64; }
 __host__ __device__ inline int s64_b3() { return s64_b1() + 64; }
 __host__ __device__ inline int s64_ls() { return s64_b3() + 32; }
 __host__ __device__ inline int s64_size() { return s64_ls() + 32; }
+
+// 32-row GEMM with BOTH operands in LDS (weights resident): c{0,1} += A[32 x 8*nkg] . Bpacked{0,1}
+template <int LDA>
+__device__ __forceinline__ void gemm_lds_lds_r32(int a_off, int b_off0, int b_off1, int nkg, f32x16& c0, f32x16& c1,
+                                                 int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int ab = 4 * opaque((a_off + r * LDA + 4 * h) >> 2);
+  const int b0 = 4 * opaque((b_off0 >> 2) + lane), b1 = 4 * opaque((b_off1 >> 2) + lane);
+  f32x4 uA = *reinterpret_cast<const f32x4*>(&lds[ab]);
+  f32x4 pA = *reinterpret_cast<const f32x4*>(&lds[b0]), qA = *reinterpret_cast<const f32x4*>(&lds[b1]);
+  f32x4 uB, pB, qB;
+  int ao = ab, bo = 0;
+#pragma unroll 1
+  for (int kg = 0; kg < nkg - 2; kg += 2) {
+    uB = *reinterpret_cast<const f32x4*>(&lds[ao + 8]);
+    pB = *reinterpret_cast<const f32x4*>(&lds[b0 + bo + 256]);
+    qB = *reinterpret_cast<const f32x4*>(&lds[b1 + bo + 256]);
+    MFMA_KG1(uA, pA, qA)
+    uA = *reinterpret_cast<const f32x4*>(&lds[ao + 16]);
+    pA = *reinterpret_cast<const f32x4*>(&lds[b0 + bo + 512]);
+    qA = *reinterpret_cast<const f32x4*>(&lds[b1 + bo + 512]);
+    MFMA_KG1(uB, pB, qB)
+    ao += 16;
+    bo += 512;
+  }
+  uB = *reinterpret_cast<const f32x4*>(&lds[ao + 8]);
+  pB = *reinterpret_cast<const f32x4*>(&lds[b0 + bo + 256]);
+  qB = *reinterpret_cast<const f32x4*>(&lds[b1 + bo + 256]);
+  MFMA_KG1(uA, pA, qA)
+  MFMA_KG1(uB, pB, qB)
+}
 
 // forward layers of one 32-row tile held at LDS offset wb (per-wave region); leaves h1, h2 and the raw head tile
 template <int DP>
@@ -95,8 +150,58 @@ __device__ __forceinline__ void tile64_forward(const FusedNet& W, int wb, int la
   }
 }
 
+// the same forward with the network's packed weights resident in LDS at offset 0 (training kernel)
+template <int DP>
+__device__ __forceinline__ void tile64_forward_ldsw(int wb, int lane) {
+  using L = Lay64<DP>;
+  using Wt = Wts64<DP>;
+  const int r = lane & 31, h = lane >> 5;
+  {
+    f32x16 c0 = splat16(lds[Wt::B1S + r]), c1 = splat16(lds[Wt::B1S + 32 + r]);
+    constexpr int nkg = DP / 8;
+    gemm_lds_lds_r32<L::LDX>(wb + L::X, Wt::W1F, Wt::W1F + nkg * 256, nkg, c0, c1, lane);
+    const int o = opaque(wb + L::H1 + 4 * h * GLDH + r);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      lds[o + crc(i) * GLDH] = fast_tanh_scaled(c0[i]);
+      lds[o + crc(i) * GLDH + 32] = fast_tanh_scaled(c1[i]);
+    }
+  }
+  {
+    f32x16 c0 = splat16(lds[Wt::B2S + r]), c1 = splat16(lds[Wt::B2S + 32 + r]);
+    gemm_lds_lds_r32<GLDH>(wb + L::H1, Wt::W2F, Wt::W2F + 8 * 256, 8, c0, c1, lane);
+    const int o = opaque(wb + L::H2 + 4 * h * GLDH + r);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      lds[o + crc(i) * GLDH] = fast_tanh_scaled(c0[i]);
+      lds[o + crc(i) * GLDH + 32] = fast_tanh_scaled(c1[i]);
+    }
+  }
+  {
+    f32x16 acc = zero16(), acc2 = zero16();
+    const int ab = 4 * opaque((wb + L::H2 + r * GLDH + 4 * h) >> 2);
+    const int bb = 4 * opaque((Wt::W3F >> 2) + lane);
+#pragma unroll
+    for (int kg = 0; kg < 8; kg += 2) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(&lds[bb + kg * 256]);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(&lds[bb + (kg + 1) * 256]);
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8]);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8 + 8]);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        acc = MFMA32(a0[s_], b0[s_], acc);
+        acc2 = MFMA32(a1[s_], b1[s_], acc2);
+      }
+    }
+    const int o = opaque(wb + L::DO + 4 * h * FLDO + r);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lds[o + crc(i) * FLDO] = acc[i] + acc2[i];
+  }
+}
+
 struct Fused64TrainArgs {
   FusedNet net[2];
+  const float* wpack[2];  // per-network packed weight block (Wts64 layout), mirrored into LDS
   const float* obs;
   const float* actions; int A;
   const float* old_logp; const float* adv; const float* ret;
@@ -111,16 +216,21 @@ struct Fused64TrainArgs {
 
 // grid: even number of blocks; block b works for network b & 1; its NWV waves take tiles (b>>1)*NWV + wave, stride.
 template <int DP>
-__global__ __launch_bounds__(g_waves(DP) * 64, 2) void k_fused64_train(Fused64TrainArgs a) {
+__global__ __launch_bounds__(Lay64<DP>::TNWV * 64, 1) void k_fused64_train(Fused64TrainArgs a) {
   using L = Lay64<DP>;
-  constexpr int ldx = L::LDX, per = DP / 4, NWV = L::NWV;
+  using Wt = Wts64<DP>;
+  constexpr int ldx = L::LDX, per = DP / 4, NWV = L::TNWV;
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int net = blockIdx.x & 1;
   const int widx = (blockIdx.x >> 1) * NWV + wave, nw = (gridDim.x >> 1) * NWV;
-  const int wb = wave * L::WAVE;
+  const int wb = L::TW + wave * L::WAVE;
   const FusedNet W = a.net[net];
   const int ntiles = (a.count + GR - 1) / GR;
+  // mirror this network's packed weights (fragment order, scaled biases) into LDS: every GEMM operand of the
+  // tile loop then comes from LDS and no phase waits on L2
+  for (int i = tid0; i < Wt::TOTAL / 4; i += NWV * 64)
+    reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(a.wpack[net])[i];
 
   f32x16 gW2a = zero16(), gW2b = zero16(), gW2c = zero16(), gW2d = zero16();  // [ib][jb] = 00, 10, 01, 11
   f32x16 gW1a = zero16(), gW1b = zero16(), gW1c = zero16(), gW1d = zero16();
@@ -137,9 +247,9 @@ __global__ __launch_bounds__(g_waves(DP) * 64, 2) void k_fused64_train(Fused64Tr
       lc = logf(sd) + 0.91893853320467274178f;
     }
     if (k < W.head) bb = W.b3[k];
-    lds[L::CST + k] = iv;
-    lds[L::CST + 32 + k] = lc;
-    lds[L::CST + 64 + k] = bb;
+    lds[L::TCST + k] = iv;
+    lds[L::TCST + 32 + k] = lc;
+    lds[L::TCST + 64 + k] = bb;
   }
   lds[wb + L::GACC + (tid0 & 63)] = 0.f;
   __syncthreads();  // the only workgroup barrier: constants visible to the four waves
@@ -169,7 +279,7 @@ __global__ __launch_bounds__(g_waves(DP) * 64, 2) void k_fused64_train(Fused64Tr
         v = ldg16(a.obs, (unsigned)a.rows[row0 + rr] * (unsigned)(DP * 4) + (unsigned)(c * 16));
       *reinterpret_cast<f32x4*>(&lds[wb + L::X + rr * ldx + 4 * c]) = v;
     }
-    tile64_forward<DP>(W, wb, lane);
+    tile64_forward_ldsw<DP>(wb, lane);
 
     // ---- loss: two lanes per row (q = action parity); dL/d(head) -> head tile, zero padded ----
     {
@@ -177,7 +287,7 @@ __global__ __launch_bounds__(g_waves(DP) * 64, 2) void k_fused64_train(Fused64Tr
       const bool live = row0 + rr < a.count;
       const unsigned src = live ? (unsigned)a.rows[row0 + rr] : 0u;
       const int db = opaque(wb + L::DO + rr * FLDO + q);
-      const int cb = opaque(L::CST + q);
+      const int cb = opaque(L::TCST + q);
       const int gb = opaque(wb + L::GACC + q);
       const int A = a.A;
       if (net == 0) {
@@ -252,7 +362,7 @@ __global__ __launch_bounds__(g_waves(DP) * 64, 2) void k_fused64_train(Fused64Tr
     // ---- dh2 = dout . W3 (K = 32) ; dz2 = dh2 * (1 - h2^2) in place ----
     {
       f32x16 c0 = zero16(), c1 = zero16();
-      gemm_lds_packed_r32<FLDO>(wb + L::DO, W.W3b, W.W3b + 4 * 64, 4, c0, c1, lane);
+      gemm_lds_lds_r32<FLDO>(wb + L::DO, Wt::W3B, Wt::W3B + 4 * 256, 4, c0, c1, lane);
       const int o = opaque(wb + L::H2 + 4 * h * GLDH + r);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -285,7 +395,7 @@ __global__ __launch_bounds__(g_waves(DP) * 64, 2) void k_fused64_train(Fused64Tr
     {
       f32x16 c0 = zero16(), c1 = zero16();
       constexpr int nkg = GH / 8;
-      gemm_lds_packed_r32<GLDH>(wb + L::H2, W.W2b, W.W2b + (size_t)nkg * 64, nkg, c0, c1, lane);
+      gemm_lds_lds_r32<GLDH>(wb + L::H2, Wt::W2B, Wt::W2B + nkg * 256, nkg, c0, c1, lane);
       const int o = opaque(wb + L::H1 + 4 * h * GLDH + r);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -392,8 +502,8 @@ __global__ __launch_bounds__(g_waves(DP) * 64, 2) void k_fused64_train(Fused64Tr
     float b3s = 0.f, lss = 0.f;
 #pragma unroll
     for (int w = 0; w < NWV; ++w) {
-      b3s += lds[w * L::WAVE + L::GACC + lane];
-      lss += lds[w * L::WAVE + L::GACC + 32 + lane];
+      b3s += lds[L::TW + w * L::WAVE + L::GACC + lane];
+      lss += lds[L::TW + w * L::WAVE + L::GACC + 32 + lane];
     }
     slab[s64_b3() + lane] = b3s;
     slab[s64_ls() + lane] = lss;
