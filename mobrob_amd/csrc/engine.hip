@@ -106,6 +106,15 @@ struct mobrob_ppo_engine {
   float *h1p = nullptr, *h2p = nullptr, *h1v = nullptr, *h2v = nullptr, *mu = nullptr, *vout = nullptr;
   float *dmu = nullptr, *dv = nullptr, *dz2p = nullptr, *dz1p = nullptr, *dz2v = nullptr, *dz1v = nullptr;
   float *pred_obs = nullptr, *pred_act = nullptr;
+  // rollout streamer (host-env path): pinned staging + a side stream for the H2D/D2H copies
+  hipStream_t cstream = nullptr;
+  hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_store = nullptr;
+  struct Stage {
+    float *obs = nullptr, *eps = nullptr, *rew = nullptr, *term = nullptr;
+    uint8_t *dones = nullptr, *trunc = nullptr;
+  } stage[2];
+  float *o_raw = nullptr, *o_clip = nullptr, *o_val = nullptr, *o_lp = nullptr;  // pinned output staging
+  int stage_i = 0;
   // profiling
   bool prof_on = false;
   std::vector<ProfSpan> spans;
@@ -388,6 +397,49 @@ void fused_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, float 
   hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(f.slab_floats, 256), 2), dim3(256), 0, e->stream, s);
 }
 
+// ---- rollout streamer --------------------------------------------------------------------------------
+bool is_pinned(const void* p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();  // pageable memory: clear the sticky error
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+int streamer_init(mobrob_ppo_engine* e) {
+  if (e->cstream) return MOBROB_OK;
+  const size_t N = e->N, D = e->D, A = e->A;
+  HIPC(hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking));
+  HIPC(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+  HIPC(hipEventCreateWithFlags(&e->ev_k, hipEventDisableTiming));
+  HIPC(hipEventCreateWithFlags(&e->ev_store, hipEventDisableTiming));
+  for (auto& st : e->stage) {
+    HIPC(hipHostMalloc((void**)&st.obs, N * D * 4, hipHostMallocDefault));
+    HIPC(hipHostMalloc((void**)&st.eps, N * A * 4, hipHostMallocDefault));
+    HIPC(hipHostMalloc((void**)&st.rew, N * 4, hipHostMallocDefault));
+    HIPC(hipHostMalloc((void**)&st.term, N * D * 4, hipHostMallocDefault));
+    HIPC(hipHostMalloc((void**)&st.dones, N, hipHostMallocDefault));
+    HIPC(hipHostMalloc((void**)&st.trunc, N, hipHostMallocDefault));
+  }
+  HIPC(hipHostMalloc((void**)&e->o_raw, N * A * 4, hipHostMallocDefault));
+  HIPC(hipHostMalloc((void**)&e->o_clip, N * A * 4, hipHostMallocDefault));
+  HIPC(hipHostMalloc((void**)&e->o_val, N * 4, hipHostMallocDefault));
+  HIPC(hipHostMalloc((void**)&e->o_lp, N * 4, hipHostMallocDefault));
+  return MOBROB_OK;
+}
+// source pointer for an async H2D: the caller's buffer if it is pinned (zero copy), else a pinned staging copy
+template <typename Tp>
+const Tp* stage_in(const Tp* user, Tp* staging, size_t count) {
+  if (is_pinned(user)) return user;
+  memcpy(staging, user, count * sizeof(Tp));
+  return staging;
+}
+int upload_obs_on(mobrob_ppo_engine* e, hipStream_t st, const float* host, float* dev_rows, int rows) {
+  HIPC(hipMemcpy2DAsync(dev_rows, (size_t)e->Dp * 4, host, (size_t)e->D * 4, (size_t)e->D * 4, rows,
+                        hipMemcpyHostToDevice, st));
+  return MOBROB_OK;
+}
+
 int check_cfg(const mobrob_ppo_config_t* c) {
   if (c->abi_version != MOBROB_PPO_ABI_VERSION) return fail(MOBROB_ERR_INVALID, "abi_version %d != %d", c->abi_version, MOBROB_PPO_ABI_VERSION);
   if (c->obs_dim < 1 || c->act_dim < 1) return fail(MOBROB_ERR_INVALID, "obs_dim/act_dim must be >= 1");
@@ -510,6 +562,16 @@ void mobrob_ppo_destroy(mobrob_ppo_engine_t* e) {
   if (!e) return;
   (void)hipStreamSynchronize(e->stream);
   prof_resolve(e);
+  if (e->cstream) {
+    (void)hipStreamSynchronize(e->cstream);
+    for (auto& st : e->stage) {
+      (void)hipHostFree(st.obs); (void)hipHostFree(st.eps); (void)hipHostFree(st.rew); (void)hipHostFree(st.term);
+      (void)hipHostFree(st.dones); (void)hipHostFree(st.trunc);
+    }
+    (void)hipHostFree(e->o_raw); (void)hipHostFree(e->o_clip); (void)hipHostFree(e->o_val); (void)hipHostFree(e->o_lp);
+    (void)hipEventDestroy(e->ev_in); (void)hipEventDestroy(e->ev_k); (void)hipEventDestroy(e->ev_store);
+    (void)hipStreamDestroy(e->cstream);
+  }
   if (e->ro_exec) (void)hipGraphExecDestroy(e->ro_exec);
   if (e->ro_graph) (void)hipGraphDestroy(e->ro_graph);
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
@@ -584,15 +646,37 @@ int mobrob_ppo_act(mobrob_ppo_engine_t* e, const float* obs, const float* eps, f
                    float* values, float* logp) {
   if (!e || !obs) return fail(MOBROB_ERR_INVALID, "act: null argument");
   if (e->t >= e->T) return fail(MOBROB_ERR_STATE, "act: rollout buffer full (t=%d, n_steps=%d)", e->t, e->T);
-  const size_t N = e->N, A = e->A;
-  CHK(upload_obs(e, obs, e->obs + (size_t)e->t * N * e->Dp, e->N));
-  if (eps) HIPC(hipMemcpyAsync(e->eps_dev, eps, N * A * 4, hipMemcpyHostToDevice, e->stream));
+  CHK(streamer_init(e));
+  const size_t N = e->N, A = e->A, D = e->D;
+  auto& st = e->stage[e->stage_i];
+  // H2D on the side stream (pinned source -> truly asynchronous), compute stream waits on the event
+  const float* src = stage_in(obs, st.obs, N * D);
+  CHK(upload_obs_on(e, e->cstream, src, e->obs + (size_t)e->t * N * e->Dp, e->N));
+  if (eps) {
+    const float* es = stage_in(eps, st.eps, N * A);
+    HIPC(hipMemcpyAsync(e->eps_dev, es, N * A * 4, hipMemcpyHostToDevice, e->cstream));
+  }
+  HIPC(hipEventRecord(e->ev_in, e->cstream));
+  HIPC(hipStreamWaitEvent(e->stream, e->ev_in, 0));
   act_slot(e, e->t, eps ? e->eps_dev : nullptr);
-  if (a_raw) HIPC(hipMemcpyAsync(a_raw, e->actions + (size_t)e->t * N * A, N * A * 4, hipMemcpyDeviceToHost, e->stream));
-  if (a_clip) HIPC(hipMemcpyAsync(a_clip, e->clip_act, N * A * 4, hipMemcpyDeviceToHost, e->stream));
-  if (values) HIPC(hipMemcpyAsync(values, e->values + (size_t)e->t * N, N * 4, hipMemcpyDeviceToHost, e->stream));
-  if (logp) HIPC(hipMemcpyAsync(logp, e->logp + (size_t)e->t * N, N * 4, hipMemcpyDeviceToHost, e->stream));
-  HIPC(hipStreamSynchronize(e->stream));
+  HIPC(hipEventRecord(e->ev_k, e->stream));
+  HIPC(hipStreamWaitEvent(e->cstream, e->ev_k, 0));
+  // D2H of the requested outputs: straight into pinned user buffers, else through pinned staging
+  struct Out { float* user; float* stagebuf; const float* dev; size_t n; };
+  const Out outs[4] = {{a_clip, e->o_clip, e->clip_act, N * A},
+                       {a_raw, e->o_raw, e->actions + (size_t)e->t * N * A, N * A},
+                       {values, e->o_val, e->values + (size_t)e->t * N, N},
+                       {logp, e->o_lp, e->logp + (size_t)e->t * N, N}};
+  bool staged[4] = {false, false, false, false};
+  for (int i = 0; i < 4; ++i) {
+    if (!outs[i].user) continue;
+    staged[i] = !is_pinned(outs[i].user);
+    HIPC(hipMemcpyAsync(staged[i] ? outs[i].stagebuf : outs[i].user, outs[i].dev, outs[i].n * 4, hipMemcpyDeviceToHost,
+                        e->cstream));
+  }
+  HIPC(hipStreamSynchronize(e->cstream));
+  for (int i = 0; i < 4; ++i)
+    if (outs[i].user && staged[i]) memcpy(outs[i].user, outs[i].stagebuf, outs[i].n * 4);
   return MOBROB_OK;
 }
 
@@ -600,22 +684,37 @@ int mobrob_ppo_store(mobrob_ppo_engine_t* e, const float* rewards, const uint8_t
                      const float* terminal_obs) {
   if (!e || !rewards || !dones) return fail(MOBROB_ERR_INVALID, "store: null argument");
   if (e->t >= e->T) return fail(MOBROB_ERR_STATE, "store: rollout buffer full");
-  const size_t N = e->N;
-  HIPC(hipMemcpyAsync(e->rew_tmp, rewards, N * 4, hipMemcpyHostToDevice, e->stream));
-  HIPC(hipMemcpyAsync(e->dones_u8, dones, N, hipMemcpyHostToDevice, e->stream));
+  CHK(streamer_init(e));
+  const size_t N = e->N, D = e->D;
+  auto& st = e->stage[e->stage_i];
+  // Fully asynchronous: the scalars are staged in pinned memory (the caller may reuse its buffers immediately),
+  // copied on the side stream and consumed by the compute stream behind an event; nothing here waits for the GPU.
+  // The staging slot is reused two steps later, after act() of the next step has synchronised the side stream.
+  memcpy(st.rew, rewards, N * 4);
+  memcpy(st.dones, dones, N);
+  HIPC(hipMemcpyAsync(e->rew_tmp, st.rew, N * 4, hipMemcpyHostToDevice, e->cstream));
+  HIPC(hipMemcpyAsync(e->dones_u8, st.dones, N, hipMemcpyHostToDevice, e->cstream));
   bool any_trunc = false;
   if (truncated && terminal_obs)
     for (size_t i = 0; i < N; ++i) any_trunc |= truncated[i] != 0;
   if (any_trunc) {
-    HIPC(hipMemcpyAsync(e->trunc_dev, truncated, N, hipMemcpyHostToDevice, e->stream));
-    CHK(upload_obs(e, terminal_obs, e->term_obs, e->N));
-    value_flagged(e, e->term_obs, e->trunc_dev, e->term_val);
+    memcpy(st.trunc, truncated, N);
+    memcpy(st.term, terminal_obs, N * D * 4);
+    HIPC(hipMemcpyAsync(e->trunc_dev, st.trunc, N, hipMemcpyHostToDevice, e->cstream));
+    CHK(upload_obs_on(e, e->cstream, st.term, e->term_obs, e->N));
   }
+  HIPC(hipEventRecord(e->ev_store, e->cstream));
+  HIPC(hipStreamWaitEvent(e->stream, e->ev_store, 0));
+  if (any_trunc) value_flagged(e, e->term_obs, e->trunc_dev, e->term_val);
   hipLaunchKernelGGL(k_store_step, dim3(cdiv(e->N, 256)), dim3(256), 0, e->stream, e->rew_tmp, e->prev_dones,
                      any_trunc ? e->trunc_dev : nullptr, e->term_val, (float)e->cfg.gamma, e->N,
                      e->rewards + (size_t)e->t * N, e->es + (size_t)e->t * N);
   hipLaunchKernelGGL(k_u8_to_f32, dim3(cdiv(e->N, 256)), dim3(256), 0, e->stream, e->dones_u8, e->prev_dones, e->N);
-  HIPC(hipStreamSynchronize(e->stream));  // host buffers may be reused by the caller
+  // the next step's H2D of rew_tmp/dones_u8 must not overtake these kernels
+  HIPC(hipEventRecord(e->ev_k, e->stream));
+  HIPC(hipStreamWaitEvent(e->cstream, e->ev_k, 0));
+  HIPC(hipGetLastError());
+  e->stage_i ^= 1;
   e->t++;
   return MOBROB_OK;
 }
@@ -623,10 +722,16 @@ int mobrob_ppo_store(mobrob_ppo_engine_t* e, const float* rewards, const uint8_t
 int mobrob_ppo_finish_rollout(mobrob_ppo_engine_t* e, const float* last_obs, const uint8_t* dones) {
   if (!e || !last_obs || !dones) return fail(MOBROB_ERR_INVALID, "finish_rollout: null argument");
   if (e->t != e->T) return fail(MOBROB_ERR_STATE, "finish_rollout: %d of %d steps stored", e->t, e->T);
+  CHK(streamer_init(e));
   const size_t N = e->N;
+  auto& st = e->stage[e->stage_i];
   float* slot = e->obs + (size_t)e->T * N * e->Dp;
-  CHK(upload_obs(e, last_obs, slot, e->N));
-  HIPC(hipMemcpyAsync(e->dones_u8, dones, N, hipMemcpyHostToDevice, e->stream));
+  const float* src = stage_in(last_obs, st.obs, N * e->D);
+  CHK(upload_obs_on(e, e->cstream, src, slot, e->N));
+  memcpy(st.dones, dones, N);
+  HIPC(hipMemcpyAsync(e->dones_u8, st.dones, N, hipMemcpyHostToDevice, e->cstream));
+  HIPC(hipEventRecord(e->ev_in, e->cstream));
+  HIPC(hipStreamWaitEvent(e->stream, e->ev_in, 0));
   hipLaunchKernelGGL(k_u8_to_f32, dim3(cdiv(e->N, 256)), dim3(256), 0, e->stream, e->dones_u8, e->last_dones, e->N);
   forward(e, slot, e->N, false, nullptr, true, e->last_values);
   run_gae(e);

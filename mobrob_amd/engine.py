@@ -84,6 +84,9 @@ class PPOEngine:
         if getattr(self, "_h", None) is not None and self._h.value:
             self.lib.mobrob_ppo_destroy(self._h)
             self._h = C.c_void_p()
+            for ptr in getattr(self, "_pinned", []):
+                self.lib.mobrob_ppo_host_free(C.c_void_p(ptr))
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -137,10 +140,17 @@ class PPOEngine:
     def rollout_begin(self):
         check(self.lib.mobrob_ppo_rollout_begin(self._h))
 
-    def act(self, obs, eps=None):
+    def act(self, obs, eps=None, out_clipped=None, want_all=True):
+        """-> (raw actions, clipped actions, values, log_probs).  With want_all=False only the clipped actions the
+        env needs are copied back (raw actions / values / log-probs stay in the device rollout buffer);
+        out_clipped may be a pinned array (engine.pinned) to skip the staging copy."""
         obs = _f32c(obs, (self.N, self.D))
         eps = None if eps is None else _f32c(eps, (self.N, self.A))
-        a_raw, a_clip = np.empty((self.N, self.A), F32), np.empty((self.N, self.A), F32)
+        a_clip = np.empty((self.N, self.A), F32) if out_clipped is None else out_clipped
+        if not want_all:
+            check(self.lib.mobrob_ppo_act(self._h, _fp(obs), _fp(eps), None, _fp(a_clip), None, None))
+            return None, a_clip, None, None
+        a_raw = np.empty((self.N, self.A), F32)
         val, lp = np.empty(self.N, F32), np.empty(self.N, F32)
         check(self.lib.mobrob_ppo_act(self._h, _fp(obs), _fp(eps), _fp(a_raw), _fp(a_clip), _fp(val), _fp(lp)))
         return a_raw, a_clip, val, lp
@@ -262,6 +272,19 @@ class PPOEngine:
         check(self.lib.mobrob_ppo_feistel_permutation(self._h, int(n), int(key) & (2 ** 64 - 1),
                                                       out.ctypes.data_as(C.POINTER(C.c_int64))))
         return out
+
+    def pinned(self, shape, dtype=np.float32):
+        """NumPy array backed by pinned host memory (mobrob_ppo_host_alloc): buffers handed to act()/store() from
+        such arrays are copied by DMA without the staging memcpy.  Freed when the engine is closed."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        ptr = self.lib.mobrob_ppo_host_alloc(max(n, 1))
+        if not ptr:
+            raise MemoryError("hipHostMalloc failed")
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(ptr)
+        buf = (C.c_char * max(n, 1)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def set_stream(self, stream_handle):
         check(self.lib.mobrob_ppo_set_stream(self._h, C.c_void_p(stream_handle)))

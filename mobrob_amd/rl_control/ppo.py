@@ -260,7 +260,7 @@ class PPO:
         e.rollout_begin()
         dones = np.zeros(N, bool)
         for _ in range(self.n_steps):
-            _, clipped, _, _ = e.act(self._last_obs)
+            _, clipped, _, _ = e.act(self._last_obs, want_all=False)
             new_obs, rewards, dones, infos = env.step(clipped)
             self.num_timesteps += N
             if not callback.on_step():
