@@ -184,7 +184,7 @@ def main():
                          "flops_per_launch": flops_per_launch},
             "phase_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out), flush=True)
     if use_dp:

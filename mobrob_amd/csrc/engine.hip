@@ -808,7 +808,17 @@ int mobrob_ppo_collect_synthetic(mobrob_ppo_engine_t* e, float p_term, int32_t t
       if (e->ro_graph) { (void)hipGraphDestroy(e->ro_graph); e->ro_graph = nullptr; }
       const bool prof = e->prof_on;
       e->prof_on = false;  // event records cannot be part of the captured graph
-      HIPC(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+      hipError_t be = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+      if (be != hipSuccess) {  // e.g. a stream that does not support capture: run eagerly from now on
+        (void)hipGetLastError();
+        e->prof_on = prof;
+        e->cfg.rollout_graph = 0;
+        CHK(enqueue_rollout(e, p_term, time_limit));
+        HIPC(hipGetLastError());
+        e->t = e->T;
+        e->rollout_ready = true;
+        return MOBROB_OK;
+      }
       const int rc = enqueue_rollout(e, p_term, time_limit);
       hipError_t ce = hipStreamEndCapture(e->stream, &e->ro_graph);
       e->prof_on = prof;
