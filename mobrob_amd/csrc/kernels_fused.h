@@ -698,14 +698,22 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     if (PHASE_ON(128)) {
       const int ao = opaque(L::H2 + h * FLDH + 64 * wave + r);
       const int bo = opaque(L::H1 + h * FLDH + r);
+      // operands of k-step k+2 are read from LDS before the 16 MFMAs of k-step k are issued (the MFMA statement is
+      // opaque to the scheduler, so the lookahead is written out by hand)
+      float x0 = lds[ao], x1 = lds[ao + 32];
+      float y0 = lds[bo], y1 = lds[bo + 32], y2 = lds[bo + 64], y3 = lds[bo + 96], y4 = lds[bo + 128],
+            y5 = lds[bo + 160], y6 = lds[bo + 192], y7 = lds[bo + 224];
 #pragma unroll 2
-      for (int k = 0; k < FR; k += 2) {
+      for (int k = 2; k < FR; k += 2) {
         const float* bk = &lds[bo + k * FLDH];
-        dw2_kstep(gW2, lds[ao + k * FLDH], lds[ao + k * FLDH + 32], bk[0], bk[32], bk[64], bk[96], bk[128], bk[160], bk[192],
-                  bk[224]);
+        const float nx0 = lds[ao + k * FLDH], nx1 = lds[ao + k * FLDH + 32];
+        const float n0 = bk[0], n1 = bk[32], n2 = bk[64], n3 = bk[96], n4 = bk[128], n5 = bk[160], n6 = bk[192],
+                    n7 = bk[224];
+        dw2_kstep(gW2, x0, x1, y0, y1, y2, y3, y4, y5, y6, y7);
+        x0 = nx0; x1 = nx1; y0 = n0; y1 = n1; y2 = n2; y3 = n3; y4 = n4; y5 = n5; y6 = n6; y7 = n7;
       }
+      dw2_kstep(gW2, x0, x1, y0, y1, y2, y3, y4, y5, y6, y7);
     }
-    STAMP(15)
     // ---- dh1 = dz2 . W2 (K = 256), then dz1 = dh1 * (1 - h1^2) in place ----
     {
       f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
