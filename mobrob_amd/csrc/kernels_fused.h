@@ -677,11 +677,12 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
       mfma_x1y2(gW3a, gW3b, x, y0, y1);
     }
     STAMP(10)
-    // ---- dh2 = dout . W3 (K = 32), then dz2 = dh2 * (1 - h2^2) in place ----
+    // ---- dh2 = dout . W3 (K = 16 or 32), then dz2 = dh2 * (1 - h2^2) in place ----
     {
       f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
       if (PHASE_ON(64))
-        gemm_lds_packed<FLDO>(L::DO, W.W3b + (size_t)(2 * wave) * 4 * 64, W.W3b + (size_t)(2 * wave + 1) * 4 * 64, 4,
+        gemm_lds_packed<FLDO>(L::DO, W.W3b + (size_t)(2 * wave) * 4 * 64, W.W3b + (size_t)(2 * wave + 1) * 4 * 64,
+                              W.head <= 16 ? 2 : 4,  // k-groups of 8: head columns beyond `head` are zero padding
                               c00, c01, c10, c11, lane, fh2);
       STAMP(11)
       __syncthreads();  // every wave is done reading h2 (dW3) before it is overwritten
