@@ -30,6 +30,9 @@ WORKLOADS = {
     "doggo-4096env-2x256": dict(D=58, A=12, H=256, N=4096, T=1000, E=5, B=65536, p_term=1 / 107.0, tl=1000),
     "point-1024env-2x64": dict(D=14, A=2, H=64, N=1024, T=2048, E=10, B=65536, p_term=1 / 119.0, tl=1000),
     "doggo-ref-16env-2x64": dict(D=58, A=12, H=64, N=16, T=1000, E=5, B=100, p_term=1 / 107.0, tl=1000),
+    # BASELINE configs[4]: mixed fleet, ragged obs/act dims packed into one rollout arena (mobrob_amd/fleet.py)
+    "fleet-car-drone-turtlebot3-2x64": dict(segments=["car", "drone", "turtlebot3"], H=64, N=1024, T=2048, E=10,
+                                            B=65536, tl=1000),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
@@ -76,6 +79,82 @@ def cpu_baseline(w, budget_s=20.0):
                       f"= {done_steps} env-steps of the NumPy oracle in {el:.1f} s"}
 
 
+def bench_fleet(args, w, rank, local_rank, world, use_dp, force_dp):
+    """Mixed-fleet workload: every rank holds all segments (N envs each); segments overlap on per-segment streams."""
+    import torch
+    import torch.distributed as dist
+    from mobrob_amd.fleet import ROBOT_DIMS, MixedFleet, train_fleet_data_parallel
+    from mobrob_amd.parallel import EngineBackend
+    H, N, T, E, B = w["H"], w["N"], w["T"], w["E"], w["B"]
+    fleet = MixedFleet(w["segments"], n_envs=N, n_steps=T, batch_size=B * world, n_epochs=E, pi=(H, H), vf=(H, H),
+                       ent_coef=0.01, seed=0, device_id=local_rank, rank=rank, world_size=world,
+                       fast_kernels=not args.generic)
+    for s in fleet.segments:
+        s.engine.set_params(init_params(s.obs_dim, s.act_dim, H, seed=0))
+    streams, backends = [], []
+    if use_dp:
+        for s in fleet.segments:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                backends.append(EngineBackend(s.engine))
+            streams.append(st)
+
+    def iteration():
+        fleet.collect_synthetic(time_limit=w["tl"])
+        if use_dp:
+            train_fleet_data_parallel(backends, streams, force_collectives=force_dp)
+        else:
+            fleet.train_enqueue()
+
+    def fence():
+        fleet.synchronize()
+        torch.cuda.synchronize()
+        if use_dp:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        iteration()
+    fence()
+    for s in fleet.segments:
+        s.engine.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        iteration()
+    fence()
+    dt = time.perf_counter() - t0
+    profs = [s.engine.profile_read() for s in fleet.segments]
+    if use_dp:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        env_steps = fleet.env_steps_per_iteration * world * args.steps
+        ms = sum(p["train_grad"][0] for p in profs)
+        calls = sum(p["train_grad"][1] for p in profs)
+        flops = sum(3.0 * f_fwd(s.obs_dim, H, s.act_dim) * float(N) * T * E * args.steps for s in fleet.segments)
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out = {
+            "metric": "env-steps/sec (whole node)", "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload,
+                       "segments": [{"robot": s.name, "obs_dim": s.obs_dim, "act_dim": s.act_dim, "envs_per_gpu": s.n_envs,
+                                     "arena_offset": s.offset, "arena_bytes": s.nbytes} for s in fleet.segments],
+                       "net_arch": [H, H], "n_steps": T, "n_epochs": E, "minibatch_per_gpu": B,
+                       "env_source": "device-resident synthetic (Philox)", "parallelism": f"dp{world}",
+                       "kernels": "generic" if args.generic else "fused"},
+            "roofline": {"bound": "mfma", "kernel": "k_fused64_train, all segments (their launches overlap on per-segment "
+                                                    "streams, so per-launch durations include time sharing)",
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_ms": ms / max(calls, 1), "launches": calls, "flops_per_launch": flops / max(calls, 1)},
+            "phase_ms_per_step": {k: sum(p[k][0] for p in profs) / args.steps for k in profs[0]},
+        }
+        print(json.dumps(out), flush=True)
+    fleet.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +195,12 @@ def main():
     from mobrob_amd.engine import PPOEngine
     from mobrob_amd.parallel import EngineBackend, train_data_parallel
 
+    if "segments" in w:
+        bench_fleet(args, w, rank, local_rank, world, use_dp, force_dp)
+        if use_dp:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     D, A, H, N, T, E, B = w["D"], w["A"], w["H"], w["N"], w["T"], w["E"], w["B"]
     eng = PPOEngine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B * world, n_epochs=E, pi=(H, H), vf=(H, H),
                     gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.01, seed=0, device_id=local_rank,

@@ -86,6 +86,18 @@ void mobrob_ppo_default_config(mobrob_ppo_config_t* cfg);
  * parameters are initialised to zero -- the caller uploads weights (set_params). */
 int mobrob_ppo_create(const mobrob_ppo_config_t* cfg, mobrob_ppo_engine_t** out);
 void mobrob_ppo_destroy(mobrob_ppo_engine_t* e);
+
+/* Mixed fleet (several robot types = several PPO(...) objects with different obs/act dims trained side by
+ * side, the loop of examples/train.py:42-46 run once per env name): every device buffer of an engine is
+ * carved out of ONE arena, so the ragged segments of a fleet pack back to back into one rollout allocation,
+ * each with its own (obs_dim, act_dim) strides.  device_bytes is a host-only sizing pass (no device needed);
+ * create_in_arena builds the engine inside caller-owned device memory (256-byte aligned, >= device_bytes),
+ * which must outlive the engine.  mobrob_ppo_create == device_bytes + one private arena. */
+int mobrob_ppo_device_bytes(const mobrob_ppo_config_t* cfg, size_t* bytes);
+int mobrob_ppo_create_in_arena(const mobrob_ppo_config_t* cfg, void* arena, size_t arena_bytes,
+                               mobrob_ppo_engine_t** out);
+void* mobrob_ppo_device_alloc(int32_t device_id, size_t bytes);
+void mobrob_ppo_device_free(void* p);
 const char* mobrob_ppo_last_error(void);
 int mobrob_ppo_abi_version(void);
 
@@ -149,6 +161,10 @@ typedef struct mobrob_ppo_train_stats {
  * env-major permutations of range(T*N) (what np.random.permutation would have produced), or NULL ->
  * counter-based Feistel permutations keyed by (seed, rank, update counter).  world_size must be 1. */
 int mobrob_ppo_train(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_ppo_train_stats_t* stats);
+/* Same update, enqueued on the engine's stream without waiting for it (mobrob_ppo_train == train_enqueue +
+ * statistics read-back).  Lets the engines of a mixed fleet overlap their updates on one GPU; `perms`, when
+ * given, must stay valid until mobrob_ppo_synchronize. */
+int mobrob_ppo_train_enqueue(mobrob_ppo_engine_t* e, const int64_t* perms);
 
 /* The same update split at the two points where data-parallel ranks exchange data:
  *   epoch_begin   -> local (sum adv, sum adv^2, count) per minibatch into advstat_dev

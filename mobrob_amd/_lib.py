@@ -45,6 +45,10 @@ SYMBOLS = {
     "mobrob_ppo_default_config": (None, [C.POINTER(Config)]),
     "mobrob_ppo_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "mobrob_ppo_destroy": (None, [_P]),
+    "mobrob_ppo_device_bytes": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_size_t)]),
+    "mobrob_ppo_create_in_arena": (C.c_int, [C.POINTER(Config), _P, C.c_size_t, C.POINTER(_P)]),
+    "mobrob_ppo_device_alloc": (_P, [C.c_int32, C.c_size_t]),
+    "mobrob_ppo_device_free": (None, [_P]),
     "mobrob_ppo_last_error": (C.c_char_p, []),
     "mobrob_ppo_abi_version": (C.c_int, []),
     "mobrob_ppo_set_stream": (C.c_int, [_P, _P]),
@@ -62,6 +66,7 @@ SYMBOLS = {
     "mobrob_ppo_finish_rollout": (C.c_int, [_P, _F, _U8]),
     "mobrob_ppo_collect_synthetic": (C.c_int, [_P, C.c_float, C.c_int32]),
     "mobrob_ppo_train": (C.c_int, [_P, _I64, C.POINTER(TrainStats)]),
+    "mobrob_ppo_train_enqueue": (C.c_int, [_P, _I64]),
     "mobrob_ppo_epoch_begin": (C.c_int, [_P, _I64]),
     "mobrob_ppo_num_minibatches": (C.c_int, [_P]),
     "mobrob_ppo_minibatch_grad": (C.c_int, [_P, C.c_int32]),

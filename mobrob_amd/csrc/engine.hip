@@ -122,18 +122,32 @@ struct mobrob_ppo_engine {
   double prof_ms[MOBROB_K_COUNT] = {0};
   int64_t prof_calls[MOBROB_K_COUNT] = {0};
   std::vector<void*> allocs;
+  // device arena: every device buffer of the engine is carved out of ONE allocation (owned, or handed in by the
+  // caller so that several engines -- the robot types of a mixed fleet -- pack into one rollout buffer)
+  char* arena = nullptr;
+  size_t arena_bytes = 0, arena_used = 0;
+  bool plan_only = false;  // sizing pass: count bytes, touch no device
+  std::vector<NormChunk> chunk_table;
   FusedState fused;
 };
 
 namespace {
 
+constexpr size_t kArenaAlign = 256;
+
 template <typename Tp>
 int dalloc(mobrob_ppo_engine* e, Tp** p, size_t count) {
-  void* q = nullptr;
-  const size_t bytes = std::max<size_t>(count, 1) * sizeof(Tp);
-  HIPC(hipMalloc(&q, bytes));
+  const size_t bytes = (std::max<size_t>(count, 1) * sizeof(Tp) + kArenaAlign - 1) / kArenaAlign * kArenaAlign;
+  if (e->plan_only) {
+    e->arena_used += bytes;
+    *p = nullptr;
+    return MOBROB_OK;
+  }
+  if (e->arena_used + bytes > e->arena_bytes)
+    return fail(MOBROB_ERR_INVALID, "device arena too small: need more than %zu bytes", e->arena_bytes);
+  void* q = e->arena + e->arena_used;
+  e->arena_used += bytes;
   HIPC(hipMemsetAsync(q, 0, bytes, e->stream));
-  e->allocs.push_back(q);
   *p = static_cast<Tp*>(q);
   return MOBROB_OK;
 }
@@ -339,7 +353,7 @@ int fused_init(mobrob_ppo_engine* e) {
     f.lds_act_bytes = fused_lds_act_bytes(e->Dp);
   }
   CHK(dalloc(e, &f.stamps, 32));
-  HIPC(fused_set_lds_attr(f));
+  if (!e->plan_only) HIPC(fused_set_lds_attr(f));
   return MOBROB_OK;
 }
 
@@ -482,20 +496,12 @@ void* mobrob_ppo_host_alloc(size_t bytes) {
 }
 void mobrob_ppo_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
-int mobrob_ppo_create(const mobrob_ppo_config_t* cfg, mobrob_ppo_engine_t** out) {
-  if (!cfg || !out) return fail(MOBROB_ERR_INVALID, "null argument");
-  CHK(check_cfg(cfg));
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-    return fail(MOBROB_ERR_NO_DEVICE, "no HIP device visible: libmobrob_ppo has no CPU fallback");
-  if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(MOBROB_ERR_INVALID, "device_id %d out of range (%d devices)", cfg->device_id, ndev);
-  HIPC(hipSetDevice(cfg->device_id));
-  hipDeviceProp_t prop;
-  HIPC(hipGetDeviceProperties(&prop, cfg->device_id));
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(MOBROB_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", cfg->device_id, prop.gcnArchName);
+}  // extern "C"
 
-  auto* e = new mobrob_ppo_engine();
+namespace {
+
+// host-only: dimensions, parameter offsets, the norm chunk table
+int engine_dims(mobrob_ppo_engine* e, const mobrob_ppo_config_t* cfg) {
   e->cfg = *cfg;
   e->D = cfg->obs_dim; e->Dp = rup(cfg->obs_dim, 8); e->A = cfg->act_dim; e->Ap = rup(cfg->act_dim, 8);
   e->H1 = cfg->pi_hidden[0]; e->H2 = cfg->pi_hidden[1]; e->G1 = cfg->vf_hidden[0]; e->G2 = cfg->vf_hidden[1];
@@ -509,11 +515,20 @@ int mobrob_ppo_create(const mobrob_ppo_config_t* cfg, mobrob_ppo_engine_t** out)
   e->offs[0] = 0;
   for (int i = 0; i < T_COUNT; ++i) e->offs[i + 1] = e->offs[i] + sizes[i];
   e->P = e->offs[T_COUNT];
-  HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-  e->own_stream = true;
-  *out = e;  // so that destroy() can clean up after a partial failure
+  e->stats_cap = std::max(64, 4 * e->nmb * cfg->n_epochs);
+  // chunk table for the gradient-norm reduction: <= 4096 elements per block, chunks sorted by tensor
+  e->chunk_table.clear();
+  for (int tt = 0; tt < T_COUNT; ++tt)
+    for (int s0 = e->offs[tt]; s0 < e->offs[tt + 1]; s0 += 4096)
+      e->chunk_table.push_back(NormChunk{tt, s0, std::min(s0 + 4096, e->offs[tt + 1]), 0});
+  e->nchunks = (int)e->chunk_table.size();
+  if (e->nchunks > 256) return fail(MOBROB_ERR_INVALID, "parameter vector too large for the norm chunk table (%d chunks)", e->nchunks);
+  return MOBROB_OK;
+}
 
-  const size_t P = e->P, N = e->N, T = e->T, Dp = e->Dp, A = e->A, Bl = std::min(e->Bl, total), R = e->rows_max;
+// carve every device buffer out of the arena (or, with plan_only, just add up the bytes)
+int engine_alloc(mobrob_ppo_engine* e) {
+  const size_t P = e->P, N = e->N, T = e->T, Dp = e->Dp, A = e->A, Bl = std::min(e->Bl, e->N * e->T), R = e->rows_max;
   CHK(dalloc(e, &e->params, P)); CHK(dalloc(e, &e->grads, P + 8)); CHK(dalloc(e, &e->m, P)); CHK(dalloc(e, &e->v, P));
   CHK(dalloc(e, &e->offs_dev, T_COUNT + 1)); CHK(dalloc(e, &e->tensor_sq, T_COUNT));
   CHK(dalloc(e, &e->pW1p, (size_t)e->H1 * Dp)); CHK(dalloc(e, &e->vW1p, (size_t)e->G1 * Dp));
@@ -526,7 +541,6 @@ int mobrob_ppo_create(const mobrob_ppo_config_t* cfg, mobrob_ppo_engine_t** out)
   CHK(dalloc(e, &e->term_obs, N * Dp)); CHK(dalloc(e, &e->term_val, N)); CHK(dalloc(e, &e->eps_dev, R * A));
   CHK(dalloc(e, &e->trunc_dev, N)); CHK(dalloc(e, &e->dones_u8, N)); CHK(dalloc(e, &e->ep_len, N)); CHK(dalloc(e, &e->ep_len2, N)); CHK(dalloc(e, &e->ctr_dev, 2));
   CHK(dalloc(e, &e->rows, T * N)); CHK(dalloc(e, &e->perm_dev, T * N)); CHK(dalloc(e, &e->advstat, (size_t)e->nmb * 4));
-  e->stats_cap = std::max(64, 4 * e->nmb * cfg->n_epochs);
   CHK(dalloc(e, &e->stats, (size_t)e->stats_cap * 8));
   CHK(dalloc(e, &e->Xg, Bl * Dp)); CHK(dalloc(e, &e->actg, Bl * A)); CHK(dalloc(e, &e->lpg, Bl));
   CHK(dalloc(e, &e->advg, Bl)); CHK(dalloc(e, &e->retg, Bl));
@@ -536,26 +550,91 @@ int mobrob_ppo_create(const mobrob_ppo_config_t* cfg, mobrob_ppo_engine_t** out)
   CHK(dalloc(e, &e->dz2p, Bl * e->H2)); CHK(dalloc(e, &e->dz1p, Bl * e->H1));
   CHK(dalloc(e, &e->dz2v, Bl * e->G2)); CHK(dalloc(e, &e->dz1v, Bl * e->G1));
   CHK(dalloc(e, &e->pred_obs, R * Dp)); CHK(dalloc(e, &e->pred_act, R * A));
-  HIPC(hipMemcpyAsync(e->offs_dev, e->offs, sizeof e->offs, hipMemcpyHostToDevice, e->stream));
+  CHK(dalloc(e, &e->chunks_dev, e->chunk_table.size()));
+  CHK(dalloc(e, &e->chunk_partial, e->chunk_table.size()));
   CHK(fused_init(e));
-  {  // chunk table for the gradient-norm reduction: <= 4096 elements per block, chunks sorted by tensor
-    std::vector<NormChunk> ch;
-    for (int tt = 0; tt < T_COUNT; ++tt)
-      for (int s0 = e->offs[tt]; s0 < e->offs[tt + 1]; s0 += 4096) ch.push_back(NormChunk{tt, s0, std::min(s0 + 4096, e->offs[tt + 1]), 0});
-    e->nchunks = (int)ch.size();
-    if (e->nchunks > 256) return fail(MOBROB_ERR_INVALID, "parameter vector too large for the norm chunk table (%d chunks)", e->nchunks);
-    CHK(dalloc(e, &e->chunks_dev, ch.size()));
-    CHK(dalloc(e, &e->chunk_partial, ch.size()));
-    HIPC(hipMemcpyAsync(e->chunks_dev, ch.data(), ch.size() * sizeof(NormChunk), hipMemcpyHostToDevice, e->stream));
-    HIPC(hipStreamSynchronize(e->stream));
+  return MOBROB_OK;
+}
+
+int check_device(const mobrob_ppo_config_t* cfg) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(MOBROB_ERR_NO_DEVICE, "no HIP device visible: libmobrob_ppo has no CPU fallback");
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(MOBROB_ERR_INVALID, "device_id %d out of range (%d devices)", cfg->device_id, ndev);
+  HIPC(hipSetDevice(cfg->device_id));
+  hipDeviceProp_t prop;
+  HIPC(hipGetDeviceProperties(&prop, cfg->device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(MOBROB_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", cfg->device_id, prop.gcnArchName);
+  return MOBROB_OK;
+}
+
+int engine_create(const mobrob_ppo_config_t* cfg, void* arena, size_t arena_bytes, mobrob_ppo_engine_t** out) {
+  CHK(check_cfg(cfg));
+  CHK(check_device(cfg));
+  auto* e = new mobrob_ppo_engine();
+  *out = e;  // so that destroy() can clean up after a partial failure
+  CHK(engine_dims(e, cfg));
+  HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  e->own_stream = true;
+  if (arena) {
+    if (reinterpret_cast<uintptr_t>(arena) % kArenaAlign) return fail(MOBROB_ERR_INVALID, "arena must be %zu-byte aligned", kArenaAlign);
+    e->arena = static_cast<char*>(arena);
+    e->arena_bytes = arena_bytes;
+  } else {  // one allocation per engine, sized by the same planning pass callers of create_in_arena use
+    size_t need = 0;
+    CHK(mobrob_ppo_device_bytes(cfg, &need));
+    void* q = nullptr;
+    HIPC(hipMalloc(&q, need));
+    e->allocs.push_back(q);
+    e->arena = static_cast<char*>(q);
+    e->arena_bytes = need;
   }
+  CHK(engine_alloc(e));
+  HIPC(hipMemcpyAsync(e->offs_dev, e->offs, sizeof e->offs, hipMemcpyHostToDevice, e->stream));
+  HIPC(hipMemcpyAsync(e->chunks_dev, e->chunk_table.data(), e->chunk_table.size() * sizeof(NormChunk), hipMemcpyHostToDevice, e->stream));
   // `_last_episode_starts` is all-True at _setup_learn (Appendix A.5)
-  std::vector<float> ones(N, 1.0f);
-  HIPC(hipMemcpyAsync(e->prev_dones, ones.data(), N * 4, hipMemcpyHostToDevice, e->stream));
+  std::vector<float> ones(e->N, 1.0f);
+  HIPC(hipMemcpyAsync(e->prev_dones, ones.data(), (size_t)e->N * 4, hipMemcpyHostToDevice, e->stream));
   HIPC(hipStreamSynchronize(e->stream));
   repack(e);
   HIPC(hipStreamSynchronize(e->stream));
   return MOBROB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mobrob_ppo_device_bytes(const mobrob_ppo_config_t* cfg, size_t* bytes) {
+  if (!cfg || !bytes) return fail(MOBROB_ERR_INVALID, "null argument");
+  CHK(check_cfg(cfg));
+  mobrob_ppo_engine plan;  // host-only sizing pass: no device is touched
+  plan.plan_only = true;
+  CHK(engine_dims(&plan, cfg));
+  CHK(engine_alloc(&plan));
+  *bytes = plan.arena_used;
+  return MOBROB_OK;
+}
+
+void* mobrob_ppo_device_alloc(int32_t device_id, size_t bytes) {
+  void* p = nullptr;
+  if (hipSetDevice(device_id) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) {
+    fail(MOBROB_ERR_HIP, "device_alloc(%zu bytes) failed", bytes);
+    return nullptr;
+  }
+  return p;
+}
+void mobrob_ppo_device_free(void* p) { if (p) (void)hipFree(p); }
+
+int mobrob_ppo_create(const mobrob_ppo_config_t* cfg, mobrob_ppo_engine_t** out) {
+  if (!cfg || !out) return fail(MOBROB_ERR_INVALID, "null argument");
+  return engine_create(cfg, nullptr, 0, out);
+}
+
+int mobrob_ppo_create_in_arena(const mobrob_ppo_config_t* cfg, void* arena, size_t arena_bytes, mobrob_ppo_engine_t** out) {
+  if (!cfg || !out || !arena) return fail(MOBROB_ERR_INVALID, "null argument");
+  return engine_create(cfg, arena, arena_bytes, out);
 }
 
 void mobrob_ppo_destroy(mobrob_ppo_engine_t* e) {
@@ -967,7 +1046,7 @@ int mobrob_ppo_fetch_step_stats(mobrob_ppo_engine_t* e, float* out, int32_t max_
   return n;
 }
 
-int mobrob_ppo_train(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_ppo_train_stats_t* st) {
+int mobrob_ppo_train_enqueue(mobrob_ppo_engine_t* e, const int64_t* perms) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   if (e->cfg.world_size != 1)
     return fail(MOBROB_ERR_STATE, "mobrob_ppo_train is the single-rank loop; data-parallel ranks drive epoch_begin/"
@@ -983,6 +1062,11 @@ int mobrob_ppo_train(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_ppo_tr
     }
   }
   e->epoch_open = false;
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_train(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_ppo_train_stats_t* st) {
+  CHK(mobrob_ppo_train_enqueue(e, perms));
   if (st) {
     std::vector<float> rows((size_t)e->nmb * 8);
     const int n = mobrob_ppo_fetch_step_stats(e, rows.data(), e->nmb);

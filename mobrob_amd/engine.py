@@ -48,16 +48,17 @@ def param_shapes(obs_dim, act_dim, pi, vf):
 
 
 class PPOEngine:
-    def __init__(self, obs_dim, act_dim, n_envs, n_steps, batch_size=64, n_epochs=10, pi=(64, 64), vf=(64, 64),
-                 gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
-                 learning_rate=3e-4, adam_betas=(0.9, 0.999), adam_eps=1e-5, normalize_advantage=True,
-                 action_low=-1.0, action_high=1.0, seed=0, device_id=0, rank=0, world_size=1, fast_kernels=True,
-                 rollout_graph=True):
-        self.lib = _lib.load()
+    @staticmethod
+    def make_config(obs_dim, act_dim, n_envs, n_steps, batch_size=64, n_epochs=10, pi=(64, 64), vf=(64, 64),
+                    gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
+                    learning_rate=3e-4, adam_betas=(0.9, 0.999), adam_eps=1e-5, normalize_advantage=True,
+                    action_low=-1.0, action_high=1.0, seed=0, device_id=0, rank=0, world_size=1, fast_kernels=True,
+                    rollout_graph=True) -> Config:
+        """PPO(...) keyword arguments -> `mobrob_ppo_config_t` (SB3 defaults, Appendix A.1)."""
         if len(pi) != 2 or len(vf) != 2:
             raise ValueError("net_arch must have exactly two hidden layers per network (pi=[h1,h2], vf=[h1,h2])")
         cfg = Config()
-        self.lib.mobrob_ppo_default_config(C.byref(cfg))
+        _lib.load().mobrob_ppo_default_config(C.byref(cfg))
         cfg.obs_dim, cfg.act_dim = int(obs_dim), int(act_dim)
         cfg.pi_hidden[0], cfg.pi_hidden[1] = int(pi[0]), int(pi[1])
         cfg.vf_hidden[0], cfg.vf_hidden[1] = int(vf[0]), int(vf[1])
@@ -71,11 +72,31 @@ class PPOEngine:
         cfg.seed, cfg.device_id, cfg.rank, cfg.world_size = int(seed), int(device_id), int(rank), int(world_size)
         cfg.fast_kernels = int(bool(fast_kernels))
         cfg.rollout_graph = int(bool(rollout_graph))
+        return cfg
+
+    @staticmethod
+    def device_bytes(**kwargs) -> int:
+        """Device bytes an engine with these arguments occupies (host-only sizing pass, no GPU needed)."""
+        cfg = PPOEngine.make_config(**kwargs)
+        n = C.c_size_t(0)
+        check(_lib.load().mobrob_ppo_device_bytes(C.byref(cfg), C.byref(n)))
+        return int(n.value)
+
+    def __init__(self, obs_dim, act_dim, n_envs, n_steps, *, arena=None, **kwargs):
+        """arena: optional (device_pointer, bytes) -- build the engine inside caller-owned device memory
+        (mobrob_ppo_create_in_arena; the fleet packs several engines into one allocation this way)."""
+        self.lib = _lib.load()
+        cfg = self.make_config(obs_dim, act_dim, n_envs, n_steps, **kwargs)
+        pi, vf = tuple(cfg.pi_hidden), tuple(cfg.vf_hidden)
         self.cfg = cfg
         self.D, self.A, self.N, self.T = int(obs_dim), int(act_dim), int(n_envs), int(n_steps)
-        self.shapes = param_shapes(self.D, self.A, tuple(pi), tuple(vf))
+        self.shapes = param_shapes(self.D, self.A, pi, vf)
         self._h = C.c_void_p()
-        check(self.lib.mobrob_ppo_create(C.byref(cfg), C.byref(self._h)))
+        if arena is None:
+            check(self.lib.mobrob_ppo_create(C.byref(cfg), C.byref(self._h)))
+        else:
+            check(self.lib.mobrob_ppo_create_in_arena(C.byref(cfg), C.c_void_p(int(arena[0])), C.c_size_t(int(arena[1])),
+                                                      C.byref(self._h)))
         self.P = int(self.lib.mobrob_ppo_param_count(self._h))
         assert self.P == sum(int(np.prod(s)) for s in self.shapes.values())
         self.n_minibatches = int(self.lib.mobrob_ppo_num_minibatches(self._h))
@@ -188,6 +209,16 @@ class PPOEngine:
         st = TrainStats()
         check(self.lib.mobrob_ppo_train(self._h, p, C.byref(st)))
         return {k: float(getattr(st, k)) for k in STAT_KEYS} | {"n_minibatches": int(st.n_minibatches)}
+
+    def train_enqueue(self):
+        """PPO.train() enqueued on the engine's stream without waiting (device-drawn permutations)."""
+        check(self.lib.mobrob_ppo_train_enqueue(self._h, None))
+
+    def train_stats(self):
+        """Means over the last epoch's minibatches of the most recent update (waits for the stream)."""
+        rows = self.fetch_step_stats(self.n_minibatches)
+        m = rows.astype(np.float64).mean(axis=0) if len(rows) else np.zeros(7)
+        return {k: float(m[i]) for i, k in enumerate(STAT_KEYS)}
 
     def epoch_begin(self, perm=None):
         p = None

@@ -1,0 +1,103 @@
+"""GPU: mixed fleet (BASELINE config 5) -- car + drone + turtlebot3 learners packed into one device arena."""
+import numpy as np
+import pytest
+
+from oracle import ppo_oracle as O
+from tests.util import scaled_err
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(n_steps=24, batch_size=256, n_epochs=2, ent_coef=0.01)
+NAMES = ["car", "drone", "turtlebot3"]
+
+
+def _fleet(n_envs=48, seed=5, **kw):
+    from mobrob_amd.fleet import MixedFleet
+    a = dict(KW)
+    a.update(kw)
+    return MixedFleet(NAMES, n_envs=n_envs, seed=seed, **a)
+
+
+def test_segments_pack_back_to_back_in_one_arena():
+    from mobrob_amd.engine import PPOEngine
+    from mobrob_amd.fleet import ROBOT_DIMS
+    f = _fleet()
+    lay = f.layout()
+    assert [l[0] for l in lay] == NAMES
+    off = 0
+    for (name, o, nb, d, a, n), seg in zip(lay, f.segments):
+        assert (d, a) == ROBOT_DIMS[name] and o == off and nb % 256 == 0
+        assert nb >= PPOEngine.device_bytes(obs_dim=d, act_dim=a, n_envs=n, **KW)
+        # the segment's rollout buffers really live inside its slice of the arena, with its own strides
+        for buf, width in (("obs", 8 * ((d + 7) // 8)), ("actions", a)):
+            ptr, nbytes = seg.engine.device_buffer(buf)
+            assert f._arena + o <= ptr and ptr + nbytes <= f._arena + o + nb
+            rows = (KW["n_steps"] + (buf == "obs")) * n
+            assert nbytes >= rows * width * 4
+        off += nb
+    assert off == f.arena_bytes
+    f.close()
+
+
+def test_fleet_iteration_equals_standalone_engines_bit_for_bit():
+    """Segments overlap on the device (own streams, one arena) yet compute exactly what a stand-alone engine does."""
+    from mobrob_amd.engine import PPOEngine
+    from mobrob_amd.fleet import ROBOT_DIMS, ROBOT_P_TERM
+    f = _fleet()
+    ps = []
+    for i, s in enumerate(f.segments):
+        p = O.init_params(s.obs_dim, s.act_dim, seed=10 + i)
+        ps.append(p)
+        s.engine.set_params(p)
+    for _ in range(2):
+        f.iteration(time_limit=10)
+    stats = f.train()  # third update on the second rollout, with statistics
+    f.synchronize()
+    for i, s in enumerate(f.segments):
+        d, a = ROBOT_DIMS[s.name]
+        e = PPOEngine(obs_dim=d, act_dim=a, n_envs=48, seed=5 + i, **KW)
+        e.set_params(ps[i])
+        for _ in range(2):
+            e.collect_synthetic(p_term=ROBOT_P_TERM[s.name], time_limit=10)
+            e.train(None)
+        st = e.train(None)
+        for k, v in e.get_params().items():
+            assert np.array_equal(v, s.engine.get_params()[k]), (s.name, k)
+        assert np.array_equal(e.read("obs"), s.engine.read("obs"))
+        assert abs(st["loss"] - stats[s.name]["loss"]) <= 1e-6 * max(1.0, abs(st["loss"]))
+        e.close()
+    f.close()
+
+
+def test_fleet_update_matches_oracle_per_segment():
+    f = _fleet(n_envs=32, n_epochs=1)
+    h = O.Hyper(n_epochs=1, batch_size=256, ent_coef=0.01)
+    for i, s in enumerate(f.segments):
+        s.engine.set_params(O.init_params(s.obs_dim, s.act_dim, seed=20 + i))
+    f.collect_synthetic(time_limit=15)
+    f.synchronize()
+    before = []
+    for s in f.segments:
+        e = s.engine
+        T, N = e.T, e.N
+        buf = {k: e.read(k) for k in ("actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns")}
+        buf["obs"] = e.read("obs")[:T]
+        before.append((e.get_params(), buf))
+    perms = [np.stack([np.random.default_rng(3 + i).permutation(s.engine.T * s.engine.N)]) for i, s in enumerate(f.segments)]
+    for s, pm in zip(f.segments, perms):
+        s.engine.train(pm)
+    for (p, buf), s, pm in zip(before, f.segments, perms):
+        q = {k: v.copy() for k, v in p.items()}
+        O.train(q, O.AdamState.zeros_like(q), buf, h, pm)
+        got = s.engine.get_params()
+        for k in q:
+            assert scaled_err(got[k], q[k]) < 1e-4, (s.name, k)
+    f.close()
+
+
+def test_fleet_errors():
+    from mobrob_amd.fleet import MixedFleet
+    with pytest.raises(ValueError):
+        MixedFleet(["car", "submarine"], n_envs=4, **KW)
+    with pytest.raises(ValueError):
+        MixedFleet([], **KW)
