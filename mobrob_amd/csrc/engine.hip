@@ -324,7 +324,8 @@ int fused_init(mobrob_ppo_engine* e) {
   const int H = f.H;
   const size_t nW1 = (size_t)(H / 32) * (e->Dp / 8) * 256, nW2 = (size_t)(H / 32) * (H / 8) * 256;
   const size_t nW3f = (size_t)(H / 8) * 256, nW3b = (size_t)(H / 32) * 4 * 256;
-  const size_t per_net = nW1 + 2 * nW2 + nW3f + nW3b + 2 * H;
+  const size_t nW3h = (size_t)(H / 16) * 256;  // 16x16x4 pack of heads <= 16 wide (H = 256 train kernel)
+  const size_t per_net = nW1 + 2 * nW2 + nW3f + nW3h + nW3b + 2 * H;
   f.packed_floats = 2 * per_net;
   CHK(dalloc(e, &f.packed, f.packed_floats));
   const int bias_ids[2][3] = {{T_PB1, T_PB2, T_AB}, {T_VB1, T_VB2, T_VB}};
@@ -337,6 +338,7 @@ int fused_init(mobrob_ppo_engine* e) {
     f.net[n].W3b = reinterpret_cast<const f32x4*>(p); p += nW3b;
     f.net[n].b1s = p; p += H;
     f.net[n].b2s = p; p += H;
+    f.net[n].W3h = reinterpret_cast<const f32x4*>(p); p += nW3h;  // last: the H = 64 kernels mirror [W1f, b2s] as one block
     f.net[n].b3 = e->params + e->offs[bias_ids[n][2]];
     f.net[n].head = n == 0 ? e->A : 1;
   }
@@ -406,7 +408,7 @@ void fused_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, float 
   SlabReduceArgs s{};
   s.slabs = f.slabs; s.slab_floats = f.slab_floats; s.nslabs = grid; s.grads = e->grads; s.P = e->P;
   for (int i = 0; i < 14; ++i) s.offs[i] = e->offs[i];
-  s.D = e->D; s.Dp = e->Dp; s.A = e->A; s.ent_coef = (float)e->cfg.ent_coef; s.b_local = (float)B; s.inv_bg = inv_bg;
+  s.D = e->D; s.Dp = e->Dp; s.A = e->A; s.h16 = e->A <= 16; s.ent_coef = (float)e->cfg.ent_coef; s.b_local = (float)B; s.inv_bg = inv_bg;
   s.sums = e->grads + e->P;
   hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(f.slab_floats, 256), 2), dim3(256), 0, e->stream, s);
 }
@@ -1024,6 +1026,7 @@ int mobrob_ppo_minibatch_apply(mobrob_ppo_engine_t* e) {
     a.fW3f[n] = on ? (float*)e->fused.net[n].W3f : nullptr;
     a.fW2b[n] = on ? (float*)e->fused.net[n].W2b : nullptr;
     a.fW3b[n] = on ? (float*)e->fused.net[n].W3b : nullptr;
+    a.fW3h[n] = (on && e->fused.H == FH && e->fused.A <= 16) ? (float*)e->fused.net[n].W3h : nullptr;
     a.fb1s[n] = on ? (float*)e->fused.net[n].b1s : nullptr;
     a.fb2s[n] = on ? (float*)e->fused.net[n].b2s : nullptr;
   }

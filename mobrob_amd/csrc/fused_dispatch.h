@@ -25,7 +25,11 @@ inline void fused_launch_act(FusedState& f, FusedActArgs& a, hipStream_t st) {
   }
 }
 inline void fused_launch_train(FusedState& f, FusedTrainArgs& a, int grid, hipStream_t st) {
-  FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused_train<DPc>), dim3(grid), dim3(FTHREADS), f.lds_bytes, st, a));
+  if (f.A <= 16) {  // both heads <= 16 wide: 16x16x4 head / dW3 variant
+    FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused_train<DPc, true>), dim3(grid), dim3(FTHREADS), f.lds_bytes, st, a));
+  } else {
+    FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused_train<DPc, false>), dim3(grid), dim3(FTHREADS), f.lds_bytes, st, a));
+  }
 }
 inline void fused64_launch_train(FusedState& f, Fused64TrainArgs& a, int grid, hipStream_t st) {
   FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused64_train<DPc>), dim3(grid), dim3(Lay64<DPc>::TNWV * 64), f.lds_bytes, st, a));
@@ -40,7 +44,9 @@ inline hipError_t fused_set_lds_attr(FusedState& f) {
     });
   } else {
     FUSED_DISPATCH_DP(f.Dp, {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_train<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_train<DPc, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_train<DPc, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_act<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_act_bytes);
     });

@@ -26,6 +26,7 @@ struct FusedNet {
   const f32x4* W1f;  // [H/32][Dp/8][64]   fwd pack of W1 [H][Dp]
   const f32x4* W2f;  // [H/32][H/8][64]    fwd pack of W2 [H][H]
   const f32x4* W3f;  // [1][H/8][64]       fwd pack of head [32 (zero padded)][H]
+  const f32x4* W3h;  // [H/16][64]         16x16x4 fwd pack of head [16 (zero padded)][H] (heads <= 16 wide)
   const f32x4* W2b;  // [H/32][H/8][64]    bwd pack: B[k=n][j] = W2[n][j]
   const f32x4* W3b;  // [H/32][32/8][64]   bwd pack: B[k=a][j] = head[a][j], a < 32 zero padded
   const float* b1s; const float* b2s;  // hidden biases pre-multiplied by kTanhScale (see fast_tanh_scaled)
@@ -285,6 +286,20 @@ __device__ __forceinline__ void mfma_x2y2(f32x16& c00, f32x16& c10, f32x16& c01,
                : "v"(x0), "v"(x1), "v"(y0), "v"(y1));
 }
 
+// v_mfma_f32_16x16x4_f32 (A: lane l -> A[l&15][l>>4], B: lane l -> B[l>>4][l&15], C: reg e -> C[4(l>>4)+e][l&15]):
+// same MAC rate as 32x32x2 but N = 16, so a head of <= 16 outputs costs half the cycles of a 32-wide tile.
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+__device__ __forceinline__ void mfma16_x1y4(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3, float x, float y0, float y1,
+                                            float y2, float y3) {
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f32_16x16x4_f32 %0, %4, %5, %0\n\t"
+               "v_mfma_f32_16x16x4_f32 %1, %4, %6, %1\n\t"
+               "v_mfma_f32_16x16x4_f32 %2, %4, %7, %2\n\t"
+               "v_mfma_f32_16x16x4_f32 %3, %4, %8, %3"
+               : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+               : "v"(x), "v"(y0), "v"(y1), "v"(y2), "v"(y3));
+}
+
 // ------------------------------------------------------------------------------------------------
 // epilogue helpers for the wave's 64x64 output block (2 column blocks x 2 row blocks, C layout)
 // ------------------------------------------------------------------------------------------------
@@ -378,7 +393,7 @@ struct Lay {
 // forward of one 64-row tile through one network; leaves h1, h2 in LDS and the raw head tile
 // (without bias) in the head tile [64][FLDO].  All 4 waves participate; ends with a barrier.
 // ------------------------------------------------------------------------------------------------
-template <int DP>
+template <int DP, bool H16>
 __device__ __forceinline__ Frag2 tile_layers(const FusedNet& W, int wave, int lane, const Frag2& f1 STAMP_PARAMS) {
   using L = Lay<DP>;
   constexpr int nkg2 = FH / 8;
@@ -402,7 +417,7 @@ __device__ __forceinline__ Frag2 tile_layers(const FusedNet& W, int wave, int la
   __syncthreads();
   STAMP(3)
   // head GEMM operands: K split in two halves; wave = (khalf << 1) | rowblock
-  const f32x4* bp = W.W3f + (size_t)((wave >> 1) * 16) * 64;
+  const f32x4* bp = H16 ? W.W3h : W.W3f + (size_t)((wave >> 1) * 16) * 64;
   Frag2 f3;
   {  // layer 2: K = H
     const float bz0 = W.b2s[64 * wave + r_], bz1 = W.b2s[64 * wave + 32 + r_];
@@ -470,10 +485,49 @@ __device__ __forceinline__ void tile_head(const FusedNet& W, int wave, int lane,
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// The training kernel.
-// ------------------------------------------------------------------------------------------------
+// Heads of <= 16 outputs: wave w computes rows [16w, 16w+16) of the head tile over the full K = 256 with
+// v_mfma_f32_16x16x4_f32 (half the MFMA cycles of the zero-padded 32-wide tile).  No cross-wave reduction, and the
+// loss stage of wave w (4 lanes per row, rows 16w..16w+15) consumes exactly the rows this wave wrote -> no barrier.
 template <int DP>
+__device__ __forceinline__ void tile_head16(const FusedNet& W, int wave, int lane, const Frag2& f3) {
+  using L = Lay<DP>;
+  const int i = lane & 15, g = lane >> 4;
+  const f32x4* bp = W.W3h;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};  // two independent chains (even / odd k-groups)
+  const int ab = 4 * opaque((L::H2 + (16 * wave + i) * FLDH + 4 * g) >> 2);
+  unsigned bo = opaque_u((unsigned)lane * 16u);
+  f32x4 bA = f3.p, bB = f3.q;
+  f32x4 aA = *reinterpret_cast<const f32x4*>(&lds[ab]), aB = *reinterpret_cast<const f32x4*>(&lds[ab + 16]);
+  int ao = ab;
+#pragma unroll 1
+  for (int kg = 0; kg < FH / 16 - 2; kg += 2) {
+    const f32x4 b0 = bA, b1 = bB, a0 = aA, a1 = aB;
+    bA = ldg16(bp, bo + 2048u);
+    bB = ldg16(bp, bo + 3072u);
+    aA = *reinterpret_cast<const f32x4*>(&lds[ao + 32]);
+    aB = *reinterpret_cast<const f32x4*>(&lds[ao + 48]);
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      acc = MFMA16(a0[s_], b0[s_], acc);
+      acc2 = MFMA16(a1[s_], b1[s_], acc2);
+    }
+    bo += 2048u;
+    ao += 32;
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) {
+    acc = MFMA16(aA[s_], bA[s_], acc);
+    acc2 = MFMA16(aB[s_], bB[s_], acc2);
+  }
+  const int o = opaque(L::DO + (16 * wave + 4 * g) * FLDO + i);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) lds[o + e * FLDO] = acc[e] + acc2[e];
+}
+
+// ------------------------------------------------------------------------------------------------
+// The training kernel.  H16: both heads are <= 16 wide (A <= 16) -> 16x16x4 head / dW3, dh2 over K = 16.
+// ------------------------------------------------------------------------------------------------
+template <int DP, bool H16>
 __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   using L = Lay<DP>;
   constexpr int ldx = L::LDX, per = DP / 4;
@@ -491,7 +545,8 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   // dW1 (4 tiles) and dW3 (2 tiles) accumulate in arch VGPRs across all tiles of the workgroup (96 registers):
   // the hot GEMM loops need ~100 VGPRs, so everything fits without spilling and no per-tile slab traffic remains.
   f32x16 gW1a = zero16(), gW1b = zero16(), gW1c = zero16(), gW1d = zero16();  // [ib][jb] = 00, 10, 01, 11
-  f32x16 gW3a = zero16(), gW3b = zero16();
+  f32x16 gW3a = zero16(), gW3b = zero16();  // 32-wide heads: [32][this wave's 64 columns]
+  f32x4 gW3h0 = {0.f, 0.f, 0.f, 0.f}, gW3h1 = gW3h0, gW3h2 = gW3h0, gW3h3 = gW3h0;  // H16: [16][64] as 4 16x16 tiles
   float* slab = a.slabs + (size_t)blockIdx.x * a.slab_floats;
   float* slab_w1 = slab + slab_off_w1();
   float* slab_w3 = slab + slab_off_w3(DP);
@@ -564,28 +619,32 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     }
     __syncthreads();
     STAMP(0)
-    const Frag2 f3 = tile_layers<DP>(W, wave, lane, f1 STAMP_ARGS);
+    const Frag2 f3 = tile_layers<DP, H16>(W, wave, lane, f1 STAMP_ARGS);
     // operands of the loss stage, fetched while the head GEMM runs (4 lanes per row, q = action residue mod 4)
     const int lrr = tid >> 2, lq = tid & 3;
     const bool llive = row0 + lrr < a.count;
-    float l_adv = 0.f, l_old = 0.f, l_act[8];
+    constexpr int NJ = H16 ? 4 : 8;  // action columns per lane (4 lanes per row)
+    float l_adv = 0.f, l_old = 0.f, l_act[NJ];
     {
       const unsigned src = llive ? (unsigned)a.rows[row0 + lrr] : 0u;
       if (net == 0) {
         const unsigned aoff = (src * (unsigned)a.A + (unsigned)lq) * 4u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < NJ; ++j)
           l_act[j] = (4 * j + lq < a.A && llive)
                          ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.actions) + (aoff + 16u * j))
                          : 0.f;
         if (llive) { l_adv = a.adv[src]; l_old = a.old_logp[src]; }
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) l_act[j] = 0.f;
+        for (int j = 0; j < NJ; ++j) l_act[j] = 0.f;
         if (llive) l_old = a.ret[src];
       }
     }
-    if (PHASE_ON(8)) tile_head<DP>(W, wave, lane, f3 STAMP_ARGS);
+    if (PHASE_ON(8)) {
+      if constexpr (H16) tile_head16<DP>(W, wave, lane, f3);
+      else tile_head<DP>(W, wave, lane, f3 STAMP_ARGS);
+    }
     STAMP(8)
 
     const Frag2 fh2 = prefetch_frag(W.W3b + (size_t)(2 * wave) * 4 * 64, W.W3b + (size_t)(2 * wave + 1) * 4 * 64, lane);
@@ -600,9 +659,9 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
       const int A = a.A;
       if (net == 0) {
         float lp = 0.f;
-        float dk[8];
+        float dk[NJ];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           float d = 0.f;
           if (4 * j + q < A && live) {
             d = l_act[j] - (lds[db + 4 * j] + lds[cb + 64 + 4 * j]);
@@ -630,7 +689,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
           g_logp = -(w1 * adv + (1.0f - w1) * adv * in_range) * a.inv_bg * ratio;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           const float iv = lds[cb + 4 * j];
           float gm = g_logp * dk[j] * iv;  // zero for k >= A (dk = 0, iv = 0)
           float gl = (4 * j + q < A) ? g_logp * (dk[j] * dk[j] * iv - 1.0f) : 0.f;
@@ -655,7 +714,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
           dv = a.vf_coef * 2.0f * (v - rt) * a.inv_bg;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) lds[db + 4 * j] = (j == 0) ? dv : 0.f;  // q != 0 lanes hold dv = 0
+        for (int j = 0; j < NJ; ++j) lds[db + 4 * j] = (j == 0) ? dv : 0.f;  // q != 0 lanes hold dv = 0
         const float t = wave_sum(dv);
         if (lane == 0) lds[gb] += t;
       }
@@ -663,18 +722,36 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     __syncthreads();
     STAMP(9)
 
-    // ---- dW3 += dout^T . h2  (M = 32 head rows, this wave's 64 columns, K = 64 rows) ----
+    // ---- dW3 += dout^T . h2  (M = 32 or 16 head rows, this wave's 64 columns, K = 64 rows) ----
     if (PHASE_ON(32)) {
-      const int ao = opaque(L::DO + h * FLDO + r);              // A[i=a][k=row] = dout[row][a]
-      const int bo = opaque(L::H2 + h * FLDH + 64 * wave + r);  // B[k=row][j]  = h2[row][j]
-      float x = lds[ao], y0 = lds[bo], y1 = lds[bo + 32];
+      if constexpr (H16) {
+        // lane group g = lane>>4 takes batch rows kk + 4g (kk = 16s + j): LDS bank offset 16g -> conflict-free
+        const int i16 = lane & 15, g4 = 4 * (lane >> 4);
+        const int ao = opaque(L::DO + g4 * FLDO + i16);              // A[i=a][k=row] = dout[row][a]
+        const int bo = opaque(L::H2 + g4 * FLDH + 64 * wave + i16);  // B[k=row][j]  = h2[row][j], 4 column tiles
+        float x = lds[ao], y0 = lds[bo], y1 = lds[bo + 16], y2 = lds[bo + 32], y3 = lds[bo + 48];
+#pragma unroll 5
+        for (int t = 1; t < 16; ++t) {
+          const int kk = (t >> 2) * 16 + (t & 3);
+          const float xn = lds[ao + kk * FLDO];
+          const float* bk = &lds[bo + kk * FLDH];
+          const float y0n = bk[0], y1n = bk[16], y2n = bk[32], y3n = bk[48];
+          mfma16_x1y4(gW3h0, gW3h1, gW3h2, gW3h3, x, y0, y1, y2, y3);
+          x = xn; y0 = y0n; y1 = y1n; y2 = y2n; y3 = y3n;
+        }
+        mfma16_x1y4(gW3h0, gW3h1, gW3h2, gW3h3, x, y0, y1, y2, y3);
+      } else {
+        const int ao = opaque(L::DO + h * FLDO + r);              // A[i=a][k=row] = dout[row][a]
+        const int bo = opaque(L::H2 + h * FLDH + 64 * wave + r);  // B[k=row][j]  = h2[row][j]
+        float x = lds[ao], y0 = lds[bo], y1 = lds[bo + 32];
 #pragma unroll 4
-      for (int k = 0; k < FR - 2; k += 2) {
-        const float xn = lds[ao + (k + 2) * FLDO], y0n = lds[bo + (k + 2) * FLDH], y1n = lds[bo + (k + 2) * FLDH + 32];
+        for (int k = 0; k < FR - 2; k += 2) {
+          const float xn = lds[ao + (k + 2) * FLDO], y0n = lds[bo + (k + 2) * FLDH], y1n = lds[bo + (k + 2) * FLDH + 32];
+          mfma_x1y2(gW3a, gW3b, x, y0, y1);
+          x = xn; y0 = y0n; y1 = y1n;
+        }
         mfma_x1y2(gW3a, gW3b, x, y0, y1);
-        x = xn; y0 = y0n; y1 = y1n;
       }
-      mfma_x1y2(gW3a, gW3b, x, y0, y1);
     }
     STAMP(10)
     // ---- dh2 = dout . W3 (K = 16 or 32), then dz2 = dh2 * (1 - h2^2) in place ----
@@ -682,7 +759,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
       f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
       if (PHASE_ON(64))
         gemm_lds_packed<FLDO>(L::DO, W.W3b + (size_t)(2 * wave) * 4 * 64, W.W3b + (size_t)(2 * wave + 1) * 4 * 64,
-                              W.head <= 16 ? 2 : 4,  // k-groups of 8: head columns beyond `head` are zero padding
+                              H16 ? 2 : 4,  // k-groups of 8: head columns beyond `head` are zero padding
                               c00, c01, c10, c11, lane, fh2);
       STAMP(11)
       __syncthreads();  // every wave is done reading h2 (dW3) before it is overwritten
@@ -786,12 +863,21 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
           for (int e = 0; e < 4; ++e) v[e] = gW1d[4 * qd + e];
           stg16(slab_w1, s1 + (3 * 4 + qd) * 1024u, v);
         }
+        if constexpr (!H16) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gW3a[4 * qd + e];
-        stg16(slab_w3, s3 + qd * 1024u, v);
+          for (int e = 0; e < 4; ++e) v[e] = gW3a[4 * qd + e];
+          stg16(slab_w3, s3 + qd * 1024u, v);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gW3b[4 * qd + e];
-        stg16(slab_w3, s3 + (4 + qd) * 1024u, v);
+          for (int e = 0; e < 4; ++e) v[e] = gW3b[4 * qd + e];
+          stg16(slab_w3, s3 + (4 + qd) * 1024u, v);
+        }
+      }
+      if constexpr (H16) {  // [w][column tile b][lane] x 16 B
+        const unsigned sh = (unsigned)(wave * 4 * 64 + lane) * 16u;
+        stg16(slab_w3, sh, gW3h0);
+        stg16(slab_w3, sh + 1024u, gW3h1);
+        stg16(slab_w3, sh + 2048u, gW3h2);
+        stg16(slab_w3, sh + 3072u, gW3h3);
       }
     }
     float* w2base = slab + slab_off_w2();
@@ -843,6 +929,7 @@ struct SlabReduceArgs {
   float* grads; int P;
   int offs[14];   // canonical offsets
   int D, Dp, A;
+  int h16;        // dW3 region written by the 16x16x4 variant (k_fused_train<DP, true>)
   float ent_coef, b_local, inv_bg;
   float* sums;    // sums[4] = rows (for the stats finaliser)
 };
@@ -869,6 +956,13 @@ __device__ __forceinline__ int slab_to_canonical(const SlabReduceArgs& s, int ne
     frag(p - slab_off_w1(), 4, &w, &t, &i, &lane);
     const int n = 64 * w + 32 * (t >> 1) + crc(i) + 4 * (lane >> 5), j = 32 * (t & 1) + (lane & 31);
     return j < s.D ? s.offs[T_W1] + n * s.D + j : -1;
+  }
+  if (p < slab_off_b2(s.Dp) && s.h16) {  // dW3, 16x16 tiles: [w][b][lane][e] -> head row 4(lane>>4)+e, column 64w+16b+(lane&15)
+    const int q = p - slab_off_w3(s.Dp);
+    if (q >= 16 * FH) return -1;
+    const int e = q & 3, l = (q >> 2) & 63, b = (q >> 8) & 3, w_ = q >> 10;
+    const int a_ = 4 * (l >> 4) + e, j = 64 * w_ + 16 * b + (l & 15);
+    return a_ < head ? s.offs[T_W3] + a_ * FH + j : -1;
   }
   if (p < slab_off_b2(s.Dp)) {  // dW3
     frag(p - slab_off_w3(s.Dp), 2, &w, &t, &i, &lane);
@@ -924,6 +1018,15 @@ __global__ void k_pack_fwd(const float* __restrict__ W, int N, int K, int ld, fl
   const int s = i & 3, lane = (i >> 2) & 63, kg = (i >> 8) % KG, nb = (i >> 8) / KG;
   const int n = nb * 32 + (lane & 31), k = kg * 8 + 4 * (lane >> 5) + s;
   out[i] = (n < N && k < K) ? scale * W[(size_t)n * ld + k] : 0.f;
+}
+// 16x16x4 fwd pack of a head [N <= 16][K]: out[kg][lane][s] = W[lane & 15][16 kg + 4 (lane >> 4) + s]
+__host__ __device__ inline int pack_h16_idx(int n, int k) { return (((k >> 4) * 64) + 16 * ((k >> 2) & 3) + n) * 4 + (k & 3); }
+__global__ void k_pack_h16(const float* __restrict__ W, int N, int K, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (K / 16) * 256) return;
+  const int s = i & 3, lane = (i >> 2) & 63, kg = i >> 8;
+  const int n = lane & 15, k = 16 * kg + 4 * (lane >> 4) + s;
+  out[i] = n < N ? W[(size_t)n * K + k] : 0.f;
 }
 __global__ void k_scale_copy(const float* __restrict__ src, float* __restrict__ dst, int n, float scale) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1159,7 +1262,7 @@ struct AdamPackArgs {
   // generic-path padded copies (always maintained: cheap, and k_value_flagged/predict fallbacks use canonical)
   float* pW1p; float* vW1p; float* aWp; float* vWp;
   // fused-path packs (null when the fused path is disabled)
-  float* fW1f[2]; float* fW2f[2]; float* fW3f[2]; float* fW2b[2]; float* fW3b[2]; float* fb1s[2]; float* fb2s[2];
+  float* fW1f[2]; float* fW2f[2]; float* fW3f[2]; float* fW3h[2]; float* fW2b[2]; float* fW3b[2]; float* fb1s[2]; float* fb2s[2];
   float* stats_row;  // [6] <- total gradient norm
   float* loss_sums_zero;  // fused path: the 8 loss accumulators are re-zeroed here instead of by a memset launch
 };
@@ -1229,6 +1332,7 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
       if (a.fW3f[net]) {
         a.fW3f[net][pack_fwd_idx(n, k, K / 8)] = pn;
         a.fW3b[net][pack_bwd_idx(n, k, 4)] = pn;
+        if (a.fW3h[net] && n < 16) a.fW3h[net][pack_h16_idx(n, k)] = pn;
       }
     } break;
     case 2: case 6: if (a.fb1s[t == 6]) a.fb1s[t == 6][e] = kTanhScale * pn; break;  // hidden biases (scaled copies)
@@ -1281,6 +1385,8 @@ inline void fused_repack(FusedState& f, const float* params, const int* offs, hi
     fwd(params + offs[w1[n]], H, D, D, f.net[n].W1f, H / 32, Dp / 8, kTanhScale);
     fwd(params + offs[w2[n]], H, H, H, f.net[n].W2f, H / 32, H / 8, kTanhScale);
     fwd(params + offs[w3[n]], heads[n], H, H, f.net[n].W3f, 1, H / 8, 1.0f);
+    if (H == FH && heads[n] <= 16)
+      hipLaunchKernelGGL(k_pack_h16, dim3(H / 16), dim3(256), 0, st, params + offs[w3[n]], heads[n], H, (float*)f.net[n].W3h);
     hipLaunchKernelGGL(k_scale_copy, dim3(1), dim3(256), 0, st, params + offs[w1[n] + 1], (float*)f.net[n].b1s, H, kTanhScale);
     hipLaunchKernelGGL(k_scale_copy, dim3(1), dim3(256), 0, st, params + offs[w2[n] + 1], (float*)f.net[n].b2s, H, kTanhScale);
     bwd(params + offs[w2[n]], H, H, H, f.net[n].W2b, H / 32, H / 8);

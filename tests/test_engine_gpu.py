@@ -285,7 +285,9 @@ def test_fused_act_matches_oracle(D, A):
                                  dict(D=58, A=12, T=50, N=200, B=10000, E=1),    # 157 tiles -> 128 WGs, some with 2 tiles
                                  dict(D=14, A=2, T=30, N=100, B=1000, E=2),      # 3 minibatches, DP=16
                                  dict(D=43, A=2, T=20, N=64, B=512, E=1),        # DP=48
-                                 dict(D=26, A=2, T=9, N=7, B=63, E=2)])          # DP=32, single tile, count < 64
+                                 dict(D=26, A=2, T=9, N=7, B=63, E=2),           # DP=32, single tile, count < 64
+                                 dict(D=12, A=18, T=12, N=40, B=200, E=1),       # head wider than 16 -> 32-wide head path
+                                 dict(D=30, A=16, T=10, N=33, B=330, E=1)])      # head exactly 16 (16x16x4 path, no padding)
 def test_fused_train_matches_oracle_and_generic(cfg):
     D, A, T, N, B, E = (cfg[k] for k in "DATNBE")
     H = 256
