@@ -202,7 +202,10 @@ enum {
   MOBROB_BUF_LAST_DONES = 12,  /* f32 [N] (0/1)                                                  */
   MOBROB_BUF_CLIPPED_ACTIONS = 13, /* f32 [N][A] of the most recent act                          */
   MOBROB_BUF_EPISODE_START_STATE = 14, /* f32 [N] `_last_episode_starts` carried between rollouts   */
-  MOBROB_BUF_COUNT = 15
+  MOBROB_BUF_TERMINAL_OBS = 15,    /* f32 [N][Dp] terminal observations of the rows truncated in the latest step */
+  MOBROB_BUF_TERMINAL_VALUES = 16, /* f32 [N] V(terminal_obs) of those rows (time-limit bootstrap)              */
+  MOBROB_BUF_TRUNCATED = 17,       /* u8  [N] TimeLimit.truncated flags of the latest step                       */
+  MOBROB_BUF_COUNT = 18
 };
 int mobrob_ppo_buffer_info(mobrob_ppo_engine_t* e, int32_t which, void** ptr_dev, size_t* bytes);
 /* copy with host layout [..][D] <-> device layout [..][Dp] handled for MOBROB_BUF_OBS */

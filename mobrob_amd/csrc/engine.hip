@@ -844,16 +844,17 @@ int enqueue_rollout(mobrob_ppo_engine* e, float p_term, int time_limit) {
   const uint64_t env_seed = e->cfg.seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(e->cfg.rank + 1));
   // the previous rollout's last observation is this rollout's first
   HIPC(hipMemcpyAsync(e->obs, e->obs + (size_t)e->T * slot, slot * 4, hipMemcpyDeviceToDevice, e->stream));
+  BootArgs bt{Pp(e, T_VW1), Pp(e, T_VB1), Pp(e, T_VW2), Pp(e, T_VB2), Pp(e, T_VW), Pp(e, T_VB), e->G1, e->G2,
+              (float)e->cfg.gamma, e->term_val};
   for (int t = 0; t < e->T; ++t) {
     act_slot(e, t, nullptr, true);
     {
       ProfScope ps(e, MOBROB_K_ENV);
-      hipLaunchKernelGGL(k_env_step_store, dim3(cdiv(N * per, 256)), dim3(256), 0, e->stream, env_seed, (uint32_t)t,
-                         e->ctr_dev + 1, N, e->D, Dp, p_term, time_limit, e->ep_len, e->ep_len2,
-                         e->obs + (size_t)(t + 1) * slot, e->term_obs, e->prev_dones, e->dones_tmp, e->trunc_dev,
-                         e->rewards + (size_t)t * N, e->es + (size_t)t * N);
-      // time-limit bootstrap of the (rare) truncated rows, in place: rewards += gamma * V(terminal_obs)
-      value_flagged(e, e->term_obs, e->trunc_dev, e->term_val, e->rewards + (size_t)t * N);
+      // env draw + rollout_buffer.add scalars + time-limit bootstrap of the (rare) truncated rows in one launch
+      hipLaunchKernelGGL(k_env_step_store, dim3(cdiv(N * per, 256)), dim3(256), env_step_lds_bytes(Dp, e->G1, e->G2),
+                         e->stream, env_seed, (uint32_t)t, e->ctr_dev + 1, N, e->D, Dp, p_term, time_limit, e->ep_len,
+                         e->ep_len2, e->obs + (size_t)(t + 1) * slot, e->term_obs, e->prev_dones, e->dones_tmp,
+                         e->trunc_dev, e->rewards + (size_t)t * N, e->es + (size_t)t * N, bt);
     }
     std::swap(e->prev_dones, e->dones_tmp);
     std::swap(e->ep_len, e->ep_len2);
@@ -1141,6 +1142,9 @@ int mobrob_ppo_buffer_info(mobrob_ppo_engine_t* e, int32_t which, void** ptr, si
     case MOBROB_BUF_LAST_DONES: p = e->last_dones; b = N * 4; break;
     case MOBROB_BUF_CLIPPED_ACTIONS: p = e->clip_act; b = N * e->A * 4; break;
     case MOBROB_BUF_EPISODE_START_STATE: p = e->prev_dones; b = N * 4; break;
+    case MOBROB_BUF_TERMINAL_OBS: p = e->term_obs; b = N * e->Dp * 4; break;
+    case MOBROB_BUF_TERMINAL_VALUES: p = e->term_val; b = N * 4; break;
+    case MOBROB_BUF_TRUNCATED: p = e->trunc_dev; b = N; break;
     default: return fail(MOBROB_ERR_INVALID, "unknown buffer id %d", which);
   }
   if (ptr) *ptr = p;

@@ -212,6 +212,29 @@ __global__ void k_u8_to_f32(const uint8_t* __restrict__ in, float* __restrict__ 
 // Value of flagged rows only (time-limit bootstrap is rare: one block per env, exits unless flagged).
 // V(x) = Wv . tanh(W2 tanh(W1 x + b1) + b2) + bv with the canonical (unpadded) parameter vector.
 // ------------------------------------------------------------------------------------------------
+// x[D] is already in LDS; h1[G1], h2[G2], red[16] are LDS scratch.  Every thread of the block returns V(x).
+__device__ __forceinline__ float value_row_lds(const float* x, float* h1, float* h2, float* red,
+                                               const float* __restrict__ W1, const float* __restrict__ b1,
+                                               const float* __restrict__ W2, const float* __restrict__ b2,
+                                               const float* __restrict__ Wv, const float* __restrict__ bv, int D, int G1,
+                                               int G2) {
+  for (int j = threadIdx.x; j < G1; j += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < D; ++k) s = fmaf(x[k], W1[(size_t)j * D + k], s);
+    h1[j] = tanhf(s + b1[j]);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < G2; j += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < G1; ++k) s = fmaf(h1[k], W2[(size_t)j * G1 + k], s);
+    h2[j] = tanhf(s + b2[j]);
+  }
+  __syncthreads();
+  float p = 0.f;
+  for (int k = threadIdx.x; k < G2; k += blockDim.x) p += h2[k] * Wv[k];
+  return block_sum(p, red) + bv[0];
+}
+
 __global__ __launch_bounds__(256) void k_value_flagged(const float* __restrict__ obs, int ldo,
                                                        const uint8_t* __restrict__ flags,
                                                        const float* __restrict__ W1, const float* __restrict__ b1,
@@ -228,23 +251,8 @@ __global__ __launch_bounds__(256) void k_value_flagged(const float* __restrict__
   float* red = h2 + G2;
   for (int i = threadIdx.x; i < D; i += blockDim.x) x[i] = obs[(size_t)row * ldo + i];
   __syncthreads();
-  for (int j = threadIdx.x; j < G1; j += blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < D; ++k) s = fmaf(x[k], W1[(size_t)j * D + k], s);
-    h1[j] = tanhf(s + b1[j]);
-  }
-  __syncthreads();
-  for (int j = threadIdx.x; j < G2; j += blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < G1; ++k) s = fmaf(h1[k], W2[(size_t)j * G1 + k], s);
-    h2[j] = tanhf(s + b2[j]);
-  }
-  __syncthreads();
-  float p = 0.f;
-  for (int k = threadIdx.x; k < G2; k += blockDim.x) p += h2[k] * Wv[k];
-  const float tot = block_sum(p, red);
+  const float v = value_row_lds(x, h1, h2, red, W1, b1, W2, b2, Wv, bv, D, G1, G2);
   if (threadIdx.x == 0) {
-    const float v = tot + bv[0];
     out[row] = v;
     if (rew_inout != nullptr)  // rewards[idx] += gamma * V(terminal_obs)  [oracle bootstrap_reward]
       rew_inout[row] = (float)((double)rew_inout[row] + (double)__fmul_rn(gamma, v));
@@ -589,47 +597,97 @@ __global__ void k_env_step(uint64_t seed, uint32_t step, int N, int D, int Dp, f
 }
 // One-launch variant used by the device-resident rollout: env draw + rollout_buffer.add scalars.
 // ep_len is double buffered (every chunk thread of an env must see the OLD value); the time-limit
-// bootstrap of the (rare) truncated rows is applied afterwards by k_value_flagged in place.
+// bootstrap of the (rare) truncated rows is applied in the same launch (see below).
 __global__ void k_add_counters(uint32_t* ctr, uint32_t d0, uint32_t d1) {
   if (threadIdx.x == 0 && blockIdx.x == 0) { ctr[0] += d0; ctr[1] += d1; }
 }
-__global__ void k_env_step_store(uint64_t seed, uint32_t step_rel, const uint32_t* __restrict__ step_base, int N, int D,
+struct BootArgs {  // value network (canonical parameters) for the in-kernel time-limit bootstrap
+  const float *W1, *b1, *W2, *b2, *Wv, *bv;
+  int G1, G2;
+  float gamma;
+  float* term_val;  // [N] V(terminal_obs) of truncated rows (diagnostics / tests)
+};
+constexpr int kBootMaxEnvs = 72;  // envs whose chunk-0 thread can live in one 256-thread block (Dp >= 16: <= 65)
+inline size_t env_step_lds_bytes(int Dp, int G1, int G2) { return (size_t)(Dp + G1 + G2 + 16 + 4 + 2 * kBootMaxEnvs) * 4; }
+
+// Time-limit truncation is rare (one row in `time_limit`), so the bootstrap  r += gamma * V(terminal_obs)  [oracle
+// bootstrap_reward] runs in the same launch: the block that owns chunk 0 of a truncated env re-draws its terminal
+// observation into LDS and evaluates the value MLP with all 256 threads (same arithmetic as k_value_flagged).
+__global__ __launch_bounds__(256) void k_env_step_store(uint64_t seed, uint32_t step_rel, const uint32_t* __restrict__ step_base, int N, int D,
                                  int Dp, float p_term, int time_limit,
                                  const int* __restrict__ ep_len_in, int* __restrict__ ep_len_out,
                                  float* __restrict__ obs_next, float* __restrict__ term_obs,
                                  const float* __restrict__ prev_dones, float* __restrict__ next_dones,
-                                 uint8_t* __restrict__ trunc, float* __restrict__ rew_out, float* __restrict__ es_out) {
+                                 uint8_t* __restrict__ trunc, float* __restrict__ rew_out, float* __restrict__ es_out,
+                                 BootArgs bt) {
+  extern __shared__ float sm[];  // x[Dp] | h1[G1] | h2[G2] | red[16] | cnt[4] | env[kBootMaxEnvs] | rew[kBootMaxEnvs]
+  float* x = sm;
+  float* h1 = x + Dp;
+  float* h2 = h1 + bt.G1;
+  float* red = h2 + bt.G2;
+  int* cnt = reinterpret_cast<int*>(red + 16);
+  int* lenv = cnt + 4;
+  float* lrew = reinterpret_cast<float*>(lenv + kBootMaxEnvs);
+  if (threadIdx.x == 0) *cnt = 0;
+  __syncthreads();
   const int per = Dp / 4;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * per) return;
-  const int n = i / per, c = i - n * per;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   const uint32_t step = step_rel + (step_base ? *step_base : 0u);  // device-resident base: graph replays advance it
-  const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, k0, k1);
-  const bool term = u32_to_unit_open(mr.x) < p_term;
-  const int len = ep_len_in[n] + 1;
-  const bool tr = (len >= time_limit) && !term;
-  const bool done = term || tr;
-  float z[4];
-  box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, k0, k1), z);
-  f32x4 o;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
-  if (tr) {
-    reinterpret_cast<f32x4*>(term_obs)[(size_t)n * per + c] = o;
-    box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, k0, k1), z);
+  if (i < N * per) {
+    const int n = i / per, c = i - n * per;
+    const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, k0, k1);
+    const bool term = u32_to_unit_open(mr.x) < p_term;
+    const int len = ep_len_in[n] + 1;
+    const bool tr = (len >= time_limit) && !term;
+    const bool done = term || tr;
+    float z[4];
+    box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, k0, k1), z);
+    f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
+    if (tr) {
+      reinterpret_cast<f32x4*>(term_obs)[(size_t)n * per + c] = o;
+      box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, k0, k1), z);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
+    }
+    reinterpret_cast<f32x4*>(obs_next)[(size_t)n * per + c] = o;
+    if (c == 0) {
+      float zz[4];
+      box_muller4(Philox4{mr.y, mr.z, mr.w, mr.x ^ 0x9E3779B9u}, zz);
+      const float rew = 0.03f + 0.1f * zz[0] + (term ? 5.0f : 0.f);
+      if (tr) {  // reward is written after the bootstrap below
+        const int q = atomicAdd(cnt, 1);
+        lenv[q] = n;
+        lrew[q] = rew;
+      } else {
+        rew_out[n] = rew;
+      }
+      es_out[n] = prev_dones[n];
+      next_dones[n] = done ? 1.f : 0.f;
+      trunc[n] = tr ? 1 : 0;
+      ep_len_out[n] = done ? 0 : len;
+    }
   }
-  reinterpret_cast<f32x4*>(obs_next)[(size_t)n * per + c] = o;
-  if (c == 0) {
-    float zz[4];
-    box_muller4(Philox4{mr.y, mr.z, mr.w, mr.x ^ 0x9E3779B9u}, zz);
-    rew_out[n] = 0.03f + 0.1f * zz[0] + (term ? 5.0f : 0.f);
-    es_out[n] = prev_dones[n];
-    next_dones[n] = done ? 1.f : 0.f;
-    trunc[n] = tr ? 1 : 0;
-    ep_len_out[n] = done ? 0 : len;
+  __syncthreads();
+  const int m = *cnt;
+  for (int q = 0; q < m; ++q) {  // block-uniform; order within the list does not matter (rows are independent)
+    const int n = lenv[q];
+    if ((int)threadIdx.x < per) {  // the terminal observation = this step's kStreamEnvObs draw of env n
+      const int c = threadIdx.x;
+      float z[4];
+      box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, k0, k1), z);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[4 * c + j] = (4 * c + j < D) ? z[j] : 0.f;
+    }
+    __syncthreads();
+    const float v = value_row_lds(x, h1, h2, red, bt.W1, bt.b1, bt.W2, bt.b2, bt.Wv, bt.bv, D, bt.G1, bt.G2);
+    if (threadIdx.x == 0) {
+      bt.term_val[n] = v;
+      rew_out[n] = (float)((double)lrew[q] + (double)__fmul_rn(bt.gamma, v));
+    }
+    __syncthreads();
   }
 }
 // ep_len update is a separate tiny kernel so that every chunk thread above sees the same old value

@@ -263,7 +263,9 @@ class PPOEngine:
                 "episode_starts": ((T, N), F32), "values": ((T, N), F32), "log_probs": ((T, N), F32),
                 "advantages": ((T, N), F32), "returns": ((T, N), F32), "params": ((self.P,), F32),
                 "grads": ((self.P,), F32), "advstat": ((self.n_minibatches, 4), np.float64),
-                "last_values": ((N,), F32), "last_dones": ((N,), F32), "clipped_actions": ((N, self.A), F32), "episode_start_state": ((N,), F32)}[name]
+                "last_values": ((N,), F32), "last_dones": ((N,), F32), "clipped_actions": ((N, self.A), F32), "episode_start_state": ((N,), F32),
+                "terminal_obs": ((N, 8 * ((self.D + 7) // 8)), F32), "terminal_values": ((N,), F32),
+                "truncated": ((N,), np.uint8)}[name]
 
     def read(self, name):
         shape, dt = self._buf_shape(name)

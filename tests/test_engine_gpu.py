@@ -231,6 +231,35 @@ def test_synthetic_collect_statistics_and_consistency():
     e.close()
 
 
+@pytest.mark.parametrize("H", [64, 256, 32])  # H=64 / H=256 fused families and the generic path
+def test_device_rollout_time_limit_bootstrap(H):
+    """Truncated rows of the device env source: reward += gamma * V(terminal_obs), computed inside the env-step launch
+    (SB3 collect_rollouts' TimeLimit.truncated branch; oracle bootstrap_reward)."""
+    D, A, N, T, TL = 26, 2, 96, 20, 10
+    p = O.init_params(D, A, (H, H), (H, H), seed=2)
+    p["value_net.bias"] = np.array([7.0], np.float32)  # makes the bootstrap term visible: gamma * V ~ 6.9
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=480, n_epochs=1, pi=(H, H), vf=(H, H), seed=9)
+    e.set_params(p)
+    e.collect_synthetic(p_term=0.0, time_limit=TL)  # no terminations: every env is truncated at steps 9 and 19
+    e.synchronize()
+    rew, es = e.read("rewards"), e.read("episode_starts")
+    assert np.all(es[TL] == 1.0) and np.all(es[1:TL] == 0.0)
+    tr = e.read("truncated")
+    assert np.all(tr == 1)  # latest step (t = 19) truncated everywhere
+    tobs = e.read("terminal_obs")[:, :D]
+    _, v = O.policy_outputs(p, tobs)
+    tv = e.read("terminal_values")
+    assert scaled_err(tv, v) < 1e-4
+    raw = rew[T - 1].astype(np.float64) - np.float64(np.float32(0.99) * tv)
+    assert np.all(np.abs(raw - 0.03) < 0.6) and abs(raw.mean() - 0.03) < 0.05  # what is left is the N(0.03, 0.1^2) draw
+    plain = np.delete(rew, [TL - 1, T - 1], axis=0)
+    assert np.all(np.abs(plain - 0.03) < 0.6)
+    assert np.all(rew[TL - 1] > 5.0) and np.all(rew[T - 1] > 5.0)
+    # terminal observations are not the stored next observations (those are the reset draws)
+    assert not np.allclose(e.read("obs")[T][:, :D], tobs)
+    e.close()
+
+
 def test_error_paths():
     from mobrob_amd.engine import PPOEngine
     with pytest.raises(ValueError):
