@@ -149,6 +149,36 @@ int mobrob_ppo_finish_rollout(mobrob_ppo_engine_t* e, const float* last_obs, con
  * truncation at time_limit with a terminal observation.  State persists across calls. */
 int mobrob_ppo_collect_synthetic(mobrob_ppo_engine_t* e, float p_term, int32_t time_limit);
 
+/* Device-resident GOAL environment: the reference's env-side rules evaluated on the GPU inside the rollout
+ * loop -- reward_fn (src/mobrob/envs/wrapper.py:137-154, drone bonus :491-496), step/terminate_on_goal
+ * (:156-171), lazy reset + new goal (:173-201), reached (:203-207), TimeLimit truncation as get_env wraps it
+ * (:549-571), VecEnv auto-reset with terminal observation and the time-limit bootstrap.  The robot itself is
+ * the kinematic stand-in of mobrob_amd/envs/wrapper.py (the reference's MuJoCo / Bullet physics is out of
+ * scope): vel <- 0.8 vel + 0.2 mix.clip(a); pos <- clip(pos + dt vel, +-extent); observation =
+ * [unit vector to the goal, vel, pos, N(0, obs_noise^2) padding].  init_space = +-extent/2, goal_space =
+ * +-extent.  State persists across calls; switching between env kinds restarts the environments. */
+typedef struct mobrob_goal_env {
+  int32_t pos_dim;            /* 1..3, 3*pos_dim <= obs_dim                                              */
+  int32_t terminate_on_goal;  /* PPOCtrl passes True (ppo.py:37-48)                                      */
+  int32_t time_limit;         /* max_episode_steps                                                       */
+  float dt, extent;
+  float reach_radius;         /* 0.3 in the reference                                                    */
+  float goal_bonus;           /* +5 on reach                                                             */
+  float extra_bonus;          /* +10 more for the drone                                                  */
+  float obs_noise;            /* std of the padding features                                             */
+  float mix[3][32];           /* [pos_dim][act_dim] action -> velocity command read-out                  */
+} mobrob_goal_env_t;
+int mobrob_ppo_collect_goal_env(mobrob_ppo_engine_t* e, const mobrob_goal_env_t* env);
+
+/* Monitor-style statistics of the episodes the goal environment finished since the last reset of the
+ * counters (SB3's rollout/ep_rew_mean, ep_len_mean).  Waits for the engine's stream. */
+typedef struct mobrob_episode_stats {
+  int64_t episodes;
+  double return_sum, length_sum;
+  int64_t goals;              /* episodes that ended inside the reach radius */
+} mobrob_episode_stats_t;
+int mobrob_ppo_episode_stats(mobrob_ppo_engine_t* e, mobrob_episode_stats_t* out, int32_t reset);
+
 /* ---- update: PPO.train (SB3 ppo/ppo.py) ----------------------------------------------------- */
 
 typedef struct mobrob_ppo_train_stats {

@@ -34,6 +34,16 @@ class Config(C.Structure):
     ]
 
 
+class GoalEnv(C.Structure):  # mobrob_goal_env_t
+    _fields_ = [("pos_dim", C.c_int32), ("terminate_on_goal", C.c_int32), ("time_limit", C.c_int32),
+                ("dt", C.c_float), ("extent", C.c_float), ("reach_radius", C.c_float), ("goal_bonus", C.c_float),
+                ("extra_bonus", C.c_float), ("obs_noise", C.c_float), ("mix", (C.c_float * 32) * 3)]
+
+
+class EpisodeStats(C.Structure):  # mobrob_episode_stats_t
+    _fields_ = [("episodes", C.c_int64), ("return_sum", C.c_double), ("length_sum", C.c_double), ("goals", C.c_int64)]
+
+
 class TrainStats(C.Structure):
     _fields_ = [(k, C.c_float) for k in
                 ("policy_loss", "value_loss", "entropy_loss", "loss", "approx_kl", "clip_fraction", "grad_norm")] + \
@@ -66,6 +76,8 @@ SYMBOLS = {
     "mobrob_ppo_store": (C.c_int, [_P, _F, _U8, _U8, _F]),
     "mobrob_ppo_finish_rollout": (C.c_int, [_P, _F, _U8]),
     "mobrob_ppo_collect_synthetic": (C.c_int, [_P, C.c_float, C.c_int32]),
+    "mobrob_ppo_collect_goal_env": (C.c_int, [_P, C.POINTER(GoalEnv)]),
+    "mobrob_ppo_episode_stats": (C.c_int, [_P, C.POINTER(EpisodeStats), C.c_int32]),
     "mobrob_ppo_train": (C.c_int, [_P, _I64, C.POINTER(TrainStats)]),
     "mobrob_ppo_train_enqueue": (C.c_int, [_P, _I64]),
     "mobrob_ppo_epoch_begin": (C.c_int, [_P, _I64]),

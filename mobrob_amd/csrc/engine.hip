@@ -15,6 +15,7 @@
 #include "kernels_generic.h"
 #include "kernels_fused.h"
 #include "fused_dispatch.h"
+#include "kernels_env.h"
 
 using namespace mobrob;
 
@@ -84,9 +85,15 @@ struct mobrob_ppo_engine {
   uint32_t* ctr_dev = nullptr;  // [0] eps draw base, [1] env step base (device-resident: graph replays advance them)
   hipGraph_t ro_graph = nullptr;
   hipGraphExec_t ro_exec = nullptr;
-  float ro_p_term = -1.f;
-  int ro_time_limit = -1;
-  bool env_started = false;
+  struct RolloutSpec {  // what the captured rollout graph was built for
+    int kind = 0;       // 0 none, 1 synthetic source, 2 goal environment
+    float p_term = 0.f;
+    int time_limit = 0;
+    GoalEnvParams goal{};
+  } ro_spec;
+  int env_started = 0;  // env kind whose state is live on the device (0 = none)
+  float* gstate[2] = {nullptr, nullptr};  // goal env state, double buffered [N][kGoalStateFloats]
+  double* ep_stats = nullptr;             // [4] episode statistics of the goal env
   uint32_t draw_counter = 0;  // Philox draw index for eps
   uint32_t env_step_counter = 0;
   int t = 0;
@@ -552,6 +559,8 @@ int engine_alloc(mobrob_ppo_engine* e) {
   CHK(dalloc(e, &e->dz2p, Bl * e->H2)); CHK(dalloc(e, &e->dz1p, Bl * e->H1));
   CHK(dalloc(e, &e->dz2v, Bl * e->G2)); CHK(dalloc(e, &e->dz1v, Bl * e->G1));
   CHK(dalloc(e, &e->pred_obs, R * Dp)); CHK(dalloc(e, &e->pred_act, R * A));
+  CHK(dalloc(e, &e->gstate[0], N * kGoalStateFloats)); CHK(dalloc(e, &e->gstate[1], N * kGoalStateFloats));
+  CHK(dalloc(e, &e->ep_stats, 4));
   CHK(dalloc(e, &e->chunks_dev, e->chunk_table.size()));
   CHK(dalloc(e, &e->chunk_partial, e->chunk_table.size()));
   CHK(fused_init(e));
@@ -838,26 +847,43 @@ int mobrob_ppo_mark_rollout_ready(mobrob_ppo_engine_t* e) {
 
 namespace {
 // enqueue one whole device-resident rollout (T steps + last values + GAE) on the engine stream
-int enqueue_rollout(mobrob_ppo_engine* e, float p_term, int time_limit) {
+uint64_t env_seed_of(const mobrob_ppo_engine* e) {
+  return e->cfg.seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(e->cfg.rank + 1));
+}
+
+int enqueue_rollout(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& sp) {
   const int N = e->N, Dp = e->Dp, per = Dp / 4;
   const size_t slot = (size_t)N * Dp;
-  const uint64_t env_seed = e->cfg.seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(e->cfg.rank + 1));
+  const uint64_t env_seed = env_seed_of(e);
   // the previous rollout's last observation is this rollout's first
   HIPC(hipMemcpyAsync(e->obs, e->obs + (size_t)e->T * slot, slot * 4, hipMemcpyDeviceToDevice, e->stream));
   BootArgs bt{Pp(e, T_VW1), Pp(e, T_VB1), Pp(e, T_VW2), Pp(e, T_VB2), Pp(e, T_VW), Pp(e, T_VB), e->G1, e->G2,
               (float)e->cfg.gamma, e->term_val};
+  const size_t sm = env_step_lds_bytes(Dp, e->G1, e->G2);
   for (int t = 0; t < e->T; ++t) {
     act_slot(e, t, nullptr, true);
     {
       ProfScope ps(e, MOBROB_K_ENV);
-      // env draw + rollout_buffer.add scalars + time-limit bootstrap of the (rare) truncated rows in one launch
-      hipLaunchKernelGGL(k_env_step_store, dim3(cdiv(N * per, 256)), dim3(256), env_step_lds_bytes(Dp, e->G1, e->G2),
-                         e->stream, env_seed, (uint32_t)t, e->ctr_dev + 1, N, e->D, Dp, p_term, time_limit, e->ep_len,
-                         e->ep_len2, e->obs + (size_t)(t + 1) * slot, e->term_obs, e->prev_dones, e->dones_tmp,
-                         e->trunc_dev, e->rewards + (size_t)t * N, e->es + (size_t)t * N, bt);
+      // env step + rollout_buffer.add scalars + time-limit bootstrap of the (rare) truncated rows in one launch
+      if (sp.kind == 1) {
+        hipLaunchKernelGGL(k_env_step_store, dim3(cdiv(N * per, 256)), dim3(256), sm, e->stream, env_seed, (uint32_t)t,
+                           e->ctr_dev + 1, N, e->D, Dp, sp.p_term, sp.time_limit, e->ep_len, e->ep_len2,
+                           e->obs + (size_t)(t + 1) * slot, e->term_obs, e->prev_dones, e->dones_tmp, e->trunc_dev,
+                           e->rewards + (size_t)t * N, e->es + (size_t)t * N, bt);
+        std::swap(e->ep_len, e->ep_len2);
+      } else {
+        GoalEnvArgs g{};
+        g.seed = env_seed; g.step_rel = (uint32_t)t; g.step_base = e->ctr_dev + 1;
+        g.N = N; g.D = e->D; g.Dp = Dp; g.A = e->A; g.p = sp.goal;
+        g.act = e->clip_act; g.st_in = e->gstate[0]; g.st_out = e->gstate[1];
+        g.obs_next = e->obs + (size_t)(t + 1) * slot; g.term_obs = e->term_obs;
+        g.prev_dones = e->prev_dones; g.next_dones = e->dones_tmp; g.trunc = e->trunc_dev;
+        g.rew_out = e->rewards + (size_t)t * N; g.es_out = e->es + (size_t)t * N; g.ep_stats = e->ep_stats;
+        hipLaunchKernelGGL(k_goal_env_step_store, dim3(cdiv(N * per, 256)), dim3(256), sm, e->stream, g, bt);
+        std::swap(e->gstate[0], e->gstate[1]);
+      }
     }
     std::swap(e->prev_dones, e->dones_tmp);
-    std::swap(e->ep_len, e->ep_len2);
   }
   hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, e->stream, e->ctr_dev, (uint32_t)e->T, (uint32_t)e->T);
   HIPC(hipMemcpyAsync(e->last_dones, e->prev_dones, (size_t)N * 4, hipMemcpyDeviceToDevice, e->stream));
@@ -865,27 +891,34 @@ int enqueue_rollout(mobrob_ppo_engine* e, float p_term, int time_limit) {
   run_gae(e);
   return MOBROB_OK;
 }
-}  // namespace
 
-int mobrob_ppo_collect_synthetic(mobrob_ppo_engine_t* e, float p_term, int32_t time_limit) {
-  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+// device-resident rollout of either env kind: (re)start the env if needed, then replay / enqueue the T-step loop
+int collect_device(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& sp) {
   const int N = e->N, Dp = e->Dp, per = Dp / 4;
   const size_t slot = (size_t)N * Dp;
-  if (!e->env_started) {
-    const uint64_t env_seed = e->cfg.seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(e->cfg.rank + 1));
+  if (e->env_started != sp.kind) {
     float* last = e->obs + (size_t)e->T * slot;  // reset writes the "previous last observation"
-    hipLaunchKernelGGL(k_env_reset, dim3(cdiv(N * per, 256)), dim3(256), 0, e->stream, env_seed, N, e->D, Dp, last,
-                       e->ep_len);
-    e->env_started = true;
+    if (sp.kind == 1) {
+      hipLaunchKernelGGL(k_env_reset, dim3(cdiv(N * per, 256)), dim3(256), 0, e->stream, env_seed_of(e), N, e->D, Dp, last,
+                         e->ep_len);
+    } else {
+      hipLaunchKernelGGL(k_goal_env_reset, dim3(cdiv(N * per, 256)), dim3(256), 0, e->stream, env_seed_of(e), N, e->D, Dp,
+                         sp.goal, e->gstate[0], last);
+      HIPC(hipMemsetAsync(e->ep_stats, 0, 4 * sizeof(double), e->stream));
+    }
+    std::vector<float> ones(N, 1.0f);  // a fresh env starts every episode: `_last_episode_starts` all True
+    HIPC(hipMemcpyAsync(e->prev_dones, ones.data(), (size_t)N * 4, hipMemcpyHostToDevice, e->stream));
+    HIPC(hipStreamSynchronize(e->stream));
+    e->env_started = sp.kind;
   }
   e->rollout_ready = false;
   // Graph replay: every kernel argument of the T-step loop is fixed (slot pointers, ping-pong buffers with even T,
   // counters relative to device-resident bases), so the loop is captured once and replayed per rollout.
   const bool use_graph = e->cfg.rollout_graph && (e->T % 2 == 0);
   if (!use_graph) {
-    CHK(enqueue_rollout(e, p_term, time_limit));
+    CHK(enqueue_rollout(e, sp));
   } else {
-    if (e->ro_exec == nullptr || e->ro_p_term != p_term || e->ro_time_limit != time_limit) {
+    if (e->ro_exec == nullptr || memcmp(&e->ro_spec, &sp, sizeof sp) != 0) {
       if (e->ro_exec) { (void)hipGraphExecDestroy(e->ro_exec); e->ro_exec = nullptr; }
       if (e->ro_graph) { (void)hipGraphDestroy(e->ro_graph); e->ro_graph = nullptr; }
       const bool prof = e->prof_on;
@@ -895,20 +928,19 @@ int mobrob_ppo_collect_synthetic(mobrob_ppo_engine_t* e, float p_term, int32_t t
         (void)hipGetLastError();
         e->prof_on = prof;
         e->cfg.rollout_graph = 0;
-        CHK(enqueue_rollout(e, p_term, time_limit));
+        CHK(enqueue_rollout(e, sp));
         HIPC(hipGetLastError());
         e->t = e->T;
         e->rollout_ready = true;
         return MOBROB_OK;
       }
-      const int rc = enqueue_rollout(e, p_term, time_limit);
+      const int rc = enqueue_rollout(e, sp);
       hipError_t ce = hipStreamEndCapture(e->stream, &e->ro_graph);
       e->prof_on = prof;
       if (rc != MOBROB_OK) return rc;
       if (ce != hipSuccess) return fail(MOBROB_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
       HIPC(hipGraphInstantiate(&e->ro_exec, e->ro_graph, nullptr, nullptr, 0));
-      e->ro_p_term = p_term;
-      e->ro_time_limit = time_limit;
+      memcpy(&e->ro_spec, &sp, sizeof sp);
     }
     ProfScope ps(e, MOBROB_K_ACT);  // with graph replay the ACT scope covers the whole rollout (forward+env+GAE)
     HIPC(hipGraphLaunch(e->ro_exec, e->stream));
@@ -916,6 +948,43 @@ int mobrob_ppo_collect_synthetic(mobrob_ppo_engine_t* e, float p_term, int32_t t
   HIPC(hipGetLastError());
   e->t = e->T;
   e->rollout_ready = true;
+  return MOBROB_OK;
+}
+}  // namespace
+
+int mobrob_ppo_collect_synthetic(mobrob_ppo_engine_t* e, float p_term, int32_t time_limit) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  mobrob_ppo_engine::RolloutSpec sp;
+  memset(&sp, 0, sizeof sp);  // padding bytes too: specs are compared with memcmp
+  sp.kind = 1; sp.p_term = p_term; sp.time_limit = time_limit;
+  return collect_device(e, sp);
+}
+
+int mobrob_ppo_collect_goal_env(mobrob_ppo_engine_t* e, const mobrob_goal_env_t* env) {
+  if (!e || !env) return fail(MOBROB_ERR_INVALID, "null argument");
+  if (env->pos_dim < 1 || env->pos_dim > 3 || 3 * env->pos_dim > e->D)
+    return fail(MOBROB_ERR_INVALID, "goal env: pos_dim must be 1..3 and 3*pos_dim <= obs_dim");
+  if (e->A > 32) return fail(MOBROB_ERR_INVALID, "goal env: act_dim must be <= 32");
+  if (env->time_limit < 1) return fail(MOBROB_ERR_INVALID, "goal env: time_limit must be >= 1");
+  mobrob_ppo_engine::RolloutSpec sp;
+  memset(&sp, 0, sizeof sp);
+  sp.kind = 2; sp.time_limit = env->time_limit;
+  GoalEnvParams& g = sp.goal;
+  g.P = env->pos_dim; g.terminate_on_goal = env->terminate_on_goal != 0; g.time_limit = env->time_limit;
+  g.dt = env->dt; g.extent = env->extent; g.reach = env->reach_radius; g.bonus = env->goal_bonus;
+  g.extra_bonus = env->extra_bonus; g.noise = env->obs_noise;
+  for (int j = 0; j < 3; ++j)
+    for (int k = 0; k < 32; ++k) g.mix[j][k] = (j < env->pos_dim && k < e->A) ? env->mix[j][k] : 0.f;
+  return collect_device(e, sp);
+}
+
+int mobrob_ppo_episode_stats(mobrob_ppo_engine_t* e, mobrob_episode_stats_t* out, int32_t reset) {
+  if (!e || !out) return fail(MOBROB_ERR_INVALID, "null argument");
+  double h[4];
+  HIPC(hipMemcpyAsync(h, e->ep_stats, sizeof h, hipMemcpyDeviceToHost, e->stream));
+  if (reset) HIPC(hipMemsetAsync(e->ep_stats, 0, sizeof h, e->stream));
+  HIPC(hipStreamSynchronize(e->stream));
+  out->episodes = (int64_t)h[0]; out->return_sum = h[1]; out->length_sum = h[2]; out->goals = (int64_t)h[3];
   return MOBROB_OK;
 }
 

@@ -1094,6 +1094,48 @@ __device__ __forceinline__ void gemm_lds_packed_r32(int a_off, const f32x4* __re
   MFMA_KG1(uB, pB, qB)
 }
 
+// Deep-pipelined 32-row variant for K = 256 (nkg % 4 == 0, nkg >= 8): one k-group is only 8 MFMAs (~0.2 us), far
+// less than the L2 latency of the weight stream, so fragments are fetched three k-groups ahead (4-deep ring).
+template <int LDA>
+__device__ __forceinline__ void gemm_lds_packed_r32_deep(int a_off, const f32x4* __restrict__ Bp0,
+                                                         const f32x4* __restrict__ Bp1, int nkg, f32x16& c0,
+                                                         f32x16& c1, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int ab = 4 * opaque((a_off + r * LDA + 4 * h) >> 2);
+  unsigned bo = opaque_u((unsigned)lane * 16u);
+  f32x4 p0 = ldg16(Bp0, bo), q0 = ldg16(Bp1, bo);
+  f32x4 p1 = ldg16(Bp0, bo + 1024u), q1 = ldg16(Bp1, bo + 1024u);
+  f32x4 p2 = ldg16(Bp0, bo + 2048u), q2 = ldg16(Bp1, bo + 2048u);
+  f32x4 p3, q3;
+  f32x4 uA = *reinterpret_cast<const f32x4*>(&lds[ab]), uB;
+  int ao = ab;
+#pragma unroll 1
+  for (int kg = 0; kg < nkg - 4; kg += 4) {
+    p3 = ldg16(Bp0, bo + 3072u); q3 = ldg16(Bp1, bo + 3072u);
+    uB = *reinterpret_cast<const f32x4*>(&lds[ao + 8]);
+    MFMA_KG1(uA, p0, q0)
+    p0 = ldg16(Bp0, bo + 4096u); q0 = ldg16(Bp1, bo + 4096u);
+    uA = *reinterpret_cast<const f32x4*>(&lds[ao + 16]);
+    MFMA_KG1(uB, p1, q1)
+    p1 = ldg16(Bp0, bo + 5120u); q1 = ldg16(Bp1, bo + 5120u);
+    uB = *reinterpret_cast<const f32x4*>(&lds[ao + 24]);
+    MFMA_KG1(uA, p2, q2)
+    p2 = ldg16(Bp0, bo + 6144u); q2 = ldg16(Bp1, bo + 6144u);
+    uA = *reinterpret_cast<const f32x4*>(&lds[ao + 32]);
+    MFMA_KG1(uB, p3, q3)
+    bo += 4096u;
+    ao += 32;
+  }
+  p3 = ldg16(Bp0, bo + 3072u); q3 = ldg16(Bp1, bo + 3072u);
+  uB = *reinterpret_cast<const f32x4*>(&lds[ao + 8]);
+  MFMA_KG1(uA, p0, q0)
+  uA = *reinterpret_cast<const f32x4*>(&lds[ao + 16]);
+  MFMA_KG1(uB, p1, q1)
+  uB = *reinterpret_cast<const f32x4*>(&lds[ao + 24]);
+  MFMA_KG1(uA, p2, q2)
+  MFMA_KG1(uB, p3, q3)
+}
+
 // LDS carve-up of the 32-row rollout kernel
 template <int DP>
 struct Lay32 {
@@ -1142,8 +1184,8 @@ __global__ __launch_bounds__(FTHREADS, 2) void k_fused_act(FusedActArgs a) {
   {  // layer 2
     f32x16 c0 = splat16(W.b2s[64 * wave + r]), c1 = splat16(W.b2s[64 * wave + 32 + r]);
     constexpr int nkg = FH / 8;
-    gemm_lds_packed_r32<FLDH>(L::H1, W.W2f + (size_t)(2 * wave) * nkg * 64, W.W2f + (size_t)(2 * wave + 1) * nkg * 64,
-                              nkg, c0, c1, lane);
+    gemm_lds_packed_r32_deep<FLDH>(L::H1, W.W2f + (size_t)(2 * wave) * nkg * 64,
+                                   W.W2f + (size_t)(2 * wave + 1) * nkg * 64, nkg, c0, c1, lane);
     const int o = opaque(L::H2 + 4 * h * FLDH + 64 * wave + r);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {

@@ -7,7 +7,7 @@ from collections import OrderedDict
 import numpy as np
 
 from . import _lib
-from ._lib import BUF, Config, TrainStats, check
+from ._lib import BUF, Config, EpisodeStats, GoalEnv, TrainStats, check
 
 F32 = np.float32
 STAT_KEYS = ("policy_loss", "value_loss", "entropy_loss", "loss", "approx_kl", "clip_fraction", "grad_norm")
@@ -190,6 +190,30 @@ class PPOEngine:
 
     def collect_synthetic(self, p_term=1.0 / 107.0, time_limit=1000):
         check(self.lib.mobrob_ppo_collect_synthetic(self._h, float(p_term), int(time_limit)))
+
+    def collect_goal_env(self, pos_dim, mix, time_limit, terminate_on_goal=True, dt=0.05, extent=3.0, reach_radius=0.3,
+                         goal_bonus=5.0, extra_bonus=0.0, obs_noise=0.1):
+        """Whole rollout + GAE against the device-resident goal environment (mobrob_ppo_collect_goal_env).
+        mix: [pos_dim, act_dim] action -> velocity command read-out."""
+        g = GoalEnv()
+        g.pos_dim, g.terminate_on_goal, g.time_limit = int(pos_dim), int(bool(terminate_on_goal)), int(time_limit)
+        g.dt, g.extent, g.reach_radius = float(dt), float(extent), float(reach_radius)
+        g.goal_bonus, g.extra_bonus, g.obs_noise = float(goal_bonus), float(extra_bonus), float(obs_noise)
+        mix = np.asarray(mix, F32)
+        if mix.shape != (int(pos_dim), self.A):
+            raise ValueError(f"mix must be [{int(pos_dim)}, {self.A}], got {mix.shape}")
+        for j in range(mix.shape[0]):
+            for k in range(mix.shape[1]):
+                g.mix[j][k] = float(mix[j, k])
+        check(self.lib.mobrob_ppo_collect_goal_env(self._h, C.byref(g)))
+
+    def episode_stats(self, reset=True):
+        """Episodes finished by the goal environment since the counters were last reset."""
+        st = EpisodeStats()
+        check(self.lib.mobrob_ppo_episode_stats(self._h, C.byref(st), int(bool(reset))))
+        n = int(st.episodes)
+        return {"episodes": n, "goals": int(st.goals), "ep_rew_mean": st.return_sum / n if n else float("nan"),
+                "ep_len_mean": st.length_sum / n if n else float("nan")}
 
     def compute_gae(self):
         check(self.lib.mobrob_ppo_compute_gae(self._h))

@@ -12,6 +12,8 @@ Three sources:
                          between processes are gone; thousands of light envs step in one address space)
   * SyntheticVecEnv      host NumPy statistical env source with the VecEnv contract (no simulator needed)
   * DeviceSyntheticVecEnv  marker: the engine's device-resident synthetic source (no host round trip at all)
+  * DeviceGoalVecEnv     marker: the goal-reaching task of envs/wrapper.py stepped on the GPU (reward, termination,
+                         lazy reset, time limit of the reference's EnvWrapper evaluated inside the rollout loop)
 """
 from __future__ import annotations
 
@@ -19,7 +21,7 @@ import time
 
 import numpy as np
 
-from .wrapper import MEAN_EPISODE_LEN, ROBOT_DIMS
+from .wrapper import MEAN_EPISODE_LEN, ROBOT_DIMS, KinematicSim
 
 
 class VecEnvBase:
@@ -163,6 +165,38 @@ class DeviceSyntheticVecEnv(VecEnvBase):
 
     def reset(self):
         raise RuntimeError("DeviceSyntheticVecEnv lives on the GPU; it is stepped by the engine, not from the host")
+
+    step = reset
+
+
+class DeviceGoalVecEnv(VecEnvBase):
+    """The goal-reaching task of `KinematicGoalEnv` (same kinematics, reward, termination, lazy reset and time
+    limit as the host classes in envs/wrapper.py) stepped entirely on the GPU by
+    mobrob_ppo_collect_goal_env -- the device counterpart of make_vec_env(get_env, ...) for learner-bound runs."""
+
+    def __init__(self, n_envs, obs_dim, act_dim, pos_dim, time_limit=1000, terminate_on_goal=True, extra_bonus=0.0,
+                 seed=0):
+        self.num_envs, self.obs_dim, self.act_dim, self.pos_dim = int(n_envs), int(obs_dim), int(act_dim), int(pos_dim)
+        self.time_limit, self.terminate_on_goal, self.extra_bonus, self._seed = int(time_limit), bool(terminate_on_goal), float(extra_bonus), seed
+        sim = KinematicSim(obs_dim, act_dim, pos_dim)  # same action read-out and constants as the host stand-in
+        self.mix, self.dt, self.extent = sim._mix.astype(np.float32), sim.dt, sim.extent
+
+    @classmethod
+    def for_robot(cls, env_name, n_envs, time_limit=1000, seed=0, terminate_on_goal=True):
+        if env_name not in ROBOT_DIMS:
+            raise ValueError(f"Env {env_name} not found")
+        d, a, p = ROBOT_DIMS[env_name]
+        return cls(n_envs, d, a, p, time_limit, terminate_on_goal, 10.0 if env_name == "drone" else 0.0, seed)
+
+    def collect(self, engine):
+        engine.collect_goal_env(self.pos_dim, self.mix, self.time_limit, self.terminate_on_goal, dt=self.dt,
+                                extent=self.extent, extra_bonus=self.extra_bonus)
+
+    def seed(self, seed=None):
+        self._seed = seed
+
+    def reset(self):
+        raise RuntimeError("DeviceGoalVecEnv lives on the GPU; it is stepped by the engine, not from the host")
 
     step = reset
 

@@ -22,7 +22,7 @@ import numpy as np
 
 from ..checkpoint import load_zip, save_zip
 from ..engine import PPOEngine
-from ..envs.vec_env import DeviceSyntheticVecEnv, HostVecEnv, SyntheticVecEnv, make_vec_env
+from ..envs.vec_env import DeviceGoalVecEnv, DeviceSyntheticVecEnv, HostVecEnv, SyntheticVecEnv, make_vec_env
 from ..envs.wrapper import get_env
 from ..utils import DATA_DIR
 from .init import orthogonal_policy_init
@@ -249,8 +249,16 @@ class PPO:
     def _collect_rollouts(self, callback) -> bool:
         e, env, N = self.engine, self.env, self.n_envs
         callback.on_rollout_start()
-        if isinstance(env, DeviceSyntheticVecEnv):
-            e.collect_synthetic(env.p_term, env.time_limit)
+        if isinstance(env, (DeviceSyntheticVecEnv, DeviceGoalVecEnv)):
+            if isinstance(env, DeviceGoalVecEnv):
+                env.collect(e)
+                st = e.episode_stats(reset=True)  # Monitor statistics of the episodes this rollout finished
+                self.device_episode_stats = st
+                if st["episodes"] > 0:  # the info buffer holds the rollout's means (per-episode values stay on the GPU)
+                    self.ep_info_buffer.extend([{"r": st["ep_rew_mean"], "l": st["ep_len_mean"], "t": 0.0}]
+                                               * min(st["episodes"], self.ep_info_buffer.maxlen or 100))
+            else:
+                e.collect_synthetic(env.p_term, env.time_limit)
             for _ in range(self.n_steps):
                 self.num_timesteps += N
                 if not callback.on_step():
@@ -296,7 +304,7 @@ class PPO:
         else:
             total_timesteps += self.num_timesteps
         self._total_timesteps, self._num_timesteps_at_start = total_timesteps, self.num_timesteps
-        host_env = not isinstance(self.env, DeviceSyntheticVecEnv)
+        host_env = not isinstance(self.env, (DeviceSyntheticVecEnv, DeviceGoalVecEnv))
         if host_env and (reset_num_timesteps or self._last_obs is None):
             self._last_obs = self.env.reset()
             self._last_episode_starts = np.ones(self.n_envs, bool)
@@ -421,7 +429,8 @@ class PPOCtrl:
     """Same constructor, `from_config`, `learn`, `save_model` and `.ppo` attribute as the reference class
     (src/mobrob/rl_control/ppo.py:14-77).  `vec_env_type` accepts the reference values "subproc" and "dummy"
     (ValueError otherwise, ppo.py:35) -- both run the in-process batched VecEnv -- plus two build extensions:
-    "synthetic" (host NumPy env source) and "device" (device-resident synthetic source)."""
+    "synthetic" (host NumPy env source), "device" (device-resident synthetic source) and "device_goal" (the
+    goal-reaching task of envs/wrapper.py stepped on the GPU)."""
 
     def __init__(self, ppo_kwargs: dict, env_name: str, time_limit: int, n_env: int, vec_env_type: str = "dummy",
                  enable_gui: bool = False, seed: int = 0) -> None:
@@ -438,6 +447,8 @@ class PPOCtrl:
             vec_env = SyntheticVecEnv.for_robot(env_name, n_env, time_limit, seed)
         elif vec_env_type == "device":
             vec_env = DeviceSyntheticVecEnv.for_robot(env_name, n_env, time_limit, seed)
+        elif vec_env_type == "device_goal":
+            vec_env = DeviceGoalVecEnv.for_robot(env_name, n_env, time_limit, seed, terminate_on_goal=True)
         else:
             raise ValueError(f"Unknown vec_env_type: {vec_env_type}")
         self.ppo = PPO(env=vec_env, seed=seed,
