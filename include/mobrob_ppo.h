@@ -76,7 +76,8 @@ typedef struct mobrob_ppo_config {
   int32_t rank, world_size;   /* data-parallel position; batch_size is split batch_size/world    */
   int32_t fast_kernels;       /* 1: use the fused MFMA kernels when the shape allows; 0: generic */
   int32_t rollout_graph;      /* 1: replay the device-resident rollout as one captured hipGraph  */
-  int32_t reserved[6];
+  int32_t rollout_persistent; /* 1: run the device-resident rollout as one persistent kernel (fused widths) */
+  int32_t reserved[5];
 } mobrob_ppo_config_t;
 
 /* Fill `cfg` with SB3 2.0.0 defaults (Appendix A.1).  Replaces PPO.__init__'s default kwargs. */
@@ -235,7 +236,8 @@ enum {
   MOBROB_BUF_TERMINAL_OBS = 15,    /* f32 [N][Dp] terminal observations of the rows truncated in the latest step */
   MOBROB_BUF_TERMINAL_VALUES = 16, /* f32 [N] V(terminal_obs) of those rows (time-limit bootstrap)              */
   MOBROB_BUF_TRUNCATED = 17,       /* u8  [N] TimeLimit.truncated flags of the latest step                       */
-  MOBROB_BUF_COUNT = 18
+  MOBROB_BUF_ENV_STATE = 18,       /* f32 [N][12] goal-env state: pos[3] vel[3] goal[3] return length pad         */
+  MOBROB_BUF_COUNT = 19
 };
 int mobrob_ppo_buffer_info(mobrob_ppo_engine_t* e, int32_t which, void** ptr_dev, size_t* bytes);
 /* copy with host layout [..][D] <-> device layout [..][Dp] handled for MOBROB_BUF_OBS */

@@ -16,7 +16,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
 BUF = dict(obs=0, actions=1, rewards=2, episode_starts=3, values=4, log_probs=5, advantages=6, returns=7,
            params=8, grads=9, advstat=10, last_values=11, last_dones=12, clipped_actions=13, episode_start_state=14,
-           terminal_obs=15, terminal_values=16, truncated=17)
+           terminal_obs=15, terminal_values=16, truncated=17, env_state=18)
 KERNEL_IDS = dict(act=0, gae=1, train_grad=2, apply=3, env=4, grad_reduce=5)
 
 
@@ -30,7 +30,8 @@ class Config(C.Structure):
         ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
         ("action_low", C.c_double), ("action_high", C.c_double),
         ("normalize_advantage", C.c_int32), ("seed", C.c_uint64), ("device_id", C.c_int32),
-        ("rank", C.c_int32), ("world_size", C.c_int32), ("fast_kernels", C.c_int32), ("rollout_graph", C.c_int32), ("reserved", C.c_int32 * 6),
+        ("rank", C.c_int32), ("world_size", C.c_int32), ("fast_kernels", C.c_int32), ("rollout_graph", C.c_int32), ("rollout_persistent", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 

@@ -70,7 +70,8 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t 
   return Philox4{c0, c1, c2, c3};
 }
 __device__ __forceinline__ float u32_to_unit_open(uint32_t x) {  // (0,1)
-  return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  // explicit roundings: every kernel must map a draw to the same float (no context-dependent fma contraction)
+  return __fmul_rn(__fadd_rn((float)(x >> 8), 0.5f), 1.0f / 16777216.0f);
 }
 // 4 uniforms -> 4 standard normals (Box-Muller)
 __device__ __forceinline__ void box_muller4(const Philox4& r, float out[4]) {

@@ -16,6 +16,7 @@
 #include "kernels_fused.h"
 #include "fused_dispatch.h"
 #include "kernels_env.h"
+#include "kernels_rollout.h"
 
 using namespace mobrob;
 
@@ -496,6 +497,7 @@ void mobrob_ppo_default_config(mobrob_ppo_config_t* c) {
   c->action_low = -1.0; c->action_high = 1.0;
   c->normalize_advantage = 1; c->seed = 0; c->device_id = 0; c->rank = 0; c->world_size = 1; c->fast_kernels = 1;
   c->rollout_graph = 1;
+  c->rollout_persistent = 1;
 }
 
 void* mobrob_ppo_host_alloc(size_t bytes) {
@@ -543,9 +545,10 @@ int engine_alloc(mobrob_ppo_engine* e) {
   CHK(dalloc(e, &e->pW1p, (size_t)e->H1 * Dp)); CHK(dalloc(e, &e->vW1p, (size_t)e->G1 * Dp));
   CHK(dalloc(e, &e->aWp, (size_t)e->Ap * e->H2)); CHK(dalloc(e, &e->vWp, (size_t)8 * e->G2));
   CHK(dalloc(e, &e->obs, (T + 1) * N * Dp)); CHK(dalloc(e, &e->actions, T * N * A));
-  CHK(dalloc(e, &e->rewards, T * N)); CHK(dalloc(e, &e->es, T * N)); CHK(dalloc(e, &e->values, T * N));
+  CHK(dalloc(e, &e->rewards, T * N)); CHK(dalloc(e, &e->es, T * N)); CHK(dalloc(e, &e->values, (T + 1) * N));
+  e->last_values = e->values + T * N;  // V(last_obs) sits behind the stored values: one batched pass covers both
   CHK(dalloc(e, &e->logp, T * N)); CHK(dalloc(e, &e->adv, T * N)); CHK(dalloc(e, &e->ret, T * N));
-  CHK(dalloc(e, &e->last_values, N)); CHK(dalloc(e, &e->last_dones, N)); CHK(dalloc(e, &e->prev_dones, N));
+  CHK(dalloc(e, &e->last_dones, N)); CHK(dalloc(e, &e->prev_dones, N));
   CHK(dalloc(e, &e->dones_tmp, N)); CHK(dalloc(e, &e->clip_act, N * A)); CHK(dalloc(e, &e->rew_tmp, N));
   CHK(dalloc(e, &e->term_obs, N * Dp)); CHK(dalloc(e, &e->term_val, N)); CHK(dalloc(e, &e->eps_dev, R * A));
   CHK(dalloc(e, &e->trunc_dev, N)); CHK(dalloc(e, &e->dones_u8, N)); CHK(dalloc(e, &e->ep_len, N)); CHK(dalloc(e, &e->ep_len2, N)); CHK(dalloc(e, &e->ctr_dev, 2));
@@ -851,7 +854,46 @@ uint64_t env_seed_of(const mobrob_ppo_engine* e) {
   return e->cfg.seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(e->cfg.rank + 1));
 }
 
+// One persistent launch for all T steps (policy forward + sample + env + store), then the value network over all
+// stored observations in one batched pass, then GAE (kernels_rollout.h).
+bool rollout_persistent_ok(const mobrob_ppo_engine* e) {
+  return e->cfg.rollout_persistent && e->fused.enabled && e->fused.H == FH;
+}
+int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& sp) {
+  const int N = e->N, Dp = e->Dp, T = e->T;
+  const size_t slot = (size_t)N * Dp;
+  HIPC(hipMemcpyAsync(e->obs, e->obs + (size_t)T * slot, slot * 4, hipMemcpyDeviceToDevice, e->stream));
+  RolloutArgs a{};
+  a.pi = e->fused.net[0];
+  a.log_std = Pp(e, T_LOGSTD); a.seed = eps_seed(e); a.draw_base = e->ctr_dev;
+  a.lo = (float)e->cfg.action_low; a.hi = (float)e->cfg.action_high;
+  a.kind = sp.kind; a.env_seed = env_seed_of(e); a.step_base = e->ctr_dev + 1;
+  a.p_term = sp.p_term; a.time_limit = sp.time_limit; a.goal = sp.goal;
+  a.bt = BootArgs{Pp(e, T_VW1), Pp(e, T_VB1), Pp(e, T_VW2), Pp(e, T_VB2), Pp(e, T_VW), Pp(e, T_VB), e->G1, e->G2,
+                  (float)e->cfg.gamma, e->term_val};
+  a.N = N; a.D = e->D; a.A = e->A; a.t0 = 0; a.t1 = T;
+  a.obs = e->obs; a.actions = e->actions; a.logp = e->logp; a.rewards = e->rewards; a.es = e->es;
+  a.term_obs = e->term_obs; a.trunc = e->trunc_dev; a.clip_act = e->clip_act;
+  a.ep_len = e->ep_len; a.prev_dones = e->prev_dones; a.gstate = e->gstate[0]; a.ep_stats = e->ep_stats;
+  {
+    ProfScope ps(e, MOBROB_K_ENV);
+    FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout_persistent<DPc>), dim3(cdiv(N, 32)), dim3(FTHREADS),
+                                             rollout_lds_bytes(Dp), e->stream, a));
+  }
+  hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, e->stream, e->ctr_dev, (uint32_t)T, (uint32_t)T);
+  HIPC(hipMemcpyAsync(e->last_dones, e->prev_dones, (size_t)N * 4, hipMemcpyDeviceToDevice, e->stream));
+  {
+    ProfScope ps(e, MOBROB_K_ACT);  // V(obs[t]) for every stored observation, and V(last_obs)
+    const int rows = (T + 1) * N;  // obs[T] = last_obs, values[T*N..] = last_values
+    FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_value_batch<DPc>), dim3(std::min(256, cdiv(rows, FR))), dim3(FTHREADS),
+                                             e->fused.lds_bytes, e->stream, e->fused.net[1], e->obs, rows, e->values));
+  }
+  run_gae(e);
+  return MOBROB_OK;
+}
+
 int enqueue_rollout(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& sp) {
+  if (rollout_persistent_ok(e)) return enqueue_rollout_persistent(e, sp);
   const int N = e->N, Dp = e->Dp, per = Dp / 4;
   const size_t slot = (size_t)N * Dp;
   const uint64_t env_seed = env_seed_of(e);
@@ -914,7 +956,7 @@ int collect_device(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& s
   e->rollout_ready = false;
   // Graph replay: every kernel argument of the T-step loop is fixed (slot pointers, ping-pong buffers with even T,
   // counters relative to device-resident bases), so the loop is captured once and replayed per rollout.
-  const bool use_graph = e->cfg.rollout_graph && (e->T % 2 == 0);
+  const bool use_graph = e->cfg.rollout_graph && (e->T % 2 == 0 || rollout_persistent_ok(e));
   if (!use_graph) {
     CHK(enqueue_rollout(e, sp));
   } else {
@@ -1096,7 +1138,7 @@ int mobrob_ppo_minibatch_apply(mobrob_ppo_engine_t* e) {
     a.fW3f[n] = on ? (float*)e->fused.net[n].W3f : nullptr;
     a.fW2b[n] = on ? (float*)e->fused.net[n].W2b : nullptr;
     a.fW3b[n] = on ? (float*)e->fused.net[n].W3b : nullptr;
-    a.fW3h[n] = (on && e->fused.H == FH && e->fused.A <= 16) ? (float*)e->fused.net[n].W3h : nullptr;
+    a.fW3h[n] = (on && e->fused.H == FH && (n == 1 || e->fused.A <= 16)) ? (float*)e->fused.net[n].W3h : nullptr;
     a.fb1s[n] = on ? (float*)e->fused.net[n].b1s : nullptr;
     a.fb2s[n] = on ? (float*)e->fused.net[n].b2s : nullptr;
   }
@@ -1214,6 +1256,7 @@ int mobrob_ppo_buffer_info(mobrob_ppo_engine_t* e, int32_t which, void** ptr, si
     case MOBROB_BUF_TERMINAL_OBS: p = e->term_obs; b = N * e->Dp * 4; break;
     case MOBROB_BUF_TERMINAL_VALUES: p = e->term_val; b = N * 4; break;
     case MOBROB_BUF_TRUNCATED: p = e->trunc_dev; b = N; break;
+    case MOBROB_BUF_ENV_STATE: p = e->gstate[0]; b = N * kGoalStateFloats * 4; break;
     default: return fail(MOBROB_ERR_INVALID, "unknown buffer id %d", which);
   }
   if (ptr) *ptr = p;

@@ -2,6 +2,7 @@
 #pragma once
 #include "kernels_fused.h"
 #include "kernels_fused64.h"
+#include "kernels_rollout.h"
 
 namespace mobrob {
 
@@ -49,6 +50,10 @@ inline hipError_t fused_set_lds_attr(FusedState& f) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_train<DPc, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_act<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_act_bytes);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_persistent<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rollout_lds_bytes(f.Dp));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_value_batch<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);
     });
   }
   return e;

@@ -59,25 +59,43 @@ __device__ __forceinline__ void goal_store(float* s, const GoalState& g) {
   s[10] = (float)g.ep_len;
   s[11] = 0.f;
 }
+// (all loops over position components are fully unrolled over 3 with a `j < P` guard: no dynamic register indexing;
+//  HIP's __fmul_rn / __fsub_rn are plain operators after inlining and hipcc contracts across statements
+//  (-ffp-contract=fast ignores pragmas), so a product that later feeds a subtraction -- the freshly drawn pose /
+//  goal in goal_reset -- is pinned to its rounded value with an empty asm; otherwise goal - extent * u is fused
+//  into one fma in one kernel and not in the other.  With that the per-step kernel and the persistent rollout
+//  kernel step bit-identical environments.)
+__device__ __forceinline__ float rounded(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
 __device__ __forceinline__ float goal_dist(const float* a, const float* b, int P) {
   float s = 0.f;
-  for (int j = 0; j < P; ++j) s += (a[j] - b[j]) * (a[j] - b[j]);
-  return sqrtf(s);
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    if (j < P) {
+      const float d = __fsub_rn(a[j], b[j]);
+      s = __fmaf_rn(d, d, s);
+    }
+  return (float)sqrt((double)s);  // via f64: hipcc may pick a 2.5-ulp f32 sqrt / divide per context
 }
 // observation features 4c..4c+3 of state g (KinematicSim.obs): [rel / (|rel| + 1e-6), vel, pos, noise ...]
 __device__ __forceinline__ f32x4 goal_features(const GoalState& g, int P, int D, int c, const float z[4], float noise) {
-  const float d = goal_dist(g.goal, g.pos, P) + 1e-6f;
+  const float d = __fadd_rn(goal_dist(g.goal, g.pos, P), 1e-6f);
   f32x4 o;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int f = 4 * c + j;
-    float v;
-    if (f >= D) v = 0.f;
-    else if (f < P) v = (g.goal[f] - g.pos[f]) / d;
-    else if (f < 2 * P) v = g.vel[f - P];
-    else if (f < 3 * P) v = g.pos[f - 2 * P];
-    else v = noise * z[j];
-    o[j] = v;
+    float v = rounded(__fmul_rn(noise, z[j]));
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      if (q < P) {
+        if (f == q) v = (float)((double)__fsub_rn(g.goal[q], g.pos[q]) / (double)d);
+        if (f == P + q) v = g.vel[q];
+        if (f == 2 * P + q) v = g.pos[q];
+      }
+    }
+    o[j] = f < D ? v : 0.f;
   }
   return o;
 }
@@ -91,20 +109,23 @@ __device__ __forceinline__ GoalOutcome goal_advance(GoalState& g, const GoalEnvP
   for (int k = 0; k < A; ++k) {
     const float a = act[k];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) cmd[j] = fmaf(p.mix[j][k], a, cmd[j]);
+    for (int j = 0; j < 3; ++j) cmd[j] = __fmaf_rn(p.mix[j][k], a, cmd[j]);
   }
   const float d0 = goal_dist(g.goal, g.pos, p.P);
-  for (int j = 0; j < p.P; ++j) {
-    g.vel[j] = 0.8f * g.vel[j] + 0.2f * cmd[j];
-    g.pos[j] = fminf(fmaxf(g.pos[j] + p.dt * g.vel[j], -p.extent), p.extent);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (j < p.P) {
+      g.vel[j] = __fmaf_rn(0.8f, g.vel[j], __fmul_rn(0.2f, cmd[j]));
+      g.pos[j] = fminf(fmaxf(__fmaf_rn(p.dt, g.vel[j], g.pos[j]), -p.extent), p.extent);
+    }
   }
   const float d1 = goal_dist(g.goal, g.pos, p.P);
   GoalOutcome o;
   o.reached = d1 < p.reach;
-  o.reward = d0 - d1 + (o.reached ? p.bonus + p.extra_bonus : 0.f);
+  o.reward = __fadd_rn(__fsub_rn(d0, d1), o.reached ? __fadd_rn(p.bonus, p.extra_bonus) : 0.f);
   o.term = p.terminate_on_goal && o.reached;
   g.ep_len += 1;
-  g.ep_ret += o.reward;
+  g.ep_ret = __fadd_rn(g.ep_ret, o.reward);
   o.tr = g.ep_len >= p.time_limit && !o.term;
   o.done = o.term || o.tr;
   return o;
@@ -116,12 +137,15 @@ __device__ __forceinline__ void goal_reset(GoalState& g, const GoalEnvParams& p,
   const Philox4 b = philox4x32_10(n, 1u, step, kStreamEnvReset, k0, k1);
   const float ua[3] = {u32_to_unit_open(a.x), u32_to_unit_open(a.y), u32_to_unit_open(a.z)};
   const float ub[3] = {u32_to_unit_open(b.x), u32_to_unit_open(b.y), u32_to_unit_open(b.z)};
-  for (int j = 0; j < p.P; ++j) {
-    if (!reached) {
-      g.vel[j] = 0.f;
-      g.pos[j] = p.extent * (ua[j] - 0.5f);      // init_space = [-extent/2, extent/2]
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (j < p.P) {
+      if (!reached) {
+        g.vel[j] = 0.f;
+        g.pos[j] = rounded(__fmul_rn(p.extent, __fsub_rn(ua[j], 0.5f)));      // init_space = [-extent/2, extent/2]
+      }
+      g.goal[j] = rounded(__fmul_rn(p.extent, __fmaf_rn(2.0f, ub[j], -1.0f)));  // goal_space = [-extent, extent]
     }
-    g.goal[j] = p.extent * (2.0f * ub[j] - 1.0f);  // goal_space = [-extent, extent]
   }
   g.ep_ret = 0.f;
   g.ep_len = 0;

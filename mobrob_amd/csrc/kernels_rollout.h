@@ -1,0 +1,364 @@
+// Persistent device rollout (hidden width 256): ONE launch runs all T steps of collect_rollouts for the block's 32
+// environments -- policy forward (MFMA, as k_fused_act) -> Gaussian sample + log-prob -> env step (synthetic source
+// or goal environment) with VecEnv auto-reset -> rollout_buffer.add scalars -> time-limit bootstrap -> next step.
+//
+// Why it is legal: environments are independent and the policy weights are constant during a rollout, so a block
+// never needs anything another block produced -- no grid synchronisation, no kernel boundary per step (a boundary
+// costs ~4-5 us of drain/fill even inside a hipGraph; at 1000 steps x 2 kernels that was 40 % of the rollout).
+// The observation tile of step t+1 is produced in LDS by the env phase of step t (and streamed to the rollout
+// buffer for training); episode length / goal state / episode-start flags live in LDS for the whole launch.
+// The value network is NOT evaluated here: V(obs[t]) only feeds GAE, so it is computed afterwards for all T*N
+// stored observations in one batched pass (k_value_batch below: 64-row tiles through the training kernel's forward
+// code) at throughput instead of per-step latency.
+// The rare truncated rows need V(terminal_obs) at once (r += gamma V): the block evaluates the value MLP for
+// such a row with all 256 threads (value_row_lds, same arithmetic as the per-step path).
+//
+// Arithmetic per row and step is that of k_fused_act + k_env_step_store / k_goal_env_step_store; the Philox
+// counters are (row, chunk, base + t), so the persistent and the per-step rollouts are bit-identical
+// (tests/test_engine_gpu.py::test_persistent_rollout_equals_per_step_rollout).
+#pragma once
+#include "kernels_env.h"
+#include "kernels_fused.h"
+
+namespace mobrob {
+
+struct RolloutArgs {
+  FusedNet pi;                       // policy network packs
+  const float* log_std; uint64_t seed; const uint32_t* draw_base; float lo, hi;
+  int kind;                          // 1 synthetic source, 2 goal environment
+  uint64_t env_seed; const uint32_t* step_base;
+  float p_term; int time_limit;
+  GoalEnvParams goal;
+  BootArgs bt;
+  int N, D, A, t0, t1;
+  // rollout storage
+  float* obs;                        // [T+1][N][DP]
+  float* actions; float* logp; float* rewards; float* es;  // [T][N][.]
+  float* term_obs; uint8_t* trunc; float* clip_act;        // latest-step buffers
+  // carried state (in/out)
+  int* ep_len; float* prev_dones; float* gstate; double* ep_stats;
+};
+
+template <int DP>
+struct LayRo {
+  using B = Lay32<DP>;
+  static constexpr int CA = B::END;         // [32][33] clipped actions of the current step
+  static constexpr int ST = CA + 32 * 33;   // [32][16] row state: goal state [0..11] | prev_done [12] | ep_len [13]
+  static constexpr int BL = ST + 32 * 16;   // bootstrap list: cnt[4] | row[32] | reward[32]
+  static constexpr int AC = BL + 4 + 64;    // per-action constants: sd[32] | 2 sd^2 [32] | log sd [32] | b3[32]
+  static constexpr int ZN = AC + 128;       // [32][32] standard normals of the current step
+  static constexpr int TM = ZN + 32 * 32;   // [32][33] log-prob terms of the current step
+  static constexpr int END = TM + 32 * 33;
+};
+inline size_t rollout_lds_bytes(int Dp) {
+  return fused_lds_act_bytes(Dp) + (size_t)(32 * 33 + 32 * 16 + 68 + 128 + 32 * 32 + 32 * 33) * sizeof(float);
+}
+
+template <int DP>
+__global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs a) {
+  using L = LayRo<DP>;
+  using LB = Lay32<DP>;
+  constexpr int ldx = LB::LDX, per = DP / 4, R = 32;
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const FusedNet W = a.pi;
+  const int row0 = blockIdx.x * R;
+  const int N = a.N, A = a.A, D = a.D;
+  int* cnt = reinterpret_cast<int*>(&lds[L::BL]);
+  int* lrow = cnt + 4;
+  float* lrew = &lds[L::BL + 4 + 32];
+  // ---- carried state and the observation tile of step t0 -> LDS ----
+  if (tid0 < R) {
+    const int n = row0 + tid0;
+    float* S = &lds[L::ST + tid0 * 16];
+    if (n < N) {
+      if (a.kind == 2) {
+#pragma unroll
+        for (int j = 0; j < kGoalStateFloats; ++j) S[j] = a.gstate[(size_t)n * kGoalStateFloats + j];
+      } else {
+        reinterpret_cast<int*>(S)[13] = a.ep_len[n];
+      }
+      S[12] = a.prev_dones[n];
+    }
+  }
+  if (tid0 < 32) {  // per-action constants of the Gaussian head (the same expressions k_fused_act evaluates per row)
+    float sd = 1.f, bb = 0.f;
+    if (tid0 < A) { sd = expf(a.log_std[tid0]); bb = W.b3[tid0]; }
+    lds[L::AC + tid0] = sd;
+    lds[L::AC + 32 + tid0] = 2.0f * (sd * sd);
+    lds[L::AC + 64 + tid0] = logf(sd);
+    lds[L::AC + 96 + tid0] = bb;
+  }
+  for (int i = tid0; i < R * per; i += FTHREADS) {
+    const int rr = i / per, c = i - rr * per;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row0 + rr < N)
+      v = ldg16(a.obs, (unsigned)((size_t)a.t0 * N + row0 + rr) * (unsigned)(DP * 4) + (unsigned)(c * 16));
+    *reinterpret_cast<f32x4*>(&lds[LB::X + rr * ldx + 4 * c]) = v;
+  }
+  __syncthreads();
+  const uint32_t dbase = a.draw_base ? *a.draw_base : 0u, sbase = a.step_base ? *a.step_base : 0u;
+  const uint32_t ek0 = (uint32_t)a.env_seed, ek1 = (uint32_t)(a.env_seed >> 32);
+
+  for (int t = a.t0; t < a.t1; ++t) {
+    const int tid = opaque(tid0), lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    {  // standard normals of this step (independent of the forward pass: drawn first, consumed after the head)
+      const int ngrp = (A + 3) >> 2;
+      for (int i = tid; i < R * ngrp; i += FTHREADS) {
+        const int rr_ = i / ngrp, gq = i - rr_ * ngrp;
+        float z[4];
+        box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)gq, (uint32_t)t + dbase, 0x45505331u, (uint32_t)a.seed,
+                                  (uint32_t)(a.seed >> 32)), z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[L::ZN + rr_ * 32 + 4 * gq + j] = z[j];
+      }
+    }
+    {  // layer 1
+      f32x16 c0 = splat16(W.b1s[64 * wave + r]), c1 = splat16(W.b1s[64 * wave + 32 + r]);
+      constexpr int nkg = DP / 8;
+      gemm_lds_packed_r32<ldx>(LB::X, W.W1f + (size_t)(2 * wave) * nkg * 64, W.W1f + (size_t)(2 * wave + 1) * nkg * 64, nkg,
+                               c0, c1, lane);
+      const int o = opaque(LB::H1 + 4 * h * FLDH + 64 * wave + r);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        lds[o + crc(i) * FLDH] = fast_tanh_scaled(c0[i]);
+        lds[o + crc(i) * FLDH + 32] = fast_tanh_scaled(c1[i]);
+      }
+    }
+    __syncthreads();
+    {  // layer 2
+      f32x16 c0 = splat16(W.b2s[64 * wave + r]), c1 = splat16(W.b2s[64 * wave + 32 + r]);
+      constexpr int nkg = FH / 8;
+      gemm_lds_packed_r32_deep<FLDH>(LB::H1, W.W2f + (size_t)(2 * wave) * nkg * 64,
+                                     W.W2f + (size_t)(2 * wave + 1) * nkg * 64, nkg, c0, c1, lane);
+      const int o = opaque(LB::H2 + 4 * h * FLDH + 64 * wave + r);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        lds[o + crc(i) * FLDH] = fast_tanh_scaled(c0[i]);
+        lds[o + crc(i) * FLDH + 32] = fast_tanh_scaled(c1[i]);
+      }
+    }
+    __syncthreads();
+    {  // head: K split over the 4 waves (64 each); partial tiles side by side, summed in the sampling stage
+      f32x16 acc = zero16(), acc2 = zero16();
+      const int ab = 4 * opaque((LB::H2 + r * FLDH + wave * 64 + 4 * h) >> 2);
+      const f32x4* bp = W.W3f + (size_t)(wave * 8) * 64;
+      const unsigned bo = opaque_u((unsigned)lane * 16u);
+#pragma unroll
+      for (int kg = 0; kg < 8; kg += 2) {
+        const f32x4 b0 = ldg16(bp, bo + kg * 1024u), b1 = ldg16(bp, bo + (kg + 1) * 1024u);
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8]);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8 + 8]);
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+          acc = MFMA32(a0[s_], b0[s_], acc);
+          acc2 = MFMA32(a1[s_], b1[s_], acc2);
+        }
+      }
+      const int o = opaque(LB::DO + wave * R * FLDO + 4 * h * FLDO + r);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) lds[o + crc(i) * FLDO] = acc[i] + acc2[i];
+    }
+    if (tid == 0) *cnt = 0;
+    __syncthreads();
+    // ---- Gaussian sample + log-prob.  Same expressions and Philox counters as k_fused_act, spread over the block:
+    //      (row, action group) items draw the normals, (row, action) items form action and log-prob term, one lane
+    //      per row adds the terms in action order (-> bit-identical log-probs) ----
+    for (int i = tid; i < R * A; i += FTHREADS) {
+      const int rr_ = i / A, k = i - rr_ * A;
+      const int row = row0 + rr_;
+      if (row < N) {
+        const int db = LB::DO + rr_ * FLDO + k;
+        const float m = ((lds[db] + lds[db + R * FLDO]) + (lds[db + 2 * R * FLDO] + lds[db + 3 * R * FLDO])) + lds[L::AC + 96 + k];
+        const float sd = lds[L::AC + k];
+        const float act = m + lds[L::ZN + rr_ * 32 + k] * sd;
+        const float d = act - m;
+        lds[L::TM + rr_ * 33 + k] = -(d * d) / lds[L::AC + 32 + k] - lds[L::AC + 64 + k] - 0.91893853320467274178f;
+        const float ac = fminf(fmaxf(act, a.lo), a.hi);
+        a.actions[((size_t)t * N + row) * A + k] = act;
+        a.clip_act[(size_t)row * A + k] = ac;
+        lds[L::CA + rr_ * 33 + k] = ac;
+      }
+    }
+    __syncthreads();
+    if (tid < R && row0 + tid < N) {
+      float lp = 0.f;
+      for (int k = 0; k < A; ++k) lp += lds[L::TM + tid * 33 + k];
+      a.logp[(size_t)t * N + row0 + tid] = lp;
+    }
+    // ---- env.step(clipped actions) + auto-reset: 8 threads per row, observation chunks sub and sub + 8 ----
+    const int rr = tid >> 3, sub = tid & 7;
+    const int n = row0 + rr;
+    const bool live = n < N;
+    const uint32_t step = sbase + (uint32_t)t;
+    float* S = &lds[L::ST + rr * 16];
+    float* xrow = &lds[LB::X + rr * ldx];
+    float* trow = &lds[LB::H2 + rr * DP];  // terminal observation staging (h2 is dead after the head GEMM)
+    const size_t onext = ((size_t)(t + 1) * N + (live ? n : 0)) * per;
+    bool tr = false, done = false, reached = false;
+    float reward = 0.f, ep_ret = 0.f;
+    int ep_len_new = 0, ep_len_fin = 0;
+    GoalState g{};
+    if (live) {
+      if (a.kind == 1) {
+        const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, ek0, ek1);
+        const bool term = u32_to_unit_open(mr.x) < a.p_term;
+        const int len = reinterpret_cast<const int*>(S)[13] + 1;
+        tr = (len >= a.time_limit) && !term;
+        done = term || tr;
+        ep_len_new = done ? 0 : len;
+        for (int c = sub; c < per; c += 8) {
+          float z[4];
+          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, ek0, ek1), z);
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
+          if (tr) {
+            reinterpret_cast<f32x4*>(a.term_obs)[(size_t)n * per + c] = o;
+            *reinterpret_cast<f32x4*>(&trow[4 * c]) = o;
+            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
+          }
+          reinterpret_cast<f32x4*>(a.obs)[onext + c] = o;
+          *reinterpret_cast<f32x4*>(&xrow[4 * c]) = o;
+        }
+        if (sub == 0) {
+          float zz[4];
+          box_muller4(Philox4{mr.y, mr.z, mr.w, mr.x ^ 0x9E3779B9u}, zz);
+          reward = 0.03f + 0.1f * zz[0] + (term ? 5.0f : 0.f);
+        }
+      } else {
+        g = goal_load(S);
+        const GoalOutcome o = goal_advance(g, a.goal, &lds[L::CA + rr * 33], A);
+        tr = o.tr; done = o.done; reached = o.reached; reward = o.reward;
+        ep_ret = g.ep_ret; ep_len_fin = g.ep_len;
+        GoalState gn = g;
+        if (done) goal_reset(gn, a.goal, o.reached, (uint32_t)n, step, ek0, ek1);
+        for (int c = sub; c < per; c += 8) {
+          float z[4];
+          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, ek0, ek1), z);
+          f32x4 ob = goal_features(g, a.goal.P, D, c, z, a.goal.noise);
+          if (done) {
+            if (tr) {
+              reinterpret_cast<f32x4*>(a.term_obs)[(size_t)n * per + c] = ob;
+              *reinterpret_cast<f32x4*>(&trow[4 * c]) = ob;
+            }
+            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
+            ob = goal_features(gn, a.goal.P, D, c, z, a.goal.noise);
+          }
+          reinterpret_cast<f32x4*>(a.obs)[onext + c] = ob;
+          *reinterpret_cast<f32x4*>(&xrow[4 * c]) = ob;
+        }
+        g = gn;
+      }
+    }
+    __syncthreads();  // every thread of a row has read the row's old state
+    if (live && sub == 0) {
+      const size_t so = (size_t)t * N + n;
+      a.es[so] = S[12];
+      S[12] = done ? 1.f : 0.f;
+      a.trunc[n] = tr ? 1 : 0;
+      if (a.kind == 1) {
+        reinterpret_cast<int*>(S)[13] = ep_len_new;
+      } else {
+        goal_store(S, g);
+        if (done) {
+          atomicAdd(&a.ep_stats[0], 1.0);
+          atomicAdd(&a.ep_stats[1], (double)ep_ret);
+          atomicAdd(&a.ep_stats[2], (double)ep_len_fin);
+          if (reached) atomicAdd(&a.ep_stats[3], 1.0);
+        }
+      }
+      if (tr) {  // reward is written after the bootstrap below
+        const int q = atomicAdd(cnt, 1);
+        lrow[q] = rr;
+        lrew[q] = reward;
+      } else {
+        a.rewards[so] = reward;
+      }
+    }
+    __syncthreads();
+    // ---- time-limit bootstrap of the (rare) truncated rows: r += gamma * V(terminal_obs) ----
+    const int m = *cnt;
+    for (int q = 0; q < m; ++q) {
+      const int br = lrow[q];
+      float* sc = &lds[LB::H1];  // h1 is dead after the layer-2 GEMM: scratch h1[G1] | h2[G2] | red[16]
+      const float v = value_row_lds(&lds[LB::H2 + br * DP], sc, sc + a.bt.G1, sc + a.bt.G1 + a.bt.G2, a.bt.W1, a.bt.b1,
+                                    a.bt.W2, a.bt.b2, a.bt.Wv, a.bt.bv, D, a.bt.G1, a.bt.G2);
+      if (tid == 0) {
+        a.bt.term_val[row0 + br] = v;
+        a.rewards[(size_t)t * N + row0 + br] = (float)((double)lrew[q] + (double)__fmul_rn(a.bt.gamma, v));
+      }
+      __syncthreads();
+    }
+  }
+  // ---- carried state back to global ----
+  if (tid0 < R) {
+    const int n = row0 + tid0;
+    const float* S = &lds[L::ST + tid0 * 16];
+    if (n < N) {
+      if (a.kind == 2) {
+#pragma unroll
+        for (int j = 0; j < kGoalStateFloats; ++j) a.gstate[(size_t)n * kGoalStateFloats + j] = S[j];
+      } else {
+        a.ep_len[n] = reinterpret_cast<const int*>(S)[13];
+      }
+      a.prev_dones[n] = S[12];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched value forward: v[row] = V(X[row]) for `rows` contiguous observations.  Persistent 256-thread blocks loop
+// over 64-row tiles with the forward code of the training kernel (tile_layers + the 16x16x4 head); the next tile's
+// rows are in flight while the current tile computes.
+// ------------------------------------------------------------------------------------------------
+template <int DP>
+__global__ __launch_bounds__(FTHREADS, 1) void k_value_batch(FusedNet W, const float* __restrict__ X, int rows,
+                                                             float* __restrict__ v) {
+  using L = Lay<DP>;
+  constexpr int ldx = L::LDX, per = DP / 4;
+  constexpr int NG = (FR * per + FTHREADS - 1) / FTHREADS;
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int ntiles = (rows + FR - 1) / FR;
+  f32x4 xr[NG];
+#pragma unroll
+  for (int u = 0; u < NG; ++u) {
+    const int i = tid0 + u * FTHREADS, rr = i / per, c = i - rr * per;
+    xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if ((int)blockIdx.x < ntiles && blockIdx.x * FR + rr < rows)
+      xr[u] = ldg16(X, (unsigned)(blockIdx.x * FR + rr) * (unsigned)(DP * 4) + (unsigned)(c * 16));
+  }
+  const float bv = W.b3[0];
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tid = opaque(tid0), lane = tid & 63;
+    const Frag2 f1 = prefetch_frag(W.W1f + (size_t)(2 * wave) * (DP / 8) * 64,
+                                   W.W1f + (size_t)(2 * wave + 1) * (DP / 8) * 64, lane);
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int i = tid + u * FTHREADS, rr = i / per, c = i - rr * per;
+      *reinterpret_cast<f32x4*>(&lds[L::X + rr * ldx + 4 * c]) = xr[u];
+    }
+    const int nt = tile + gridDim.x;
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int i = tid + u * FTHREADS, rr = i / per, c = i - rr * per;
+      xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (nt < ntiles && nt * FR + rr < rows)
+        xr[u] = ldg16(X, (unsigned)(nt * FR + rr) * (unsigned)(DP * 4) + (unsigned)(c * 16));
+    }
+    __syncthreads();
+    const Frag2 f3 = tile_layers<DP, true>(W, wave, lane, f1);
+    tile_head16<DP>(W, wave, lane, f3);  // wave w writes head rows 16w..16w+15, read back by the same wave below
+    if (lane < 16) {
+      const int rr = 16 * wave + lane, row = tile * FR + rr;
+      if (row < rows) v[row] = lds[L::DO + rr * FLDO] + bv;
+    }
+    __syncthreads();  // X / h1 / h2 / head tile are rewritten by the next tile
+  }
+}
+
+}  // namespace mobrob

@@ -260,6 +260,41 @@ def test_device_rollout_time_limit_bootstrap(H):
     e.close()
 
 
+@pytest.mark.parametrize("kind", ["synthetic", "goal"])
+@pytest.mark.parametrize("H,D,A,N", [(256, 58, 12, 200), (256, 26, 2, 64), (256, 12, 18, 33), (64, 14, 2, 100), (64, 43, 2, 37)])
+def test_persistent_rollout_equals_per_step_rollout(kind, H, D, A, N):
+    """One persistent launch for all T steps vs one launch per step: same Philox counters, same arithmetic ->
+    bit-identical rollout buffers (observations, actions, log-probs, rewards incl. bootstrap, episode starts);
+    values come from the batched pass and agree to float tolerance; two consecutive rollouts (carried state)."""
+    from mobrob_amd.envs.vec_env import DeviceGoalVecEnv
+    T, TL = 24, 7
+    p = O.init_params(D, A, (H, H), (H, H), seed=8)
+    p["value_net.bias"] = np.array([2.0], np.float32)
+    res = {}
+    for persistent in (True, False):
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=256, n_epochs=1, pi=(H, H), vf=(H, H), seed=21,
+                        rollout_persistent=persistent)
+        e.set_params(p)
+        out = []
+        for _ in range(2):
+            if kind == "synthetic":
+                e.collect_synthetic(p_term=0.05, time_limit=TL)
+            else:
+                DeviceGoalVecEnv(N, D, A, 2 if D < 12 or A != 18 else 3, time_limit=TL).collect(e)
+            e.synchronize()
+            out.append({k: e.read(k) for k in ("obs", "actions", "log_probs", "rewards", "episode_starts", "values",
+                                               "last_values", "last_dones", "advantages", "truncated", "terminal_values")})
+        res[persistent] = out
+        e.close()
+    for a, b in zip(res[True], res[False]):
+        for k in ("obs", "actions", "log_probs", "episode_starts", "last_dones", "truncated"):
+            assert np.array_equal(a[k], b[k]), k
+        assert np.max(np.abs(a["rewards"] - b["rewards"])) < 1e-5  # bootstrapped rows: V through a different reduction order
+        assert np.max(np.abs(a["values"] - b["values"])) < 1e-4 and np.max(np.abs(a["last_values"] - b["last_values"])) < 1e-4
+        assert np.max(np.abs(a["advantages"] - b["advantages"])) < 1e-3
+        assert a["episode_starts"][1:].sum() > 0  # the comparison covers resets and truncations
+
+
 def test_error_paths():
     from mobrob_amd.engine import PPOEngine
     with pytest.raises(ValueError):
