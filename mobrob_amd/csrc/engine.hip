@@ -93,6 +93,8 @@ struct mobrob_ppo_engine {
     GoalEnvParams goal{};
   } ro_spec;
   int env_started = 0;  // env kind whose state is live on the device (0 = none)
+  hipStream_t vstream = nullptr;          // batched value pass of finished rollout chunks, concurrent with the rollout
+  hipEvent_t ev_chunk = nullptr, ev_vdone = nullptr;
   float* gstate[2] = {nullptr, nullptr};  // goal env state, double buffered [N][kGoalStateFloats]
   double* ep_stats = nullptr;             // [4] episode statistics of the goal env
   uint32_t draw_counter = 0;  // Philox draw index for eps
@@ -667,6 +669,11 @@ void mobrob_ppo_destroy(mobrob_ppo_engine_t* e) {
   }
   if (e->ro_exec) (void)hipGraphExecDestroy(e->ro_exec);
   if (e->ro_graph) (void)hipGraphDestroy(e->ro_graph);
+  if (e->vstream) {
+    (void)hipStreamSynchronize(e->vstream);
+    (void)hipEventDestroy(e->ev_chunk); (void)hipEventDestroy(e->ev_vdone);
+    (void)hipStreamDestroy(e->vstream);
+  }
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -857,7 +864,7 @@ uint64_t env_seed_of(const mobrob_ppo_engine* e) {
 // One persistent launch for all T steps (policy forward + sample + env + store), then the value network over all
 // stored observations in one batched pass, then GAE (kernels_rollout.h).
 bool rollout_persistent_ok(const mobrob_ppo_engine* e) {
-  return e->cfg.rollout_persistent && e->fused.enabled && e->fused.H == FH;
+  return e->cfg.rollout_persistent && e->fused.enabled;  // both fused widths (256: kernels_rollout.h top, 64: bottom)
 }
 int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& sp) {
   const int N = e->N, Dp = e->Dp, T = e->T;
@@ -871,22 +878,67 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
   a.p_term = sp.p_term; a.time_limit = sp.time_limit; a.goal = sp.goal;
   a.bt = BootArgs{Pp(e, T_VW1), Pp(e, T_VB1), Pp(e, T_VW2), Pp(e, T_VB2), Pp(e, T_VW), Pp(e, T_VB), e->G1, e->G2,
                   (float)e->cfg.gamma, e->term_val};
-  a.N = N; a.D = e->D; a.A = e->A; a.t0 = 0; a.t1 = T;
+  a.N = N; a.D = e->D; a.A = e->A;
   a.obs = e->obs; a.actions = e->actions; a.logp = e->logp; a.rewards = e->rewards; a.es = e->es;
   a.term_obs = e->term_obs; a.trunc = e->trunc_dev; a.clip_act = e->clip_act;
   a.ep_len = e->ep_len; a.prev_dones = e->prev_dones; a.gstate = e->gstate[0]; a.ep_stats = e->ep_stats;
+  if (e->fused.H == GH) {  // 64-wide nets: one wave per 32-env tile, weights LDS resident; the value pass is cheap
+    a.t0 = 0; a.t1 = T;
+    const int nwv = rollout64_waves(Dp);
+    {
+      ProfScope ps(e, MOBROB_K_ENV);
+      FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout64_persistent<DPc>), dim3(cdiv(cdiv(N, 32), nwv)), dim3(nwv * 64),
+                                               rollout64_lds_bytes(Dp), e->stream, a));
+    }
+    hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, e->stream, e->ctr_dev, (uint32_t)T, (uint32_t)T);
+    HIPC(hipMemcpyAsync(e->last_dones, e->prev_dones, (size_t)N * 4, hipMemcpyDeviceToDevice, e->stream));
+    {
+      ProfScope ps(e, MOBROB_K_ACT);  // V(obs[0..T]) in one pass; values[T*N..] = last_values
+      forward(e, e->obs, (T + 1) * N, false, nullptr, true, e->values);
+    }
+    run_gae(e);
+    return MOBROB_OK;
+  }
+  // The rollout blocks (32 envs each, ~100 KB of LDS) leave CUs idle when N < 32 * 256; the value pass of the steps
+  // already finished runs there at the same time: the rollout is cut into chunks, chunk c's value pass is enqueued
+  // on a second stream behind an event and overlaps the rollout of chunk c+1.
+  if (!e->vstream) {
+    HIPC(hipStreamCreateWithFlags(&e->vstream, hipStreamNonBlocking));
+    HIPC(hipEventCreateWithFlags(&e->ev_chunk, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&e->ev_vdone, hipEventDisableTiming));
+  }
+  const int rblocks = cdiv(N, 32);
+  const bool overlap = rblocks <= 192;                      // otherwise the rollout itself fills the device
+  const int chunk = overlap ? std::max(16, cdiv(T, 20)) : T;
+  const int vgrid_max = overlap ? std::max(32, 256 - rblocks) : 256;
+  auto value_pass = [&](hipStream_t st, int r0, int r1) {  // rows [r0, r1) of obs -> values
+    FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_value_batch<DPc>), dim3(std::min(vgrid_max, cdiv(r1 - r0, FR))),
+                                             dim3(FTHREADS), e->fused.lds_bytes, st, e->fused.net[1],
+                                             e->obs + (size_t)r0 * Dp, r1 - r0, e->values + r0));
+  };
   {
     ProfScope ps(e, MOBROB_K_ENV);
-    FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout_persistent<DPc>), dim3(cdiv(N, 32)), dim3(FTHREADS),
-                                             rollout_lds_bytes(Dp), e->stream, a));
+    for (int t0 = 0; t0 < T; t0 += chunk) {
+      a.t0 = t0; a.t1 = std::min(T, t0 + chunk);
+      FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout_persistent<DPc>), dim3(rblocks), dim3(FTHREADS),
+                                               rollout_lds_bytes(Dp), e->stream, a));
+      if (overlap && a.t1 < T) {  // observations [t0, t1) are final: value them on the side stream
+        HIPC(hipEventRecord(e->ev_chunk, e->stream));
+        HIPC(hipStreamWaitEvent(e->vstream, e->ev_chunk, 0));
+        value_pass(e->vstream, t0 * N, a.t1 * N);
+      }
+    }
   }
   hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, e->stream, e->ctr_dev, (uint32_t)T, (uint32_t)T);
   HIPC(hipMemcpyAsync(e->last_dones, e->prev_dones, (size_t)N * 4, hipMemcpyDeviceToDevice, e->stream));
   {
-    ProfScope ps(e, MOBROB_K_ACT);  // V(obs[t]) for every stored observation, and V(last_obs)
-    const int rows = (T + 1) * N;  // obs[T] = last_obs, values[T*N..] = last_values
-    FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_value_batch<DPc>), dim3(std::min(256, cdiv(rows, FR))), dim3(FTHREADS),
-                                             e->fused.lds_bytes, e->stream, e->fused.net[1], e->obs, rows, e->values));
+    ProfScope ps(e, MOBROB_K_ACT);  // V of the last chunk and V(last_obs) (obs[T]; values[T*N..] = last_values)
+    const int done_rows = overlap ? ((T - 1) / chunk) * chunk * N : 0;
+    value_pass(e->stream, done_rows, (T + 1) * N);
+    if (overlap && done_rows > 0) {  // join the side stream before GAE
+      HIPC(hipEventRecord(e->ev_vdone, e->vstream));
+      HIPC(hipStreamWaitEvent(e->stream, e->ev_vdone, 0));
+    }
   }
   run_gae(e);
   return MOBROB_OK;

@@ -42,6 +42,8 @@ inline hipError_t fused_set_lds_attr(FusedState& f) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused64_train<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused64_act<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_act_bytes);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout64_persistent<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rollout64_lds_bytes(f.Dp));
     });
   } else {
     FUSED_DISPATCH_DP(f.Dp, {

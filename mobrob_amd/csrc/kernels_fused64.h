@@ -151,10 +151,9 @@ __device__ __forceinline__ void tile64_forward(const FusedNet& W, int wb, int la
 }
 
 // the same forward with the network's packed weights resident in LDS at offset 0 (training kernel)
-template <int DP>
+template <int DP, class Wt = Wts64<DP>>
 __device__ __forceinline__ void tile64_forward_ldsw(int wb, int lane) {
   using L = Lay64<DP>;
-  using Wt = Wts64<DP>;
   const int r = lane & 31, h = lane >> 5;
   {
     f32x16 c0 = splat16(lds[Wt::B1S + r]), c1 = splat16(lds[Wt::B1S + 32 + r]);

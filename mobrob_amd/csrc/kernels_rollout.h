@@ -19,6 +19,7 @@
 #pragma once
 #include "kernels_env.h"
 #include "kernels_fused.h"
+#include "kernels_fused64.h"
 
 namespace mobrob {
 
@@ -358,6 +359,274 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_value_batch(FusedNet W, const f
       if (row < rows) v[row] = lds[L::DO + rr * FLDO] + bv;
     }
     __syncthreads();  // X / h1 / h2 / head tile are rewritten by the next tile
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hidden width 64 (reference YAML shape): the same persistent rollout with ONE WAVE per 32-env tile and the
+// policy's forward packs resident in LDS for the whole launch (no weight traffic, no workgroup barrier in the step
+// loop: every phase of a tile is wave-synchronous, ordered by the wave's in-order DS queue).  A step is ~100 MFMAs
+// plus sampling and the env rules -- a few microseconds; the per-step launches of the graph path cost more than that.
+// ------------------------------------------------------------------------------------------------
+template <int DP>
+struct WtsF64 {  // forward packs + scaled biases as mirrored into LDS (a prefix and a suffix of Wts64<DP>)
+  static constexpr int W1F = 0;
+  static constexpr int W2F = W1F + 2 * (DP / 8) * 256;
+  static constexpr int W3F = W2F + 2 * 8 * 256;
+  static constexpr int B1S = W3F + 8 * 256;
+  static constexpr int B2S = B1S + 64;
+  static constexpr int TOTAL = B2S + 64;
+};
+template <int DP>
+struct LayRo64 {
+  using B = Lay64<DP>;
+  static constexpr int CA = B::WAVE;          // [32][33] clipped actions
+  static constexpr int ST = CA + 32 * 33;     // [32][16] row state
+  static constexpr int ZN = ST + 32 * 16;     // [32][32] standard normals
+  static constexpr int TM = ZN + 32 * 32;     // [32][33] log-prob terms
+  static constexpr int WAVE = TM + 32 * 33;   // floats per wave
+  static constexpr int AC = WtsF64<DP>::TOTAL;            // block: per-action constants [4][32]
+  static constexpr int W0 = AC + 128;                     // first wave region
+  static constexpr int NWV = (40960 - W0) / WAVE >= 4 ? 4 : (40960 - W0) / WAVE;  // waves per block (<= 160 KB)
+  static constexpr int END = W0 + NWV * WAVE;
+};
+inline int rollout64_waves(int Dp) {
+  const int w0 = 2 * (Dp / 8) * 256 + 4096 + 2048 + 128 + 128;
+  const int wave = 32 * (Dp + 4) + 2 * 32 * GLDH + 32 * FLDO + 64 + 32 * 33 + 32 * 16 + 32 * 32 + 32 * 33;
+  return std::min(4, (40960 - w0) / wave);
+}
+inline size_t rollout64_lds_bytes(int Dp) {
+  const int w0 = 2 * (Dp / 8) * 256 + 4096 + 2048 + 128 + 128;
+  const int wave = 32 * (Dp + 4) + 2 * 32 * GLDH + 32 * FLDO + 64 + 32 * 33 + 32 * 16 + 32 * 32 + 32 * 33;
+  return (size_t)(w0 + rollout64_waves(Dp) * wave) * sizeof(float);
+}
+
+// V(x) for one row by one wave (x[D], h1[G1], h2[G2] in the wave's LDS).  Same per-unit fma chains as value_row_lds;
+// for G2 <= 64 the final wave_sum equals its block_sum (the other waves contribute exact zeros).
+__device__ __forceinline__ float value_row_wave(const float* x, float* h1, float* h2, const BootArgs& bt, int D, int lane) {
+  for (int j = lane; j < bt.G1; j += 64) {
+    float s = 0.f;
+    for (int k = 0; k < D; ++k) s = fmaf(x[k], bt.W1[(size_t)j * D + k], s);
+    h1[j] = tanhf(s + bt.b1[j]);
+  }
+  for (int j = lane; j < bt.G2; j += 64) {
+    float s = 0.f;
+    for (int k = 0; k < bt.G1; ++k) s = fmaf(h1[k], bt.W2[(size_t)j * bt.G1 + k], s);
+    h2[j] = tanhf(s + bt.b2[j]);
+  }
+  float p = 0.f;
+  for (int k = lane; k < bt.G2; k += 64) p += h2[k] * bt.Wv[k];
+  return wave_sum(p) + bt.bv[0];
+}
+
+template <int DP>
+__global__ __launch_bounds__(LayRo64<DP>::NWV * 64, 1) void k_rollout64_persistent(RolloutArgs a) {
+  using L = LayRo64<DP>;
+  using LB = Lay64<DP>;
+  using WF = WtsF64<DP>;
+  using WS = Wts64<DP>;
+  constexpr int ldx = LB::LDX, per = DP / 4, R = 32;
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int N = a.N, A = a.A, D = a.D;
+  // ---- forward packs of the policy network and the per-action constants -> LDS (whole block) ----
+  {
+    const f32x4* src = a.pi.W1f;  // W1F | W2F | W3F are contiguous in the per-network pack (Wts64 layout)
+    for (int i = tid0; i < WF::B1S / 4; i += blockDim.x) reinterpret_cast<f32x4*>(lds)[i] = src[i];
+    for (int i = tid0; i < 64; i += blockDim.x) {
+      lds[WF::B1S + i] = a.pi.b1s[i];
+      lds[WF::B2S + i] = a.pi.b2s[i];
+    }
+    if (tid0 < 32) {
+      float sd = 1.f, bb = 0.f;
+      if (tid0 < A) { sd = expf(a.log_std[tid0]); bb = a.pi.b3[tid0]; }
+      lds[L::AC + tid0] = sd;
+      lds[L::AC + 32 + tid0] = 2.0f * (sd * sd);
+      lds[L::AC + 64 + tid0] = logf(sd);
+      lds[L::AC + 96 + tid0] = bb;
+    }
+  }
+  __syncthreads();  // the only workgroup barrier of the kernel
+  (void)sizeof(WS);
+  const int tile = blockIdx.x * L::NWV + wave;
+  const int row0 = tile * R;
+  if (row0 >= N) return;
+  const int wb = L::W0 + wave * L::WAVE;
+  const int lane0 = tid0 & 63;
+  // ---- carried state and the observation tile of step t0 ----
+  if (lane0 < R) {
+    const int n = row0 + lane0;
+    float* S = &lds[wb + L::ST + lane0 * 16];
+    if (n < N) {
+      if (a.kind == 2) {
+#pragma unroll
+        for (int j = 0; j < kGoalStateFloats; ++j) S[j] = a.gstate[(size_t)n * kGoalStateFloats + j];
+      } else {
+        reinterpret_cast<int*>(S)[13] = a.ep_len[n];
+      }
+      S[12] = a.prev_dones[n];
+    }
+  }
+  for (int i = lane0; i < R * per; i += 64) {
+    const int rr = i / per, c = i - rr * per;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row0 + rr < N)
+      v = ldg16(a.obs, (unsigned)((size_t)a.t0 * N + row0 + rr) * (unsigned)(DP * 4) + (unsigned)(c * 16));
+    *reinterpret_cast<f32x4*>(&lds[wb + LB::X + rr * ldx + 4 * c]) = v;
+  }
+  const uint32_t dbase = a.draw_base ? *a.draw_base : 0u, sbase = a.step_base ? *a.step_base : 0u;
+  const uint32_t ek0 = (uint32_t)a.env_seed, ek1 = (uint32_t)(a.env_seed >> 32);
+
+  for (int t = a.t0; t < a.t1; ++t) {
+    const int lane = opaque(lane0);
+    {  // standard normals of this step
+      const int ngrp = (A + 3) >> 2;
+      for (int i = lane; i < R * ngrp; i += 64) {
+        const int rr_ = i / ngrp, gq = i - rr_ * ngrp;
+        float z[4];
+        box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)gq, (uint32_t)t + dbase, 0x45505331u, (uint32_t)a.seed,
+                                  (uint32_t)(a.seed >> 32)), z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[wb + L::ZN + rr_ * 32 + 4 * gq + j] = z[j];
+      }
+    }
+    tile64_forward_ldsw<DP, WF>(wb, lane);  // h1, h2, raw head tile (policy) in the wave's region
+    // ---- Gaussian sample + log-prob (expressions and Philox counters of k_fused64_act) ----
+    for (int i = lane; i < R * A; i += 64) {
+      const int rr_ = i / A, k = i - rr_ * A;
+      const int row = row0 + rr_;
+      if (row < N) {
+        const float m = lds[wb + LB::DO + rr_ * FLDO + k] + lds[L::AC + 96 + k];
+        const float sd = lds[L::AC + k];
+        const float act = m + lds[wb + L::ZN + rr_ * 32 + k] * sd;
+        const float d = act - m;
+        lds[wb + L::TM + rr_ * 33 + k] = -(d * d) / lds[L::AC + 32 + k] - lds[L::AC + 64 + k] - 0.91893853320467274178f;
+        const float ac = fminf(fmaxf(act, a.lo), a.hi);
+        a.actions[((size_t)t * N + row) * A + k] = act;
+        a.clip_act[(size_t)row * A + k] = ac;
+        lds[wb + L::CA + rr_ * 33 + k] = ac;
+      }
+    }
+    if (lane < R && row0 + lane < N) {
+      float lp = 0.f;
+      for (int k = 0; k < A; ++k) lp += lds[wb + L::TM + lane * 33 + k];
+      a.logp[(size_t)t * N + row0 + lane] = lp;
+    }
+    // ---- env.step + auto-reset: 2 lanes per row, observation chunks sub, sub + 2, ... ----
+    const int rr = lane >> 1, sub = lane & 1;
+    const int n = row0 + rr;
+    const bool live = n < N;
+    const uint32_t step = sbase + (uint32_t)t;
+    float* S = &lds[wb + L::ST + rr * 16];
+    float* xrow = &lds[wb + LB::X + rr * ldx];
+    float* trow = &lds[wb + LB::H2 + rr * GLDH];  // terminal observation staging (h2 is dead after the head GEMM)
+    const size_t onext = ((size_t)(t + 1) * N + (live ? n : 0)) * per;
+    bool tr = false, done = false, reached = false;
+    float reward = 0.f, ep_ret = 0.f;
+    int ep_len_new = 0, ep_len_fin = 0;
+    GoalState g{};
+    if (live) {
+      if (a.kind == 1) {
+        const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, ek0, ek1);
+        const bool term = u32_to_unit_open(mr.x) < a.p_term;
+        const int len = reinterpret_cast<const int*>(S)[13] + 1;
+        tr = (len >= a.time_limit) && !term;
+        done = term || tr;
+        ep_len_new = done ? 0 : len;
+        for (int c = sub; c < per; c += 2) {
+          float z[4];
+          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, ek0, ek1), z);
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
+          if (tr) {
+            reinterpret_cast<f32x4*>(a.term_obs)[(size_t)n * per + c] = o;
+            *reinterpret_cast<f32x4*>(&trow[4 * c]) = o;
+            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
+          }
+          reinterpret_cast<f32x4*>(a.obs)[onext + c] = o;
+          *reinterpret_cast<f32x4*>(&xrow[4 * c]) = o;
+        }
+        if (sub == 0) {
+          float zz[4];
+          box_muller4(Philox4{mr.y, mr.z, mr.w, mr.x ^ 0x9E3779B9u}, zz);
+          reward = 0.03f + 0.1f * zz[0] + (term ? 5.0f : 0.f);
+        }
+      } else {
+        g = goal_load(S);
+        const GoalOutcome o = goal_advance(g, a.goal, &lds[wb + L::CA + rr * 33], A);
+        tr = o.tr; done = o.done; reached = o.reached; reward = o.reward;
+        ep_ret = g.ep_ret; ep_len_fin = g.ep_len;
+        GoalState gn = g;
+        if (done) goal_reset(gn, a.goal, o.reached, (uint32_t)n, step, ek0, ek1);
+        for (int c = sub; c < per; c += 2) {
+          float z[4];
+          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, ek0, ek1), z);
+          f32x4 ob = goal_features(g, a.goal.P, D, c, z, a.goal.noise);
+          if (done) {
+            if (tr) {
+              reinterpret_cast<f32x4*>(a.term_obs)[(size_t)n * per + c] = ob;
+              *reinterpret_cast<f32x4*>(&trow[4 * c]) = ob;
+            }
+            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
+            ob = goal_features(gn, a.goal.P, D, c, z, a.goal.noise);
+          }
+          reinterpret_cast<f32x4*>(a.obs)[onext + c] = ob;
+          *reinterpret_cast<f32x4*>(&xrow[4 * c]) = ob;
+        }
+        g = gn;
+      }
+    }
+    // every lane of the wave has consumed the old row state (program order within the wave): commit
+    const bool boot = live && sub == 0 && tr;
+    if (live && sub == 0) {
+      const size_t so = (size_t)t * N + n;
+      a.es[so] = S[12];
+      S[12] = done ? 1.f : 0.f;
+      a.trunc[n] = tr ? 1 : 0;
+      if (a.kind == 1) {
+        reinterpret_cast<int*>(S)[13] = ep_len_new;
+      } else {
+        goal_store(S, g);
+        if (done) {
+          atomicAdd(&a.ep_stats[0], 1.0);
+          atomicAdd(&a.ep_stats[1], (double)ep_ret);
+          atomicAdd(&a.ep_stats[2], (double)ep_len_fin);
+          if (reached) atomicAdd(&a.ep_stats[3], 1.0);
+        }
+      }
+      if (!tr) a.rewards[so] = reward;
+    }
+    // ---- time-limit bootstrap of the (rare) truncated rows: the wave evaluates the value MLP row by row ----
+    unsigned long long pending = __ballot(boot);
+    while (pending) {
+      const int src = __ffsll((long long)pending) - 1;  // lane that owns the truncated row
+      pending &= pending - 1;
+      const int br = src >> 1;
+      const float rw = __shfl(reward, src, 64);
+      float* sc = &lds[wb + LB::H1];  // h1 is dead: scratch h1[G1] | h2[G2]
+      const float v = value_row_wave(&lds[wb + LB::H2 + br * GLDH], sc, sc + a.bt.G1, a.bt, D, lane);
+      if (lane == 0) {
+        a.bt.term_val[row0 + br] = v;
+        a.rewards[(size_t)t * N + row0 + br] = (float)((double)rw + (double)__fmul_rn(a.bt.gamma, v));
+      }
+    }
+  }
+  // ---- carried state back to global ----
+  if (lane0 < R) {
+    const int n = row0 + lane0;
+    const float* S = &lds[wb + L::ST + lane0 * 16];
+    if (n < N) {
+      if (a.kind == 2) {
+#pragma unroll
+        for (int j = 0; j < kGoalStateFloats; ++j) a.gstate[(size_t)n * kGoalStateFloats + j] = S[j];
+      } else {
+        a.ep_len[n] = reinterpret_cast<const int*>(S)[13];
+      }
+      a.prev_dones[n] = S[12];
+    }
   }
 }
 
