@@ -250,7 +250,8 @@ def main():
         traffic = None
         tj = os.path.join(ROOT, "profiles", "r1", "hbm_traffic_pmc.json")
         if os.path.exists(tj) and not args.generic and args.workload == "doggo-4096env-2x256":
-            k = json.load(open(tj))["kernels"].get("void mobrob::k_fused_train<64>")
+            ks = json.load(open(tj))["kernels"]
+            k = next((v for n, v in ks.items() if n.startswith("void mobrob::k_fused_train<64")), None)
             traffic = k["hbm_bytes_per_launch_corrected"] if k else None
         out = {
             "metric": "env-steps/sec (whole node), doggo PPO" if "doggo" in args.workload else "env-steps/sec (whole node)",
