@@ -490,112 +490,11 @@ __global__ void k_entropy_grad(float* g_log_std, int A, float ent_coef, float b_
 }
 
 // ------------------------------------------------------------------------------------------------
-// clip_grad_norm_ + Adam [torch 2.0.1 single-tensor path; oracle clip_grad_norm / adam_step]
-// ------------------------------------------------------------------------------------------------
-// per-tensor sum of squares in f64: one block per tensor
-__global__ __launch_bounds__(1024) void k_tensor_sqnorm(const float* __restrict__ grads,
-                                                        const int* __restrict__ offsets, int ntensors,
-                                                        double* __restrict__ out) {
-  __shared__ double sc[16];
-  const int t = blockIdx.x;
-  const int s = offsets[t], e = offsets[t + 1];
-  double a = 0.0;
-  for (int i = s + threadIdx.x; i < e; i += blockDim.x) {
-    const double x = (double)grads[i];
-    a += x * x;
-  }
-  const double tot = block_sum_d(a, sc);
-  if (threadIdx.x == 0) out[t] = tot;
-}
-
-struct AdamArgs {
-  float* p; float* g; float* m; float* v;
-  int P;
-  const double* tensor_sq; int ntensors;
-  float max_norm;
-  float step_size;      // lr / (1 - beta1^t)
-  float bc2_sqrt;       // sqrt(1 - beta2^t)
-  float beta1, beta2, eps;
-  float* stats_row;     // [8] row of this step: [6] <- total grad norm ; finalised losses
-  const float* loss_sums; float ent_coef, vf_coef, inv_bg; const float* log_std; int A;
-};
-
-__global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
-  // total norm = norm of per-tensor norms (torch: torch.norm(torch.stack(norms)))
-  float tot_sq = 0.f;
-  for (int t = 0; t < a.ntensors; ++t) {
-    const float nt = (float)sqrt(a.tensor_sq[t]);
-    tot_sq += nt * nt;
-  }
-  const float total = sqrtf(tot_sq);
-  const float coef = fminf(a.max_norm / (total + 1e-6f), 1.0f);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0 && a.stats_row != nullptr) {
-    const float pl = -a.loss_sums[0] * a.inv_bg;
-    const float vl = a.loss_sums[1] * a.inv_bg;
-    float ent = 0.f;
-    for (int k = 0; k < a.A; ++k) ent += (0.5f + 0.91893853320467274178f) + logf(expf(a.log_std[k]));
-    const float el = -(ent * a.loss_sums[4]) * a.inv_bg;
-    a.stats_row[0] = pl;
-    a.stats_row[1] = vl;
-    a.stats_row[2] = el;
-    a.stats_row[3] = pl + a.ent_coef * el + a.vf_coef * vl;
-    a.stats_row[4] = a.loss_sums[2] * a.inv_bg;
-    a.stats_row[5] = a.loss_sums[3] * a.inv_bg;
-    a.stats_row[6] = total;
-    a.stats_row[7] = 0.f;
-  }
-  if (i >= a.P) return;
-  const float g = a.g[i] * coef;
-  const float m = a.m[i] * a.beta1 + (1.0f - a.beta1) * g;
-  const float v = a.v[i] * a.beta2 + (1.0f - a.beta2) * (g * g);
-  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-  a.p[i] = a.p[i] - a.step_size * (m / denom);
-  a.m[i] = m;
-  a.v[i] = v;
-}
-
-// ------------------------------------------------------------------------------------------------
 // Device-resident synthetic env source.  One thread per (env, 4 obs features).
 // state: ep_len[N].  Writes next obs into rollout slot t+1, reward/done/trunc flags, terminal obs rows.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_env_step(uint64_t seed, uint32_t step, int N, int D, int Dp, float p_term, int time_limit,
-                           int* __restrict__ ep_len, float* __restrict__ obs_next, float* __restrict__ term_obs,
-                           float* __restrict__ rewards, float* __restrict__ dones_f, uint8_t* __restrict__ trunc) {
-  const int per = Dp / 4;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * per) return;
-  const int n = i / per, c = i - n * per;
-  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-  // env-level draws (identical for every chunk thread of the env)
-  const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, k0, k1);
-  const bool term = u32_to_unit_open(mr.x) < p_term;
-  const int len = ep_len[n] + 1;
-  const bool tr = (len >= time_limit) && !term;
-  const bool done = term || tr;
-  float z[4];
-  const Philox4 orr = philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, k0, k1);
-  box_muller4(orr, z);
-  f32x4 o;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
-  if (tr) {  // the observation the episode ended on; the stored next obs is the post-reset one
-    reinterpret_cast<f32x4*>(term_obs)[(size_t)n * per + c] = o;
-    const Philox4 rr = philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, k0, k1);
-    box_muller4(rr, z);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
-  }
-  reinterpret_cast<f32x4*>(obs_next)[(size_t)n * per + c] = o;
-  if (c == 0) {
-    float zz[4];
-    box_muller4(Philox4{mr.y, mr.z, mr.w, mr.x ^ 0x9E3779B9u}, zz);
-    rewards[n] = 0.03f + 0.1f * zz[0] + (term ? 5.0f : 0.f);
-    dones_f[n] = done ? 1.f : 0.f;
-    trunc[n] = tr ? 1 : 0;
-  }
-}
-// One-launch variant used by the device-resident rollout: env draw + rollout_buffer.add scalars.
+// Per-step kernel of the device-resident rollout (the persistent kernels of kernels_rollout.h inline the same
+// rules): env draw + rollout_buffer.add scalars.
 // ep_len is double buffered (every chunk thread of an env must see the OLD value); the time-limit
 // bootstrap of the (rare) truncated rows is applied in the same launch (see below).
 __global__ void k_add_counters(uint32_t* ctr, uint32_t d0, uint32_t d1) {
@@ -689,11 +588,6 @@ __global__ __launch_bounds__(256) void k_env_step_store(uint64_t seed, uint32_t 
     }
     __syncthreads();
   }
-}
-// ep_len update is a separate tiny kernel so that every chunk thread above sees the same old value
-__global__ void k_env_advance(int N, const float* __restrict__ dones_f, int* __restrict__ ep_len) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n < N) ep_len[n] = dones_f[n] != 0.f ? 0 : ep_len[n] + 1;
 }
 __global__ void k_env_reset(uint64_t seed, int N, int D, int Dp, float* __restrict__ obs0, int* __restrict__ ep_len) {
   const int per = Dp / 4;

@@ -261,13 +261,16 @@ def test_device_rollout_time_limit_bootstrap(H):
 
 
 @pytest.mark.parametrize("kind", ["synthetic", "goal"])
-@pytest.mark.parametrize("H,D,A,N", [(256, 58, 12, 200), (256, 26, 2, 64), (256, 12, 18, 33), (64, 14, 2, 100), (64, 43, 2, 37)])
-def test_persistent_rollout_equals_per_step_rollout(kind, H, D, A, N):
+@pytest.mark.parametrize("H,D,A,N,T", [(256, 58, 12, 200, 24), (256, 26, 2, 64, 24), (256, 12, 18, 33, 24),
+                                       (256, 43, 2, 6200, 18),   # 194 rollout blocks: no side-stream overlap, Dp = 48
+                                       (256, 58, 12, 70, 40),    # 3 chunks of 16 steps + a short one
+                                       (64, 14, 2, 100, 24), (64, 43, 2, 37, 24), (64, 58, 12, 300, 10)])
+def test_persistent_rollout_equals_per_step_rollout(kind, H, D, A, N, T):
     """One persistent launch for all T steps vs one launch per step: same Philox counters, same arithmetic ->
     bit-identical rollout buffers (observations, actions, log-probs, rewards incl. bootstrap, episode starts);
     values come from the batched pass and agree to float tolerance; two consecutive rollouts (carried state)."""
     from mobrob_amd.envs.vec_env import DeviceGoalVecEnv
-    T, TL = 24, 7
+    TL = 7
     p = O.init_params(D, A, (H, H), (H, H), seed=8)
     p["value_net.bias"] = np.array([2.0], np.float32)
     res = {}
