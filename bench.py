@@ -29,7 +29,8 @@ WORKLOADS = {
     # name: obs, act, hidden, envs/GPU, T, E, minibatch/GPU, p_term, time_limit
     "doggo-4096env-2x256": dict(D=58, A=12, H=256, N=4096, T=1000, E=5, B=65536, p_term=1 / 107.0, tl=1000),
     "point-1024env-2x64": dict(D=14, A=2, H=64, N=1024, T=2048, E=10, B=65536, p_term=1 / 119.0, tl=1000),
-    "doggo-ref-16env-2x64": dict(D=58, A=12, H=64, N=16, T=1000, E=5, B=100, p_term=1 / 107.0, tl=1000),
+    # BASELINE.md §3 B1 "reference-shaped": data/configs/doggo-ppo.yaml, CPU baseline on ONE thread (examples/train.py:13)
+    "doggo-ref-16env-2x64": dict(D=58, A=12, H=64, N=16, T=1000, E=5, B=100, p_term=1 / 107.0, tl=1000, cpu_threads=1),
     # BASELINE configs[4]: mixed fleet, ragged obs/act dims packed into one rollout arena (mobrob_amd/fleet.py)
     "fleet-car-drone-turtlebot3-2x64": dict(segments=["car", "drone", "turtlebot3"], H=64, N=1024, T=2048, E=10,
                                             B=65536, tl=1000),
@@ -50,13 +51,16 @@ def init_params(D, A, H, seed):
 def cpu_baseline(w, budget_s=20.0):
     """The CPU oracle (SB3-semantics NumPy restatement) on a bounded sample of the same workload."""
     from oracle import ppo_oracle as O
+    limiter = None
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
+        if w.get("cpu_threads"):
+            limiter = threadpool_limits(limits=int(w["cpu_threads"]))
         cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [os.cpu_count() or 1])
     except Exception:
         cores = os.cpu_count() or 1
     D, A, H, N = w["D"], w["A"], w["H"], w["N"]
-    Ts = max(2, min(w["T"], int(np.ceil(w["B"] / N))))  # at least one full minibatch
+    Ts = w["T"] if N * w["T"] <= 65536 else max(2, min(w["T"], int(np.ceil(w["B"] / N))))  # >= one full minibatch
     p = O.init_params(D, A, (H, H), (H, H), seed=0)
     h = O.Hyper(n_epochs=w["E"], batch_size=w["B"], ent_coef=0.01)
     rng = np.random.default_rng(0)
@@ -74,6 +78,8 @@ def cpu_baseline(w, budget_s=20.0):
         el = time.perf_counter() - t0
         if el > budget_s or el + el / reps > 1.5 * budget_s:
             break
+    if limiter is not None:
+        limiter.restore_original_limits()
     return {"value": done_steps / el, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
             "sample": f"{reps} x (rollout {Ts} steps x {N} envs + {h.n_epochs} epochs, minibatch {w['B']}) "
                       f"= {done_steps} env-steps of the NumPy oracle in {el:.1f} s"}

@@ -842,7 +842,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   const int tid = tid0, lane = tid & 63;
   // ---- store this workgroup's partial gradients to its slab ----
   STAMP(22)
-  {
+  if (PHASE_ON(16384) || blockIdx.x < 2) {  // (ablation bit 16384: only two workgroups write their slabs)
     asm volatile("s_nop 15\n\ts_nop 3");  // last asm MFMA's D -> v_accvgpr_read (16-pass XDL)
     {  // dW1 / dW3 tiles, fragment order: [w][tile][quad][lane] x 16 B
       const unsigned s1 = (unsigned)(wave * 4 * 4 * 64 + lane) * 16u, s3 = (unsigned)(wave * 2 * 4 * 64 + lane) * 16u;

@@ -1,11 +1,15 @@
 """fixed vs per-tile cost of k_fused_train: time launches for 1, 2, 4, 8 tiles per workgroup"""
 import sys, numpy as np
 sys.path.insert(0, '.')
+import os
+from mobrob_amd import _lib
+if len(sys.argv) > 1:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 from mobrob_amd.engine import PPOEngine
 from mobrob_amd.rl_control.init import orthogonal_policy_init
 D, A, H, N, T = 58, 12, 256, 4096, 64
 res = []
-for B in (8192, 16384, 32768, 65536, 131072):
+for B in (8192, 16384, 65536):
     e = PPOEngine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=4, pi=(H, H), vf=(H, H), ent_coef=0.01)
     e.set_params(orthogonal_policy_init(D, A, (H, H), (H, H), 0))
     e.collect_synthetic()

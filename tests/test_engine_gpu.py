@@ -196,6 +196,48 @@ def test_host_rollout_matches_oracle():
     e.close()
 
 
+@pytest.mark.parametrize("H", [64, 256])
+def test_three_learn_iterations_match_oracle(H):
+    """OnPolicyAlgorithm.learn for three iterations -- collect (with carried last_obs / episode starts), GAE, all
+    epochs of minibatch updates -- engine vs oracle on the same env stream, action noise and permutations."""
+    D, A, N, T, B, E, ITERS = 26, 2, 10, 16, 40, 2, 3
+    p0 = O.init_params(D, A, (H, H), (H, H), seed=12)
+    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=E, batch_size=B)
+    rng = np.random.default_rng(5)
+    eps = rng.standard_normal((ITERS, T, N, A)).astype(np.float32)
+    perms = np.stack([[rng.permutation(T * N) for _ in range(E)] for _ in range(ITERS)])
+    # oracle
+    po = {k: v.copy() for k, v in p0.items()}
+    st = O.AdamState.zeros_like(po)
+    env_a = O.NumpySyntheticVecEnv(N, D, A, p_term=0.08, time_limit=9, seed=1)
+    obs_a, starts = env_a.reset(), np.ones(N, bool)
+    for it in range(ITERS):
+        buf, obs_a, starts = O.collect_rollout(po, env_a, obs_a, starts, T, h, lambda t: eps[it, t])
+        O.train(po, st, buf, h, perms[it])
+    # engine, host path
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H),
+                    gamma=h.gamma, gae_lambda=h.gae_lambda, ent_coef=h.ent_coef)
+    e.set_params(p0)
+    env_b = O.NumpySyntheticVecEnv(N, D, A, p_term=0.08, time_limit=9, seed=1)
+    obs = env_b.reset()
+    for it in range(ITERS):
+        e.rollout_begin()
+        for t in range(T):
+            _, a_clip, _, _ = e.act(obs, eps[it, t])
+            obs, rew, done, trunc, term_obs = env_b.step(a_clip)
+            e.store(rew, done, trunc, term_obs)
+        e.finish_rollout(obs, done)
+        e.train(perms[it])
+    got = e.get_params()
+    for k in po:
+        assert np.max(np.abs(got[k] - po[k])) < 1e-4, (k, float(np.max(np.abs(got[k] - po[k]))))
+    m, v, step = e.get_optimizer_state()
+    assert step == ITERS * E * (T * N // B)
+    for k in po:
+        assert scaled_err(m[k], st.exp_avg[k]) < 1e-3 and scaled_err(v[k], st.exp_avg_sq[k]) < 1e-3, k
+    e.close()
+
+
 def test_synthetic_collect_statistics_and_consistency():
     """Device-resident env source: statistics of the generator and self-consistency of the stored rollout."""
     D, A, N, T = 58, 12, 512, 64
@@ -296,6 +338,29 @@ def test_persistent_rollout_equals_per_step_rollout(kind, H, D, A, N, T):
         assert np.max(np.abs(a["values"] - b["values"])) < 1e-4 and np.max(np.abs(a["last_values"] - b["last_values"])) < 1e-4
         assert np.max(np.abs(a["advantages"] - b["advantages"])) < 1e-3
         assert a["episode_starts"][1:].sum() > 0  # the comparison covers resets and truncations
+
+
+def test_rollouts_beyond_4gib_use_the_64bit_generic_kernels():
+    """Maximum sizes: the fused kernels address rollout rows with 32-bit byte offsets; an observation buffer of
+    >= 4 GiB must fall back to the generic (64-bit indexed) kernels and still match the oracle."""
+    D, A, H, N, T = 58, 12, 256, 8192, 2050   # obs: 2051 * 8192 * 64 * 4 B = 4.3 GB
+    p = O.init_params(D, A, (H, H), (H, H), seed=5)
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=65536, n_epochs=1, pi=(H, H), vf=(H, H), seed=2)
+    e.set_params(p)
+    # write one rollout step worth of data at the END of the buffers (beyond the 4 GiB mark) through the host path
+    rng = np.random.default_rng(0)
+    e.rollout_begin()
+    obs = rng.standard_normal((N, D)).astype(np.float32)
+    raw, clipped, values, logp = e.act(obs)
+    mean, val = O.policy_outputs(p, obs)
+    assert scaled_err(values, val) < 1e-4
+    assert np.allclose(logp, O.gaussian_log_prob(mean, p["log_std"], raw), rtol=1e-4, atol=1e-3)
+    # the profile ids of the fused path must stay silent: this engine runs the generic GEMM chain
+    e.profile(True)
+    e.act(obs)
+    e.synchronize()
+    assert e.profile_read()["act"][1] >= 1
+    e.close()
 
 
 def test_error_paths():
