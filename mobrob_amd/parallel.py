@@ -41,14 +41,21 @@ def device_tensor(ptr: int, shape, dtype: torch.dtype, device) -> torch.Tensor:
 
 
 class EngineBackend:
-    """Adapter: mobrob_amd.engine.PPOEngine -> the protocol above (device buffers exposed as torch tensors,
-    engine kernels enqueued on torch's current stream so that collectives are stream-ordered)."""
+    """Adapter: mobrob_amd.engine.PPOEngine -> the protocol above (device buffers exposed as torch tensors).
+
+    Stream ordering: the engine's kernels and the collectives must be ordered on ONE stream.  torch's default
+    stream has the handle 0, which `mobrob_ppo_set_stream` reads as "use your own stream", so the backend always
+    owns a dedicated `torch.cuda.Stream`: the engine adopts it, and `train_data_parallel` issues the collectives
+    with that stream current (ProcessGroupNCCL orders its RCCL launch after the current stream's work and makes
+    the current stream wait for the result)."""
 
     def __init__(self, engine, device=None):
         self.e = engine
         self.device = torch.device("cuda", engine.cfg.device_id) if device is None else device
         torch.cuda.set_device(self.device)
-        self.e.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        cur = torch.cuda.current_stream(self.device)
+        self.stream = cur if cur.cuda_stream != 0 else torch.cuda.Stream(self.device)
+        self.e.set_stream(self.stream.cuda_stream)
         gp, gb = engine.device_buffer("grads")
         ap, ab = engine.device_buffer("advstat")
         self._grad = device_tensor(gp, (gb // 4,), torch.float32, self.device)
@@ -77,6 +84,15 @@ def train_data_parallel(backend, perms=None, group=None, force_collectives=False
     force_collectives issues the all-reduces even at world size 1 (plumbing self-test)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     comm = world > 1 or (force_collectives and dist.is_initialized())
+    stream = getattr(backend, "stream", None)
+    if stream is not None:  # GPU backend: collectives are issued with the engine's stream current
+        with torch.cuda.stream(stream):
+            _update_loop(backend, perms, group, comm)
+    else:
+        _update_loop(backend, perms, group, comm)
+
+
+def _update_loop(backend, perms, group, comm):
     for ep in range(backend.n_epochs):
         backend.epoch_begin(None if perms is None else perms[ep])
         if comm:

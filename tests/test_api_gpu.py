@@ -110,3 +110,40 @@ def test_device_env_learn_and_engine_backend_equivalence():
     e.minibatch_grad(0)
     e.synchronize()
     assert np.array_equal(be.grad_tensor().cpu().numpy(), e.read("grads"))  # zero-copy view of the engine buffer
+
+
+def test_torch_ops_between_grad_and_apply_are_stream_ordered_with_the_engine():
+    """The data-parallel loop relies on torch ops (the RCCL all-reduce) being ordered between minibatch_grad and
+    minibatch_apply on the backend's stream.  Stand-in for the collective: zero / double the gradient in place."""
+    import torch
+    from mobrob_amd.engine import PPOEngine
+    from mobrob_amd.parallel import EngineBackend
+    from mobrob_amd.rl_control.init import orthogonal_policy_init
+    D, A, H, N, T = 58, 12, 256, 512, 16
+    e = PPOEngine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=N * T, n_epochs=1, pi=(H, H), vf=(H, H), seed=3)
+    e.set_params(orthogonal_policy_init(D, A, (H, H), (H, H), 0))
+    be = EngineBackend(e)
+    assert be.stream.cuda_stream != 0  # never the legacy default stream: handle 0 would mean "engine-owned stream"
+    e.collect_synthetic(p_term=0.05, time_limit=50)
+    p0 = e.get_flat_params()
+    for _ in range(5):  # (a) gradient zeroed by a torch op -> Adam must see exactly zero: parameters do not move
+        with torch.cuda.stream(be.stream):
+            be.epoch_begin(None)
+            be.minibatch_grad(0)
+            be.grad_tensor().zero_()
+            be.minibatch_apply()
+    e.synchronize()
+    assert np.array_equal(e.get_flat_params(), p0)
+    # (b) x2 on the torch side == the engine's own gradient doubled (global-norm clip makes the update identical
+    #     once the norm exceeds max_grad_norm, so compare the gradients that apply() consumed via the stats row)
+    with torch.cuda.stream(be.stream):
+        be.epoch_begin(None)
+        be.minibatch_grad(0)
+        g1 = be.grad_tensor().clone()
+        be.grad_tensor().mul_(2.0)
+        be.minibatch_apply()
+    rows = e.fetch_step_stats()
+    torch.cuda.synchronize()
+    n1 = float(torch.sqrt(sum((g1[a:b].double() ** 2).sum() for a, b in [(0, e.P)])))
+    assert abs(rows[-1][6] - 2.0 * n1) < 1e-3 * max(1.0, n1)  # grad_norm logged by apply() saw the doubled gradient
+    e.close()
