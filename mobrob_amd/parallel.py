@@ -27,6 +27,23 @@ import torch
 import torch.distributed as dist
 
 
+def distributed_context(init=True):
+    """(world_size, rank, local_rank) of this process.  An already initialised process group wins; otherwise the
+    torchrun environment (WORLD_SIZE / RANK / LOCAL_RANK, rendezvous on MASTER_ADDR -- use 127.0.0.1 on one node) is
+    used to initialise the "nccl" (= RCCL) group, one process per GPU."""
+    import os
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank(), int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or not init:
+        return 1, 0, int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return dist.get_world_size(), dist.get_rank(), local
+
+
 class _DevArray:
     """__cuda_array_interface__ view of an engine-owned device buffer (zero-copy into torch)."""
 

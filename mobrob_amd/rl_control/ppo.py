@@ -212,6 +212,7 @@ class PPO:
             raise ValueError("PPO needs an environment (or load a checkpoint with PPO.load)")
         self.engine = None
         self.policy = None
+        self.world_size, self.rank, self._backend = 1, 0, None
         if _init_setup_model:
             self._setup_model()
 
@@ -224,8 +225,15 @@ class PPO:
                   gamma=self.gamma, gae_lambda=self.gae_lambda, clip_range=self.clip_range, ent_coef=self.ent_coef,
                   vf_coef=self.vf_coef, max_grad_norm=self.max_grad_norm, learning_rate=self.learning_rate,
                   normalize_advantage=self.normalize_advantage, seed=0 if self.seed is None else int(self.seed))
+        # data parallel: under torchrun / an initialised process group every rank owns its n_envs
+        # environments and rollout shard; batch_size stays SB3's GLOBAL minibatch and must divide by the world size
+        from ..parallel import distributed_context
+        self.world_size, self.rank, local_rank = distributed_context()
+        if self.world_size > 1:
+            kw.update(rank=self.rank, world_size=self.world_size, device_id=local_rank)
         kw.update(self._engine_kwargs)
         self.engine = PPOEngine(**kw)
+        self._backend = None
         self.engine.set_params(orthogonal_policy_init(self.obs_dim, self.act_dim, self.net_arch[0], self.net_arch[1],
                                                       seed=0 if self.seed is None else int(self.seed)))
         self.policy = ActorCriticPolicyHandle(self)
@@ -260,7 +268,7 @@ class PPO:
             else:
                 e.collect_synthetic(env.p_term, env.time_limit)
             for _ in range(self.n_steps):
-                self.num_timesteps += N
+                self.num_timesteps += N * self.world_size  # time/total_timesteps counts the whole job
                 if not callback.on_step():
                     return False
             callback.on_rollout_end()
@@ -270,7 +278,7 @@ class PPO:
         for _ in range(self.n_steps):
             _, clipped, _, _ = e.act(self._last_obs, want_all=False)
             new_obs, rewards, dones, infos = env.step(clipped)
-            self.num_timesteps += N
+            self.num_timesteps += N * self.world_size
             if not callback.on_step():
                 return False
             trunc, term_obs = None, None
@@ -289,7 +297,23 @@ class PPO:
         return True
 
     def train(self):
-        stats = self.engine.train(None)
+        if self.world_size > 1:
+            import torch
+            import torch.distributed as dist
+            from ..parallel import EngineBackend, train_data_parallel
+            if self._backend is None:
+                self._backend = EngineBackend(self.engine)
+            train_data_parallel(self._backend)
+            stats = self.engine.train_stats()
+            # every rank logged local sums / B_global: the sum over ranks is the global mean (grad_norm is already global)
+            keys = [k for k in stats if k != "grad_norm"]
+            t = torch.tensor([stats[k] for k in keys], dtype=torch.float64,
+                             device=self._backend.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t)
+            stats.update({k: float(v) for k, v in zip(keys, t.tolist())})
+            stats["n_minibatches"] = self.n_epochs * self.engine.n_minibatches
+        else:
+            stats = self.engine.train(None)
         self._n_updates += self.n_epochs
         return stats
 
@@ -366,7 +390,10 @@ class PPO:
                     normalize_advantage=self.normalize_advantage, n_envs=self.n_envs)
 
     def save(self, path):
-        """SB3-layout zip (checkpoint.py); appends .zip like SB3 when the suffix is missing."""
+        """SB3-layout zip (checkpoint.py); appends .zip like SB3 when the suffix is missing.  Data-parallel replicas
+        are identical: only rank 0 writes."""
+        if getattr(self, "rank", 0) != 0:
+            return
         m, v, step = self.engine.get_optimizer_state()
         d = os.path.dirname(str(path))
         if d:
@@ -438,13 +465,16 @@ class PPOCtrl:
         self.env_name = env_name
         self.time_limit = time_limit
         self.n_env = n_env
+        from ..parallel import distributed_context
+        _, rank, _ = distributed_context()
+        env_seed = seed + 1000 * rank  # data-parallel ranks own different environments (the model seed stays shared)
         if vec_env_type in ("subproc", "dummy"):
             vec_env = make_vec_env(get_env, n_envs=n_env,
                                    env_kwargs={"env_name": env_name, "enable_gui": enable_gui,
                                                "terminate_on_goal": True, "time_limit": time_limit},
-                                   vec_env_cls=HostVecEnv, seed=seed)
+                                   vec_env_cls=HostVecEnv, seed=env_seed)
         elif vec_env_type == "synthetic":
-            vec_env = SyntheticVecEnv.for_robot(env_name, n_env, time_limit, seed)
+            vec_env = SyntheticVecEnv.for_robot(env_name, n_env, time_limit, env_seed)
         elif vec_env_type == "device":
             vec_env = DeviceSyntheticVecEnv.for_robot(env_name, n_env, time_limit, seed)
         elif vec_env_type == "device_goal":

@@ -82,3 +82,45 @@ def test_two_engine_ranks_equal_single_process_union_batch(case, tmp_path):
             O.train_minibatch(p, st, batch, h)
     ref = O.flatten_params(p)
     assert np.max(np.abs(ref - r[0])) < 1e-4, float(np.max(np.abs(ref - r[0])))
+
+
+def _learn_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mobrob_amd.rl_control.ppo import PPOCtrl
+    cfg = {"ppo_kwargs": {"policy": "MlpPolicy", "n_steps": 64, "batch_size": 4096, "n_epochs": 4, "gamma": 0.99,
+                          "gae_lambda": 0.95, "ent_coef": 0.0, "clip_range": 0.2,
+                          "policy_kwargs": {"net_arch": {"pi": [64, 64], "vf": [64, 64]}}},
+           "env_name": "point", "time_limit": 100, "n_envs": 128, "vec_env_type": "device_goal", "enable_gui": False,
+           "seed": 0}
+    ctrl = PPOCtrl.from_config(cfg)
+    ppo = ctrl.ppo
+    assert ppo.world_size == world and ppo.rank == rank
+    hist = []
+    for _ in range(25):
+        ppo.learn(total_timesteps=64 * 128 * world, reset_num_timesteps=False)
+        st = ppo.device_episode_stats
+        hist.append((st["episodes"], st["goals"]))
+    ctrl.save_model(out.format(rank="model"))  # only rank 0 writes
+    np.savez(out.format(rank=rank), flat=ppo.engine.get_flat_params(), hist=np.array(hist), steps=ppo.num_timesteps,
+             obs0=ppo.engine.read("obs")[0])
+    ppo.engine.close()
+    dist.destroy_process_group()
+
+
+def test_ppo_learn_is_data_parallel_under_a_process_group(tmp_path):
+    """examples/train.py under torchrun: PPOCtrl picks the process group up, shards the envs, all-reduces the gradient;
+    both replicas end with identical weights although they saw different environments, and the task is learned."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    out = str(tmp_path / "r{rank}.npz")
+    mp.spawn(_learn_worker, args=(world, port, out), nprocs=world, join=True)
+    r = [np.load(out.format(rank=i)) for i in range(world)]
+    assert np.array_equal(r[0]["flat"], r[1]["flat"])
+    assert not np.array_equal(r[0]["obs0"], r[1]["obs0"])          # different env shards
+    assert int(r[0]["steps"]) == 25 * 64 * 128 * world              # time/total_timesteps counts the whole job
+    assert os.path.exists(out.format(rank="model") + ".zip") or os.path.exists(out.format(rank="model"))
+    h = r[0]["hist"].astype(np.float64)
+    first, last = h[:4].sum(0), h[-4:].sum(0)
+    assert last[1] / max(last[0], 1) > first[1] / max(first[0], 1) + 0.2, (first, last)
