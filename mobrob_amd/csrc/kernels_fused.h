@@ -1318,17 +1318,21 @@ __device__ __forceinline__ int pack_bwd_idx(int krow, int j, int KG) {
 
 __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
   __shared__ double part[256];
+  __shared__ int tens[256];
   __shared__ float coef_s, total_s;
-  for (int c = threadIdx.x; c < a.nchunks; c += blockDim.x) part[c] = a.partial[c];
+  for (int c = threadIdx.x; c < a.nchunks; c += blockDim.x) {  // one parallel round trip; the serial fold below is LDS only
+    part[c] = a.partial[c];
+    tens[c] = a.chunks[c].tensor;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     // total norm = norm of per-tensor norms (torch.norm(torch.stack(norms))), chunks are sorted by tensor
     float tot_sq = 0.f;
     int c = 0;
     while (c < a.nchunks) {
-      const int t = a.chunks[c].tensor;
+      const int t = tens[c];
       double ts = 0.0;
-      while (c < a.nchunks && a.chunks[c].tensor == t) ts += part[c++];
+      while (c < a.nchunks && tens[c] == t) ts += part[c++];
       const float nt = (float)sqrt(ts);
       tot_sq += nt * nt;
     }
