@@ -265,44 +265,79 @@ __global__ __launch_bounds__(Lay64<DP>::TNWV * 64, 1) void k_fused64_train(Fused
     adv_sd = (float)sqrt(var);
   }
 
+  // software-pipelined gather (one wave has nothing else to hide global latency with): xr holds the observation
+  // rows of the tile about to be processed, nsrc the row indices of the tile after it
+  constexpr int NGW = GR * per / 64;
+  static_assert((GR * per) % 64 == 0, "gather assumes a whole number of 16-byte chunks per lane");
+  f32x4 xr[NGW];
+  int nsrc[NGW];
+#pragma unroll
+  for (int u = 0; u < NGW; ++u) {
+    const int i = (tid0 & 63) + u * 64, rr = i / per, c = i - rr * per;
+    xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (widx < ntiles && widx * GR + rr < a.count)
+      xr[u] = ldg16(a.obs, (unsigned)a.rows[widx * GR + rr] * (unsigned)(DP * 4) + (unsigned)(c * 16));
+  }
   for (int tile = widx; tile < ntiles; tile += nw) {
     const int lane = opaque(tid0) & 63;
     const int r = lane & 31, h = lane >> 5;
     const int row0 = tile * GR;
-    // ---- gather 32 observation rows (zero beyond the minibatch) ----
+    // ---- the observation rows of this tile were fetched during the previous tile ----
 #pragma unroll
-    for (int i = lane; i < GR * per; i += 64) {
-      const int rr = i / per, c = i - rr * per;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row0 + rr < a.count)
-        v = ldg16(a.obs, (unsigned)a.rows[row0 + rr] * (unsigned)(DP * 4) + (unsigned)(c * 16));
-      *reinterpret_cast<f32x4*>(&lds[wb + L::X + rr * ldx + 4 * c]) = v;
+    for (int u = 0; u < NGW; ++u) {
+      const int i = lane + u * 64, rr = i / per, c = i - rr * per;
+      *reinterpret_cast<f32x4*>(&lds[wb + L::X + rr * ldx + 4 * c]) = xr[u];
+    }
+    const int nrow0 = (tile + nw) * GR;
+#pragma unroll
+    for (int u = 0; u < NGW; ++u) {
+      const int rr = (lane + u * 64) / per;
+      nsrc[u] = (tile + nw < ntiles && nrow0 + rr < a.count) ? a.rows[nrow0 + rr] : -1;
+    }
+    // operands of the loss stage (two lanes per row), in flight while the forward pass runs
+    const bool llive = row0 + r < a.count;
+    float l_adv = 0.f, l_old = 0.f, l_act[16];
+    {
+      const unsigned src = llive ? (unsigned)a.rows[row0 + r] : 0u;
+      if (net == 0) {
+        const float* arow = a.actions + (size_t)src * a.A + h;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) l_act[j] = (2 * j + h < a.A && llive) ? arow[2 * j] : 0.f;
+        if (llive) { l_adv = a.adv[src]; l_old = a.old_logp[src]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) l_act[j] = 0.f;
+        if (llive) l_old = a.ret[src];
+      }
     }
     tile64_forward_ldsw<DP>(wb, lane);
 
     // ---- loss: two lanes per row (q = action parity); dL/d(head) -> head tile, zero padded ----
     {
       const int rr = r, q = h;
-      const bool live = row0 + rr < a.count;
-      const unsigned src = live ? (unsigned)a.rows[row0 + rr] : 0u;
+      const bool live = llive;
       const int db = opaque(wb + L::DO + rr * FLDO + q);
       const int cb = opaque(L::TCST + q);
       const int gb = opaque(wb + L::GACC + q);
       const int A = a.A;
       if (net == 0) {
-        const float* arow = a.actions + (size_t)src * A + q;
         float lp = 0.f;
-        if (live)
-          for (int j = 0; 2 * j + q < A; ++j) {
-            const float d = arow[2 * j] - (lds[db + 2 * j] + lds[cb + 64 + 2 * j]);
+        float dk[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          float d = 0.f;
+          if (2 * j + q < A && live) {
+            d = l_act[j] - (lds[db + 2 * j] + lds[cb + 64 + 2 * j]);
             lp += -(d * d) * (0.5f * lds[cb + 2 * j]) - lds[cb + 32 + 2 * j];
           }
+          dk[j] = d;
+        }
         lp += __shfl_xor(lp, 32, 64);
         float g_logp = 0.f;
         if (live) {
-          float adv = a.adv[src];
+          float adv = l_adv;
           if (a.normalize && adv_on) adv = (adv - adv_mean) / (adv_sd + 1e-8f);
-          const float log_ratio = lp - a.old_logp[src];
+          const float log_ratio = lp - l_old;
           const float ratio = expf(log_ratio);
           const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
           const float s1 = adv * ratio, s2 = adv * fminf(fmaxf(ratio, lo), hi);
@@ -315,12 +350,13 @@ __global__ __launch_bounds__(Lay64<DP>::TNWV * 64, 1) void k_fused64_train(Fused
           const float w1 = (s1 < s2) ? 1.f : ((s1 > s2) ? 0.f : 0.5f);
           g_logp = -(w1 * adv + (1.0f - w1) * adv * in_range) * a.inv_bg * ratio;
         }
+#pragma unroll
         for (int j = 0; j < 16; ++j) {  // k = 2j + q; wave-uniform trip count
           const int k = 2 * j + q;
           float gm = 0.f, gl = 0.f;
           if (k < A && live) {
             const float iv = lds[cb + 2 * j];
-            const float d = arow[2 * j] - (lds[db + 2 * j] + lds[cb + 64 + 2 * j]);
+            const float d = dk[j];
             gm = g_logp * d * iv;
             gl = g_logp * (d * d * iv - 1.0f);
           }
@@ -340,7 +376,7 @@ __global__ __launch_bounds__(Lay64<DP>::TNWV * 64, 1) void k_fused64_train(Fused
       } else {
         float dv = 0.f;
         if (live && q == 0) {
-          const float v = lds[db] + lds[cb + 64], rt = a.ret[src];
+          const float v = lds[db] + lds[cb + 64], rt = l_old;
           s_vl += (rt - v) * (rt - v);
           dv = a.vf_coef * 2.0f * (v - rt) * a.inv_bg;
         }
@@ -380,6 +416,12 @@ __global__ __launch_bounds__(Lay64<DP>::TNWV * 64, 1) void k_fused64_train(Fused
         s1 += lds[o + (rr + 1) * GLDH];
       }
       gb2 += s0 + s1;
+    }
+#pragma unroll
+    for (int u = 0; u < NGW; ++u) {  // next tile's observation rows: in flight during dW2 / dh1 / dW1
+      const int c = (lane + u * 64) % per;
+      xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (nsrc[u] >= 0) xr[u] = ldg16(a.obs, (unsigned)nsrc[u] * (unsigned)(DP * 4) + (unsigned)(c * 16));
     }
     // ---- dW2 += dz2^T . h1  (64 x 64, K = 32 rows) ----
     {
