@@ -129,3 +129,34 @@ def test_ppo_learns_to_reach_goals_on_the_device_env():
     assert goal_rate_last > 0.9 and goal_rate_last > goal_rate_first + 0.3, (goal_rate_first, goal_rate_last, hist[-1])
     assert np.nanmean(last[:, 3]) < 0.6 * np.nanmean(first[:, 3]), (first[:, 3], last[:, 3])
     assert np.nanmean(last[:, 2]) > np.nanmean(first[:, 2]) + 1.0
+
+
+def test_policy_trained_on_the_device_env_solves_the_host_env(tmp_path, monkeypatch):
+    """Device goal env == host `KinematicGoalEnv` task: train on the GPU env, save an SB3 zip, load it through
+    `load_policy` (examples/control.py path) and roll it out deterministically on the HOST environment."""
+    import mobrob_amd.utils as U
+    from mobrob_amd import get_env
+    from mobrob_amd.rl_control.ppo import PPOCtrl
+    cfg = {"ppo_kwargs": {"policy": "MlpPolicy", "n_steps": 128, "batch_size": 4096, "n_epochs": 10, "gamma": 0.99,
+                          "gae_lambda": 0.95, "ent_coef": 0.0, "clip_range": 0.2,
+                          "policy_kwargs": {"net_arch": {"pi": [64, 64], "vf": [64, 64]}}},
+           "env_name": "point", "time_limit": 200, "n_envs": 512, "vec_env_type": "device_goal", "enable_gui": False,
+           "seed": 1}
+    ctrl = PPOCtrl.from_config(cfg)
+    ctrl.learn(total_timesteps=30 * 128 * 512)
+    monkeypatch.setattr(U, "DATA_DIR", str(tmp_path))
+    ctrl.save_model(f"{tmp_path}/policies/point-ppo.zip")
+    policy = U.load_policy("point", "ppo")
+    env = get_env("point", terminate_on_goal=True, time_limit=200)
+    reached, lengths = 0, []
+    for ep in range(12):
+        obs, _ = env.reset(seed=100 + ep)
+        for t in range(200):
+            action, _ = policy.predict(obs, deterministic=True)
+            obs, reward, terminated, truncated, _ = env.step(action)
+            if terminated or truncated:
+                break
+        reached += int(terminated)
+        lengths.append(t + 1)
+    assert reached >= 10, (reached, lengths)          # an untrained policy reaches ~40 % of the goals within 200 steps
+    assert np.mean(lengths) < 120, lengths
