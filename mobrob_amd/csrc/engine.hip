@@ -389,7 +389,7 @@ void fused64_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, floa
   }
   ProfScope pr(e, MOBROB_K_GRAD_REDUCE);
   Slab64ReduceArgs s{};
-  s.slabs = f.slabs; s.nblocks = grid; s.grads = e->grads;
+  s.slabs = f.slabs; s.nblocks = grid; s.grads = e->grads; s.P = e->P;
   for (int i = 0; i < 14; ++i) s.offs[i] = e->offs[i];
   s.D = e->D; s.A = e->A; s.ent_coef = (float)e->cfg.ent_coef; s.b_local = (float)B; s.inv_bg = inv_bg;
   s.sums = e->grads + e->P;

@@ -52,7 +52,7 @@ struct FusedTrainArgs {
   unsigned long long* stamps;    // diagnostic build only (MOBROB_STAMPS): per-phase cycle sums
 };
 
-// slab layout (floats): dW2 [H][H] | dW1 [H][64] | dW3 [32][H] | db2 [H] | db1 [H] | db3 [32] | dls [32]
+// slab layout (floats): dW2 [H][H] | dW1 [H][64] | dW3 [32][H] | db2 [H] | db1 [H] | db3 [32] | dls [32] | loss sums [8]
 // The three weight regions are stored in MFMA *fragment order* (the slab is private scratch, only k_slab_reduce
 // reads it): wave w, 32x32 tile t, accumulator register i, lane l  ->  ((w*NT + t)*4 + i/4)*256 + l*4 + i%4,
 // so that every lane moves its 16 registers of a tile with four coalesced 16-byte accesses.
@@ -74,7 +74,8 @@ __host__ __device__ inline int slab_off_b2(int Dp) { return slab_off_w3(Dp) + 32
 __host__ __device__ inline int slab_off_b1(int Dp) { return slab_off_b2(Dp) + FH; }
 __host__ __device__ inline int slab_off_b3(int Dp) { return slab_off_b1(Dp) + FH; }
 __host__ __device__ inline int slab_off_ls(int Dp) { return slab_off_b3(Dp) + 32; }
-__host__ __device__ inline int slab_size(int Dp) { return slab_off_ls(Dp) + 32; }
+__host__ __device__ inline int slab_off_st(int Dp) { return slab_off_ls(Dp) + 32; }  // loss sums: pl, vl, kl, clip count
+__host__ __device__ inline int slab_size(int Dp) { return slab_off_st(Dp) + 8; }
 
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
@@ -354,7 +355,8 @@ struct Lay {
   static constexpr int DO = H2 + FR * FLDH;
   static constexpr int CST = DO + FR * FLDO;  // [3][32]: 1/var, log(sd)+log(sqrt(2pi)), head bias
   static constexpr int GACC = CST + 96;       // [4 waves][2][32]: per-wave head-bias / log_std gradient sums
-  static constexpr int END = GACC + 256;
+  static constexpr int STAT = GACC + 256;     // [4 waves][4]: per-wave loss sums (kernel end)
+  static constexpr int END = STAT + 16;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -906,17 +908,18 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
       slab[slab_off_ls(DP) + tid] = lss;
     }
   }
-  {
+  {  // loss statistics: per-wave sums -> LDS -> fixed-order workgroup sum -> slab (k_slab_reduce adds the slabs up;
+     // contended float atomics on four addresses cost ~25 us per launch and made the logged losses order dependent)
     const float t0 = wave_sum(s_pl), t1 = wave_sum(s_vl), t2 = wave_sum(s_kl), t3 = wave_sum(s_cf);
     if (lane == 0) {
-      if (net == 0) {
-        atomicAdd(&a.sums[0], t0);
-        atomicAdd(&a.sums[2], t2);
-        atomicAdd(&a.sums[3], t3);
-      } else {
-        atomicAdd(&a.sums[1], t1);
-      }
+      lds[L::STAT + wave * 4 + 0] = t0;
+      lds[L::STAT + wave * 4 + 1] = t1;
+      lds[L::STAT + wave * 4 + 2] = t2;
+      lds[L::STAT + wave * 4 + 3] = t3;
     }
+    __syncthreads();
+    if (tid < 4)
+      slab[slab_off_st(DP) + tid] = (lds[L::STAT + tid] + lds[L::STAT + 4 + tid]) + (lds[L::STAT + 8 + tid] + lds[L::STAT + 12 + tid]);
   }
 }
 
@@ -975,8 +978,14 @@ __device__ __forceinline__ int slab_to_canonical(const SlabReduceArgs& s, int ne
     const int k = p - slab_off_b3(s.Dp);
     return k < head ? s.offs[T_B3] + k : -1;
   }
-  const int k = p - slab_off_ls(s.Dp);
-  return (net == 0 && k < s.A) ? s.offs[0] + k : -1;
+  if (p < slab_off_st(s.Dp)) {
+    const int k = p - slab_off_ls(s.Dp);
+    return (net == 0 && k < s.A) ? s.offs[0] + k : -1;
+  }
+  // loss sums live behind the gradient vector (sums = grads + P): policy slabs carry pl / kl / clip count, value slabs vl
+  const int k = p - slab_off_st(s.Dp);
+  const bool mine = net == 0 ? (k == 0 || k == 2 || k == 3) : k == 1;
+  return mine ? s.P + k : -1;
 }
 
 // grid = (ceil(slab_floats / 256), 2 networks): thread p sums slab position p over the slabs of its network
@@ -1403,7 +1412,7 @@ struct FusedState {
   size_t lds_bytes = 0, lds_act_bytes = 0;
 };
 
-inline size_t fused_lds_bytes(int Dp) { return (size_t)(FR * (Dp + 4) + 2 * FR * FLDH + FR * FLDO + 96 + 256) * sizeof(float); }
+inline size_t fused_lds_bytes(int Dp) { return (size_t)(FR * (Dp + 4) + 2 * FR * FLDH + FR * FLDO + 96 + 256 + 16) * sizeof(float); }
 
 inline size_t fused_lds_act_bytes(int Dp) { return (size_t)(32 * (Dp + 4) + 2 * 32 * FLDH + 4 * 32 * FLDO) * sizeof(float); }
 

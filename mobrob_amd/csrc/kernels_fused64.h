@@ -69,7 +69,8 @@ __host__ __device__ inline int s64_b2() { return 10 * 1024; }
 __host__ __device__ inline int s64_b1() { return s64_b2() + 64; }
 __host__ __device__ inline int s64_b3() { return s64_b1() + 64; }
 __host__ __device__ inline int s64_ls() { return s64_b3() + 32; }
-__host__ __device__ inline int s64_size() { return s64_ls() + 32; }
+__host__ __device__ inline int s64_st() { return s64_ls() + 32; }  // loss sums: pl, vl, kl, clip count
+__host__ __device__ inline int s64_size() { return s64_st() + 8; }
 
 // 32-row GEMM with BOTH operands in LDS (weights resident): c{0,1} += A[32 x 8*nkg] . Bpacked{0,1}
 template <int LDA>
@@ -512,18 +513,22 @@ __global__ __launch_bounds__(Lay64<DP>::TNWV * 64, 1) void k_fused64_train(Fused
       }
     }
   }
-  const float t0 = wave_sum(s_pl), t1 = wave_sum(s_vl), t2 = wave_sum(s_kl), t3 = wave_sum(s_cf);
-  if (lane == 0) {
-    if (net == 0) {
-      atomicAdd(&a.sums[0], t0);
-      atomicAdd(&a.sums[2], t2);
-      atomicAdd(&a.sums[3], t3);
-    } else {
-      atomicAdd(&a.sums[1], t1);
+  {  // loss statistics through the slab (fixed order; no contended atomics)
+    const float t0 = wave_sum(s_pl), t1 = wave_sum(s_vl), t2 = wave_sum(s_kl), t3 = wave_sum(s_cf);
+    __syncthreads();  // the bias partials above have been consumed
+    if (lane == 0) {
+      lds[wave * 4 + 0] = t0; lds[wave * 4 + 1] = t1; lds[wave * 4 + 2] = t2; lds[wave * 4 + 3] = t3;
     }
+    __syncthreads();
   }
   if (wave != 0) return;
   float* slab = a.slabs + (size_t)blockIdx.x * s64_size();
+  if (lane < 4) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) t += lds[w * 4 + lane];
+    slab[s64_st() + lane] = t;
+  }
   auto put = [&](int region, int t, const f32x16& g) {
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(Lay64<DP>::TNWV * 64, 1) void k_fused64_train(Fused
 // ---- slab reduction for the 64-wide path: thread p sums slab position p over the waves of its network ----
 struct Slab64ReduceArgs {
   const float* slabs; int nblocks;  // train grid size; slab index = block, network = block & 1
-  float* grads;
+  float* grads; int P;
   int offs[14];
   int D, A;
   float ent_coef, b_local, inv_bg;
@@ -590,8 +595,13 @@ __device__ __forceinline__ int slab64_to_canonical(const Slab64ReduceArgs& s, in
     const int k = p - s64_b3();
     return k < head ? s.offs[T_B3] + k : -1;
   }
-  const int k = p - s64_ls();
-  return (net == 0 && k < s.A) ? s.offs[0] + k : -1;
+  if (p < s64_st()) {
+    const int k = p - s64_ls();
+    return (net == 0 && k < s.A) ? s.offs[0] + k : -1;
+  }
+  const int k = p - s64_st();  // loss sums behind the gradient vector (sums = grads + P)
+  const bool mine = net == 0 ? (k == 0 || k == 2 || k == 3) : k == 1;
+  return mine ? s.P + k : -1;
 }
 __global__ __launch_bounds__(256) void k_slab64_reduce(Slab64ReduceArgs s) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
