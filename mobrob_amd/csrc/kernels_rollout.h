@@ -23,6 +23,13 @@
 
 namespace mobrob {
 
+// timing-only ablation (never in the product build): -DROLL_SKIP=<mask> drops phases of k_rollout_persistent
+#ifndef ROLL_SKIP
+#define ROLL_SKIP 0
+#endif
+#define ROLL_ON(bit) (!((ROLL_SKIP) & (bit)))
+#define ROLL_TANH(x) (ROLL_ON(32) ? fast_tanh_scaled(x) : (x))
+
 struct RolloutArgs {
   FusedNet pi;                       // policy network packs
   const float* log_std; uint64_t seed; const uint32_t* draw_base; float lo, hi;
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
   for (int t = a.t0; t < a.t1; ++t) {
     const int tid = opaque(tid0), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
-    {  // standard normals of this step (independent of the forward pass: drawn first, consumed after the head)
+    if (ROLL_ON(1)) {  // standard normals of this step (independent of the forward pass: drawn first, consumed after the head)
       const int ngrp = (A + 3) >> 2;
       for (int i = tid; i < R * ngrp; i += FTHREADS) {
         const int rr_ = i / ngrp, gq = i - rr_ * ngrp;
@@ -118,26 +125,28 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
     {  // layer 1
       f32x16 c0 = splat16(W.b1s[64 * wave + r]), c1 = splat16(W.b1s[64 * wave + 32 + r]);
       constexpr int nkg = DP / 8;
-      gemm_lds_packed_r32<ldx>(LB::X, W.W1f + (size_t)(2 * wave) * nkg * 64, W.W1f + (size_t)(2 * wave + 1) * nkg * 64, nkg,
-                               c0, c1, lane);
+      if (ROLL_ON(2))
+        gemm_lds_packed_r32<ldx>(LB::X, W.W1f + (size_t)(2 * wave) * nkg * 64, W.W1f + (size_t)(2 * wave + 1) * nkg * 64, nkg,
+                                 c0, c1, lane);
       const int o = opaque(LB::H1 + 4 * h * FLDH + 64 * wave + r);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        lds[o + crc(i) * FLDH] = fast_tanh_scaled(c0[i]);
-        lds[o + crc(i) * FLDH + 32] = fast_tanh_scaled(c1[i]);
+        lds[o + crc(i) * FLDH] = ROLL_TANH(c0[i]);
+        lds[o + crc(i) * FLDH + 32] = ROLL_TANH(c1[i]);
       }
     }
     __syncthreads();
     {  // layer 2
       f32x16 c0 = splat16(W.b2s[64 * wave + r]), c1 = splat16(W.b2s[64 * wave + 32 + r]);
       constexpr int nkg = FH / 8;
-      gemm_lds_packed_r32_deep<FLDH>(LB::H1, W.W2f + (size_t)(2 * wave) * nkg * 64,
-                                     W.W2f + (size_t)(2 * wave + 1) * nkg * 64, nkg, c0, c1, lane);
+      if (ROLL_ON(4))
+        gemm_lds_packed_r32_deep<FLDH>(LB::H1, W.W2f + (size_t)(2 * wave) * nkg * 64,
+                                       W.W2f + (size_t)(2 * wave + 1) * nkg * 64, nkg, c0, c1, lane);
       const int o = opaque(LB::H2 + 4 * h * FLDH + 64 * wave + r);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        lds[o + crc(i) * FLDH] = fast_tanh_scaled(c0[i]);
-        lds[o + crc(i) * FLDH + 32] = fast_tanh_scaled(c1[i]);
+        lds[o + crc(i) * FLDH] = ROLL_TANH(c0[i]);
+        lds[o + crc(i) * FLDH + 32] = ROLL_TANH(c1[i]);
       }
     }
     __syncthreads();
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
       const f32x4* bp = W.W3f + (size_t)(wave * 8) * 64;
       const unsigned bo = opaque_u((unsigned)lane * 16u);
 #pragma unroll
-      for (int kg = 0; kg < 8; kg += 2) {
+      for (int kg = 0; kg < (ROLL_ON(64) ? 8 : 0); kg += 2) {
         const f32x4 b0 = ldg16(bp, bo + kg * 1024u), b1 = ldg16(bp, bo + (kg + 1) * 1024u);
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8]);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8 + 8]);
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
     // ---- Gaussian sample + log-prob.  Same expressions and Philox counters as k_fused_act, spread over the block:
     //      (row, action group) items draw the normals, (row, action) items form action and log-prob term, one lane
     //      per row adds the terms in action order (-> bit-identical log-probs) ----
-    for (int i = tid; i < R * A; i += FTHREADS) {
+    for (int i = tid; i < (ROLL_ON(8) ? R * A : 0); i += FTHREADS) {
       const int rr_ = i / A, k = i - rr_ * A;
       const int row = row0 + rr_;
       if (row < N) {
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
     float reward = 0.f, ep_ret = 0.f;
     int ep_len_new = 0, ep_len_fin = 0;
     GoalState g{};
-    if (live) {
+    if (live && ROLL_ON(16)) {
       if (a.kind == 1) {
         const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, ek0, ek1);
         const bool term = u32_to_unit_open(mr.x) < a.p_term;
