@@ -41,7 +41,7 @@ if __name__ == "__main__":
     ap.add_argument("--env-name", type=str, default="drone")
     ap.add_argument("--finetune", action="store_true", default=False)
     ap.add_argument("--save-freq", type=int, default=1_000_000)
-    ap.add_argument("--vec-env-type", type=str, default=None, help="override the YAML (subproc|dummy|synthetic|device|device_goal)")
+    ap.add_argument("--vec-env-type", type=str, default=None, help="override the YAML (subproc|dummy|synthetic|native|device|device_goal)")
     ap.add_argument("--total-timesteps", type=int, default=None, help="override the YAML")
     a = ap.parse_args()
     train_with_ppo(a.env_name, a.finetune, a.save_freq, a.vec_env_type, a.total_timesteps)

@@ -23,6 +23,7 @@ import numpy as np
 from ..checkpoint import load_zip, save_zip
 from ..engine import PPOEngine
 from ..envs.vec_env import DeviceGoalVecEnv, DeviceSyntheticVecEnv, HostVecEnv, SyntheticVecEnv, make_vec_env
+from ..envs.native_env import NativeGoalVecEnv
 from ..envs.wrapper import get_env
 from ..utils import DATA_DIR
 from .init import orthogonal_policy_init
@@ -213,6 +214,7 @@ class PPO:
         self.engine = None
         self.policy = None
         self.world_size, self.rank, self._backend = 1, 0, None
+        self._host_bufs = None
         if _init_setup_model:
             self._setup_model()
 
@@ -273,6 +275,8 @@ class PPO:
                     return False
             callback.on_rollout_end()
             return True
+        if hasattr(env, "step_arrays"):
+            return self._collect_rollouts_arrays(callback)
         e.rollout_begin()
         dones = np.zeros(N, bool)
         for _ in range(self.n_steps):
@@ -293,6 +297,36 @@ class PPO:
             e.store(rewards, dones, trunc, term_obs)
             self._last_obs, self._last_episode_starts = new_obs, dones
         e.finish_rollout(self._last_obs, dones)
+        callback.on_rollout_end()
+        return True
+
+    def _setup_host_buffers(self):
+        """Pinned staging shared by the env and the engine: the env writes step results where the DMA reads them."""
+        e, N = self.engine, self.n_envs
+        self._host_bufs = dict(obs=e.pinned((N, self.obs_dim)), clip=e.pinned((N, self.act_dim)), rew=e.pinned((N,)),
+                               done=e.pinned((N,), np.uint8), trunc=e.pinned((N,), np.uint8),
+                               term=e.pinned((N, self.obs_dim)))
+        b = self._host_bufs
+        self.env.use_buffers(obs=b["obs"], rewards=b["rew"], dones=b["done"], truncated=b["trunc"], terminal_obs=b["term"])
+
+    def _collect_rollouts_arrays(self, callback) -> bool:
+        """Host env with the array protocol (NativeGoalVecEnv): O(1) Python work per step; observations, rewards and
+        flags travel through pinned staging on the engine's side stream; one stream sync per step (the actions)."""
+        e, env, N, b = self.engine, self.env, self.n_envs, self._host_bufs
+        e.rollout_begin()
+        for _ in range(self.n_steps):
+            e.act(b["obs"], out_clipped=b["clip"], want_all=False)
+            _, _, _, _, _, ntrunc = env.step_arrays(b["clip"])
+            self.num_timesteps += N * self.world_size
+            if not callback.on_step():
+                return False
+            e.store(b["rew"], b["done"], b["trunc"] if ntrunc else None, b["term"] if ntrunc else None)
+        e.finish_rollout(b["obs"], b["done"])
+        st = env.episode_stats(reset=True)
+        self.device_episode_stats = st
+        if st["episodes"] > 0:
+            self.ep_info_buffer.extend([{"r": st["ep_rew_mean"], "l": st["ep_len_mean"], "t": 0.0}]
+                                       * min(st["episodes"], self.ep_info_buffer.maxlen or 100))
         callback.on_rollout_end()
         return True
 
@@ -329,6 +363,8 @@ class PPO:
             total_timesteps += self.num_timesteps
         self._total_timesteps, self._num_timesteps_at_start = total_timesteps, self.num_timesteps
         host_env = not isinstance(self.env, (DeviceSyntheticVecEnv, DeviceGoalVecEnv))
+        if host_env and hasattr(self.env, "step_arrays") and getattr(self, "_host_bufs", None) is None:
+            self._setup_host_buffers()
         if host_env and (reset_num_timesteps or self._last_obs is None):
             self._last_obs = self.env.reset()
             self._last_episode_starts = np.ones(self.n_envs, bool)
@@ -456,8 +492,8 @@ class PPOCtrl:
     """Same constructor, `from_config`, `learn`, `save_model` and `.ppo` attribute as the reference class
     (src/mobrob/rl_control/ppo.py:14-77).  `vec_env_type` accepts the reference values "subproc" and "dummy"
     (ValueError otherwise, ppo.py:35) -- both run the in-process batched VecEnv -- plus two build extensions:
-    "synthetic" (host NumPy env source), "device" (device-resident synthetic source) and "device_goal" (the
-    goal-reaching task of envs/wrapper.py stepped on the GPU)."""
+    "synthetic" (host NumPy env source), "native" (the goal task stepped by the multi-threaded C host environment,
+    csrc/host_env.c), "device" (device-resident synthetic source) and "device_goal" (the goal task stepped on the GPU)."""
 
     def __init__(self, ppo_kwargs: dict, env_name: str, time_limit: int, n_env: int, vec_env_type: str = "dummy",
                  enable_gui: bool = False, seed: int = 0) -> None:
@@ -477,6 +513,8 @@ class PPOCtrl:
             vec_env = SyntheticVecEnv.for_robot(env_name, n_env, time_limit, env_seed)
         elif vec_env_type == "device":
             vec_env = DeviceSyntheticVecEnv.for_robot(env_name, n_env, time_limit, seed)
+        elif vec_env_type == "native":
+            vec_env = NativeGoalVecEnv.for_robot(env_name, n_env, time_limit, env_seed, terminate_on_goal=True)
         elif vec_env_type == "device_goal":
             vec_env = DeviceGoalVecEnv.for_robot(env_name, n_env, time_limit, seed, terminate_on_goal=True)
         else:

@@ -27,3 +27,11 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _libraries_built():
+    """Both shared libraries are built in-tree (no-op when up to date): libmobrob_ppo.so (hipcc cross-compiles
+    without a GPU) and libmobrob_hostenv.so (gcc)."""
+    import __graft_entry__
+    __graft_entry__.build()

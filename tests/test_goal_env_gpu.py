@@ -160,3 +160,24 @@ def test_policy_trained_on_the_device_env_solves_the_host_env(tmp_path, monkeypa
         lengths.append(t + 1)
     assert reached >= 10, (reached, lengths)          # an untrained policy reaches ~40 % of the goals within 200 steps
     assert np.mean(lengths) < 120, lengths
+
+
+def test_ppo_learns_with_the_native_host_env_through_pinned_staging():
+    """Host-env path at scale: the multi-threaded C environment steps 512 robots, observations / rewards / flags
+    travel through pinned staging on the side stream, actions come back once per step -- and PPO learns the task."""
+    from mobrob_amd.rl_control.ppo import PPOCtrl
+    cfg = {"ppo_kwargs": {"policy": "MlpPolicy", "n_steps": 128, "batch_size": 4096, "n_epochs": 10, "gamma": 0.99,
+                          "gae_lambda": 0.95, "ent_coef": 0.0, "clip_range": 0.2,
+                          "policy_kwargs": {"net_arch": {"pi": [64, 64], "vf": [64, 64]}}},
+           "env_name": "point", "time_limit": 200, "n_envs": 512, "vec_env_type": "native", "enable_gui": False, "seed": 0}
+    ctrl = PPOCtrl.from_config(cfg)
+    ppo = ctrl.ppo
+    hist = []
+    for it in range(24):
+        ppo.learn(total_timesteps=128 * 512, reset_num_timesteps=False)
+        st = ppo.device_episode_stats
+        hist.append((st["episodes"], st["goals"], st["ep_len_mean"]))
+    h = np.array(hist, dtype=np.float64)
+    first, last = h[:4].sum(0), h[-4:].sum(0)
+    assert last[1] / max(last[0], 1) > 0.9 and last[1] / max(last[0], 1) > first[1] / max(first[0], 1) + 0.3, (first, last)
+    assert ppo.num_timesteps == 24 * 128 * 512
