@@ -748,6 +748,24 @@ int mobrob_ppo_act(mobrob_ppo_engine_t* e, const float* obs, const float* eps, f
   if (e->t >= e->T) return fail(MOBROB_ERR_STATE, "act: rollout buffer full (t=%d, n_steps=%d)", e->t, e->T);
   CHK(streamer_init(e));
   const size_t N = e->N, A = e->A, D = e->D;
+  // Pinned fast path: every buffer of the call is hipHostMalloc memory -> the GPU reads / writes it in place
+  // (k_pull_rows, k_copy_f32) on the compute stream; one stream, no events, one synchronisation.
+  if (!eps && is_pinned(obs) && (!a_raw || is_pinned(a_raw)) && (!a_clip || is_pinned(a_clip)) &&
+      (!values || is_pinned(values)) && (!logp || is_pinned(logp))) {
+    hipLaunchKernelGGL(k_pull_rows, dim3(cdiv((int)(N * e->Dp), 256)), dim3(256), 0, e->stream, obs,
+                       e->obs + (size_t)e->t * N * e->Dp, (int)N, (int)D, e->Dp);
+    act_slot(e, e->t, nullptr);
+    auto push = [&](const float* dev, float* host, size_t n) {
+      if (host) hipLaunchKernelGGL(k_copy_f32, dim3(cdiv((int)n, 256)), dim3(256), 0, e->stream, dev, host, (int)n);
+    };
+    push(e->clip_act, a_clip, N * A);
+    push(e->actions + (size_t)e->t * N * A, a_raw, N * A);
+    push(e->values + (size_t)e->t * N, values, N);
+    push(e->logp + (size_t)e->t * N, logp, N);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(e->stream));
+    return MOBROB_OK;
+  }
   auto& st = e->stage[e->stage_i];
   // H2D on the side stream (pinned source -> truly asynchronous), compute stream waits on the event
   const float* src = stage_in(obs, st.obs, N * D);
@@ -786,6 +804,27 @@ int mobrob_ppo_store(mobrob_ppo_engine_t* e, const float* rewards, const uint8_t
   if (e->t >= e->T) return fail(MOBROB_ERR_STATE, "store: rollout buffer full");
   CHK(streamer_init(e));
   const size_t N = e->N, D = e->D;
+  if (is_pinned(rewards) && is_pinned(dones) && (!truncated || is_pinned(truncated)) &&
+      (!terminal_obs || is_pinned(terminal_obs))) {
+    // Pinned fast path: the kernels read the caller's buffers in place.  The caller may overwrite them only after
+    // the next act() has returned (act synchronises the compute stream) -- the order every rollout loop has.
+    bool any = false;
+    if (truncated && terminal_obs)
+      for (size_t i = 0; i < N; ++i) any |= truncated[i] != 0;
+    if (any) {
+      hipLaunchKernelGGL(k_pull_rows, dim3(cdiv((int)(N * e->Dp), 256)), dim3(256), 0, e->stream, terminal_obs, e->term_obs,
+                         (int)N, (int)D, e->Dp);
+      HIPC(hipMemcpyAsync(e->trunc_dev, truncated, N, hipMemcpyHostToDevice, e->stream));
+      value_flagged(e, e->term_obs, e->trunc_dev, e->term_val);
+    }
+    hipLaunchKernelGGL(k_store_step, dim3(cdiv(e->N, 256)), dim3(256), 0, e->stream, rewards, e->prev_dones,
+                       any ? e->trunc_dev : nullptr, e->term_val, (float)e->cfg.gamma, e->N,
+                       e->rewards + (size_t)e->t * N, e->es + (size_t)e->t * N);
+    hipLaunchKernelGGL(k_u8_to_f32, dim3(cdiv(e->N, 256)), dim3(256), 0, e->stream, dones, e->prev_dones, e->N);
+    HIPC(hipGetLastError());
+    e->t++;
+    return MOBROB_OK;
+  }
   auto& st = e->stage[e->stage_i];
   // Fully asynchronous: the scalars are staged in pinned memory (the caller may reuse its buffers immediately),
   // copied on the side stream and consumed by the compute stream behind an event; nothing here waits for the GPU.

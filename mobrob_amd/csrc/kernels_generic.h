@@ -203,6 +203,20 @@ __global__ void k_store_step(const float* __restrict__ rew_in, const float* __re
   es_out[i] = prev_dones[i];
 }
 
+// Zero-copy staging for pinned host buffers (hipHostMalloc memory is device-visible under the same address): the
+// kernel itself pulls the rows over PCIe with coalesced loads and pads them to the device row stride -- no DMA
+// descriptor per row as hipMemcpy2DAsync needs, no second stream, no events.
+__global__ void k_pull_rows(const float* __restrict__ src, float* __restrict__ dst, int rows, int D, int Dp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * Dp) return;
+  const int r = i / Dp, c = i - r * Dp;
+  dst[i] = c < D ? src[(size_t)r * D + c] : 0.f;
+}
+__global__ void k_copy_f32(const float* __restrict__ src, float* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
 __global__ void k_u8_to_f32(const uint8_t* __restrict__ in, float* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i] ? 1.f : 0.f;

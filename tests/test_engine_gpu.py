@@ -238,6 +238,40 @@ def test_three_learn_iterations_match_oracle(H):
     e.close()
 
 
+def test_pinned_zero_copy_path_equals_staged_path():
+    """act/store with hipHostMalloc buffers (kernels read / write them in place) == the staged-copy path."""
+    D, A, N, T = 43, 2, 70, 9
+    p = O.init_params(D, A, seed=2)
+    rng = np.random.default_rng(1)
+    obs_seq = rng.standard_normal((T + 1, N, D)).astype(np.float32)
+    rew_seq = rng.standard_normal((T, N)).astype(np.float32)
+    done_seq = rng.random((T, N)) < 0.2
+    trunc_seq = done_seq & (rng.random((T, N)) < 0.5)
+    term_seq = rng.standard_normal((T, N, D)).astype(np.float32)
+    out = {}
+    for pinned in (False, True):
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=64, n_epochs=1, seed=6)
+        e.set_params(p)
+        mk = (lambda shape, dt=np.float32: e.pinned(shape, dt)) if pinned else (lambda shape, dt=np.float32: np.zeros(shape, dt))
+        ob, cl, rw, dn, tr, tm = mk((N, D)), mk((N, A)), mk((N,)), mk((N,), np.uint8), mk((N,), np.uint8), mk((N, D))
+        e.rollout_begin()
+        clips = []
+        for t in range(T):
+            ob[:] = obs_seq[t]
+            e.act(ob, out_clipped=cl, want_all=False)
+            clips.append(cl.copy())
+            rw[:], dn[:], tr[:], tm[:] = rew_seq[t], done_seq[t], trunc_seq[t], term_seq[t]
+            e.store(rw, dn, tr if trunc_seq[t].any() else None, tm if trunc_seq[t].any() else None)
+        ob[:] = obs_seq[T]
+        e.finish_rollout(ob, dn)
+        out[pinned] = {k: e.read(k) for k in ("obs", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages")}
+        out[pinned]["clips"] = np.stack(clips)
+        e.close()
+    for k in out[True]:
+        assert np.array_equal(out[True][k], out[False][k]), k
+    assert np.array_equal(out[True]["clips"], np.clip(out[True]["actions"], -1, 1))
+
+
 def test_synthetic_collect_statistics_and_consistency():
     """Device-resident env source: statistics of the generator and self-consistency of the stored rollout."""
     D, A, N, T = 58, 12, 512, 64
