@@ -31,6 +31,10 @@ WORKLOADS = {
     "point-1024env-2x64": dict(D=14, A=2, H=64, N=1024, T=2048, E=10, B=65536, p_term=1 / 119.0, tl=1000),
     # BASELINE.md §3 B1 "reference-shaped": data/configs/doggo-ppo.yaml, CPU baseline on ONE thread (examples/train.py:13)
     "doggo-ref-16env-2x64": dict(D=58, A=12, H=64, N=16, T=1000, E=5, B=100, p_term=1 / 107.0, tl=1000, cpu_threads=1),
+    # the headline shape with the environments on the HOST (native C goal env, pinned zero-copy staging): the
+    # PCIe-inclusive rate of DESIGN.md -- never the headline `value`, which keeps its inputs resident in HBM
+    "doggo-4096env-2x256-hostenv": dict(D=58, A=12, H=256, N=4096, T=1000, E=5, B=65536, p_term=1 / 107.0, tl=1000,
+                                        host_env="doggo"),
     # BASELINE configs[4]: mixed fleet, ragged obs/act dims packed into one rollout arena (mobrob_amd/fleet.py)
     "fleet-car-drone-turtlebot3-2x64": dict(segments=["car", "drone", "turtlebot3"], H=64, N=1024, T=2048, E=10,
                                             B=65536, tl=1000),
@@ -214,8 +218,28 @@ def main():
     eng.set_params(init_params(D, A, H, seed=0))  # identical replicas on every rank
     backend = EngineBackend(eng) if use_dp else None
 
+    host = None
+    if w.get("host_env"):
+        from mobrob_amd.envs.native_env import NativeGoalVecEnv
+        host = NativeGoalVecEnv.for_robot(w["host_env"], N, time_limit=w["tl"], seed=1000 * rank)
+        hb = dict(obs=eng.pinned((N, D)), clip=eng.pinned((N, A)), rew=eng.pinned((N,)), done=eng.pinned((N,), np.uint8),
+                  trunc=eng.pinned((N,), np.uint8), term=eng.pinned((N, D)))
+        host.use_buffers(obs=hb["obs"], rewards=hb["rew"], dones=hb["done"], truncated=hb["trunc"], terminal_obs=hb["term"])
+        host.reset()
+
+    def host_rollout():
+        eng.rollout_begin()
+        for _ in range(T):
+            eng.act(hb["obs"], out_clipped=hb["clip"], want_all=False)
+            nt = host.step_arrays(hb["clip"])[5]
+            eng.store(hb["rew"], hb["done"], hb["trunc"] if nt else None, hb["term"] if nt else None)
+        eng.finish_rollout(hb["obs"], hb["done"])
+
     def iteration():
-        eng.collect_synthetic(p_term=w["p_term"], time_limit=w["tl"])
+        if host is not None:
+            host_rollout()
+        else:
+            eng.collect_synthetic(p_term=w["p_term"], time_limit=w["tl"])
         if use_dp:
             train_data_parallel(backend, force_collectives=force_dp)
         else:
@@ -266,8 +290,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "obs_dim": D, "act_dim": A, "net_arch": [H, H], "envs_per_gpu": N,
                        "n_steps": T, "n_epochs": E, "minibatch_per_gpu": B, "minibatches_per_epoch": nmb,
-                       "env_source": "device-resident synthetic (Philox)", "parallelism": f"dp{world}",
-                       "kernels": "generic" if args.generic else "fused"},
+                       "env_source": ("native host env (csrc/host_env.c, OpenMP), pinned zero-copy staging over PCIe"
+                                      if host is not None else "device-resident synthetic (Philox)"),
+                       "parallelism": f"dp{world}", "kernels": "generic" if args.generic else "fused"},
             "roofline": {"bound": "mfma", "kernel": "k_fused_train (minibatch forward+loss+backward)" if not args.generic else "generic GEMM chain",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
