@@ -397,6 +397,35 @@ def test_rollouts_beyond_4gib_use_the_64bit_generic_kernels():
     e.close()
 
 
+@pytest.mark.parametrize("H", [256, 64, 16])
+@pytest.mark.parametrize("N,T,B", [(1, 2, 2), (1, 1, 1), (3, 5, 7), (33, 3, 64)])
+def test_tiny_and_ragged_shapes_run_end_to_end(H, N, T, B):
+    """Degenerate sizes (one env, one step, minibatch larger than / not dividing the rollout) through rollout,
+    GAE and update on every kernel family, against the oracle."""
+    D, A = 12, 18
+    p = O.init_params(D, A, (H, H), (H, H), seed=1)
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=2, pi=(H, H), vf=(H, H), seed=3)
+    e.set_params(p)
+    e.collect_synthetic(p_term=0.3, time_limit=2)
+    e.synchronize()
+    buf = {k: e.read(k) for k in ("actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns")}
+    buf["obs"] = e.read("obs")[:T]
+    adv, ret = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], e.read("last_values"), e.read("last_dones") > 0, 0.99, 0.95)
+    assert np.array_equal(buf["advantages"], adv)
+    rng = np.random.default_rng(0)
+    perms = np.stack([rng.permutation(T * N) for _ in range(2)])
+    st = e.train(perms)
+    assert np.isfinite(st["loss"]) or T * N == 1   # a single sample has no advantage std: SB3 also yields nan there
+    q = {k: v.copy() for k, v in p.items()}
+    h = O.Hyper(n_epochs=2, batch_size=B)
+    O.train(q, O.AdamState.zeros_like(q), buf, h, perms)
+    got = e.get_params()
+    if T * N > 1:
+        for k in q:
+            assert np.max(np.abs(got[k] - q[k])) < 2e-4, (k, float(np.max(np.abs(got[k] - q[k]))))
+    e.close()
+
+
 def test_error_paths():
     from mobrob_amd.engine import PPOEngine
     with pytest.raises(ValueError):
