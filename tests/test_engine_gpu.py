@@ -426,6 +426,30 @@ def test_tiny_and_ragged_shapes_run_end_to_end(H, N, T, B):
     e.close()
 
 
+@pytest.mark.parametrize("H", [256, 64])
+def test_graph_replay_equals_eager_enqueue(H):
+    """The captured hipGraph (persistent rollout chunks + side-stream value pass + GAE) replays exactly what the
+    eager enqueue does, rollout after rollout (device-resident counters advance inside the graph)."""
+    D, A, N, T = 26, 2, 96, 40
+    p = O.init_params(D, A, (H, H), (H, H), seed=3)
+    outs = []
+    for graph in (True, False):
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=512, n_epochs=1, pi=(H, H), vf=(H, H), seed=5,
+                        rollout_graph=graph)
+        e.set_params(p)
+        res = []
+        for _ in range(3):
+            e.collect_synthetic(p_term=0.05, time_limit=15)
+            e.synchronize()
+            res.append({k: e.read(k) for k in ("obs", "actions", "rewards", "values", "advantages", "last_values")})
+        outs.append(res)
+        e.close()
+    for a, b in zip(*outs):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+    assert not np.array_equal(outs[0][0]["obs"], outs[0][1]["obs"])  # consecutive rollouts differ (counters advanced)
+
+
 def test_error_paths():
     from mobrob_amd.engine import PPOEngine
     with pytest.raises(ValueError):
