@@ -94,7 +94,8 @@ struct mobrob_ppo_engine {
   } ro_spec;
   int env_started = 0;  // env kind whose state is live on the device (0 = none)
   hipStream_t vstream = nullptr;          // batched value pass of finished rollout chunks, concurrent with the rollout
-  hipEvent_t ev_chunk = nullptr, ev_vdone = nullptr;
+  std::vector<hipEvent_t> ev_chunks;      // one event per rollout chunk (an event is recorded once per capture)
+  hipEvent_t ev_vdone = nullptr;
   float* gstate[2] = {nullptr, nullptr};  // goal env state, double buffered [N][kGoalStateFloats]
   double* ep_stats = nullptr;             // [4] episode statistics of the goal env
   uint32_t draw_counter = 0;  // Philox draw index for eps
@@ -671,7 +672,8 @@ void mobrob_ppo_destroy(mobrob_ppo_engine_t* e) {
   if (e->ro_graph) (void)hipGraphDestroy(e->ro_graph);
   if (e->vstream) {
     (void)hipStreamSynchronize(e->vstream);
-    (void)hipEventDestroy(e->ev_chunk); (void)hipEventDestroy(e->ev_vdone);
+    for (auto ev : e->ev_chunks) (void)hipEventDestroy(ev);
+    (void)hipEventDestroy(e->ev_vdone);
     (void)hipStreamDestroy(e->vstream);
   }
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
@@ -905,6 +907,21 @@ uint64_t env_seed_of(const mobrob_ppo_engine* e) {
 bool rollout_persistent_ok(const mobrob_ppo_engine* e) {
   return e->cfg.rollout_persistent && e->fused.enabled;  // both fused widths (256: kernels_rollout.h top, 64: bottom)
 }
+// side stream and events of the overlapped value pass: created OUTSIDE any stream capture (resource creation is
+// not a capturable operation)
+int rollout_side_stream_init(mobrob_ppo_engine* e) {
+  if (!e->vstream) {
+    HIPC(hipStreamCreateWithFlags(&e->vstream, hipStreamNonBlocking));
+    HIPC(hipEventCreateWithFlags(&e->ev_vdone, hipEventDisableTiming));
+  }
+  while ((int)e->ev_chunks.size() < e->T / 16 + 2) {  // chunks are >= 16 steps
+    hipEvent_t ev;
+    HIPC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    e->ev_chunks.push_back(ev);
+  }
+  return MOBROB_OK;
+}
+
 int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& sp) {
   const int N = e->N, Dp = e->Dp, T = e->T;
   const size_t slot = (size_t)N * Dp;
@@ -941,11 +958,6 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
   // The rollout blocks (32 envs each, ~100 KB of LDS) leave CUs idle when N < 32 * 256; the value pass of the steps
   // already finished runs there at the same time: the rollout is cut into chunks, chunk c's value pass is enqueued
   // on a second stream behind an event and overlaps the rollout of chunk c+1.
-  if (!e->vstream) {
-    HIPC(hipStreamCreateWithFlags(&e->vstream, hipStreamNonBlocking));
-    HIPC(hipEventCreateWithFlags(&e->ev_chunk, hipEventDisableTiming));
-    HIPC(hipEventCreateWithFlags(&e->ev_vdone, hipEventDisableTiming));
-  }
   const int rblocks = cdiv(N, 32);
   const bool overlap = rblocks <= 192;                      // otherwise the rollout itself fills the device
   const int chunk = overlap ? std::max(16, cdiv(T, 20)) : T;
@@ -962,8 +974,9 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
       FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout_persistent<DPc>), dim3(rblocks), dim3(FTHREADS),
                                                rollout_lds_bytes(Dp), e->stream, a));
       if (overlap && a.t1 < T) {  // observations [t0, t1) are final: value them on the side stream
-        HIPC(hipEventRecord(e->ev_chunk, e->stream));
-        HIPC(hipStreamWaitEvent(e->vstream, e->ev_chunk, 0));
+        hipEvent_t ev = e->ev_chunks[t0 / chunk];
+        HIPC(hipEventRecord(ev, e->stream));
+        HIPC(hipStreamWaitEvent(e->vstream, ev, 0));
         value_pass(e->vstream, t0 * N, a.t1 * N);
       }
     }
@@ -1045,9 +1058,13 @@ int collect_device(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& s
     e->env_started = sp.kind;
   }
   e->rollout_ready = false;
+  if (rollout_persistent_ok(e)) CHK(rollout_side_stream_init(e));
   // Graph replay: every kernel argument of the T-step loop is fixed (slot pointers, ping-pong buffers with even T,
   // counters relative to device-resident bases), so the loop is captured once and replayed per rollout.
-  const bool use_graph = e->cfg.rollout_graph && (e->T % 2 == 0 || rollout_persistent_ok(e));
+  // The persistent path is ~45 launches on two streams: enqueued eagerly (the launches hide behind the 18 ms of
+  // GPU work; a captured multi-stream graph was both slower to launch and, after many capture / destroy cycles in
+  // one process, crashed inside the runtime).  Only the per-step path (thousands of launches) is replayed as a graph.
+  const bool use_graph = e->cfg.rollout_graph && e->T % 2 == 0 && !rollout_persistent_ok(e);
   if (!use_graph) {
     CHK(enqueue_rollout(e, sp));
   } else {

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
   const uint32_t dbase = a.draw_base ? *a.draw_base : 0u, sbase = a.step_base ? *a.step_base : 0u;
   const uint32_t ek0 = (uint32_t)a.env_seed, ek1 = (uint32_t)(a.env_seed >> 32);
 
+  double es_n = 0.0, es_ret = 0.0, es_len = 0.0, es_goal = 0.0;  // finished episodes of this thread's row
   for (int t = a.t0; t < a.t1; ++t) {
     const int tid = opaque(tid0), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
@@ -274,11 +275,8 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
         reinterpret_cast<int*>(S)[13] = ep_len_new;
       } else {
         goal_store(S, g);
-        if (done) {
-          atomicAdd(&a.ep_stats[0], 1.0);
-          atomicAdd(&a.ep_stats[1], (double)ep_ret);
-          atomicAdd(&a.ep_stats[2], (double)ep_len_fin);
-          if (reached) atomicAdd(&a.ep_stats[3], 1.0);
+        if (done) {  // Monitor statistics: accumulated per thread, flushed once per launch (see the kernel end)
+          es_n += 1.0; es_ret += (double)ep_ret; es_len += (double)ep_len_fin; es_goal += reached ? 1.0 : 0.0;
         }
       }
       if (tr) {  // reward is written after the bootstrap below
@@ -302,6 +300,13 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
         a.rewards[(size_t)t * N + row0 + br] = (float)((double)lrew[q] + (double)__fmul_rn(a.bt.gamma, v));
       }
       __syncthreads();
+    }
+  }
+  // ---- episode statistics: one set of atomics per wave and launch (order irrelevant: diagnostics) ----
+  if (a.kind == 2) {
+    const double n = wave_sum_d(es_n), r = wave_sum_d(es_ret), l = wave_sum_d(es_len), g = wave_sum_d(es_goal);
+    if ((tid0 & 63) == 0 && n > 0.0) {
+      atomicAdd(&a.ep_stats[0], n); atomicAdd(&a.ep_stats[1], r); atomicAdd(&a.ep_stats[2], l); atomicAdd(&a.ep_stats[3], g);
     }
   }
   // ---- carried state back to global ----
@@ -486,6 +491,7 @@ __global__ __launch_bounds__(LayRo64<DP>::NWV * 64, 1) void k_rollout64_persiste
   const uint32_t dbase = a.draw_base ? *a.draw_base : 0u, sbase = a.step_base ? *a.step_base : 0u;
   const uint32_t ek0 = (uint32_t)a.env_seed, ek1 = (uint32_t)(a.env_seed >> 32);
 
+  double es_n = 0.0, es_ret = 0.0, es_len = 0.0, es_goal = 0.0;  // finished episodes of this thread's row
   for (int t = a.t0; t < a.t1; ++t) {
     const int lane = opaque(lane0);
     {  // standard normals of this step
@@ -599,11 +605,8 @@ __global__ __launch_bounds__(LayRo64<DP>::NWV * 64, 1) void k_rollout64_persiste
         reinterpret_cast<int*>(S)[13] = ep_len_new;
       } else {
         goal_store(S, g);
-        if (done) {
-          atomicAdd(&a.ep_stats[0], 1.0);
-          atomicAdd(&a.ep_stats[1], (double)ep_ret);
-          atomicAdd(&a.ep_stats[2], (double)ep_len_fin);
-          if (reached) atomicAdd(&a.ep_stats[3], 1.0);
+        if (done) {  // Monitor statistics: accumulated per thread, flushed once per launch (see the kernel end)
+          es_n += 1.0; es_ret += (double)ep_ret; es_len += (double)ep_len_fin; es_goal += reached ? 1.0 : 0.0;
         }
       }
       if (!tr) a.rewards[so] = reward;
@@ -621,6 +624,13 @@ __global__ __launch_bounds__(LayRo64<DP>::NWV * 64, 1) void k_rollout64_persiste
         a.bt.term_val[row0 + br] = v;
         a.rewards[(size_t)t * N + row0 + br] = (float)((double)rw + (double)__fmul_rn(a.bt.gamma, v));
       }
+    }
+  }
+  // ---- episode statistics: one set of atomics per wave and launch (order irrelevant: diagnostics) ----
+  if (a.kind == 2) {
+    const double n = wave_sum_d(es_n), r = wave_sum_d(es_ret), l = wave_sum_d(es_len), g = wave_sum_d(es_goal);
+    if ((tid0 & 63) == 0 && n > 0.0) {
+      atomicAdd(&a.ep_stats[0], n); atomicAdd(&a.ep_stats[1], r); atomicAdd(&a.ep_stats[2], l); atomicAdd(&a.ep_stats[3], g);
     }
   }
   // ---- carried state back to global ----
