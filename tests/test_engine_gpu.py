@@ -450,6 +450,23 @@ def test_graph_replay_equals_eager_enqueue(H):
     assert not np.array_equal(outs[0][0]["obs"], outs[0][1]["obs"])  # consecutive rollouts differ (counters advanced)
 
 
+def test_many_engine_lifecycles_in_one_process():
+    """Create / roll out / update / destroy 60 engines of every kernel family in one process (graphs, side streams,
+    events, arenas are all released; a leak or a stale handle shows up as a crash or an allocation failure here)."""
+    rng = np.random.default_rng(0)
+    for i in range(60):
+        H = (256, 64, 32)[i % 3]
+        D, A = ((58, 12), (14, 2), (26, 2), (12, 18))[i % 4]
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=int(rng.integers(1, 200)), n_steps=int(rng.integers(1, 12)) * 2,
+                        batch_size=64, n_epochs=1, pi=(H, H), vf=(H, H), seed=i, rollout_persistent=bool(i % 2))
+        e.set_params(O.init_params(D, A, (H, H), (H, H), seed=i))
+        for _ in range(2):
+            e.collect_synthetic(p_term=0.1, time_limit=5)
+            st = e.train(None)
+        assert np.isfinite(st["loss"])
+        e.close()
+
+
 def test_error_paths():
     from mobrob_amd.engine import PPOEngine
     with pytest.raises(ValueError):
