@@ -75,7 +75,8 @@ typedef struct mobrob_ppo_config {
   int32_t device_id;          /* HIP device ordinal                                              */
   int32_t rank, world_size;   /* data-parallel position; batch_size is split batch_size/world    */
   int32_t fast_kernels;       /* 1: use the fused MFMA kernels when the shape allows; 0: generic */
-  int32_t rollout_graph;      /* 1: replay the device-resident rollout as one captured hipGraph  */
+  int32_t rollout_graph;      /* 1: the per-step device rollout (2 launches per step) is replayed as one
+                                 captured hipGraph; the persistent rollout needs no graph          */
   int32_t rollout_persistent; /* 1: run the device-resident rollout as one persistent kernel (fused widths) */
   int32_t reserved[5];
 } mobrob_ppo_config_t;
