@@ -279,7 +279,11 @@ __global__ __launch_bounds__(Lay64<DP>::TNWV * 64, 1) void k_fused64_train(Fused
     if (widx < ntiles && widx * GR + rr < a.count)
       xr[u] = ldg16(a.obs, (unsigned)a.rows[widx * GR + rr] * (unsigned)(DP * 4) + (unsigned)(c * 16));
   }
+#ifdef MOBROB64_EMPTY
+  for (int tile = widx; tile < 0; tile += nw) {
+#else
   for (int tile = widx; tile < ntiles; tile += nw) {
+#endif
     const int lane = opaque(tid0) & 63;
     const int r = lane & 31, h = lane >> 5;
     const int row0 = tile * GR;
