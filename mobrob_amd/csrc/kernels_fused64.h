@@ -402,7 +402,8 @@ __global__ __launch_bounds__(Lay64<DP>::TNWV * 64, 1) void k_fused64_train(Fused
     // ---- dh2 = dout . W3 (K = 32) ; dz2 = dh2 * (1 - h2^2) in place ----
     {
       f32x16 c0 = zero16(), c1 = zero16();
-      gemm_lds_lds_r32<FLDO>(wb + L::DO, Wt::W3B, Wt::W3B + 4 * 256, 4, c0, c1, lane);
+      gemm_lds_lds_r32<FLDO>(wb + L::DO, Wt::W3B, Wt::W3B + 4 * 256, W.head <= 16 ? 2 : 4,  // head columns beyond `head` are zero
+                             c0, c1, lane);
       const int o = opaque(wb + L::H2 + 4 * h * GLDH + r);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
