@@ -11,7 +11,8 @@ Appendix A) and is pinned by
 
   * the five reference checkpoints `data/policies/<env>-ppo.zip` (real trained weights, real
     Adam moments and step counters, real simulator observations `_last_obs`), and
-  * golden vectors in `tests/golden/*.npz`, produced by `tests/golden/make_fixtures.py` with
+  * golden vectors in `tests/golden/*.npz`, produced by `tests/golden/make_fixtures.py` (single steps per robot)
+    and `tests/golden/make_loop_fixture.py` (a whole iteration: buffer GAE, flatten, 8 optimizer steps) with
     the *same third-party kernels SB3 calls* (torch.nn.Linear / Tanh, torch.distributions
     Normal, autograd, `clip_grad_norm_`, `torch.optim.Adam` loaded with the checkpoint's real
     optimizer state).

@@ -467,6 +467,38 @@ def test_many_engine_lifecycles_in_one_process():
         e.close()
 
 
+@pytest.mark.parametrize("fast", [True, False])
+def test_whole_iteration_matches_torch_golden(fast):
+    """tests/golden/train_loop.npz: GAE + 2 epochs x 4 minibatches (last one short) computed with NumPy + torch from
+    the real doggo checkpoint (weights and Adam state) -- the engine must reproduce advantages bit for bit and the
+    losses / parameters / Adam moments within tolerance."""
+    import os
+    from collections import OrderedDict
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_loop.npz"))
+    T, N, B, E, D, A = (int(x) for x in g["shape"])
+    gamma, lam, clip, ent_coef, vf_coef, max_norm, lr, eps = (float(x) for x in g["hyper"])
+    keys = O.param_keys()
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, gamma=gamma, gae_lambda=lam,
+                    clip_range=clip, ent_coef=ent_coef, vf_coef=vf_coef, max_grad_norm=max_norm, learning_rate=lr,
+                    adam_eps=eps, fast_kernels=fast)
+    e.set_params(OrderedDict((k, g[f"p0/{k}"]) for k in keys))
+    e.set_optimizer_state(OrderedDict((k, g[f"m0/{k}"]) for k in keys), OrderedDict((k, g[f"v0/{k}"]) for k in keys),
+                          int(g["adam_step"]))
+    buf = {k: g[k] for k in ("obs", "actions", "rewards", "episode_starts", "values", "log_probs")}
+    e.load_rollout(buf, g["last_values"], g["dones"])
+    e.compute_gae()
+    assert np.array_equal(e.read("advantages"), g["advantages"]) and np.array_equal(e.read("returns"), g["returns"])
+    e.train(g["perms"])
+    got = e.get_params()
+    for k in keys:
+        assert np.max(np.abs(got[k] - g[f"p1/{k}"])) < 1e-5, (k, float(np.max(np.abs(got[k] - g[f"p1/{k}"]))))
+    m, v, step = e.get_optimizer_state()
+    assert step == int(g["adam_step"]) + E * 4
+    for k in keys:
+        assert scaled_err(m[k], g[f"m1/{k}"]) < 1e-3, k
+    e.close()
+
+
 def test_error_paths():
     from mobrob_amd.engine import PPOEngine
     with pytest.raises(ValueError):

@@ -155,3 +155,34 @@ def test_checkpoint_sanity_anchors():
     _, v = O.policy_outputs(golden_params(g), g["last_obs"])
     assert np.allclose(v[:4], [3.464, 3.274, 3.692, 3.804], atol=2e-3)
     assert int(g["adam_step"]) == 1499200 == int(g["hyper/_n_updates"]) * 160
+
+
+def test_whole_iteration_matches_torch_golden():
+    """tests/golden/train_loop.npz (make_loop_fixture.py): RolloutBuffer GAE, env-major flatten, 2 epochs of 4
+    minibatches (the last one short) computed with NumPy + torch from the real doggo checkpoint.  The oracle's gae /
+    gather / train loop must land on the same advantages (bit for bit), losses and parameters."""
+    import os
+    from collections import OrderedDict
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_loop.npz"))
+    T, N, B, E, D, A = (int(x) for x in g["shape"])
+    gamma, lam, clip, ent_coef, vf_coef, max_norm, lr, eps = (float(x) for x in g["hyper"])
+    keys = O.param_keys()
+    p = OrderedDict((k, g[f"p0/{k}"].copy()) for k in keys)
+    st = O.AdamState(OrderedDict((k, g[f"m0/{k}"].copy()) for k in keys), OrderedDict((k, g[f"v0/{k}"].copy()) for k in keys),
+                     int(g["adam_step"]))
+    adv, ret = O.gae(g["rewards"], g["values"], g["episode_starts"], g["last_values"], g["dones"], gamma, lam)
+    assert np.array_equal(adv, g["advantages"]) and np.array_equal(ret, g["returns"])
+    buf = {k: g[k] for k in ("obs", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns")}
+    h = O.Hyper(gamma=gamma, gae_lambda=lam, clip_range=clip, ent_coef=ent_coef, vf_coef=vf_coef, max_grad_norm=max_norm,
+                learning_rate=lr, adam_eps=eps, n_epochs=E, batch_size=B)
+    stats = O.train(p, st, buf, h, g["perms"])
+    ref = g["stats"]
+    assert len(stats) == len(ref) == E * 4 and int(ref[3][7]) == T * N - 3 * B   # last minibatch of an epoch is short
+    for s, r in zip(stats, ref):
+        for k, j in (("policy_loss", 0), ("value_loss", 1), ("entropy_loss", 2), ("loss", 3), ("approx_kl", 4),
+                     ("clip_fraction", 5), ("grad_norm", 6)):
+            assert abs(float(s[k]) - r[j]) < 2e-5 * max(1.0, abs(r[j])), (k, float(s[k]), r[j])
+    for k in keys:
+        assert np.max(np.abs(p[k] - g[f"p1/{k}"])) < 2e-6, k
+        assert scaled_err(st.exp_avg[k], g[f"m1/{k}"]) < 1e-4, k
+    assert st.step == int(g["adam_step"]) + E * 4
