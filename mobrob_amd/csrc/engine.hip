@@ -1069,6 +1069,7 @@ int collect_device(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& s
     CHK(enqueue_rollout(e, sp));
   } else {
     if (e->ro_exec == nullptr || memcmp(&e->ro_spec, &sp, sizeof sp) != 0) {
+      HIPC(hipStreamSynchronize(e->stream));  // never destroy an executable graph that may still be running
       if (e->ro_exec) { (void)hipGraphExecDestroy(e->ro_exec); e->ro_exec = nullptr; }
       if (e->ro_graph) { (void)hipGraphDestroy(e->ro_graph); e->ro_graph = nullptr; }
       const bool prof = e->prof_on;

@@ -48,7 +48,7 @@ struct FusedTrainArgs {
   float clip, vf_coef, ent_coef, inv_bg;
   float* slabs;                  // [gridDim.x][slab_floats]
   int slab_floats;
-  float* sums;                   // [8] loss statistics (float atomics; diagnostics only)
+  float* sums;                   // [8] loss statistics (written by k_slab_reduce from the slabs' loss entries)
   unsigned long long* stamps;    // diagnostic build only (MOBROB_STAMPS): per-phase cycle sums
 };
 
