@@ -290,7 +290,7 @@ uint64_t eps_seed(const mobrob_ppo_engine* e) { return e->cfg.seed ^ (0xD1B54A32
 void run_gae(mobrob_ppo_engine* e) {
   ProfScope ps(e, MOBROB_K_GAE);
   const double gl = e->cfg.gamma * e->cfg.gae_lambda;  // python: self.gamma * self.gae_lambda (float64)
-  hipLaunchKernelGGL(k_gae, dim3(cdiv(e->N, 64)), dim3(64), 0, e->stream, e->rewards, e->values, e->es, e->last_values,
+  hipLaunchKernelGGL(k_gae, dim3(cdiv(e->N, kGaeEnvs)), dim3(kGaeThreads), 0, e->stream, e->rewards, e->values, e->es, e->last_values,
                      e->last_dones, (float)e->cfg.gamma, gl, e->T, e->N, e->adv, e->ret);
 }
 

@@ -275,67 +275,146 @@ __global__ __launch_bounds__(256) void k_value_flagged(const float* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 // GAE(lambda) reverse scan [SB3 RolloutBuffer.compute_returns_and_advantage; oracle gae()].
-// One lane per env, serial in t, [T][N] layout -> every wave load is 256 contiguous bytes.
-// Bit-exact vs the oracle: same operation order, explicit round-to-nearest ops (no fma contraction),
-// f64 carry.  Loads for the next kPF steps do not depend on the carry and are issued ahead.
+// The recurrence g[t] = delta[t] + coef[t] * g[t+1] is serial in t (and must stay in the oracle's order to be
+// bit-exact: float64 carry, one rounding per operation), but everything around it is not.  One block owns
+// kGaeEnvs = 16 envs (64-byte row segments of the [T][N] arrays -> cdiv(N,16) blocks: 256 at N = 4096) and walks
+// time in tiles of kGaeChunk = 64 steps with its waves specialised:
+//   wave 0 (16 lanes)   the serial steps of tile k out of LDS: two dependent f64 operations per step;
+//   waves 1-4           meanwhile write advantages / returns of tile k-1, turn the rows of tile k+1 (already in
+//                       registers) into delta and coef in the other LDS buffer -- no carry involved -- and issue
+//                       the global loads of tile k+2.
+// One barrier per tile.  The former one-lane-per-env kernel had 64 waves chip-wide and was bound by HBM latency
+// (205 us at T = 1000, N = 4096); this one is bound by the 1000-step dependent f64 chain.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_gae(const float* __restrict__ rewards, const float* __restrict__ values,
-                                            const float* __restrict__ episode_starts,
-                                            const float* __restrict__ last_values,
-                                            const float* __restrict__ last_dones, float gamma, double gl_d, int T,
-                                            int N, float* __restrict__ adv, float* __restrict__ ret) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+#ifndef GAE_SKIP
+#define GAE_SKIP 0  // timing-only ablation switch (scratch/time_gae.py)
+#endif
+constexpr int kGaeEnvs = 16;
+constexpr int kGaeChunk = 64;
+constexpr int kGaeThreads = 64 + 256;
+__device__ __forceinline__ double pinned(double x) {  // keeps a product from being contracted into the next add
+  asm volatile("" : "+v"(x));
+  return x;
+}
+__global__ __launch_bounds__(kGaeThreads) void k_gae(const float* __restrict__ rewards,
+                                                     const float* __restrict__ values,
+                                                     const float* __restrict__ episode_starts,
+                                                     const float* __restrict__ last_values,
+                                                     const float* __restrict__ last_dones, float gamma, double gl_d,
+                                                     int T, int N, float* __restrict__ adv, float* __restrict__ ret) {
+  constexpr int E = kGaeEnvs, C = kGaeChunk, PER = C * E / 256;
+  // row j of tile k <-> t = tlo(k) + j.  delta / coef / carry cross LDS as float64 so that the conversions (as slow
+  // as the f64 arithmetic itself) are done by the loader waves, not on the serial chain.
+  __shared__ double s_d[2][C * E], s_c[2][C * E], s_a[2][C * E];
+  __shared__ float s_v[2][C * E];
+  const int tid = threadIdx.x, n0 = blockIdx.x * E;
   const float gl_f = (float)gl_d;  // python-float gamma*lambda meets a float32 array -> rounded to f32
-  // t = T-1: float64 arithmetic because `1.0 - dones` (bool) is float64 in SB3
-  double g;
-  {
-    const size_t o = (size_t)(T - 1) * N + n;
-    const double nnt = 1.0 - (double)last_dones[n];
-    const float gv = __fmul_rn(gamma, last_values[n]);
-    const double tmp = __dmul_rn((double)gv, nnt);
-    const float v = values[o];
-    const double delta = __dsub_rn(__dadd_rn((double)rewards[o], tmp), (double)v);
-    g = delta;  // + (gl * nnt) * 0
-    const float a = (float)g;
-    adv[o] = a;
-    ret[o] = __fadd_rn(a, v);
-  }
-  constexpr int kPF = 8;
-  int t = T - 2;
-  for (; t >= kPF - 1; t -= kPF) {
-    float r[kPF], v[kPF], vn[kPF], es[kPF];
+  const int K = (T - 1 + C - 1) / C;  // tiles over t = T-2 .. 0; tile k ends at t_hi = T-2 - k*C
+  const bool scan_wave = tid < 64;
+  const int lt = tid - 64;  // loader thread id
+
+  float pr[PER], pv[PER], pn[PER], pe[PER];
+  auto fetch = [&](int k) {  // rows of tile k -> registers (rows with t < 0 are padding)
+    const int tlo = T - 2 - k * C - C + 1;
 #pragma unroll
-    for (int j = 0; j < kPF; ++j) {
-      const size_t o = (size_t)(t - j) * N + n;
-      r[j] = rewards[o];
-      v[j] = values[o];
-      vn[j] = values[o + N];
-      es[j] = episode_starts[o + N];
+    for (int i = 0; i < PER; ++i) {
+      const int idx = lt + i * 256, t = tlo + (idx / E), n = n0 + (idx % E);
+      const bool ok = t >= 0 && n < N;
+      const size_t o = ok ? (size_t)t * N + n : 0;
+      pr[i] = ok ? rewards[o] : 0.f;
+      pv[i] = ok ? values[o] : 0.f;
+      pn[i] = ok ? values[o + N] : 0.f;
+      pe[i] = ok ? episode_starts[o + N] : 0.f;
     }
+  };
+  auto stash = [&](int b) {  // registers -> delta / coef / values of the tile in LDS buffer b
 #pragma unroll
-    for (int j = 0; j < kPF; ++j) {
-      const size_t o = (size_t)(t - j) * N + n;
-      const float nnt = __fsub_rn(1.0f, es[j]);
-      const float delta = __fsub_rn(__fadd_rn(r[j], __fmul_rn(__fmul_rn(gamma, vn[j]), nnt)), v[j]);
-      const float coef = __fmul_rn(gl_f, nnt);
-      g = __dadd_rn((double)delta, __dmul_rn((double)coef, g));
+    for (int i = 0; i < PER; ++i) {
+      const int idx = lt + i * 256;
+      const float nnt = __fsub_rn(1.0f, pe[i]);
+      s_d[b][idx] = (double)__fsub_rn(__fadd_rn(pr[i], __fmul_rn(__fmul_rn(gamma, pn[i]), nnt)), pv[i]);
+      s_c[b][idx] = (double)__fmul_rn(gl_f, nnt);
+      s_v[b][idx] = pv[i];
+    }
+  };
+  auto write_out = [&](int k) {
+    const int tlo = T - 2 - k * C - C + 1, b = k & 1;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = lt + i * 256, t = tlo + (idx / E), n = n0 + (idx % E);
+      if (t >= 0 && n < N) {
+        const size_t o = (size_t)t * N + n;
+        const float a = (float)s_a[b][idx];
+        adv[o] = a;
+        ret[o] = __fadd_rn(a, s_v[b][idx]);
+      }
+    }
+  };
+
+  double g = 0.0;
+  if (scan_wave) {
+    if (tid < E && n0 + tid < N) {  // t = T-1: float64 arithmetic because `1.0 - dones` (bool) is float64 in SB3
+      const int n = n0 + tid;
+      const size_t o = (size_t)(T - 1) * N + n;
+      const double nnt = 1.0 - (double)last_dones[n];
+      const float gv = __fmul_rn(gamma, last_values[n]);
+      const double tmp = pinned(__dmul_rn((double)gv, nnt));
+      const float v = values[o];
+      g = __dsub_rn(__dadd_rn((double)rewards[o], tmp), (double)v);  // + (gl * nnt) * 0
       const float a = (float)g;
       adv[o] = a;
-      ret[o] = __fadd_rn(a, v[j]);
+      ret[o] = __fadd_rn(a, v);
     }
+  } else if (K > 0) {
+    fetch(0);
+    stash(0);
+    if (K > 1) fetch(1);
   }
-  for (; t >= 0; --t) {
-    const size_t o = (size_t)t * N + n;
-    const float v = values[o];
-    const float nnt = __fsub_rn(1.0f, episode_starts[o + N]);
-    const float delta = __fsub_rn(__fadd_rn(rewards[o], __fmul_rn(__fmul_rn(gamma, values[o + N]), nnt)), v);
-    const float coef = __fmul_rn(gl_f, nnt);
-    g = __dadd_rn((double)delta, __dmul_rn((double)coef, g));
-    const float a = (float)g;
-    adv[o] = a;
-    ret[o] = __fadd_rn(a, v);
+  __syncthreads();
+  for (int k = 0; k < K; ++k) {
+    if (scan_wave) {
+      if (tid < E && !(GAE_SKIP & 1)) {  // padding rows (t < 0, last tile only) are scanned too: their results are never written out
+        const double* sd = s_d[k & 1] + tid;
+        const double* sc = s_c[k & 1] + tid;
+        double* sa = s_a[k & 1] + tid;
+        double d[8], c[8], dn[8], cn[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          d[u] = sd[(C - 1 - u) * E];
+          c[u] = sc[(C - 1 - u) * E];
+        }
+#pragma unroll
+        for (int j = C - 1; j >= 0; j -= 8) {
+          if (j - 8 >= 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              dn[u] = sd[(j - 8 - u) * E];
+              cn[u] = sc[(j - 8 - u) * E];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {  // the chain first, its eight LDS stores after it
+            g = __dadd_rn(d[u], pinned(__dmul_rn(c[u], g)));
+            d[u] = g;
+          }
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int u = 0; u < 8; ++u) sa[(j - u) * E] = d[u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            d[u] = dn[u];
+            c[u] = cn[u];
+          }
+        }
+      }
+    } else {
+      if (k >= 1 && !(GAE_SKIP & 2)) write_out(k - 1);
+      if (k + 1 < K && !(GAE_SKIP & 8)) stash((k + 1) & 1);
+      if (k + 2 < K && !(GAE_SKIP & 4)) fetch(k + 2);
+    }
+    __syncthreads();
   }
+  if (!scan_wave && K > 0) write_out(K - 1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -44,7 +44,9 @@ def test_act_matches_golden_and_oracle(env, fast):
     e.close()
 
 
-@pytest.mark.parametrize("T,N", [(1, 1), (2, 3), (37, 5), (64, 130), (257, 64)])
+# k_gae walks time in 64-step tiles over 16-env column groups: cover both sides of every boundary
+@pytest.mark.parametrize("T,N", [(1, 1), (2, 3), (37, 5), (64, 130), (257, 64), (65, 16), (66, 17), (129, 15), (130, 33),
+                                 (1000, 48)])
 def test_gae_bit_exact(T, N):
     buf, lv, dones = synthetic_rollout(T, N, 4, 2, seed=T * 1000 + N, p_done=0.05)
     e = make_engine(obs_dim=4, act_dim=2, n_envs=N, n_steps=T, batch_size=8, n_epochs=1, gamma=0.99, gae_lambda=0.95)
