@@ -173,6 +173,10 @@ def main():
     ap.add_argument("--workload", default="doggo-4096env-2x256", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the generic (unfused) kernels")
+    ap.add_argument("--host-python-loop", action="store_true",
+                    help="host-env workloads: drive the pipelined rollout from Python instead of mobrob_ppo_collect_host")
+    ap.add_argument("--host-parts", type=int, default=2,
+                    help="host-env workloads: row ranges of the pipelined rollout (1 = whole batch per step)")
     args = ap.parse_args()
     w = WORKLOADS[args.workload]
 
@@ -226,13 +230,29 @@ def main():
                   trunc=eng.pinned((N,), np.uint8), term=eng.pinned((N, D)))
         host.use_buffers(obs=hb["obs"], rewards=hb["rew"], dones=hb["done"], truncated=hb["trunc"], terminal_obs=hb["term"])
         host.reset()
+        pipe = (eng.part_pipeline(args.host_parts, hb["obs"], hb["clip"], hb["rew"], hb["done"], hb["trunc"], hb["term"])
+                if args.host_parts > 1 else None)
 
     def host_rollout():
         eng.rollout_begin()
-        for _ in range(T):
-            eng.act(hb["obs"], out_clipped=hb["clip"], want_all=False)
-            nt = host.step_arrays(hb["clip"])[5]
-            eng.store(hb["rew"], hb["done"], hb["trunc"] if nt else None, hb["term"] if nt else None)
+        if args.host_parts > 1 and not args.host_python_loop:  # the whole pipelined collector loop in one native call
+            pipe.collect(host.step_range_fn, host.handle)
+            return
+        if args.host_parts > 1:  # same pipeline driven from Python (what a Python-stepped env would use)
+            for p in range(args.host_parts):
+                pipe.act(p)
+            for t in range(T):
+                for p in range(args.host_parts):
+                    pipe.wait(p)
+                    nt = host.step_range(*pipe.bounds[p], hb["clip"])
+                    pipe.store(p, nt > 0)
+                    if t + 1 < T:
+                        pipe.act(p)
+        else:
+            for _ in range(T):
+                eng.act(hb["obs"], out_clipped=hb["clip"], want_all=False)
+                nt = host.step_arrays(hb["clip"])[5]
+                eng.store(hb["rew"], hb["done"], hb["trunc"] if nt else None, hb["term"] if nt else None)
         eng.finish_rollout(hb["obs"], hb["done"])
 
     def iteration():
@@ -290,7 +310,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "obs_dim": D, "act_dim": A, "net_arch": [H, H], "envs_per_gpu": N,
                        "n_steps": T, "n_epochs": E, "minibatch_per_gpu": B, "minibatches_per_epoch": nmb,
-                       "env_source": ("native host env (csrc/host_env.c, OpenMP), pinned zero-copy staging over PCIe"
+                       "env_source": (f"native host env (csrc/host_env.c, OpenMP), pinned zero-copy staging over PCIe, {args.host_parts} pipelined row ranges"
                                       if host is not None else "device-resident synthetic (Philox)"),
                        "parallelism": f"dp{world}", "kernels": "generic" if args.generic else "fused"},
             "roofline": {"bound": "mfma", "kernel": "k_fused_train (minibatch forward+loss+backward)" if not args.generic else "generic GEMM chain",

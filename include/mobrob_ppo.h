@@ -141,6 +141,42 @@ int mobrob_ppo_act(mobrob_ppo_engine_t* e, const float* obs, const float* eps, f
 int mobrob_ppo_store(mobrob_ppo_engine_t* e, const float* rewards, const uint8_t* dones,
                      const uint8_t* truncated, const float* terminal_obs);
 
+/* ---- pipelined host-environment rollout -------------------------------------------------------------------
+ * Same results as act()/store() over all N rows, but the rows are cut into `nparts` contiguous ranges
+ * [N*part/nparts, N*(part+1)/nparts) so that the host simulator steps one range while the GPU runs the policy for
+ * another (the reference alternates strictly: SubprocVecEnv.step_async/step_wait after policy.forward,
+ * ppo.py:30-33 + SB3 collect_rollouts).  Every pointer is the FULL [N][...] array in device-visible pinned memory
+ * (mobrob_ppo_host_alloc); a call touches only the rows of its part.
+ *   act_part    enqueue: pull the part's obs rows -> policy/value forward + sample -> push its clipped actions;
+ *               returns without waiting
+ *   wait_part   block until the clipped actions of the part's latest act_part are in actions_clipped
+ *   store_part  enqueue rollout_buffer.add for the part (rewards, episode starts, time-limit bootstrap); with
+ *               next_obs != NULL the same launch also pulls the part's next observations into slot t+1, so the
+ *               following act_part launches the policy kernel only
+ * Each part keeps its own step index (part p may act on step t+1 before part q has stored step t);
+ * finish_rollout() requires every part to have stored n_steps steps.  nparts is fixed between rollout_begin()
+ * and finish_rollout(), 1 <= nparts <= MOBROB_MAX_PARTS. */
+#define MOBROB_MAX_PARTS 8
+int mobrob_ppo_act_part(mobrob_ppo_engine_t* e, int32_t part, int32_t nparts, const float* obs,
+                        float* actions_clipped);
+int mobrob_ppo_wait_part(mobrob_ppo_engine_t* e, int32_t part);
+int mobrob_ppo_store_part(mobrob_ppo_engine_t* e, int32_t part, int32_t nparts, const float* rewards,
+                          const uint8_t* dones, const uint8_t* truncated, const float* terminal_obs,
+                          const float* next_obs);
+
+/* The whole pipelined rollout as ONE native call -- SB3's collect_rollouts loop (on_policy_algorithm.py, reached via
+ * ppo.py:73-74) without a Python frame per step: rollout_begin, n_steps x nparts x (wait_part, step_range of the
+ * part's envs, store_part + act_part), finish_rollout.  `step_range(env, i0, i1, actions, obs, rewards, dones,
+ * truncated, terminal_obs)` steps the envs [i0, i1) of a vectorised environment over the FULL pinned arrays (VecEnv
+ * semantics: auto-reset, terminal observation of truncated rows) and returns how many of them were truncated (< 0:
+ * error).  csrc/host_env.c's mobrob_hostenv_step_range has exactly this signature.  `obs` must hold the current
+ * observations (VecEnv.reset() or the previous rollout's last step) on entry and holds the last ones on return. */
+typedef int32_t (*mobrob_env_step_range_fn)(void* env, int32_t i0, int32_t i1, const float* actions, float* obs,
+                                            float* rewards, uint8_t* dones, uint8_t* truncated, float* terminal_obs);
+int mobrob_ppo_collect_host(mobrob_ppo_engine_t* e, mobrob_env_step_range_fn step_range, void* env, int32_t nparts,
+                            float* obs, float* actions_clipped, float* rewards, uint8_t* dones, uint8_t* truncated,
+                            float* terminal_obs);
+
 /* `values = policy.predict_values(new_obs)` + RolloutBuffer.compute_returns_and_advantage
  * (GAE(lambda) reverse scan).  last_obs[N*D], dones[N] = dones of the final step. */
 int mobrob_ppo_finish_rollout(mobrob_ppo_engine_t* e, const float* last_obs, const uint8_t* dones);

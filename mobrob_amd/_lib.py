@@ -75,6 +75,10 @@ SYMBOLS = {
     "mobrob_ppo_rollout_begin": (C.c_int, [_P]),
     "mobrob_ppo_act": (C.c_int, [_P, _F, _F, _F, _F, _F, _F]),
     "mobrob_ppo_store": (C.c_int, [_P, _F, _U8, _U8, _F]),
+    "mobrob_ppo_act_part": (C.c_int, [_P, C.c_int32, C.c_int32, _F, _F]),
+    "mobrob_ppo_wait_part": (C.c_int, [_P, C.c_int32]),
+    "mobrob_ppo_store_part": (C.c_int, [_P, C.c_int32, C.c_int32, _F, _U8, _U8, _F, _F]),
+    "mobrob_ppo_collect_host": (C.c_int, [_P, _P, _P, C.c_int32, _F, _F, _F, _U8, _U8, _F]),
     "mobrob_ppo_finish_rollout": (C.c_int, [_P, _F, _U8]),
     "mobrob_ppo_collect_synthetic": (C.c_int, [_P, C.c_float, C.c_int32]),
     "mobrob_ppo_collect_goal_env": (C.c_int, [_P, C.POINTER(GoalEnv)]),

@@ -8,6 +8,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -99,6 +101,14 @@ struct mobrob_ppo_engine {
   float* gstate[2] = {nullptr, nullptr};  // goal env state, double buffered [N][kGoalStateFloats]
   double* ep_stats = nullptr;             // [4] episode statistics of the goal env
   uint32_t draw_counter = 0;  // Philox draw index for eps
+  // pipelined host-env rollout (act_part / wait_part / store_part): per-part step indices and completion events
+  int nparts = 0;
+  int part_act_t[MOBROB_MAX_PARTS] = {0}, part_store_t[MOBROB_MAX_PARTS] = {0};
+  int part_obs_t[MOBROB_MAX_PARTS] = {0};  // rollout slot whose observations store_part already pulled (-1: none)
+  hipEvent_t ev_part[MOBROB_MAX_PARTS] = {nullptr};
+  const void* pinned_seen[8] = {nullptr};  // pointers validated by is_pinned_cached since rollout_begin
+  unsigned pinned_seen_n = 0;
+  uint32_t draw_ro0 = 0;  // draw_counter at rollout_begin: part p at its step t draws with draw_ro0 + t
   uint32_t env_step_counter = 0;
   int t = 0;
   bool rollout_ready = false;
@@ -294,26 +304,33 @@ void run_gae(mobrob_ppo_engine* e) {
                      e->last_dones, (float)e->cfg.gamma, gl, e->T, e->N, e->adv, e->ret);
 }
 
-// policy forward + sample for rollout slot t (observations already in the slot)
-void act_slot(mobrob_ppo_engine* e, int t, const float* eps_dev_or_null, bool device_counter = false) {
-  const uint32_t draw = device_counter ? (uint32_t)t : e->draw_counter;
-  const uint32_t* draw_base = device_counter ? e->ctr_dev : nullptr;
+// policy forward + sample for rows [r0, r0 + n) of rollout slot t (observations already in the slot).
+// draw = Philox draw index of the step (the whole-step callers pass the running counter and advance it).
+void act_rows(mobrob_ppo_engine* e, int t, int r0, int n, const float* eps_dev_or_null, uint32_t draw,
+              const uint32_t* draw_base, float* clip_out = nullptr) {
+  // clip_out: where the clipped actions of the rows go (default: the device staging rows; the pipelined host path
+  // passes the caller's pinned buffer -- the sampling epilogue writes them over PCIe itself, no copy kernel)
   ProfScope ps(e, MOBROB_K_ACT);
-  const float* X = e->obs + (size_t)t * e->N * e->Dp;
+  if (!clip_out) clip_out = e->clip_act + (size_t)r0 * e->A;
+  const size_t row = (size_t)t * e->N + r0;
+  const float* X = e->obs + row * e->Dp;
   if (e->fused.enabled) {
     FusedActArgs a{};
-    a.X = X; a.rows = e->N; a.want_pi = 1; a.want_v = 1; a.mu = nullptr; a.ldmu = e->Ap;
-    a.v = e->values + (size_t)t * e->N; a.sample = 1; a.A = e->A; a.log_std = Pp(e, T_LOGSTD); a.eps = eps_dev_or_null;
+    a.X = X; a.rows = n; a.row0 = r0; a.want_pi = 1; a.want_v = 1; a.mu = nullptr; a.ldmu = e->Ap;
+    a.v = e->values + row; a.sample = 1; a.A = e->A; a.log_std = Pp(e, T_LOGSTD); a.eps = eps_dev_or_null;
     a.seed = eps_seed(e); a.draw = draw; a.draw_base = draw_base; a.lo = (float)e->cfg.action_low; a.hi = (float)e->cfg.action_high;
-    a.act_raw = e->actions + (size_t)t * e->N * e->A; a.act_clip = e->clip_act; a.logp = e->logp + (size_t)t * e->N;
+    a.act_raw = e->actions + row * e->A; a.act_clip = clip_out; a.logp = e->logp + row;
     fused_launch_act(e->fused, a, e->stream);
-    if (!device_counter) e->draw_counter++;
     return;
   }
-  forward(e, X, e->N, true, e->mu, true, e->values + (size_t)t * e->N);
-  hipLaunchKernelGGL(k_sample, dim3(cdiv(e->N, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, Pp(e, T_LOGSTD),
-                     eps_dev_or_null, e->N, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high, eps_seed(e),
-                     draw, draw_base, e->actions + (size_t)t * e->N * e->A, e->clip_act, e->logp + (size_t)t * e->N);
+  forward(e, X, n, true, e->mu, true, e->values + row);
+  hipLaunchKernelGGL(k_sample, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, Pp(e, T_LOGSTD),
+                     eps_dev_or_null, n, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high, eps_seed(e),
+                     draw, draw_base, e->actions + row * e->A, clip_out, e->logp + row, r0);
+}
+void act_slot(mobrob_ppo_engine* e, int t, const float* eps_dev_or_null, bool device_counter = false) {
+  act_rows(e, t, 0, e->N, eps_dev_or_null, device_counter ? (uint32_t)t : e->draw_counter,
+           device_counter ? e->ctr_dev : nullptr);
   if (!device_counter) e->draw_counter++;
 }
 
@@ -432,6 +449,15 @@ bool is_pinned(const void* p) {
     return false;
   }
   return at.type == hipMemoryTypeHost;
+}
+// The per-step calls of the pipelined host path see the same few buffers for a whole rollout: a pointer that was
+// found pinned is remembered until the next rollout_begin (the driver query costs about a microsecond each time).
+bool is_pinned_cached(mobrob_ppo_engine* e, const void* p) {
+  for (const void* q : e->pinned_seen)
+    if (q == p) return true;
+  if (!is_pinned(p)) return false;
+  e->pinned_seen[e->pinned_seen_n++ % 8] = p;
+  return true;
 }
 int streamer_init(mobrob_ppo_engine* e) {
   if (e->cstream) return MOBROB_OK;
@@ -668,6 +694,8 @@ void mobrob_ppo_destroy(mobrob_ppo_engine_t* e) {
     (void)hipEventDestroy(e->ev_in); (void)hipEventDestroy(e->ev_k); (void)hipEventDestroy(e->ev_store);
     (void)hipStreamDestroy(e->cstream);
   }
+  for (hipEvent_t ev : e->ev_part)
+    if (ev) (void)hipEventDestroy(ev);
   if (e->ro_exec) (void)hipGraphExecDestroy(e->ro_exec);
   if (e->ro_graph) (void)hipGraphDestroy(e->ro_graph);
   if (e->vstream) {
@@ -741,6 +769,14 @@ int mobrob_ppo_rollout_begin(mobrob_ppo_engine_t* e) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   e->t = 0;
   e->rollout_ready = false;
+  e->nparts = 0;
+  for (auto& q : e->pinned_seen) q = nullptr;
+  e->pinned_seen_n = 0;
+  e->draw_ro0 = e->draw_counter;
+  for (int p = 0; p < MOBROB_MAX_PARTS; ++p) {
+    e->part_act_t[p] = e->part_store_t[p] = 0;
+    e->part_obs_t[p] = -1;
+  }
   return MOBROB_OK;
 }
 
@@ -858,6 +894,119 @@ int mobrob_ppo_store(mobrob_ppo_engine_t* e, const float* rewards, const uint8_t
   e->stage_i ^= 1;
   e->t++;
   return MOBROB_OK;
+}
+
+// ---- pipelined host-env rollout: the same arithmetic as act()/store(), one contiguous row range at a time ----
+namespace {
+int part_range(mobrob_ppo_engine* e, int part, int nparts, int* r0, int* n) {
+  if (nparts < 1 || nparts > MOBROB_MAX_PARTS || nparts > e->N || part < 0 || part >= nparts)
+    return fail(MOBROB_ERR_INVALID, "part %d of %d (1..%d parts, at most one per env)", part, nparts, MOBROB_MAX_PARTS);
+  if (e->nparts == 0) e->nparts = nparts;
+  if (e->nparts != nparts) return fail(MOBROB_ERR_STATE, "nparts changed from %d to %d inside a rollout", e->nparts, nparts);
+  *r0 = (int)((int64_t)e->N * part / nparts);
+  *n = (int)((int64_t)e->N * (part + 1) / nparts) - *r0;
+  return MOBROB_OK;
+}
+}  // namespace
+
+int mobrob_ppo_act_part(mobrob_ppo_engine_t* e, int32_t part, int32_t nparts, const float* obs, float* a_clip) {
+  if (!e || !obs || !a_clip) return fail(MOBROB_ERR_INVALID, "act_part: null argument");
+  int r0, n;
+  CHK(part_range(e, part, nparts, &r0, &n));
+  const int t = e->part_act_t[part];
+  if (t >= e->T) return fail(MOBROB_ERR_STATE, "act_part: rollout buffer full (part %d, t=%d)", part, t);
+  if (t != e->part_store_t[part]) return fail(MOBROB_ERR_STATE, "act_part: part %d acted on step %d but has not stored it", part, t - 1);
+  if (!is_pinned_cached(e, obs) || !is_pinned_cached(e, a_clip))
+    return fail(MOBROB_ERR_INVALID, "act_part needs device-visible pinned buffers (mobrob_ppo_host_alloc)");
+  if (!e->ev_part[part]) HIPC(hipEventCreateWithFlags(&e->ev_part[part], hipEventDisableTiming));
+  const size_t D = e->D, A = e->A;
+  if (e->part_obs_t[part] != t)  // not already pulled by the preceding store_part(next_obs)
+    hipLaunchKernelGGL(k_pull_rows, dim3(cdiv(n * e->Dp, 256)), dim3(256), 0, e->stream, obs + (size_t)r0 * D,
+                       e->obs + ((size_t)t * e->N + r0) * e->Dp, n, (int)D, e->Dp);
+  act_rows(e, t, r0, n, nullptr, e->draw_ro0 + (uint32_t)t, nullptr, a_clip + (size_t)r0 * A);
+  HIPC(hipGetLastError());
+  HIPC(hipEventRecord(e->ev_part[part], e->stream));
+  e->part_act_t[part] = t + 1;
+  if (e->draw_counter < e->draw_ro0 + (uint32_t)t + 1) e->draw_counter = e->draw_ro0 + (uint32_t)t + 1;
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_wait_part(mobrob_ppo_engine_t* e, int32_t part) {
+  if (!e || part < 0 || part >= MOBROB_MAX_PARTS || !e->ev_part[part])
+    return fail(MOBROB_ERR_STATE, "wait_part: part %d has no act_part in flight", part);
+  HIPC(hipEventSynchronize(e->ev_part[part]));
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_store_part(mobrob_ppo_engine_t* e, int32_t part, int32_t nparts, const float* rewards,
+                          const uint8_t* dones, const uint8_t* truncated, const float* terminal_obs,
+                          const float* next_obs) {
+  if (!e || !rewards || !dones) return fail(MOBROB_ERR_INVALID, "store_part: null argument");
+  int r0, n;
+  CHK(part_range(e, part, nparts, &r0, &n));
+  const int t = e->part_store_t[part];
+  if (t + 1 != e->part_act_t[part]) return fail(MOBROB_ERR_STATE, "store_part: part %d has no acted step to store (t=%d)", part, t);
+  if (!is_pinned_cached(e, rewards) || !is_pinned_cached(e, dones) || (truncated && !is_pinned_cached(e, truncated)) ||
+      (terminal_obs && !is_pinned_cached(e, terminal_obs)) || (next_obs && !is_pinned_cached(e, next_obs)))
+    return fail(MOBROB_ERR_INVALID, "store_part needs device-visible pinned buffers (mobrob_ppo_host_alloc)");
+  bool any = false;
+  if (truncated && terminal_obs)
+    for (int i = r0; i < r0 + n; ++i) any |= truncated[i] != 0;
+  const size_t o = (size_t)t * e->N + r0;
+  StorePullArgs a{};
+  a.rew_in = rewards + r0; a.dones = dones + r0;
+  a.trunc = any ? truncated + r0 : nullptr; a.term_obs = any ? terminal_obs + (size_t)r0 * e->D : nullptr;
+  a.W1 = Pp(e, T_VW1); a.b1 = Pp(e, T_VB1); a.W2 = Pp(e, T_VW2); a.b2 = Pp(e, T_VB2); a.Wv = Pp(e, T_VW); a.bv = Pp(e, T_VB);
+  a.D = e->D; a.Dp = e->Dp; a.G1 = e->G1; a.G2 = e->G2; a.n = n; a.gamma = (float)e->cfg.gamma;
+  a.prev_dones = e->prev_dones + r0; a.rew_out = e->rewards + o; a.es_out = e->es + o; a.term_val = e->term_val + r0;
+  if (next_obs) {  // slot t+1 exists for every t < T (slot T holds the last observations)
+    a.next_obs = next_obs + (size_t)r0 * e->D;
+    a.obs_slot = e->obs + ((size_t)(t + 1) * e->N + r0) * e->Dp;
+    e->part_obs_t[part] = t + 1;
+  }
+  const size_t sm = (size_t)(e->D + e->G1 + e->G2 + 32) * sizeof(float);
+  hipLaunchKernelGGL(k_store_pull_part, dim3(cdiv(n, kPartRows)), dim3(256), sm, e->stream, a);
+  HIPC(hipGetLastError());
+  e->part_store_t[part] = t + 1;
+  int tmin = e->T;
+  for (int p = 0; p < nparts; ++p) tmin = std::min(tmin, e->part_store_t[p]);
+  e->t = tmin;
+  return MOBROB_OK;
+}
+
+// The whole pipelined rollout in one call: rollout_begin, n_steps x nparts x (wait_part, env step of the range,
+// store_part + act_part), finish_rollout -- the collector loop of SB3's collect_rollouts as native code, driving a
+// native vectorised environment through one function pointer.
+int mobrob_ppo_collect_host(mobrob_ppo_engine_t* e, mobrob_env_step_range_fn step_range, void* env, int32_t nparts,
+                            float* obs, float* actions_clipped, float* rewards, uint8_t* dones, uint8_t* truncated,
+                            float* terminal_obs) {
+  if (!e || !step_range || !obs || !actions_clipped || !rewards || !dones || !truncated || !terminal_obs)
+    return fail(MOBROB_ERR_INVALID, "collect_host: null argument");
+  CHK(mobrob_ppo_rollout_begin(e));
+  for (int p = 0; p < nparts; ++p) CHK(mobrob_ppo_act_part(e, p, nparts, obs, actions_clipped));
+  const bool timing = getenv("MOBROB_COLLECT_TIMING") != nullptr;
+  double tw = 0, te = 0, tq = 0;
+  auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
+  for (int t = 0; t < e->T; ++t) {
+    for (int p = 0; p < nparts; ++p) {
+      int r0, n;
+      CHK(part_range(e, p, nparts, &r0, &n));
+      const double t0 = timing ? now() : 0;
+      CHK(mobrob_ppo_wait_part(e, p));
+      const double t1 = timing ? now() : 0;
+      const int32_t ntrunc = step_range(env, r0, r0 + n, actions_clipped, obs, rewards, dones, truncated, terminal_obs);
+      const double t2 = timing ? now() : 0;
+      if (ntrunc < 0) return fail(MOBROB_ERR_STATE, "collect_host: the environment's step_range returned %d", ntrunc);
+      CHK(mobrob_ppo_store_part(e, p, nparts, rewards, dones, ntrunc ? truncated : nullptr,
+                                ntrunc ? terminal_obs : nullptr, obs));
+      if (t + 1 < e->T) CHK(mobrob_ppo_act_part(e, p, nparts, obs, actions_clipped));
+      if (timing) { tw += t1 - t0; te += t2 - t1; tq += now() - t2; }
+    }
+  }
+  if (timing)
+    fprintf(stderr, "[collect_host] per step: wait %.1f us, env %.1f us, enqueue %.1f us (%d parts)\n", tw / e->T, te / e->T,
+            tq / e->T, nparts);
+  return mobrob_ppo_finish_rollout(e, obs, dones);
 }
 
 int mobrob_ppo_finish_rollout(mobrob_ppo_engine_t* e, const float* last_obs, const uint8_t* dones) {

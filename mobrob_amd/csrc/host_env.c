@@ -10,7 +10,8 @@
  * csrc/kernels_env.h, not a simulator port.  This file is the ENVIRONMENT (what sits below the drop-in boundary);
  * it contains no PPO arithmetic and is not a fallback for anything in libmobrob_ppo.
  *
- * gcc -O3 -fopenmp -shared -fPIC -o libmobrob_hostenv.so host_env.c -lm     (built by __graft_entry__.build())
+ * gcc -O3 -ffast-math -mavx2 -mfma -fopenmp -shared -fPIC -o libmobrob_hostenv.so host_env.c -lm
+ *                                                                          (built by __graft_entry__.build())
  */
 #include <math.h>
 #include <omp.h>
@@ -48,14 +49,45 @@ static inline uint64_t next_u64(uint64_t* s) {
   return r;
 }
 static inline double next_unit(uint64_t* s) { return ((double)(next_u64(s) >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
-/* two standard normals per 64 random bits (float Box-Muller: the padding features are sensor noise) */
-static inline void next_normal2(uint64_t* s, float* a, float* b) {
-  const uint64_t r = next_u64(s);
-  const float u = ((float)(uint32_t)(r >> 40) + 0.5f) * (1.0f / 16777216.0f);
-  const float v = ((float)(uint32_t)((r >> 8) & 0xFFFFFF) + 0.5f) * (1.0f / 16777216.0f);
-  const float m = sqrtf(-2.0f * logf(u));
-  *a = m * cosf(6.2831853f * v);
-  *b = m * sinf(6.2831853f * v);
+/* Observation padding noise: `count` standard normals scaled by `scale`, two per 64 random bits (Box-Muller in float:
+ * the padding features are sensor noise).  The random words are drawn first (the generator is serial), the
+ * transcendental part is a branch-free loop over arrays that the compiler vectorises (-O3 -mavx2 -mfma): ln and
+ * sin/cos are short polynomials (relative error ~1e-6, far below what a noise source needs).  This is 80 % of an env
+ * step for doggo (49 padding features). */
+#define MAX_PAIRS 64
+static inline void fill_normals(uint64_t* s, float* out, int count, float scale) {
+  uint32_t ua[MAX_PAIRS], va[MAX_PAIRS];
+  float c[MAX_PAIRS], d[MAX_PAIRS];
+  const int np = (count + 1) / 2;
+  for (int i = 0; i < np; ++i) {
+    const uint64_t r = next_u64(s);
+    ua[i] = (uint32_t)(r >> 40);
+    va[i] = (uint32_t)((r >> 8) & 0xFFFFFF);
+  }
+  for (int i = 0; i < np; ++i) {
+    /* u in (0,1): -2 ln u = -2 (e ln2 + ln m), m in [1,2); ln m = 2 atanh((m-1)/(m+1)) */
+    const float u = ((float)ua[i] + 0.5f) * (1.0f / 16777216.0f);
+    union { float f; uint32_t i; } b;
+    b.f = u;
+    const float e = (float)((int)(b.i >> 23) - 127);
+    b.i = (b.i & 0x007FFFFFu) | 0x3F800000u;
+    const float q = (b.f - 1.0f) / (b.f + 1.0f), q2 = q * q;
+    const float lnm = 2.0f * q * (1.0f + q2 * (1.0f / 3.0f + q2 * (1.0f / 5.0f + q2 * (1.0f / 7.0f + q2 * (1.0f / 9.0f + q2 * (1.0f / 11.0f))))));
+    const float mag = scale * sqrtf(-2.0f * (e * 0.69314718056f + lnm));
+    /* angle 2 pi v: quadrant k = floor(4v), f = 4v - k in [0,1); sin/cos of f pi/2 by polynomials, then rotate */
+    const uint32_t vi = va[i];
+    const int k = (int)(vi >> 22);
+    const float f = ((float)(vi & 0x3FFFFF) + 0.5f) * (1.0f / 4194304.0f);
+    const float x = f * 1.57079632679f, x2 = x * x;
+    const float sn = x * (1.0f + x2 * (-1.0f / 6.0f + x2 * (1.0f / 120.0f + x2 * (-1.0f / 5040.0f + x2 * (1.0f / 362880.0f)))));
+    const float cs = 1.0f + x2 * (-0.5f + x2 * (1.0f / 24.0f + x2 * (-1.0f / 720.0f + x2 * (1.0f / 40320.0f + x2 * (-1.0f / 3628800.0f)))));
+    const float a0 = (k & 1) ? -sn : cs, b0 = (k & 1) ? cs : sn; /* rotate by k quarter turns */
+    c[i] = mag * ((k & 2) ? -a0 : a0);
+    d[i] = mag * ((k & 2) ? -b0 : b0);
+  }
+  const int nd = count - np;
+  for (int i = 0; i < np; ++i) out[i] = c[i];
+  for (int i = 0; i < nd; ++i) out[np + i] = d[i];
 }
 static inline uint64_t splitmix(uint64_t* x) {
   uint64_t z = (*x += 0x9E3779B97F4A7C15ull);
@@ -78,18 +110,7 @@ static void write_obs(const mobrob_hostenv* e, env_state* s, float* o) {
   for (int j = 0; j < p && k < d; ++j) o[k++] = (float)((s->goal[j] - s->pos[j]) / dn);
   for (int j = 0; j < p && k < d; ++j) o[k++] = (float)s->vel[j];
   for (int j = 0; j < p && k < d; ++j) o[k++] = (float)s->pos[j];
-  const float nz = (float)e->noise;
-  for (; k + 1 < d; k += 2) {
-    float a, b;
-    next_normal2(s->rng, &a, &b);
-    o[k] = nz * a;
-    o[k + 1] = nz * b;
-  }
-  if (k < d) {
-    float a, b;
-    next_normal2(s->rng, &a, &b);
-    o[k] = nz * a;
-  }
+  if (k < d) fill_normals(s->rng, o + k, d - k, (float)e->noise);
 }
 
 /* EnvWrapper.reset: pose only if the goal was not reached (lazy reset), always a new goal */
@@ -109,6 +130,7 @@ mobrob_hostenv* mobrob_hostenv_create(int32_t n, int32_t obs_dim, int32_t act_di
                                       int32_t terminate_on_goal, int32_t time_limit, double dt, double extent,
                                       double reach, double bonus, double extra_bonus, double noise,
                                       const double* mix /* [pos_dim][act_dim] */, uint64_t seed) {
+  if (obs_dim - 3 * pos_dim > 2 * MAX_PAIRS) return NULL;
   if (n < 1 || obs_dim < 3 * pos_dim || pos_dim < 1 || pos_dim > 3 || act_dim < 1 || act_dim > 32 || time_limit < 1) return NULL;
   mobrob_hostenv* e = (mobrob_hostenv*)calloc(1, sizeof *e);
   if (!e) return NULL;
@@ -153,13 +175,20 @@ void mobrob_hostenv_reset(mobrob_hostenv* e, float* obs) {
 /* VecEnv.step(actions): next obs (post-reset where an episode ended), rewards, dones, TimeLimit.truncated flags and
  * the terminal observation of truncated rows (term_obs rows of other envs are left untouched).  Returns the number
  * of truncated envs.  Episode statistics accumulate in the handle (mobrob_hostenv_episode_stats). */
-int32_t mobrob_hostenv_step(mobrob_hostenv* e, const float* actions, float* obs, float* rewards, uint8_t* dones,
-                            uint8_t* truncated, float* term_obs) {
+/* ... for the envs [i0, i1) only: all arrays are the full [n][...] buffers, rows outside the range are not touched.
+ * This is what lets a pipelined collector step one half of the robots while the GPU evaluates the policy for the
+ * other half (mobrob_ppo_act_part / store_part). */
+int32_t mobrob_hostenv_step_range(mobrob_hostenv* e, int32_t i0, int32_t i1, const float* actions, float* obs,
+                                  float* rewards, uint8_t* dones, uint8_t* truncated, float* term_obs) {
   int64_t episodes = 0, goals = 0;
   int32_t ntrunc = 0;
   double ret_sum = 0.0, len_sum = 0.0;
-#pragma omp parallel for schedule(static) num_threads(e->threads) reduction(+ : episodes, goals, ntrunc, ret_sum, len_sum)
-  for (int i = 0; i < e->n; ++i) {
+  if (i0 < 0) i0 = 0;
+  if (i1 > e->n) i1 = e->n;
+  int team = (i1 - i0) / 64 < 1 ? 1 : (i1 - i0) / 64;
+  if (team > e->threads) team = e->threads;
+#pragma omp parallel for schedule(static) num_threads(team) reduction(+ : episodes, goals, ntrunc, ret_sum, len_sum)
+  for (int i = i0; i < i1; ++i) {
     env_state* s = &e->st[i];
     const float* a = actions + (size_t)i * e->act_dim;
     const int p = e->pos_dim;
@@ -199,6 +228,11 @@ int32_t mobrob_hostenv_step(mobrob_hostenv* e, const float* actions, float* obs,
   }
   e->episodes += episodes; e->goals += goals; e->ret_sum += ret_sum; e->len_sum += len_sum;
   return ntrunc;
+}
+
+int32_t mobrob_hostenv_step(mobrob_hostenv* e, const float* actions, float* obs, float* rewards, uint8_t* dones,
+                            uint8_t* truncated, float* term_obs) {
+  return mobrob_hostenv_step_range(e, 0, e->n, actions, obs, rewards, dones, truncated, term_obs);
 }
 
 /* out[4] = episodes, goals, sum of returns, sum of lengths since the last call with reset != 0 */

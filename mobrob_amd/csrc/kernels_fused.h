@@ -1058,6 +1058,7 @@ __global__ void k_pack_bwd(const float* __restrict__ W, int N, int K, int ld, fl
 struct FusedActArgs {
   FusedNet net[2];
   const float* X; int Dp; int rows;
+  int row0;                // env index of row 0 (sampling noise is a function of the env index)
   int want_pi, want_v;
   float* mu; int ldmu;     // optional raw mean output [rows][ldmu]
   float* v;                // [rows]
@@ -1247,7 +1248,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void k_fused_act(FusedActArgs a) {
       } else {
         if ((k & 3) == 0) {
           float z[4];
-          box_muller4(philox4x32_10((uint32_t)row, (uint32_t)(k >> 2), a.draw + (a.draw_base ? *a.draw_base : 0u),
+          box_muller4(philox4x32_10((uint32_t)(row + a.row0), (uint32_t)(k >> 2), a.draw + (a.draw_base ? *a.draw_base : 0u),
                                     0x45505331u, (uint32_t)a.seed,
                                     (uint32_t)(a.seed >> 32)), z);
           z0 = z[0]; z1 = z[1]; z2 = z[2]; z3 = z[3];

@@ -674,7 +674,7 @@ __global__ __launch_bounds__(g_waves(DP) * 64, 2) void k_fused64_act(FusedActArg
       } else {
         if ((k & 3) == 0) {
           float z[4];
-          box_muller4(philox4x32_10((uint32_t)row, (uint32_t)(k >> 2), a.draw + (a.draw_base ? *a.draw_base : 0u),
+          box_muller4(philox4x32_10((uint32_t)(row + a.row0), (uint32_t)(k >> 2), a.draw + (a.draw_base ? *a.draw_base : 0u),
                                     0x45505331u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32)), z);
           z0 = z[0]; z1 = z[1]; z2 = z[2]; z3 = z[3];
         }

@@ -146,7 +146,8 @@ constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
 __global__ void k_sample(const float* __restrict__ mu, int ldmu, const float* __restrict__ log_std,
                          const float* __restrict__ eps, int n, int A, float lo, float hi, uint64_t seed,
                          uint32_t draw_rel, const uint32_t* __restrict__ draw_base, float* __restrict__ act_raw,
-                         float* __restrict__ act_clip, float* __restrict__ logp_out) {
+                         float* __restrict__ act_clip, float* __restrict__ logp_out, int row0 = 0) {
+  // row0: env index of row 0 (the noise of env n is a function of n, not of the launch that samples it)
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n) return;
   const uint32_t draw = draw_rel + (draw_base ? *draw_base : 0u);
@@ -158,7 +159,7 @@ __global__ void k_sample(const float* __restrict__ mu, int ldmu, const float* __
       e = eps[(size_t)row * A + a];
     } else {
       if ((a & 3) == 0) {
-        const Philox4 rr = philox4x32_10((uint32_t)row, (uint32_t)(a >> 2), draw, kStreamEps, (uint32_t)seed,
+        const Philox4 rr = philox4x32_10((uint32_t)(row + row0), (uint32_t)(a >> 2), draw, kStreamEps, (uint32_t)seed,
                                          (uint32_t)(seed >> 32));
         box_muller4(rr, z);
       }
@@ -270,6 +271,64 @@ __global__ __launch_bounds__(256) void k_value_flagged(const float* __restrict__
     out[row] = v;
     if (rew_inout != nullptr)  // rewards[idx] += gamma * V(terminal_obs)  [oracle bootstrap_reward]
       rew_inout[row] = (float)((double)rew_inout[row] + (double)__fmul_rn(gamma, v));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined host-env rollout: everything that follows one env step of a row range, in ONE launch (every launch is
+// ~5 us of host time on this path).  Block b owns rows [16 b, 16 b + 16) of the range:
+//   * rows flagged TimeLimit.truncated: V(terminal_obs) with the row read from the caller's pinned buffer in place,
+//     then the bootstrap r = f32(f64(r) + f64(f32(gamma) * V))            [same arithmetic as k_value_flagged + k_store_step]
+//   * rollout_buffer.add scalars: rewards, episode_starts (= previous dones), previous dones <- dones
+//   * the NEXT observations of the rows are pulled into rollout slot t+1 (padded to Dp), so that the following
+//     act_part launches only the policy kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPartRows = 16;
+struct StorePullArgs {
+  const float* rew_in; const uint8_t* dones; const uint8_t* trunc; const float* term_obs;  // caller's pinned rows (range base)
+  const float *W1, *b1, *W2, *b2, *Wv, *bv;                                                // value network (canonical)
+  int D, Dp, G1, G2, n;
+  float gamma;
+  float *prev_dones, *rew_out, *es_out, *term_val;
+  const float* next_obs; float* obs_slot;  // null: no pull
+};
+__global__ __launch_bounds__(256) void k_store_pull_part(StorePullArgs a) {
+  extern __shared__ float sm[];  // x[D] | h1[G1] | h2[G2] | red[16] | tv[16]
+  float* x = sm;
+  float* h1 = x + a.D;
+  float* h2 = h1 + a.G1;
+  float* red = h2 + a.G2;
+  float* tv = red + 16;
+  const int i0 = blockIdx.x * kPartRows, tid = threadIdx.x;
+  if (a.trunc != nullptr) {
+    for (int r = 0; r < kPartRows; ++r) {
+      const int i = i0 + r;
+      if (i >= a.n || !a.trunc[i]) continue;  // block-uniform
+      for (int k = tid; k < a.D; k += blockDim.x) x[k] = a.term_obs[(size_t)i * a.D + k];
+      __syncthreads();
+      const float v = value_row_lds(x, h1, h2, red, a.W1, a.b1, a.W2, a.b2, a.Wv, a.bv, a.D, a.G1, a.G2);
+      if (tid == 0) tv[r] = v;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  if (tid < kPartRows && i0 + tid < a.n) {
+    const int i = i0 + tid;
+    float r = a.rew_in[i];
+    if (a.trunc != nullptr && a.trunc[i]) {
+      const float gv = __fmul_rn(a.gamma, tv[tid]);
+      r = (float)((double)r + (double)gv);
+      a.term_val[i] = tv[tid];
+    }
+    a.rew_out[i] = r;
+    a.es_out[i] = a.prev_dones[i];
+    a.prev_dones[i] = a.dones[i] ? 1.f : 0.f;
+  }
+  if (a.next_obs != nullptr) {
+    for (int idx = tid; idx < kPartRows * a.Dp; idx += blockDim.x) {
+      const int r = idx / a.Dp, c = idx - r * a.Dp, i = i0 + r;
+      if (i < a.n) a.obs_slot[(size_t)i * a.Dp + c] = c < a.D ? a.next_obs[(size_t)i * a.D + c] : 0.f;
+    }
   }
 }
 

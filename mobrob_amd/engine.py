@@ -47,6 +47,59 @@ def param_shapes(obs_dim, act_dim, pi, vf):
     return s
 
 
+class PartPipeline:
+    """The N envs cut into `nparts` contiguous row ranges: while the host simulator steps range p, the GPU runs the
+    policy for the other ranges.  Results equal act()/store() over all rows (same noise per env and step).  The
+    ctypes pointers of the pinned arrays are taken once: the loop below is the per-step hot path of a host-env rollout.
+
+        pipe = engine.part_pipeline(2, obs, clip, rew, done, trunc, term); engine.rollout_begin()
+        for p in range(2): pipe.act(p)
+        for t in range(T):
+            for p in range(2):
+                pipe.wait(p); n_trunc = env.step_range(*pipe.bounds[p], clip); pipe.store(p, n_trunc > 0)
+                if t + 1 < T: pipe.act(p)
+        engine.finish_rollout(obs, done)
+
+    or, for an environment stepped by a C function, the same loop without Python: pipe.collect(fn, handle).
+    """
+
+    def __init__(self, engine, nparts, obs, clipped, rewards, dones, truncated, terminal_obs):
+        e, n = engine, int(nparts)
+        want = dict(obs=((e.N, e.D), F32), clipped=((e.N, e.A), F32), rewards=((e.N,), F32), dones=((e.N,), np.uint8),
+                    truncated=((e.N,), np.uint8), terminal_obs=((e.N, e.D), F32))
+        for name, arr in dict(obs=obs, clipped=clipped, rewards=rewards, dones=dones, truncated=truncated,
+                              terminal_obs=terminal_obs).items():
+            shape, dt = want[name]
+            if arr.shape != shape or arr.dtype != dt or not arr.flags.c_contiguous:
+                raise ValueError(f"{name} must be a C-contiguous {np.dtype(dt).name}{shape} array from engine.pinned()")
+        self._keep = (obs, clipped, rewards, dones, truncated, terminal_obs)
+        self.nparts, self._h, self._lib = n, engine._h, engine.lib
+        self.bounds = [(e.N * p // n, e.N * (p + 1) // n) for p in range(n)]
+        self._obs, self._clip, self._rew = _fp(obs), _fp(clipped), _fp(rewards)
+        self._done, self._trunc, self._term = _u8(dones), _u8(truncated), _fp(terminal_obs)
+
+    def act(self, part):
+        check(self._lib.mobrob_ppo_act_part(self._h, part, self.nparts, self._obs, self._clip))
+
+    def wait(self, part):
+        check(self._lib.mobrob_ppo_wait_part(self._h, part))
+
+    def store(self, part, any_truncated=True, pull_next_obs=True):
+        """pull_next_obs: the same launch also moves the part's next observations (already in `obs`: the env wrote
+        them) into the next rollout slot, so the following act() launches the policy kernel only."""
+        check(self._lib.mobrob_ppo_store_part(self._h, part, self.nparts, self._rew, self._done,
+                                              self._trunc if any_truncated else None,
+                                              self._term if any_truncated else None,
+                                              self._obs if pull_next_obs else None))
+
+    def collect(self, step_range_fn, env_handle):
+        """The whole rollout (rollout_begin ... finish_rollout) in one native call: mobrob_ppo_collect_host drives the
+        environment through `step_range_fn` (address of a C function with mobrob_env_step_range_fn's signature, e.g.
+        NativeGoalVecEnv.step_range_fn) -- no Python frame per step."""
+        check(self._lib.mobrob_ppo_collect_host(self._h, step_range_fn, env_handle, self.nparts, self._obs, self._clip,
+                                                self._rew, self._done, self._trunc, self._term))
+
+
 class PPOEngine:
     @staticmethod
     def make_config(obs_dim, act_dim, n_envs, n_steps, batch_size=64, n_epochs=10, pi=(64, 64), vf=(64, 64),
@@ -183,6 +236,11 @@ class PPOEngine:
         tr = None if truncated is None else np.ascontiguousarray(truncated, dtype=np.uint8)
         to = None if terminal_obs is None else _f32c(terminal_obs, (self.N, self.D))
         check(self.lib.mobrob_ppo_store(self._h, _fp(rewards), _u8(dones), _u8(tr), _fp(to)))
+
+    def part_pipeline(self, nparts, obs, clipped, rewards, dones, truncated, terminal_obs):
+        """Driver of the pipelined host-env rollout (mobrob_ppo_act_part / wait_part / store_part) over FULL [N][...]
+        pinned arrays (`engine.pinned`); see PartPipeline."""
+        return PartPipeline(self, nparts, obs, clipped, rewards, dones, truncated, terminal_obs)
 
     def finish_rollout(self, last_obs, dones):
         last_obs = _f32c(last_obs, (self.N, self.D))

@@ -33,6 +33,8 @@ def _load():
         lib.mobrob_hostenv_reset.argtypes = [C.c_void_p, F]
         lib.mobrob_hostenv_step.restype = C.c_int32
         lib.mobrob_hostenv_step.argtypes = [C.c_void_p, F, F, F, U8, U8, F]
+        lib.mobrob_hostenv_step_range.restype = C.c_int32
+        lib.mobrob_hostenv_step_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32, F, F, F, U8, U8, F]
         lib.mobrob_hostenv_episode_stats.argtypes = [C.c_void_p, D, C.c_int32]
         lib.mobrob_hostenv_get_state.argtypes = [C.c_void_p, C.c_int32, D]
         lib.mobrob_hostenv_set_threads.argtypes = [C.c_void_p, C.c_int32]
@@ -72,6 +74,7 @@ class NativeGoalVecEnv(VecEnvBase):
         self._trunc = np.zeros(n, np.uint8)
         self._term = np.zeros((n, d), np.float32)
         self._t0 = time.time()
+        self._act_arr = self._act_ptr = self._out_ptrs = None  # pointer cache of step_range
 
     @classmethod
     def for_robot(cls, env_name, n_envs, time_limit=1000, seed=0, terminate_on_goal=True):
@@ -88,6 +91,7 @@ class NativeGoalVecEnv(VecEnvBase):
                 if arr.shape != cur.shape or arr.dtype != cur.dtype or not arr.flags.c_contiguous:
                     raise ValueError(f"buffer for {name[1:]} must be C-contiguous {cur.dtype}{cur.shape}")
                 setattr(self, name, arr)
+        self._act_arr = None
 
     def seed(self, seed=None):
         pass  # seeded at construction (make_vec_env semantics: env i <- seed + i)
@@ -102,6 +106,26 @@ class NativeGoalVecEnv(VecEnvBase):
         nt = self.lib.mobrob_hostenv_step(self._h, _fp(a), _fp(self._obs), _fp(self._rew), _u8(self._done), _u8(self._trunc),
                                           _fp(self._term))
         return self._obs, self._rew, self._done, self._trunc, self._term, int(nt)
+
+    def step_range(self, i0, i1, actions):
+        """Step the envs [i0, i1) only (actions is the full [n, act_dim] float32 array; result rows outside the range
+        are untouched) -> number of truncated envs in the range.  Used by the pipelined collector."""
+        if actions is not self._act_arr:
+            if actions.dtype != np.float32 or not actions.flags.c_contiguous or actions.shape != (self.num_envs, self.act_dim):
+                raise ValueError("step_range needs the full C-contiguous float32 [n_envs, act_dim] action array")
+            self._act_arr, self._act_ptr = actions, _fp(actions)
+            self._out_ptrs = (_fp(self._obs), _fp(self._rew), _u8(self._done), _u8(self._trunc), _fp(self._term))
+        return self.lib.mobrob_hostenv_step_range(self._h, i0, i1, self._act_ptr, *self._out_ptrs)
+
+    @property
+    def step_range_fn(self):
+        """Address of mobrob_hostenv_step_range (a mobrob_env_step_range_fn) for mobrob_ppo_collect_host; the env
+        argument is `self.handle`.  The native collector writes into the arrays given to `use_buffers`."""
+        return C.cast(self.lib.mobrob_hostenv_step_range, C.c_void_p).value
+
+    @property
+    def handle(self):
+        return self._h
 
     def step(self, actions):
         """SB3 VecEnv contract (infos only carry what the collector reads; per-episode Monitor values are aggregated in

@@ -215,6 +215,8 @@ class PPO:
         self.policy = None
         self.world_size, self.rank, self._backend = 1, 0, None
         self._host_bufs = None
+        # row ranges of the pipelined host-env rollout (engine.part_pipeline); 1 = whole batch per step
+        self.host_parts = int(self._engine_kwargs.pop("host_parts", 2))
         if _init_setup_model:
             self._setup_model()
 
@@ -311,17 +313,45 @@ class PPO:
 
     def _collect_rollouts_arrays(self, callback) -> bool:
         """Host env with the array protocol (NativeGoalVecEnv): O(1) Python work per step; observations, rewards and
-        flags travel through pinned staging on the engine's side stream; one stream sync per step (the actions)."""
+        flags live in pinned staging that the GPU reads and writes in place.  With `host_parts` > 1 (default 2 for
+        envs that can step a row range) the rollout is pipelined: the simulator steps one range of robots while the
+        GPU runs the policy for the others -- same results as the whole-batch loop."""
         e, env, N, b = self.engine, self.env, self.n_envs, self._host_bufs
+        parts = self.host_parts if hasattr(env, "step_range") else 1
+        finished = False
         e.rollout_begin()
-        for _ in range(self.n_steps):
-            e.act(b["obs"], out_clipped=b["clip"], want_all=False)
-            _, _, _, _, _, ntrunc = env.step_arrays(b["clip"])
-            self.num_timesteps += N * self.world_size
-            if not callback.on_step():
-                return False
-            e.store(b["rew"], b["done"], b["trunc"] if ntrunc else None, b["term"] if ntrunc else None)
-        e.finish_rollout(b["obs"], b["done"])
+        if parts > 1 and type(callback) is BaseCallback and hasattr(env, "step_range_fn"):
+            # nothing to call per step and a natively stepped env: the whole collector loop runs in C
+            pipe = e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"])
+            pipe.collect(env.step_range_fn, env.handle)  # includes finish_rollout
+            finished = True
+            self.num_timesteps += N * self.world_size * self.n_steps
+            callback.n_calls += self.n_steps
+            callback.num_timesteps = self.num_timesteps
+        elif parts > 1:
+            pipe = e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"])
+            for p in range(parts):
+                pipe.act(p)
+            for t in range(self.n_steps):
+                for p in range(parts):
+                    pipe.wait(p)
+                    ntrunc = env.step_range(*pipe.bounds[p], b["clip"])
+                    pipe.store(p, ntrunc > 0)
+                    if t + 1 < self.n_steps:
+                        pipe.act(p)
+                self.num_timesteps += N * self.world_size
+                if not callback.on_step():
+                    return False
+        else:
+            for _ in range(self.n_steps):
+                e.act(b["obs"], out_clipped=b["clip"], want_all=False)
+                _, _, _, _, _, ntrunc = env.step_arrays(b["clip"])
+                self.num_timesteps += N * self.world_size
+                if not callback.on_step():
+                    return False
+                e.store(b["rew"], b["done"], b["trunc"] if ntrunc else None, b["term"] if ntrunc else None)
+        if not finished:
+            e.finish_rollout(b["obs"], b["done"])
         st = env.episode_stats(reset=True)
         self.device_episode_stats = st
         if st["episodes"] > 0:

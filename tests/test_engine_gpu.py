@@ -274,6 +274,75 @@ def test_pinned_zero_copy_path_equals_staged_path():
     assert np.array_equal(out[True]["clips"], np.clip(out[True]["actions"], -1, 1))
 
 
+@pytest.mark.parametrize("robot,hidden,N,parts", [("doggo", 256, 100, 3), ("point", 64, 96, 2), ("car", 48, 70, 2),
+                                                  ("doggo", 256, 7, 7)])
+def test_pipelined_part_rollout_equals_whole_batch_rollout(robot, hidden, N, parts):
+    """act_part / wait_part / store_part over row ranges (the env steps one range while the GPU runs the policy for
+    the others) == act / store over all rows, bit for bit: same noise per env and step, same bootstrap, same GAE.
+    Shapes cover the H=256 and H=64 fused kernels and the generic path, ragged ranges and one env per part."""
+    from mobrob_amd.envs.native_env import NativeGoalVecEnv
+    from mobrob_amd.envs.wrapper import ROBOT_DIMS
+    D, A, _ = ROBOT_DIMS[robot]
+    T = 23
+    p = O.init_params(D, A, (hidden, hidden), (hidden, hidden), seed=4)
+    keys = ("obs", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns", "last_values")
+    out = {}
+    for mode in ("whole", "parts", "native"):
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=64, n_epochs=1, seed=9,
+                        pi=(hidden, hidden), vf=(hidden, hidden))
+        e.set_params(p)
+        env = NativeGoalVecEnv.for_robot(robot, N, time_limit=6, seed=3)  # short episodes: truncations every rollout
+        b = dict(obs=e.pinned((N, D)), clip=e.pinned((N, A)), rew=e.pinned((N,)), done=e.pinned((N,), np.uint8),
+                 trunc=e.pinned((N,), np.uint8), term=e.pinned((N, D)))
+        env.use_buffers(obs=b["obs"], rewards=b["rew"], dones=b["done"], truncated=b["trunc"], terminal_obs=b["term"])
+        env.reset()
+        for _ in range(2):  # two rollouts: the noise counter carries over
+            e.rollout_begin()
+            if mode == "whole":
+                for _t in range(T):
+                    e.act(b["obs"], out_clipped=b["clip"], want_all=False)
+                    nt = env.step_arrays(b["clip"])[5]
+                    e.store(b["rew"], b["done"], b["trunc"] if nt else None, b["term"] if nt else None)
+            elif mode == "native":  # the same pipeline as one C call (mobrob_ppo_collect_host), finish_rollout included
+                e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"]).collect(
+                    env.step_range_fn, env.handle)
+                continue
+            else:
+                pipe = e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"])
+                assert pipe.bounds[0][0] == 0 and pipe.bounds[-1][1] == N
+                for q in range(parts):
+                    pipe.act(q)
+                for t in range(T):
+                    for q in range(parts):
+                        pipe.wait(q)
+                        nt = env.step_range(*pipe.bounds[q], b["clip"])
+                        pipe.store(q, nt > 0)
+                        if t + 1 < T:
+                            pipe.act(q)
+            e.finish_rollout(b["obs"], b["done"])
+        out[mode] = {k: e.read(k) for k in keys}
+        out[mode]["stats"] = env.episode_stats()
+        if mode == "parts":  # protocol errors are reported, not executed
+            e.rollout_begin()
+            with pytest.raises(Exception):
+                pipe.store(0)                      # nothing acted yet
+            pipe.act(0)
+            with pytest.raises(Exception):
+                pipe.act(0)                        # step 0 of part 0 not stored yet
+            with pytest.raises(Exception):
+                e.part_pipeline(parts + 1, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"]).act(0)
+            with pytest.raises(ValueError):
+                e.part_pipeline(parts, np.zeros((N, D), np.float32), b["clip"], b["rew"], b["done"], b["trunc"], b["term"]).act(1)  # pageable
+        env.close()
+        e.close()
+    assert out["whole"]["stats"]["episodes"] > N  # truncations and goals happened
+    for mode in ("parts", "native"):
+        for k in keys:
+            assert np.array_equal(out["whole"][k], out[mode][k]), (mode, k)
+        sw, sp = out["whole"]["stats"], out[mode]["stats"]
+        assert (sw["episodes"], sw["goals"]) == (sp["episodes"], sp["goals"]) and abs(sw["ep_rew_mean"] - sp["ep_rew_mean"]) < 1e-9
+
+
 def test_synthetic_collect_statistics_and_consistency():
     """Device-resident env source: statistics of the generator and self-consistency of the stored rollout."""
     D, A, N, T = 58, 12, 512, 64
