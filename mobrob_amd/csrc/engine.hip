@@ -1111,8 +1111,8 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
   const bool overlap = rblocks <= 192;                      // otherwise the rollout itself fills the device
   const int chunk = overlap ? std::max(16, cdiv(T, 20)) : T;
   const int vgrid_max = overlap ? std::max(32, 256 - rblocks) : 256;
-  auto value_pass = [&](hipStream_t st, int r0, int r1) {  // rows [r0, r1) of obs -> values
-    FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_value_batch<DPc>), dim3(std::min(vgrid_max, cdiv(r1 - r0, FR))),
+  auto value_pass = [&](hipStream_t st, int r0, int r1, int grid_max) {  // rows [r0, r1) of obs -> values
+    FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_value_batch<DPc>), dim3(std::min(grid_max, cdiv(r1 - r0, FR))),
                                              dim3(FTHREADS), e->fused.lds_bytes, st, e->fused.net[1],
                                              e->obs + (size_t)r0 * Dp, r1 - r0, e->values + r0));
   };
@@ -1126,7 +1126,7 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
         hipEvent_t ev = e->ev_chunks[t0 / chunk];
         HIPC(hipEventRecord(ev, e->stream));
         HIPC(hipStreamWaitEvent(e->vstream, ev, 0));
-        value_pass(e->vstream, t0 * N, a.t1 * N);
+        value_pass(e->vstream, t0 * N, a.t1 * N, vgrid_max);
       }
     }
   }
@@ -1135,7 +1135,7 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
   {
     ProfScope ps(e, MOBROB_K_ACT);  // V of the last chunk and V(last_obs) (obs[T]; values[T*N..] = last_values)
     const int done_rows = overlap ? ((T - 1) / chunk) * chunk * N : 0;
-    value_pass(e->stream, done_rows, (T + 1) * N);
+    value_pass(e->stream, done_rows, (T + 1) * N, 256);  // the rollout is over: the whole device
     if (overlap && done_rows > 0) {  // join the side stream before GAE
       HIPC(hipEventRecord(e->ev_vdone, e->vstream));
       HIPC(hipStreamWaitEvent(e->stream, e->ev_vdone, 0));
