@@ -221,6 +221,12 @@ def main():
                     rank=rank, world_size=world, fast_kernels=not args.generic)
     eng.set_params(init_params(D, A, H, seed=0))  # identical replicas on every rank
     backend = EngineBackend(eng) if use_dp else None
+    if use_dp:  # RCCL sets up channels / peer connections lazily at the first collective of a given size: do that
+        # outside the timed region whatever --warmup is (both buffers are rewritten before they are read)
+        with torch.cuda.stream(backend.stream):
+            dist.all_reduce(backend.grad_tensor())
+            dist.all_reduce(backend.advstat_tensor())
+        torch.cuda.synchronize()
 
     host = None
     if w.get("host_env"):
