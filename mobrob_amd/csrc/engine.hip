@@ -71,8 +71,6 @@ struct mobrob_ppo_engine {
   bool own_stream = false;
   // parameters / optimizer
   float *params = nullptr, *grads = nullptr /* [P] + 8 loss sums */, *m = nullptr, *v = nullptr;
-  int* offs_dev = nullptr;
-  double* tensor_sq = nullptr;  // [13]
   NormChunk* chunks_dev = nullptr;
   double* chunk_partial = nullptr;
   int nchunks = 0;
@@ -85,7 +83,7 @@ struct mobrob_ppo_engine {
   float *clip_act = nullptr, *rew_tmp = nullptr, *term_obs = nullptr, *term_val = nullptr, *eps_dev = nullptr;
   uint8_t *trunc_dev = nullptr, *dones_u8 = nullptr;
   int *ep_len = nullptr, *ep_len2 = nullptr;
-  uint32_t* ctr_dev = nullptr;  // [0] eps draw base, [1] env step base (device-resident: graph replays advance them)
+  uint32_t* ctr_dev = nullptr;  // [0] eps draw base, [1] env step base (device-resident: graph replays and the persistent rollout kernels advance them)
   hipGraph_t ro_graph = nullptr;
   hipGraphExec_t ro_exec = nullptr;
   struct RolloutSpec {  // what the captured rollout graph was built for
@@ -570,7 +568,6 @@ int engine_dims(mobrob_ppo_engine* e, const mobrob_ppo_config_t* cfg) {
 int engine_alloc(mobrob_ppo_engine* e) {
   const size_t P = e->P, N = e->N, T = e->T, Dp = e->Dp, A = e->A, Bl = std::min(e->Bl, e->N * e->T), R = e->rows_max;
   CHK(dalloc(e, &e->params, P)); CHK(dalloc(e, &e->grads, P + 8)); CHK(dalloc(e, &e->m, P)); CHK(dalloc(e, &e->v, P));
-  CHK(dalloc(e, &e->offs_dev, T_COUNT + 1)); CHK(dalloc(e, &e->tensor_sq, T_COUNT));
   CHK(dalloc(e, &e->pW1p, (size_t)e->H1 * Dp)); CHK(dalloc(e, &e->vW1p, (size_t)e->G1 * Dp));
   CHK(dalloc(e, &e->aWp, (size_t)e->Ap * e->H2)); CHK(dalloc(e, &e->vWp, (size_t)8 * e->G2));
   CHK(dalloc(e, &e->obs, (T + 1) * N * Dp)); CHK(dalloc(e, &e->actions, T * N * A));
@@ -634,7 +631,6 @@ int engine_create(const mobrob_ppo_config_t* cfg, void* arena, size_t arena_byte
     e->arena_bytes = need;
   }
   CHK(engine_alloc(e));
-  HIPC(hipMemcpyAsync(e->offs_dev, e->offs, sizeof e->offs, hipMemcpyHostToDevice, e->stream));
   HIPC(hipMemcpyAsync(e->chunks_dev, e->chunk_table.data(), e->chunk_table.size() * sizeof(NormChunk), hipMemcpyHostToDevice, e->stream));
   // `_last_episode_starts` is all-True at _setup_learn (Appendix A.5)
   std::vector<float> ones(e->N, 1.0f);
