@@ -343,6 +343,60 @@ def test_pipelined_part_rollout_equals_whole_batch_rollout(robot, hidden, N, par
         assert (sw["episodes"], sw["goals"]) == (sp["episodes"], sp["goals"]) and abs(sw["ep_rew_mean"] - sp["ep_rew_mean"]) < 1e-9
 
 
+def test_part_rollout_protocol_and_counter_continuity():
+    """One part == the whole batch; a rollout cannot be finished while a part lags; and a whole-batch rollout after a
+    pipelined one continues the same noise sequence as after a whole-batch one."""
+    from mobrob_amd.envs.native_env import NativeGoalVecEnv
+    D, A, N, T = 14, 2, 40, 6
+    p = O.init_params(D, A, seed=8)
+    res = {}
+    for first in ("whole", "one_part", "two_parts"):
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=40, n_epochs=1, seed=2)
+        e.set_params(p)
+        env = NativeGoalVecEnv.for_robot("point", N, time_limit=4, seed=1)
+        b = dict(obs=e.pinned((N, D)), clip=e.pinned((N, A)), rew=e.pinned((N,)), done=e.pinned((N,), np.uint8),
+                 trunc=e.pinned((N,), np.uint8), term=e.pinned((N, D)))
+        env.use_buffers(obs=b["obs"], rewards=b["rew"], dones=b["done"], truncated=b["trunc"], terminal_obs=b["term"])
+        env.reset()
+
+        def whole():
+            e.rollout_begin()
+            for _ in range(T):
+                e.act(b["obs"], out_clipped=b["clip"], want_all=False)
+                nt = env.step_arrays(b["clip"])[5]
+                e.store(b["rew"], b["done"], b["trunc"] if nt else None, b["term"] if nt else None)
+            e.finish_rollout(b["obs"], b["done"])
+
+        if first == "whole":
+            whole()
+        else:
+            parts = 1 if first == "one_part" else 2
+            pipe = e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"])
+            e.rollout_begin()
+            for q in range(parts):
+                pipe.act(q)
+            for t in range(T):
+                for q in range(parts):
+                    pipe.wait(q)
+                    nt = env.step_range(*pipe.bounds[q], b["clip"])
+                    if t == T - 1 and q == parts - 1 and parts == 2:
+                        with pytest.raises(Exception):  # the last part has not stored its last step yet
+                            e.finish_rollout(b["obs"], b["done"])
+                    pipe.store(q, nt > 0, pull_next_obs=(t % 2 == 0))  # both pull variants
+                    if t + 1 < T:
+                        pipe.act(q)
+            e.finish_rollout(b["obs"], b["done"])
+        first_ro = {k: e.read(k) for k in ("actions", "rewards", "advantages")}
+        whole()  # second rollout: always the whole-batch loop
+        res[first] = (first_ro, {k: e.read(k) for k in ("actions", "rewards", "advantages")})
+        env.close()
+        e.close()
+    for mode in ("one_part", "two_parts"):
+        for i in (0, 1):
+            for k in res["whole"][i]:
+                assert np.array_equal(res["whole"][i][k], res[mode][i][k]), (mode, i, k)
+
+
 def test_synthetic_collect_statistics_and_consistency():
     """Device-resident env source: statistics of the generator and self-consistency of the stored rollout."""
     D, A, N, T = 58, 12, 512, 64
