@@ -127,7 +127,7 @@ def bench_fleet(args, w, rank, local_rank, world, use_dp, force_dp):
         iteration()
     fence()
     for s in fleet.segments:
-        s.engine.profile(True)
+        s.engine.profile(True, only=None if args.phases else ["train_grad"])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         iteration()
@@ -159,7 +159,9 @@ def bench_fleet(args, w, rank, local_rank, world, use_dp, force_dp):
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                          "avg_launch_ms": ms / max(calls, 1), "launches": calls, "flops_per_launch": flops / max(calls, 1)},
-            "phase_ms_per_step": {k: sum(p[k][0] for p in profs) / args.steps for k in profs[0]},
+            "phases_bracketed": "all" if args.phases else "dominant kernel only",
+            "phase_ms_per_step": {k: sum(p[k][0] for p in profs) / args.steps for k in profs[0]
+                                  if sum(p[k][1] for p in profs) > 0},
         }
         print(json.dumps(out), flush=True)
     fleet.close()
@@ -173,6 +175,9 @@ def main():
     ap.add_argument("--workload", default="doggo-4096env-2x256", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the generic (unfused) kernels")
+    ap.add_argument("--phases", action="store_true",
+                    help="bracket every phase with HIP events (phase_ms_per_step; costs ~4 %% of the throughput); "
+                         "by default only the dominant kernel is bracketed")
     ap.add_argument("--host-python-loop", action="store_true",
                     help="host-env workloads: drive the pipelined rollout from Python instead of mobrob_ppo_collect_host")
     ap.add_argument("--host-parts", type=int, default=2,
@@ -281,7 +286,9 @@ def main():
     for _ in range(args.warmup):
         iteration()
     fence()
-    eng.profile(True)
+    # HIP events around every launch of the dominant kernel over the whole timed region (the roofline figure); the
+    # other phases only with --phases: an event pair costs GPU time at every launch boundary
+    eng.profile(True, only=None if args.phases else ["train_grad"])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         iteration()
@@ -325,7 +332,8 @@ def main():
                          "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/r1/hbm_traffic_pmc.json)",
                          "avg_launch_ms": ms / max(calls, 1), "launches": calls,
                          "flops_per_launch": flops_per_launch},
-            "phase_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "phases_bracketed": "all" if args.phases else "dominant kernel only",
+            "phase_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1] > 0},
         }
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(w)

@@ -136,6 +136,7 @@ struct mobrob_ppo_engine {
   int stage_i = 0;
   // profiling
   bool prof_on = false;
+  uint32_t prof_mask = ~0u;  // which MOBROB_K_* phases are bracketed while prof_on
   std::vector<ProfSpan> spans;
   std::vector<hipEvent_t> ev_pool;
   double prof_ms[MOBROB_K_COUNT] = {0};
@@ -186,7 +187,7 @@ struct ProfScope {
   mobrob_ppo_engine* e;
   ProfSpan s;
   bool on;
-  ProfScope(mobrob_ppo_engine* e_, int id) : e(e_), on(e_->prof_on) {
+  ProfScope(mobrob_ppo_engine* e_, int id) : e(e_), on(e_->prof_on && ((e_->prof_mask >> id) & 1u)) {
     if (on) {
       s.id = id;
       s.a = get_event(e);
@@ -1570,6 +1571,7 @@ int mobrob_ppo_profile_enable(mobrob_ppo_engine_t* e, int32_t on) {
   HIPC(hipStreamSynchronize(e->stream));
   prof_resolve(e);
   e->prof_on = on != 0;
+  e->prof_mask = on == 1 ? ~0u : (uint32_t)on >> 1;  // 1: every phase; otherwise bit (id + 1) selects phase id
   for (int i = 0; i < MOBROB_K_COUNT; ++i) { e->prof_ms[i] = 0; e->prof_calls[i] = 0; }
   return MOBROB_OK;
 }

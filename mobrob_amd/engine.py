@@ -408,8 +408,13 @@ class PPOEngine:
     def synchronize(self):
         check(self.lib.mobrob_ppo_synchronize(self._h))
 
-    def profile(self, on=True):
-        check(self.lib.mobrob_ppo_profile_enable(self._h, int(on)))
+    def profile(self, on=True, only=None):
+        """HIP-event bracketing of the engine's phases.  only: names from _lib.KERNEL_IDS to restrict it to (each
+        bracketed launch costs a few microseconds of GPU time)."""
+        v = int(bool(on))
+        if on and only is not None:
+            v = sum(1 << (_lib.KERNEL_IDS[k] + 1) for k in only)
+        check(self.lib.mobrob_ppo_profile_enable(self._h, v))
 
     def profile_read(self):
         ms, calls = (C.c_double * 6)(), (C.c_int64 * 6)()
