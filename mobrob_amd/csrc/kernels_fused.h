@@ -1335,17 +1335,20 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
     tens[c] = a.chunks[c].tensor;
   }
   __syncthreads();
+  // total norm = norm of per-tensor norms (torch.norm(torch.stack(norms))).  One thread per tensor folds that
+  // tensor's chunk partials in chunk order and takes the float64 square root (a software routine: thirteen of them
+  // one after the other were half of this kernel), thread 0 then adds the thirteen squares in tensor order.
+  __shared__ float nts[16];
+  if (threadIdx.x < 13) {
+    double ts = 0.0;
+    for (int c = 0; c < a.nchunks; ++c)
+      if (tens[c] == (int)threadIdx.x) ts += part[c];
+    nts[threadIdx.x] = (float)sqrt(ts);
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    // total norm = norm of per-tensor norms (torch.norm(torch.stack(norms))), chunks are sorted by tensor
     float tot_sq = 0.f;
-    int c = 0;
-    while (c < a.nchunks) {
-      const int t = tens[c];
-      double ts = 0.0;
-      while (c < a.nchunks && tens[c] == t) ts += part[c++];
-      const float nt = (float)sqrt(ts);
-      tot_sq += nt * nt;
-    }
+    for (int t = 0; t < 13; ++t) tot_sq = __fmaf_rn(nts[t], nts[t], tot_sq);  // explicit: one rounding per tensor
     const float total = sqrtf(tot_sq);
     total_s = total;
     coef_s = fminf(a.max_norm / (total + 1e-6f), 1.0f);
