@@ -522,6 +522,30 @@ def test_rollouts_beyond_4gib_use_the_64bit_generic_kernels():
     e.close()
 
 
+def test_profile_phase_selection():
+    """engine.profile(only=[...]) brackets just the named phases (what bench.py does for the dominant kernel); the
+    per-phase call counts are what the roofline line divides by."""
+    D, A, H, N, T, B, E = 14, 2, 64, 64, 16, 256, 2
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H), seed=3)
+    e.set_params(O.init_params(D, A, (H, H), (H, H), seed=1))
+    nmb = E * (N * T // B)
+    e.profile(True, only=["train_grad"])
+    e.collect_synthetic(p_term=0.1, time_limit=10)
+    e.train(None)
+    pr = e.profile_read()
+    assert pr["train_grad"][1] == nmb and pr["train_grad"][0] > 0.0
+    assert all(pr[k][1] == 0 for k in pr if k != "train_grad")
+    e.profile(True)
+    e.collect_synthetic(p_term=0.1, time_limit=10)
+    e.train(None)
+    pr = e.profile_read()
+    assert pr["train_grad"][1] == nmb and pr["apply"][1] == nmb and pr["grad_reduce"][1] == nmb and pr["gae"][1] == 1
+    e.profile(False)
+    e.train(None)
+    assert all(v[1] == 0 for v in e.profile_read().values())
+    e.close()
+
+
 @pytest.mark.parametrize("H", [256, 64, 16])
 @pytest.mark.parametrize("N,T,B", [(1, 2, 2), (1, 1, 1), (3, 5, 7), (33, 3, 64)])
 def test_tiny_and_ragged_shapes_run_end_to_end(H, N, T, B):
