@@ -163,8 +163,16 @@ def bench_fleet(args, w, rank, local_rank, world, use_dp, force_dp):
             "phase_ms_per_step": {k: sum(p[k][0] for p in profs) / args.steps for k in profs[0]
                                   if sum(p[k][1] for p in profs) > 0},
         }
-        print(json.dumps(out), flush=True)
+        emit(out)
     fleet.close()
+
+
+_RESULT_FD = None
+
+
+def emit(obj):
+    """The ONE JSON line of the contract, written to the process's original stdout."""
+    os.write(_RESULT_FD if _RESULT_FD is not None else 1, (json.dumps(obj) + "\n").encode())
 
 
 def main():
@@ -183,6 +191,12 @@ def main():
     ap.add_argument("--host-parts", type=int, default=2,
                     help="host-env workloads: row ranges of the pipelined rollout (1 = whole batch per step)")
     args = ap.parse_args()
+    # RCCL prints a version banner to the C stdout of every rank (flushed at exit, i.e. after the result line):
+    # keep the real stdout for the JSON line only and send everything else written to fd 1 to stderr.
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
     w = WORKLOADS[args.workload]
 
     import torch
@@ -337,7 +351,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(w)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_dp:
         dist.barrier()
         dist.destroy_process_group()
