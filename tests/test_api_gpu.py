@@ -147,3 +147,26 @@ def test_torch_ops_between_grad_and_apply_are_stream_ordered_with_the_engine():
     n1 = float(torch.sqrt(sum((g1[a:b].double() ** 2).sum() for a, b in [(0, e.P)])))
     assert abs(rows[-1][6] - 2.0 * n1) < 1e-3 * max(1.0, n1)  # grad_norm logged by apply() saw the doubled gradient
     e.close()
+
+
+@pytest.mark.gpu
+def test_bench_prints_exactly_one_json_line_on_stdout():
+    """The driver parses bench.py's stdout: ONE JSON line, also on the data-parallel path where RCCL writes a version
+    banner to the C stdout at exit.  Runs the BASELINE config-2 workload once through the forced-DP plumbing."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MOBROB_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29581")
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "point-1024env-2x64", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["value"] > 1e6 and d["config"]["workload"] == "point-1024env-2x64"
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
