@@ -143,7 +143,7 @@ mobrob_hostenv* mobrob_hostenv_create(int32_t n, int32_t obs_dim, int32_t act_di
   if (!e->st) { free(e); return NULL; }
   e->threads = n / 64 < 1 ? 1 : n / 64;
   if (e->threads > 16) e->threads = 16;
-  if (e->threads > omp_get_max_threads()) e->threads = omp_get_max_threads();
+  if (e->threads > omp_get_num_procs()) e->threads = omp_get_num_procs(); /* not omp_get_max_threads(): torchrun exports OMP_NUM_THREADS=1 */
   uint64_t sm = seed;
   for (int i = 0; i < n; ++i) { /* make_vec_env: env i is seeded with seed + i */
     uint64_t x = sm + (uint64_t)i * 0xD1342543DE82EF95ull;
