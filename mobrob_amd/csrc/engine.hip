@@ -19,6 +19,9 @@
 #include "fused_dispatch.h"
 #include "kernels_env.h"
 #include "kernels_rollout.h"
+#ifdef MOBROB_VALUE8
+#include "kernels_fused8.h"
+#endif
 
 using namespace mobrob;
 
@@ -1109,9 +1112,17 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
   const int chunk = overlap ? std::max(16, cdiv(T, 20)) : T;
   const int vgrid_max = overlap ? std::max(32, 256 - rblocks) : 256;
   auto value_pass = [&](hipStream_t st, int r0, int r1, int grid_max) {  // rows [r0, r1) of obs -> values
+#ifdef MOBROB_VALUE8  // experiment: two waves per SIMD (kernels_fused8.h)
+    FUSED_DISPATCH_DP(Dp, (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_value_batch8<DPc>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->fused.lds_bytes));
+    FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_value_batch8<DPc>), dim3(std::min(grid_max, cdiv(r1 - r0, FR))),
+                                             dim3(FTHREADS8), e->fused.lds_bytes, st, e->fused.net[1],
+                                             e->obs + (size_t)r0 * Dp, r1 - r0, e->values + r0));
+#else
     FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_value_batch<DPc>), dim3(std::min(grid_max, cdiv(r1 - r0, FR))),
                                              dim3(FTHREADS), e->fused.lds_bytes, st, e->fused.net[1],
                                              e->obs + (size_t)r0 * Dp, r1 - r0, e->values + r0));
+#endif
   };
   {
     ProfScope ps(e, MOBROB_K_ENV);

@@ -590,13 +590,37 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   constexpr int NG = (FR * per + FTHREADS - 1) / FTHREADS;
   static_assert((FR * per) % FTHREADS == 0, "gather assumes a whole number of 16-byte chunks per thread");
   f32x4 xr[NG];
-  int nsrc[NG];
 #pragma unroll
   for (int u = 0; u < NG; ++u) {
     const int i = tid0 + u * FTHREADS, rr = i / per, c = i - rr * per;
     xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (PHASE_ON(1) && wg < ntiles && wg * FR + rr < a.count)
       xr[u] = ldg16(a.obs, (unsigned)a.rows[wg * FR + rr] * (unsigned)(DP * 4) + (unsigned)(c * 16));
+  }
+  // Operands of the loss stage (4 lanes per row, q = action residue mod 4) of the tile about to be processed: a
+  // two-level gather (row index, then actions / advantage / old log-prob or return of that row).  vmcnt retires in
+  // order, so a long-latency gather that is in flight when a GEMM phase waits for its next weight fragment stalls
+  // that phase for the whole HBM / TLB latency.  All gathers for tile t+1 are therefore issued inside the dW2 phase
+  // of tile t -- 13 us of MFMAs fed from LDS only, no global load to wait for -- row indices at its start, the
+  // dependent rows at its mid-point; here: the first tile (exposed once per launch).
+  constexpr int NJ = H16 ? 4 : 8;  // action columns per lane (4 lanes per row)
+  float l_adv = 0.f, l_old = 0.f, l_act[NJ];
+  auto gather_loss = [&](int src_or_neg, int lq_) {  // one load per destination register, each after its zero init
+    const bool live = src_or_neg >= 0, pol = net == 0;
+    const unsigned src = live ? (unsigned)src_or_neg : 0u;
+    const unsigned aoff = (src * (unsigned)a.A + (unsigned)lq_) * 4u;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      l_act[j] = (pol && 4 * j + lq_ < a.A && live)
+                     ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.actions) + (aoff + 16u * j))
+                     : 0.f;
+    const float* old_or_ret = pol ? a.old_logp : a.ret;  // policy: old log-prob; value net: return target
+    l_old = live ? old_or_ret[src] : 0.f;
+    l_adv = (live && pol) ? a.adv[src] : 0.f;
+  };
+  {
+    const int lrr0 = tid0 >> 2;
+    gather_loss((wg < ntiles && wg * FR + lrr0 < a.count) ? a.rows[wg * FR + lrr0] : -1, tid0 & 3);
   }
   for (int tile = wg; tile < ntiles; tile += nwg) {
     // Per-lane indices are re-derived from an opaque copy of the thread id in every tile: otherwise LLVM hoists
@@ -606,43 +630,19 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     const int row0 = tile * FR;
     const Frag2 f1 = prefetch_frag(W.W1f + (size_t)(2 * wave) * (DP / 8) * 64,
                                    W.W1f + (size_t)(2 * wave + 1) * (DP / 8) * 64, lane);
-    // ---- the observation rows of this tile were fetched during the previous tile's dW1 phase ----
+    // ---- the observation rows of this tile were fetched during the previous tile's backward pass ----
 #pragma unroll
     for (int u = 0; u < NG; ++u) {
       const int i = tid + u * FTHREADS, rr = i / per, c = i - rr * per;
       *reinterpret_cast<f32x4*>(&lds[L::X + rr * ldx + 4 * c]) = xr[u];
     }
-    // row indices of the NEXT tile (their observation loads are issued before this tile's dW1 phase)
     const int nrow0 = (tile + nwg) * FR;
-#pragma unroll
-    for (int u = 0; u < NG; ++u) {
-      const int rr = (tid + u * FTHREADS) / per;
-      nsrc[u] = (PHASE_ON(1) && tile + nwg < ntiles && nrow0 + rr < a.count) ? a.rows[nrow0 + rr] : -1;
-    }
+    const bool has_next = PHASE_ON(1) && tile + nwg < ntiles;
+    const int lrr = tid >> 2, lq = tid & 3;
+    const bool llive = row0 + lrr < a.count;
     __syncthreads();
     STAMP(0)
     const Frag2 f3 = tile_layers<DP, H16>(W, wave, lane, f1 STAMP_ARGS);
-    // operands of the loss stage, fetched while the head GEMM runs (4 lanes per row, q = action residue mod 4)
-    const int lrr = tid >> 2, lq = tid & 3;
-    const bool llive = row0 + lrr < a.count;
-    constexpr int NJ = H16 ? 4 : 8;  // action columns per lane (4 lanes per row)
-    float l_adv = 0.f, l_old = 0.f, l_act[NJ];
-    {
-      const unsigned src = llive ? (unsigned)a.rows[row0 + lrr] : 0u;
-      if (net == 0) {
-        const unsigned aoff = (src * (unsigned)a.A + (unsigned)lq) * 4u;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          l_act[j] = (4 * j + lq < a.A && llive)
-                         ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.actions) + (aoff + 16u * j))
-                         : 0.f;
-        if (llive) { l_adv = a.adv[src]; l_old = a.old_logp[src]; }
-      } else {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) l_act[j] = 0.f;
-        if (llive) l_old = a.ret[src];
-      }
-    }
     if (PHASE_ON(8)) {
       if constexpr (H16) tile_head16<DP>(W, wave, lane, f3);
       else tile_head<DP>(W, wave, lane, f3 STAMP_ARGS);
@@ -783,8 +783,34 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
       float x0 = lds[ao], x1 = lds[ao + 32];
       float y0 = lds[bo], y1 = lds[bo + 32], y2 = lds[bo + 64], y3 = lds[bo + 96], y4 = lds[bo + 128],
             y5 = lds[bo + 160], y6 = lds[bo + 192], y7 = lds[bo + 224];
+      // level 1 of the next tile's gathers: row indices (X rows of the 64-row tile, loss-stage row of this lane)
+      int nsrc[NG];
+#pragma unroll
+      for (int u = 0; u < NG; ++u) {
+        const int rr = (tid + u * FTHREADS) / per;
+        nsrc[u] = (has_next && nrow0 + rr < a.count) ? a.rows[nrow0 + rr] : -1;
+      }
+      const int lsrc_next = (has_next && nrow0 + lrr < a.count) ? a.rows[nrow0 + lrr] : -1;
 #pragma unroll 2
-      for (int k = 2; k < FR; k += 2) {
+      for (int k = 2; k < FR / 2; k += 2) {
+        const float* bk = &lds[bo + k * FLDH];
+        const float nx0 = lds[ao + k * FLDH], nx1 = lds[ao + k * FLDH + 32];
+        const float n0 = bk[0], n1 = bk[32], n2 = bk[64], n3 = bk[96], n4 = bk[128], n5 = bk[160], n6 = bk[192],
+                    n7 = bk[224];
+        dw2_kstep(gW2, x0, x1, y0, y1, y2, y3, y4, y5, y6, y7);
+        x0 = nx0; x1 = nx1; y0 = n0; y1 = n1; y2 = n2; y3 = n3; y4 = n4; y5 = n5; y6 = n6; y7 = n7;
+      }
+      // level 2 (the indices have had half of the phase to arrive): the rows themselves, in flight during the
+      // second half; written to LDS / consumed by the loss stage in the next tile
+#pragma unroll
+      for (int u = 0; u < NG; ++u) {
+        const int c = (tid + u * FTHREADS) % per;
+        xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (nsrc[u] >= 0) xr[u] = ldg16(a.obs, (unsigned)nsrc[u] * (unsigned)(DP * 4) + (unsigned)(c * 16));
+      }
+      gather_loss(lsrc_next, lq);
+#pragma unroll 2
+      for (int k = FR / 2; k < FR; k += 2) {
         const float* bk = &lds[bo + k * FLDH];
         const float nx0 = lds[ao + k * FLDH], nx1 = lds[ao + k * FLDH + 32];
         const float n0 = bk[0], n1 = bk[32], n2 = bk[64], n3 = bk[96], n4 = bk[128], n5 = bk[160], n6 = bk[192],
@@ -811,12 +837,6 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     __syncthreads();
     STAMP(19)
     // ---- dW1 += dz1^T . X  (this wave: 64 neurons x DP inputs, K = 64 rows) ----
-#pragma unroll
-    for (int u = 0; u < NG; ++u) {  // next tile's X rows: in flight during dW1, written to LDS at the loop top
-      const int c = (tid + u * FTHREADS) % per;
-      xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (nsrc[u] >= 0) xr[u] = ldg16(a.obs, (unsigned)nsrc[u] * (unsigned)(DP * 4) + (unsigned)(c * 16));
-    }
     if (PHASE_ON(2048)) gb1 += column_sum(L::H1, tid);
     if (PHASE_ON(512)) {
       constexpr bool two = DP > 32;

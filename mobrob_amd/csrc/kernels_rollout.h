@@ -348,6 +348,11 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_value_batch(FusedNet W, const f
       xr[u] = ldg16(X, (unsigned)(blockIdx.x * FR + rr) * (unsigned)(DP * 4) + (unsigned)(c * 16));
   }
   const float bv = W.b3[0];
+#ifdef MOBROB_STAMPS  // diagnostic build: the shared forward code stamps into a scratch array here
+  __shared__ unsigned long long stamps_sink[32];
+  unsigned long long* stamps_ = stamps_sink;
+  unsigned long long tprev_ = 0;
+#endif
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int tid = opaque(tid0), lane = tid & 63;
     const Frag2 f1 = prefetch_frag(W.W1f + (size_t)(2 * wave) * (DP / 8) * 64,
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_value_batch(FusedNet W, const f
         xr[u] = ldg16(X, (unsigned)(nt * FR + rr) * (unsigned)(DP * 4) + (unsigned)(c * 16));
     }
     __syncthreads();
-    const Frag2 f3 = tile_layers<DP, true>(W, wave, lane, f1);
+    const Frag2 f3 = tile_layers<DP, true>(W, wave, lane, f1 STAMP_ARGS);
     tile_head16<DP>(W, wave, lane, f3);  // wave w writes head rows 16w..16w+15, read back by the same wave below
     if (lane < 16) {
       const int rr = 16 * wave + lane, row = tile * FR + rr;
