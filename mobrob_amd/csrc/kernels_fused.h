@@ -370,23 +370,33 @@ struct Lay {
 #endif
 #define PHASE_ON(bit) (!((MOBROB_SKIP) & (bit)))
 #ifdef MOBROB_STAMPS
+// The deltas are accumulated in (scalar) registers and flushed once at the end of the kernel: a global atomic per
+// stamp would sit in the in-order vmcnt queue in front of the next phase's weight-fragment loads and charge its own
+// latency to that phase.
 #define STAMP(id)                                                                                  \
   {                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                             \
     unsigned long long t_;                                                                         \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
     __builtin_amdgcn_sched_barrier(0);                                                             \
-    if (lane == 0) atomicAdd(&stamps_[id], t_ - tprev_);                                          \
+    tacc_[id] += t_ - tprev_;                                                                      \
     tprev_ = t_;                                                                                   \
   }
 #define STAMP_INIT()                                                                               \
   unsigned long long tprev_;                                                                       \
+  unsigned long long tacc_[24];                                                                    \
+  _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) tacc_[i_] = 0;                                 \
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev_)::"memory");
-#define STAMP_PARAMS , unsigned long long *stamps_, unsigned long long &tprev_
-#define STAMP_ARGS , stamps_, tprev_
+#define STAMP_FLUSH()                                                                              \
+  if ((threadIdx.x & 63) == 0) {                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) atomicAdd(&stamps_[i_], tacc_[i_]);          \
+  }
+#define STAMP_PARAMS , unsigned long long (&tacc_)[24], unsigned long long &tprev_
+#define STAMP_ARGS , tacc_, tprev_
 #else
 #define STAMP(id)
 #define STAMP_INIT()
+#define STAMP_FLUSH()
 #define STAMP_PARAMS
 #define STAMP_ARGS
 #endif
@@ -864,6 +874,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   const int tid = tid0, lane = tid & 63;
   // ---- store this workgroup's partial gradients to its slab ----
   STAMP(22)
+  STAMP_FLUSH()
   if (PHASE_ON(16384) || blockIdx.x < 2) {  // (ablation bit 16384: only two workgroups write their slabs)
     asm volatile("s_nop 15\n\ts_nop 3");  // last asm MFMA's D -> v_accvgpr_read (16-pass XDL)
     {  // dW1 / dW3 tiles, fragment order: [w][tile][quad][lane] x 16 B
