@@ -19,8 +19,8 @@
 #include "fused_dispatch.h"
 #include "kernels_env.h"
 #include "kernels_rollout.h"
-#ifdef MOBROB_VALUE8
-#include "kernels_fused8.h"
+#ifdef MOBROB_VALUE8  // experiment, see scratch/value8.py
+#include "../../scratch/kernels_fused8.h"
 #endif
 
 using namespace mobrob;

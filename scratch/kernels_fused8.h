@@ -5,7 +5,7 @@
 // same k order as in the four-wave kernel: results are bit-identical (scratch/value8.py checks that).
 // This is the forward third of the two-waves-per-SIMD training kernel planned in DESIGN.md section 7.
 #pragma once
-#include "kernels_fused.h"
+#include "../mobrob_amd/csrc/kernels_fused.h"
 
 namespace mobrob {
 
