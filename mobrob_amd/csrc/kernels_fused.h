@@ -847,24 +847,43 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     __syncthreads();
     STAMP(19)
     // ---- dW1 += dz1^T . X  (this wave: 64 neurons x DP inputs, K = 64 rows) ----
-    if (PHASE_ON(2048)) gb1 += column_sum(L::H1, tid);
     if (PHASE_ON(512)) {
       constexpr bool two = DP > 32;
       const int ao = opaque(L::H1 + h * FLDH + 64 * wave + r);
       const int c0 = (r < DP) ? r : 0;
       const int c1 = (32 + r < DP) ? 32 + r : c0;  // clamped columns are never read back
       const int b0o = opaque(L::X + h * ldx + c0), b1o = opaque(L::X + h * ldx + c1);
+      // The bias gradient gb1 (sum of column `tid` of dz1 over the 64 rows) rides in the same loop: four partial sums
+      // over rows = 0..3 (mod 4), added as (s0 + s1) + (s2 + s3) -- the order of column_sum() -- with their LDS reads
+      // under the MFMAs instead of in front of them.  Two k-steps (4 rows) per iteration, ping-pong operand sets.
+      const int co = opaque(L::H1 + tid);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
       float x0 = lds[ao], x1 = lds[ao + 32], y0 = lds[b0o], y1 = two ? lds[b1o] : 0.f;
-#pragma unroll 4
-      for (int k = 0; k < FR - 2; k += 2) {  // operands of step k+2 are fetched before the MFMAs of step k
-        const float x0n = lds[ao + (k + 2) * FLDH], x1n = lds[ao + (k + 2) * FLDH + 32];
-        const float y0n = lds[b0o + (k + 2) * ldx], y1n = two ? lds[b1o + (k + 2) * ldx] : 0.f;
-        if (two) mfma_x2y2(gW1a, gW1b, gW1c, gW1d, x0, x1, y0, y1);
-        else mfma_x2y1(gW1a, gW1b, x0, x1, y0);
-        x0 = x0n; x1 = x1n; y0 = y0n; y1 = y1n;
+      float xa, xb, ya, yb;
+#define DW1_STEP(X0, X1, Y0, Y1)                                  \
+  if (two) mfma_x2y2(gW1a, gW1b, gW1c, gW1d, X0, X1, Y0, Y1);     \
+  else mfma_x2y1(gW1a, gW1b, X0, X1, Y0);
+#pragma unroll 2
+      for (int k = 0; k < FR - 4; k += 4) {
+        xa = lds[ao + (k + 2) * FLDH]; xb = lds[ao + (k + 2) * FLDH + 32];
+        ya = lds[b0o + (k + 2) * ldx]; yb = two ? lds[b1o + (k + 2) * ldx] : 0.f;
+        if (PHASE_ON(2048)) { s0 += lds[co + k * FLDH]; s1 += lds[co + (k + 1) * FLDH]; }
+        DW1_STEP(x0, x1, y0, y1)
+        x0 = lds[ao + (k + 4) * FLDH]; x1 = lds[ao + (k + 4) * FLDH + 32];
+        y0 = lds[b0o + (k + 4) * ldx]; y1 = two ? lds[b1o + (k + 4) * ldx] : 0.f;
+        if (PHASE_ON(2048)) { s2 += lds[co + (k + 2) * FLDH]; s3 += lds[co + (k + 3) * FLDH]; }
+        DW1_STEP(xa, xb, ya, yb)
       }
-      if (two) mfma_x2y2(gW1a, gW1b, gW1c, gW1d, x0, x1, y0, y1);
-      else mfma_x2y1(gW1a, gW1b, x0, x1, y0);
+      xa = lds[ao + (FR - 2) * FLDH]; xb = lds[ao + (FR - 2) * FLDH + 32];
+      ya = lds[b0o + (FR - 2) * ldx]; yb = two ? lds[b1o + (FR - 2) * ldx] : 0.f;
+      if (PHASE_ON(2048)) { s0 += lds[co + (FR - 4) * FLDH]; s1 += lds[co + (FR - 3) * FLDH]; }
+      DW1_STEP(x0, x1, y0, y1)
+      if (PHASE_ON(2048)) { s2 += lds[co + (FR - 2) * FLDH]; s3 += lds[co + (FR - 1) * FLDH]; }
+      DW1_STEP(xa, xb, ya, yb)
+#undef DW1_STEP
+      gb1 += (s0 + s1) + (s2 + s3);
+    } else if (PHASE_ON(2048)) {
+      gb1 += column_sum(L::H1, tid);
     }
     STAMP(20)
     __syncthreads();  // X / h1 / h2 are rewritten by the next tile
