@@ -187,8 +187,8 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
         const float d = act - m;
         lds[L::TM + rr_ * 33 + k] = -(d * d) / lds[L::AC + 32 + k] - lds[L::AC + 64 + k] - 0.91893853320467274178f;
         const float ac = fminf(fmaxf(act, a.lo), a.hi);
-        a.actions[((size_t)t * N + row) * A + k] = act;
-        a.clip_act[(size_t)row * A + k] = ac;
+        if (ROLL_ON(128)) a.actions[((size_t)t * N + row) * A + k] = act;
+        if (ROLL_ON(128)) a.clip_act[(size_t)row * A + k] = ac;
         lds[L::CA + rr_ * 33 + k] = ac;
       }
     }
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
     if (tid < R && row0 + tid < N) {
       float lp = 0.f;
       for (int k = 0; k < A; ++k) lp += lds[L::TM + tid * 33 + k];
-      a.logp[(size_t)t * N + row0 + tid] = lp;
+      if (ROLL_ON(128)) a.logp[(size_t)t * N + row0 + tid] = lp;
     }
     // ---- env.step(clipped actions) + auto-reset: 8 threads per row, observation chunks sub and sub + 8 ----
     const int rr = tid >> 3, sub = tid & 7;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
           }
-          reinterpret_cast<f32x4*>(a.obs)[onext + c] = o;
+          if (ROLL_ON(128)) reinterpret_cast<f32x4*>(a.obs)[onext + c] = o;
           *reinterpret_cast<f32x4*>(&xrow[4 * c]) = o;
         }
         if (sub == 0) {
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
             box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
             ob = goal_features(gn, a.goal.P, D, c, z, a.goal.noise);
           }
-          reinterpret_cast<f32x4*>(a.obs)[onext + c] = ob;
+          if (ROLL_ON(128)) reinterpret_cast<f32x4*>(a.obs)[onext + c] = ob;
           *reinterpret_cast<f32x4*>(&xrow[4 * c]) = ob;
         }
         g = gn;
@@ -268,9 +268,9 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
     __syncthreads();  // every thread of a row has read the row's old state
     if (live && sub == 0) {
       const size_t so = (size_t)t * N + n;
-      a.es[so] = S[12];
+      if (ROLL_ON(128)) a.es[so] = S[12];
       S[12] = done ? 1.f : 0.f;
-      a.trunc[n] = tr ? 1 : 0;
+      if (ROLL_ON(128)) a.trunc[n] = tr ? 1 : 0;
       if (a.kind == 1) {
         reinterpret_cast<int*>(S)[13] = ep_len_new;
       } else {
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
         lrow[q] = rr;
         lrew[q] = reward;
       } else {
-        a.rewards[so] = reward;
+        if (ROLL_ON(128)) a.rewards[so] = reward;
       }
     }
     __syncthreads();
