@@ -11,12 +11,16 @@ Workload (config.workload): BASELINE.json configs[2] "doggo env (58 obs / 12 act
 minibatch of 65536 per GPU (the YAML's batch_size=100 would be 40960 serial Adam steps per epoch).
 Inputs are resident in HBM (the synthetic env source generates observations on the device).
 
-Launch: python bench.py --gpus 1 --steps K --warmup W
+Launch: python bench.py --gpus N --steps K --warmup W      (N > 1 without a torchrun environment: this process
+                                                            starts the N ranks itself, one child per GPU)
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -52,14 +56,14 @@ def init_params(D, A, H, seed):
     return orthogonal_policy_init(D, A, (H, H), (H, H), seed)
 
 
-def cpu_baseline(w, budget_s=20.0):
-    """The CPU oracle (SB3-semantics NumPy restatement) on a bounded sample of the same workload."""
+def _oracle_throughput(w, budget_s, threads=None):
+    """The CPU oracle (SB3-semantics NumPy restatement) on a bounded sample of workload `w`."""
     from oracle import ppo_oracle as O
     limiter = None
     try:
         from threadpoolctl import threadpool_info, threadpool_limits
-        if w.get("cpu_threads"):
-            limiter = threadpool_limits(limits=int(w["cpu_threads"]))
+        if threads:
+            limiter = threadpool_limits(limits=int(threads))
         cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [os.cpu_count() or 1])
     except Exception:
         cores = os.cpu_count() or 1
@@ -87,6 +91,184 @@ def cpu_baseline(w, budget_s=20.0):
     return {"value": done_steps / el, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
             "sample": f"{reps} x (rollout {Ts} steps x {N} envs + {h.n_epochs} epochs, minibatch {w['B']}) "
                       f"= {done_steps} env-steps of the NumPy oracle in {el:.1f} s"}
+
+
+def _sb3_throughput(w, budget_s):
+    """when stable-baselines3 happens to be importable on the box, time the REAL reference stack
+    (`stable_baselines3.PPO(device="cpu")`, what /root/reference/src/mobrob/rl_control/ppo.py:50-59 constructs) on a
+    synthetic VecEnv of the reference shape.  Neither this container nor the GPU image ships SB3, so this normally
+    reports why it is absent."""
+    try:
+        import gymnasium as gym
+        import stable_baselines3 as sb3
+        from stable_baselines3.common.vec_env import DummyVecEnv
+    except Exception as ex:  # noqa: BLE001 - any import problem means "no third column"
+        return {"available": False, "reason": f"{type(ex).__name__}: {ex}"}
+    try:
+        import torch
+        torch.set_num_threads(1)  # examples/train.py:13
+        D, A, H, N, T = w["D"], w["A"], w["H"], w["N"], w["T"]
+
+        class Synthetic(gym.Env):
+            observation_space = gym.spaces.Box(-np.inf, np.inf, (D,), np.float32)
+            action_space = gym.spaces.Box(-1.0, 1.0, (A,), np.float32)
+
+            def __init__(self, seed):
+                self.rng, self.t = np.random.default_rng(seed), 0
+
+            def reset(self, *, seed=None, options=None):
+                self.t = 0
+                return self.rng.standard_normal(D, dtype=np.float32), {}
+
+            def step(self, action):
+                self.t += 1
+                term = bool(self.rng.random() < w["p_term"])
+                rew = float(0.03 + 0.1 * self.rng.standard_normal() + 5.0 * term)
+                return self.rng.standard_normal(D, dtype=np.float32), rew, term, (self.t >= w["tl"]) and not term, {}
+
+        venv = DummyVecEnv([(lambda i=i: Synthetic(i)) for i in range(N)])
+        model = sb3.PPO("MlpPolicy", venv, n_steps=T, batch_size=w["B"], n_epochs=w["E"], ent_coef=0.01, device="cpu",
+                        policy_kwargs=dict(net_arch=dict(pi=[H, H], vf=[H, H])), verbose=0, seed=0)
+        t0 = time.perf_counter()
+        iters = 0
+        while time.perf_counter() - t0 < budget_s:
+            model.learn(total_timesteps=N * T, reset_num_timesteps=False)
+            iters += 1
+        el = time.perf_counter() - t0
+        return {"available": True, "value": iters * N * T / el, "unit": "env-steps/s", "cores": 1, "kind": "sb3",
+                "version": sb3.__version__, "sample": f"{iters} x PPO.learn({N * T}) in {el:.1f} s, DummyVecEnv of {N} synthetic envs"}
+    except Exception as ex:  # noqa: BLE001
+        return {"available": False, "reason": f"stable_baselines3 imported but the run failed: {type(ex).__name__}: {ex}"}
+
+
+def cpu_baseline(w, budget_s=14.0, workload_name=None):
+    """Contract object = BASELINE.md §3 column B2 (all host cores, the benchmarked shape); beside it column B1 (ONE
+    thread, the reference's own shape data/configs/doggo-ppo.yaml + examples/train.py:13) and the SB3 probe."""
+    out = _oracle_throughput(w, budget_s, w.get("cpu_threads"))
+    ref_name = "doggo-ref-16env-2x64"
+    if workload_name != ref_name:
+        b1 = _oracle_throughput(WORKLOADS[ref_name], 7.0, threads=1)
+        b1["shape"] = ref_name + " (16 envs x 1000 steps, minibatch 100, 2x64, 5 epochs)"
+        out["reference_shape_1thread"] = b1
+    out["sb3"] = _sb3_throughput(WORKLOADS[ref_name], 8.0)
+    return out
+
+
+def csrc_sha256():
+    """Fingerprint of the kernel sources; profiles/rN/hbm_traffic_pmc.json records the one it was measured on."""
+    d = os.path.join(ROOT, "mobrob_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def measured_traffic(kernel_prefix):
+    """(bytes per launch | None, note): PMC-counted HBM traffic of the dominant kernel from the newest committed
+    profile -- only if that profile was taken on exactly these kernel sources; otherwise None (never a stale figure)."""
+    for rnd in ("r2", "r1"):
+        tj = os.path.join(ROOT, "profiles", rnd, "hbm_traffic_pmc.json")
+        if not os.path.exists(tj):
+            continue
+        j = json.load(open(tj))
+        if j.get("csrc_sha256") != csrc_sha256():
+            return None, (f"profiles/{rnd}/hbm_traffic_pmc.json was measured on other kernel sources "
+                          f"(csrc_sha256 {str(j.get('csrc_sha256'))[:12]} != {csrc_sha256()[:12]}): not reported")
+        k = next((v for n, v in j["kernels"].items() if n.startswith(kernel_prefix)), None)
+        if k is None:
+            return None, f"kernel not in profiles/{rnd}/hbm_traffic_pmc.json"
+        return k["hbm_bytes_per_launch_corrected"], (f"HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                                      f"command on these kernel sources (profiles/{rnd}/hbm_traffic_pmc.json, "
+                                                      f"csrc_sha256 {csrc_sha256()[:12]}); not re-measured inside this run")
+    return None, "no PMC profile committed"
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as child processes (one per GPU, RCCL rendezvous
+    on 127.0.0.1) BEFORE this process touches the GPU, pass rank 0's JSON line through, fail if any rank fails."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(n))
+    while pending and rc == 0:
+        time.sleep(0.05)
+        for r in list(pending):
+            code = procs[r].poll()
+            if r == 0 and code is None:
+                continue
+            if code is not None:
+                pending.discard(r)
+                if code != 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+    line = b""
+    if rc == 0:
+        line = procs[0].stdout.read()
+    else:
+        for r in pending:  # our own children, by handle
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    if rc == 0 and not line.strip():
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    os.write(1, line)
+    return rc
+
+
+def dry_run_cpu(args, rank, world):
+    """Launcher / rendezvous / timing-contract check without a GPU (tests only): gloo ranks run the barrier + the
+    per-optimizer-step all-reduce of a gradient-sized buffer and print the line's skeleton.  No PPO work happens here
+    and no throughput is claimed (`value` is null)."""
+    import torch
+    import torch.distributed as dist
+    w = WORKLOADS[args.workload]
+    if world > 1:
+        dist.init_process_group("gloo")
+    P = 2 * (w["D"] * w["H"] + w["H"] * w["H"] + 2 * w["H"]) + w["H"] * (w["A"] + 1) + 2 * w["A"] + 1
+    g = torch.full((P,), float(rank + 1))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        if world > 1:
+            dist.all_reduce(g.clone())
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = g.clone()
+        if world > 1:
+            dist.all_reduce(x)
+        assert float(x[0]) == world * (world + 1) / 2
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        emit({"metric": "env-steps/sec (whole node), doggo PPO", "value": None, "unit": "env-steps/s", "n_gpus": world,
+              "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * float(tt) / max(args.steps, 1),
+              "dry_run": "cpu/gloo launcher check: no PPO work, no throughput claim",
+              "config": {"workload": args.workload, "parallelism": f"dp{world}",
+                         "n_ranks_seen": dist.get_world_size() if world > 1 else 1}})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def bench_fleet(args, w, rank, local_rank, world, use_dp, force_dp):
@@ -190,7 +372,11 @@ def main():
                     help="host-env workloads: drive the pipelined rollout from Python instead of mobrob_ppo_collect_host")
     ap.add_argument("--host-parts", type=int, default=2,
                     help="host-env workloads: row ranges of the pipelined rollout (1 = whole batch per step)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="tests: exercise the rank launcher / rendezvous / one-line contract with gloo on CPU (no PPO work)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # not under torchrun: start the ranks ourselves
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))      # (no GPU call has happened in this process)
     # RCCL prints a version banner to the C stdout of every rank (flushed at exit, i.e. after the result line):
     # keep the real stdout for the JSON line only and send everything else written to fd 1 to stderr.
     global _RESULT_FD
@@ -205,7 +391,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -324,12 +512,9 @@ def main():
         # minibatch of an epoch is short when batch does not divide T*N)
         flops_per_launch = 3.0 * f_fwd(D, H, A) * (float(N) * T * E * args.steps) / max(calls, 1)
         achieved = (flops_per_launch * calls / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r1", "hbm_traffic_pmc.json")
-        if os.path.exists(tj) and not args.generic and args.workload == "doggo-4096env-2x256":
-            ks = json.load(open(tj))["kernels"]
-            k = next((v for n, v in ks.items() if n.startswith("void mobrob::k_fused_train<64")), None)
-            traffic = k["hbm_bytes_per_launch_corrected"] if k else None
+        traffic, traffic_note = None, "PMC traffic is profiled for the default workload on one GPU only"
+        if not args.generic and args.workload == "doggo-4096env-2x256" and not use_dp and not args.phases:
+            traffic, traffic_note = measured_traffic("void mobrob::k_fused_train<64")
         out = {
             "metric": "env-steps/sec (whole node), doggo PPO" if "doggo" in args.workload else "env-steps/sec (whole node)",
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -339,18 +524,19 @@ def main():
                        "n_steps": T, "n_epochs": E, "minibatch_per_gpu": B, "minibatches_per_epoch": nmb,
                        "env_source": (f"native host env (csrc/host_env.c, OpenMP), pinned zero-copy staging over PCIe, {args.host_parts} pipelined row ranges"
                                       if host is not None else "device-resident synthetic (Philox)"),
-                       "parallelism": f"dp{world}", "kernels": "generic" if args.generic else "fused"},
+                       "parallelism": f"dp{world}", "n_ranks_seen": dist.get_world_size() if use_dp else 1,
+                       "kernels": "generic" if args.generic else "fused"},
             "roofline": {"bound": "mfma", "kernel": "k_fused_train (minibatch forward+loss+backward)" if not args.generic else "generic GEMM chain",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/r1/hbm_traffic_pmc.json)",
+                         "traffic_note": traffic_note,
                          "avg_launch_ms": ms / max(calls, 1), "launches": calls,
                          "flops_per_launch": flops_per_launch},
             "phases_bracketed": "all" if args.phases else "dominant kernel only",
             "phase_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1] > 0},
         }
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(w)
+            out["cpu_baseline"] = cpu_baseline(w, workload_name=args.workload)
         emit(out)
     if use_dp:
         dist.barrier()

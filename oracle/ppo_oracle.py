@@ -131,19 +131,33 @@ def _net_layers(p, prefix):
 # --------------------------------------------------------------------------------------
 # forward pieces  [SB3 common/policies.py ActorCriticPolicy, common/torch_layers.py MlpExtractor]
 # --------------------------------------------------------------------------------------
-def _linear(x, w, b):
+def _mm(a, b, acc=None):
+    """a @ b with float32 operands and a float32 result.  acc=np.float64 accumulates the dot products in
+    float64 (every f32*f32 product is exact there), which is what the full-size parity tests use so that the
+    checker's own summation error over 65 536 rows stays far below the 1e-4 bar; acc=None is plain float32
+    BLAS, torch-CPU's arithmetic."""
+    if acc is None:
+        return (a @ b).astype(F32)
+    return (a.astype(acc) @ b.astype(acc)).astype(F32)
+
+
+def _colsum(a, acc=None):
+    return a.sum(axis=0, dtype=F32 if acc is None else acc).astype(F32)
+
+
+def _linear(x, w, b, acc=None):
     # torch.nn.Linear: x @ W^T + b in float32
-    return (x @ w.T + b).astype(F32)
+    return (_mm(x, w.T, acc) + b).astype(F32)
 
 
-def mlp_latents(p, obs):
+def mlp_latents(p, obs, acc=None):
     """Returns (per-layer activations of the policy net, of the value net); index 0 is the input."""
     x = np.asarray(obs).astype(F32)  # FlattenExtractor + obs.float()
     acts_pi, acts_vf = [x], [x]
     for w, b in _net_layers(p, "mlp_extractor.policy_net"):
-        acts_pi.append(np.tanh(_linear(acts_pi[-1], w, b)).astype(F32))
+        acts_pi.append(np.tanh(_linear(acts_pi[-1], w, b, acc)).astype(F32))
     for w, b in _net_layers(p, "mlp_extractor.value_net"):
-        acts_vf.append(np.tanh(_linear(acts_vf[-1], w, b)).astype(F32))
+        acts_vf.append(np.tanh(_linear(acts_vf[-1], w, b, acc)).astype(F32))
     return acts_pi, acts_vf
 
 
@@ -314,18 +328,19 @@ class Hyper:
     batch_size: int = 64
 
 
-def normalize_advantages(adv):
+def normalize_advantages(adv, acc=None):
     """(adv - mean) / (std + 1e-8) with torch's UNBIASED std; skipped when len <= 1."""
     adv = np.asarray(adv, F32)
     if adv.shape[0] <= 1:
         return adv
-    mean = adv.mean(dtype=F32)
-    std = F32(np.sqrt(np.sum((adv - mean).astype(F32) ** 2, dtype=F32) / F32(adv.shape[0] - 1)))
+    sdt = F32 if acc is None else acc
+    mean = F32(adv.mean(dtype=sdt))
+    std = F32(np.sqrt(np.sum((adv - mean).astype(F32) ** 2, dtype=sdt) / sdt(adv.shape[0] - 1)))
     return ((adv - mean) / (std + F32(1e-8))).astype(F32)
 
 
 def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, returns, h: Hyper,
-                   adv_mean_std=None, denom=None):
+                   adv_mean_std=None, denom=None, acc=None):
     """One minibatch: loss terms + all parameter gradients (same key order as `p`).
 
     Hand-derived backward of PPO.train's graph, following torch's sub-gradient conventions
@@ -334,14 +349,18 @@ def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, return
 
     adv_mean_std / denom support data-parallel sharding: when a rank holds only a shard of the
     global minibatch it passes the GLOBAL (mean, std) and the GLOBAL batch size so that the sum
-    of per-rank gradients equals the single-process gradient."""
+    of per-rank gradients equals the single-process gradient.
+
+    acc=np.float64: every contraction over the batch or a hidden width (GEMMs, column sums, loss sums) is
+    accumulated in float64 and rounded once to float32 (see `_mm`); element-wise math stays float32."""
+    sdt = F32 if acc is None else acc
     obs = np.asarray(obs).astype(F32)
     actions = np.asarray(actions, F32)
     B = obs.shape[0]
     Bg = F32(B if denom is None else denom)
-    acts_pi, acts_vf = mlp_latents(p, obs)
-    mean = _linear(acts_pi[-1], p["action_net.weight"], p["action_net.bias"])
-    values = _linear(acts_vf[-1], p["value_net.weight"], p["value_net.bias"])[:, 0]
+    acts_pi, acts_vf = mlp_latents(p, obs, acc)
+    mean = _linear(acts_pi[-1], p["action_net.weight"], p["action_net.bias"], acc)
+    values = _linear(acts_vf[-1], p["value_net.weight"], p["value_net.bias"], acc)[:, 0]
     log_std = p["log_std"].astype(F32)
     std = np.exp(log_std).astype(F32)
     var = (std * std).astype(F32)
@@ -351,7 +370,7 @@ def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, return
     adv = np.asarray(advantages, F32)
     if h.normalize_advantage and (denom if denom is not None else B) > 1:
         if adv_mean_std is None:
-            adv = normalize_advantages(adv)
+            adv = normalize_advantages(adv, acc)
         else:
             m, s = F32(adv_mean_std[0]), F32(adv_mean_std[1])
             adv = ((adv - m) / (s + F32(1e-8))).astype(F32)
@@ -361,13 +380,13 @@ def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, return
     lo, hi = F32(1.0 - h.clip_range), F32(1.0 + h.clip_range)
     s1 = (adv * ratio).astype(F32)
     s2 = (adv * np.clip(ratio, lo, hi)).astype(F32)
-    policy_loss = F32(-(np.minimum(s1, s2).sum(dtype=F32) / Bg))
-    clip_fraction = F32((np.abs(ratio - F32(1.0)) > F32(h.clip_range)).astype(F32).sum(dtype=F32) / Bg)
+    policy_loss = F32(-(F32(np.minimum(s1, s2).sum(dtype=sdt)) / Bg))
+    clip_fraction = F32(F32((np.abs(ratio - F32(1.0)) > F32(h.clip_range)).astype(F32).sum(dtype=sdt)) / Bg)
     ret = np.asarray(returns, F32)
-    value_loss = F32(((ret - values) ** 2).sum(dtype=F32) / Bg)
+    value_loss = F32(F32(((ret - values) ** 2).sum(dtype=sdt)) / Bg)
     entropy_loss = F32(-(entropy.sum(dtype=F32) / Bg))
     loss = F32(policy_loss + F32(h.ent_coef) * entropy_loss + F32(h.vf_coef) * value_loss)
-    approx_kl = F32(((np.exp(log_ratio) - F32(1.0)) - log_ratio).astype(F32).sum(dtype=F32) / Bg)
+    approx_kl = F32(F32(((np.exp(log_ratio) - F32(1.0)) - log_ratio).astype(F32).sum(dtype=sdt)) / Bg)
 
     # ---- backward ----
     in_range = ((ratio >= lo) & (ratio <= hi)).astype(F32)
@@ -377,7 +396,7 @@ def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, return
     g_logp = (d_ratio * ratio).astype(F32)  # dL/dlog_prob_i
     d = (actions - mean).astype(F32)
     g_mean = (g_logp[:, None] * d / var).astype(F32)  # [B, A]
-    g_log_std = (g_logp[:, None] * (d * d / var - F32(1.0))).sum(axis=0, dtype=F32)
+    g_log_std = _colsum((g_logp[:, None] * (d * d / var - F32(1.0))).astype(F32), acc)
     # entropy: d(-mean(entropy))/dlog_std_a = -(B_local / B_global)
     g_log_std = (g_log_std + F32(h.ent_coef) * F32(-float(B)) / Bg).astype(F32)
     g_value = (F32(h.vf_coef) * F32(2.0) * (values - ret) / Bg).astype(F32)  # [B]
@@ -386,16 +405,16 @@ def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, return
     grads["log_std"] = g_log_std
 
     def backprop(prefix, head_w_key, head_b_key, acts, g_out):
-        grads[head_w_key] = (g_out.T @ acts[-1]).astype(F32)
-        grads[head_b_key] = g_out.sum(axis=0, dtype=F32)
-        g_h = (g_out @ p[head_w_key]).astype(F32)
+        grads[head_w_key] = _mm(g_out.T, acts[-1], acc)
+        grads[head_b_key] = _colsum(g_out, acc)
+        g_h = _mm(g_out, p[head_w_key], acc)
         layers = _net_layers(p, prefix)
         for li in reversed(range(len(layers))):
             w, _ = layers[li]
             g_z = (g_h * (F32(1.0) - acts[li + 1] * acts[li + 1])).astype(F32)
-            grads[f"{prefix}.{2 * li}.weight"] = (g_z.T @ acts[li]).astype(F32)
-            grads[f"{prefix}.{2 * li}.bias"] = g_z.sum(axis=0, dtype=F32)
-            g_h = (g_z @ w).astype(F32)
+            grads[f"{prefix}.{2 * li}.weight"] = _mm(g_z.T, acts[li], acc)
+            grads[f"{prefix}.{2 * li}.bias"] = _colsum(g_z, acc)
+            g_h = _mm(g_z, w, acc)
 
     backprop("mlp_extractor.policy_net", "action_net.weight", "action_net.bias", acts_pi, g_mean)
     backprop("mlp_extractor.value_net", "value_net.weight", "value_net.bias", acts_vf, g_value[:, None])

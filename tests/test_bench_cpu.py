@@ -1,0 +1,68 @@
+"""CPU: `python bench.py --gpus N` starts its own ranks (no torchrun), forwards exactly one JSON line from rank 0 and
+fails when a rank fails.  Driven through `--dry-run-cpu` (gloo, no PPO work: the launcher, the rendezvous on
+127.0.0.1, the barrier + max-over-ranks timing and the one-line contract are what is under test here; the GPU
+bench line itself is covered by tests/test_api_gpu.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    env.update(extra)
+    return env
+
+
+@pytest.mark.parametrize("n", [1, 2, 4])
+def test_bench_launches_its_own_ranks(n):
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--steps", "2", "--warmup", "1", "--dry-run-cpu"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["config"]["n_ranks_seen"] == n and out["config"]["parallelism"] == f"dp{n}"
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["value"] is None and "dry_run" in out
+
+
+def test_bench_under_a_torchrun_environment_does_not_spawn():
+    """With RANK/WORLD_SIZE already set (torch.distributed.run form) the process IS a rank: a world-size mismatch is
+    an error instead of a second level of children."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run-cpu"],
+                       env=_clean_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_bench_fails_when_a_rank_fails():
+    """Without a GPU every real rank exits with an error; the launcher must report it (non-zero, no JSON line) and
+    not hang on the surviving ranks."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not r.stdout.strip()
+    assert "exited with code" in r.stderr
+
+
+def test_traffic_figure_is_tied_to_the_kernel_sources():
+    sys.path.insert(0, ROOT)
+    import bench
+    sha = bench.csrc_sha256()
+    assert len(sha) == 64 and sha == bench.csrc_sha256()
+    val, note = bench.measured_traffic("void mobrob::k_fused_train<64")
+    newest = next(r for r in ("r2", "r1") if os.path.exists(os.path.join(ROOT, "profiles", r, "hbm_traffic_pmc.json")))
+    recorded = json.load(open(os.path.join(ROOT, "profiles", newest, "hbm_traffic_pmc.json"))).get("csrc_sha256")
+    if recorded == sha:
+        assert isinstance(val, int) and val > 0
+    else:
+        assert val is None and "not reported" in note

@@ -1,10 +1,18 @@
-"""GPU: size-independent properties at BASELINE.json's full sizes (doggo 58/12, 2x256, 4096 envs, 1000 steps,
-minibatch 65536), where the NumPy oracle would take minutes: permutation coverage, GAE linearity, gradient
-additivity over a split minibatch, bit-reproducibility, and conservation checks on a full device rollout."""
+"""GPU: the BENCHMARKED shapes against the oracle, and size-independent properties at the same sizes.
+
+BASELINE.json config 3 (doggo 58/12, 2x256, 4096 envs x 1000 steps, minibatch 65536 -> 63 launches per epoch, the
+last one 32768 rows) and config 2 (point 14/2, 2x64, 1024 envs x 2048 steps, minibatch 65536 -> 32 launches per
+epoch), exactly as `bench.py` runs them: device rollout, device-drawn Feistel permutation, advantage normalisation
+on.  Checked against `oracle/ppo_oracle.py`: a 65536-row minibatch gradient (13 tensors, six loss scalars) with the
+oracle accumulating in float64, clip + Adam from a non-trivial optimizer state, the short last minibatch, and a
+whole epoch of optimizer steps followed step by step.  A whole rollout is too much for the NumPy oracle, so the
+rollout itself is covered by properties: permutation coverage, GAE linearity + a bit-exact column slice, gradient
+additivity over a split minibatch, bit-reproducibility, conservation checks on a full device rollout."""
 import numpy as np
 import pytest
 
 from oracle import ppo_oracle as O
+from tests.util import scaled_err
 
 pytestmark = pytest.mark.gpu
 
@@ -109,4 +117,168 @@ def test_full_size_device_rollout_conservation():
     st = e.episode_stats()
     assert st["episodes"] == int(es[1:].sum() + e.read("last_dones").sum())
     assert 4096 * 1000 // 200 <= st["episodes"] and st["ep_len_mean"] <= 200
+    e.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# the benchmarked shapes against the oracle
+# ------------------------------------------------------------------------------------------------
+GOLDEN_RATIO = 0x9E3779B97F4A7C15
+STAT_KEYS = ("policy_loss", "value_loss", "entropy_loss", "loss", "approx_kl", "clip_fraction")
+
+
+def _device_perm_key(seed, draw, rank=0):
+    """The key mobrob_ppo_epoch_begin(NULL) derives for its `draw`-th (0-based) device permutation."""
+    return ((seed * GOLDEN_RATIO) & (2 ** 64 - 1)) ^ ((rank + 1) << 48) ^ (draw + 1)
+
+
+def _bench_like_engine(D, A, H, n_envs, T, B, seed, rng):
+    """Engine + oracle state set up the way bench.py leaves them after a rollout, with two changes that make the
+    comparison bite: stored log-probs are perturbed so the ratios straddle the clip range (an on-policy first
+    minibatch has ratio == 1 in every row), and the optimizer starts from a non-zero Adam state."""
+    from mobrob_amd.engine import PPOEngine
+    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=1, batch_size=B, learning_rate=3e-4)
+    e = PPOEngine(obs_dim=D, act_dim=A, n_envs=n_envs, n_steps=T, batch_size=B, n_epochs=1, pi=(H, H), vf=(H, H),
+                  gamma=h.gamma, gae_lambda=h.gae_lambda, ent_coef=h.ent_coef, learning_rate=h.learning_rate, seed=seed)
+    p = O.init_params(D, A, (H, H), (H, H), seed=seed)
+    p["log_std"] = rng.normal(-0.3, 0.2, A).astype(np.float32)
+    p["action_net.weight"] *= 30
+    for k in p:
+        if k.endswith("bias"):
+            p[k] = rng.normal(0, 0.05, p[k].shape).astype(np.float32)
+    # Adam moments of a run in progress: |m| / sqrt(v) of order one, so a step moves a parameter by about lr.  (Moments
+    # with v << m^2 make single steps of 1e-2 and push the policy so far from the stored actions that log-ratios reach
+    # several units; the clip-range membership of many rows then hinges on the last bits of log-prob and the test
+    # measures the conditioning of its own inputs instead of the kernel.)
+    st = O.AdamState(type(p)((k, rng.normal(0, 1e-3, v.shape).astype(np.float32)) for k, v in p.items()),
+                     type(p)((k, (1e-6 * (0.5 + 1.5 * rng.random(v.shape))).astype(np.float32)) for k, v in p.items()), 1000)
+    e.set_params(p)
+    e.set_optimizer_state(st.exp_avg, st.exp_avg_sq, st.step)
+    e.collect_synthetic(p_term=0.01, time_limit=500)
+    lp = e.read("log_probs")
+    e.write("log_probs", lp + rng.normal(0, 0.12, lp.shape).astype(np.float32))
+    buf = {k: e.read(k) for k in ("actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns")}
+    buf["obs"] = e.read("obs")[:T]
+    return e, p, st, buf, h
+
+
+def _check_grad(e, p, buf, idx, h, mb, tag):
+    """The clipped surrogate's gradient is DISCONTINUOUS in the ratio at 1 +- clip, and the gradient of a minibatch is a
+    sum of B random-signed row terms, so one row is ~1/sqrt(B) of it (0.5 % at 32768 rows).  A row whose ratio sits
+    within float32 rounding of a clip boundary is in range for one correct implementation and out of range for another
+    (measured: the fused kernel and the generic GEMM chain agree to 1.5e-6 with each other and both differ from the
+    oracle by 4.5e-3 on such a minibatch; about one minibatch in five of this size contains such a row).  Those rows are
+    moved off the boundary (stored log-prob changed by 0.01, on the device and in the oracle's buffer) before comparing."""
+    stats, og, aux = O.loss_and_grads(p, *O.gather_minibatch(buf, idx), h, acc=np.float64)
+    lo, hi = 1.0 - h.clip_range, 1.0 + h.clip_range
+    near = (np.abs(aux["ratio"] - lo) < 2e-5) | (np.abs(aux["ratio"] - hi) < 2e-5)
+    if near.any():
+        t, n = O.flat_to_tn(idx[near], buf["rewards"].shape[0])
+        buf["log_probs"][t, n] -= np.float32(0.01)
+        e.write("log_probs", buf["log_probs"])
+        stats, og, aux = O.loss_and_grads(p, *O.gather_minibatch(buf, idx), h, acc=np.float64)
+        print(f"{tag}: {int(near.sum())} row(s) moved off the clip boundary")
+    e.minibatch_grad(mb)
+    got = e.unflatten(e.read("grads"))
+    frac_clipped = float(np.mean((aux["ratio"] < 0.8) | (aux["ratio"] > 1.2)))
+    errs = {k: scaled_err(got[k], og[k]) for k in og}
+    assert max(errs.values()) < 1e-4, (tag, {k: f"{v:.2e}" for k, v in errs.items()}, got["log_std"], og["log_std"])
+    return stats, og, frac_clipped
+
+
+def _check_apply(e, p, st, og, stats, h, tag):
+    e.minibatch_apply()
+    row = e.fetch_step_stats(1)[0]
+    clipped, total = O.clip_grad_norm(og, h.max_grad_norm)
+    O.adam_step(p, clipped, st, h.learning_rate, h.beta1, h.beta2, h.adam_eps)
+    for i, k in enumerate(STAT_KEYS):
+        ref = float(stats[k])
+        assert abs(float(row[i]) - ref) < 1e-4 * max(1.0, abs(ref)), (tag, k, float(row[i]), ref)
+    assert abs(float(row[6]) - float(total)) < 1e-4 * max(1.0, float(total)), (tag, "grad_norm")
+    newp = e.get_params()
+    m, v, step = e.get_optimizer_state()
+    assert step == st.step
+    for k in p:
+        assert np.max(np.abs(newp[k] - p[k])) < 1e-5, (tag, k, float(np.max(np.abs(newp[k] - p[k]))))
+        assert scaled_err(m[k], st.exp_avg[k]) < 1e-4 and scaled_err(v[k], st.exp_avg_sq[k]) < 1e-4, (tag, k)
+
+
+@pytest.mark.parametrize("shape", [dict(name="doggo-4096env-2x256", D=58, A=12, H=256, N=4096, T=1000),
+                                   dict(name="point-1024env-2x64", D=14, A=2, H=64, N=1024, T=2048)])
+def test_benchmarked_minibatch_matches_oracle(shape):
+    """One full-size optimizer step of the bench workload (grad + loss scalars, then clip + Adam), and the gradient
+    of the LAST minibatch of the epoch (32768 rows at the headline shape: the short-launch path)."""
+    D, A, H, n_envs, T = (shape[k] for k in "DAHNT")
+    B, seed = 65536, 11
+    rng = np.random.default_rng(5)
+    e, p, st, buf, h = _bench_like_engine(D, A, H, n_envs, T, B, seed, rng)
+    total = T * n_envs
+    nmb = -(-total // B)
+    assert e.n_minibatches == nmb
+    perm = O.feistel_permutation(total, _device_perm_key(seed, 0))
+    e.epoch_begin(None)                                   # device-drawn permutation, as in bench.py
+    stats, og, frac = _check_grad(e, p, buf, perm[:B], h, 0, shape["name"] + "/mb0")
+    assert 0.02 < frac < 0.6, frac                        # both clip branches populated
+    _check_apply(e, p, st, og, stats, h, shape["name"] + "/mb0")
+    last = perm[(nmb - 1) * B:]
+    assert len(last) == total - (nmb - 1) * B
+    _check_grad(e, p, buf, last, h, nmb - 1, shape["name"] + "/last")   # at the post-step parameters
+    e.close()
+
+
+@pytest.mark.parametrize("shape", [dict(name="doggo-4096env-2x256", D=58, A=12, H=256, N=4096, T=1000),
+                                   dict(name="point-1024env-2x64", D=14, A=2, H=64, N=1024, T=2048)])
+def test_benchmarked_epoch_matches_oracle(shape):
+    """A whole epoch of the bench workload through the single C call (`mobrob_ppo_train`, 63 / 32 launches incl. the
+    short last one), the oracle following every optimizer step (float32 BLAS, SB3-CPU's arithmetic)."""
+    D, A, H, n_envs, T = (shape[k] for k in "DAHNT")
+    B, seed = 65536, 23
+    rng = np.random.default_rng(6)
+    e, p, st, buf, h = _bench_like_engine(D, A, H, n_envs, T, B, seed, rng)
+    total = T * n_envs
+    nmb = -(-total // B)
+    perm = O.feistel_permutation(total, _device_perm_key(seed, 0))
+    stats = e.train(None)
+    assert stats["n_minibatches"] == nmb
+    ostats = O.train(p, st, buf, h, perm[None])
+    newp = e.get_params()
+    for k in p:
+        assert np.max(np.abs(newp[k] - p[k])) < 1e-4, (k, float(np.max(np.abs(newp[k] - p[k]))))
+    for k in STAT_KEYS + ("grad_norm",):
+        ref = float(np.mean([float(s[k]) for s in ostats]))
+        assert abs(stats[k] - ref) < 2e-4 * max(1.0, abs(ref)), (k, stats[k], ref)
+    m, v, step = e.get_optimizer_state()
+    assert step == st.step == 1000 + nmb
+    e.close()
+
+
+def test_full_size_point_persistent_rollout_conservation():
+    """Config 2's rollout (1024 envs x 2048 steps, 2x64 nets: the H=64 persistent rollout kernel) on the device
+    goal environment: finite everywhere, Monitor counters consistent with the stored episode starts,
+    returns == advantages + values, stored values and log-probs reproduce from the stored observations/actions
+    (oracle forward on a slice), GAE bit-exact on a column slice."""
+    from mobrob_amd.engine import PPOEngine
+    from mobrob_amd.envs.vec_env import DeviceGoalVecEnv
+    Dp, Ap, Hp, n_envs, T = 14, 2, 64, 1024, 2048
+    e = PPOEngine(obs_dim=Dp, act_dim=Ap, n_envs=n_envs, n_steps=T, batch_size=65536, n_epochs=1, pi=(Hp, Hp), vf=(Hp, Hp),
+                  gae_lambda=0.5, seed=3)
+    p = O.init_params(Dp, Ap, (Hp, Hp), (Hp, Hp), seed=4)
+    e.set_params(p)
+    DeviceGoalVecEnv.for_robot("point", n_envs, time_limit=300).collect(e)
+    e.synchronize()
+    es, adv, val, ret = e.read("episode_starts"), e.read("advantages"), e.read("values"), e.read("returns")
+    rew, lp, act, obs = e.read("rewards"), e.read("log_probs"), e.read("actions"), e.read("obs")
+    for k, a in dict(rewards=rew, log_probs=lp, actions=act, obs=obs, adv=adv).items():
+        assert np.isfinite(a).all(), k
+    assert np.array_equal(ret, adv + val)
+    st = e.episode_stats()
+    assert st["episodes"] == int(es[1:].sum() + e.read("last_dones").sum())
+    assert st["episodes"] > 0 and st["ep_len_mean"] <= 300 and st["episodes"] * 300 >= n_envs * (T - 300)
+    cols = slice(100, 116)
+    mean, v = O.policy_outputs(p, obs[:T, cols].reshape(-1, Dp))
+    assert scaled_err(val[:, cols].reshape(-1), v) < 1e-4
+    olp = O.gaussian_log_prob(mean, p["log_std"], act[:, cols].reshape(-1, Ap))
+    assert np.allclose(lp[:, cols].reshape(-1), olp, rtol=1e-4, atol=1e-3)
+    oadv, _ = O.gae(rew[:, cols], val[:, cols], es[:, cols], e.read("last_values")[cols], e.read("last_dones")[cols] > 0, 0.99, 0.5)
+    assert np.array_equal(adv[:, cols], oadv)
     e.close()
