@@ -111,6 +111,14 @@ int mobrob_ppo_synchronize(mobrob_ppo_engine_t* e);
 /* Pinned host memory for the rollout streamer (hipHostMalloc / hipHostFree). */
 void* mobrob_ppo_host_alloc(size_t bytes);
 void mobrob_ppo_host_free(void* p);
+/* Pin and map caller-owned host memory in place (hipHostRegister, mapped + portable): afterwards the range is
+ * accepted wherever host_alloc memory is (zero-copy act/store, act_part/store_part, collect_host).  Meant for the
+ * POSIX shared-memory block that environment worker PROCESSES write their step results into -- the replacement of
+ * the pipes between SubprocVecEnv workers and the learner (/root/reference/src/mobrob/rl_control/ppo.py:30-33 with
+ * make_vec_env :37-48): `p` must stay mapped until host_unregister.  Fails (MOBROB_ERR_HIP) if the range cannot be
+ * pinned or is not device visible at its host address. */
+int mobrob_ppo_host_register(void* p, size_t bytes);
+int mobrob_ppo_host_unregister(void* p);
 
 /* policy.state_dict() / load_state_dict() (examples/train.py:31-33) and the optimizer state of
  * policy.optimizer.pth.  n must equal mobrob_ppo_param_count(). */

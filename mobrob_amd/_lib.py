@@ -67,6 +67,8 @@ SYMBOLS = {
     "mobrob_ppo_synchronize": (C.c_int, [_P]),
     "mobrob_ppo_host_alloc": (_P, [C.c_size_t]),
     "mobrob_ppo_host_free": (None, [_P]),
+    "mobrob_ppo_host_register": (C.c_int, [_P, C.c_size_t]),
+    "mobrob_ppo_host_unregister": (C.c_int, [_P]),
     "mobrob_ppo_param_count": (C.c_int64, [_P]),
     "mobrob_ppo_get_params": (C.c_int, [_P, _F, C.c_int64]),
     "mobrob_ppo_set_params": (C.c_int, [_P, _F, C.c_int64]),

@@ -538,6 +538,33 @@ void* mobrob_ppo_host_alloc(size_t bytes) {
 }
 void mobrob_ppo_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+int mobrob_ppo_host_register(void* p, size_t bytes) {
+  if (!p || bytes == 0) return fail(MOBROB_ERR_INVALID, "host_register: null pointer or empty range");
+  hipError_t r = hipHostRegister(p, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+  if (r != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(MOBROB_ERR_HIP, "hipHostRegister(%p, %zu): %s", p, bytes, hipGetErrorString(r));
+  }
+  // the zero-copy kernels dereference the HOST address: it must also be the device address of the mapping
+  void* d = nullptr;
+  r = hipHostGetDevicePointer(&d, p, 0);
+  if (r != hipSuccess || d != p) {
+    (void)hipGetLastError();
+    (void)hipHostUnregister(p);
+    return fail(MOBROB_ERR_HIP, "host_register: the registered range is not device visible at its host address (%p -> %p)", p, d);
+  }
+  return MOBROB_OK;
+}
+int mobrob_ppo_host_unregister(void* p) {
+  if (!p) return fail(MOBROB_ERR_INVALID, "host_unregister: null pointer");
+  hipError_t r = hipHostUnregister(p);
+  if (r != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(MOBROB_ERR_HIP, "hipHostUnregister(%p): %s", p, hipGetErrorString(r));
+  }
+  return MOBROB_OK;
+}
+
 }  // extern "C"
 
 namespace {

@@ -47,6 +47,28 @@ def param_shapes(obs_dim, act_dim, pi, vf):
     return s
 
 
+class _PinnedBlock:
+    """Owner of one hipHostMalloc allocation.  NumPy arrays made from it keep it alive through `.base`, and the memory
+    is returned to the driver when the LAST such array dies -- not when the engine closes: the rollout collector, the
+    environment (`use_buffers`) and `PPO._last_obs` all hold views that outlive `PPOEngine.close()`."""
+
+    def __init__(self, lib, nbytes, shape, dtype):
+        self._lib, self.ptr = lib, lib.mobrob_ppo_host_alloc(max(int(nbytes), 1))
+        if not self.ptr:
+            raise MemoryError("hipHostMalloc failed")
+        C.memset(self.ptr, 0, max(int(nbytes), 1))
+        self.__array_interface__ = {"shape": tuple(shape), "typestr": np.dtype(dtype).str, "data": (self.ptr, False),
+                                    "version": 3}
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if ptr:
+            try:
+                self._lib.mobrob_ppo_host_free(C.c_void_p(ptr))
+            except Exception:  # noqa: BLE001 - interpreter shutdown
+                pass
+
+
 class PartPipeline:
     """The N envs cut into `nparts` contiguous row ranges: while the host simulator steps range p, the GPU runs the
     policy for the other ranges.  Results equal act()/store() over all rows (same noise per env and step).  The
@@ -159,9 +181,8 @@ class PPOEngine:
         if getattr(self, "_h", None) is not None and self._h.value:
             self.lib.mobrob_ppo_destroy(self._h)
             self._h = C.c_void_p()
-            for ptr in getattr(self, "_pinned", []):
-                self.lib.mobrob_ppo_host_free(C.c_void_p(ptr))
-            self._pinned = []
+            for addr in list(getattr(self, "_registered", [])):
+                self.unregister_host(addr)
 
     def __del__(self):
         try:
@@ -390,17 +411,25 @@ class PPOEngine:
         return out
 
     def pinned(self, shape, dtype=np.float32):
-        """NumPy array backed by pinned host memory (mobrob_ppo_host_alloc): buffers handed to act()/store() from
-        such arrays are copied by DMA without the staging memcpy.  Freed when the engine is closed."""
+        """Zero-filled NumPy array backed by pinned, device-visible host memory (mobrob_ppo_host_alloc): the kernels
+        read / write such buffers in place (no staging copy).  The allocation lives as long as any view of the
+        array does (see _PinnedBlock), also past close()."""
         dtype = np.dtype(dtype)
-        n = int(np.prod(shape)) * dtype.itemsize
-        ptr = self.lib.mobrob_ppo_host_alloc(max(n, 1))
-        if not ptr:
-            raise MemoryError("hipHostMalloc failed")
-        self._pinned = getattr(self, "_pinned", [])
-        self._pinned.append(ptr)
-        buf = (C.c_char * max(n, 1)).from_address(ptr)
-        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        shape = tuple(int(s) for s in np.atleast_1d(shape)) if not isinstance(shape, tuple) else shape
+        block = _PinnedBlock(self.lib, int(np.prod(shape)) * dtype.itemsize, shape, dtype)
+        return np.asarray(block)
+
+    def register_host(self, address, nbytes):
+        """Pin + map caller-owned host memory in place (mobrob_ppo_host_register), e.g. the shared block of
+        `ShmVecEnv`; unregistered by unregister_host() or close()."""
+        check(self.lib.mobrob_ppo_host_register(C.c_void_p(int(address)), C.c_size_t(int(nbytes))))
+        self._registered = getattr(self, "_registered", [])
+        self._registered.append(int(address))
+
+    def unregister_host(self, address):
+        if int(address) in getattr(self, "_registered", []):
+            self._registered.remove(int(address))
+            check(self.lib.mobrob_ppo_host_unregister(C.c_void_p(int(address))))
 
     def set_stream(self, stream_handle):
         check(self.lib.mobrob_ppo_set_stream(self._h, C.c_void_p(stream_handle)))

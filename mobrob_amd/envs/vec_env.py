@@ -17,6 +17,7 @@ Three sources:
 """
 from __future__ import annotations
 
+import functools
 import time
 
 import numpy as np
@@ -203,6 +204,6 @@ class DeviceGoalVecEnv(VecEnvBase):
 
 def make_vec_env(env_fn, n_envs, env_kwargs=None, vec_env_cls=None, seed=None):
     """Signature of SB3's helper as the reference calls it (ppo.py:37-48)."""
-    env_kwargs = dict(env_kwargs or {})
     cls = vec_env_cls or HostVecEnv
-    return cls([(lambda: env_fn(**env_kwargs)) for _ in range(n_envs)], seed=seed)
+    thunk = functools.partial(env_fn, **dict(env_kwargs or {}))  # picklable: worker processes rebuild it
+    return cls([thunk] * n_envs, seed=seed)

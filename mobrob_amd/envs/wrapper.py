@@ -18,6 +18,7 @@ from abc import ABC, abstractmethod
 
 import numpy as np
 
+from . import goal_rules as rules
 from .spaces import Box
 
 # obs/act dims per robot: reference wrapper.py:293-299 (point 14/2), :309-318 (car 26/2),
@@ -76,103 +77,130 @@ class KinematicSim:
 
 
 class EnvWrapper(ABC):
-    """gymnasium-style goal environment; see module docstring for the reference lines mirrored."""
+    """One goal-conditioned robot behind the gymnasium 5-tuple API -- the class a user subclasses to add a robot
+    (nine abstract methods, reference README.md:82-92 / wrapper.py:39-93) and the unit `get_env` hands to the vector
+    layers (`HostVecEnv` in-process, `ShmVecEnv` across worker processes).
+
+    The task rules themselves live in `goal_rules` (array form); this class binds them to ONE simulator instance:
+    it keeps the goal, the goal distance measured at the end of the previous step and whether the robot was ever
+    reset, and asks the subclass for positions.  Public names, signatures and return conventions are the
+    reference's (`step`, `reset(init_pos=None, seed=...)`, `reward_fn`, `reached`, `set_goal`, ...), because callers
+    and subclasses use them (e.g. a subclass may extend `reward_fn`, which `step` therefore always goes through)."""
+
+    reach_radius = rules.REACH_RADIUS
+    goal_bonus = rules.GOAL_BONUS
 
     def __init__(self, enable_gui: bool = False, terminate_on_goal: bool = False):
-        self.enable_gui = enable_gui
-        self.terminate_on_goal = terminate_on_goal
-        self._goal = None
-        self._prev_pos = None
-        self.env = self.build_env()
-        self.observation_space = self.get_observation_space()
-        self.action_space = self.get_action_space()
-        self.init_space = self.get_init_space()
-        self.goal_space = self.get_goal_space()
-        self._first_reset = True
+        self.enable_gui = bool(enable_gui)
+        self.terminate_on_goal = bool(terminate_on_goal)
         self.render_mode = "human"
+        self._goal = None               # ndarray once set_goal() ran
+        self._dist_before = np.nan      # goal distance at the end of the previous step (NaN: not measured yet)
+        self._ever_reset = False
+        self.env = self.build_env()
+        self.observation_space, self.action_space = self.get_observation_space(), self.get_action_space()
+        self.init_space, self.goal_space = self.get_init_space(), self.get_goal_space()
 
-    # -- the nine methods a new robot implements (reference README.md:82-92, wrapper.py:39-93) --
+    # ---- what a robot implements ---------------------------------------------------------------------------
     @abstractmethod
-    def _set_goal(self, goal): ...
+    def build_env(self):
+        """Create the simulator object kept in `self.env` (needs seed/reset/step/render/close)."""
+
     @abstractmethod
-    def build_env(self): ...
+    def _set_goal(self, goal):
+        """Move the goal marker inside the simulator."""
+
     @abstractmethod
-    def get_pos(self): ...
+    def get_pos(self):
+        """Robot position in goal coordinates."""
+
     @abstractmethod
-    def set_pos(self, pos): ...
+    def set_pos(self, pos):
+        """Teleport the robot."""
+
     @abstractmethod
-    def get_obs(self) -> np.ndarray: ...
+    def get_obs(self) -> np.ndarray:
+        """Current observation vector."""
+
     @abstractmethod
     def get_observation_space(self) -> Box: ...
+
     @abstractmethod
     def get_action_space(self) -> Box: ...
+
     @abstractmethod
     def get_init_space(self) -> Box: ...
+
     @abstractmethod
     def get_goal_space(self) -> Box: ...
 
-    def seed(self, seed=None):
-        self.env.seed(seed)
-        self.init_space.seed(seed)
-        self.goal_space.seed(seed + 1 if seed is not None else None)  # avoid init on goal
-        self.action_space.seed(seed)
-        self.observation_space.seed(seed)
-
-    def toggle_render_mode(self):
-        self.render_mode = "human" if self.render_mode == "rgb_array" else "rgb_array"
+    # ---- goal bookkeeping ----------------------------------------------------------------------------------
+    def _distance_now(self) -> float:
+        return float(rules.goal_distance(self.get_goal(), self.get_pos()))
 
     def set_goal(self, goal):
         self._set_goal(goal)
         self._goal = np.array(goal)
+        if not np.isnan(self._dist_before):  # progress is always measured against the goal in force
+            self._dist_before = self._distance_now()
+
+    def get_goal(self) -> np.ndarray:
+        return self._goal if self._goal is not None else np.array([])
 
     def reset_random_goal(self):
         self.set_goal(self.goal_space.sample())
 
-    def get_goal(self) -> np.ndarray:
-        return np.array([]) if self._goal is None else self._goal
+    def reached(self, reach_radius: float | None = None) -> bool:
+        radius = self.reach_radius if reach_radius is None else reach_radius
+        return bool(rules.inside_goal(self._distance_now(), radius))
 
     def reward_fn(self) -> float:
-        """progress towards the goal since the previous step, +5 when inside the reach radius"""
-        cur = self.get_pos()
-        if self._goal is None or self._prev_pos is None:
-            reward = 0.0
-        else:
-            reward = float(np.linalg.norm(self._goal - self._prev_pos) - np.linalg.norm(self._goal - cur))
-        self._prev_pos = cur
-        if self.reached():
-            reward += 5.0
-        return reward
+        if self._goal is None:
+            return 0.0
+        dist = self._distance_now()
+        reward, _ = rules.progress_reward(self._dist_before, dist, self.reach_radius, self.goal_bonus)
+        self._dist_before = dist
+        return float(reward)
+
+    # ---- gymnasium API -------------------------------------------------------------------------------------
+    def seed(self, seed=None):
+        """Simulator and the four spaces; the goal space is offset by one so that the first start pose and the first
+        goal of an environment are not the same draw."""
+        self.env.seed(seed)
+        for space, offset in ((self.init_space, 0), (self.goal_space, 1), (self.action_space, 0),
+                              (self.observation_space, 0)):
+            space.seed(None if seed is None else seed + offset)
 
     def step(self, action):
-        obs, _, _, truncated, info = self.env.step(action)  # inner reward/termination are discarded
+        # the simulator's own reward / termination are not the task's: only its observation, truncation and info count
+        obs, _, _, truncated, info = self.env.step(action)
         reward = self.reward_fn()
-        terminated = self.terminate_on_goal and self.reached()
+        terminated = bool(rules.episode_over(self.reached(), self.terminate_on_goal))
         return obs, reward, terminated, truncated, info
 
     def reset(self, init_pos=None, *args, **kwargs):
-        if "seed" in kwargs:
-            seed = kwargs.pop("seed")
-            if seed is not None:
-                self.seed(seed)
-        if self._first_reset or not self.reached():
-            # lazy reset: a robot that has just reached its goal keeps its pose and only gets a new goal
+        seed = kwargs.pop("seed", None)
+        if seed is not None:
+            self.seed(seed)
+        if rules.must_respawn(self._ever_reset, self._ever_reset and self.reached()):
             self.env.reset()
             self.set_pos(self.init_space.sample())
         if init_pos is not None:
             self.set_pos(init_pos)
+        self._ever_reset = True
         self.reset_random_goal()
-        self._prev_pos = self.get_pos()
-        self._first_reset = False
+        self._dist_before = self._distance_now()
         return self.get_obs(), {}
 
-    def reached(self, reach_radius: float = 0.3) -> bool:
-        return bool(np.linalg.norm(self.get_pos() - self.get_goal()) < reach_radius)
-
+    # ---- odds and ends of the surface ----------------------------------------------------------------------
     def reset_init_space(self, init_space: Box):
         self.init_space = init_space
 
     def reset_goal_space(self, goal_space: Box):
         self.goal_space = goal_space
+
+    def toggle_render_mode(self):
+        self.render_mode = {"human": "rgb_array", "rgb_array": "human"}[self.render_mode]
 
     def render(self):
         return self.env.render(mode=self.render_mode)
@@ -235,9 +263,10 @@ class DoggoEnv(KinematicGoalEnv):
 class DroneEnv(KinematicGoalEnv):
     robot = "drone"
 
-    def reward_fn(self) -> float:  # reference wrapper.py:491-496: extra +10 on reach
-        r = super().reward_fn()
-        return r + 10.0 if self.reached() else r
+    extra_goal_bonus = 10.0  # the drone moves fast: a larger arrival bonus (reference wrapper.py:491-496)
+
+    def reward_fn(self) -> float:
+        return super().reward_fn() + (self.extra_goal_bonus if self.reached() else 0.0)
 
 
 class Turtlebot3Env(KinematicGoalEnv):

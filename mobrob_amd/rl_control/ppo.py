@@ -24,7 +24,8 @@ from ..checkpoint import load_zip, save_zip
 from ..engine import PPOEngine
 from ..envs.vec_env import DeviceGoalVecEnv, DeviceSyntheticVecEnv, HostVecEnv, SyntheticVecEnv, make_vec_env
 from ..envs.native_env import NativeGoalVecEnv
-from ..envs.wrapper import get_env
+from ..envs.shm_vec_env import ShmVecEnv
+from ..envs.wrapper import ROBOT_DIMS, get_env
 from ..utils import DATA_DIR
 from .init import orthogonal_policy_init
 
@@ -33,8 +34,8 @@ try:
 except ImportError:
     tensorboard = None
 
-DummyVecEnv = HostVecEnv  # both reference choices (ppo.py:30-33) map to the in-process batched VecEnv
-SubprocVecEnv = HostVecEnv
+DummyVecEnv = HostVecEnv   # reference ppo.py:32-33: environments stepped in the learner process
+SubprocVecEnv = ShmVecEnv  # reference ppo.py:30-31: environments stepped by worker processes on the host cores
 
 
 # --------------------------------------------------------------------------------------------------
@@ -248,8 +249,12 @@ class PPO:
     def set_env(self, env):
         if (env.num_envs, env.obs_dim, env.act_dim) != (self.n_envs, self.obs_dim, self.act_dim):
             raise ValueError("environment does not match the model's (n_envs, obs_dim, act_dim)")
+        if getattr(self.env, "_registered_with", None) is self.engine and env is not self.env:
+            self.env._registered_with = None
+            self.engine.unregister_host(self.env.shared_block()[0])
         self.env = env
         self._last_obs = None
+        self._host_bufs = None  # staging is bound to an environment (use_buffers / shared block): rebuilt in learn()
 
     # ---------------------------------------------------------------------------------------------
     def predict(self, observation, state=None, episode_start=None, deterministic: bool = False):
@@ -303,8 +308,16 @@ class PPO:
         return True
 
     def _setup_host_buffers(self):
-        """Pinned staging shared by the env and the engine: the env writes step results where the DMA reads them."""
+        """Pinned staging shared by the env and the engine: the env writes step results where the GPU reads them.
+        `ShmVecEnv` owns its block (worker processes have it mapped): the engine pins and maps it in place;
+        environments with `use_buffers` are pointed at fresh pinned arrays instead."""
         e, N = self.engine, self.n_envs
+        if hasattr(self.env, "shared_block"):
+            if getattr(self.env, "_registered_with", None) is not e:
+                e.register_host(*self.env.shared_block())
+                self.env._registered_with = e
+            self._host_bufs = self.env.buffers()
+            return
         self._host_bufs = dict(obs=e.pinned((N, self.obs_dim)), clip=e.pinned((N, self.act_dim)), rew=e.pinned((N,)),
                                done=e.pinned((N,), np.uint8), trunc=e.pinned((N,), np.uint8),
                                term=e.pinned((N, self.obs_dim)))
@@ -354,7 +367,9 @@ class PPO:
             e.finish_rollout(b["obs"], b["done"])
         st = env.episode_stats(reset=True)
         self.device_episode_stats = st
-        if st["episodes"] > 0:
+        if hasattr(env, "pop_episodes"):  # real Monitor records {r, l, t}, in completion order
+            self.ep_info_buffer.extend(env.pop_episodes())
+        elif st["episodes"] > 0:
             self.ep_info_buffer.extend([{"r": st["ep_rew_mean"], "l": st["ep_len_mean"], "t": 0.0}]
                                        * min(st["episodes"], self.ep_info_buffer.maxlen or 100))
         callback.on_rollout_end()
@@ -393,9 +408,13 @@ class PPO:
             total_timesteps += self.num_timesteps
         self._total_timesteps, self._num_timesteps_at_start = total_timesteps, self.num_timesteps
         host_env = not isinstance(self.env, (DeviceSyntheticVecEnv, DeviceGoalVecEnv))
-        if host_env and hasattr(self.env, "step_arrays") and getattr(self, "_host_bufs", None) is None:
+        fresh_staging = host_env and hasattr(self.env, "step_arrays") and getattr(self, "_host_bufs", None) is None
+        if fresh_staging:
             self._setup_host_buffers()
-        if host_env and (reset_num_timesteps or self._last_obs is None):
+        # an array-protocol env reads its first observations from the staging: a `_last_obs` restored from a checkpoint
+        # (PPO.load(force_reset=False)) describes environments that no longer exist, so new staging always starts with
+        # a reset
+        if host_env and (reset_num_timesteps or self._last_obs is None or fresh_staging):
             self._last_obs = self.env.reset()
             self._last_episode_starts = np.ones(self.n_envs, bool)
             self.engine.write("episode_start_state", np.ones(self.n_envs, np.float32))
@@ -521,8 +540,9 @@ class PPO:
 class PPOCtrl:
     """Same constructor, `from_config`, `learn`, `save_model` and `.ppo` attribute as the reference class
     (src/mobrob/rl_control/ppo.py:14-77).  `vec_env_type` accepts the reference values "subproc" and "dummy"
-    (ValueError otherwise, ppo.py:35) -- both run the in-process batched VecEnv -- plus two build extensions:
-    "synthetic" (host NumPy env source), "native" (the goal task stepped by the multi-threaded C host environment,
+    (ValueError otherwise, ppo.py:35): "subproc" steps the environments in worker processes on all host cores
+    (`ShmVecEnv`: shared GPU-visible block instead of pipes), "dummy" in the learner process (`HostVecEnv`) -- plus
+    the build's extensions: "synthetic" (host NumPy env source), "native" (the goal task stepped by the multi-threaded C host environment,
     csrc/host_env.c), "device" (device-resident synthetic source) and "device_goal" (the goal task stepped on the GPU)."""
 
     def __init__(self, ppo_kwargs: dict, env_name: str, time_limit: int, n_env: int, vec_env_type: str = "dummy",
@@ -535,10 +555,12 @@ class PPOCtrl:
         _, rank, _ = distributed_context()
         env_seed = seed + 1000 * rank  # data-parallel ranks own different environments (the model seed stays shared)
         if vec_env_type in ("subproc", "dummy"):
+            if env_name not in ROBOT_DIMS:
+                raise ValueError(f"Env {env_name} not found")  # what get_env would raise inside a worker
             vec_env = make_vec_env(get_env, n_envs=n_env,
                                    env_kwargs={"env_name": env_name, "enable_gui": enable_gui,
                                                "terminate_on_goal": True, "time_limit": time_limit},
-                                   vec_env_cls=HostVecEnv, seed=env_seed)
+                                   vec_env_cls=SubprocVecEnv if vec_env_type == "subproc" else DummyVecEnv, seed=env_seed)
         elif vec_env_type == "synthetic":
             vec_env = SyntheticVecEnv.for_robot(env_name, n_env, time_limit, env_seed)
         elif vec_env_type == "device":
