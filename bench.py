@@ -88,7 +88,9 @@ def _oracle_throughput(w, budget_s, threads=None):
             break
     if limiter is not None:
         limiter.restore_original_limits()
-    return {"value": done_steps / el, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
+    from mobrob_amd.envs.shm_vec_env import usable_cores
+    return {"value": done_steps / el, "unit": "env-steps/s", "cores": int(min(cores, usable_cores())), "kind": "port",
+            "threads": int(cores), "cpu_quota_cores": usable_cores(),
             "sample": f"{reps} x (rollout {Ts} steps x {N} envs + {h.n_epochs} epochs, minibatch {w['B']}) "
                       f"= {done_steps} env-steps of the NumPy oracle in {el:.1f} s"}
 

@@ -6,7 +6,7 @@ This is what `vec_env_type: subproc` selects -- the reference's `SubprocVecEnv`
 thousands of environments next to a GPU learner:
 
   * SB3 starts ONE process per environment and moves every observation through a pipe as a pickled array.  Here W
-    workers (default: one per host core) each own n/W environment instances, and observations, rewards, done /
+    workers (default: one per USABLE host core: affinity mask and cgroup CPU quota respected) each own n/W environment instances, and observations, rewards, done /
     truncated flags and terminal observations never travel through a pipe: every worker writes its rows into one
     POSIX shared-memory block.  The learner process registers that block with the GPU once
     (`mobrob_ppo_host_register` -> hipHostRegister), so the rollout kernels read observations and write clipped
@@ -63,6 +63,29 @@ def _layout(n, d, a, n_workers):
 def _views(mm, layout):
     return {k: np.frombuffer(mm, dtype=dt, count=int(np.prod(shape)), offset=off).reshape(shape)
             for k, (off, shape, dt) in layout.items()}
+
+
+def usable_cores():
+    """Host cores this process may actually use: the smallest of the processor count, the affinity mask and the
+    cgroup CPU quota (containers often show all 256 hardware threads of the node and grant 16 of them)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:                                                                      # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def owned_rows(worker, n_workers, n, block):
@@ -177,8 +200,7 @@ class ShmVecEnv(VecEnvBase):
         self.num_envs = n = len(env_fns)
         if n < 1:
             raise ValueError("ShmVecEnv needs at least one environment")
-        cores = os.cpu_count() or 1
-        self.n_workers = W = max(1, min(n, int(n_workers or cores)))
+        self.n_workers = W = max(1, min(n, int(n_workers or os.environ.get("MOBROB_ENV_WORKERS", 0) or usable_cores())))
         self.block = int(block) if block else max(1, n // (W * 8))
         self._rows = [owned_rows(w, W, n, self.block) for w in range(W)]
         ctx = mp.get_context(start_method)

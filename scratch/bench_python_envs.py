@@ -16,7 +16,7 @@ def main():
     n_envs = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     out = {"n_envs": n_envs, "n_steps": n_steps, "host_cores": os.cpu_count()}
-    for kind in ("dummy", "subproc"):
+    for kind in (("subproc",) if os.environ.get("MOBROB_ENV_WORKERS") else ("dummy", "subproc")):
         cfg = {"ppo_kwargs": {"policy": "MlpPolicy", "n_steps": n_steps, "batch_size": 65536, "n_epochs": 5, "gamma": 0.99,
                               "gae_lambda": 0.95, "ent_coef": 0.01, "clip_range": 0.2,
                               "policy_kwargs": {"net_arch": {"pi": [256, 256], "vf": [256, 256]}}},
@@ -35,7 +35,8 @@ def main():
                      "build_s": t_build, "workers": getattr(ppo.env, "n_workers", 1)}
         ppo.env.close()
         ppo.engine.close()
-    out["speedup"] = out["subproc"]["env_steps_per_s"] / out["dummy"]["env_steps_per_s"]
+    if "dummy" in out:
+        out["speedup"] = out["subproc"]["env_steps_per_s"] / out["dummy"]["env_steps_per_s"]
     print(json.dumps(out))
 
 
