@@ -224,6 +224,10 @@ typedef struct mobrob_episode_stats {
   int64_t goals;              /* episodes that ended inside the reach radius */
 } mobrob_episode_stats_t;
 int mobrob_ppo_episode_stats(mobrob_ppo_engine_t* e, mobrob_episode_stats_t* out, int32_t reset);
+/* The Monitor records SB3 keeps in `ep_info_buffer` (what `rollout/ep_rew_mean` averages and PPO.save stores):
+ * (return, length) of the episodes the device goal environment finished since the previous call, oldest first,
+ * newest `max_records` at most (the device keeps the last 128).  out = [max_records][2] floats; returns the count. */
+int mobrob_ppo_episode_records(mobrob_ppo_engine_t* e, float* out, int32_t max_records);
 
 /* ---- update: PPO.train (SB3 ppo/ppo.py) ----------------------------------------------------- */
 

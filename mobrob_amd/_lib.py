@@ -85,6 +85,7 @@ SYMBOLS = {
     "mobrob_ppo_collect_synthetic": (C.c_int, [_P, C.c_float, C.c_int32]),
     "mobrob_ppo_collect_goal_env": (C.c_int, [_P, C.POINTER(GoalEnv)]),
     "mobrob_ppo_episode_stats": (C.c_int, [_P, C.POINTER(EpisodeStats), C.c_int32]),
+    "mobrob_ppo_episode_records": (C.c_int, [_P, _F, C.c_int32]),
     "mobrob_ppo_train": (C.c_int, [_P, _I64, C.POINTER(TrainStats)]),
     "mobrob_ppo_train_enqueue": (C.c_int, [_P, _I64]),
     "mobrob_ppo_epoch_begin": (C.c_int, [_P, _I64]),

@@ -47,10 +47,11 @@ POLICY_KEYS = ["log_std",
 # ---------------------------------------------------------------------------------------------------
 # tiny pickle assembler (protocol 5, same opcodes as the reference blobs; payloads are bytearrays)
 # ---------------------------------------------------------------------------------------------------
-def _s(x: str) -> bytes:  # SHORT_BINUNICODE
+def _s(x: str) -> bytes:  # SHORT_BINUNICODE, BINUNICODE for 256 bytes and more
     b = x.encode()
-    assert len(b) < 256
-    return b"\x8c" + bytes([len(b)]) + b
+    if len(b) < 256:
+        return b"\x8c" + bytes([len(b)]) + b
+    return b"X" + struct.pack("<I", len(b)) + b
 
 
 def _glob(mod: str, name: str) -> bytes:  # STACK_GLOBAL
@@ -86,14 +87,26 @@ def pickle_ndarray(a) -> bytes:
     return _wrap(_ndarray(np.asarray(a)))
 
 
+def short_repr(x) -> str:
+    """gymnasium 0.28.1 `spaces.box._short_repr`: the scalar when every bound is the same number, else str(array)."""
+    x = np.asarray(x)
+    return str(np.min(x)) if x.size != 0 and np.min(x) == np.max(x) else str(x)
+
+
+def box_state(low, high, dtype=np.float32) -> "OrderedDict":
+    """The nine-key `__dict__` of a gymnasium 0.28.1 Box(low, high) (verified against the by-value pickles inside
+    /root/reference/data/policies/*.zip, tests/test_checkpoint.py)."""
+    low, high = np.asarray(low, dtype), np.asarray(high, dtype)
+    return OrderedDict([("dtype", np.dtype(dtype)), ("bounded_below", np.isfinite(low)), ("bounded_above", np.isfinite(high)),
+                        ("_shape", tuple(int(s) for s in low.shape)), ("low", low), ("high", high),
+                        ("low_repr", short_repr(low)), ("high_repr", short_repr(high)), ("_np_random", None)])
+
+
 def pickle_box(low, high, dtype=np.float32) -> bytes:
     """gymnasium.spaces.box.Box(low, high) by value: NEWOBJ + the 9-key state dict of gymnasium 0.28.1."""
     low = np.asarray(low, dtype)
     high = np.asarray(high, dtype)
-
-    def rep(x):
-        return str(float(x.flat[0])) if np.all(x == x.flat[0]) and np.isfinite(x.flat[0]) else \
-            (("-inf" if x.flat[0] < 0 else "inf") if np.all(x == x.flat[0]) else str(x))
+    rep = short_repr
 
     items = [(_s("dtype"), _dtype("f4", "<")),
              (_s("bounded_below"), _ndarray(np.isfinite(low))),
@@ -114,6 +127,43 @@ def _blob(type_repr: str, payload: bytes, **extra) -> dict:
     d = {":type:": type_repr, ":serialized:": base64.b64encode(payload).decode()}
     d.update(extra)
     return d
+
+
+def box_entry(low, high) -> dict:
+    """The JSON entry SB3's `data_to_json` writes for a Box: the by-value pickle plus str() of every state item."""
+    st = box_state(low, high)
+    extra = {k: (str(v) if isinstance(v, (np.ndarray, np.dtype)) else (list(v) if isinstance(v, tuple) else v))
+             for k, v in st.items()}
+    return _blob("<class 'gymnasium.spaces.box.Box'>", pickle_box(low, high), **extra)
+
+
+class _BoxStandIn:
+    """What a `gymnasium.spaces.box.Box` pickle is rebuilt into when gymnasium is absent: just its state."""
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+
+class _SpaceUnpickler(pickle.Unpickler):
+    """Restricted: only NumPy's array / dtype / random-generator reconstructors and the Box stand-in."""
+
+    def find_class(self, module, name):
+        if (module, name) == ("gymnasium.spaces.box", "Box"):
+            return _BoxStandIn
+        if module == "numpy" or module.startswith(("numpy.core", "numpy._core", "numpy.random")):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"{module}.{name} is not allowed in a space blob")
+
+
+def unpickle_box(entry) -> dict:
+    """A Box JSON entry (or raw pickle bytes) -> its state dict (low, high, dtype, _shape, bounded_*, *_repr)."""
+    raw = base64.b64decode(entry[":serialized:"]) if isinstance(entry, dict) else entry
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        obj = _SpaceUnpickler(io.BytesIO(raw)).load()
+    return dict(obj.__dict__)
 
 
 def _unblob(entry):
@@ -143,7 +193,13 @@ def load_zip(path):
                     except Exception:  # blobs that need gymnasium/SB3/py3.11 code objects are skipped, like SB3 does
                         data[k] = None
                 elif k in ("observation_space", "action_space"):
-                    data[k] = {"shape": tuple(v.get("_shape", ())), "low_repr": v.get("low_repr"), "high_repr": v.get("high_repr")}
+                    try:
+                        st = unpickle_box(v)
+                        data[k] = {"shape": tuple(st["_shape"]), "low": np.asarray(st["low"]), "high": np.asarray(st["high"]),
+                                   "dtype": np.dtype(st["dtype"]), "low_repr": st["low_repr"], "high_repr": st["high_repr"]}
+                    except Exception:  # noqa: BLE001 - unknown blob layout: fall back to the JSON side
+                        data[k] = {"shape": tuple(v.get("_shape", ())), "low": None, "high": None,
+                                   "low_repr": v.get("low_repr"), "high_repr": v.get("high_repr")}
                 else:
                     data[k] = None
             else:
@@ -170,20 +226,21 @@ def load_zip(path):
 # ---------------------------------------------------------------------------------------------------
 def save_zip(path, *, params, optimizer, hyper, obs_dim, act_dim, net_arch=None, counters=None, last_obs=None,
              last_episode_starts=None, ep_info_buffer=None, action_low=-1.0, action_high=1.0, verbose=1, seed=0,
-             tensorboard_log=None):
+             tensorboard_log=None, obs_low=None, obs_high=None):
     """Write an SB3-2.0.0-layout zip.  `hyper` carries n_steps, batch_size, n_epochs, gamma, gae_lambda,
     ent_coef, vf_coef, max_grad_norm, learning_rate, clip_range, n_envs; `optimizer` = dict(exp_avg, exp_avg_sq,
-    step, lr, betas, eps) with per-key arrays."""
+    step, lr, betas, eps) with per-key arrays.  obs_low / obs_high: the bounds of `env.observation_space` (what
+    `PPO.save` stores and `PPO.load(path, env=...)` checks with `check_for_correct_spaces`); default unbounded."""
     import torch
     if not str(path).endswith(".zip"):
         path = str(path) + ".zip"
     counters = dict(counters or {})
     keys = list(params.keys())
     assert keys == POLICY_KEYS, "parameters must be in SB3 registration order"
-    obs_low = np.full((obs_dim,), -np.inf, np.float32)
-    obs_high = np.full((obs_dim,), np.inf, np.float32)
-    act_low = np.full((act_dim,), action_low, np.float32)
-    act_high = np.full((act_dim,), action_high, np.float32)
+    obs_low = np.broadcast_to(np.asarray(-np.inf if obs_low is None else obs_low, np.float32), (obs_dim,)).copy()
+    obs_high = np.broadcast_to(np.asarray(np.inf if obs_high is None else obs_high, np.float32), (obs_dim,)).copy()
+    act_low = np.broadcast_to(np.asarray(action_low, np.float32), (act_dim,)).copy()
+    act_high = np.broadcast_to(np.asarray(action_high, np.float32), (act_dim,)).copy()
     n_envs = int(hyper["n_envs"])
     if last_obs is None:
         last_obs = np.zeros((n_envs, obs_dim), np.float32)
@@ -221,11 +278,8 @@ def save_zip(path, *, params, optimizer, hyper, obs_dim, act_dim, net_arch=None,
     data["clip_range_vf"] = None
     data["normalize_advantage"] = bool(hyper.get("normalize_advantage", True))
     data["target_kl"] = None
-    data["observation_space"] = _blob("<class 'gymnasium.spaces.box.Box'>", pickle_box(obs_low, obs_high),
-                                      dtype="float32", _shape=[obs_dim], low_repr="-inf", high_repr="inf", _np_random=None)
-    data["action_space"] = _blob("<class 'gymnasium.spaces.box.Box'>", pickle_box(act_low, act_high), dtype="float32",
-                                 _shape=[act_dim], low_repr=str(float(action_low)), high_repr=str(float(action_high)),
-                                 _np_random=None)
+    data["observation_space"] = box_entry(obs_low, obs_high)
+    data["action_space"] = box_entry(act_low, act_high)
     data["n_envs"] = n_envs
 
     sd = OrderedDict((k, torch.from_numpy(np.ascontiguousarray(params[k], dtype=np.float32)).clone()) for k in keys)

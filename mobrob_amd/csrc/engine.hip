@@ -100,7 +100,8 @@ struct mobrob_ppo_engine {
   std::vector<hipEvent_t> ev_chunks;      // one event per rollout chunk (an event is recorded once per capture)
   hipEvent_t ev_vdone = nullptr;
   float* gstate[2] = {nullptr, nullptr};  // goal env state, double buffered [N][kGoalStateFloats]
-  double* ep_stats = nullptr;             // [4] episode statistics of the goal env
+  double* ep_stats = nullptr;             // [4] episode statistics of the goal env + the Monitor ring (kernels_env.h)
+  uint64_t ep_ring_read = 0;              // records already handed out by mobrob_ppo_episode_records
   uint32_t draw_counter = 0;  // Philox draw index for eps
   // pipelined host-env rollout (act_part / wait_part / store_part): per-part step indices and completion events
   int nparts = 0;
@@ -620,7 +621,7 @@ int engine_alloc(mobrob_ppo_engine* e) {
   CHK(dalloc(e, &e->dz2v, Bl * e->G2)); CHK(dalloc(e, &e->dz1v, Bl * e->G1));
   CHK(dalloc(e, &e->pred_obs, R * Dp)); CHK(dalloc(e, &e->pred_act, R * A));
   CHK(dalloc(e, &e->gstate[0], N * kGoalStateFloats)); CHK(dalloc(e, &e->gstate[1], N * kGoalStateFloats));
-  CHK(dalloc(e, &e->ep_stats, 4));
+  CHK(dalloc(e, &e->ep_stats, kEpStatsDoubles));
   CHK(dalloc(e, &e->chunks_dev, e->chunk_table.size()));
   CHK(dalloc(e, &e->chunk_partial, e->chunk_table.size()));
   CHK(fused_init(e));
@@ -1234,7 +1235,8 @@ int collect_device(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& s
     } else {
       hipLaunchKernelGGL(k_goal_env_reset, dim3(cdiv(N * per, 256)), dim3(256), 0, e->stream, env_seed_of(e), N, e->D, Dp,
                          sp.goal, e->gstate[0], last);
-      HIPC(hipMemsetAsync(e->ep_stats, 0, 4 * sizeof(double), e->stream));
+      HIPC(hipMemsetAsync(e->ep_stats, 0, kEpStatsDoubles * sizeof(double), e->stream));
+      e->ep_ring_read = 0;
     }
     std::vector<float> ones(N, 1.0f);  // a fresh env starts every episode: `_last_episode_starts` all True
     HIPC(hipMemcpyAsync(e->prev_dones, ones.data(), (size_t)N * 4, hipMemcpyHostToDevice, e->stream));
@@ -1321,6 +1323,24 @@ int mobrob_ppo_episode_stats(mobrob_ppo_engine_t* e, mobrob_episode_stats_t* out
   HIPC(hipStreamSynchronize(e->stream));
   out->episodes = (int64_t)h[0]; out->return_sum = h[1]; out->length_sum = h[2]; out->goals = (int64_t)h[3];
   return MOBROB_OK;
+}
+
+int mobrob_ppo_episode_records(mobrob_ppo_engine_t* e, float* out, int32_t max_records) {
+  if (!e || !out || max_records < 0) return fail(MOBROB_ERR_INVALID, "episode_records: bad argument");
+  std::vector<double> h(kEpStatsDoubles);
+  HIPC(hipMemcpyAsync(h.data(), e->ep_stats, h.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPC(hipStreamSynchronize(e->stream));
+  const uint64_t written = (uint64_t)h[4];
+  uint64_t first = e->ep_ring_read;
+  if (written - first > (uint64_t)kEpRing) first = written - kEpRing;           // older ones were overwritten
+  if (written - first > (uint64_t)max_records) first = written - max_records;   // the caller wants the newest
+  int n = 0;
+  for (uint64_t k = first; k < written; ++k, ++n) {
+    out[2 * n] = (float)h[5 + 2 * (k % kEpRing)];
+    out[2 * n + 1] = (float)h[6 + 2 * (k % kEpRing)];
+  }
+  e->ep_ring_read = written;
+  return n;
 }
 
 // ---- update ----------------------------------------------------------------------------------------

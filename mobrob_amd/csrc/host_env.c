@@ -35,6 +35,8 @@ typedef struct mobrob_hostenv {
                       lose more to wake-up and barrier than they gain -- measured on the 256-core GPU host) */
   /* Monitor statistics since the last read */
   int64_t episodes, goals;
+  int64_t ring_written, ring_read;   /* Monitor ring: (return, length) of the last EP_RING finished episodes */
+  double ring[2 * 128];
   double ret_sum, len_sum;
 } mobrob_hostenv;
 
@@ -219,6 +221,13 @@ int32_t mobrob_hostenv_step_range(mobrob_hostenv* e, int32_t i0, int32_t i1, con
         ntrunc += 1;
       }
       episodes += 1; goals += reached; ret_sum += s->ep_ret; len_sum += s->ep_len;
+      {
+        int64_t k;
+#pragma omp atomic capture
+        k = e->ring_written++;
+        e->ring[2 * (k % 128)] = s->ep_ret;
+        e->ring[2 * (k % 128) + 1] = (double)s->ep_len;
+      }
       reset_env(e, s, reached);
     }
     write_obs(e, s, o);
@@ -239,6 +248,22 @@ int32_t mobrob_hostenv_step(mobrob_hostenv* e, const float* actions, float* obs,
 void mobrob_hostenv_episode_stats(mobrob_hostenv* e, double* out, int32_t reset) {
   out[0] = (double)e->episodes; out[1] = (double)e->goals; out[2] = e->ret_sum; out[3] = e->len_sum;
   if (reset) { e->episodes = e->goals = 0; e->ret_sum = e->len_sum = 0.0; }
+}
+
+/* (return, length) of the episodes finished since the previous call, oldest first, the newest `max_records` at most
+ * (the last 128 are kept); returns the count.  Within one step the order of simultaneous finishes is the order
+ * the threads got to them. */
+int32_t mobrob_hostenv_episode_records(mobrob_hostenv* e, double* out, int32_t max_records) {
+  int64_t first = e->ring_read;
+  if (e->ring_written - first > 128) first = e->ring_written - 128;
+  if (e->ring_written - first > max_records) first = e->ring_written - max_records;
+  int32_t n = 0;
+  for (int64_t k = first; k < e->ring_written; ++k, ++n) {
+    out[2 * n] = e->ring[2 * (k % 128)];
+    out[2 * n + 1] = e->ring[2 * (k % 128) + 1];
+  }
+  e->ring_read = e->ring_written;
+  return n;
 }
 
 void mobrob_hostenv_set_threads(mobrob_hostenv* e, int32_t t) { e->threads = t < 1 ? 1 : t; }

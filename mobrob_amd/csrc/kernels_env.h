@@ -28,6 +28,16 @@ struct GoalEnvParams {
   float mix[3][32];          // velocity command = mix . clip(action)
 };
 
+// Monitor ring: the last kEpRing finished episodes (return, length) in completion order.  ep_stats[4] counts the
+// records ever written (a double, like its neighbours: one atomic per finished episode), slot = count mod kEpRing.
+constexpr int kEpRing = 128;
+constexpr int kEpStatsDoubles = 5 + 2 * kEpRing;
+__device__ __forceinline__ void ep_ring_push(double* ep_stats, float ep_ret, float ep_len) {
+  const unsigned slot = (unsigned)((unsigned long long)atomicAdd(&ep_stats[4], 1.0) % (unsigned)kEpRing);
+  ep_stats[5 + 2 * slot] = (double)ep_ret;
+  ep_stats[6 + 2 * slot] = (double)ep_len;
+}
+
 struct GoalEnvArgs {
   uint64_t seed; uint32_t step_rel; const uint32_t* step_base;
   int N, D, Dp, A;
@@ -36,7 +46,8 @@ struct GoalEnvArgs {
   const float* st_in; float* st_out;   // [N][kGoalStateFloats]
   float* obs_next; float* term_obs;
   const float* prev_dones; float* next_dones; uint8_t* trunc; float* rew_out; float* es_out;
-  double* ep_stats;                    // [4] finished episodes, sum of returns, sum of lengths, goals reached
+  double* ep_stats;                    // [4] finished episodes, sum of returns, sum of lengths, goals reached;
+                                       // then the Monitor ring: [4] records written so far, [5 + 2k] return / length
 };
 
 struct GoalState {
@@ -215,6 +226,7 @@ __global__ __launch_bounds__(256) void k_goal_env_step_store(GoalEnvArgs a, Boot
         atomicAdd(&a.ep_stats[1], (double)ep_ret);
         atomicAdd(&a.ep_stats[2], (double)ep_len);
         if (o.reached) atomicAdd(&a.ep_stats[3], 1.0);
+        ep_ring_push(a.ep_stats, ep_ret, (float)ep_len);
       }
     }
   }

@@ -277,6 +277,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
         goal_store(S, g);
         if (done) {  // Monitor statistics: accumulated per thread, flushed once per launch (see the kernel end)
           es_n += 1.0; es_ret += (double)ep_ret; es_len += (double)ep_len_fin; es_goal += reached ? 1.0 : 0.0;
+          ep_ring_push(a.ep_stats, ep_ret, (float)ep_len_fin);
         }
       }
       if (tr) {  // reward is written after the bootstrap below
@@ -611,6 +612,7 @@ __global__ __launch_bounds__(LayRo64<DP>::NWV * 64, 1) void k_rollout64_persiste
         goal_store(S, g);
         if (done) {  // Monitor statistics: accumulated per thread, flushed once per launch (see the kernel end)
           es_n += 1.0; es_ret += (double)ep_ret; es_len += (double)ep_len_fin; es_goal += reached ? 1.0 : 0.0;
+          ep_ring_push(a.ep_stats, ep_ret, (float)ep_len_fin);
         }
       }
       if (!tr) a.rewards[so] = reward;

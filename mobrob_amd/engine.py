@@ -295,6 +295,13 @@ class PPOEngine:
         return {"episodes": n, "goals": int(st.goals), "ep_rew_mean": st.return_sum / n if n else float("nan"),
                 "ep_len_mean": st.length_sum / n if n else float("nan")}
 
+    def episode_records(self, max_records=100):
+        """Monitor records [{r, l}] of the episodes the device goal environment finished since the last call
+        (oldest first, the newest `max_records` at most)."""
+        out = np.zeros((int(max_records), 2), F32)
+        n = check(self.lib.mobrob_ppo_episode_records(self._h, _fp(out), int(max_records)))
+        return [{"r": float(r), "l": int(l)} for r, l in out[:n]]
+
     def compute_gae(self):
         check(self.lib.mobrob_ppo_compute_gae(self._h))
 

@@ -14,7 +14,7 @@ import time
 import numpy as np
 
 from .vec_env import VecEnvBase
-from .wrapper import ROBOT_DIMS, KinematicSim
+from .wrapper import ROBOT_DIMS, KinematicSim, observation_space_of
 
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libmobrob_hostenv.so")
@@ -36,6 +36,8 @@ def _load():
         lib.mobrob_hostenv_step_range.restype = C.c_int32
         lib.mobrob_hostenv_step_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32, F, F, F, U8, U8, F]
         lib.mobrob_hostenv_episode_stats.argtypes = [C.c_void_p, D, C.c_int32]
+        lib.mobrob_hostenv_episode_records.restype = C.c_int32
+        lib.mobrob_hostenv_episode_records.argtypes = [C.c_void_p, D, C.c_int32]
         lib.mobrob_hostenv_get_state.argtypes = [C.c_void_p, C.c_int32, D]
         lib.mobrob_hostenv_set_threads.argtypes = [C.c_void_p, C.c_int32]
         lib.mobrob_hostenv_get_threads.restype = C.c_int32
@@ -81,7 +83,9 @@ class NativeGoalVecEnv(VecEnvBase):
         if env_name not in ROBOT_DIMS:
             raise ValueError(f"Env {env_name} not found")
         d, a, p = ROBOT_DIMS[env_name]
-        return cls(n_envs, d, a, p, time_limit, terminate_on_goal, 10.0 if env_name == "drone" else 0.0, seed)
+        env = cls(n_envs, d, a, p, time_limit, terminate_on_goal, 10.0 if env_name == "drone" else 0.0, seed)
+        env.observation_space = observation_space_of(env_name)
+        return env
 
     def use_buffers(self, obs=None, rewards=None, dones=None, truncated=None, terminal_obs=None):
         """Write step results into caller-owned arrays (e.g. `engine.pinned(...)` staging: no extra copy before DMA)."""
@@ -144,6 +148,13 @@ class NativeGoalVecEnv(VecEnvBase):
         n = int(out[0])
         return {"episodes": n, "goals": int(out[1]), "ep_rew_mean": out[2] / n if n else float("nan"),
                 "ep_len_mean": out[3] / n if n else float("nan")}
+
+    def pop_episodes(self, max_records=100):
+        """Monitor records {r, l, t} of the episodes finished since the last call (oldest first, newest 100 at most)."""
+        out = np.zeros((int(max_records), 2), np.float64)
+        n = self.lib.mobrob_hostenv_episode_records(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), int(max_records))
+        now = round(time.time() - self._t0, 6)
+        return [{"r": float(r), "l": int(l), "t": now} for r, l in out[:n]]
 
     @property
     def threads(self):

@@ -22,7 +22,7 @@ import time
 
 import numpy as np
 
-from .wrapper import MEAN_EPISODE_LEN, ROBOT_DIMS, KinematicSim
+from .wrapper import MEAN_EPISODE_LEN, ROBOT_DIMS, KinematicSim, observation_space_of
 
 
 class VecEnvBase:
@@ -31,6 +31,7 @@ class VecEnvBase:
     act_dim: int
     action_low = -1.0
     action_high = 1.0
+    observation_space = None  # a Box when the robot is known (bounds go into the checkpoint)
 
     def close(self):
         pass
@@ -114,7 +115,9 @@ class SyntheticVecEnv(VecEnvBase):
         if env_name not in ROBOT_DIMS:
             raise ValueError(f"Env {env_name} not found")
         d, a, _ = ROBOT_DIMS[env_name]
-        return cls(n_envs, d, a, 1.0 / MEAN_EPISODE_LEN[env_name], time_limit, seed)
+        env = cls(n_envs, d, a, 1.0 / MEAN_EPISODE_LEN[env_name], time_limit, seed)
+        env.observation_space = observation_space_of(env_name)  # what PPO.save records for this robot
+        return env
 
     def seed(self, seed=None):
         self.rng = np.random.default_rng(seed)
@@ -159,7 +162,9 @@ class DeviceSyntheticVecEnv(VecEnvBase):
         if env_name not in ROBOT_DIMS:
             raise ValueError(f"Env {env_name} not found")
         d, a, _ = ROBOT_DIMS[env_name]
-        return cls(n_envs, d, a, 1.0 / MEAN_EPISODE_LEN[env_name], time_limit, seed)
+        env = cls(n_envs, d, a, 1.0 / MEAN_EPISODE_LEN[env_name], time_limit, seed)
+        env.observation_space = observation_space_of(env_name)  # what PPO.save records for this robot
+        return env
 
     def seed(self, seed=None):
         self._seed = seed
@@ -187,7 +192,9 @@ class DeviceGoalVecEnv(VecEnvBase):
         if env_name not in ROBOT_DIMS:
             raise ValueError(f"Env {env_name} not found")
         d, a, p = ROBOT_DIMS[env_name]
-        return cls(n_envs, d, a, p, time_limit, terminate_on_goal, 10.0 if env_name == "drone" else 0.0, seed)
+        env = cls(n_envs, d, a, p, time_limit, terminate_on_goal, 10.0 if env_name == "drone" else 0.0, seed)
+        env.observation_space = observation_space_of(env_name)
+        return env
 
     def collect(self, engine):
         engine.collect_goal_env(self.pos_dim, self.mix, self.time_limit, self.terminate_on_goal, dt=self.dt,

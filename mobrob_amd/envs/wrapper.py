@@ -25,6 +25,26 @@ from .spaces import Box
 # :330-346 (doggo 58/12), :417-489 (drone 12/18), :509-546 (turtlebot3 43/2)
 ROBOT_DIMS = {"point": (14, 2, 2), "car": (26, 2, 2), "doggo": (58, 12, 2), "drone": (12, 18, 3),
               "turtlebot3": (43, 2, 2)}  # (obs_dim, act_dim, position_dim)
+# Finite observation bounds two robots declare (reference wrapper.py:423-468 drone: pose / Euler angles / velocities /
+# body rates; :515-529 turtlebot3: sin, cos, x, y scaled by sqrt 2, velocity limits 0.26 / 0.26 / 1.82, 36 lidar rays of
+# length 1).  The numbers are also inside the reference checkpoints' `observation_space` blobs, which
+# tests/test_checkpoint.py decodes and compares with these.  The MuJoCo robots are unbounded.
+_PI = float(np.float32(np.pi))
+OBS_BOUNDS = {
+    "drone": (np.array([-10, -10, -50] + [-_PI] * 3 + [-15] * 3 + [-0.2 * np.pi] * 3, np.float32),
+              np.array([10, 10, 5] + [_PI] * 3 + [15] * 3 + [0.2 * np.pi] * 3, np.float32)),
+    "turtlebot3": (-np.array([1, 1, 2 ** 0.5, 2 ** 0.5, 0.26, 0.26, 1.82] + [1.0] * 36, np.float32),
+                   np.array([1, 1, 2 ** 0.5, 2 ** 0.5, 0.26, 0.26, 1.82] + [1.0] * 36, np.float32)),
+}
+
+
+def observation_space_of(env_name: str) -> Box:
+    """`env.observation_space` of a robot without building the robot (vector layers that live on the GPU or in C)."""
+    d = ROBOT_DIMS[env_name][0]
+    low, high = OBS_BOUNDS.get(env_name, (np.full(d, -np.inf, np.float32), np.full(d, np.inf, np.float32)))
+    return Box(low, high, (d,), np.float32)
+
+
 # mean episode lengths recorded in the reference checkpoints (SURVEY.md §6) -> synthetic p_term
 MEAN_EPISODE_LEN = {"point": 119, "car": 91, "doggo": 107, "drone": 568, "turtlebot3": 131}
 
@@ -234,7 +254,7 @@ class KinematicGoalEnv(EnvWrapper):
         return self.env.obs()
 
     def get_observation_space(self):
-        return self.env.observation_space
+        return observation_space_of(self.robot)
 
     def get_action_space(self):
         return self.env.action_space

@@ -212,6 +212,10 @@ class PPO:
             self.n_envs, self.obs_dim, self.act_dim = _dims
         else:
             raise ValueError("PPO needs an environment (or load a checkpoint with PPO.load)")
+        # observation bounds travel with the model like SB3's `self.observation_space` (PPO.save writes them,
+        # PPO.load(path, env=...) of real SB3 checks them against the env): from the env, else from the checkpoint
+        sp = getattr(env, "observation_space", None)
+        self.obs_bounds = None if sp is None else (np.asarray(sp.low, np.float32), np.asarray(sp.high, np.float32))
         self.engine = None
         self.policy = None
         self.world_size, self.rank, self._backend = 1, 0, None
@@ -253,6 +257,9 @@ class PPO:
             self.env._registered_with = None
             self.engine.unregister_host(self.env.shared_block()[0])
         self.env = env
+        sp = getattr(env, "observation_space", None)
+        if sp is not None:
+            self.obs_bounds = (np.asarray(sp.low, np.float32), np.asarray(sp.high, np.float32))
         self._last_obs = None
         self._host_bufs = None  # staging is bound to an environment (use_buffers / shared block): rebuilt in learn()
 
@@ -271,9 +278,11 @@ class PPO:
                 env.collect(e)
                 st = e.episode_stats(reset=True)  # Monitor statistics of the episodes this rollout finished
                 self.device_episode_stats = st
-                if st["episodes"] > 0:  # the info buffer holds the rollout's means (per-episode values stay on the GPU)
-                    self.ep_info_buffer.extend([{"r": st["ep_rew_mean"], "l": st["ep_len_mean"], "t": 0.0}]
-                                               * min(st["episodes"], self.ep_info_buffer.maxlen or 100))
+                self._episode_num += st["episodes"]
+                # real Monitor records: the device keeps (return, length) of the last 128 finished episodes
+                now = round((time.time_ns() - (self.start_time or time.time_ns())) / 1e9, 6)
+                self.ep_info_buffer.extend({"r": r["r"], "l": r["l"], "t": now}
+                                           for r in e.episode_records(self.ep_info_buffer.maxlen or 100))
             else:
                 e.collect_synthetic(env.p_term, env.time_limit)
             for _ in range(self.n_steps):
@@ -367,11 +376,8 @@ class PPO:
             e.finish_rollout(b["obs"], b["done"])
         st = env.episode_stats(reset=True)
         self.device_episode_stats = st
-        if hasattr(env, "pop_episodes"):  # real Monitor records {r, l, t}, in completion order
-            self.ep_info_buffer.extend(env.pop_episodes())
-        elif st["episodes"] > 0:
-            self.ep_info_buffer.extend([{"r": st["ep_rew_mean"], "l": st["ep_len_mean"], "t": 0.0}]
-                                       * min(st["episodes"], self.ep_info_buffer.maxlen or 100))
+        self._episode_num += st["episodes"]
+        self.ep_info_buffer.extend(env.pop_episodes())  # real Monitor records {r, l, t}, in completion order
         callback.on_rollout_end()
         return True
 
@@ -494,7 +500,9 @@ class PPO:
                                _current_progress_remaining=self._current_progress_remaining),
                  last_obs=self._last_obs, last_episode_starts=self._last_episode_starts,
                  ep_info_buffer=list(self.ep_info_buffer), verbose=self.verbose, seed=self.seed,
-                 tensorboard_log=self.tensorboard_log)
+                 tensorboard_log=self.tensorboard_log,
+                 obs_low=None if self.obs_bounds is None else self.obs_bounds[0],
+                 obs_high=None if self.obs_bounds is None else self.obs_bounds[1])
 
     @classmethod
     def load(cls, path, env=None, device="auto", custom_objects=None, print_system_info=False, force_reset=True,
@@ -532,6 +540,9 @@ class PPO:
                 setattr(model, k, d[k])
         if d.get("ep_info_buffer") is not None:
             model.ep_info_buffer = deque(d["ep_info_buffer"], maxlen=model._stats_window_size)
+        sp = d.get("observation_space") or {}
+        if model.obs_bounds is None and sp.get("low") is not None:
+            model.obs_bounds = (np.asarray(sp["low"], np.float32), np.asarray(sp["high"], np.float32))
         if not force_reset and d.get("_last_obs") is not None:
             model._last_obs = np.asarray(d["_last_obs"], np.float32)
         return model

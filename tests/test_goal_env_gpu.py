@@ -181,3 +181,37 @@ def test_ppo_learns_with_the_native_host_env_through_pinned_staging():
     first, last = h[:4].sum(0), h[-4:].sum(0)
     assert last[1] / max(last[0], 1) > 0.9 and last[1] / max(last[0], 1) > first[1] / max(first[0], 1) + 0.3, (first, last)
     assert ppo.num_timesteps == 24 * 128 * 512
+
+
+def test_ep_info_buffer_holds_real_monitor_records_and_the_zip_keeps_the_robot_bounds(tmp_path):
+    """Device goal env and native host env: `ep_info_buffer` gets the (return, length) of individual finished episodes
+    (it used to get the rollout mean repeated), consistent with the aggregated counters; a saved drone model carries
+    the drone's finite observation bounds and PPO.load restores them."""
+    from mobrob_amd import checkpoint as ck
+    from mobrob_amd.envs.wrapper import observation_space_of
+    from mobrob_amd.rl_control.ppo import PPO, PPOCtrl
+    for kind in ("device_goal", "native"):
+        cfg = {"ppo_kwargs": {"policy": "MlpPolicy", "n_steps": 64, "batch_size": 1024, "n_epochs": 2},
+               "env_name": "drone", "time_limit": 30, "n_envs": 64, "vec_env_type": kind, "enable_gui": False, "seed": 3}
+        ctrl = PPOCtrl.from_config(cfg)
+        ppo = ctrl.ppo
+        ppo.learn(total_timesteps=64 * 64)
+        st = ppo.device_episode_stats
+        recs = list(ppo.ep_info_buffer)
+        assert st["episodes"] >= 64 * 2 and len(recs) == 100 and ppo._episode_num == st["episodes"]
+        lens = np.array([r["l"] for r in recs]); rets = np.array([r["r"] for r in recs])
+        assert lens.min() >= 1 and lens.max() <= 30 and np.all(lens == lens.astype(int))
+        assert len(set(np.round(rets, 5))) > 20, kind              # individual episodes, not one mean repeated
+        assert (lens == 30).any()                                   # most episodes of an untrained policy hit the time limit
+        assert abs(rets.mean() - st["ep_rew_mean"]) < 3 * rets.std() + 1e-3
+        path = str(tmp_path / f"drone-{kind}.zip")
+        ctrl.save_model(path)
+        c = ck.load_zip(path)
+        sp = observation_space_of("drone")
+        assert np.array_equal(c["data"]["observation_space"]["low"], sp.low) and np.array_equal(c["data"]["observation_space"]["high"], sp.high)
+        assert [e["l"] for e in c["data"]["ep_info_buffer"]] == [r["l"] for r in recs]
+        again = PPO.load(path)
+        assert np.array_equal(again.obs_bounds[0], sp.low)
+        again.save(str(tmp_path / "again.zip"))                     # no env attached: the bounds come from the checkpoint
+        assert np.array_equal(ck.load_zip(str(tmp_path / "again.zip"))["data"]["observation_space"]["high"], sp.high)
+        ppo.engine.close()
