@@ -430,11 +430,13 @@ def main():
                     rank=rank, world_size=world, fast_kernels=not args.generic)
     eng.set_params(init_params(D, A, H, seed=0))  # identical replicas on every rank
     backend = EngineBackend(eng) if use_dp else None
-    if use_dp:  # RCCL sets up channels / peer connections lazily at the first collective of a given size: do that
-        # outside the timed region whatever --warmup is (both buffers are rewritten before they are read)
-        with torch.cuda.stream(backend.stream):
-            dist.all_reduce(backend.grad_tensor())
-            dist.all_reduce(backend.advstat_tensor())
+    if use_dp:  # the engine's own RCCL communicator (the update loop runs in C: mobrob_ppo_train_dp); RCCL sets up
+        # channels / peer connections lazily at the first collective of a given size, so one full update is run
+        # outside the timed region whatever --warmup is (its input is a throw-away rollout)
+        backend.ensure_comm()
+        eng.collect_synthetic(p_term=w["p_term"], time_limit=w["tl"])
+        train_data_parallel(backend, force_collectives=force_dp)
+        eng.set_params(init_params(D, A, H, seed=0))
         torch.cuda.synchronize()
 
     host = None

@@ -237,6 +237,24 @@ typedef struct mobrob_ppo_train_stats {
   int32_t n_minibatches; /* optimizer steps taken by the call */
 } mobrob_ppo_train_stats_t;
 
+/* ---- data-parallel update: one process per GPU, rank r owns its envs and rollout shard ------------
+ * PPO.train() of the reference (reached through PPOCtrl.learn, /root/reference/src/mobrob/rl_control/ppo.py:73-74)
+ * across `cfg.world_size` ranks: per epoch ONE all-reduce of the [n_minibatches][4] float64 advantage statistics, per
+ * optimizer step ONE all-reduce (sum) of the flat [P] float32 gradient, both enqueued on the engine's stream between
+ * the kernels -- no host synchronisation and no interpreter in the loop.  Every rank then applies the identical
+ * clip + Adam, so replicas stay bit-identical.  batch_size in the config is the GLOBAL minibatch.
+ *   comm_unique_id  rank 0 makes the 128-byte RCCL id; the caller ships it to the other ranks (any side channel)
+ *   comm_init       collective: ncclCommInitRank(world_size, id, rank) -> the engine's communicator (RCCL over xGMI)
+ *   train_dp        the loop.  fn == NULL: RCCL on the communicator.  fn != NULL: the caller's all-reduce, called with
+ *                   (ctx, device pointer, element count, dtype 0 = f32 / 1 = f64, hipStream_t of the engine); it must
+ *                   leave the SUM over ranks in place, ordered after prior work on that stream, and return 0
+ *                   (tests: gloo between two ranks that share one GPU). */
+typedef int (*mobrob_allreduce_fn)(void* ctx, void* buf_dev, size_t count, int32_t dtype, void* hip_stream);
+int mobrob_ppo_comm_unique_id(uint8_t* out128);
+int mobrob_ppo_comm_init(mobrob_ppo_engine_t* e, const uint8_t* id128);
+int mobrob_ppo_comm_destroy(mobrob_ppo_engine_t* e);
+int mobrob_ppo_train_dp(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_allreduce_fn fn, void* ctx);
+
 /* Whole PPO.train(): n_epochs x ceil(T*N / batch) optimizer steps.  perms = n_epochs concatenated
  * env-major permutations of range(T*N) (what np.random.permutation would have produced), or NULL ->
  * counter-based Feistel permutations keyed by (seed, rank, update counter).  world_size must be 1. */

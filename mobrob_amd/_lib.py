@@ -88,6 +88,10 @@ SYMBOLS = {
     "mobrob_ppo_episode_records": (C.c_int, [_P, _F, C.c_int32]),
     "mobrob_ppo_train": (C.c_int, [_P, _I64, C.POINTER(TrainStats)]),
     "mobrob_ppo_train_enqueue": (C.c_int, [_P, _I64]),
+    "mobrob_ppo_comm_unique_id": (C.c_int, [_U8]),
+    "mobrob_ppo_comm_init": (C.c_int, [_P, _U8]),
+    "mobrob_ppo_comm_destroy": (C.c_int, [_P]),
+    "mobrob_ppo_train_dp": (C.c_int, [_P, _I64, _P, _P]),
     "mobrob_ppo_epoch_begin": (C.c_int, [_P, _I64]),
     "mobrob_ppo_num_minibatches": (C.c_int, [_P]),
     "mobrob_ppo_minibatch_grad": (C.c_int, [_P, C.c_int32]),
@@ -103,6 +107,8 @@ SYMBOLS = {
     "mobrob_ppo_profile_enable": (C.c_int, [_P, C.c_int32]),
     "mobrob_ppo_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), _I64]),
 }
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p)  # mobrob_allreduce_fn
 
 _lib = None
 

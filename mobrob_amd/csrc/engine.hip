@@ -2,6 +2,8 @@
 // Reference surface replaced: stable_baselines3.PPO as configured by the reference's
 // src/mobrob/rl_control/ppo.py:50-59 and driven by :73-77 (see the header for per-entry citations).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is dlopen'ed by comm_init (no link-time dependency)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -124,6 +126,7 @@ struct mobrob_ppo_engine {
   int stats_cap = 0, stats_n = 0;
   int cur_count = 0;
   bool grad_pending = false;
+  ncclComm_t comm = nullptr;  // RCCL communicator of the data-parallel job (mobrob_ppo_comm_init)
   // generic-path workspace
   float *Xg = nullptr, *actg = nullptr, *lpg = nullptr, *advg = nullptr, *retg = nullptr;
   float *h1p = nullptr, *h2p = nullptr, *h1v = nullptr, *h2v = nullptr, *mu = nullptr, *vout = nullptr;
@@ -711,6 +714,7 @@ int mobrob_ppo_create_in_arena(const mobrob_ppo_config_t* cfg, void* arena, size
 void mobrob_ppo_destroy(mobrob_ppo_engine_t* e) {
   if (!e) return;
   (void)hipStreamSynchronize(e->stream);
+  (void)mobrob_ppo_comm_destroy(e);
   prof_resolve(e);
   if (e->cstream) {
     (void)hipStreamSynchronize(e->cstream);
@@ -1492,6 +1496,103 @@ int mobrob_ppo_train_enqueue(mobrob_ppo_engine_t* e, const int64_t* perms) {
   e->epoch_open = false;
   return MOBROB_OK;
 }
+
+// ---- data parallel: the whole update loop in C, one RCCL all-reduce per optimizer step on the engine's stream ----
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+RcclApi g_rccl;
+int rccl_load() {
+  if (g_rccl.lib) return MOBROB_OK;
+  // by SONAME: a process that already holds RCCL (torch.distributed's "nccl" backend) shares that copy
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail(MOBROB_ERR_STATE, "RCCL not found: %s", dlerror());
+#define RSYM(field, name)                                                     \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));   \
+  if (!g_rccl.field) return fail(MOBROB_ERR_STATE, "RCCL symbol %s missing", name);
+  RSYM(GetUniqueId, "ncclGetUniqueId")
+  RSYM(CommInitRank, "ncclCommInitRank")
+  RSYM(CommDestroy, "ncclCommDestroy")
+  RSYM(AllReduce, "ncclAllReduce")
+  RSYM(GetErrorString, "ncclGetErrorString")
+#undef RSYM
+  g_rccl.lib = h;
+  return MOBROB_OK;
+}
+#define NCCLC(expr)                                                                                   \
+  do {                                                                                                \
+    ncclResult_t _r = (expr);                                                                         \
+    if (_r != ncclSuccess) return fail(MOBROB_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(_r)); \
+  } while (0)
+
+// sum `count` elements (dtype 0 = f32, 1 = f64) in place across the ranks, ordered on the engine's stream
+int dp_all_reduce(mobrob_ppo_engine* e, void* buf, size_t count, int dtype, mobrob_allreduce_fn fn, void* ctx) {
+  if (fn) {
+    const int r = fn(ctx, buf, count, dtype, (void*)e->stream);
+    return r == 0 ? MOBROB_OK : fail(MOBROB_ERR_STATE, "all-reduce callback returned %d", r);
+  }
+  NCCLC(g_rccl.AllReduce(buf, buf, count, dtype == 1 ? ncclDouble : ncclFloat, ncclSum, e->comm, e->stream));
+  return MOBROB_OK;
+}
+}  // namespace
+
+extern "C" {
+int mobrob_ppo_comm_unique_id(uint8_t* out128) {
+  if (!out128) return fail(MOBROB_ERR_INVALID, "comm_unique_id: null argument");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  CHK(rccl_load());
+  ncclUniqueId id;
+  NCCLC(g_rccl.GetUniqueId(&id));
+  memcpy(out128, &id, sizeof id);
+  return MOBROB_OK;
+}
+int mobrob_ppo_comm_init(mobrob_ppo_engine_t* e, const uint8_t* id128) {
+  if (!e || !id128) return fail(MOBROB_ERR_INVALID, "comm_init: null argument");
+  if (e->comm) return fail(MOBROB_ERR_STATE, "comm_init: the engine already has a communicator");
+  CHK(rccl_load());
+  HIPC(hipSetDevice(e->cfg.device_id));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  NCCLC(g_rccl.CommInitRank(&e->comm, e->cfg.world_size, id, e->cfg.rank));
+  return MOBROB_OK;
+}
+int mobrob_ppo_comm_destroy(mobrob_ppo_engine_t* e) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  if (e->comm) {
+    (void)hipStreamSynchronize(e->stream);
+    (void)g_rccl.CommDestroy(e->comm);
+    e->comm = nullptr;
+  }
+  return MOBROB_OK;
+}
+int mobrob_ppo_train_dp(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_allreduce_fn fn, void* ctx) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  if (!fn && !e->comm)
+    return fail(MOBROB_ERR_STATE, "train_dp: no communicator (mobrob_ppo_comm_init) and no all-reduce callback");
+  const size_t total = (size_t)e->N * e->T;
+  e->stats_n = 0;
+  for (int ep = 0; ep < e->cfg.n_epochs; ++ep) {
+    CHK(mobrob_ppo_epoch_begin(e, perms ? perms + (size_t)ep * total : nullptr));
+    // per-minibatch (sum, sum of squares, count) of the advantages: global statistics for the normalisation
+    CHK(dp_all_reduce(e, e->advstat, (size_t)e->nmb * 4, 1, fn, ctx));
+    if (ep == e->cfg.n_epochs - 1) e->stats_n = 0;
+    for (int mb = 0; mb < e->nmb; ++mb) {
+      CHK(mobrob_ppo_minibatch_grad(e, mb));
+      CHK(dp_all_reduce(e, e->grads, (size_t)e->P, 0, fn, ctx));  // THE exchange step: one per optimizer step
+      CHK(mobrob_ppo_minibatch_apply(e));
+    }
+  }
+  e->epoch_open = false;
+  return MOBROB_OK;
+}
+}  // extern "C"
 
 int mobrob_ppo_train(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_ppo_train_stats_t* st) {
   CHK(mobrob_ppo_train_enqueue(e, perms));

@@ -321,6 +321,47 @@ class PPOEngine:
         check(self.lib.mobrob_ppo_train(self._h, p, C.byref(st)))
         return {k: float(getattr(st, k)) for k in STAT_KEYS} | {"n_minibatches": int(st.n_minibatches)}
 
+    def comm_init(self, unique_id=None):
+        """Collective over the ranks of the job: build the engine's RCCL communicator.  Rank 0 calls
+        `PPOEngine.comm_unique_id()` and ships the 128 bytes to the others (parallel.py uses torch.distributed)."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        check(self.lib.mobrob_ppo_comm_init(self._h, buf))
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        check(_lib.load().mobrob_ppo_comm_unique_id(buf))
+        return bytes(buf)
+
+    def train_dp(self, perms=None, allreduce=None):
+        """PPO.train() across the ranks, the whole loop in C (mobrob_ppo_train_dp): one all-reduce of the gradient per
+        optimizer step on the engine's stream.  allreduce: None -> RCCL on the communicator of comm_init; or a Python
+        callable (device_ptr, count, dtype_code, hip_stream) -> None that sums in place (tests)."""
+        p = None
+        if perms is not None:
+            perms = np.ascontiguousarray(perms, dtype=np.int64)
+            if perms.shape != (self.cfg.n_epochs, self.N * self.T):
+                raise ValueError(f"perms must be [{self.cfg.n_epochs}, {self.N * self.T}]")
+            p = perms.ctypes.data_as(C.POINTER(C.c_int64))
+        if allreduce is None:
+            check(self.lib.mobrob_ppo_train_dp(self._h, p, None, None))
+            return
+        failure = []
+
+        def trampoline(_ctx, buf, count, dtype, stream):
+            try:
+                allreduce(int(buf), int(count), int(dtype), int(stream or 0))
+                return 0
+            except BaseException as ex:  # noqa: BLE001 - must not propagate through the C frame
+                failure.append(ex)
+                return 1
+
+        cb = _lib.ALLREDUCE_FN(trampoline)
+        rc = self.lib.mobrob_ppo_train_dp(self._h, p, C.cast(cb, C.c_void_p), None)
+        if failure:
+            raise failure[0]
+        check(rc)
+
     def train_enqueue(self):
         """PPO.train() enqueued on the engine's stream without waiting (device-drawn permutations)."""
         check(self.lib.mobrob_ppo_train_enqueue(self._h, None))

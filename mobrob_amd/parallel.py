@@ -8,8 +8,13 @@ for 2x256) and, once per epoch, one tiny all-reduce of the per-minibatch advanta
 clip equal single-process SB3 arithmetic on the union minibatch.  Every rank then applies the identical
 clip + Adam step -> replicas stay bit-identical without a parameter broadcast.
 
-The update loop is written against a small backend protocol so that the very same code is exercised
-with the HIP engine on GPUs and with a NumPy backend in the world_size-2 gloo tests:
+On GPUs the loop runs in C (`mobrob_ppo_train_dp`): grad kernel -> ncclAllReduce on the engine's stream -> clip +
+Adam kernels, no interpreter and no host synchronisation between optimizer steps; the engine owns its RCCL
+communicator (`mobrob_ppo_comm_init`; the 128-byte id travels through torch.distributed).  Under a gloo group (two
+test ranks sharing one GPU) the same C loop calls back into `gloo_all_reduce`.
+
+The exchange protocol itself is also written out below against a small backend interface (`_update_loop`), so that it
+can be exercised WITHOUT a GPU by the world_size-2 gloo tests on a NumPy backend:
 
     backend.epoch_begin(perm_or_None)           -> local advantage partial sums ready
     backend.advstat_tensor()                    -> torch tensor [n_mb, 4] float64 (in-place all-reduce target)
@@ -95,14 +100,43 @@ class EngineBackend:
     def minibatch_apply(self):
         self.e.minibatch_apply()
 
+    # ---- the C loop ------------------------------------------------------------------------------------
+    def ensure_comm(self, group=None):
+        """RCCL communicator of the engine over the ranks of `group` (collective, once)."""
+        if getattr(self, "_comm_ready", False):
+            return
+        box = [self.e.comm_unique_id() if dist.get_rank(group) == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self.e.comm_init(box[0])
+        self._comm_ready = True
 
-def train_data_parallel(backend, perms=None, group=None, force_collectives=False):
+    def gloo_all_reduce(self, group=None):
+        """All-reduce callback for `engine.train_dp` under a CPU process group: stage through the host."""
+        def reduce_in_place(ptr, count, dtype, _stream):
+            t = device_tensor(ptr, (count,), torch.float64 if dtype == 1 else torch.float32, self.device)
+            with torch.cuda.stream(self.stream):
+                host = t.cpu()                       # ordered after the engine's kernels on the shared stream
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                t.copy_(host)
+            self.stream.synchronize()
+        return reduce_in_place
+
+
+def train_data_parallel(backend, perms=None, group=None, force_collectives=False, python_loop=False):
     """PPO.train() across ranks.  perms: per-epoch LOCAL permutations ([n_epochs, T*N_local]) or None.
-    force_collectives issues the all-reduces even at world size 1 (plumbing self-test)."""
+    force_collectives issues the all-reduces even at world size 1 (plumbing self-test).  An `EngineBackend` runs the
+    loop in C (RCCL under an "nccl" group, the gloo callback otherwise); other backends, or python_loop=True, run the
+    protocol loop below with torch.distributed collectives."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     comm = world > 1 or (force_collectives and dist.is_initialized())
     stream = getattr(backend, "stream", None)
-    if stream is not None:  # GPU backend: collectives are issued with the engine's stream current
+    if isinstance(backend, EngineBackend) and comm and not python_loop:
+        if dist.get_backend(group) == "nccl":
+            backend.ensure_comm(group)
+            backend.e.train_dp(perms)
+        else:
+            backend.e.train_dp(perms, allreduce=backend.gloo_all_reduce(group))
+    elif stream is not None:  # GPU backend, Python loop: collectives are issued with the engine's stream current
         with torch.cuda.stream(stream):
             _update_loop(backend, perms, group, comm)
     else:

@@ -124,3 +124,48 @@ def test_ppo_learn_is_data_parallel_under_a_process_group(tmp_path):
     h = r[0]["hist"].astype(np.float64)
     first, last = h[:4].sum(0), h[-4:].sum(0)
     assert last[1] / max(last[0], 1) > first[1] / max(first[0], 1) + 0.2, (first, last)
+
+
+def _rccl_world1_worker(rank, world, port, out):
+    """One rank, "nccl" backend: the C loop with the engine's own RCCL communicator (ncclCommInitRank from an id made
+    by mobrob_ppo_comm_unique_id, ncclAllReduce on the engine's stream) against the single-rank C call and against
+    the Python protocol loop with torch.distributed collectives."""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from mobrob_amd.engine import PPOEngine
+    from mobrob_amd.parallel import EngineBackend, train_data_parallel
+    res = {}
+    for case in ("h256", "h64"):
+        c = CASES[case]
+        p, buf, lv, dones, h, perms = _rank_data(c, 0)
+        H = c["H"]
+        e = PPOEngine(obs_dim=c["D"], act_dim=c["A"], n_envs=c["N"], n_steps=c["T"], batch_size=c["B"], n_epochs=c["E"],
+                      pi=(H, H), vf=(H, H), ent_coef=h.ent_coef, device_id=0)
+        e.load_rollout(buf, lv, dones)
+        z = {k: np.zeros_like(v) for k, v in p.items()}
+        be = EngineBackend(e)
+        for mode in ("single", "c_rccl", "python_torch"):
+            e.set_params(p)
+            e.set_optimizer_state(z, z, 0)
+            if mode == "single":
+                e.train(perms)
+            else:
+                train_data_parallel(be, perms, force_collectives=True, python_loop=(mode == "python_torch"))
+            torch.cuda.synchronize()
+            res[f"{case}/{mode}"] = e.get_flat_params()
+        e.close()
+    np.savez(out, **res)
+    dist.destroy_process_group()
+
+
+def test_c_loop_with_rccl_equals_the_single_rank_call(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "rccl.npz")
+    mp.spawn(_rccl_world1_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    r = np.load(out)
+    for case in ("h256", "h64"):
+        assert np.array_equal(r[f"{case}/c_rccl"], r[f"{case}/single"]), case
+        assert np.array_equal(r[f"{case}/python_torch"], r[f"{case}/single"]), case
