@@ -374,6 +374,9 @@ def main():
                     help="host-env workloads: drive the pipelined rollout from Python instead of mobrob_ppo_collect_host")
     ap.add_argument("--host-parts", type=int, default=2,
                     help="host-env workloads: row ranges of the pipelined rollout (1 = whole batch per step)")
+    ap.add_argument("--persistent-train", action="store_true",
+                    help="small-minibatch 2x64 workloads: one persistent launch per epoch (kernels_train_small.h) instead of "
+                         "four launches per optimizer step")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="tests: exercise the rank launcher / rendezvous / one-line contract with gloo on CPU (no PPO work)")
     args = ap.parse_args()
@@ -427,7 +430,8 @@ def main():
     D, A, H, N, T, E, B = w["D"], w["A"], w["H"], w["N"], w["T"], w["E"], w["B"]
     eng = PPOEngine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B * world, n_epochs=E, pi=(H, H), vf=(H, H),
                     gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.01, seed=0, device_id=local_rank,
-                    rank=rank, world_size=world, fast_kernels=not args.generic)
+                    rank=rank, world_size=world, fast_kernels=not args.generic,
+                    persistent_train=args.persistent_train)
     eng.set_params(init_params(D, A, H, seed=0))  # identical replicas on every rank
     backend = EngineBackend(eng) if use_dp else None
     if use_dp:  # the engine's own RCCL communicator (the update loop runs in C: mobrob_ppo_train_dp); RCCL sets up

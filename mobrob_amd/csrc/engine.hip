@@ -127,6 +127,12 @@ struct mobrob_ppo_engine {
   int cur_count = 0;
   bool grad_pending = false;
   ncclComm_t comm = nullptr;  // RCCL communicator of the data-parallel job (mobrob_ppo_comm_init)
+  // persistent small-batch update (kernels_train_small.h): one launch per epoch for 64-wide nets, minibatch <= 160 rows
+  float* sched_dev = nullptr;              // [nmb][2] per-step Adam scalars of the epoch being enqueued
+  unsigned long long* mail = nullptr;      // [2][2][16] hand-off words of the two workgroups
+  int* small_err = nullptr;                // raised by the kernel when a hand-off times out
+  std::vector<float> sched_host;           // [n_epochs][nmb][2], kept alive until the copies have run
+  unsigned long long small_steps = 0;      // optimizer steps ever enqueued through the persistent kernel (hand-off ids)
   // generic-path workspace
   float *Xg = nullptr, *actg = nullptr, *lpg = nullptr, *advg = nullptr, *retg = nullptr;
   float *h1p = nullptr, *h2p = nullptr, *h1v = nullptr, *h2v = nullptr, *mu = nullptr, *vout = nullptr;
@@ -533,6 +539,7 @@ void mobrob_ppo_default_config(mobrob_ppo_config_t* c) {
   c->normalize_advantage = 1; c->seed = 0; c->device_id = 0; c->rank = 0; c->world_size = 1; c->fast_kernels = 1;
   c->rollout_graph = 1;
   c->rollout_persistent = 1;
+  c->persistent_train = 0;  // opt-in: see kernels_train_small.h (bit-identical, but two CUs lose to four wide launches)
 }
 
 void* mobrob_ppo_host_alloc(size_t bytes) {
@@ -615,6 +622,9 @@ int engine_alloc(mobrob_ppo_engine* e) {
   CHK(dalloc(e, &e->trunc_dev, N)); CHK(dalloc(e, &e->dones_u8, N)); CHK(dalloc(e, &e->ep_len, N)); CHK(dalloc(e, &e->ep_len2, N)); CHK(dalloc(e, &e->ctr_dev, 2));
   CHK(dalloc(e, &e->rows, T * N)); CHK(dalloc(e, &e->perm_dev, T * N)); CHK(dalloc(e, &e->advstat, (size_t)e->nmb * 4));
   CHK(dalloc(e, &e->stats, (size_t)e->stats_cap * 8));
+  CHK(dalloc(e, &e->sched_dev, (size_t)2 * e->nmb * std::max(1, e->cfg.n_epochs)));
+  CHK(dalloc(e, &e->mail, 64));
+  CHK(dalloc(e, &e->small_err, 4));
   CHK(dalloc(e, &e->Xg, Bl * Dp)); CHK(dalloc(e, &e->actg, Bl * A)); CHK(dalloc(e, &e->lpg, Bl));
   CHK(dalloc(e, &e->advg, Bl)); CHK(dalloc(e, &e->retg, Bl));
   CHK(dalloc(e, &e->h1p, R * e->H1)); CHK(dalloc(e, &e->h2p, R * e->H2)); CHK(dalloc(e, &e->h1v, R * e->G1));
@@ -1423,6 +1433,30 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
   return MOBROB_OK;
 }
 
+namespace {
+// everything of AdamPackArgs that does not change from step to step
+void fill_adam_pack_args(mobrob_ppo_engine* e, AdamPackArgs& a) {
+  a.p = e->params; a.g = e->grads; a.m = e->m; a.v = e->v; a.P = e->P;
+  a.chunks = e->chunks_dev; a.partial = e->chunk_partial; a.nchunks = e->nchunks;
+  a.max_norm = (float)e->cfg.max_grad_norm; a.beta1 = (float)e->cfg.adam_beta1; a.beta2 = (float)e->cfg.adam_beta2;
+  a.eps = (float)e->cfg.adam_eps;
+  for (int i = 0; i < 14; ++i) a.offs[i] = e->offs[i];
+  a.D = e->D; a.Dp = e->Dp; a.A = e->A; a.Ap = e->Ap; a.H1 = e->H1; a.H2 = e->H2; a.G1 = e->G1; a.G2 = e->G2;
+  a.pW1p = e->pW1p; a.vW1p = e->vW1p; a.aWp = e->aWp; a.vWp = e->vWp;
+  for (int n = 0; n < 2; ++n) {
+    const bool on = e->fused.enabled;
+    a.fW1f[n] = on ? (float*)e->fused.net[n].W1f : nullptr;
+    a.fW2f[n] = on ? (float*)e->fused.net[n].W2f : nullptr;
+    a.fW3f[n] = on ? (float*)e->fused.net[n].W3f : nullptr;
+    a.fW2b[n] = on ? (float*)e->fused.net[n].W2b : nullptr;
+    a.fW3b[n] = on ? (float*)e->fused.net[n].W3b : nullptr;
+    a.fW3h[n] = (on && e->fused.H == FH && (n == 1 || e->fused.A <= 16)) ? (float*)e->fused.net[n].W3h : nullptr;
+    a.fb1s[n] = on ? (float*)e->fused.net[n].b1s : nullptr;
+    a.fb2s[n] = on ? (float*)e->fused.net[n].b2s : nullptr;
+  }
+}
+}  // namespace
+
 int mobrob_ppo_minibatch_apply(mobrob_ppo_engine_t* e) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   if (!e->grad_pending) return fail(MOBROB_ERR_STATE, "minibatch_apply without a pending gradient");
@@ -1441,24 +1475,9 @@ int mobrob_ppo_minibatch_apply(mobrob_ppo_engine_t* e) {
   hipLaunchKernelGGL(k_sqnorm_chunks, dim3(e->nchunks), dim3(256), 0, e->stream, e->grads, e->chunks_dev,
                      e->chunk_partial, st);
   AdamPackArgs a{};
-  a.p = e->params; a.g = e->grads; a.m = e->m; a.v = e->v; a.P = e->P;
-  a.chunks = e->chunks_dev; a.partial = e->chunk_partial; a.nchunks = e->nchunks;
-  a.max_norm = (float)e->cfg.max_grad_norm; a.step_size = (float)(e->cfg.learning_rate / bc1);
-  a.bc2_sqrt = (float)std::sqrt(bc2); a.beta1 = (float)b1; a.beta2 = (float)b2; a.eps = (float)e->cfg.adam_eps;
-  for (int i = 0; i < 14; ++i) a.offs[i] = e->offs[i];
-  a.D = e->D; a.Dp = e->Dp; a.A = e->A; a.Ap = e->Ap; a.H1 = e->H1; a.H2 = e->H2; a.G1 = e->G1; a.G2 = e->G2;
-  a.pW1p = e->pW1p; a.vW1p = e->vW1p; a.aWp = e->aWp; a.vWp = e->vWp;
-  for (int n = 0; n < 2; ++n) {
-    const bool on = e->fused.enabled;
-    a.fW1f[n] = on ? (float*)e->fused.net[n].W1f : nullptr;
-    a.fW2f[n] = on ? (float*)e->fused.net[n].W2f : nullptr;
-    a.fW3f[n] = on ? (float*)e->fused.net[n].W3f : nullptr;
-    a.fW2b[n] = on ? (float*)e->fused.net[n].W2b : nullptr;
-    a.fW3b[n] = on ? (float*)e->fused.net[n].W3b : nullptr;
-    a.fW3h[n] = (on && e->fused.H == FH && (n == 1 || e->fused.A <= 16)) ? (float*)e->fused.net[n].W3h : nullptr;
-    a.fb1s[n] = on ? (float*)e->fused.net[n].b1s : nullptr;
-    a.fb2s[n] = on ? (float*)e->fused.net[n].b2s : nullptr;
-  }
+  fill_adam_pack_args(e, a);
+  a.step_size = (float)(e->cfg.learning_rate / bc1);
+  a.bc2_sqrt = (float)std::sqrt(bc2);
   a.stats_row = stats_row;
   a.loss_sums_zero = e->fused.enabled ? e->grads + e->P : nullptr;
   hipLaunchKernelGGL(k_adam_pack, dim3(cdiv(e->P, 256)), dim3(256), 0, e->stream, a);
@@ -1473,10 +1492,56 @@ int mobrob_ppo_fetch_step_stats(mobrob_ppo_engine_t* e, float* out, int32_t max_
   if (n > 0) {
     HIPC(hipMemcpyAsync(out, e->stats + (size_t)(e->stats_n - n) * 8, (size_t)n * 32, hipMemcpyDeviceToHost, e->stream));
   }
+  int small_err = 0;
+  HIPC(hipMemcpyAsync(&small_err, e->small_err, sizeof small_err, hipMemcpyDeviceToHost, e->stream));
   HIPC(hipStreamSynchronize(e->stream));
   e->stats_n = 0;
+  if (small_err != 0) {
+    (void)hipMemsetAsync(e->small_err, 0, sizeof(int), e->stream);
+    return fail(MOBROB_ERR_HIP, "persistent update kernel: a hand-off between its two workgroups timed out");
+  }
   return n;
 }
+
+namespace {
+// One launch per epoch instead of four per optimizer step: 64-wide nets, single rank, a minibatch of at most one
+// 32-row tile per wave (the bit-identity condition of kernels_train_small.h), and enough steps to be worth it.
+bool train_small_ok(const mobrob_ppo_engine* e) {
+  if (!e->fused.enabled || e->fused.H != 64 || e->cfg.world_size != 1 || e->cfg.persistent_train == 0) return false;
+  // <= one tile per wave, and at most one tile beyond the first block of the per-step path: then both paths add the
+  // tiles of a minibatch in the same order ((t0 + t1 + ...) + t_last) and stay bit-identical
+  const int ntiles = cdiv(e->Bl, GR);
+  return ntiles >= 2 && ntiles <= train_small_max_waves(e->Dp) && ntiles <= g_train_waves(e->Dp) + 1 && e->nmb >= 2 &&
+         e->nmb <= e->stats_cap && e->nchunks <= 16;
+}
+int train_small_epoch(mobrob_ppo_engine* e, int ep) {
+  FusedState& f = e->fused;
+  ProfScope ps(e, MOBROB_K_TRAIN_GRAD);
+  TrainSmallArgs a{};
+  Fused64TrainArgs& t = a.t;
+  t.net[0] = f.net[0]; t.net[1] = f.net[1];
+  t.wpack[0] = reinterpret_cast<const float*>(f.net[0].W1f);
+  t.wpack[1] = reinterpret_cast<const float*>(f.net[1].W1f);
+  t.obs = e->obs; t.actions = e->actions; t.A = e->A; t.old_logp = e->logp; t.adv = e->adv; t.ret = e->ret;
+  t.log_std = e->params + e->offs[T_LOGSTD]; t.normalize = e->cfg.normalize_advantage;
+  t.clip = (float)e->cfg.clip_range; t.vf_coef = (float)e->cfg.vf_coef; t.ent_coef = (float)e->cfg.ent_coef;
+  a.rows = e->rows; a.total = e->N * e->T; a.Bl = e->Bl; a.nmb = e->nmb; a.nw = cdiv(e->Bl, GR);
+  a.advstat = e->advstat;
+  fill_adam_pack_args(e, a.pk);
+  a.pk.g_out = e->grads;
+  a.pk.stats_row = nullptr; a.pk.loss_sums_zero = nullptr;
+  a.chunks = e->chunks_dev; a.nchunks = e->nchunks;
+  a.sched = e->sched_dev + (size_t)2 * e->nmb * ep;
+  a.stats = e->stats;
+  a.mail = e->mail; a.step0 = e->small_steps + 1; a.error = e->small_err;
+  train_small_launch(f, a, e->stream);
+  HIPC(hipGetLastError());
+  e->small_steps += (unsigned long long)e->nmb;
+  e->adam_step += e->nmb;
+  e->stats_n = e->nmb;
+  return MOBROB_OK;
+}
+}  // namespace
 
 int mobrob_ppo_train_enqueue(mobrob_ppo_engine_t* e, const int64_t* perms) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
@@ -1485,8 +1550,23 @@ int mobrob_ppo_train_enqueue(mobrob_ppo_engine_t* e, const int64_t* perms) {
                                   "minibatch_grad/[all-reduce]/minibatch_apply");
   const size_t total = (size_t)e->N * e->T;
   e->stats_n = 0;
+  const bool small = train_small_ok(e);
+  if (small) {  // Adam's bias corrections of every step of this call, in float64 on the host like the per-step path
+    e->sched_host.resize((size_t)2 * e->nmb * e->cfg.n_epochs);
+    const double b1 = e->cfg.adam_beta1, b2 = e->cfg.adam_beta2;
+    for (size_t k = 0; k < (size_t)e->nmb * e->cfg.n_epochs; ++k) {
+      const double step = (double)(e->adam_step + 1 + (int64_t)k);
+      e->sched_host[2 * k] = (float)(e->cfg.learning_rate / (1.0 - std::pow(b1, step)));
+      e->sched_host[2 * k + 1] = (float)std::sqrt(1.0 - std::pow(b2, step));
+    }
+    HIPC(hipMemcpyAsync(e->sched_dev, e->sched_host.data(), e->sched_host.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  }
   for (int ep = 0; ep < e->cfg.n_epochs; ++ep) {
     CHK(mobrob_ppo_epoch_begin(e, perms ? perms + (size_t)ep * total : nullptr));
+    if (small) {
+      CHK(train_small_epoch(e, ep));
+      continue;
+    }
     if (ep == e->cfg.n_epochs - 1) e->stats_n = 0;
     for (int mb = 0; mb < e->nmb; ++mb) {
       CHK(mobrob_ppo_minibatch_grad(e, mb));

@@ -3,6 +3,7 @@
 #include "kernels_fused.h"
 #include "kernels_fused64.h"
 #include "kernels_rollout.h"
+#include "kernels_train_small.h"
 
 namespace mobrob {
 
@@ -35,6 +36,10 @@ inline void fused_launch_train(FusedState& f, FusedTrainArgs& a, int grid, hipSt
 inline void fused64_launch_train(FusedState& f, Fused64TrainArgs& a, int grid, hipStream_t st) {
   FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused64_train<DPc>), dim3(grid), dim3(Lay64<DPc>::TNWV * 64), f.lds_bytes, st, a));
 }
+inline void train_small_launch(FusedState& f, TrainSmallArgs& a, hipStream_t st) {
+  const int threads = std::max(a.nw, 4) * 64;  // the norm reduction runs on 256 threads like k_sqnorm_chunks
+  FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_train_small<DPc>), dim3(2), dim3(threads), train_small_lds_bytes(f.Dp, a.nw), st, a));
+}
 inline hipError_t fused_set_lds_attr(FusedState& f) {
   hipError_t e = hipSuccess;
   if (f.H == 64) {
@@ -44,6 +49,9 @@ inline hipError_t fused_set_lds_attr(FusedState& f) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused64_act<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_act_bytes);
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout64_persistent<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rollout64_lds_bytes(f.Dp));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_small<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)train_small_lds_bytes(f.Dp, train_small_max_waves(f.Dp)));
     });
   } else {
     FUSED_DISPATCH_DP(f.Dp, {

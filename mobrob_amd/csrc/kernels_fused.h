@@ -545,7 +545,21 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   constexpr int ldx = L::LDX, per = DP / 4;
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);  // wave-uniform -> SGPR addressing of weights/slabs
-  const int net = blockIdx.x & 1, wg = blockIdx.x >> 1, nwg = gridDim.x >> 1;
+  // blockIdx -> (network, tile sequence).  The hardware deals workgroups round-robin over the 8 XCDs (XCD = blockIdx
+  // mod 8, each with a private L2).  Blocks are taken in groups of 16: the first 8 run the policy network for tile
+  // sequences 8g .. 8g+7, the next 8 the value network for the SAME sequences, so the two workgroups that gather the
+  // same observation rows sit on the same XCD and the second gather hits that XCD's L2 instead of HBM (with the old
+  // `blockIdx & 1` mapping they sat on different XCDs and every X row came from HBM twice).  A last partial group of
+  // r blocks is split r/2 : r/2.  Each L2 holds the fragment packs of both networks (1.2 MB of 4 MB).
+  const int nwg = gridDim.x >> 1;
+  int net, wg;
+  {
+    const int b = blockIdx.x, g16 = b >> 4, o = b & 15;
+    const int gsz = min(16, (int)gridDim.x - 16 * g16), half = gsz >> 1;
+    net = o >= half ? 1 : 0;
+    wg = 8 * g16 + (o - net * half);
+  }
+  const int slab_id = 2 * wg + net;   // k_slab_reduce expects the slabs of a network at stride 2
   const FusedNet W = a.net[net];
   const int ntiles = (a.count + FR - 1) / FR;
 
@@ -559,7 +573,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   f32x16 gW1a = zero16(), gW1b = zero16(), gW1c = zero16(), gW1d = zero16();  // [ib][jb] = 00, 10, 01, 11
   f32x16 gW3a = zero16(), gW3b = zero16();  // 32-wide heads: [32][this wave's 64 columns]
   f32x4 gW3h0 = {0.f, 0.f, 0.f, 0.f}, gW3h1 = gW3h0, gW3h2 = gW3h0, gW3h3 = gW3h0;  // H16: [16][64] as 4 16x16 tiles
-  float* slab = a.slabs + (size_t)blockIdx.x * a.slab_floats;
+  float* slab = a.slabs + (size_t)slab_id * a.slab_floats;
   float* slab_w1 = slab + slab_off_w1();
   float* slab_w3 = slab + slab_off_w3(DP);
   float gb2 = 0.f, gb1 = 0.f;  // bias gradients of hidden column `tid`
@@ -894,7 +908,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   // ---- store this workgroup's partial gradients to its slab ----
   STAMP(22)
   STAMP_FLUSH()
-  if (PHASE_ON(16384) || blockIdx.x < 2) {  // (ablation bit 16384: only two workgroups write their slabs)
+  if (PHASE_ON(16384) || slab_id < 2) {  // (ablation bit 16384: only two workgroups write their slabs)
     asm volatile("s_nop 15\n\ts_nop 3");  // last asm MFMA's D -> v_accvgpr_read (16-pass XDL)
     {  // dW1 / dW3 tiles, fragment order: [w][tile][quad][lane] x 16 B
       const unsigned s1 = (unsigned)(wave * 4 * 4 * 64 + lane) * 16u, s3 = (unsigned)(wave * 2 * 4 * 64 + lane) * 16u;
@@ -1330,6 +1344,16 @@ struct NormChunk { int tensor, start, end, pad; };
 struct StatsArgs {
   float* stats_row; const float* loss_sums; const float* log_std; float ent_coef, vf_coef, inv_bg; int n_act;
 };
+// thread `tid` of 256: its share of the sum of squares of one chunk (float64).  Shared by k_sqnorm_chunks and the
+// persistent small-batch kernel (kernels_train_small.h) so that both sum in exactly the same order.
+__device__ __forceinline__ double chunk_sumsq_thread(const float* __restrict__ g, const NormChunk c, int tid) {
+  double a = 0.0;
+  for (int i = c.start + tid; i < c.end; i += 256) {
+    const double x = (double)g[i];
+    a += x * x;
+  }
+  return a;
+}
 __global__ __launch_bounds__(256) void k_sqnorm_chunks(const float* __restrict__ g, const NormChunk* __restrict__ chunks,
                                                        double* __restrict__ partial, StatsArgs st) {
   __shared__ double sc[16];
@@ -1345,18 +1369,13 @@ __global__ __launch_bounds__(256) void k_sqnorm_chunks(const float* __restrict__
     st.stats_row[5] = st.loss_sums[3] * st.inv_bg;
     st.stats_row[7] = 0.f;
   }
-  const NormChunk c = chunks[blockIdx.x];
-  double a = 0.0;
-  for (int i = c.start + threadIdx.x; i < c.end; i += blockDim.x) {
-    const double x = (double)g[i];
-    a += x * x;
-  }
-  const double tot = block_sum_d(a, sc);
+  const double tot = block_sum_d(chunk_sumsq_thread(g, chunks[blockIdx.x], threadIdx.x), sc);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
 struct AdamPackArgs {
   float* p; const float* g; float* m; float* v; int P;
+  float* g_out;  // the same vector, writable (persistent small-batch kernel: it produces the gradient itself)
   const NormChunk* chunks; const double* partial; int nchunks;
   float max_norm, step_size, bc2_sqrt, beta1, beta2, eps;
   int offs[14];
@@ -1374,6 +1393,55 @@ __device__ __forceinline__ int pack_fwd_idx(int n, int k, int KG) {
 }
 __device__ __forceinline__ int pack_bwd_idx(int krow, int j, int KG) {
   return (((j >> 5) * KG + (krow >> 3)) * 64 + (j & 31) + 32 * ((krow >> 2) & 1)) * 4 + (krow & 3);
+}
+
+// clip + Adam of canonical parameter i and its scatter into the padded copies / fragment packs [torch 2.0.1
+// single-tensor Adam; oracle adam_step].  Shared by k_adam_pack and the persistent small-batch kernel.
+__device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, float graw, float m0, float v0, float p0, float coef);
+__device__ __forceinline__ void adam_pack_element(const AdamPackArgs& a, int i, float coef) {
+  adam_pack_apply(a, i, a.g[i], a.m[i], a.v[i], a.p[i], coef);
+}
+// the same with the four operands already in registers (callers that batch their loads)
+__device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, float graw, float m0, float v0, float p0, float coef) {
+  const float g = graw * coef;
+  const float m = m0 * a.beta1 + (1.0f - a.beta1) * g;
+  const float v = v0 * a.beta2 + (1.0f - a.beta2) * (g * g);
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  const float pn = p0 - a.step_size * (m / denom);
+  a.m[i] = m;
+  a.v[i] = v;
+  a.p[i] = pn;
+  int t = 0;
+#pragma unroll
+  for (int k = 1; k < 13; ++k) t += (i >= a.offs[k]) ? 1 : 0;
+  const int e = i - a.offs[t];
+  switch (t) {
+    case 1: case 5: {  // W1 [H][D]
+      const int net = t == 5, n = e / a.D, k = e - n * a.D;
+      (net ? a.vW1p : a.pW1p)[n * a.Dp + k] = pn;
+      if (a.fW1f[net]) a.fW1f[net][pack_fwd_idx(n, k, a.Dp / 8)] = kTanhScale * pn;
+    } break;
+    case 3: case 7: {  // W2 [H2][H1]
+      const int net = t == 7;
+      if (a.fW2f[net]) {
+        const int K = net ? a.G1 : a.H1, n = e / K, k = e - n * K;
+        a.fW2f[net][pack_fwd_idx(n, k, K / 8)] = kTanhScale * pn;
+        a.fW2b[net][pack_bwd_idx(n, k, (net ? a.G2 : a.H2) / 8)] = pn;
+      }
+    } break;
+    case 9: case 11: {  // head [A or 1][H2]
+      const int net = t == 11, K = net ? a.G2 : a.H2, n = e / K, k = e - n * K;
+      (net ? a.vWp : a.aWp)[e] = pn;
+      if (a.fW3f[net]) {
+        a.fW3f[net][pack_fwd_idx(n, k, K / 8)] = pn;
+        a.fW3b[net][pack_bwd_idx(n, k, 4)] = pn;
+        if (a.fW3h[net] && n < 16) a.fW3h[net][pack_h16_idx(n, k)] = pn;
+      }
+    } break;
+    case 2: case 6: if (a.fb1s[t == 6]) a.fb1s[t == 6][e] = kTanhScale * pn; break;  // hidden biases (scaled copies)
+    case 4: case 8: if (a.fb2s[t == 8]) a.fb2s[t == 8][e] = kTanhScale * pn; break;
+    default: break;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
@@ -1409,45 +1477,7 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
   if (i == 0 && a.stats_row != nullptr) a.stats_row[6] = total_s;
   if (i < 8 && a.loss_sums_zero != nullptr) a.loss_sums_zero[i] = 0.f;  // consumed by k_sqnorm_chunks; ready for the next step
   if (i >= a.P) return;
-  const float g = a.g[i] * coef;
-  const float m = a.m[i] * a.beta1 + (1.0f - a.beta1) * g;
-  const float v = a.v[i] * a.beta2 + (1.0f - a.beta2) * (g * g);
-  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-  const float pn = a.p[i] - a.step_size * (m / denom);
-  a.m[i] = m;
-  a.v[i] = v;
-  a.p[i] = pn;
-  int t = 0;
-#pragma unroll
-  for (int k = 1; k < 13; ++k) t += (i >= a.offs[k]) ? 1 : 0;
-  const int e = i - a.offs[t];
-  switch (t) {
-    case 1: case 5: {  // W1 [H][D]
-      const int net = t == 5, n = e / a.D, k = e - n * a.D;
-      (net ? a.vW1p : a.pW1p)[n * a.Dp + k] = pn;
-      if (a.fW1f[net]) a.fW1f[net][pack_fwd_idx(n, k, a.Dp / 8)] = kTanhScale * pn;
-    } break;
-    case 3: case 7: {  // W2 [H2][H1]
-      const int net = t == 7;
-      if (a.fW2f[net]) {
-        const int K = net ? a.G1 : a.H1, n = e / K, k = e - n * K;
-        a.fW2f[net][pack_fwd_idx(n, k, K / 8)] = kTanhScale * pn;
-        a.fW2b[net][pack_bwd_idx(n, k, (net ? a.G2 : a.H2) / 8)] = pn;
-      }
-    } break;
-    case 9: case 11: {  // head [A or 1][H2]
-      const int net = t == 11, K = net ? a.G2 : a.H2, n = e / K, k = e - n * K;
-      (net ? a.vWp : a.aWp)[e] = pn;
-      if (a.fW3f[net]) {
-        a.fW3f[net][pack_fwd_idx(n, k, K / 8)] = pn;
-        a.fW3b[net][pack_bwd_idx(n, k, 4)] = pn;
-        if (a.fW3h[net] && n < 16) a.fW3h[net][pack_h16_idx(n, k)] = pn;
-      }
-    } break;
-    case 2: case 6: if (a.fb1s[t == 6]) a.fb1s[t == 6][e] = kTanhScale * pn; break;  // hidden biases (scaled copies)
-    case 4: case 8: if (a.fb2s[t == 8]) a.fb2s[t == 8][e] = kTanhScale * pn; break;
-    default: break;
-  }
+  adam_pack_element(a, i, coef);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -214,6 +214,230 @@ struct Fused64TrainArgs {
   float* sums;
 };
 
+// Per-wave gradient accumulators of one network (registers): dW2 4 tiles [ib][jb] = 00, 10, 01, 11; dW1 <= 4 tiles;
+// dW3 2 tiles; bias gradients of hidden column `lane`; loss sums.
+struct Grad64 {
+  f32x16 W2a, W2b, W2c, W2d, W1a, W1b, W1c, W1d, W3a, W3b;
+  float b2, b1, pl, vl, kl, cf;
+  __device__ __forceinline__ void zero() {
+    W2a = W2b = W2c = W2d = W1a = W1b = W1c = W1d = W3a = W3b = zero16();
+    b2 = b1 = pl = vl = kl = cf = 0.f;
+  }
+};
+
+// One 32-row tile of one network by ONE wave: rows -> forward -> loss -> backward, gradients added to `g`.
+//   WL         the network's packed weights are LDS resident at offset 0 (Wts64 layout; k_fused64_train) | streamed
+//              from L2 through W's fragment packs (k_train_small: the packs are rewritten by Adam every step)
+//   wb / cst   LDS offsets of this wave's tile region and of the block's [3][32] per-action constants
+//   rows, cnt  permuted row indices and row count of the minibatch this tile belongs to; the tile starts at row0
+//   xr         observation rows of THIS tile (fetched earlier); on return it holds those of the wave's next tile:
+//              rows nrows[nrow0 ...] of a minibatch of ncnt rows (nrows == nullptr: none)
+template <int DP, bool WL>
+__device__ __forceinline__ void tile64_train(const Fused64TrainArgs& a, const FusedNet& W, int net, int wb, int cst, int lane0,
+                                             const int* rows, int cnt, int row0, const int* nrows, int ncnt, int nrow0,
+                                             f32x4 (&xr)[GR * (DP / 4) / 64], float adv_mean, float adv_sd, bool adv_on,
+                                             Grad64& g) {
+  using L = Lay64<DP>;
+  using Wt = Wts64<DP>;
+  constexpr int ldx = L::LDX, per = DP / 4;
+  constexpr int NGW = GR * per / 64;
+  int nsrc[NGW];
+  const int lane = opaque(lane0) & 63;
+  const int r = lane & 31, h = lane >> 5;
+  // ---- the observation rows of this tile were fetched during the previous tile ----
+#pragma unroll
+  for (int u = 0; u < NGW; ++u) {
+    const int i = lane + u * 64, rr = i / per, c = i - rr * per;
+    *reinterpret_cast<f32x4*>(&lds[wb + L::X + rr * ldx + 4 * c]) = xr[u];
+  }
+#pragma unroll
+  for (int u = 0; u < NGW; ++u) {
+    const int rr = (lane + u * 64) / per;
+    nsrc[u] = (nrows != nullptr && nrow0 + rr < ncnt) ? nrows[nrow0 + rr] : -1;
+  }
+  // operands of the loss stage (two lanes per row), in flight while the forward pass runs
+  const bool llive = row0 + r < cnt;
+  float l_adv = 0.f, l_old = 0.f, l_act[16];
+  {
+    const unsigned src = llive ? (unsigned)rows[row0 + r] : 0u;
+    if (net == 0) {
+      const float* arow = a.actions + (size_t)src * a.A + h;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) l_act[j] = (2 * j + h < a.A && llive) ? arow[2 * j] : 0.f;
+      if (llive) { l_adv = a.adv[src]; l_old = a.old_logp[src]; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) l_act[j] = 0.f;
+      if (llive) l_old = a.ret[src];
+    }
+  }
+  if constexpr (WL) tile64_forward_ldsw<DP>(wb, lane);
+  else tile64_forward<DP>(W, wb, lane);
+
+  // ---- loss: two lanes per row (q = action parity); dL/d(head) -> head tile, zero padded ----
+  {
+    const int rr = r, q = h;
+    const bool live = llive;
+    const int db = opaque(wb + L::DO + rr * FLDO + q);
+    const int cb = opaque(cst + q);
+    const int gb = opaque(wb + L::GACC + q);
+    const int A = a.A;
+    if (net == 0) {
+      float lp = 0.f;
+      float dk[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float d = 0.f;
+        if (2 * j + q < A && live) {
+          d = l_act[j] - (lds[db + 2 * j] + lds[cb + 64 + 2 * j]);
+          lp += -(d * d) * (0.5f * lds[cb + 2 * j]) - lds[cb + 32 + 2 * j];
+        }
+        dk[j] = d;
+      }
+      lp += __shfl_xor(lp, 32, 64);
+      float g_logp = 0.f;
+      if (live) {
+        float adv = l_adv;
+        if (a.normalize && adv_on) adv = (adv - adv_mean) / (adv_sd + 1e-8f);
+        const float log_ratio = lp - l_old;
+        const float ratio = expf(log_ratio);
+        const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
+        const float s1 = adv * ratio, s2 = adv * fminf(fmaxf(ratio, lo), hi);
+        if (q == 0) {
+          g.pl += fminf(s1, s2);
+          g.cf += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
+          g.kl += (ratio - 1.0f) - log_ratio;
+        }
+        const float in_range = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+        const float w1 = (s1 < s2) ? 1.f : ((s1 > s2) ? 0.f : 0.5f);
+        g_logp = -(w1 * adv + (1.0f - w1) * adv * in_range) * a.inv_bg * ratio;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {  // k = 2j + q; wave-uniform trip count
+        const int k = 2 * j + q;
+        float gm = 0.f, gl = 0.f;
+        if (k < A && live) {
+          const float iv = lds[cb + 2 * j];
+          const float d = dk[j];
+          gm = g_logp * d * iv;
+          gl = g_logp * (d * d * iv - 1.0f);
+        }
+        lds[db + 2 * j] = gm;
+        if (2 * j < A) {  // wave-uniform: sum over the 32 rows (lanes with equal q)
+#pragma unroll
+          for (int o = 1; o < 32; o <<= 1) {
+            gm += __shfl_xor(gm, o, 64);
+            gl += __shfl_xor(gl, o, 64);
+          }
+          if (r == 0) {
+            lds[gb + 2 * j] += gm;
+            lds[gb + 32 + 2 * j] += gl;
+          }
+        }
+      }
+    } else {
+      float dv = 0.f;
+      if (live && q == 0) {
+        const float v = lds[db] + lds[cb + 64], rt = l_old;
+        g.vl += (rt - v) * (rt - v);
+        dv = a.vf_coef * 2.0f * (v - rt) * a.inv_bg;
+      }
+      for (int j = 0; j < 16; ++j) lds[db + 2 * j] = (j == 0) ? dv : 0.f;
+      const float t = wave_sum(dv);
+      if (lane == 0) lds[gb] += t;
+    }
+  }
+
+  // ---- dW3 += dout^T . h2  (K = 32 rows) ----
+  {
+    const int ao = opaque(wb + L::DO + h * FLDO + r);
+    const int bo = opaque(wb + L::H2 + h * GLDH + r);
+#pragma unroll 4
+    for (int k = 0; k < GR; k += 2)
+      mfma_x1y2(g.W3a, g.W3b, lds[ao + k * FLDO], lds[bo + k * GLDH], lds[bo + k * GLDH + 32]);
+  }
+  // ---- dh2 = dout . W3 (K = 32) ; dz2 = dh2 * (1 - h2^2) in place ----
+  {
+    f32x16 c0 = zero16(), c1 = zero16();
+    const int nkh = W.head <= 16 ? 2 : 4;  // k-groups of 8 head columns; those beyond `head` are zero
+    if constexpr (WL) gemm_lds_lds_r32<FLDO>(wb + L::DO, Wt::W3B, Wt::W3B + 4 * 256, nkh, c0, c1, lane);
+    else gemm_lds_packed_r32<FLDO>(wb + L::DO, W.W3b, W.W3b + 4 * 64, nkh, c0, c1, lane);
+    const int o = opaque(wb + L::H2 + 4 * h * GLDH + r);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float hv;
+      hv = lds[o + crc(i) * GLDH];      lds[o + crc(i) * GLDH] = c0[i] * (1.0f - hv * hv);
+      hv = lds[o + crc(i) * GLDH + 32]; lds[o + crc(i) * GLDH + 32] = c1[i] * (1.0f - hv * hv);
+    }
+  }
+  // ---- bias gradient of layer 2: column sums of dz2 (lane c <-> column c) ----
+  {
+    const int o = opaque(wb + L::H2 + lane);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
+    for (int rr = 0; rr < GR; rr += 2) {
+      s0 += lds[o + rr * GLDH];
+      s1 += lds[o + (rr + 1) * GLDH];
+    }
+    g.b2 += s0 + s1;
+  }
+#pragma unroll
+  for (int u = 0; u < NGW; ++u) {  // next tile's observation rows: in flight during dW2 / dh1 / dW1
+    const int c = (lane + u * 64) % per;
+    xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nsrc[u] >= 0) xr[u] = ldg16(a.obs, (unsigned)nsrc[u] * (unsigned)(DP * 4) + (unsigned)(c * 16));
+  }
+  // ---- dW2 += dz2^T . h1  (64 x 64, K = 32 rows) ----
+  {
+    const int ao = opaque(wb + L::H2 + h * GLDH + r);
+    const int bo = opaque(wb + L::H1 + h * GLDH + r);
+#pragma unroll 4
+    for (int k = 0; k < GR; k += 2)
+      mfma_x2y2(g.W2a, g.W2b, g.W2c, g.W2d, lds[ao + k * GLDH], lds[ao + k * GLDH + 32], lds[bo + k * GLDH],
+                lds[bo + k * GLDH + 32]);
+  }
+  // ---- dh1 = dz2 . W2 (K = 64) ; dz1 = dh1 * (1 - h1^2) in place ----
+  {
+    f32x16 c0 = zero16(), c1 = zero16();
+    constexpr int nkg = GH / 8;
+    if constexpr (WL) gemm_lds_lds_r32<GLDH>(wb + L::H2, Wt::W2B, Wt::W2B + nkg * 256, nkg, c0, c1, lane);
+    else gemm_lds_packed_r32<GLDH>(wb + L::H2, W.W2b, W.W2b + nkg * 64, nkg, c0, c1, lane);
+    const int o = opaque(wb + L::H1 + 4 * h * GLDH + r);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float hv;
+      hv = lds[o + crc(i) * GLDH];      lds[o + crc(i) * GLDH] = c0[i] * (1.0f - hv * hv);
+      hv = lds[o + crc(i) * GLDH + 32]; lds[o + crc(i) * GLDH + 32] = c1[i] * (1.0f - hv * hv);
+    }
+  }
+  {
+    const int o = opaque(wb + L::H1 + lane);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
+    for (int rr = 0; rr < GR; rr += 2) {
+      s0 += lds[o + rr * GLDH];
+      s1 += lds[o + (rr + 1) * GLDH];
+    }
+    g.b1 += s0 + s1;
+  }
+  // ---- dW1 += dz1^T . X  (64 x DP, K = 32 rows) ----
+  {
+    constexpr bool two = DP > 32;
+    const int ao = opaque(wb + L::H1 + h * GLDH + r);
+    const int c0 = (r < DP) ? r : 0;
+    const int c1 = (32 + r < DP) ? 32 + r : c0;
+    const int b0o = opaque(wb + L::X + h * ldx + c0), b1o = opaque(wb + L::X + h * ldx + c1);
+#pragma unroll 4
+    for (int k = 0; k < GR; k += 2) {
+      if (two)
+        mfma_x2y2(g.W1a, g.W1b, g.W1c, g.W1d, lds[ao + k * GLDH], lds[ao + k * GLDH + 32], lds[b0o + k * ldx],
+                  lds[b1o + k * ldx]);
+      else
+        mfma_x2y1(g.W1a, g.W1b, lds[ao + k * GLDH], lds[ao + k * GLDH + 32], lds[b0o + k * ldx]);
+    }
+  }
+}
+
 // grid: even number of blocks; block b works for network b & 1; its NWV waves take tiles (b>>1)*NWV + wave, stride.
 template <int DP>
 __global__ __launch_bounds__(Lay64<DP>::TNWV * 64, 1) void k_fused64_train(Fused64TrainArgs a) {
@@ -232,11 +456,8 @@ __global__ __launch_bounds__(Lay64<DP>::TNWV * 64, 1) void k_fused64_train(Fused
   for (int i = tid0; i < Wt::TOTAL / 4; i += NWV * 64)
     reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(a.wpack[net])[i];
 
-  f32x16 gW2a = zero16(), gW2b = zero16(), gW2c = zero16(), gW2d = zero16();  // [ib][jb] = 00, 10, 01, 11
-  f32x16 gW1a = zero16(), gW1b = zero16(), gW1c = zero16(), gW1d = zero16();
-  f32x16 gW3a = zero16(), gW3b = zero16();
-  float gb2 = 0.f, gb1 = 0.f;  // lane c: bias gradient of hidden column c
-  float s_pl = 0.f, s_vl = 0.f, s_kl = 0.f, s_cf = 0.f;
+  Grad64 g;
+  g.zero();
 
   if (tid0 < 32) {  // per-action constants (block level)
     const int k = tid0;
@@ -271,7 +492,6 @@ __global__ __launch_bounds__(Lay64<DP>::TNWV * 64, 1) void k_fused64_train(Fused
   constexpr int NGW = GR * per / 64;
   static_assert((GR * per) % 64 == 0, "gather assumes a whole number of 16-byte chunks per lane");
   f32x4 xr[NGW];
-  int nsrc[NGW];
 #pragma unroll
   for (int u = 0; u < NGW; ++u) {
     const int i = (tid0 & 63) + u * 64, rr = i / per, c = i - rr * per;
@@ -284,242 +504,73 @@ __global__ __launch_bounds__(Lay64<DP>::TNWV * 64, 1) void k_fused64_train(Fused
 #else
   for (int tile = widx; tile < ntiles; tile += nw) {
 #endif
-    const int lane = opaque(tid0) & 63;
-    const int r = lane & 31, h = lane >> 5;
-    const int row0 = tile * GR;
-    // ---- the observation rows of this tile were fetched during the previous tile ----
-#pragma unroll
-    for (int u = 0; u < NGW; ++u) {
-      const int i = lane + u * 64, rr = i / per, c = i - rr * per;
-      *reinterpret_cast<f32x4*>(&lds[wb + L::X + rr * ldx + 4 * c]) = xr[u];
-    }
-    const int nrow0 = (tile + nw) * GR;
-#pragma unroll
-    for (int u = 0; u < NGW; ++u) {
-      const int rr = (lane + u * 64) / per;
-      nsrc[u] = (tile + nw < ntiles && nrow0 + rr < a.count) ? a.rows[nrow0 + rr] : -1;
-    }
-    // operands of the loss stage (two lanes per row), in flight while the forward pass runs
-    const bool llive = row0 + r < a.count;
-    float l_adv = 0.f, l_old = 0.f, l_act[16];
-    {
-      const unsigned src = llive ? (unsigned)a.rows[row0 + r] : 0u;
-      if (net == 0) {
-        const float* arow = a.actions + (size_t)src * a.A + h;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) l_act[j] = (2 * j + h < a.A && llive) ? arow[2 * j] : 0.f;
-        if (llive) { l_adv = a.adv[src]; l_old = a.old_logp[src]; }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) l_act[j] = 0.f;
-        if (llive) l_old = a.ret[src];
-      }
-    }
-    tile64_forward_ldsw<DP>(wb, lane);
-
-    // ---- loss: two lanes per row (q = action parity); dL/d(head) -> head tile, zero padded ----
-    {
-      const int rr = r, q = h;
-      const bool live = llive;
-      const int db = opaque(wb + L::DO + rr * FLDO + q);
-      const int cb = opaque(L::TCST + q);
-      const int gb = opaque(wb + L::GACC + q);
-      const int A = a.A;
-      if (net == 0) {
-        float lp = 0.f;
-        float dk[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          float d = 0.f;
-          if (2 * j + q < A && live) {
-            d = l_act[j] - (lds[db + 2 * j] + lds[cb + 64 + 2 * j]);
-            lp += -(d * d) * (0.5f * lds[cb + 2 * j]) - lds[cb + 32 + 2 * j];
-          }
-          dk[j] = d;
-        }
-        lp += __shfl_xor(lp, 32, 64);
-        float g_logp = 0.f;
-        if (live) {
-          float adv = l_adv;
-          if (a.normalize && adv_on) adv = (adv - adv_mean) / (adv_sd + 1e-8f);
-          const float log_ratio = lp - l_old;
-          const float ratio = expf(log_ratio);
-          const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
-          const float s1 = adv * ratio, s2 = adv * fminf(fmaxf(ratio, lo), hi);
-          if (q == 0) {
-            s_pl += fminf(s1, s2);
-            s_cf += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
-            s_kl += (ratio - 1.0f) - log_ratio;
-          }
-          const float in_range = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
-          const float w1 = (s1 < s2) ? 1.f : ((s1 > s2) ? 0.f : 0.5f);
-          g_logp = -(w1 * adv + (1.0f - w1) * adv * in_range) * a.inv_bg * ratio;
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {  // k = 2j + q; wave-uniform trip count
-          const int k = 2 * j + q;
-          float gm = 0.f, gl = 0.f;
-          if (k < A && live) {
-            const float iv = lds[cb + 2 * j];
-            const float d = dk[j];
-            gm = g_logp * d * iv;
-            gl = g_logp * (d * d * iv - 1.0f);
-          }
-          lds[db + 2 * j] = gm;
-          if (2 * j < A) {  // wave-uniform: sum over the 32 rows (lanes with equal q)
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) {
-              gm += __shfl_xor(gm, o, 64);
-              gl += __shfl_xor(gl, o, 64);
-            }
-            if (r == 0) {
-              lds[gb + 2 * j] += gm;
-              lds[gb + 32 + 2 * j] += gl;
-            }
-          }
-        }
-      } else {
-        float dv = 0.f;
-        if (live && q == 0) {
-          const float v = lds[db] + lds[cb + 64], rt = l_old;
-          s_vl += (rt - v) * (rt - v);
-          dv = a.vf_coef * 2.0f * (v - rt) * a.inv_bg;
-        }
-        for (int j = 0; j < 16; ++j) lds[db + 2 * j] = (j == 0) ? dv : 0.f;
-        const float t = wave_sum(dv);
-        if (lane == 0) lds[gb] += t;
-      }
-    }
-
-    // ---- dW3 += dout^T . h2  (K = 32 rows) ----
-    {
-      const int ao = opaque(wb + L::DO + h * FLDO + r);
-      const int bo = opaque(wb + L::H2 + h * GLDH + r);
-#pragma unroll 4
-      for (int k = 0; k < GR; k += 2)
-        mfma_x1y2(gW3a, gW3b, lds[ao + k * FLDO], lds[bo + k * GLDH], lds[bo + k * GLDH + 32]);
-    }
-    // ---- dh2 = dout . W3 (K = 32) ; dz2 = dh2 * (1 - h2^2) in place ----
-    {
-      f32x16 c0 = zero16(), c1 = zero16();
-      gemm_lds_lds_r32<FLDO>(wb + L::DO, Wt::W3B, Wt::W3B + 4 * 256, W.head <= 16 ? 2 : 4,  // head columns beyond `head` are zero
-                             c0, c1, lane);
-      const int o = opaque(wb + L::H2 + 4 * h * GLDH + r);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float hv;
-        hv = lds[o + crc(i) * GLDH];      lds[o + crc(i) * GLDH] = c0[i] * (1.0f - hv * hv);
-        hv = lds[o + crc(i) * GLDH + 32]; lds[o + crc(i) * GLDH + 32] = c1[i] * (1.0f - hv * hv);
-      }
-    }
-    // ---- bias gradient of layer 2: column sums of dz2 (lane c <-> column c) ----
-    {
-      const int o = opaque(wb + L::H2 + lane);
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll 4
-      for (int rr = 0; rr < GR; rr += 2) {
-        s0 += lds[o + rr * GLDH];
-        s1 += lds[o + (rr + 1) * GLDH];
-      }
-      gb2 += s0 + s1;
-    }
-#pragma unroll
-    for (int u = 0; u < NGW; ++u) {  // next tile's observation rows: in flight during dW2 / dh1 / dW1
-      const int c = (lane + u * 64) % per;
-      xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (nsrc[u] >= 0) xr[u] = ldg16(a.obs, (unsigned)nsrc[u] * (unsigned)(DP * 4) + (unsigned)(c * 16));
-    }
-    // ---- dW2 += dz2^T . h1  (64 x 64, K = 32 rows) ----
-    {
-      const int ao = opaque(wb + L::H2 + h * GLDH + r);
-      const int bo = opaque(wb + L::H1 + h * GLDH + r);
-#pragma unroll 4
-      for (int k = 0; k < GR; k += 2)
-        mfma_x2y2(gW2a, gW2b, gW2c, gW2d, lds[ao + k * GLDH], lds[ao + k * GLDH + 32], lds[bo + k * GLDH],
-                  lds[bo + k * GLDH + 32]);
-    }
-    // ---- dh1 = dz2 . W2 (K = 64) ; dz1 = dh1 * (1 - h1^2) in place ----
-    {
-      f32x16 c0 = zero16(), c1 = zero16();
-      constexpr int nkg = GH / 8;
-      gemm_lds_lds_r32<GLDH>(wb + L::H2, Wt::W2B, Wt::W2B + nkg * 256, nkg, c0, c1, lane);
-      const int o = opaque(wb + L::H1 + 4 * h * GLDH + r);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float hv;
-        hv = lds[o + crc(i) * GLDH];      lds[o + crc(i) * GLDH] = c0[i] * (1.0f - hv * hv);
-        hv = lds[o + crc(i) * GLDH + 32]; lds[o + crc(i) * GLDH + 32] = c1[i] * (1.0f - hv * hv);
-      }
-    }
-    {
-      const int o = opaque(wb + L::H1 + lane);
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll 4
-      for (int rr = 0; rr < GR; rr += 2) {
-        s0 += lds[o + rr * GLDH];
-        s1 += lds[o + (rr + 1) * GLDH];
-      }
-      gb1 += s0 + s1;
-    }
-    // ---- dW1 += dz1^T . X  (64 x DP, K = 32 rows) ----
-    {
-      constexpr bool two = DP > 32;
-      const int ao = opaque(wb + L::H1 + h * GLDH + r);
-      const int c0 = (r < DP) ? r : 0;
-      const int c1 = (32 + r < DP) ? 32 + r : c0;
-      const int b0o = opaque(wb + L::X + h * ldx + c0), b1o = opaque(wb + L::X + h * ldx + c1);
-#pragma unroll 4
-      for (int k = 0; k < GR; k += 2) {
-        if (two)
-          mfma_x2y2(gW1a, gW1b, gW1c, gW1d, lds[ao + k * GLDH], lds[ao + k * GLDH + 32], lds[b0o + k * ldx],
-                    lds[b1o + k * ldx]);
-        else
-          mfma_x2y1(gW1a, gW1b, lds[ao + k * GLDH], lds[ao + k * GLDH + 32], lds[b0o + k * ldx]);
-      }
-    }
+    tile64_train<DP, true>(a, W, net, wb, L::TCST, tid0, a.rows, a.count, tile * GR,
+                           tile + nw < ntiles ? a.rows : nullptr, a.count, (tile + nw) * GR, xr, adv_mean, adv_sd, adv_on, g);
   }
 
   // ---- sum the block's waves through LDS (fixed order), then wave 0 writes the block slab ----
   const int lane = tid0 & 63;
   asm volatile("s_nop 15\n\ts_nop 3");  // last asm MFMA's D -> VALU read
   __syncthreads();                          // every wave has left its tile loop: the tile regions are free
-  auto block_sum16 = [&](f32x16& g) {
+  // Two rounds of five accumulator tiles: waves 1.. stage theirs in LDS ([wave-1][slot][16][64] floats; the tile
+  // regions and the weight mirror are dead by now), wave 0 adds them to its own in wave order.  (Ten separate
+  // store / barrier / add / barrier rounds, one per tile, cost 20 us of a 31 us launch at small minibatches.)
+  auto stage = [&](int slot, const f32x16& acc) {
     if (wave > 0) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) lds[(wave - 1) * 1024 + i * 64 + lane] = g[i];
+      for (int i = 0; i < 16; ++i) lds[((wave - 1) * 5 + slot) * 1024 + i * 64 + lane] = acc[i];
     }
-    __syncthreads();
+  };
+  auto fold = [&](int slot, f32x16& acc) {
     if (wave == 0) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        float v = g[i];
+        float x[NWV - 1];
 #pragma unroll
-        for (int w = 0; w < NWV - 1; ++w) v += lds[w * 1024 + i * 64 + lane];
-        g[i] = v;
+        for (int w = 0; w < NWV - 1; ++w) x[w] = lds[(w * 5 + slot) * 1024 + i * 64 + lane];
+        float v = acc[i];
+#pragma unroll
+        for (int w = 0; w < NWV - 1; ++w) v += x[w];
+        acc[i] = v;
       }
     }
-    __syncthreads();
   };
-  block_sum16(gW2a); block_sum16(gW2b); block_sum16(gW2c); block_sum16(gW2d);
-  block_sum16(gW1a); block_sum16(gW1b);
-  if (DP > 32) { block_sum16(gW1c); block_sum16(gW1d); }
-  block_sum16(gW3a); block_sum16(gW3b);
+  // head-bias / log_std sums of all waves: read before the staging overwrites the GACC regions
+  float b3s = 0.f, lss = 0.f;
+  if (wave == 0 && lane < 32) {
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+      b3s += lds[L::TW + w * L::WAVE + L::GACC + lane];
+      lss += lds[L::TW + w * L::WAVE + L::GACC + 32 + lane];
+    }
+  }
+  __syncthreads();
+  stage(0, g.W2a); stage(1, g.W2b); stage(2, g.W2c); stage(3, g.W2d); stage(4, g.W1a);
+  __syncthreads();
+  fold(0, g.W2a); fold(1, g.W2b); fold(2, g.W2c); fold(3, g.W2d); fold(4, g.W1a);
+  __syncthreads();
+  stage(0, g.W1b); stage(1, g.W3a); stage(2, g.W3b);
+  if (DP > 32) { stage(3, g.W1c); stage(4, g.W1d); }
+  __syncthreads();
+  fold(0, g.W1b); fold(1, g.W3a); fold(2, g.W3b);
+  if (DP > 32) { fold(3, g.W1c); fold(4, g.W1d); }
+  __syncthreads();
   {
     if (wave > 0) {
-      lds[(wave - 1) * 128 + lane] = gb2;
-      lds[(wave - 1) * 128 + 64 + lane] = gb1;
+      lds[(wave - 1) * 128 + lane] = g.b2;
+      lds[(wave - 1) * 128 + 64 + lane] = g.b1;
     }
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
       for (int w = 0; w < NWV - 1; ++w) {
-        gb2 += lds[w * 128 + lane];
-        gb1 += lds[w * 128 + 64 + lane];
+        g.b2 += lds[w * 128 + lane];
+        g.b1 += lds[w * 128 + 64 + lane];
       }
     }
   }
   {  // loss statistics through the slab (fixed order; no contended atomics)
-    const float t0 = wave_sum(s_pl), t1 = wave_sum(s_vl), t2 = wave_sum(s_kl), t3 = wave_sum(s_cf);
+    const float t0 = wave_sum(g.pl), t1 = wave_sum(g.vl), t2 = wave_sum(g.kl), t3 = wave_sum(g.cf);
     __syncthreads();  // the bias partials above have been consumed
     if (lane == 0) {
       lds[wave * 4 + 0] = t0; lds[wave * 4 + 1] = t1; lds[wave * 4 + 2] = t2; lds[wave * 4 + 3] = t3;
@@ -534,28 +585,22 @@ __global__ __launch_bounds__(Lay64<DP>::TNWV * 64, 1) void k_fused64_train(Fused
     for (int w = 0; w < NWV; ++w) t += lds[w * 4 + lane];
     slab[s64_st() + lane] = t;
   }
-  auto put = [&](int region, int t, const f32x16& g) {
+  auto put = [&](int region, int t, const f32x16& acc) {
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = g[4 * qd + e];
+      for (int e = 0; e < 4; ++e) v[e] = acc[4 * qd + e];
       stg16(slab + region, (unsigned)((t * 4 + qd) * 64 + lane) * 16u, v);
     }
   };
-  put(s64_w2(), 0, gW2a); put(s64_w2(), 2, gW2b); put(s64_w2(), 1, gW2c); put(s64_w2(), 3, gW2d);  // t = ib*2 + jb
-  put(s64_w1(), 0, gW1a); put(s64_w1(), 2, gW1b);
-  if (DP > 32) { put(s64_w1(), 1, gW1c); put(s64_w1(), 3, gW1d); }
-  put(s64_w3(), 0, gW3a); put(s64_w3(), 1, gW3b);
-  slab[s64_b2() + lane] = gb2;
-  slab[s64_b1() + lane] = gb1;
-  if (lane < 32) {  // head-bias / log_std sums of all waves (their GACC regions were not touched by the reduction)
-    float b3s = 0.f, lss = 0.f;
-#pragma unroll
-    for (int w = 0; w < NWV; ++w) {
-      b3s += lds[L::TW + w * L::WAVE + L::GACC + lane];
-      lss += lds[L::TW + w * L::WAVE + L::GACC + 32 + lane];
-    }
+  put(s64_w2(), 0, g.W2a); put(s64_w2(), 2, g.W2b); put(s64_w2(), 1, g.W2c); put(s64_w2(), 3, g.W2d);  // t = ib*2 + jb
+  put(s64_w1(), 0, g.W1a); put(s64_w1(), 2, g.W1b);
+  if (DP > 32) { put(s64_w1(), 1, g.W1c); put(s64_w1(), 3, g.W1d); }
+  put(s64_w3(), 0, g.W3a); put(s64_w3(), 1, g.W3b);
+  slab[s64_b2() + lane] = g.b2;
+  slab[s64_b1() + lane] = g.b1;
+  if (lane < 32) {  // head-bias / log_std sums of all waves (summed before the reduction reused their LDS)
     slab[s64_b3() + lane] = b3s;
     slab[s64_ls() + lane] = lss;
   }
