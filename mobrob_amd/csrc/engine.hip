@@ -127,6 +127,10 @@ struct mobrob_ppo_engine {
   int cur_count = 0;
   bool grad_pending = false;
   ncclComm_t comm = nullptr;  // RCCL communicator of the data-parallel job (mobrob_ppo_comm_init)
+  // norm records of the reduction kernels (kernels_fused.h: block_norm_records): used inside mobrob_ppo_train only
+  double* norm_rec_sum = nullptr; int* norm_rec_t = nullptr; int* fold_idx_dev = nullptr;
+  int fold_start[14] = {0};
+  bool use_norm_records = false;
   // persistent small-batch update (kernels_train_small.h): one launch per epoch for 64-wide nets, minibatch <= 160 rows
   float* sched_dev = nullptr;              // [nmb][2] per-step Adam scalars of the epoch being enqueued
   unsigned long long* mail = nullptr;      // [2][2][16] hand-off words of the two workgroups
@@ -396,6 +400,46 @@ int fused_init(mobrob_ppo_engine* e) {
   }
   CHK(dalloc(e, &f.stamps, 32));
   if (!e->plan_only) HIPC(fused_set_lds_attr(f));
+  {  // norm-record tables: which (network, block, slot) of the reduction kernel holds which tensor -- emulated here
+    // exactly as block_norm_records forms them (per wave: tensors by first occurrence; adjacent equal ones merge)
+    const int nb = cdiv(f.slab_floats, 256);
+    CHK(dalloc(e, &e->norm_rec_sum, (size_t)2 * nb * kNormRec));
+    CHK(dalloc(e, &e->norm_rec_t, (size_t)2 * nb * kNormRec));
+    CHK(dalloc(e, &e->fold_idx_dev, (size_t)2 * nb * kNormRec));
+    SlabReduceArgs s256{};
+    Slab64ReduceArgs s64{};
+    for (int i = 0; i < 14; ++i) { s256.offs[i] = e->offs[i]; s64.offs[i] = e->offs[i]; }
+    s256.D = e->D; s256.Dp = e->Dp; s256.A = e->A; s256.h16 = e->A <= 16; s256.P = e->P; s256.slab_floats = f.slab_floats;
+    s64.D = e->D; s64.A = e->A; s64.P = e->P;
+    std::vector<std::vector<int>> per_tensor(13);
+    for (int net = 0; net < 2; ++net)
+      for (int b = 0; b < nb; ++b) {
+        std::vector<int> recs;  // tensors of this block's records, in order
+        for (int w = 0; w < 4; ++w) {
+          std::vector<int> wave;
+          for (int l = 0; l < 64; ++l) {
+            const int p = b * 256 + w * 64 + l;
+            const int dst = p < f.slab_floats ? (H == 64 ? slab64_to_canonical(s64, net, p) : slab_to_canonical(s256, net, p)) : -1;
+            const int t = tensor_of_canonical(e->offs, e->P, dst);
+            if (t >= 0 && std::find(wave.begin(), wave.end(), t) == wave.end()) wave.push_back(t);
+          }
+          for (int t : wave)
+            if (recs.empty() || recs.back() != t) recs.push_back(t);
+        }
+        if ((int)recs.size() > kNormRec) return fail(MOBROB_ERR_INVALID, "norm record table: %zu tensors in one reduction block", recs.size());
+        for (size_t k = 0; k < recs.size(); ++k) per_tensor[recs[k]].push_back((net * nb + b) * kNormRec + (int)k);
+      }
+    std::vector<int> fold;
+    for (int t = 0; t < 13; ++t) {
+      e->fold_start[t] = (int)fold.size();
+      fold.insert(fold.end(), per_tensor[t].begin(), per_tensor[t].end());
+    }
+    e->fold_start[13] = (int)fold.size();
+    if (fold.size() > 1024) return fail(MOBROB_ERR_INVALID, "norm record table too large (%zu)", fold.size());
+    if (!e->plan_only)
+      HIPC(hipMemcpyAsync(e->fold_idx_dev, fold.data(), fold.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    if (!e->plan_only) HIPC(hipStreamSynchronize(e->stream));
+  }
   return MOBROB_OK;
 }
 
@@ -423,6 +467,7 @@ void fused64_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, floa
   for (int i = 0; i < 14; ++i) s.offs[i] = e->offs[i];
   s.D = e->D; s.A = e->A; s.ent_coef = (float)e->cfg.ent_coef; s.b_local = (float)B; s.inv_bg = inv_bg;
   s.sums = e->grads + e->P;
+  s.rec_sum = e->use_norm_records ? e->norm_rec_sum : nullptr; s.rec_t = e->norm_rec_t;
   hipLaunchKernelGGL(k_slab64_reduce, dim3(cdiv(s64_size(), 256), 2), dim3(256), 0, e->stream, s);
 }
 
@@ -450,6 +495,7 @@ void fused_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, float 
   for (int i = 0; i < 14; ++i) s.offs[i] = e->offs[i];
   s.D = e->D; s.Dp = e->Dp; s.A = e->A; s.h16 = e->A <= 16; s.ent_coef = (float)e->cfg.ent_coef; s.b_local = (float)B; s.inv_bg = inv_bg;
   s.sums = e->grads + e->P;
+  s.rec_sum = e->use_norm_records ? e->norm_rec_sum : nullptr; s.rec_t = e->norm_rec_t;
   hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(f.slab_floats, 256), 2), dim3(256), 0, e->stream, s);
 }
 
@@ -1472,12 +1518,18 @@ int mobrob_ppo_minibatch_apply(mobrob_ppo_engine_t* e) {
   st.stats_row = stats_row; st.loss_sums = e->grads + e->P; st.log_std = Pp(e, T_LOGSTD);
   st.ent_coef = (float)e->cfg.ent_coef; st.vf_coef = (float)e->cfg.vf_coef;
   st.inv_bg = 1.0f / (float)((int64_t)e->cur_count * e->cfg.world_size); st.n_act = e->A;
-  hipLaunchKernelGGL(k_sqnorm_chunks, dim3(e->nchunks), dim3(256), 0, e->stream, e->grads, e->chunks_dev,
-                     e->chunk_partial, st);
+  const bool records = e->use_norm_records && e->fused.enabled;  // the reduction kernel of this step left the norm records
+  if (!records)
+    hipLaunchKernelGGL(k_sqnorm_chunks, dim3(e->nchunks), dim3(256), 0, e->stream, e->grads, e->chunks_dev,
+                       e->chunk_partial, st);
   AdamPackArgs a{};
   fill_adam_pack_args(e, a);
   a.step_size = (float)(e->cfg.learning_rate / bc1);
   a.bc2_sqrt = (float)std::sqrt(bc2);
+  if (records) {
+    a.partial = e->norm_rec_sum; a.fold_idx = e->fold_idx_dev; a.st = st;
+    for (int i = 0; i < 14; ++i) a.fold_start[i] = e->fold_start[i];
+  }
   a.stats_row = stats_row;
   a.loss_sums_zero = e->fused.enabled ? e->grads + e->P : nullptr;
   hipLaunchKernelGGL(k_adam_pack, dim3(cdiv(e->P, 256)), dim3(256), 0, e->stream, a);
@@ -1561,6 +1613,13 @@ int mobrob_ppo_train_enqueue(mobrob_ppo_engine_t* e, const int64_t* perms) {
     }
     HIPC(hipMemcpyAsync(e->sched_dev, e->sched_host.data(), e->sched_host.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
   }
+  // 64-wide nets only: ~90 records.  At 2x256 the table has 712 records, every k_adam_pack block pays for folding
+  // them and the reduction kernel for forming them: measured 12.9 instead of 11.4 ms per iteration (A/B on one box).
+  struct RecordsOn {  // nothing can touch the gradient between reduction and clip inside this loop
+    mobrob_ppo_engine* e;
+    explicit RecordsOn(mobrob_ppo_engine* e_) : e(e_) { e->use_norm_records = e->fused.enabled && e->fused.H == 64 && getenv("MOBROB_NO_NORM_RECORDS") == nullptr; }
+    ~RecordsOn() { e->use_norm_records = false; }
+  } records_on(e);
   for (int ep = 0; ep < e->cfg.n_epochs; ++ep) {
     CHK(mobrob_ppo_epoch_begin(e, perms ? perms + (size_t)ep * total : nullptr));
     if (small) {

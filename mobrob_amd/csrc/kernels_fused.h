@@ -128,7 +128,7 @@ __device__ __forceinline__ void stg16(void* base, unsigned byte_off, const f32x4
   *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 // C layout: element i of a 32x32 accumulator sits at row crc(i) + 4*h, column r of the tile
-__device__ __forceinline__ constexpr int crc(int i) { return (i & 3) + 8 * (i >> 2); }
+__host__ __device__ __forceinline__ constexpr int crc(int i) { return (i & 3) + 8 * (i >> 2); }
 
 // acc[cb][rb] += A[rb*32 + 0..31][0..8*nkg) . Bpacked[cb]  for this wave's two 32-column blocks.
 // a_off: LDS offset of the A tile (row stride lda floats); Bp0/Bp1: packed fragments [nkg][64] of the two blocks.
@@ -999,10 +999,62 @@ struct SlabReduceArgs {
   int h16;        // dW3 region written by the 16x16x4 variant (k_fused_train<DP, true>)
   float ent_coef, b_local, inv_bg;
   float* sums;    // sums[4] = rows (for the stats finaliser)
+  double* rec_sum; int* rec_t;  // optional [2][gridDim.x][kNormRec]: sums of squares of what each block produced, by tensor
 };
 
+// ------------------------------------------------------------------------------------------------
+// clip_grad_norm_ needs the sum of squares of every gradient tensor.  Inside mobrob_ppo_train (single rank, nothing
+// touches the gradient between reduction and clip) the reduction kernels produce them on the fly instead of a
+// separate k_sqnorm_chunks launch: every 256-thread block records (tensor, sum of squares in float64) of the
+// entries it produced -- one record per block, except the last block of a network, which holds the small tensors
+// (<= kNormRec of them).  The table layout is static, so the host lists for each tensor which records to fold, in
+// order (norm_fold_table), and k_adam_pack folds them like it folds chunk partials.
+// ------------------------------------------------------------------------------------------------
+constexpr int kNormRec = 4;
+__host__ __device__ inline int tensor_of_canonical(const int* offs, int P, int dst) {
+  if (dst < 0 || dst >= P) return -1;
+  int t = 0;
+  for (int k = 1; k < 13; ++k) t += (dst >= offs[k]) ? 1 : 0;
+  return t;
+}
+// records of one wave in lane order: first occurrence of a tensor opens a record (<= kNormRec distinct tensors)
+__device__ __forceinline__ void block_norm_records(int t, float val, double* rec_sum, int* rec_t) {
+  __shared__ double sc[4 * kNormRec];
+  __shared__ int sct[4 * kNormRec];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double sq = t >= 0 ? (double)val * (double)val : 0.0;
+  int nrec = 0;
+  unsigned long long todo = __ballot(t >= 0);
+  while (todo != 0ull) {
+    const int first = __ffsll((long long)todo) - 1;
+    const int tsel = __shfl(t, first, 64);
+    const bool m = t == tsel;
+    const double sum = wave_sum_d(m ? sq : 0.0);
+    if (lane == 0 && nrec < kNormRec) { sc[wave * kNormRec + nrec] = sum; sct[wave * kNormRec + nrec] = tsel; }
+    ++nrec;
+    todo &= ~__ballot(m);
+  }
+  if (lane == 0)
+    for (int k = nrec; k < kNormRec; ++k) sct[wave * kNormRec + k] = -1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int n = 0, cur = -1;
+    double acc = 0.0;
+    for (int k = 0; k < 4 * kNormRec; ++k) {
+      const int tt = sct[k];
+      if (tt < 0) continue;
+      if (tt == cur) { acc += sc[k]; continue; }
+      if (cur >= 0 && n < kNormRec) { rec_sum[n] = acc; rec_t[n] = cur; ++n; }
+      cur = tt;
+      acc = sc[k];
+    }
+    if (cur >= 0 && n < kNormRec) { rec_sum[n] = acc; rec_t[n] = cur; ++n; }
+    for (; n < kNormRec; ++n) rec_t[n] = -1;
+  }
+}
+
 // slab position -> canonical gradient index of network `net` (or -1 for padding / unused positions)
-__device__ __forceinline__ int slab_to_canonical(const SlabReduceArgs& s, int net, int p) {
+__host__ __device__ __forceinline__ int slab_to_canonical(const SlabReduceArgs& s, int net, int p) {
   const int T_W1 = net == 0 ? 1 : 5, T_B1 = net == 0 ? 2 : 6, T_W2 = net == 0 ? 3 : 7, T_B2 = net == 0 ? 4 : 8;
   const int T_W3 = net == 0 ? 9 : 11, T_B3 = net == 0 ? 10 : 12;
   const int head = net == 0 ? s.A : 1;
@@ -1058,24 +1110,29 @@ __global__ __launch_bounds__(256) void k_slab_reduce(SlabReduceArgs s) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int net = blockIdx.y;
   if (p == 0 && net == 0) s.sums[4] = s.b_local;
-  if (p >= s.slab_floats) return;
-  const int dst = slab_to_canonical(s, net, p);
-  if (dst < 0) return;
-  const float* src = s.slabs + (size_t)net * s.slab_floats + p;
-  const size_t stride = 2 * (size_t)s.slab_floats;
-  const int n = (s.nslabs - net + 1) / 2;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int w = 0;
-  for (; w + 4 <= n; w += 4) {
-    a0 += src[(size_t)w * stride];
-    a1 += src[(size_t)(w + 1) * stride];
-    a2 += src[(size_t)(w + 2) * stride];
-    a3 += src[(size_t)(w + 3) * stride];
+  const int dst = p < s.slab_floats ? slab_to_canonical(s, net, p) : -1;
+  float acc = 0.f;
+  if (dst >= 0) {
+    const float* src = s.slabs + (size_t)net * s.slab_floats + p;
+    const size_t stride = 2 * (size_t)s.slab_floats;
+    const int n = (s.nslabs - net + 1) / 2;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int w = 0;
+    for (; w + 4 <= n; w += 4) {
+      a0 += src[(size_t)w * stride];
+      a1 += src[(size_t)(w + 1) * stride];
+      a2 += src[(size_t)(w + 2) * stride];
+      a3 += src[(size_t)(w + 3) * stride];
+    }
+    for (; w < n; ++w) a0 += src[(size_t)w * stride];
+    acc = (a0 + a1) + (a2 + a3);
+    if (dst < s.offs[1]) acc += s.ent_coef * (-s.b_local) * s.inv_bg;  // entropy bonus gradient on log_std
+    s.grads[dst] = acc;
   }
-  for (; w < n; ++w) a0 += src[(size_t)w * stride];
-  float acc = (a0 + a1) + (a2 + a3);
-  if (dst < s.offs[1]) acc += s.ent_coef * (-s.b_local) * s.inv_bg;  // entropy bonus gradient on log_std
-  s.grads[dst] = acc;
+  if (s.rec_sum != nullptr) {
+    const size_t b = ((size_t)net * gridDim.x + blockIdx.x) * kNormRec;
+    block_norm_records(tensor_of_canonical(s.offs, s.P, dst), acc, s.rec_sum + b, s.rec_t + b);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1344,6 +1401,19 @@ struct NormChunk { int tensor, start, end, pad; };
 struct StatsArgs {
   float* stats_row; const float* loss_sums; const float* log_std; float ent_coef, vf_coef, inv_bg; int n_act;
 };
+// logged loss statistics of one optimizer step from the loss sums behind the gradient vector
+__device__ __forceinline__ void stats_row_from_sums(const StatsArgs& st) {
+  const float pl = -st.loss_sums[0] * st.inv_bg;
+  const float vl = st.loss_sums[1] * st.inv_bg;
+  float ent = 0.f;
+  for (int k = 0; k < st.n_act; ++k) ent += (0.5f + 0.91893853320467274178f) + logf(expf(st.log_std[k]));
+  const float el = -(ent * st.loss_sums[4]) * st.inv_bg;
+  st.stats_row[0] = pl; st.stats_row[1] = vl; st.stats_row[2] = el;
+  st.stats_row[3] = pl + st.ent_coef * el + st.vf_coef * vl;
+  st.stats_row[4] = st.loss_sums[2] * st.inv_bg;
+  st.stats_row[5] = st.loss_sums[3] * st.inv_bg;
+  st.stats_row[7] = 0.f;
+}
 // thread `tid` of 256: its share of the sum of squares of one chunk (float64).  Shared by k_sqnorm_chunks and the
 // persistent small-batch kernel (kernels_train_small.h) so that both sum in exactly the same order.
 __device__ __forceinline__ double chunk_sumsq_thread(const float* __restrict__ g, const NormChunk c, int tid) {
@@ -1357,18 +1427,7 @@ __device__ __forceinline__ double chunk_sumsq_thread(const float* __restrict__ g
 __global__ __launch_bounds__(256) void k_sqnorm_chunks(const float* __restrict__ g, const NormChunk* __restrict__ chunks,
                                                        double* __restrict__ partial, StatsArgs st) {
   __shared__ double sc[16];
-  if (blockIdx.x == 0 && threadIdx.x == 0 && st.stats_row != nullptr) {  // loss statistics (pre-update log_std)
-    const float pl = -st.loss_sums[0] * st.inv_bg;
-    const float vl = st.loss_sums[1] * st.inv_bg;
-    float ent = 0.f;
-    for (int k = 0; k < st.n_act; ++k) ent += (0.5f + 0.91893853320467274178f) + logf(expf(st.log_std[k]));
-    const float el = -(ent * st.loss_sums[4]) * st.inv_bg;
-    st.stats_row[0] = pl; st.stats_row[1] = vl; st.stats_row[2] = el;
-    st.stats_row[3] = pl + st.ent_coef * el + st.vf_coef * vl;
-    st.stats_row[4] = st.loss_sums[2] * st.inv_bg;
-    st.stats_row[5] = st.loss_sums[3] * st.inv_bg;
-    st.stats_row[7] = 0.f;
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && st.stats_row != nullptr) stats_row_from_sums(st);  // pre-update log_std
   const double tot = block_sum_d(chunk_sumsq_thread(g, chunks[blockIdx.x], threadIdx.x), sc);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
@@ -1377,6 +1436,7 @@ struct AdamPackArgs {
   float* p; const float* g; float* m; float* v; int P;
   float* g_out;  // the same vector, writable (persistent small-batch kernel: it produces the gradient itself)
   const NormChunk* chunks; const double* partial; int nchunks;
+  const int* fold_idx; int fold_start[14];  // non-null: `partial` is a record table; tensor t folds partial[fold_idx[k]], k in [fold_start[t], fold_start[t+1])
   float max_norm, step_size, bc2_sqrt, beta1, beta2, eps;
   int offs[14];
   int D, Dp, A, Ap, H1, H2, G1, G2;
@@ -1386,6 +1446,7 @@ struct AdamPackArgs {
   float* fW1f[2]; float* fW2f[2]; float* fW3f[2]; float* fW3h[2]; float* fW2b[2]; float* fW3b[2]; float* fb1s[2]; float* fb2s[2];
   float* stats_row;  // [6] <- total gradient norm
   float* loss_sums_zero;  // fused path: the 8 loss accumulators are re-zeroed here instead of by a memset launch
+  StatsArgs st;           // st.stats_row != null: this kernel also writes the step's loss statistics (no k_sqnorm_chunks launch)
 };
 
 __device__ __forceinline__ int pack_fwd_idx(int n, int k, int KG) {
@@ -1445,23 +1506,35 @@ __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, fl
 }
 
 __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
-  __shared__ double part[256];
+  __shared__ double part[1024];
   __shared__ int tens[256];
-  __shared__ float coef_s, total_s;
-  for (int c = threadIdx.x; c < a.nchunks; c += blockDim.x) {  // one parallel round trip; the serial fold below is LDS only
-    part[c] = a.partial[c];
-    tens[c] = a.chunks[c].tensor;
-  }
-  __syncthreads();
-  // total norm = norm of per-tensor norms (torch.norm(torch.stack(norms))).  One thread per tensor folds that
-  // tensor's chunk partials in chunk order and takes the float64 square root (a software routine: thirteen of them
-  // one after the other were half of this kernel), thread 0 then adds the thirteen squares in tensor order.
   __shared__ float nts[16];
-  if (threadIdx.x < 13) {
-    double ts = 0.0;
-    for (int c = 0; c < a.nchunks; ++c)
-      if (tens[c] == (int)threadIdx.x) ts += part[c];
-    nts[threadIdx.x] = (float)sqrt(ts);
+  __shared__ float coef_s, total_s;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.st.stats_row != nullptr) stats_row_from_sums(a.st);  // pre-update log_std
+  if (a.fold_idx != nullptr) {  // norm records of the reduction kernel, listed per tensor by the host
+    const int nrec = a.fold_start[13];
+    for (int c = threadIdx.x; c < nrec; c += blockDim.x) part[c] = a.partial[a.fold_idx[c]];
+    __syncthreads();
+    if (threadIdx.x < 13) {
+      double ts = 0.0;
+      for (int c = a.fold_start[threadIdx.x]; c < a.fold_start[threadIdx.x + 1]; ++c) ts += part[c];
+      nts[threadIdx.x] = (float)sqrt(ts);
+    }
+  } else {
+    for (int c = threadIdx.x; c < a.nchunks; c += blockDim.x) {  // one parallel round trip; the serial fold below is LDS only
+      part[c] = a.partial[c];
+      tens[c] = a.chunks[c].tensor;
+    }
+    __syncthreads();
+    // total norm = norm of per-tensor norms (torch.norm(torch.stack(norms))).  One thread per tensor folds that
+    // tensor's chunk partials in chunk order and takes the float64 square root (a software routine: thirteen of them
+    // one after the other were half of this kernel), thread 0 then adds the thirteen squares in tensor order.
+    if (threadIdx.x < 13) {
+      double ts = 0.0;
+      for (int c = 0; c < a.nchunks; ++c)
+        if (tens[c] == (int)threadIdx.x) ts += part[c];
+      nts[threadIdx.x] = (float)sqrt(ts);
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {

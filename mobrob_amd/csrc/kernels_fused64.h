@@ -614,8 +614,9 @@ struct Slab64ReduceArgs {
   int D, A;
   float ent_coef, b_local, inv_bg;
   float* sums;
+  double* rec_sum; int* rec_t;  // optional norm records (block_norm_records, kernels_fused.h)
 };
-__device__ __forceinline__ int slab64_to_canonical(const Slab64ReduceArgs& s, int net, int p) {
+__host__ __device__ __forceinline__ int slab64_to_canonical(const Slab64ReduceArgs& s, int net, int p) {
   const int T_W1 = net == 0 ? 1 : 5, T_B1 = net == 0 ? 2 : 6, T_W2 = net == 0 ? 3 : 7, T_B2 = net == 0 ? 4 : 8;
   const int T_W3 = net == 0 ? 9 : 11, T_B3 = net == 0 ? 10 : 12;
   const int head = net == 0 ? s.A : 1;
@@ -657,24 +658,29 @@ __global__ __launch_bounds__(256) void k_slab64_reduce(Slab64ReduceArgs s) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int net = blockIdx.y;
   if (p == 0 && net == 0) s.sums[4] = s.b_local;
-  if (p >= s64_size()) return;
-  const int dst = slab64_to_canonical(s, net, p);
-  if (dst < 0) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // blocks of this network: net, net+2, ...
-  const float* src = s.slabs + (size_t)net * s64_size() + p;
-  const size_t stride = 2 * (size_t)s64_size();
-  const int n = (s.nblocks - net + 1) / 2;
-  int w = 0;
-  for (; w + 4 <= n; w += 4) {
-    a0 += src[(size_t)w * stride];
-    a1 += src[(size_t)(w + 1) * stride];
-    a2 += src[(size_t)(w + 2) * stride];
-    a3 += src[(size_t)(w + 3) * stride];
+  const int dst = p < s64_size() ? slab64_to_canonical(s, net, p) : -1;
+  float acc = 0.f;
+  if (dst >= 0) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // blocks of this network: net, net+2, ...
+    const float* src = s.slabs + (size_t)net * s64_size() + p;
+    const size_t stride = 2 * (size_t)s64_size();
+    const int n = (s.nblocks - net + 1) / 2;
+    int w = 0;
+    for (; w + 4 <= n; w += 4) {
+      a0 += src[(size_t)w * stride];
+      a1 += src[(size_t)(w + 1) * stride];
+      a2 += src[(size_t)(w + 2) * stride];
+      a3 += src[(size_t)(w + 3) * stride];
+    }
+    for (; w < n; ++w) a0 += src[(size_t)w * stride];
+    acc = (a0 + a1) + (a2 + a3);
+    if (dst < s.offs[1]) acc += s.ent_coef * (-s.b_local) * s.inv_bg;
+    s.grads[dst] = acc;
   }
-  for (; w < n; ++w) a0 += src[(size_t)w * stride];
-  float acc = (a0 + a1) + (a2 + a3);
-  if (dst < s.offs[1]) acc += s.ent_coef * (-s.b_local) * s.inv_bg;
-  s.grads[dst] = acc;
+  if (s.rec_sum != nullptr) {
+    const size_t b = ((size_t)net * gridDim.x + blockIdx.x) * kNormRec;
+    block_norm_records(tensor_of_canonical(s.offs, s.P, dst), acc, s.rec_sum + b, s.rec_t + b);
+  }
 }
 
 // ---- rollout-time forward + sampling for 64-wide nets: one wave per 32-row tile and network ----

@@ -4,7 +4,18 @@ usage: python profiles/tools/pmc_traffic.py <fetch_dir> <write_dir> > profiles/r
 Corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB-ish
 units of 1 KB; FETCH_SIZE on gfx950 reports half of the bytes of coalesced streaming reads -> x2.
 """
-import collections, csv, glob, json, statistics, sys
+import collections, csv, glob, hashlib, json, os, statistics, sys
+
+
+def csrc_sha256():
+    """Fingerprint of the kernel sources the profile was taken on (same function as bench.csrc_sha256)."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "mobrob_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def load(d):
@@ -20,6 +31,7 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
                  "`python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline`, MI355X",
        "note": "FETCH_SIZE on gfx950 reports 1/2 of the bytes of coalesced streaming reads "
                "(MI355X_MICROARCH.md HBM section): corrected = 2 x FETCH_SIZE. WRITE_SIZE is exact.",
+       "csrc_sha256": csrc_sha256(),
        "kernels": {}}
 for k in fetch:
     if not k.startswith(('void mobrob', 'mobrob')):
