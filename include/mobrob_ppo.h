@@ -259,6 +259,25 @@ int mobrob_ppo_comm_init(mobrob_ppo_engine_t* e, const uint8_t* id128);
 int mobrob_ppo_comm_destroy(mobrob_ppo_engine_t* e);
 int mobrob_ppo_train_dp(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_allreduce_fn fn, void* ctx);
 
+/* Hyper-parameters that SB3 lets change or that the reference YAMLs never set, without growing the config struct.
+ * `ppo_kwargs` are splatted into stable_baselines3.PPO verbatim (/root/reference/src/mobrob/rl_control/ppo.py:58, README.md:49):
+ *   LEARNING_RATE / CLIP_RANGE  the value of a schedule for the coming PPO.train() (SB3 evaluates callables of
+ *                               `progress_remaining` once per train())
+ *   CLIP_RANGE_VF               value-function clipping: the loss uses old_value + clamp(value - old_value, +-c);
+ *                               negative = None (default)
+ *   TARGET_KL                   early stop: when a minibatch's approx_kl > 1.5 * target, its optimizer step and the rest
+ *                               of train() are dropped (single-rank update); <= 0 = None (default)
+ *   ENT_COEF / VF_COEF          loss coefficients */
+enum {
+  MOBROB_HYPER_LEARNING_RATE = 0, MOBROB_HYPER_CLIP_RANGE = 1, MOBROB_HYPER_CLIP_RANGE_VF = 2, MOBROB_HYPER_TARGET_KL = 3,
+  MOBROB_HYPER_ENT_COEF = 4, MOBROB_HYPER_VF_COEF = 5
+};
+int mobrob_ppo_set_hyper(mobrob_ppo_engine_t* e, int32_t which, double value);
+/* Of the latest mobrob_ppo_train / train_enqueue: epochs started (SB3's `_n_updates` increment), whether target_kl
+ * stopped it, optimizer steps applied. */
+int mobrob_ppo_last_train_info(const mobrob_ppo_engine_t* e, int32_t* epochs_started, int32_t* stopped_early,
+                               int32_t* steps_applied);
+
 /* Whole PPO.train(): n_epochs x ceil(T*N / batch) optimizer steps.  perms = n_epochs concatenated
  * env-major permutations of range(T*N) (what np.random.permutation would have produced), or NULL ->
  * counter-based Feistel permutations keyed by (seed, rank, update counter).  world_size must be 1. */

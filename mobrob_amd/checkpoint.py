@@ -275,9 +275,9 @@ def save_zip(path, *, params, optimizer, hyper, obs_dim, act_dim, net_arch=None,
     for k in ("n_steps", "gamma", "gae_lambda", "ent_coef", "vf_coef", "max_grad_norm", "batch_size", "n_epochs"):
         data[k] = hyper[k]
     data["clip_range"] = float(hyper["clip_range"])
-    data["clip_range_vf"] = None
+    data["clip_range_vf"] = hyper.get("clip_range_vf")  # float or None (schedules are stored by their current value)
     data["normalize_advantage"] = bool(hyper.get("normalize_advantage", True))
-    data["target_kl"] = None
+    data["target_kl"] = hyper.get("target_kl")
     data["observation_space"] = box_entry(obs_low, obs_high)
     data["action_space"] = box_entry(act_low, act_high)
     data["n_envs"] = n_envs

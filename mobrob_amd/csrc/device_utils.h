@@ -50,6 +50,20 @@ __device__ __forceinline__ double block_sum_d(double v, double* scratch) {
   return r;
 }
 
+// value-loss term of one row [SB3 PPO.train]: without value clipping (clip_vf < 0, SB3's clip_range_vf = None)
+// sq = (ret - v)^2; with it the prediction is old_v + clamp(v - old_v, -clip_vf, clip_vf) and the gradient passes
+// where the clamp does (torch: inclusive at both ends).  g = d sq / d v.
+__device__ __forceinline__ void value_loss_terms(float v, float rt, float old_v, float clip_vf, float& sq, float& g) {
+  float vp = v, pass = 1.f;
+  if (clip_vf >= 0.f) {
+    const float d = v - old_v;
+    vp = old_v + fminf(fmaxf(d, -clip_vf), clip_vf);
+    pass = (d >= -clip_vf && d <= clip_vf) ? 1.f : 0.f;
+  }
+  sq = (rt - vp) * (rt - vp);
+  g = 2.0f * (vp - rt) * pass;
+}
+
 // ---- Philox4x32-10 (Salmon et al. 2011); counter-based, restated bit-exactly in tests ----------
 struct Philox4 {
   uint32_t x, y, z, w;

@@ -126,6 +126,9 @@ struct mobrob_ppo_engine {
   int stats_cap = 0, stats_n = 0;
   int cur_count = 0;
   bool grad_pending = false;
+  double clip_vf = -1.0;      // SB3 clip_range_vf (< 0: None); mobrob_ppo_set_hyper
+  double target_kl = -1.0;    // SB3 target_kl (< 0: None): early stop of PPO.train() when a minibatch's approx_kl > 1.5 target
+  int last_epochs_started = 0, last_stopped_early = 0, last_steps_applied = 0;  // of the latest mobrob_ppo_train*
   ncclComm_t comm = nullptr;  // RCCL communicator of the data-parallel job (mobrob_ppo_comm_init)
   // norm records of the reduction kernels (kernels_fused.h: block_norm_records): used inside mobrob_ppo_train only
   double* norm_rec_sum = nullptr; int* norm_rec_t = nullptr; int* fold_idx_dev = nullptr;
@@ -138,7 +141,7 @@ struct mobrob_ppo_engine {
   std::vector<float> sched_host;           // [n_epochs][nmb][2], kept alive until the copies have run
   unsigned long long small_steps = 0;      // optimizer steps ever enqueued through the persistent kernel (hand-off ids)
   // generic-path workspace
-  float *Xg = nullptr, *actg = nullptr, *lpg = nullptr, *advg = nullptr, *retg = nullptr;
+  float *Xg = nullptr, *actg = nullptr, *lpg = nullptr, *advg = nullptr, *retg = nullptr, *oldvg = nullptr;
   float *h1p = nullptr, *h2p = nullptr, *h1v = nullptr, *h2v = nullptr, *mu = nullptr, *vout = nullptr;
   float *dmu = nullptr, *dv = nullptr, *dz2p = nullptr, *dz1p = nullptr, *dz2v = nullptr, *dz1v = nullptr;
   float *pred_obs = nullptr, *pred_act = nullptr;
@@ -452,6 +455,7 @@ void fused64_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, floa
   a.rows = e->rows + start; a.count = B; a.log_std = e->params + e->offs[T_LOGSTD];
   a.advstat = e->advstat + 4 * (size_t)mb; a.normalize = e->cfg.normalize_advantage;
   a.clip = (float)e->cfg.clip_range; a.vf_coef = (float)e->cfg.vf_coef; a.ent_coef = (float)e->cfg.ent_coef;
+  a.clip_vf = (float)e->clip_vf; a.old_values = e->values;
   a.inv_bg = inv_bg; a.slabs = f.slabs; a.sums = e->grads + e->P;
   const int ntiles = cdiv(B, GR);
   const int grid = 2 * std::min(f.max_grid / 2, cdiv(ntiles, g_train_waves(e->Dp)));
@@ -480,6 +484,7 @@ void fused_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, float 
   a.rows = e->rows + start; a.count = B; a.log_std = e->params + e->offs[T_LOGSTD];
   a.advstat = e->advstat + 4 * (size_t)mb; a.normalize = e->cfg.normalize_advantage;
   a.clip = (float)e->cfg.clip_range; a.vf_coef = (float)e->cfg.vf_coef; a.ent_coef = (float)e->cfg.ent_coef;
+  a.clip_vf = (float)e->clip_vf; a.old_values = e->values;
   a.inv_bg = inv_bg; a.slabs = f.slabs; a.slab_floats = f.slab_floats; a.sums = e->grads + e->P;
   a.stamps = f.stamps;
   const int ntiles = cdiv(B, FR);
@@ -672,7 +677,7 @@ int engine_alloc(mobrob_ppo_engine* e) {
   CHK(dalloc(e, &e->mail, 64));
   CHK(dalloc(e, &e->small_err, 4));
   CHK(dalloc(e, &e->Xg, Bl * Dp)); CHK(dalloc(e, &e->actg, Bl * A)); CHK(dalloc(e, &e->lpg, Bl));
-  CHK(dalloc(e, &e->advg, Bl)); CHK(dalloc(e, &e->retg, Bl));
+  CHK(dalloc(e, &e->advg, Bl)); CHK(dalloc(e, &e->retg, Bl)); CHK(dalloc(e, &e->oldvg, Bl));
   CHK(dalloc(e, &e->h1p, R * e->H1)); CHK(dalloc(e, &e->h2p, R * e->H2)); CHK(dalloc(e, &e->h1v, R * e->G1));
   CHK(dalloc(e, &e->h2v, R * e->G2)); CHK(dalloc(e, &e->mu, R * e->Ap)); CHK(dalloc(e, &e->vout, R));
   CHK(dalloc(e, &e->dmu, Bl * e->Ap)); CHK(dalloc(e, &e->dv, Bl * 8));
@@ -1448,12 +1453,14 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
   float* sums = e->grads + e->P;
   const int per = e->Dp / 4;
   hipLaunchKernelGGL(k_gather, dim3(cdiv(B * per, 256)), dim3(256), 0, e->stream, e->rows + start, B, e->obs, e->Dp,
-                     e->actions, e->A, e->logp, e->adv, e->ret, e->Xg, e->actg, e->lpg, e->advg, e->retg);
+                     e->actions, e->A, e->logp, e->adv, e->ret, e->Xg, e->actg, e->lpg, e->advg, e->retg, e->values,
+                     e->clip_vf >= 0.0 ? e->oldvg : (float*)nullptr);
   forward_generic(e, e->Xg, B, true, e->mu, true, e->vout);
   LossArgs L{};
   L.mu = e->mu; L.ldmu = e->Ap; L.v = e->vout; L.actions = e->actg; L.old_logp = e->lpg; L.adv = e->advg;
   L.ret = e->retg; L.log_std = Pp(e, T_LOGSTD); L.advstat = e->advstat + 4 * (size_t)mb; L.B = B; L.A = e->A;
   L.normalize = e->cfg.normalize_advantage; L.clip = (float)e->cfg.clip_range; L.vf_coef = (float)e->cfg.vf_coef;
+  L.clip_vf = (float)e->clip_vf; L.old_v = e->oldvg;
   L.ent_coef = (float)e->cfg.ent_coef; L.inv_bg = inv_bg; L.dmu = e->dmu; L.lddmu = e->Ap; L.dv = e->dv; L.lddv = 8;
   L.sums = sums; L.g_log_std = Gp(e, T_LOGSTD); L.g_b_action = Gp(e, T_AB); L.g_b_value = Gp(e, T_VB);
   // padding columns of dmu/dv must be zero (K padding of the NN GEMM)
@@ -1503,38 +1510,83 @@ void fill_adam_pack_args(mobrob_ppo_engine* e, AdamPackArgs& a) {
 }
 }  // namespace
 
-int mobrob_ppo_minibatch_apply(mobrob_ppo_engine_t* e) {
-  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
-  if (!e->grad_pending) return fail(MOBROB_ERR_STATE, "minibatch_apply without a pending gradient");
-  ProfScope ps(e, MOBROB_K_APPLY);
+namespace {
+struct ApplyCtx { float* stats_row; bool records; };
+// first half of an optimizer step: loss statistics + per-tensor sums of squares of the (reduced) gradient
+int apply_norms(mobrob_ppo_engine* e, ApplyCtx& c) {
+  if (e->stats_n >= e->stats_cap) e->stats_n = 0;  // ring: oldest rows are dropped if nobody fetched them
+  c.stats_row = e->stats + (size_t)e->stats_n * 8;
+  e->stats_n++;
+  StatsArgs st{};
+  st.stats_row = c.stats_row; st.loss_sums = e->grads + e->P; st.log_std = Pp(e, T_LOGSTD);
+  st.ent_coef = (float)e->cfg.ent_coef; st.vf_coef = (float)e->cfg.vf_coef;
+  st.inv_bg = 1.0f / (float)((int64_t)e->cur_count * e->cfg.world_size); st.n_act = e->A;
+  c.records = e->use_norm_records && e->fused.enabled;  // the reduction kernel of this step left the norm records
+  if (!c.records)
+    hipLaunchKernelGGL(k_sqnorm_chunks, dim3(e->nchunks), dim3(256), 0, e->stream, e->grads, e->chunks_dev,
+                       e->chunk_partial, st);
+  return MOBROB_OK;
+}
+// second half: clip coefficient, Adam, re-pack
+int apply_adam(mobrob_ppo_engine* e, const ApplyCtx& c) {
   e->adam_step++;
   const double b1 = e->cfg.adam_beta1, b2 = e->cfg.adam_beta2;
   const double bc1 = 1.0 - std::pow(b1, (double)e->adam_step);
   const double bc2 = 1.0 - std::pow(b2, (double)e->adam_step);
-  if (e->stats_n >= e->stats_cap) e->stats_n = 0;  // ring: oldest rows are dropped if nobody fetched them
-  float* stats_row = e->stats + (size_t)e->stats_n * 8;
-  e->stats_n++;
-  StatsArgs st{};
-  st.stats_row = stats_row; st.loss_sums = e->grads + e->P; st.log_std = Pp(e, T_LOGSTD);
-  st.ent_coef = (float)e->cfg.ent_coef; st.vf_coef = (float)e->cfg.vf_coef;
-  st.inv_bg = 1.0f / (float)((int64_t)e->cur_count * e->cfg.world_size); st.n_act = e->A;
-  const bool records = e->use_norm_records && e->fused.enabled;  // the reduction kernel of this step left the norm records
-  if (!records)
-    hipLaunchKernelGGL(k_sqnorm_chunks, dim3(e->nchunks), dim3(256), 0, e->stream, e->grads, e->chunks_dev,
-                       e->chunk_partial, st);
   AdamPackArgs a{};
   fill_adam_pack_args(e, a);
   a.step_size = (float)(e->cfg.learning_rate / bc1);
   a.bc2_sqrt = (float)std::sqrt(bc2);
-  if (records) {
+  if (c.records) {
+    StatsArgs st{};
+    st.stats_row = c.stats_row; st.loss_sums = e->grads + e->P; st.log_std = Pp(e, T_LOGSTD);
+    st.ent_coef = (float)e->cfg.ent_coef; st.vf_coef = (float)e->cfg.vf_coef;
+    st.inv_bg = 1.0f / (float)((int64_t)e->cur_count * e->cfg.world_size); st.n_act = e->A;
     a.partial = e->norm_rec_sum; a.fold_idx = e->fold_idx_dev; a.st = st;
     for (int i = 0; i < 14; ++i) a.fold_start[i] = e->fold_start[i];
   }
-  a.stats_row = stats_row;
+  a.stats_row = c.stats_row;
   a.loss_sums_zero = e->fused.enabled ? e->grads + e->P : nullptr;
   hipLaunchKernelGGL(k_adam_pack, dim3(cdiv(e->P, 256)), dim3(256), 0, e->stream, a);
   HIPC(hipGetLastError());
   e->grad_pending = false;
+  return MOBROB_OK;
+}
+}  // namespace
+
+int mobrob_ppo_minibatch_apply(mobrob_ppo_engine_t* e) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  if (!e->grad_pending) return fail(MOBROB_ERR_STATE, "minibatch_apply without a pending gradient");
+  ProfScope ps(e, MOBROB_K_APPLY);
+  ApplyCtx c{};
+  CHK(apply_norms(e, c));
+  return apply_adam(e, c);
+}
+
+int mobrob_ppo_set_hyper(mobrob_ppo_engine_t* e, int32_t which, double value) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  switch (which) {
+    case MOBROB_HYPER_LEARNING_RATE:
+      if (!(value >= 0.0)) return fail(MOBROB_ERR_INVALID, "learning_rate must be >= 0");
+      e->cfg.learning_rate = value; break;
+    case MOBROB_HYPER_CLIP_RANGE:
+      if (!(value >= 0.0)) return fail(MOBROB_ERR_INVALID, "clip_range must be >= 0");
+      e->cfg.clip_range = value; break;
+    case MOBROB_HYPER_CLIP_RANGE_VF: e->clip_vf = value >= 0.0 ? value : -1.0; break;  // negative / NaN: None
+    case MOBROB_HYPER_TARGET_KL: e->target_kl = value > 0.0 ? value : -1.0; break;
+    case MOBROB_HYPER_ENT_COEF: e->cfg.ent_coef = value; break;
+    case MOBROB_HYPER_VF_COEF: e->cfg.vf_coef = value; break;
+    default: return fail(MOBROB_ERR_INVALID, "unknown hyper-parameter id %d", which);
+  }
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_last_train_info(const mobrob_ppo_engine_t* e, int32_t* epochs_started, int32_t* stopped_early,
+                               int32_t* steps_applied) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  if (epochs_started) *epochs_started = e->last_epochs_started;
+  if (stopped_early) *stopped_early = e->last_stopped_early;
+  if (steps_applied) *steps_applied = e->last_steps_applied;
   return MOBROB_OK;
 }
 
@@ -1577,6 +1629,7 @@ int train_small_epoch(mobrob_ppo_engine* e, int ep) {
   t.obs = e->obs; t.actions = e->actions; t.A = e->A; t.old_logp = e->logp; t.adv = e->adv; t.ret = e->ret;
   t.log_std = e->params + e->offs[T_LOGSTD]; t.normalize = e->cfg.normalize_advantage;
   t.clip = (float)e->cfg.clip_range; t.vf_coef = (float)e->cfg.vf_coef; t.ent_coef = (float)e->cfg.ent_coef;
+  t.clip_vf = (float)e->clip_vf; t.old_values = e->values;
   a.rows = e->rows; a.total = e->N * e->T; a.Bl = e->Bl; a.nmb = e->nmb; a.nw = cdiv(e->Bl, GR);
   a.advstat = e->advstat;
   fill_adam_pack_args(e, a.pk);
@@ -1602,7 +1655,9 @@ int mobrob_ppo_train_enqueue(mobrob_ppo_engine_t* e, const int64_t* perms) {
                                   "minibatch_grad/[all-reduce]/minibatch_apply");
   const size_t total = (size_t)e->N * e->T;
   e->stats_n = 0;
-  const bool small = train_small_ok(e);
+  const bool kl = e->target_kl > 0.0;
+  e->last_epochs_started = 0; e->last_stopped_early = 0; e->last_steps_applied = 0;
+  const bool small = train_small_ok(e) && !kl;
   if (small) {  // Adam's bias corrections of every step of this call, in float64 on the host like the per-step path
     e->sched_host.resize((size_t)2 * e->nmb * e->cfg.n_epochs);
     const double b1 = e->cfg.adam_beta1, b2 = e->cfg.adam_beta2;
@@ -1617,20 +1672,43 @@ int mobrob_ppo_train_enqueue(mobrob_ppo_engine_t* e, const int64_t* perms) {
   // them and the reduction kernel for forming them: measured 12.9 instead of 11.4 ms per iteration (A/B on one box).
   struct RecordsOn {  // nothing can touch the gradient between reduction and clip inside this loop
     mobrob_ppo_engine* e;
-    explicit RecordsOn(mobrob_ppo_engine* e_) : e(e_) { e->use_norm_records = e->fused.enabled && e->fused.H == 64 && getenv("MOBROB_NO_NORM_RECORDS") == nullptr; }
+    explicit RecordsOn(mobrob_ppo_engine* e_) : e(e_) { e->use_norm_records = e->fused.enabled && e->fused.H == 64 && e->target_kl <= 0.0 && getenv("MOBROB_NO_NORM_RECORDS") == nullptr; }
     ~RecordsOn() { e->use_norm_records = false; }
   } records_on(e);
   for (int ep = 0; ep < e->cfg.n_epochs; ++ep) {
     CHK(mobrob_ppo_epoch_begin(e, perms ? perms + (size_t)ep * total : nullptr));
     if (small) {
       CHK(train_small_epoch(e, ep));
+      e->last_epochs_started = ep + 1;
+      e->last_steps_applied += e->nmb;
       continue;
     }
-    if (ep == e->cfg.n_epochs - 1) e->stats_n = 0;
-    for (int mb = 0; mb < e->nmb; ++mb) {
+    e->last_epochs_started = ep + 1;
+    if (ep == e->cfg.n_epochs - 1 || kl) e->stats_n = 0;  // the rows kept are those of the last epoch that ran
+    for (int mb = 0; mb < e->nmb && !e->last_stopped_early; ++mb) {
       CHK(mobrob_ppo_minibatch_grad(e, mb));
-      CHK(mobrob_ppo_minibatch_apply(e));
+      if (!kl) {
+        CHK(mobrob_ppo_minibatch_apply(e));
+        e->last_steps_applied++;
+        continue;
+      }
+      // target_kl [SB3 PPO.train]: the minibatch's approx_kl is known after the loss statistics; above 1.5 x target
+      // the optimizer step of THIS minibatch and everything after it is dropped.  One 4-byte read-back per step.
+      ApplyCtx c{};
+      CHK(apply_norms(e, c));
+      float approx_kl = 0.f;
+      HIPC(hipMemcpyAsync(&approx_kl, c.stats_row + 4, sizeof(float), hipMemcpyDeviceToHost, e->stream));
+      HIPC(hipStreamSynchronize(e->stream));
+      if ((double)approx_kl > 1.5 * e->target_kl) {
+        e->last_stopped_early = 1;
+        e->grad_pending = false;
+        if (e->fused.enabled) HIPC(hipMemsetAsync(e->grads + e->P, 0, 8 * sizeof(float), e->stream));  // what k_adam_pack would have re-zeroed
+        break;
+      }
+      CHK(apply_adam(e, c));
+      e->last_steps_applied++;
     }
+    if (e->last_stopped_early) break;
   }
   e->epoch_open = false;
   return MOBROB_OK;
@@ -1715,6 +1793,8 @@ int mobrob_ppo_train_dp(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_all
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   if (!fn && !e->comm)
     return fail(MOBROB_ERR_STATE, "train_dp: no communicator (mobrob_ppo_comm_init) and no all-reduce callback");
+  if (e->target_kl > 0.0)
+    return fail(MOBROB_ERR_STATE, "target_kl is implemented for the single-rank update only (the stop decision needs the global approx_kl)");
   const size_t total = (size_t)e->N * e->T;
   e->stats_n = 0;
   for (int ep = 0; ep < e->cfg.n_epochs; ++ep) {
@@ -1745,7 +1825,7 @@ int mobrob_ppo_train(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_ppo_tr
     const double d = n > 0 ? n : 1;
     st->policy_loss = (float)(acc[0] / d); st->value_loss = (float)(acc[1] / d); st->entropy_loss = (float)(acc[2] / d);
     st->loss = (float)(acc[3] / d); st->approx_kl = (float)(acc[4] / d); st->clip_fraction = (float)(acc[5] / d);
-    st->grad_norm = (float)(acc[6] / d); st->n_minibatches = e->cfg.n_epochs * e->nmb;
+    st->grad_norm = (float)(acc[6] / d); st->n_minibatches = e->last_steps_applied;
   } else {
     HIPC(hipStreamSynchronize(e->stream));
   }

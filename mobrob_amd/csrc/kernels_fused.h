@@ -46,6 +46,7 @@ struct FusedTrainArgs {
   const double* advstat;         // (sum, sumsq, n, -) of the GLOBAL minibatch
   int normalize;
   float clip, vf_coef, ent_coef, inv_bg;
+  float clip_vf; const float* old_values;  // clip_range_vf (< 0: none) and the rollout's value predictions
   float* slabs;                  // [gridDim.x][slab_floats]
   int slab_floats;
   float* sums;                   // [8] loss statistics (written by k_slab_reduce from the slabs' loss entries)
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
                      : 0.f;
     const float* old_or_ret = pol ? a.old_logp : a.ret;  // policy: old log-prob; value net: return target
     l_old = live ? old_or_ret[src] : 0.f;
-    l_adv = (live && pol) ? a.adv[src] : 0.f;
+    l_adv = live ? (pol ? a.adv[src] : (a.clip_vf >= 0.f ? a.old_values[src] : 0.f)) : 0.f;  // value net: old value (vf clipping)
   };
   {
     const int lrr0 = tid0 >> 2;
@@ -735,9 +736,10 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
       } else {
         float dv = 0.f;
         if (live && q == 0) {
-          const float v = lds[db] + lds[cb + 64], rt = l_old;
-          s_vl += (rt - v) * (rt - v);
-          dv = a.vf_coef * 2.0f * (v - rt) * a.inv_bg;
+          float sq, gv_;
+          value_loss_terms(lds[db] + lds[cb + 64], l_old, l_adv, a.clip_vf, sq, gv_);
+          s_vl += sq;
+          dv = a.vf_coef * gv_ * a.inv_bg;
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) lds[db + 4 * j] = (j == 0) ? dv : 0.f;  // q != 0 lanes hold dv = 0

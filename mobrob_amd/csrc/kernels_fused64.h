@@ -210,6 +210,7 @@ struct Fused64TrainArgs {
   const double* advstat;
   int normalize;
   float clip, vf_coef, ent_coef, inv_bg;
+  float clip_vf; const float* old_values;  // clip_range_vf (< 0: none) and the rollout's value predictions
   float* slabs;   // [gridDim.x][s64_size()]
   float* sums;
 };
@@ -268,7 +269,10 @@ __device__ __forceinline__ void tile64_train(const Fused64TrainArgs& a, const Fu
     } else {
 #pragma unroll
       for (int j = 0; j < 16; ++j) l_act[j] = 0.f;
-      if (llive) l_old = a.ret[src];
+      if (llive) {
+        l_old = a.ret[src];
+        if (a.clip_vf >= 0.f) l_adv = a.old_values[src];
+      }
     }
   }
   if constexpr (WL) tile64_forward_ldsw<DP>(wb, lane);
@@ -338,9 +342,10 @@ __device__ __forceinline__ void tile64_train(const Fused64TrainArgs& a, const Fu
     } else {
       float dv = 0.f;
       if (live && q == 0) {
-        const float v = lds[db] + lds[cb + 64], rt = l_old;
-        g.vl += (rt - v) * (rt - v);
-        dv = a.vf_coef * 2.0f * (v - rt) * a.inv_bg;
+        float sq, gv_;
+        value_loss_terms(lds[db] + lds[cb + 64], l_old, l_adv, a.clip_vf, sq, gv_);
+        g.vl += sq;
+        dv = a.vf_coef * gv_ * a.inv_bg;
       }
       for (int j = 0; j < 16; ++j) lds[db + 2 * j] = (j == 0) ? dv : 0.f;
       const float t = wave_sum(dv);

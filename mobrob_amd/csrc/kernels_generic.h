@@ -526,7 +526,7 @@ __global__ void k_gather(const int* __restrict__ rows, int count, const float* _
                          const float* __restrict__ actions, int A, const float* __restrict__ logp,
                          const float* __restrict__ adv, const float* __restrict__ ret, float* __restrict__ Xg,
                          float* __restrict__ actg, float* __restrict__ lpg, float* __restrict__ advg,
-                         float* __restrict__ retg) {
+                         float* __restrict__ retg, const float* __restrict__ values, float* __restrict__ oldvg) {
   const int per = Dp / 4;  // float4 chunks per row
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count * per) return;
@@ -537,6 +537,7 @@ __global__ void k_gather(const int* __restrict__ rows, int count, const float* _
     lpg[b] = logp[row];
     advg[b] = adv[row];
     retg[b] = ret[row];
+    if (oldvg != nullptr) oldvg[b] = values[row];
   }
   for (int a = c; a < A; a += per) actg[(size_t)b * A + a] = actions[(size_t)row * A + a];
 }
@@ -557,6 +558,7 @@ struct LossArgs {
   int B, A;
   int normalize;
   float clip, vf_coef, ent_coef, inv_bg;
+  float clip_vf; const float* old_v;  // clip_range_vf (< 0: none), gathered old value predictions [B]
   float* dmu; int lddmu;      // [B][Ap]
   float* dv; int lddv;        // [B][8]
   float* sums;                // [8]
@@ -600,9 +602,9 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs L) {
     const float w1 = (s1 < s2) ? 1.f : ((s1 > s2) ? 0.f : 0.5f);
     const float d_ratio = -(w1 * a + (1.0f - w1) * a * in_range) * L.inv_bg;
     g_logp = d_ratio * ratio;
-    const float vv = L.v[i], rr = L.ret[i];
-    s_vl = (rr - vv) * (rr - vv);
-    dvv = L.vf_coef * 2.0f * (vv - rr) * L.inv_bg;
+    float gv_;
+    value_loss_terms(L.v[i], L.ret[i], L.clip_vf >= 0.f ? L.old_v[i] : 0.f, L.clip_vf, s_vl, gv_);
+    dvv = L.vf_coef * gv_ * L.inv_bg;
     L.dv[(size_t)i * L.lddv] = dvv;
   }
   // per-action pieces + block reductions

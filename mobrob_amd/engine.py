@@ -363,6 +363,20 @@ class PPOEngine:
             raise failure[0]
         check(rc)
 
+    def set_hyper(self, **values):
+        """learning_rate / clip_range (schedule values for the coming train()), clip_range_vf (None = off), target_kl
+        (None = off), ent_coef, vf_coef -> mobrob_ppo_set_hyper."""
+        for name, v in values.items():
+            if name not in _lib.HYPER:
+                raise ValueError(f"unknown hyper-parameter {name!r} (known: {sorted(_lib.HYPER)})")
+            check(self.lib.mobrob_ppo_set_hyper(self._h, _lib.HYPER[name], -1.0 if v is None else float(v)))
+
+    def last_train_info(self):
+        """(epochs started, stopped early by target_kl, optimizer steps applied) of the latest train()."""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.lib.mobrob_ppo_last_train_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), bool(b.value), int(c.value)
+
     def train_enqueue(self):
         """PPO.train() enqueued on the engine's stream without waiting (device-drawn permutations)."""
         check(self.lib.mobrob_ppo_train_enqueue(self._h, None))

@@ -172,18 +172,28 @@ class PPO:
                  _init_setup_model=True, _dims=None, _engine_kwargs=None):
         if policy not in ("MlpPolicy",) and getattr(policy, "__name__", "") != "ActorCriticPolicy":
             raise ValueError(f"Policy {policy} unknown")
-        if callable(learning_rate) or callable(clip_range):
-            raise NotImplementedError("only constant learning_rate / clip_range schedules (all reference configs)")
-        if clip_range_vf is not None or use_sde or target_kl is not None:
-            raise NotImplementedError("clip_range_vf, use_sde and target_kl are not used by the reference configs "
-                                      "and are not implemented by the HIP engine")
+        if use_sde:
+            raise NotImplementedError("use_sde (generalised state-dependent exploration) is not implemented by the HIP "
+                                      "engine; no reference config uses it")
         self.policy_class = "MlpPolicy"
         self.env = env
-        self.learning_rate, self.n_steps, self.batch_size, self.n_epochs = float(learning_rate), int(n_steps), int(batch_size), int(n_epochs)
-        self.gamma, self.gae_lambda, self.clip_range = float(gamma), float(gae_lambda), float(clip_range)
-        self.clip_range_vf, self.normalize_advantage = None, bool(normalize_advantage)
+        # learning_rate / clip_range / clip_range_vf may be floats or SB3 schedules: callables of progress_remaining
+        # (1 at the start of learn(), 0 at the end), evaluated once per train() like SB3's _update_learning_rate
+        self.lr_schedule = learning_rate if callable(learning_rate) else None
+        self.clip_schedule = clip_range if callable(clip_range) else None
+        self.clip_vf_schedule = clip_range_vf if callable(clip_range_vf) else None
+        self.learning_rate = float(learning_rate(1.0)) if callable(learning_rate) else float(learning_rate)
+        self.n_steps, self.batch_size, self.n_epochs = int(n_steps), int(batch_size), int(n_epochs)
+        self.gamma, self.gae_lambda = float(gamma), float(gae_lambda)
+        self.clip_range = float(clip_range(1.0)) if callable(clip_range) else float(clip_range)
+        if clip_range_vf is not None and not callable(clip_range_vf) and not float(clip_range_vf) > 0:
+            raise ValueError("`clip_range_vf` must be positive, pass `None` to deactivate vf clipping")
+        self.clip_range_vf = (float(clip_range_vf(1.0)) if callable(clip_range_vf)
+                              else (None if clip_range_vf is None else float(clip_range_vf)))
+        self.normalize_advantage = bool(normalize_advantage)
         self.ent_coef, self.vf_coef, self.max_grad_norm = float(ent_coef), float(vf_coef), float(max_grad_norm)
-        self.use_sde, self.sde_sample_freq, self.target_kl = False, -1, None
+        self.use_sde, self.sde_sample_freq = False, -1
+        self.target_kl = None if target_kl is None else float(target_kl)
         self.tensorboard_log, self.verbose, self.seed, self.device = tensorboard_log, int(verbose), seed, device
         self.policy_kwargs = dict(policy_kwargs or {})
         net_arch = self.policy_kwargs.get("net_arch", dict(pi=[64, 64], vf=[64, 64]))
@@ -242,6 +252,7 @@ class PPO:
             kw.update(rank=self.rank, world_size=self.world_size, device_id=local_rank)
         kw.update(self._engine_kwargs)
         self.engine = PPOEngine(**kw)
+        self.engine.set_hyper(clip_range_vf=self.clip_range_vf, target_kl=self.target_kl)
         self._backend = None
         self.engine.set_params(orthogonal_policy_init(self.obs_dim, self.act_dim, self.net_arch[0], self.net_arch[1],
                                                       seed=0 if self.seed is None else int(self.seed)))
@@ -382,6 +393,15 @@ class PPO:
         return True
 
     def train(self):
+        p = self._current_progress_remaining
+        if self.lr_schedule is not None or self.clip_schedule is not None or self.clip_vf_schedule is not None:
+            if self.lr_schedule is not None:
+                self.learning_rate = float(self.lr_schedule(p))
+            if self.clip_schedule is not None:
+                self.clip_range = float(self.clip_schedule(p))
+            if self.clip_vf_schedule is not None:
+                self.clip_range_vf = float(self.clip_vf_schedule(p))
+            self.engine.set_hyper(learning_rate=self.learning_rate, clip_range=self.clip_range, clip_range_vf=self.clip_range_vf)
         if self.world_size > 1:
             import torch
             import torch.distributed as dist
@@ -397,9 +417,13 @@ class PPO:
             dist.all_reduce(t)
             stats.update({k: float(v) for k, v in zip(keys, t.tolist())})
             stats["n_minibatches"] = self.n_epochs * self.engine.n_minibatches
+            self._n_updates += self.n_epochs
         else:
             stats = self.engine.train(None)
-        self._n_updates += self.n_epochs
+            epochs, stopped, _ = self.engine.last_train_info()
+            self._n_updates += epochs       # SB3 counts the epochs it started (target_kl may cut the last ones)
+            if stopped and self.verbose >= 1:
+                print(f"Early stopping at step {epochs - 1} due to reaching max kl: {stats['approx_kl']:.2f}")
         return stats
 
     def learn(self, total_timesteps, callback=None, log_interval=1, tb_log_name="PPO", reset_num_timesteps=True,
@@ -478,7 +502,8 @@ class PPO:
         return dict(n_steps=self.n_steps, batch_size=self.batch_size, n_epochs=self.n_epochs, gamma=self.gamma,
                     gae_lambda=self.gae_lambda, ent_coef=self.ent_coef, vf_coef=self.vf_coef,
                     max_grad_norm=self.max_grad_norm, learning_rate=self.learning_rate, clip_range=self.clip_range,
-                    normalize_advantage=self.normalize_advantage, n_envs=self.n_envs)
+                    normalize_advantage=self.normalize_advantage, n_envs=self.n_envs, clip_range_vf=self.clip_range_vf,
+                    target_kl=self.target_kl)
 
     def save(self, path):
         """SB3-layout zip (checkpoint.py); appends .zip like SB3 when the suffix is missing.  Data-parallel replicas
@@ -524,6 +549,8 @@ class PPO:
                     n_steps=int(d.get("n_steps", 2048)), batch_size=int(d.get("batch_size", 64)),
                     n_epochs=int(d.get("n_epochs", 10)), gamma=float(d.get("gamma", 0.99)),
                     gae_lambda=float(d.get("gae_lambda", 0.95)), clip_range=float(clip) if isinstance(clip, (int, float)) else 0.2,
+                    clip_range_vf=d.get("clip_range_vf") if isinstance(d.get("clip_range_vf"), (int, float)) else None,
+                    target_kl=d.get("target_kl"),
                     normalize_advantage=bool(d.get("normalize_advantage", True)), ent_coef=float(d.get("ent_coef", 0.0)),
                     vf_coef=float(d.get("vf_coef", 0.5)), max_grad_norm=float(d.get("max_grad_norm", 0.5)),
                     tensorboard_log=d.get("tensorboard_log"), policy_kwargs=pk, verbose=int(d.get("verbose", 0)),

@@ -326,6 +326,8 @@ class Hyper:
     normalize_advantage: bool = True
     n_epochs: int = 10
     batch_size: int = 64
+    clip_range_vf: float | None = None   # SB3 default None: no value-function clipping
+    target_kl: float | None = None       # SB3 default None: no early stop
 
 
 def normalize_advantages(adv, acc=None):
@@ -383,7 +385,15 @@ def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, return
     policy_loss = F32(-(F32(np.minimum(s1, s2).sum(dtype=sdt)) / Bg))
     clip_fraction = F32(F32((np.abs(ratio - F32(1.0)) > F32(h.clip_range)).astype(F32).sum(dtype=sdt)) / Bg)
     ret = np.asarray(returns, F32)
-    value_loss = F32(F32(((ret - values) ** 2).sum(dtype=sdt)) / Bg)
+    # value clipping [SB3 PPO.train]: values_pred = old_values + clamp(values - old_values, -c, c); None -> values
+    if h.clip_range_vf is None:
+        values_pred, vf_pass = values, F32(1.0)
+    else:
+        c = F32(h.clip_range_vf)
+        dv = (values - np.asarray(old_values, F32)).astype(F32)
+        values_pred = (np.asarray(old_values, F32) + np.clip(dv, -c, c)).astype(F32)
+        vf_pass = ((dv >= -c) & (dv <= c)).astype(F32)  # torch.clamp passes the gradient inside [lo, hi], inclusive
+    value_loss = F32(F32(((ret - values_pred) ** 2).sum(dtype=sdt)) / Bg)
     entropy_loss = F32(-(entropy.sum(dtype=F32) / Bg))
     loss = F32(policy_loss + F32(h.ent_coef) * entropy_loss + F32(h.vf_coef) * value_loss)
     approx_kl = F32(F32(((np.exp(log_ratio) - F32(1.0)) - log_ratio).astype(F32).sum(dtype=sdt)) / Bg)
@@ -399,7 +409,7 @@ def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, return
     g_log_std = _colsum((g_logp[:, None] * (d * d / var - F32(1.0))).astype(F32), acc)
     # entropy: d(-mean(entropy))/dlog_std_a = -(B_local / B_global)
     g_log_std = (g_log_std + F32(h.ent_coef) * F32(-float(B)) / Bg).astype(F32)
-    g_value = (F32(h.vf_coef) * F32(2.0) * (values - ret) / Bg).astype(F32)  # [B]
+    g_value = (F32(h.vf_coef) * F32(2.0) * (values_pred - ret) * vf_pass / Bg).astype(F32)  # [B]
 
     grads = OrderedDict((k, None) for k in p.keys())
     grads["log_std"] = g_log_std
@@ -467,8 +477,14 @@ def adam_step(p, grads, st: AdamState, lr, beta1=0.9, beta2=0.999, eps=1e-5):
 
 
 def train_minibatch(p, st, batch, h: Hyper, adv_mean_std=None, denom=None):
-    """batch = (obs, actions, old_values, old_log_prob, advantages, returns) -> one optimizer step."""
+    """batch = (obs, actions, old_values, old_log_prob, advantages, returns) -> one optimizer step.  With
+    `h.target_kl`, a minibatch whose approx_kl exceeds 1.5 x target is NOT applied: stats["early_stop"] = True and the
+    caller ends train() [SB3 PPO.train: `continue_training = False; break` before optimizer.step()]."""
     stats, grads, _ = loss_and_grads(p, *batch, h, adv_mean_std=adv_mean_std, denom=denom)
+    if h.target_kl is not None and float(stats["approx_kl"]) > 1.5 * h.target_kl:
+        stats["early_stop"] = True
+        stats["grad_norm"] = F32(np.nan)
+        return stats
     grads, total = clip_grad_norm(grads, h.max_grad_norm)
     stats["grad_norm"] = total
     adam_step(p, grads, st, h.learning_rate, h.beta1, h.beta2, h.adam_eps)
@@ -494,6 +510,8 @@ def train(p, st, buf, h: Hyper, perms):
         for s in range(0, total, h.batch_size):
             idx = perm[s:s + h.batch_size]
             out.append(train_minibatch(p, st, gather_minibatch(buf, idx), h))
+            if out[-1].get("early_stop"):
+                return out
     return out
 
 

@@ -48,8 +48,10 @@ def test_minibatch_step_matches_golden(env):
         assert np.allclose(st.exp_avg_sq[k], g["step/v/" + k], rtol=1e-4, atol=1e-9), k
 
 
-def test_grads_match_torch_autograd_random_net():
-    """Hand-derived backward vs torch autograd on a random 2x32 net incl. clip edge cases."""
+@pytest.mark.parametrize("clip_range_vf", [None, 0.3])
+def test_grads_match_torch_autograd_random_net(clip_range_vf):
+    """Hand-derived backward vs torch autograd on a random 2x32 net incl. clip edge cases; with and without SB3's
+    value-function clipping (`clip_range_vf`)."""
     import torch
     rng = np.random.default_rng(3)
     D, A, B = 7, 3, 64
@@ -64,8 +66,10 @@ def test_grads_match_torch_autograd_random_net():
     adv = rng.standard_normal(B).astype(np.float32)
     adv[5] = 0.0
     ret = rng.standard_normal(B).astype(np.float32)
-    h = O.Hyper(ent_coef=0.01, normalize_advantage=False)
-    stats, grads, _ = O.loss_and_grads(p, obs, act, ret, old_lp, adv, ret, h)
+    h = O.Hyper(ent_coef=0.01, normalize_advantage=False, clip_range_vf=clip_range_vf)
+    _, val = O.policy_outputs(p, obs)
+    old_v = (val + rng.normal(0, 0.35, B)).astype(np.float32)   # some rows inside, some outside the vf clip range
+    stats, grads, _ = O.loss_and_grads(p, obs, act, old_v, old_lp, adv, ret, h)
 
     tp = {k: torch.tensor(v, requires_grad=True) for k, v in p.items()}
     x = torch.tensor(obs)
@@ -80,6 +84,11 @@ def test_grads_match_torch_autograd_random_net():
     ratio = torch.exp(logp - torch.tensor(old_lp))
     a = torch.tensor(adv)
     pl = -torch.min(a * ratio, a * torch.clamp(ratio, 0.8, 1.2)).mean()
+    if clip_range_vf is not None:
+        ov = torch.tensor(old_v)
+        frac_clipped = float(((v - ov).abs() > clip_range_vf).float().mean())
+        assert 0.1 < frac_clipped < 0.9
+        v = ov + torch.clamp(v - ov, -clip_range_vf, clip_range_vf)
     vl = torch.nn.functional.mse_loss(torch.tensor(ret), v)
     el = -dist.entropy().sum(1).mean()
     loss = pl + 0.01 * el + 0.5 * vl
@@ -186,3 +195,23 @@ def test_whole_iteration_matches_torch_golden():
         assert np.max(np.abs(p[k] - g[f"p1/{k}"])) < 2e-6, k
         assert scaled_err(st.exp_avg[k], g[f"m1/{k}"]) < 1e-4, k
     assert st.step == int(g["adam_step"]) + E * 4
+
+
+def test_target_kl_stops_before_the_offending_optimizer_step():
+    """SB3 PPO.train with target_kl: the first minibatch whose approx_kl exceeds 1.5 x target is evaluated (its
+    statistics are logged) but not applied, and nothing after it runs."""
+    from tests.util import synthetic_rollout
+    D, A, T, N, B = 6, 2, 8, 8, 16
+    p = O.init_params(D, A, (16, 16), (16, 16), seed=1)
+    buf, lv, dones = synthetic_rollout(T, N, D, A, seed=2)
+    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, 0.99, 0.95)
+    perms = [np.random.default_rng(e).permutation(T * N) for e in range(3)]
+    free = O.train({k: v.copy() for k, v in p.items()}, O.AdamState.zeros_like(p), buf, O.Hyper(n_epochs=3, batch_size=B), perms)
+    kls = [float(s["approx_kl"]) for s in free]
+    assert len(kls) == 12
+    target = sorted(kls)[6] / 1.5                       # a threshold some minibatch in the middle crosses
+    first = next(i for i, k in enumerate(kls) if k > 1.5 * target)
+    p2, st2 = {k: v.copy() for k, v in p.items()}, O.AdamState.zeros_like(p)
+    out = O.train(p2, st2, buf, O.Hyper(n_epochs=3, batch_size=B, target_kl=target), perms)
+    assert len(out) == first + 1 and out[-1].get("early_stop") and st2.step == first
+    assert all(abs(float(a["approx_kl"]) - float(b["approx_kl"])) < 1e-7 for a, b in zip(out, free))
