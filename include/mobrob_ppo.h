@@ -259,6 +259,30 @@ int mobrob_ppo_comm_init(mobrob_ppo_engine_t* e, const uint8_t* id128);
 int mobrob_ppo_comm_destroy(mobrob_ppo_engine_t* e);
 int mobrob_ppo_train_dp(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_allreduce_fn fn, void* ctx);
 
+/* ---- env-side controllers of the Bullet robots, batched over n robots on the device (csrc/robot_ctrl.h) ----------
+ * In the reference the RL action of these two robots corrects controller GAINS and the controller runs inside
+ * env.step on the host, one robot at a time.  dev_ptrs != 0: every array pointer is a DEVICE pointer and the call
+ * only enqueues the kernel on the engine's stream (a device-resident simulator calls it between physics steps);
+ * dev_ptrs == 0: host arrays, copied in and out, the call returns when the results are in place.
+ *   turtlebot3  `Turtlebot3.prop_ctrl` (robots/turtlebot3.py:214-238, from Turtlebot3Env.step, envs/wrapper.py:540-546):
+ *               pos[n][2], theta[n], goal[n][2], gain_changes[n][2] (the action) -> twist[n][2] = (v, w)
+ *   drone       `DronePIDController.control` with `finetune_*_pid_coef` (robots/drone.py:58-159, 175-193, from
+ *               DroneEnv.step, envs/wrapper.py:481-489): pos[n][3], rpy[n][3], goal[n][3], action[n][18] (6 x 3 gain
+ *               corrections: force P I D, torque P I D), ctrl_state[n][12] in/out (last position error, its integral,
+ *               last attitude error, its integral) -> out[n][4] = thrust, torque x y z.  The rotor mixing
+ *               (`_compute_rpm`) belongs to Bullet's actuator model and is not part of it. */
+typedef struct mobrob_drone_params {
+  float mass, g, dt;                                   /* kg, m/s^2, controller period (world.timestep = 1/50) */
+  float max_thrust, max_xy_torque, max_z_torque;       /* actuator limits (drone.py:260-267) */
+  float max_roll_pitch;                                /* attitude limit, pi/6 in the reference (drone.py:50) */
+  float tune_fac;                                      /* gain radius = tune_fac * default gain, 0.3 (drone.py:29) */
+} mobrob_drone_params_t;
+int mobrob_ctrl_turtlebot3(mobrob_ppo_engine_t* e, int32_t n, int32_t dev_ptrs, const float* pos, const float* theta,
+                           const float* goal, const float* gain_changes, float* twist);
+int mobrob_ctrl_drone_pid(mobrob_ppo_engine_t* e, int32_t n, int32_t dev_ptrs, const mobrob_drone_params_t* prm,
+                          const float* pos, const float* rpy, const float* goal, const float* action, float* ctrl_state,
+                          float* out);
+
 /* Hyper-parameters that SB3 lets change or that the reference YAMLs never set, without growing the config struct.
  * `ppo_kwargs` are splatted into stable_baselines3.PPO verbatim (/root/reference/src/mobrob/rl_control/ppo.py:58, README.md:49):
  *   LEARNING_RATE / CLIP_RANGE  the value of a schedule for the coming PPO.train() (SB3 evaluates callables of

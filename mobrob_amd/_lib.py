@@ -42,6 +42,11 @@ class GoalEnv(C.Structure):  # mobrob_goal_env_t
                 ("extra_bonus", C.c_float), ("obs_noise", C.c_float), ("mix", (C.c_float * 32) * 3)]
 
 
+class DroneParams(C.Structure):  # mobrob_drone_params_t
+    _fields_ = [(k, C.c_float) for k in ("mass", "g", "dt", "max_thrust", "max_xy_torque", "max_z_torque",
+                                         "max_roll_pitch", "tune_fac")]
+
+
 class EpisodeStats(C.Structure):  # mobrob_episode_stats_t
     _fields_ = [("episodes", C.c_int64), ("return_sum", C.c_double), ("length_sum", C.c_double), ("goals", C.c_int64)]
 
@@ -90,6 +95,8 @@ SYMBOLS = {
     "mobrob_ppo_train": (C.c_int, [_P, _I64, C.POINTER(TrainStats)]),
     "mobrob_ppo_train_enqueue": (C.c_int, [_P, _I64]),
     "mobrob_ppo_set_hyper": (C.c_int, [_P, C.c_int32, C.c_double]),
+    "mobrob_ctrl_turtlebot3": (C.c_int, [_P, C.c_int32, C.c_int32, _F, _F, _F, _F, _F]),
+    "mobrob_ctrl_drone_pid": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(DroneParams), _F, _F, _F, _F, _F, _F]),
     "mobrob_ppo_last_train_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mobrob_ppo_comm_unique_id": (C.c_int, [_U8]),
     "mobrob_ppo_comm_init": (C.c_int, [_P, _U8]),

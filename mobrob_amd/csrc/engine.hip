@@ -21,6 +21,7 @@
 #include "fused_dispatch.h"
 #include "kernels_env.h"
 #include "kernels_rollout.h"
+#include "robot_ctrl.h"
 #ifdef MOBROB_VALUE8  // experiment, see scratch/value8.py
 #include "../../scratch/kernels_fused8.h"
 #endif
@@ -1406,6 +1407,77 @@ int mobrob_ppo_episode_records(mobrob_ppo_engine_t* e, float* out, int32_t max_r
   }
   e->ep_ring_read = written;
   return n;
+}
+
+// ---- env-side controllers (robot_ctrl.h) -----------------------------------------------------------------
+}  // extern "C"
+namespace {
+// host arrays are staged through temporary device buffers; device arrays (dev_ptrs != 0) are used in place
+struct CtrlBuf {
+  mobrob_ppo_engine* e; bool dev; std::vector<void*> owned;
+  std::vector<std::pair<void*, std::pair<void*, size_t>>> outs;  // device -> host copies to make at the end
+  ~CtrlBuf() { for (void* p : owned) (void)hipFree(p); }
+  int in(const float* host, size_t count, const float** out) {
+    using T = float;
+    if (dev) { *out = host; return MOBROB_OK; }
+    void* d = nullptr;
+    HIPC(hipMalloc(&d, count * sizeof(T)));
+    owned.push_back(d);
+    HIPC(hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, e->stream));
+    *out = static_cast<const T*>(d);
+    return MOBROB_OK;
+  }
+  int inout(float* host, size_t count, float** out, bool copy_in) {
+    using T = float;
+    if (dev) { *out = host; return MOBROB_OK; }
+    void* d = nullptr;
+    HIPC(hipMalloc(&d, count * sizeof(T)));
+    owned.push_back(d);
+    if (copy_in) HIPC(hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, e->stream));
+    outs.push_back({d, {host, count * sizeof(T)}});
+    *out = static_cast<T*>(d);
+    return MOBROB_OK;
+  }
+  int finish() {
+    for (auto& o : outs) HIPC(hipMemcpyAsync(o.second.first, o.first, o.second.second, hipMemcpyDeviceToHost, e->stream));
+    if (!dev) HIPC(hipStreamSynchronize(e->stream));
+    return MOBROB_OK;
+  }
+};
+}  // namespace
+extern "C" {
+
+int mobrob_ctrl_turtlebot3(mobrob_ppo_engine_t* e, int32_t n, int32_t dev_ptrs, const float* pos, const float* theta,
+                           const float* goal, const float* gain_changes, float* twist) {
+  if (!e || n < 1 || !pos || !theta || !goal || !gain_changes || !twist)
+    return fail(MOBROB_ERR_INVALID, "ctrl_turtlebot3: bad argument");
+  CtrlBuf b{e, dev_ptrs != 0, {}, {}};
+  const float *dp, *dt, *dg, *da;
+  float* dtw;
+  CHK(b.in(pos, (size_t)2 * n, &dp)); CHK(b.in(theta, (size_t)n, &dt)); CHK(b.in(goal, (size_t)2 * n, &dg));
+  CHK(b.in(gain_changes, (size_t)2 * n, &da)); CHK(b.inout(twist, (size_t)2 * n, &dtw, false));
+  hipLaunchKernelGGL(k_ctrl_turtlebot3, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, n, dp, dt, dg, da, dtw);
+  HIPC(hipGetLastError());
+  return b.finish();
+}
+
+int mobrob_ctrl_drone_pid(mobrob_ppo_engine_t* e, int32_t n, int32_t dev_ptrs, const mobrob_drone_params_t* prm,
+                          const float* pos, const float* rpy, const float* goal, const float* action, float* ctrl_state,
+                          float* out) {
+  if (!e || n < 1 || !prm || !pos || !rpy || !goal || !action || !ctrl_state || !out)
+    return fail(MOBROB_ERR_INVALID, "ctrl_drone_pid: bad argument");
+  if (!(prm->dt > 0.f) || !(prm->mass > 0.f)) return fail(MOBROB_ERR_INVALID, "ctrl_drone_pid: dt and mass must be positive");
+  CtrlBuf b{e, dev_ptrs != 0, {}, {}};
+  const float *dp, *dr, *dg, *da;
+  float *ds, *dout;
+  CHK(b.in(pos, (size_t)3 * n, &dp)); CHK(b.in(rpy, (size_t)3 * n, &dr)); CHK(b.in(goal, (size_t)3 * n, &dg));
+  CHK(b.in(action, (size_t)18 * n, &da)); CHK(b.inout(ctrl_state, (size_t)12 * n, &ds, true));
+  CHK(b.inout(out, (size_t)4 * n, &dout, false));
+  DroneCtrlParams p{prm->mass, prm->g, prm->dt, prm->max_thrust, prm->max_xy_torque, prm->max_z_torque, prm->max_roll_pitch,
+                    prm->tune_fac};
+  hipLaunchKernelGGL(k_ctrl_drone_pid, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, n, p, dp, dr, dg, da, ds, dout);
+  HIPC(hipGetLastError());
+  return b.finish();
 }
 
 // ---- update ----------------------------------------------------------------------------------------

@@ -7,7 +7,7 @@ from collections import OrderedDict
 import numpy as np
 
 from . import _lib
-from ._lib import BUF, Config, EpisodeStats, GoalEnv, TrainStats, check
+from ._lib import BUF, Config, DroneParams, EpisodeStats, GoalEnv, TrainStats, check
 
 F32 = np.float32
 STAT_KEYS = ("policy_loss", "value_loss", "entropy_loss", "loss", "approx_kl", "clip_fraction", "grad_norm")
@@ -302,6 +302,33 @@ class PPOEngine:
         out = np.zeros((int(max_records), 2), F32)
         n = check(self.lib.mobrob_ppo_episode_records(self._h, _fp(out), int(max_records)))
         return [{"r": float(r), "l": int(l)} for r, l in out[:n]]
+
+    # ---- env-side controllers (batched on the device, csrc/robot_ctrl.h) ---------------------------
+    def ctrl_turtlebot3(self, pos, theta, goal, gain_changes):
+        """Turtlebot3's proportional controller for n robots: -> twist [n, 2] = (v, w)."""
+        pos, goal, gc = _f32c(pos), _f32c(goal), _f32c(gain_changes)
+        theta = _f32c(theta)
+        n = theta.shape[0]
+        if pos.shape != (n, 2) or goal.shape != (n, 2) or gc.shape != (n, 2):
+            raise ValueError("pos, goal, gain_changes must be [n, 2] and theta [n]")
+        twist = np.empty((n, 2), F32)
+        check(self.lib.mobrob_ctrl_turtlebot3(self._h, n, 0, _fp(pos), _fp(theta), _fp(goal), _fp(gc), _fp(twist)))
+        return twist
+
+    def ctrl_drone_pid(self, pos, rpy, goal, action, ctrl_state, mass, max_thrust, max_xy_torque, max_z_torque, g=9.8,
+                       dt=1.0 / 50.0, max_roll_pitch=np.pi / 6, tune_fac=0.3):
+        """The drone's cascaded PID for n robots; `ctrl_state` [n, 12] is updated in place -> [n, 4] thrust, torques."""
+        pos, rpy, goal, action = _f32c(pos), _f32c(rpy), _f32c(goal), _f32c(action)
+        n = pos.shape[0]
+        if pos.shape != (n, 3) or rpy.shape != (n, 3) or goal.shape != (n, 3) or action.shape != (n, 18):
+            raise ValueError("pos, rpy, goal must be [n, 3] and action [n, 18]")
+        if ctrl_state.shape != (n, 12) or ctrl_state.dtype != F32 or not ctrl_state.flags.c_contiguous:
+            raise ValueError("ctrl_state must be a C-contiguous float32 [n, 12] array")
+        prm = DroneParams(mass, g, dt, max_thrust, max_xy_torque, max_z_torque, max_roll_pitch, tune_fac)
+        out = np.empty((n, 4), F32)
+        check(self.lib.mobrob_ctrl_drone_pid(self._h, n, 0, C.byref(prm), _fp(pos), _fp(rpy), _fp(goal), _fp(action),
+                                             _fp(ctrl_state), _fp(out)))
+        return out
 
     def compute_gae(self):
         check(self.lib.mobrob_ppo_compute_gae(self._h))

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_symbols():
     text = open(os.path.join(ROOT, "include", "mobrob_ppo.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(mobrob_ppo_[a-z_0-9]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(mobrob_(?:ppo|ctrl)_[a-z_0-9]+)\s*\(", text)))
 
 
 def test_library_builds_and_exports_every_declared_symbol():
