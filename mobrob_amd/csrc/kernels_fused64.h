@@ -458,8 +458,24 @@ __global__ __launch_bounds__(Lay64<DP>::TNWV * 64, 1) void k_fused64_train(Fused
   const int ntiles = (a.count + GR - 1) / GR;
   // mirror this network's packed weights (fragment order, scaled biases) into LDS: every GEMM operand of the
   // tile loop then comes from LDS and no phase waits on L2
-  for (int i = tid0; i < Wt::TOTAL / 4; i += NWV * 64)
-    reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(a.wpack[net])[i];
+  {  // eight 16-byte loads in flight per thread (one load -> one LDS store at a time is a chain of L2 round trips:
+     // 22 of them for the 66 KB of a 58-dim network)
+    constexpr int NV = Wt::TOTAL / 4, NT = NWV * 64;
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack[net]);
+    for (int base = tid0; base < NV; base += 8 * NT) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * NT;
+        v[u] = i < NV ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * NT;
+        if (i < NV) reinterpret_cast<f32x4*>(lds)[i] = v[u];
+      }
+    }
+  }
 
   Grad64 g;
   g.zero();

@@ -19,6 +19,12 @@ Appendix A) and is pinned by
 
 PARITY STATUS: the reference ships no tests for this path -> "parity
 unpinned by reference tests"; it is pinned only by the artefacts and torch-op goldens above.
+(The only reference-HELD outputs are the `observation_space` / `action_space` blobs inside the
+zips; they pin the checkpoint writer, tests/golden/reference_spaces.json, not this arithmetic.)
+
+`loss_and_grads(..., acc=np.float64)` accumulates every contraction in float64 (products of
+float32 are exact there): the mode the full-size parity tests use, so that the checker's own
+summation error over 65 536 rows stays ~1e-7 (tests/test_full_size_gpu.py).
 
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
 module.  The product (`mobrob_amd`) never does: it fails loudly if the HIP library is missing.
