@@ -296,6 +296,10 @@ class PPO:
                                            for r in e.episode_records(self.ep_info_buffer.maxlen or 100))
             else:
                 e.collect_synthetic(env.p_term, env.time_limit)
+            # The whole rollout ran in one launch; the per-step callbacks are replayed afterwards.  A checkpoint taken at
+            # "step k of the rollout" holds what SB3's would: weights, optimizer state and update counters only change in
+            # train(), and num_timesteps is the replayed value -- only `_last_obs` is the rollout's last observation
+            # rather than step k's.
             for _ in range(self.n_steps):
                 self.num_timesteps += N * self.world_size  # time/total_timesteps counts the whole job
                 if not callback.on_step():
@@ -595,10 +599,16 @@ class PPOCtrl:
         if vec_env_type in ("subproc", "dummy"):
             if env_name not in ROBOT_DIMS:
                 raise ValueError(f"Env {env_name} not found")  # what get_env would raise inside a worker
+            cls = DummyVecEnv
+            if vec_env_type == "subproc":  # one rank of a data-parallel job gets its share of the usable host cores
+                import functools
+                from ..envs.shm_vec_env import usable_cores
+                world, _, _ = distributed_context(init=False)
+                cls = functools.partial(SubprocVecEnv, n_workers=max(1, usable_cores() // max(1, world)))
             vec_env = make_vec_env(get_env, n_envs=n_env,
                                    env_kwargs={"env_name": env_name, "enable_gui": enable_gui,
                                                "terminate_on_goal": True, "time_limit": time_limit},
-                                   vec_env_cls=SubprocVecEnv if vec_env_type == "subproc" else DummyVecEnv, seed=env_seed)
+                                   vec_env_cls=cls, seed=env_seed)
         elif vec_env_type == "synthetic":
             vec_env = SyntheticVecEnv.for_robot(env_name, n_env, time_limit, env_seed)
         elif vec_env_type == "device":
