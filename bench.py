@@ -440,7 +440,10 @@ def main():
         backend.ensure_comm()
         eng.collect_synthetic(p_term=w["p_term"], time_limit=w["tl"])
         train_data_parallel(backend, force_collectives=force_dp)
-        eng.set_params(init_params(D, A, H, seed=0))
+        p0 = init_params(D, A, H, seed=0)
+        eng.set_params(p0)                                   # the timed region starts from the same replicas ...
+        zeros = {k: np.zeros_like(v) for k, v in p0.items()}
+        eng.set_optimizer_state(zeros, zeros, 0)             # ... and a fresh optimizer
         torch.cuda.synchronize()
 
     host = None
