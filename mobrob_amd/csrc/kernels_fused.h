@@ -800,10 +800,20 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     STAMP(14)
     // ---- dW2 += dz2^T . h1  (this wave: 64 neurons x 256 inputs, K = 64 rows) ----
     const Frag2 fh1 = prefetch_frag(W.W2b + (size_t)(2 * wave) * (FH / 8) * 64, W.W2b + (size_t)(2 * wave + 1) * (FH / 8) * 64, lane);
-    if (PHASE_ON(2048)) gb2 += column_sum(L::H2, tid);
     if (PHASE_ON(128)) {
       const int ao = opaque(L::H2 + h * FLDH + 64 * wave + r);
       const int bo = opaque(L::H1 + h * FLDH + r);
+      // The bias gradient gb2 (sum of column `tid` of dz2 over the 64 rows) rides in this loop like gb1 rides in the
+      // dW1 loop: four partial sums over rows = 0..3 (mod 4), added as (s0 + s1) + (s2 + s3) -- column_sum()'s order,
+      // bit for bit -- with their LDS reads under the MFMAs of the previous k-step instead of in front of the phase.
+      const int co = opaque(L::H2 + tid);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      if (PHASE_ON(2048)) { s0 += lds[co]; s1 += lds[co + FLDH]; }
+#define GB2_ROWS(k)                                                                    \
+  if (PHASE_ON(2048)) {                                                                \
+    if (((k) & 2) == 0) { s0 += lds[co + (k) * FLDH]; s1 += lds[co + ((k) + 1) * FLDH]; } \
+    else { s2 += lds[co + (k) * FLDH]; s3 += lds[co + ((k) + 1) * FLDH]; }             \
+  }
       // operands of k-step k+2 are read from LDS before the 16 MFMAs of k-step k are issued (the MFMA statement is
       // opaque to the scheduler, so the lookahead is written out by hand)
       float x0 = lds[ao], x1 = lds[ao + 32];
@@ -823,6 +833,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
         const float nx0 = lds[ao + k * FLDH], nx1 = lds[ao + k * FLDH + 32];
         const float n0 = bk[0], n1 = bk[32], n2 = bk[64], n3 = bk[96], n4 = bk[128], n5 = bk[160], n6 = bk[192],
                     n7 = bk[224];
+        GB2_ROWS(k)
         dw2_kstep(gW2, x0, x1, y0, y1, y2, y3, y4, y5, y6, y7);
         x0 = nx0; x1 = nx1; y0 = n0; y1 = n1; y2 = n2; y3 = n3; y4 = n4; y5 = n5; y6 = n6; y7 = n7;
       }
@@ -841,10 +852,15 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
         const float nx0 = lds[ao + k * FLDH], nx1 = lds[ao + k * FLDH + 32];
         const float n0 = bk[0], n1 = bk[32], n2 = bk[64], n3 = bk[96], n4 = bk[128], n5 = bk[160], n6 = bk[192],
                     n7 = bk[224];
+        GB2_ROWS(k)
         dw2_kstep(gW2, x0, x1, y0, y1, y2, y3, y4, y5, y6, y7);
         x0 = nx0; x1 = nx1; y0 = n0; y1 = n1; y2 = n2; y3 = n3; y4 = n4; y5 = n5; y6 = n6; y7 = n7;
       }
       dw2_kstep(gW2, x0, x1, y0, y1, y2, y3, y4, y5, y6, y7);
+#undef GB2_ROWS
+      gb2 += (s0 + s1) + (s2 + s3);
+    } else if (PHASE_ON(2048)) {
+      gb2 += column_sum(L::H2, tid);
     }
     // ---- dh1 = dz2 . W2 (K = 256), then dz1 = dh1 * (1 - h1^2) in place ----
     {
