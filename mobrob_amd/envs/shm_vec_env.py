@@ -151,8 +151,12 @@ def _worker_main(conn, wake, finished, w, n_workers, n, rows, env_fns_blob, bloc
         return n_trunc, n_eps
 
     try:
+        learner = mp.parent_process()
         while True:
-            wake.acquire()
+            if not wake.acquire(timeout=5.0):   # nothing to do: make sure the learner still exists (it may have been killed)
+                if learner is not None and not learner.is_alive():
+                    break
+                continue
             seq, op = int(ctl[0]), int(ctl[3])
             if op == OP_STEP:
                 ack[1], ack[2] = step_rows(int(ctl[1]), int(ctl[2]))

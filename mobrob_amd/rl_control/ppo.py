@@ -354,7 +354,9 @@ class PPO:
         envs that can step a row range) the rollout is pipelined: the simulator steps one range of robots while the
         GPU runs the policy for the others -- same results as the whole-batch loop."""
         e, env, N, b = self.engine, self.env, self.n_envs, self._host_bufs
-        parts = self.host_parts if hasattr(env, "step_range") else 1
+        # a handful of environments (the reference YAMLs: 2-16) leave nothing to overlap: one range, half the launches,
+        # event waits and worker round trips per step
+        parts = self.host_parts if hasattr(env, "step_range") and N >= 64 else 1
         finished = False
         e.rollout_begin()
         if parts > 1 and type(callback) is BaseCallback and hasattr(env, "step_range_fn"):

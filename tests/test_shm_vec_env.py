@@ -117,3 +117,33 @@ def test_close_leaves_nothing_in_dev_shm_and_a_dead_worker_is_reported():
 def test_unknown_environment_fails_at_construction():
     with pytest.raises(Exception):
         ShmVecEnv([functools.partial(get_env, env_name="unicycle")] * 2, n_workers=1)
+
+
+def test_workers_leave_when_the_learner_process_is_killed(tmp_path):
+    """A learner that dies without close() (SIGKILL) must not leave worker processes behind: they notice within their
+    wake-up timeout."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    script = tmp_path / "learner.py"
+    script.write_text(
+        "import functools, os, sys, time\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "from mobrob_amd.envs.shm_vec_env import ShmVecEnv\n"
+        "from mobrob_amd.envs.wrapper import get_env\n"
+        "if __name__ == '__main__':\n"
+        "    env = ShmVecEnv([functools.partial(get_env, env_name='point')] * 4, n_workers=2)\n"
+        "    env.reset()\n"
+        "    print(' '.join(str(p.pid) for p in env._procs), flush=True)\n"
+        "    time.sleep(60)\n")
+    proc = subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, text=True)
+    pids = [int(x) for x in proc.stdout.readline().split()]
+    assert len(pids) == 2 and all(os.path.exists(f"/proc/{p}") for p in pids)
+    proc.send_signal(signal.SIGKILL)                      # our own child, by handle
+    proc.wait(timeout=10)
+    deadline = time.time() + 20
+    while time.time() < deadline and any(os.path.exists(f"/proc/{p}") and "zombie" not in open(f"/proc/{p}/status").read() for p in pids):
+        time.sleep(0.5)
+    alive = [p for p in pids if os.path.exists(f"/proc/{p}") and "zombie" not in open(f"/proc/{p}/status").read()]
+    assert not alive, alive
