@@ -47,17 +47,17 @@ def test_registered_shared_block_is_accepted_as_pinned_memory():
     e.close()
 
 
-@pytest.mark.parametrize("hidden", [64, 256])
-def test_subproc_rollout_and_update_equal_the_in_process_path(hidden):
+@pytest.mark.parametrize("hidden,n_envs", [(64, 24), (256, 24), (64, 96)])   # 96 envs: two pipelined row ranges; 24: one range
+def test_subproc_rollout_and_update_equal_the_in_process_path(hidden, n_envs):
     """Same seeds -> the worker-process layer (pipelined over two row ranges, shared block read in place) and the
     in-process loop (`dummy`: HostVecEnv, staged copies, info dicts) fill bit-identical rollout buffers, and the
     update that follows leaves identical parameters."""
     from mobrob_amd.rl_control.ppo import BaseCallback, PPOCtrl
     out = {}
     for kind in ("dummy", "subproc"):
-        ctrl = PPOCtrl.from_config(_cfg(kind, hidden=hidden))
+        ctrl = PPOCtrl.from_config(_cfg(kind, hidden=hidden, n_envs=n_envs))
         ppo = ctrl.ppo
-        ppo.learn(total_timesteps=24 * 40)
+        ppo.learn(total_timesteps=n_envs * 40)
         out[kind] = (ppo.engine.get_flat_params(), list(ppo.ep_info_buffer), ppo.num_timesteps)
         cb = BaseCallback()
         cb.init_callback(ppo)
@@ -66,7 +66,7 @@ def test_subproc_rollout_and_update_equal_the_in_process_path(hidden):
         ppo.env.close()
         ppo.engine.close()
     (p_d, ep_d, n_d, buf_d), (p_s, ep_s, n_s, buf_s) = out["dummy"], out["subproc"]
-    assert n_d == n_s == 24 * 40
+    assert n_d == n_s == n_envs * 40
     for k in BUFS:
         assert np.array_equal(buf_d[k], buf_s[k]), k
     assert np.array_equal(p_d, p_s)
