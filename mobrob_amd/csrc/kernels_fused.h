@@ -1528,6 +1528,10 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
   __shared__ int tens[256];
   __shared__ float nts[16];
   __shared__ float coef_s, total_s;
+  // this thread's four operands are requested first: their memory latency runs under the norm fold below
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float g_in = 0.f, m_in = 0.f, v_in = 0.f, p_in = 0.f;
+  if (i < a.P) { g_in = a.g[i]; m_in = a.m[i]; v_in = a.v[i]; p_in = a.p[i]; }
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.st.stats_row != nullptr) stats_row_from_sums(a.st);  // pre-update log_std
   if (a.fold_idx != nullptr) {  // norm records of the reduction kernel, listed per tensor by the host
     const int nrec = a.fold_start[13];
@@ -1564,11 +1568,10 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
   }
   __syncthreads();
   const float coef = coef_s;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0 && a.stats_row != nullptr) a.stats_row[6] = total_s;
   if (i < 8 && a.loss_sums_zero != nullptr) a.loss_sums_zero[i] = 0.f;  // consumed by k_sqnorm_chunks; ready for the next step
   if (i >= a.P) return;
-  adam_pack_element(a, i, coef);
+  adam_pack_apply(a, i, g_in, m_in, v_in, p_in, coef);
 }
 
 // ------------------------------------------------------------------------------------------------
