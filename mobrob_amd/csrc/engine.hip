@@ -135,6 +135,7 @@ struct mobrob_ppo_engine {
   double* norm_rec_sum = nullptr; int* norm_rec_t = nullptr; int* fold_idx_dev = nullptr;
   int fold_start[14] = {0};
   bool use_norm_records = false;
+  int split64_max_tiles = 64;  // minibatches of up to this many 32-row tiles use k_split64_train (MOBROB_SPLIT64_MAX_TILES)
   // persistent small-batch update (kernels_train_small.h): one launch per epoch for 64-wide nets, minibatch <= 160 rows
   float* sched_dev = nullptr;              // [nmb][2] per-step Adam scalars of the epoch being enqueued
   unsigned long long* mail = nullptr;      // [2][2][16] hand-off words of the two workgroups
@@ -462,13 +463,18 @@ void fused64_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, floa
   const int grid = 2 * std::min(f.max_grid / 2, cdiv(ntiles, g_train_waves(e->Dp)));
   a.wpack[0] = reinterpret_cast<const float*>(f.net[0].W1f);
   a.wpack[1] = reinterpret_cast<const float*>(f.net[1].W1f);
+  // Small minibatches: one workgroup per tile (kernels_split64.h); its per-tile slabs are folded in groups of
+  // g_train_waves tiles, which reproduces the block kernel bit for bit as long as that kernel would have given every
+  // wave at most one tile.
+  const bool split = ntiles <= e->split64_max_tiles && 2 * ntiles <= f.max_grid && ntiles <= (grid / 2) * g_train_waves(e->Dp);
   {
     ProfScope ps(e, MOBROB_K_TRAIN_GRAD);
-    fused64_launch_train(f, a, grid, e->stream);
+    if (split) split64_launch_train(f, a, ntiles, e->stream);
+    else fused64_launch_train(f, a, grid, e->stream);
   }
   ProfScope pr(e, MOBROB_K_GRAD_REDUCE);
   Slab64ReduceArgs s{};
-  s.slabs = f.slabs; s.nblocks = grid; s.grads = e->grads; s.P = e->P;
+  s.slabs = f.slabs; s.nblocks = split ? 2 * ntiles : grid; s.group = split ? g_train_waves(e->Dp) : 1; s.grads = e->grads; s.P = e->P;
   for (int i = 0; i < 14; ++i) s.offs[i] = e->offs[i];
   s.D = e->D; s.A = e->A; s.ent_coef = (float)e->cfg.ent_coef; s.b_local = (float)B; s.inv_bg = inv_bg;
   s.sums = e->grads + e->P;
@@ -711,6 +717,7 @@ int engine_create(const mobrob_ppo_config_t* cfg, void* arena, size_t arena_byte
   CHK(check_device(cfg));
   auto* e = new mobrob_ppo_engine();
   *out = e;  // so that destroy() can clean up after a partial failure
+  if (const char* v = getenv("MOBROB_SPLIT64_MAX_TILES")) e->split64_max_tiles = atoi(v);  // 0: block kernel only (A/B, tests)
   CHK(engine_dims(e, cfg));
   HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   e->own_stream = true;

@@ -4,6 +4,7 @@
 #include "kernels_fused64.h"
 #include "kernels_rollout.h"
 #include "kernels_train_small.h"
+#include "kernels_split64.h"
 
 namespace mobrob {
 
@@ -35,6 +36,10 @@ inline void fused_launch_train(FusedState& f, FusedTrainArgs& a, int grid, hipSt
 }
 inline void fused64_launch_train(FusedState& f, Fused64TrainArgs& a, int grid, hipStream_t st) {
   FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused64_train<DPc>), dim3(grid), dim3(Lay64<DPc>::TNWV * 64), f.lds_bytes, st, a));
+}
+// one workgroup per (tile, network): small minibatches (kernels_split64.h)
+inline void split64_launch_train(FusedState& f, Fused64TrainArgs& a, int ntiles, hipStream_t st) {
+  FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_split64_train<DPc>), dim3(2 * ntiles), dim3(256), split64_lds_bytes(f.Dp), st, a));
 }
 inline void train_small_launch(FusedState& f, TrainSmallArgs& a, hipStream_t st) {
   const int threads = std::max(a.nw, 4) * 64;  // the norm reduction runs on 256 threads like k_sqnorm_chunks

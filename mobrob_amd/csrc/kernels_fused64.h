@@ -52,6 +52,7 @@ struct Lay64 {
 __host__ __device__ constexpr int g_train_waves(int DP) {
   return (40960 - (2 * (DP / 8) * 256 + 2 * 4096 + 2048 + 4096 / 2 + 128) - 96) / (GR * (DP + 4) + 2 * GR * GLDH + GR * FLDO + 64);
 }
+static_assert(g_train_waves(16) <= 4 && g_train_waves(64) >= 1, "k_slab64_reduce folds groups of at most four tiles");
 inline size_t fused64_train_lds_bytes(int Dp) {
   const int tw = 2 * (Dp / 8) * 256 + 2 * 4096 + 2048 + 2048 + 128;
   return (size_t)(tw + g_train_waves(Dp) * (GR * (Dp + 4) + 2 * GR * GLDH + GR * FLDO + 64) + 96) * sizeof(float);
@@ -630,6 +631,9 @@ __global__ __launch_bounds__(Lay64<DP>::TNWV * 64, 1) void k_fused64_train(Fused
 // ---- slab reduction for the 64-wide path: thread p sums slab position p over the waves of its network ----
 struct Slab64ReduceArgs {
   const float* slabs; int nblocks;  // train grid size; slab index = block, network = block & 1
+  int group;                        // <= 1: one slab per block of k_fused64_train.  G > 1: one slab per TILE
+                                    // (k_split64_train); G consecutive tiles are folded first, in order -- the wave
+                                    // fold of a k_fused64_train block -- and the folds are then summed like block slabs
   float* grads; int P;
   int offs[14];
   int D, A;
@@ -685,15 +689,35 @@ __global__ __launch_bounds__(256) void k_slab64_reduce(Slab64ReduceArgs s) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // blocks of this network: net, net+2, ...
     const float* src = s.slabs + (size_t)net * s64_size() + p;
     const size_t stride = 2 * (size_t)s64_size();
-    const int n = (s.nblocks - net + 1) / 2;
-    int w = 0;
-    for (; w + 4 <= n; w += 4) {
-      a0 += src[(size_t)w * stride];
-      a1 += src[(size_t)(w + 1) * stride];
-      a2 += src[(size_t)(w + 2) * stride];
-      a3 += src[(size_t)(w + 3) * stride];
+    const int nslabs = (s.nblocks - net + 1) / 2;
+    if (s.group <= 1) {
+      const int n = nslabs;
+      int w = 0;
+      for (; w + 4 <= n; w += 4) {
+        a0 += src[(size_t)w * stride];
+        a1 += src[(size_t)(w + 1) * stride];
+        a2 += src[(size_t)(w + 2) * stride];
+        a3 += src[(size_t)(w + 3) * stride];
+      }
+      for (; w < n; ++w) a0 += src[(size_t)w * stride];
+    } else {
+      const int G = s.group, n = (nslabs + G - 1) / G;
+      auto fold = [&](int gi) {  // tiles gi*G .. gi*G + G-1 in order (an idle wave of the block kernel added 0.f)
+        const int t0 = gi * G;
+        float x[4];                // G <= 4 (g_train_waves); all loads of a fold are independent
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = (u < G && t0 + u < nslabs) ? src[(size_t)(t0 + u) * stride] : 0.f;
+        return ((x[0] + x[1]) + x[2]) + x[3];
+      };
+      int w = 0;
+      for (; w + 4 <= n; w += 4) {
+        a0 += fold(w);
+        a1 += fold(w + 1);
+        a2 += fold(w + 2);
+        a3 += fold(w + 3);
+      }
+      for (; w < n; ++w) a0 += fold(w);
     }
-    for (; w < n; ++w) a0 += src[(size_t)w * stride];
     acc = (a0 + a1) + (a2 + a3);
     if (dst < s.offs[1]) acc += s.ent_coef * (-s.b_local) * s.inv_bg;
     s.grads[dst] = acc;

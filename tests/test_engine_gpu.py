@@ -821,3 +821,66 @@ def test_persistent_small_batch_update_is_bit_identical_to_the_per_step_path(cfg
     O.train(p, st, buf, h, perms)
     ref = O.flatten_params(p)
     assert np.max(np.abs(pa - ref)) < 1e-4, float(np.max(np.abs(pa - ref)))
+
+
+# ------------------------------------------------------------------------------------------------
+# one workgroup per tile for small minibatches (kernels_split64.h) against the one-wave-per-tile block kernel
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [dict(D=58, A=12, T=100, N=16, B=100, E=2),    # data/configs/doggo-ppo.yaml: four tiles
+                                 dict(D=14, A=2, T=450, N=2, B=100, E=2),      # point-ppo.yaml (DP=16)
+                                 dict(D=58, A=12, T=70, N=15, B=100, E=2),     # short last minibatch (50 rows)
+                                 dict(D=43, A=2, T=40, N=16, B=128, E=2),      # turtlebot3 (DP=48)
+                                 dict(D=26, A=2, T=64, N=4, B=64, E=2),        # car (DP=32), SB3's default batch
+                                 dict(D=12, A=18, T=50, N=16, B=100, E=2),     # drone: 18 actions (head > 16)
+                                 dict(D=58, A=12, T=64, N=64, B=1000, E=1),    # 32 tiles, the last one 8 rows; 11 block folds
+                                 dict(D=14, A=2, T=128, N=32, B=2048, E=1),    # 64 tiles (the default limit), 4-way block sums
+                                 dict(D=58, A=12, T=20, N=5, B=33, E=2)])      # one full tile + one row
+def test_split_tile_kernel_is_bit_identical_to_the_block_kernel(cfg, monkeypatch):
+    """k_split64_train (four waves share a tile; per-tile slabs folded in the block kernel's grouping) against
+    k_fused64_train (one wave per tile): gradients of one minibatch, then parameters, both Adam moments and every logged
+    statistic after whole train() calls must be the same BITS."""
+    D, A, T, N, B, E = (cfg[k] for k in "DATNBE")
+    H = 64
+    rng = np.random.default_rng(11)
+    p0 = O.init_params(D, A, (H, H), (H, H), seed=3)
+    p0["log_std"] = rng.normal(-0.2, 0.2, A).astype(np.float32)
+    p0["action_net.weight"] *= 20
+    buf, lv, dones = _consistent_rollout(p0, T, N, D, A, seed=6)
+    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=E, batch_size=B, learning_rate=3e-4)
+    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, h.gamma, h.gae_lambda)
+    perms = np.stack([rng.permutation(T * N) for _ in range(E)])
+    m0 = {k: rng.normal(0, 1e-3, v.shape).astype(np.float32) for k, v in p0.items()}
+    v0 = {k: (1e-6 * (0.5 + rng.random(v.shape))).astype(np.float32) for k, v in p0.items()}
+    out = {}
+    for split in (True, False):
+        if split:
+            monkeypatch.delenv("MOBROB_SPLIT64_MAX_TILES", raising=False)
+        else:
+            monkeypatch.setenv("MOBROB_SPLIT64_MAX_TILES", "0")
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H),
+                        ent_coef=h.ent_coef, learning_rate=h.learning_rate)
+        e.set_params(p0)
+        e.set_optimizer_state(m0, v0, 37)
+        e.load_rollout(buf, lv, dones)
+        e.epoch_begin(perms[0])
+        e.minibatch_grad(0)
+        g_first = e.read("grads")
+        n_mb = e.n_minibatches
+        e.minibatch_grad(n_mb - 1)          # the (possibly short) last minibatch
+        g_last = e.read("grads")
+        stats = e.train(perms)
+        out[split] = (g_first, g_last, e.get_flat_params(), e.get_optimizer_state(), stats)
+        e.close()
+    (ga, gla, pa, (ma, va, sa), sta), (gb, glb, pb, (mb_, vb, sb), stb) = out[True], out[False]
+    assert np.array_equal(ga, gb), float(np.max(np.abs(ga - gb)))
+    assert np.array_equal(gla, glb), float(np.max(np.abs(gla - glb)))
+    assert sa == sb
+    assert np.array_equal(pa, pb)
+    for k in ma:
+        assert np.array_equal(ma[k], mb_[k]) and np.array_equal(va[k], vb[k]), k
+    assert sta == stb, (sta, stb)
+    p = {k: v.copy() for k, v in p0.items()}
+    st = O.AdamState(type(p0)((k, v.copy()) for k, v in m0.items()), type(p0)((k, v.copy()) for k, v in v0.items()), 37)
+    O.train(p, st, buf, h, perms)
+    ref = O.flatten_params(p)
+    assert np.max(np.abs(pa - ref)) < 1e-4, float(np.max(np.abs(pa - ref)))
