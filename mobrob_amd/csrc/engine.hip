@@ -135,6 +135,7 @@ struct mobrob_ppo_engine {
   double* norm_rec_sum = nullptr; int* norm_rec_t = nullptr; int* fold_idx_dev = nullptr;
   int fold_start[14] = {0};
   bool use_norm_records = false;
+  int rollout64_tile_max = 256;  // rollouts of up to this many 32-env tiles use k_rollout64_tile (MOBROB_ROLLOUT64_TILE_MAX)
   int split64_max_tiles = 64;  // minibatches of up to this many 32-row tiles use k_split64_train (MOBROB_SPLIT64_MAX_TILES)
   // persistent small-batch update (kernels_train_small.h): one launch per epoch for 64-wide nets, minibatch <= 160 rows
   float* sched_dev = nullptr;              // [nmb][2] per-step Adam scalars of the epoch being enqueued
@@ -717,6 +718,7 @@ int engine_create(const mobrob_ppo_config_t* cfg, void* arena, size_t arena_byte
   CHK(check_device(cfg));
   auto* e = new mobrob_ppo_engine();
   *out = e;  // so that destroy() can clean up after a partial failure
+  if (const char* v = getenv("MOBROB_ROLLOUT64_TILE_MAX")) e->rollout64_tile_max = atoi(v);  // 0: one-wave kernel only
   if (const char* v = getenv("MOBROB_SPLIT64_MAX_TILES")) e->split64_max_tiles = atoi(v);  // 0: block kernel only (A/B, tests)
   CHK(engine_dims(e, cfg));
   HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -1193,8 +1195,13 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
     const int nwv = rollout64_waves(Dp);
     {
       ProfScope ps(e, MOBROB_K_ENV);
-      FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout64_persistent<DPc>), dim3(cdiv(cdiv(N, 32), nwv)), dim3(nwv * 64),
-                                               rollout64_lds_bytes(Dp), e->stream, a));
+      if (cdiv(N, 32) <= e->rollout64_tile_max) {  // one workgroup per tile while every tile gets a CU of its own
+        FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout64_tile<DPc>), dim3(cdiv(N, 32)), dim3(256), rollout64_tile_lds_bytes(Dp),
+                                                 e->stream, a));
+      } else {
+        FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout64_persistent<DPc>), dim3(cdiv(cdiv(N, 32), nwv)), dim3(nwv * 64),
+                                                 rollout64_lds_bytes(Dp), e->stream, a));
+      }
     }
     hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, e->stream, e->ctr_dev, (uint32_t)T, (uint32_t)T);
     HIPC(hipMemcpyAsync(e->last_dones, e->prev_dones, (size_t)N * 4, hipMemcpyDeviceToDevice, e->stream));

@@ -655,4 +655,323 @@ __global__ __launch_bounds__(LayRo64<DP>::NWV * 64, 1) void k_rollout64_persiste
   }
 }
 
+// weight fragments of one 32-column block held in registers, and a single-chain 32-row GEMM over them (the k order of
+// gemm_lds_packed_r32 / gemm_lds_lds_r32; see kernels_split64.h, which has the same pair for the training tile)
+template <int NKG>
+struct Frags {
+  f32x4 f[NKG];
+};
+template <int NKG>
+__device__ __forceinline__ Frags<NKG> load_frags_ro(const f32x4* __restrict__ Bp, int lane) {
+  Frags<NKG> w;
+  const unsigned bo = opaque_u((unsigned)lane * 16u);
+#pragma unroll
+  for (int kg = 0; kg < NKG; ++kg) w.f[kg] = ldg16(Bp, bo + (unsigned)kg * 1024u);
+  return w;
+}
+template <int LDA, int NKG>
+__device__ __forceinline__ void gemm_one_ro(int a_off, const Frags<NKG>& w, f32x16& c, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int ab = 4 * opaque((a_off + r * LDA + 4 * h) >> 2);
+#pragma unroll
+  for (int kg = 0; kg < NKG; ++kg) {
+    const f32x4 u = *reinterpret_cast<const f32x4*>(&lds[ab + 8 * kg]);
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) c = MFMA32(u[s_], w.f[kg][s_], c);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hidden width 64, ONE WORKGROUP (four waves) per 32-env tile: the layout of k_rollout_persistent (8 threads per row in
+// the env phase, block-wide sampling) with the 64-wide forward of k_rollout64_persistent split over two waves.
+//
+// k_rollout64_persistent gives a tile to one wave: 160 dependent MFMAs (4.3 us) plus Philox, sampling and the env rules
+// on 64 lanes -> 11.8 us per step, and a 16-env rollout (data/configs/doggo-ppo.yaml) keeps ONE wave of the chip busy
+// for 1000 steps.  Here waves 0 / 1 each own one 32-column block of both hidden layers and one of the two accumulation
+// chains of the head, with their weight fragments held in REGISTERS for the whole launch (the weights are constant
+// during a rollout: no LDS mirror, no B-operand reads in the step loop); waves 2 / 3 draw the step's normals meanwhile;
+// sampling and env.step run on all 256 threads.  Every accumulator sees the MFMA sequence of tile64_forward, the Philox
+// counters and the per-row expressions are those of the one-wave kernel -> bit-identical rollouts
+// (tests/test_engine_gpu.py::test_rollout64_tile_kernel_is_bit_identical...).  Used while the tiles fit one workgroup
+// per CU (N <= 8192); beyond that the one-wave kernel (four tiles per workgroup) has the better throughput.
+// ------------------------------------------------------------------------------------------------
+template <int DP>
+struct LayRoT {
+  static constexpr int LDX = DP + 4;
+  static constexpr int X = 0;
+  static constexpr int H1 = X + 32 * LDX;
+  static constexpr int H2 = H1 + 32 * GLDH;
+  static constexpr int DO = H2 + 32 * GLDH;   // head partial of wave 0 (even k-groups)
+  static constexpr int DO2 = DO + 32 * FLDO;  // head partial of wave 1 (odd k-groups)
+  static constexpr int CA = DO2 + 32 * FLDO;  // [32][33] clipped actions
+  static constexpr int ST = CA + 32 * 33;     // [32][16] row state
+  static constexpr int BL = ST + 32 * 16;     // bootstrap list: cnt[4] | row[32] | reward[32]
+  static constexpr int AC = BL + 4 + 64;      // per-action constants [4][32]
+  static constexpr int ZN = AC + 128;         // [32][32] standard normals
+  static constexpr int TM = ZN + 32 * 32;     // [32][33] log-prob terms
+  static constexpr int END = TM + 32 * 33;
+};
+inline size_t rollout64_tile_lds_bytes(int Dp) {
+  return (size_t)(32 * (Dp + 4) + 2 * 32 * GLDH + 2 * 32 * FLDO + 32 * 33 + 32 * 16 + 68 + 128 + 32 * 32 + 32 * 33) * sizeof(float);
+}
+
+template <int DP>
+__global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
+  using L = LayRoT<DP>;
+  constexpr int ldx = L::LDX, per = DP / 4, R = 32, NKG1 = DP / 8;
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const FusedNet W = a.pi;
+  const int row0 = blockIdx.x * R;
+  const int N = a.N, A = a.A, D = a.D;
+  int* cnt = reinterpret_cast<int*>(&lds[L::BL]);
+  int* lrow = cnt + 4;
+  float* lrew = &lds[L::BL + 4 + 32];
+  // ---- this wave's weight fragments: registers for the whole launch ----
+  Frags<NKG1> f1;
+  Frags<8> f2;
+  Frags<4> fh;  // head k-groups wave, wave + 2, wave + 4, wave + 6
+  float bias1 = 0.f, bias2 = 0.f;
+  if (wave < 2) {
+    const int l0 = tid0 & 63;
+    f1 = load_frags_ro<NKG1>(W.W1f + (size_t)wave * NKG1 * 64, l0);
+    f2 = load_frags_ro<8>(W.W2f + (size_t)wave * 8 * 64, l0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fh.f[j] = ldg16(W.W3f, (unsigned)l0 * 16u + (unsigned)(2 * j + wave) * 1024u);
+    bias1 = W.b1s[32 * wave + (l0 & 31)];
+    bias2 = W.b2s[32 * wave + (l0 & 31)];
+  }
+  // ---- carried state and the observation tile of step t0 -> LDS ----
+  if (tid0 < R) {
+    const int n = row0 + tid0;
+    float* S = &lds[L::ST + tid0 * 16];
+    if (n < N) {
+      if (a.kind == 2) {
+#pragma unroll
+        for (int j = 0; j < kGoalStateFloats; ++j) S[j] = a.gstate[(size_t)n * kGoalStateFloats + j];
+      } else {
+        reinterpret_cast<int*>(S)[13] = a.ep_len[n];
+      }
+      S[12] = a.prev_dones[n];
+    }
+  }
+  if (tid0 >= 64 && tid0 < 96) {  // per-action constants of the Gaussian head
+    const int k = tid0 - 64;
+    float sd = 1.f, bb = 0.f;
+    if (k < A) { sd = expf(a.log_std[k]); bb = W.b3[k]; }
+    lds[L::AC + k] = sd;
+    lds[L::AC + 32 + k] = 2.0f * (sd * sd);
+    lds[L::AC + 64 + k] = logf(sd);
+    lds[L::AC + 96 + k] = bb;
+  }
+  for (int i = tid0; i < R * per; i += 256) {
+    const int rr = i / per, c = i - rr * per;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row0 + rr < N)
+      v = ldg16(a.obs, (unsigned)((size_t)a.t0 * N + row0 + rr) * (unsigned)(DP * 4) + (unsigned)(c * 16));
+    *reinterpret_cast<f32x4*>(&lds[L::X + rr * ldx + 4 * c]) = v;
+  }
+  if (tid0 == 0) *cnt = 0;
+  __syncthreads();
+  const uint32_t dbase = a.draw_base ? *a.draw_base : 0u, sbase = a.step_base ? *a.step_base : 0u;
+  const uint32_t ek0 = (uint32_t)a.env_seed, ek1 = (uint32_t)(a.env_seed >> 32);
+
+  double es_n = 0.0, es_ret = 0.0, es_len = 0.0, es_goal = 0.0;  // finished episodes of this thread's row
+  for (int t = a.t0; t < a.t1; ++t) {
+    const int tid = opaque(tid0), lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    if (wave < 2) {  // layer 1: column block `wave`
+      f32x16 c = splat16(bias1);
+      gemm_one_ro<ldx, NKG1>(L::X, f1, c, lane);
+      const int o = opaque(L::H1 + 4 * h * GLDH + 32 * wave + r);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) lds[o + crc(i) * GLDH] = fast_tanh_scaled(c[i]);
+    } else {  // standard normals of this step (consumed after the head)
+      const int ngrp = (A + 3) >> 2;
+      for (int i = tid - 128; i < R * ngrp; i += 128) {
+        const int rr_ = i / ngrp, gq = i - rr_ * ngrp;
+        float z[4];
+        box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)gq, (uint32_t)t + dbase, 0x45505331u, (uint32_t)a.seed,
+                                  (uint32_t)(a.seed >> 32)), z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[L::ZN + rr_ * 32 + 4 * gq + j] = z[j];
+      }
+    }
+    __syncthreads();
+    if (wave < 2) {  // layer 2
+      f32x16 c = splat16(bias2);
+      gemm_one_ro<GLDH, 8>(L::H1, f2, c, lane);
+      const int o = opaque(L::H2 + 4 * h * GLDH + 32 * wave + r);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) lds[o + crc(i) * GLDH] = fast_tanh_scaled(c[i]);
+    }
+    __syncthreads();
+    if (wave < 2) {  // head: wave 0 the even k-groups (tile64_forward's `acc`), wave 1 the odd ones (`acc2`)
+      f32x16 acc = zero16();
+      const int ab = 4 * opaque((L::H2 + r * GLDH + 4 * h) >> 2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(&lds[ab + (2 * j + wave) * 8]);
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) acc = MFMA32(av[s_], fh.f[j][s_], acc);
+      }
+      const int o = opaque((wave == 0 ? L::DO : L::DO2) + 4 * h * FLDO + r);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) lds[o + crc(i) * FLDO] = acc[i];
+    }
+    __syncthreads();
+    // ---- Gaussian sample + log-prob (expressions and Philox counters of k_fused64_act), spread over the block ----
+    for (int i = tid; i < R * A; i += 256) {
+      const int rr_ = i / A, k = i - rr_ * A;
+      const int row = row0 + rr_;
+      if (row < N) {
+        const float m = (lds[L::DO + rr_ * FLDO + k] + lds[L::DO2 + rr_ * FLDO + k]) + lds[L::AC + 96 + k];
+        const float sd = lds[L::AC + k];
+        const float act = m + lds[L::ZN + rr_ * 32 + k] * sd;
+        const float d = act - m;
+        lds[L::TM + rr_ * 33 + k] = -(d * d) / lds[L::AC + 32 + k] - lds[L::AC + 64 + k] - 0.91893853320467274178f;
+        const float ac = fminf(fmaxf(act, a.lo), a.hi);
+        a.actions[((size_t)t * N + row) * A + k] = act;
+        a.clip_act[(size_t)row * A + k] = ac;
+        lds[L::CA + rr_ * 33 + k] = ac;
+      }
+    }
+    __syncthreads();
+    if (tid < R && row0 + tid < N) {
+      float lp = 0.f;
+      for (int k = 0; k < A; ++k) lp += lds[L::TM + tid * 33 + k];
+      a.logp[(size_t)t * N + row0 + tid] = lp;
+    }
+    // ---- env.step(clipped actions) + auto-reset: 8 threads per row (all in one wave), chunks sub, sub + 8 ----
+    const int rr = tid >> 3, sub = tid & 7;
+    const int n = row0 + rr;
+    const bool live = n < N;
+    const uint32_t step = sbase + (uint32_t)t;
+    float* S = &lds[L::ST + rr * 16];
+    float* xrow = &lds[L::X + rr * ldx];
+    float* trow = &lds[L::H2 + rr * GLDH];  // terminal observation staging (h2 is dead after the head GEMM)
+    const size_t onext = ((size_t)(t + 1) * N + (live ? n : 0)) * per;
+    bool tr = false, done = false, reached = false;
+    float reward = 0.f, ep_ret = 0.f;
+    int ep_len_new = 0, ep_len_fin = 0;
+    GoalState g{};
+    if (live) {
+      if (a.kind == 1) {
+        const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, ek0, ek1);
+        const bool term = u32_to_unit_open(mr.x) < a.p_term;
+        const int len = reinterpret_cast<const int*>(S)[13] + 1;
+        tr = (len >= a.time_limit) && !term;
+        done = term || tr;
+        ep_len_new = done ? 0 : len;
+        for (int c = sub; c < per; c += 8) {
+          float z[4];
+          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, ek0, ek1), z);
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
+          if (tr) {
+            reinterpret_cast<f32x4*>(a.term_obs)[(size_t)n * per + c] = o;
+            *reinterpret_cast<f32x4*>(&trow[4 * c]) = o;
+            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
+          }
+          reinterpret_cast<f32x4*>(a.obs)[onext + c] = o;
+          *reinterpret_cast<f32x4*>(&xrow[4 * c]) = o;
+        }
+        if (sub == 0) {
+          float zz[4];
+          box_muller4(Philox4{mr.y, mr.z, mr.w, mr.x ^ 0x9E3779B9u}, zz);
+          reward = 0.03f + 0.1f * zz[0] + (term ? 5.0f : 0.f);
+        }
+      } else {
+        g = goal_load(S);
+        const GoalOutcome o = goal_advance(g, a.goal, &lds[L::CA + rr * 33], A);
+        tr = o.tr; done = o.done; reached = o.reached; reward = o.reward;
+        ep_ret = g.ep_ret; ep_len_fin = g.ep_len;
+        GoalState gn = g;
+        if (done) goal_reset(gn, a.goal, o.reached, (uint32_t)n, step, ek0, ek1);
+        for (int c = sub; c < per; c += 8) {
+          float z[4];
+          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, ek0, ek1), z);
+          f32x4 ob = goal_features(g, a.goal.P, D, c, z, a.goal.noise);
+          if (done) {
+            if (tr) {
+              reinterpret_cast<f32x4*>(a.term_obs)[(size_t)n * per + c] = ob;
+              *reinterpret_cast<f32x4*>(&trow[4 * c]) = ob;
+            }
+            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
+            ob = goal_features(gn, a.goal.P, D, c, z, a.goal.noise);
+          }
+          reinterpret_cast<f32x4*>(a.obs)[onext + c] = ob;
+          *reinterpret_cast<f32x4*>(&xrow[4 * c]) = ob;
+        }
+        g = gn;
+      }
+    }
+    // the 8 threads of a row sit in ONE wave and have consumed the row's old state (program order): commit
+    if (live && sub == 0) {
+      const size_t so = (size_t)t * N + n;
+      a.es[so] = S[12];
+      S[12] = done ? 1.f : 0.f;
+      a.trunc[n] = tr ? 1 : 0;
+      if (a.kind == 1) {
+        reinterpret_cast<int*>(S)[13] = ep_len_new;
+      } else {
+        goal_store(S, g);
+        if (done) {  // Monitor statistics: accumulated per thread, flushed once per launch (see the kernel end)
+          es_n += 1.0; es_ret += (double)ep_ret; es_len += (double)ep_len_fin; es_goal += reached ? 1.0 : 0.0;
+          ep_ring_push(a.ep_stats, ep_ret, (float)ep_len_fin);
+        }
+      }
+      if (tr) {  // reward is written after the bootstrap below
+        const int q = atomicAdd(cnt, 1);
+        lrow[q] = rr;
+        lrew[q] = reward;
+      } else {
+        a.rewards[so] = reward;
+      }
+    }
+    __syncthreads();  // next observation tile, row state and the bootstrap list are complete
+    // ---- time-limit bootstrap of the (rare) truncated rows: wave 0 evaluates the value MLP row by row ----
+    const int m = *cnt;
+    if (m > 0) {  // block-uniform
+      if (wave == 0) {
+        for (int q = 0; q < m; ++q) {
+          const int br = lrow[q];
+          float* sc = &lds[L::H1];  // h1 is dead: scratch h1[G1] | h2[G2]
+          const float v = value_row_wave(&lds[L::H2 + br * GLDH], sc, sc + a.bt.G1, a.bt, D, lane);
+          if (lane == 0) {
+            a.bt.term_val[row0 + br] = v;
+            a.rewards[(size_t)t * N + row0 + br] = (float)((double)lrew[q] + (double)__fmul_rn(a.bt.gamma, v));
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) *cnt = 0;  // read again only after the next step's barriers
+    }
+  }
+  // ---- episode statistics: one set of atomics per wave and launch (order irrelevant: diagnostics) ----
+  if (a.kind == 2) {
+    const double n = wave_sum_d(es_n), r = wave_sum_d(es_ret), l = wave_sum_d(es_len), g = wave_sum_d(es_goal);
+    if ((tid0 & 63) == 0 && n > 0.0) {
+      atomicAdd(&a.ep_stats[0], n); atomicAdd(&a.ep_stats[1], r); atomicAdd(&a.ep_stats[2], l); atomicAdd(&a.ep_stats[3], g);
+    }
+  }
+  // ---- carried state back to global ----
+  if (tid0 < R) {
+    const int n = row0 + tid0;
+    const float* S = &lds[L::ST + tid0 * 16];
+    if (n < N) {
+      if (a.kind == 2) {
+#pragma unroll
+        for (int j = 0; j < kGoalStateFloats; ++j) a.gstate[(size_t)n * kGoalStateFloats + j] = S[j];
+      } else {
+        a.ep_len[n] = reinterpret_cast<const int*>(S)[13];
+      }
+      a.prev_dones[n] = S[12];
+    }
+  }
+}
+
 }  // namespace mobrob

@@ -21,6 +21,7 @@
 // fetches ALL fragments of its next phases before the barrier in front of them.
 #pragma once
 #include "kernels_fused64.h"
+#include "kernels_rollout.h"  // Frags<NKG>
 
 namespace mobrob {
 
@@ -41,10 +42,6 @@ inline size_t split64_lds_bytes(int Dp) {
   return (size_t)(GR * (Dp + 4) + 4 * GR * GLDH + GR * FLDO + 64 + 96) * sizeof(float);
 }
 
-template <int NKG>
-struct Frags {
-  f32x4 f[NKG];
-};
 template <int NKG>
 __device__ __forceinline__ Frags<NKG> load_frags(const f32x4* __restrict__ Bp, int lane, int nkg = NKG) {
   Frags<NKG> w;

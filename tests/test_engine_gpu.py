@@ -884,3 +884,42 @@ def test_split_tile_kernel_is_bit_identical_to_the_block_kernel(cfg, monkeypatch
     O.train(p, st, buf, h, perms)
     ref = O.flatten_params(p)
     assert np.max(np.abs(pa - ref)) < 1e-4, float(np.max(np.abs(pa - ref)))
+
+
+@pytest.mark.parametrize("kind", ["synthetic", "goal"])
+@pytest.mark.parametrize("D,A,N,T", [(58, 12, 16, 60),     # data/configs/doggo-ppo.yaml: half a tile
+                                     (14, 2, 2, 80),       # point-ppo.yaml: two envs
+                                     (43, 2, 37, 24),      # DP = 48, a ragged second tile
+                                     (12, 18, 100, 24),    # drone: 18 actions
+                                     (26, 2, 1024, 16)])   # car, 32 tiles (BASELINE config 2's env count)
+def test_rollout64_tile_kernel_is_bit_identical_to_the_one_wave_kernel(kind, D, A, N, T, monkeypatch):
+    """k_rollout64_tile (one workgroup per 32-env tile, forward split over two waves, weight fragments in registers)
+    against k_rollout64_persistent (one wave per tile): every rollout buffer incl. the bootstrapped rewards, the
+    truncation flags and the carried state over two consecutive rollouts must be the same BITS."""
+    from mobrob_amd.envs.vec_env import DeviceGoalVecEnv
+    H, TL = 64, 7
+    p = O.init_params(D, A, (H, H), (H, H), seed=8)
+    p["value_net.bias"] = np.array([2.0], np.float32)
+    res = {}
+    for tile in (True, False):
+        if tile:
+            monkeypatch.delenv("MOBROB_ROLLOUT64_TILE_MAX", raising=False)
+        else:
+            monkeypatch.setenv("MOBROB_ROLLOUT64_TILE_MAX", "0")
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=256, n_epochs=1, pi=(H, H), vf=(H, H), seed=21)
+        e.set_params(p)
+        out = []
+        for _ in range(2):
+            if kind == "synthetic":
+                e.collect_synthetic(p_term=0.05, time_limit=TL)
+            else:
+                DeviceGoalVecEnv(N, D, A, 2 if D < 12 or A != 18 else 3, time_limit=TL).collect(e)
+            e.synchronize()
+            out.append({k: e.read(k) for k in ("obs", "actions", "log_probs", "rewards", "episode_starts", "values", "last_values",
+                                               "last_dones", "advantages", "returns", "truncated", "terminal_values", "terminal_obs")})
+        res[tile] = out
+        e.close()
+    for a, b in zip(res[True], res[False]):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+        assert a["episode_starts"][1:].sum() > 0 and a["truncated"].size  # resets and truncations were part of it
