@@ -693,6 +693,18 @@ __global__ __launch_bounds__(256) void k_slab64_reduce(Slab64ReduceArgs s) {
     if (s.group <= 1) {
       const int n = nslabs;
       int w = 0;
+      for (; w + 16 <= n; w += 16) {  // sixteen loads in flight; the adds keep the four-accumulator order below
+        float x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = src[(size_t)(w + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+          a0 += x[u];
+          a1 += x[u + 1];
+          a2 += x[u + 2];
+          a3 += x[u + 3];
+        }
+      }
       for (; w + 4 <= n; w += 4) {
         a0 += src[(size_t)w * stride];
         a1 += src[(size_t)(w + 1) * stride];
