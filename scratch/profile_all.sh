@@ -10,6 +10,7 @@ cp $(find /tmp/p_kt -name "*kernel_stats.csv" | head -1) $O/fused_kernel_stats.c
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_f -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_w -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
 python3 $R/profiles/tools/pmc_traffic.py /tmp/p_f /tmp/p_w > $O/hbm_traffic_pmc.json
+cp $O/hbm_traffic_pmc.json $R/profiles/r2/hbm_traffic_pmc.json   # the bench lines below report this run's traffic figure (same sources)
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/p_sq -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
 python3 $R/profiles/tools/pmc_sq_summary.py /tmp/p_sq > $O/sq_counters_summary.txt 2>&1
 cd $R
