@@ -11,14 +11,37 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kWave = 64;
 
+// Value of lane (l ^ o) for o = 1, 2, 4, 8 as DPP moves (one or two VALU instructions) instead of ds_bpermute_b32 (an LDS
+// round trip each: hipcc lowers every __shfl_xor to it, and a butterfly is a chain of dependent ones).  Exactly the
+// xor exchange -- same partner, same bits -- so every reduction built on it keeps its summation order.
+//   quad_perm [1,0,3,2] / [2,3,0,1];  xor 4: row_shl:4 into banks 0,2 + row_shr:4 into banks 1,3;  xor 8: row_ror:8.
+__device__ __forceinline__ int xor_lane_i(int v, int o) {
+  switch (o) {
+    case 1: return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);
+    case 2: return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);
+    case 4: {
+      const int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);
+      return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);
+    }
+    case 8: return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false);
+    default: return __shfl_xor(v, o, 64);
+  }
+}
+__device__ __forceinline__ float xor_lane(float v, int o) { return __int_as_float(xor_lane_i(__float_as_int(v), o)); }
+__device__ __forceinline__ double xor_lane(double v, int o) {
+  const long long b = __double_as_longlong(v);
+  const int lo = xor_lane_i((int)(b & 0xffffffffll), o), hi = xor_lane_i((int)(b >> 32), o);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 32; o > 0; o >>= 1) v += xor_lane(v, o);
   return v;
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 32; o > 0; o >>= 1) v += xor_lane(v, o);
   return v;
 }
 

@@ -136,6 +136,7 @@ struct mobrob_ppo_engine {
   int fold_start[14] = {0};
   bool use_norm_records = false;
   int rollout64_tile_max = 256;  // rollouts of up to this many 32-env tiles use k_rollout64_tile (MOBROB_ROLLOUT64_TILE_MAX)
+  int pair64_min_tiles = 65;     // minibatches of at least this many tiles use k_pair64_train (MOBROB_PAIR64_MIN_TILES; 0: never)
   int split64_max_tiles = 64;  // minibatches of up to this many 32-row tiles use k_split64_train (MOBROB_SPLIT64_MAX_TILES)
   // persistent small-batch update (kernels_train_small.h): one launch per epoch for 64-wide nets, minibatch <= 160 rows
   float* sched_dev = nullptr;              // [nmb][2] per-step Adam scalars of the epoch being enqueued
@@ -395,7 +396,10 @@ int fused_init(mobrob_ppo_engine* e) {
   f.max_grid = 256;
   if (H == 64) {
     f.slab_floats = s64_size();
-    CHK(dalloc(e, &f.slabs, (size_t)f.max_grid * f.slab_floats));  // one slab per block
+    // one slab per block (k_fused64_train), per tile (k_split64_train) or per two-wave workgroup (k_pair64_train)
+    const int tiles_max = cdiv(std::min(e->Bl, e->N * e->T), GR);
+    f.pair_nseq_max = std::min(kPairsPerCu * 256 / 2, tiles_max);
+    CHK(dalloc(e, &f.slabs, (size_t)std::max(f.max_grid, 2 * f.pair_nseq_max) * f.slab_floats));
     f.lds_bytes = fused64_train_lds_bytes(e->Dp);
     f.lds_act_bytes = fused64_lds_bytes(e->Dp);
   } else {
@@ -459,7 +463,7 @@ void fused64_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, floa
   a.advstat = e->advstat + 4 * (size_t)mb; a.normalize = e->cfg.normalize_advantage;
   a.clip = (float)e->cfg.clip_range; a.vf_coef = (float)e->cfg.vf_coef; a.ent_coef = (float)e->cfg.ent_coef;
   a.clip_vf = (float)e->clip_vf; a.old_values = e->values;
-  a.inv_bg = inv_bg; a.slabs = f.slabs; a.sums = e->grads + e->P;
+  a.inv_bg = inv_bg; a.slabs = f.slabs; a.sums = e->grads + e->P; a.stamps = f.stamps;
   const int ntiles = cdiv(B, GR);
   const int grid = 2 * std::min(f.max_grid / 2, cdiv(ntiles, g_train_waves(e->Dp)));
   a.wpack[0] = reinterpret_cast<const float*>(f.net[0].W1f);
@@ -468,19 +472,24 @@ void fused64_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, floa
   // g_train_waves tiles, which reproduces the block kernel bit for bit as long as that kernel would have given every
   // wave at most one tile.
   const bool split = ntiles <= e->split64_max_tiles && 2 * ntiles <= f.max_grid && ntiles <= (grid / 2) * g_train_waves(e->Dp);
+  // Large minibatches: persistent two-wave workgroups, four per CU (kernels_pair64.h); one slab per workgroup.
+  const bool pair = !split && e->pair64_min_tiles > 0 && ntiles >= e->pair64_min_tiles;
+  const int nseq = std::min(ntiles, f.pair_nseq_max);
   {
     ProfScope ps(e, MOBROB_K_TRAIN_GRAD);
     if (split) split64_launch_train(f, a, ntiles, e->stream);
+    else if (pair) pair64_launch_train(f, a, nseq, e->stream);
     else fused64_launch_train(f, a, grid, e->stream);
   }
   ProfScope pr(e, MOBROB_K_GRAD_REDUCE);
   Slab64ReduceArgs s{};
-  s.slabs = f.slabs; s.nblocks = split ? 2 * ntiles : grid; s.group = split ? g_train_waves(e->Dp) : 1; s.grads = e->grads; s.P = e->P;
+  s.slabs = f.slabs; s.nblocks = split ? 2 * ntiles : (pair ? 2 * nseq : grid); s.group = split ? g_train_waves(e->Dp) : 1; s.grads = e->grads; s.P = e->P;
   for (int i = 0; i < 14; ++i) s.offs[i] = e->offs[i];
   s.D = e->D; s.A = e->A; s.ent_coef = (float)e->cfg.ent_coef; s.b_local = (float)B; s.inv_bg = inv_bg;
   s.sums = e->grads + e->P;
   s.rec_sum = e->use_norm_records ? e->norm_rec_sum : nullptr; s.rec_t = e->norm_rec_t;
-  hipLaunchKernelGGL(k_slab64_reduce, dim3(cdiv(s64_size(), 256), 2), dim3(256), 0, e->stream, s);
+  if (pair && nseq > 128) hipLaunchKernelGGL(k_slab64_reduce_wide, dim3(cdiv(s64_size(), 256), 2), dim3(1024), 0, e->stream, s);
+  else hipLaunchKernelGGL(k_slab64_reduce, dim3(cdiv(s64_size(), 256), 2), dim3(256), 0, e->stream, s);
 }
 
 // fused minibatch gradient: one persistent kernel + the deterministic slab reduction
@@ -719,6 +728,7 @@ int engine_create(const mobrob_ppo_config_t* cfg, void* arena, size_t arena_byte
   auto* e = new mobrob_ppo_engine();
   *out = e;  // so that destroy() can clean up after a partial failure
   if (const char* v = getenv("MOBROB_ROLLOUT64_TILE_MAX")) e->rollout64_tile_max = atoi(v);  // 0: one-wave kernel only
+  if (const char* v = getenv("MOBROB_PAIR64_MIN_TILES")) e->pair64_min_tiles = atoi(v);  // 0: block kernel for large minibatches
   if (const char* v = getenv("MOBROB_SPLIT64_MAX_TILES")) e->split64_max_tiles = atoi(v);  // 0: block kernel only (A/B, tests)
   CHK(engine_dims(e, cfg));
   HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -2050,7 +2060,7 @@ int mobrob_ppo_profile_read(mobrob_ppo_engine_t* e, double* ms, int64_t* calls) 
   return MOBROB_OK;
 }
 
-#ifdef MOBROB_STAMPS
+#if defined(MOBROB_STAMPS) || defined(MOBROB_PAIR_STAMPS)
 // diagnostic build only (not part of include/mobrob_ppo.h)
 int mobrob_dbg_read_stamps(mobrob_ppo_engine_t* e, unsigned long long* out32, int reset) {
   HIPC(hipStreamSynchronize(e->stream));

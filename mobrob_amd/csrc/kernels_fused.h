@@ -696,8 +696,8 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
           }
           dk[j] = d;
         }
-        lp += __shfl_xor(lp, 1, 64);
-        lp += __shfl_xor(lp, 2, 64);
+        lp += xor_lane(lp, 1);
+        lp += xor_lane(lp, 2);
         float g_logp = 0.f;
         if (live) {
           float adv = l_adv;
@@ -724,8 +724,8 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
           if (4 * j < A) {  // wave-uniform: sum over the 16 rows of this wave (lanes with equal q)
 #pragma unroll
             for (int o = 4; o < 64; o <<= 1) {
-              gm += __shfl_xor(gm, o, 64);
-              gl += __shfl_xor(gl, o, 64);
+              gm += xor_lane(gm, o);
+              gl += xor_lane(gl, o);
             }
             if (lane < 4) {
               lds[gb + 4 * j] += gm;
@@ -1587,6 +1587,7 @@ struct FusedState {
   float* slabs = nullptr;
   unsigned long long* stamps = nullptr;  // diagnostic build only
   int slab_floats = 0, max_grid = 0;
+  int pair_nseq_max = 0;  // 64-wide nets: two-wave workgroups per network of k_pair64_train (slabs are sized for them)
   size_t lds_bytes = 0, lds_act_bytes = 0;
 };
 

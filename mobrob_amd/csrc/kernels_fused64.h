@@ -214,6 +214,7 @@ struct Fused64TrainArgs {
   float clip_vf; const float* old_values;  // clip_range_vf (< 0: none) and the rollout's value predictions
   float* slabs;   // [gridDim.x][s64_size()]
   float* sums;
+  unsigned long long* stamps;  // diagnostic builds (-DMOBROB_PAIR_STAMPS): per-phase cycle sums
 };
 
 // Per-wave gradient accumulators of one network (registers): dW2 4 tiles [ib][jb] = 00, 10, 01, 11; dW1 <= 4 tiles;
@@ -331,8 +332,8 @@ __device__ __forceinline__ void tile64_train(const Fused64TrainArgs& a, const Fu
         if (2 * j < A) {  // wave-uniform: sum over the 32 rows (lanes with equal q)
 #pragma unroll
           for (int o = 1; o < 32; o <<= 1) {
-            gm += __shfl_xor(gm, o, 64);
-            gl += __shfl_xor(gl, o, 64);
+            gm += xor_lane(gm, o);
+            gl += xor_lane(gl, o);
           }
           if (r == 0) {
             lds[gb + 2 * j] += gm;
@@ -731,6 +732,61 @@ __global__ __launch_bounds__(256) void k_slab64_reduce(Slab64ReduceArgs s) {
       for (; w < n; ++w) a0 += fold(w);
     }
     acc = (a0 + a1) + (a2 + a3);
+    if (dst < s.offs[1]) acc += s.ent_coef * (-s.b_local) * s.inv_bg;
+    s.grads[dst] = acc;
+  }
+  if (s.rec_sum != nullptr) {
+    const size_t b = ((size_t)net * gridDim.x + blockIdx.x) * kNormRec;
+    block_norm_records(tensor_of_canonical(s.offs, s.P, dst), acc, s.rec_sum + b, s.rec_t + b);
+  }
+}
+
+// The same reduction for MANY slabs per network (k_pair64_train: up to 512): four groups of 256 threads take a quarter
+// of the slabs each (sixteen loads in flight per thread), the quarters are added in fixed order, and the first group
+// finishes as k_slab64_reduce does (entropy term, store, norm records: same 256 positions per block, same record table).
+__global__ __launch_bounds__(1024) void k_slab64_reduce_wide(Slab64ReduceArgs s) {
+  __shared__ float part[4][256];
+  const int tp = threadIdx.x & 255, q = threadIdx.x >> 8;
+  const int p = blockIdx.x * 256 + tp;
+  const int net = blockIdx.y;
+  if (p == 0 && net == 0 && q == 0) s.sums[4] = s.b_local;
+  const int dst = p < s64_size() ? slab64_to_canonical(s, net, p) : -1;
+  float sum = 0.f;
+  if (dst >= 0) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float* src = s.slabs + (size_t)net * s64_size() + p;
+    const size_t stride = 2 * (size_t)s64_size();
+    const int nslabs = (s.nblocks - net + 1) / 2;
+    const int per = (nslabs + 3) / 4;
+    int w = q * per;
+    const int n = min(nslabs, w + per);
+    for (; w + 16 <= n; w += 16) {
+      float x[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) x[u] = src[(size_t)(w + u) * stride];
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) {
+        a0 += x[u];
+        a1 += x[u + 1];
+        a2 += x[u + 2];
+        a3 += x[u + 3];
+      }
+    }
+    for (; w + 4 <= n; w += 4) {
+      a0 += src[(size_t)w * stride];
+      a1 += src[(size_t)(w + 1) * stride];
+      a2 += src[(size_t)(w + 2) * stride];
+      a3 += src[(size_t)(w + 3) * stride];
+    }
+    for (; w < n; ++w) a0 += src[(size_t)w * stride];
+    sum = (a0 + a1) + (a2 + a3);
+  }
+  part[q][tp] = sum;
+  __syncthreads();
+  if (q > 0) return;  // waves 4..15 are done; the barrier inside block_norm_records counts the four that remain
+  float acc = 0.f;
+  if (dst >= 0) {
+    acc = ((part[0][tp] + part[1][tp]) + part[2][tp]) + part[3][tp];
     if (dst < s.offs[1]) acc += s.ent_coef * (-s.b_local) * s.inv_bg;
     s.grads[dst] = acc;
   }

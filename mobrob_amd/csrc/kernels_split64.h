@@ -241,8 +241,8 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
         if (2 * j < A) {  // wave-uniform: sum over the 32 rows (lanes with equal q)
 #pragma unroll
           for (int o = 1; o < 32; o <<= 1) {
-            gm += __shfl_xor(gm, o, 64);
-            gl += __shfl_xor(gl, o, 64);
+            gm += xor_lane(gm, o);
+            gl += xor_lane(gl, o);
           }
           if (r == 0) {
             lds[gb + 2 * j] += gm;

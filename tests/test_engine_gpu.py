@@ -923,3 +923,65 @@ def test_rollout64_tile_kernel_is_bit_identical_to_the_one_wave_kernel(kind, D, 
         for k in a:
             assert np.array_equal(a[k], b[k]), k
         assert a["episode_starts"][1:].sum() > 0 and a["truncated"].size  # resets and truncations were part of it
+
+
+# ------------------------------------------------------------------------------------------------
+# persistent two-wave workgroups for large minibatches (kernels_pair64.h) against the block kernel and the oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [dict(D=14, A=2, T=64, N=128, B=4096, E=1),     # BASELINE config 2's robot: 128 tiles (DP=16)
+                                 dict(D=58, A=12, T=64, N=128, B=8192, E=1),    # doggo 2x64 (DP=64): 256 tiles = one full minibatch
+                                 dict(D=43, A=2, T=50, N=100, B=3000, E=1),     # turtlebot3 (DP=48): ragged last tile, short last minibatch
+                                 dict(D=26, A=2, T=40, N=600, B=24000, E=1),    # car (DP=32): 750 tiles > 512 workgroups -> two tiles per pair
+                                 dict(D=12, A=18, T=64, N=64, B=2100, E=2)])    # drone: 18 actions (head > 16)
+def test_pair_kernel_matches_the_block_kernel_and_the_oracle(cfg, monkeypatch):
+    """k_pair64_train (two waves per tile, four workgroups per CU, accumulators over the workgroup's tiles) against
+    k_fused64_train: the same per-tile arithmetic in another tile order -> gradients agree to rounding (1e-5 of each
+    tensor's scale); a whole train() matches the oracle like the other paths."""
+    D, A, T, N, B, E = (cfg[k] for k in "DATNBE")
+    H = 64
+    rng = np.random.default_rng(12)
+    p0 = O.init_params(D, A, (H, H), (H, H), seed=4)
+    p0["log_std"] = rng.normal(-0.2, 0.2, A).astype(np.float32)
+    p0["action_net.weight"] *= 20
+    buf, lv, dones = _consistent_rollout(p0, T, N, D, A, seed=7)
+    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=E, batch_size=B, learning_rate=3e-4)
+    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, h.gamma, h.gae_lambda)
+    perms = np.stack([rng.permutation(T * N) for _ in range(E)])
+    m0 = {k: rng.normal(0, 1e-3, v.shape).astype(np.float32) for k, v in p0.items()}
+    v0 = {k: (1e-6 * (0.5 + rng.random(v.shape))).astype(np.float32) for k, v in p0.items()}
+    out = {}
+    for pair in (True, False):
+        if pair:
+            monkeypatch.delenv("MOBROB_PAIR64_MIN_TILES", raising=False)
+        else:
+            monkeypatch.setenv("MOBROB_PAIR64_MIN_TILES", "0")
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H),
+                        ent_coef=h.ent_coef, learning_rate=h.learning_rate)
+        e.set_params(p0)
+        e.set_optimizer_state(m0, v0, 37)
+        e.load_rollout(buf, lv, dones)
+        e.epoch_begin(perms[0])
+        e.minibatch_grad(0)
+        g_first = e.read("grads")
+        e.minibatch_grad(e.n_minibatches - 1)
+        g_last = e.read("grads")
+        e.minibatch_grad(0)
+        g_again = e.read("grads")
+        stats = e.train(perms)
+        out[pair] = (g_first, g_last, g_again, e.get_flat_params(), stats)
+        e.close()
+    (ga, gla, ga2, pa, sta), (gb, glb, _, pb, stb) = out[True], out[False]
+    assert np.array_equal(ga, ga2)                                  # run-to-run deterministic
+    offs = np.cumsum([0] + [v.size for v in p0.values()])
+    for g1, g2 in ((ga, gb), (gla, glb)):
+        for i, k in enumerate(p0):
+            a_, b_ = g1[offs[i]:offs[i + 1]], g2[offs[i]:offs[i + 1]]
+            assert np.max(np.abs(a_ - b_)) <= 1e-5 * max(np.max(np.abs(b_)), 1e-12), (k, float(np.max(np.abs(a_ - b_))), float(np.max(np.abs(b_))))
+    assert np.max(np.abs(pa - pb)) < 2e-6, float(np.max(np.abs(pa - pb)))
+    for k in ("policy_loss", "value_loss", "approx_kl", "clip_fraction"):
+        assert abs(sta[k] - stb[k]) <= 1e-5 * max(1.0, abs(stb[k])), (k, sta[k], stb[k])
+    p = {k: v.copy() for k, v in p0.items()}
+    st = O.AdamState(type(p0)((k, v.copy()) for k, v in m0.items()), type(p0)((k, v.copy()) for k, v in v0.items()), 37)
+    O.train(p, st, buf, h, perms)
+    ref = O.flatten_params(p)
+    assert np.max(np.abs(pa - ref)) < 1e-4, float(np.max(np.abs(pa - ref)))
