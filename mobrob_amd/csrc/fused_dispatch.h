@@ -38,12 +38,7 @@ inline void fused_launch_train(FusedState& f, FusedTrainArgs& a, int grid, hipSt
 inline void fused64_launch_train(FusedState& f, Fused64TrainArgs& a, int grid, hipStream_t st) {
   FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused64_train<DPc>), dim3(grid), dim3(Lay64<DPc>::TNWV * 64), f.lds_bytes, st, a));
 }
-// one workgroup per (tile, network): small minibatches (kernels_split64.h)
-inline void split64_launch_train(FusedState& f, Fused64TrainArgs& a, int ntiles, hipStream_t st) {
-  FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_split64_train<DPc>), dim3(2 * ntiles), dim3(256), split64_lds_bytes(f.Dp), st, a));
-}
-// persistent two-wave workgroups, four per CU: large minibatches (kernels_pair64.h)
-#define PAIR64_DISPATCH_NJ(A_, CALL)                                   \
+#define FUSED64_DISPATCH_NJ(A_, CALL)                                   \
   do {                                                                  \
   if ((A_) <= 2) { constexpr int NJc = 1; CALL; }                       \
   else if ((A_) <= 4) { constexpr int NJc = 2; CALL; }                  \
@@ -52,10 +47,15 @@ inline void split64_launch_train(FusedState& f, Fused64TrainArgs& a, int ntiles,
   else if ((A_) <= 20) { constexpr int NJc = 10; CALL; }                \
   else { constexpr int NJc = 16; CALL; }                                \
   } while (0)
+// one workgroup per (tile, network): small minibatches (kernels_split64.h)
+inline void split64_launch_train(FusedState& f, Fused64TrainArgs& a, int ntiles, hipStream_t st) {
+  FUSED_DISPATCH_DP(f.Dp, FUSED64_DISPATCH_NJ(f.A, hipLaunchKernelGGL((k_split64_train<DPc, NJc>), dim3(2 * ntiles), dim3(256), split64_lds_bytes(f.Dp), st, a)));
+}
+// persistent two-wave workgroups, four per CU: large minibatches (kernels_pair64.h)
 inline void pair64_launch_train(FusedState& f, Fused64TrainArgs& a, int nseq, hipStream_t st) {
   const int nbseq = (nseq + 1) / 2;  // two pairs (tile sequences) per workgroup
   const int grid = 16 * ((nbseq + 7) / 8);
-  FUSED_DISPATCH_DP(f.Dp, PAIR64_DISPATCH_NJ(f.A, hipLaunchKernelGGL((k_pair64_train<DPc, NJc>), dim3(grid), dim3(256), pair64_lds_bytes(f.Dp), st, a, nseq)));
+  FUSED_DISPATCH_DP(f.Dp, FUSED64_DISPATCH_NJ(f.A, hipLaunchKernelGGL((k_pair64_train<DPc, NJc>), dim3(grid), dim3(256), pair64_lds_bytes(f.Dp), st, a, nseq)));
 }
 inline void train_small_launch(FusedState& f, TrainSmallArgs& a, hipStream_t st) {
   const int threads = std::max(a.nw, 4) * 64;  // the norm reduction runs on 256 threads like k_sqnorm_chunks
@@ -71,7 +71,7 @@ inline hipError_t fused_set_lds_attr(FusedState& f) {
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout64_persistent<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rollout64_lds_bytes(f.Dp));
       if (e == hipSuccess)
-        PAIR64_DISPATCH_NJ(f.A, e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair64_train<DPc, NJc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair64_lds_bytes(f.Dp)));
+        FUSED64_DISPATCH_NJ(f.A, e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair64_train<DPc, NJc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair64_lds_bytes(f.Dp)));
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_small<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)train_small_lds_bytes(f.Dp, train_small_max_waves(f.Dp)));

@@ -67,7 +67,9 @@ __device__ __forceinline__ void gemm_one(int a_off, const Frags<NKG>& w, f32x16&
 }
 
 // slab of tile (blockIdx.x >> 1) of network (blockIdx.x & 1): layout of k_fused64_train's block slab
-template <int DP>
+// NJ: action pairs the loss stage is unrolled over (2 NJ >= A).  The head tile's columns beyond A are exact +0 from the
+// zero-padded head pack -- the very values tile64_train writes there -- so the shorter loops change no bit.
+template <int DP, int NJ>
 __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
   using L = LayS64<DP>;
   constexpr int ldx = L::LDX, per = DP / 4, NKG1 = DP / 8;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
   }
   // ---- operands of the loss stage (wave 0, two lanes per row), in flight during the forward pass ----
   const bool llive = row0 + r < cnt;
-  float l_adv = 0.f, l_old = 0.f, l_act[16];
+  float l_adv = 0.f, l_old = 0.f, l_act[NJ];
   float adv_mean = 0.f, adv_sd = 1.f;
   bool adv_on = false;
   if (wave == 0) {
@@ -109,11 +111,11 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
     if (net == 0) {
       const float* arow = a.actions + (size_t)src * a.A + h;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) l_act[j] = (2 * j + h < a.A && llive) ? arow[2 * j] : 0.f;
+      for (int j = 0; j < NJ; ++j) l_act[j] = (2 * j + h < a.A && llive) ? arow[2 * j] : 0.f;
       if (llive) { l_adv = a.adv[src]; l_old = a.old_logp[src]; }
     } else {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) l_act[j] = 0.f;
+      for (int j = 0; j < NJ; ++j) l_act[j] = 0.f;
       if (llive) {
         l_old = a.ret[src];
         if (a.clip_vf >= 0.f) l_adv = a.old_values[src];
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
     adv_sd = (float)sqrt(var);
   } else {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) l_act[j] = 0.f;
+    for (int j = 0; j < NJ; ++j) l_act[j] = 0.f;
   }
   if (tid0 >= 64 && tid0 < 96) {  // per-action constants
     const int k = tid0 - 64;
@@ -199,9 +201,9 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
     const int A = a.A;
     if (net == 0) {
       float lp = 0.f;
-      float dk[16];
+      float dk[NJ];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         float d = 0.f;
         if (2 * j + q < A && live) {
           d = l_act[j] - (lds[db + 2 * j] + lds[cb + 64 + 2 * j]);
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
         g_logp = -(w1 * adv + (1.0f - w1) * adv * in_range) * a.inv_bg * ratio;
       }
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {  // k = 2j + q; wave-uniform trip count
+      for (int j = 0; j < NJ; ++j) {  // k = 2j + q
         const int k = 2 * j + q;
         float gm = 0.f, gl = 0.f;
         if (k < A && live) {
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
         s_vl += sq;
         dv = a.vf_coef * gv_ * a.inv_bg;
       }
-      for (int j = 0; j < 16; ++j) lds[db + 2 * j] = (j == 0) ? dv : 0.f;
+      lds[db] = dv;  // column q of the row: dv (q = 0) or 0; the columns beyond are +0 already
       const float t = wave_sum(dv);
       if (lane == 0) lds[gb] += t;
     }
