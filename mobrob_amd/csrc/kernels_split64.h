@@ -200,15 +200,22 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
     const int gb = opaque(L::GACC + q);
     const int A = a.A;
     if (net == 0) {
+      // per-action constants of this lane's actions k = 2j + q (registers), masks by multiplication: the same values
+      // as the predicated form (x * 1 and s + 0 are exact), without per-lane branches
+      float c_iv[NJ], c_lc[NJ], c_bb[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        c_iv[j] = lds[cb + 2 * j];
+        c_lc[j] = lds[cb + 32 + 2 * j];
+        c_bb[j] = lds[cb + 64 + 2 * j];
+      }
       float lp = 0.f;
       float dk[NJ];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        float d = 0.f;
-        if (2 * j + q < A && live) {
-          d = l_act[j] - (lds[db + 2 * j] + lds[cb + 64 + 2 * j]);
-          lp += -(d * d) * (0.5f * lds[cb + 2 * j]) - lds[cb + 32 + 2 * j];
-        }
+        const float on = (2 * j + q < A && live) ? 1.f : 0.f;
+        const float d = on * (l_act[j] - (lds[db + 2 * j] + c_bb[j]));
+        lp += on * (-(d * d) * (0.5f * c_iv[j]) - c_lc[j]);
         dk[j] = d;
       }
       lp += __shfl_xor(lp, 32, 64);
@@ -231,14 +238,10 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {  // k = 2j + q
-        const int k = 2 * j + q;
-        float gm = 0.f, gl = 0.f;
-        if (k < A && live) {
-          const float iv = lds[cb + 2 * j];
-          const float d = dk[j];
-          gm = g_logp * d * iv;
-          gl = g_logp * (d * d * iv - 1.0f);
-        }
+        const float on = (2 * j + q < A && live) ? 1.f : 0.f;
+        const float d = dk[j];
+        float gm = on * (g_logp * d * c_iv[j]);
+        float gl = on * (g_logp * (d * d * c_iv[j] - 1.0f));
         lds[db + 2 * j] = gm;
         if (2 * j < A) {  // wave-uniform: sum over the 32 rows (lanes with equal q)
 #pragma unroll
