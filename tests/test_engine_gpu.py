@@ -932,7 +932,10 @@ def test_rollout64_tile_kernel_is_bit_identical_to_the_one_wave_kernel(kind, D, 
                                  dict(D=58, A=12, T=64, N=128, B=8192, E=1),    # doggo 2x64 (DP=64): 256 tiles = one full minibatch
                                  dict(D=43, A=2, T=50, N=100, B=3000, E=1),     # turtlebot3 (DP=48): ragged last tile, short last minibatch
                                  dict(D=26, A=2, T=40, N=600, B=24000, E=1),    # car (DP=32): 750 tiles > 512 workgroups -> two tiles per pair
-                                 dict(D=12, A=18, T=64, N=64, B=2100, E=2)])    # drone: 18 actions (head > 16)
+                                 dict(D=12, A=18, T=64, N=64, B=2100, E=2),     # drone: 18 actions (head > 16)
+                                 dict(D=14, A=2, T=67, N=32, B=2144, E=1),      # 67 tiles: odd -> the last workgroup's second pair idles
+                                 dict(D=28, A=4, T=80, N=32, B=2560, E=1),      # 4 actions: two action pairs per lane, constants in registers
+                                 dict(D=30, A=7, T=80, N=32, B=2560, E=1)])     # odd action count: a padded action in the last pair
 def test_pair_kernel_matches_the_block_kernel_and_the_oracle(cfg, monkeypatch):
     """k_pair64_train (two waves per tile, four workgroups per CU, accumulators over the workgroup's tiles) against
     k_fused64_train: the same per-tile arithmetic in another tile order -> gradients agree to rounding (1e-5 of each
