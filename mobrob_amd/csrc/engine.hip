@@ -651,7 +651,7 @@ namespace {
 // host-only: dimensions, parameter offsets, the norm chunk table
 int engine_dims(mobrob_ppo_engine* e, const mobrob_ppo_config_t* cfg) {
   e->cfg = *cfg;
-  e->D = cfg->obs_dim; e->Dp = rup(cfg->obs_dim, 8); e->A = cfg->act_dim; e->Ap = rup(cfg->act_dim, 8);
+  e->D = cfg->obs_dim; e->Dp = padded_obs_dim(cfg->obs_dim); e->A = cfg->act_dim; e->Ap = rup(cfg->act_dim, 8);
   e->H1 = cfg->pi_hidden[0]; e->H2 = cfg->pi_hidden[1]; e->G1 = cfg->vf_hidden[0]; e->G2 = cfg->vf_hidden[1];
   e->N = cfg->n_envs; e->T = cfg->n_steps;
   e->Bl = cfg->batch_size / cfg->world_size;

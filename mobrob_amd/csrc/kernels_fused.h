@@ -1595,8 +1595,11 @@ inline size_t fused_lds_bytes(int Dp) { return (size_t)(FR * (Dp + 4) + 2 * FR *
 
 inline size_t fused_lds_act_bytes(int Dp) { return (size_t)(32 * (Dp + 4) + 2 * 32 * FLDH + 4 * 32 * FLDO) * sizeof(float); }
 
+// Row stride of stored observations (floats): the fused kernels are instantiated for 16 / 32 / 48 / 64 columns, so every
+// observation of up to 64 features is padded to the next of those (zeros); wider ones to a multiple of 8 (generic path).
+inline int padded_obs_dim(int D) { return D <= 64 ? (D + 15) / 16 * 16 : (D + 7) / 8 * 8; }
 inline bool fused_shape_ok(int D, int A, int H1, int H2, int G1, int G2) {
-  const int Dp = (D + 7) / 8 * 8;
+  const int Dp = padded_obs_dim(D);
   const bool same = H1 == H2 && H1 == G1 && H1 == G2 && (H1 == FH || H1 == 64);
   return same && A <= 32 && (Dp == 16 || Dp == 32 || Dp == 48 || Dp == 64);
 }

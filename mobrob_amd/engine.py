@@ -458,7 +458,7 @@ class PPOEngine:
                 "advantages": ((T, N), F32), "returns": ((T, N), F32), "params": ((self.P,), F32),
                 "grads": ((self.P,), F32), "advstat": ((self.n_minibatches, 4), np.float64),
                 "last_values": ((N,), F32), "last_dones": ((N,), F32), "clipped_actions": ((N, self.A), F32), "episode_start_state": ((N,), F32),
-                "terminal_obs": ((N, 8 * ((self.D + 7) // 8)), F32), "terminal_values": ((N,), F32),
+                "terminal_obs": ((N, 16 * ((self.D + 15) // 16) if self.D <= 64 else 8 * ((self.D + 7) // 8)), F32), "terminal_values": ((N,), F32),
                 "truncated": ((N,), np.uint8), "env_state": ((N, 12), F32)}[name]
 
     def read(self, name):

@@ -988,3 +988,40 @@ def test_pair_kernel_matches_the_block_kernel_and_the_oracle(cfg, monkeypatch):
     O.train(p, st, buf, h, perms)
     ref = O.flatten_params(p)
     assert np.max(np.abs(pa - ref)) < 1e-4, float(np.max(np.abs(pa - ref)))
+
+
+@pytest.mark.parametrize("H", [64, 256])
+@pytest.mark.parametrize("D,A", [(5, 3), (20, 4), (37, 2), (53, 7)])
+def test_every_observation_width_up_to_64_runs_the_fused_kernels(D, A, H):
+    """Observations are padded to the next of the 16 / 32 / 48 / 64 columns the fused kernels are built for (zeros), so widths
+    like 5, 20, 37, 53 no longer fall back to the generic GEMM chain: act / rollout / train match the oracle, and the
+    profile shows the fused gradient kernel doing the work."""
+    T, N, B, E = 16, 24, 100, 2
+    rng = np.random.default_rng(23)
+    p0 = O.init_params(D, A, (H, H), (H, H), seed=6)
+    p0["log_std"] = rng.normal(-0.3, 0.2, A).astype(np.float32)
+    p0["action_net.weight"] *= 20
+    buf, lv, dones = _consistent_rollout(p0, T, N, D, A, seed=10)
+    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=E, batch_size=B, learning_rate=3e-4)
+    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, h.gamma, h.gae_lambda)
+    perms = np.stack([rng.permutation(T * N) for _ in range(E)])
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H),
+                    ent_coef=h.ent_coef, learning_rate=h.learning_rate)
+    e.set_params(p0)
+    obs = rng.standard_normal((N, D)).astype(np.float32)
+    e.rollout_begin()
+    raw, clipped, values, logp = e.act(obs)
+    mean, val = O.policy_outputs(p0, obs)
+    assert scaled_err(values, val) < 1e-4
+    assert np.allclose(logp, O.gaussian_log_prob(mean, p0["log_std"], raw), rtol=1e-4, atol=1e-3)
+    e.load_rollout(buf, lv, dones)
+    e.profile(True)
+    e.train(perms)
+    pr = e.profile_read()
+    assert pr["train_grad"][1] == E * (-(-T * N // B))          # the fused gradient kernel ran for every minibatch
+    p = {k: v.copy() for k, v in p0.items()}
+    O.train(p, O.AdamState.zeros_like(p), buf, h, perms)
+    got = e.get_params()
+    for k in p:
+        assert np.max(np.abs(got[k] - p[k])) < 1e-4, (k, float(np.max(np.abs(got[k] - p[k]))))
+    e.close()
