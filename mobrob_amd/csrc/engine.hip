@@ -121,6 +121,7 @@ struct mobrob_ppo_engine {
   int* rows = nullptr;          // [T*N] device row index per permuted position
   int64_t* perm_dev = nullptr;  // [T*N]
   double* advstat = nullptr;    // [nmb][4]
+  double* advpart = nullptr;    // [nmb][kAdvParts][2] partial sums of k_adv_stats
   uint64_t perm_counter = 0;
   bool epoch_open = false;
   float* stats = nullptr;  // [stats_cap][8]
@@ -688,7 +689,7 @@ int engine_alloc(mobrob_ppo_engine* e) {
   CHK(dalloc(e, &e->dones_tmp, N)); CHK(dalloc(e, &e->clip_act, N * A)); CHK(dalloc(e, &e->rew_tmp, N));
   CHK(dalloc(e, &e->term_obs, N * Dp)); CHK(dalloc(e, &e->term_val, N)); CHK(dalloc(e, &e->eps_dev, R * A));
   CHK(dalloc(e, &e->trunc_dev, N)); CHK(dalloc(e, &e->dones_u8, N)); CHK(dalloc(e, &e->ep_len, N)); CHK(dalloc(e, &e->ep_len2, N)); CHK(dalloc(e, &e->ctr_dev, 2));
-  CHK(dalloc(e, &e->rows, T * N)); CHK(dalloc(e, &e->perm_dev, T * N)); CHK(dalloc(e, &e->advstat, (size_t)e->nmb * 4));
+  CHK(dalloc(e, &e->rows, T * N)); CHK(dalloc(e, &e->perm_dev, T * N)); CHK(dalloc(e, &e->advstat, (size_t)e->nmb * 4)); CHK(dalloc(e, &e->advpart, (size_t)e->nmb * kAdvParts * 2));
   CHK(dalloc(e, &e->stats, (size_t)e->stats_cap * 8));
   CHK(dalloc(e, &e->sched_dev, (size_t)2 * e->nmb * std::max(1, e->cfg.n_epochs)));
   CHK(dalloc(e, &e->mail, 64));
@@ -1522,7 +1523,8 @@ int mobrob_ppo_epoch_begin(mobrob_ppo_engine_t* e, const int64_t* perm) {
                        feistel_half_bits((uint64_t)total), (uint32_t)key, (uint32_t)(key >> 32), e->rows,
                        (int64_t*)nullptr);
   }
-  hipLaunchKernelGGL(k_adv_stats, dim3(e->nmb), dim3(1024), 0, e->stream, e->adv, e->rows, total, e->Bl, e->advstat);
+  hipLaunchKernelGGL(k_adv_stats, dim3(e->nmb, kAdvParts), dim3(1024), 0, e->stream, e->adv, e->rows, total, e->Bl, e->advpart);
+  hipLaunchKernelGGL(k_adv_fold, dim3(cdiv(e->nmb, 64)), dim3(64), 0, e->stream, e->advpart, e->nmb, total, e->Bl, e->advstat);
   HIPC(hipGetLastError());
   e->epoch_open = true;
   return MOBROB_OK;

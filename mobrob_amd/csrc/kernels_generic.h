@@ -499,12 +499,17 @@ __global__ void k_perm_feistel(int total, int T, int N, int half_bits, uint32_t 
   }
 }
 
-// per-minibatch (sum, sumsq, count) of the advantages in float64 (one block per minibatch)
+// per-minibatch (sum, sumsq, count) of the advantages in float64.  The gathers through the permutation are HBM line
+// fetches (4 bytes used of each), one block per minibatch left most CUs idle: kAdvParts blocks per minibatch take a
+// contiguous quarter each (grid.y), k_adv_fold adds the quarters in fixed order -> still reproducible run to run.
+constexpr int kAdvParts = 4;
 __global__ __launch_bounds__(1024) void k_adv_stats(const float* __restrict__ adv, const int* __restrict__ rows,
-                                                    int total, int bl, double* __restrict__ out) {
+                                                    int total, int bl, double* __restrict__ part) {
   __shared__ double sc[16];
-  const int mb = blockIdx.x;
-  const int s = mb * bl, e = min(s + bl, total);
+  const int mb = blockIdx.x, q = blockIdx.y;
+  const int s0 = mb * bl, e0 = min(s0 + bl, total);
+  const int per = (e0 - s0 + kAdvParts - 1) / kAdvParts;
+  const int s = s0 + q * per, e = min(s + per, e0);
   double a = 0.0, b = 0.0;
   for (int i = s + threadIdx.x; i < e; i += blockDim.x) {
     const double x = (double)adv[rows[i]];
@@ -514,11 +519,18 @@ __global__ __launch_bounds__(1024) void k_adv_stats(const float* __restrict__ ad
   const double sa = block_sum_d(a, sc);
   const double sb = block_sum_d(b, sc);
   if (threadIdx.x == 0) {
-    out[4 * mb + 0] = sa;
-    out[4 * mb + 1] = sb;
-    out[4 * mb + 2] = (double)(e - s);
-    out[4 * mb + 3] = 0.0;
+    part[(mb * kAdvParts + q) * 2 + 0] = sa;
+    part[(mb * kAdvParts + q) * 2 + 1] = sb;
   }
+}
+__global__ void k_adv_fold(const double* __restrict__ part, int nmb, int total, int bl, double* __restrict__ out) {
+  const int mb = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mb >= nmb) return;
+  const double* p = part + (size_t)mb * kAdvParts * 2;
+  out[4 * mb + 0] = ((p[0] + p[2]) + p[4]) + p[6];
+  out[4 * mb + 1] = ((p[1] + p[3]) + p[5]) + p[7];
+  out[4 * mb + 2] = (double)(min(mb * bl + bl, total) - mb * bl);
+  out[4 * mb + 3] = 0.0;
 }
 
 // gather the minibatch rows into contiguous work arrays (generic path)
