@@ -1201,24 +1201,45 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
   a.obs = e->obs; a.actions = e->actions; a.logp = e->logp; a.rewards = e->rewards; a.es = e->es;
   a.term_obs = e->term_obs; a.trunc = e->trunc_dev; a.clip_act = e->clip_act;
   a.ep_len = e->ep_len; a.prev_dones = e->prev_dones; a.gstate = e->gstate[0]; a.ep_stats = e->ep_stats;
-  if (e->fused.H == GH) {  // 64-wide nets: one wave per 32-env tile, weights LDS resident; the value pass is cheap
-    a.t0 = 0; a.t1 = T;
+  if (e->fused.H == GH) {  // 64-wide nets (kernels_rollout.h, bottom half)
     const int nwv = rollout64_waves(Dp);
+    const int tiles = cdiv(N, 32);
+    const bool tile_kernel = tiles <= e->rollout64_tile_max;  // one workgroup per tile while every tile gets a CU of its own
+    // A rollout of <= 192 tiles leaves CUs idle for thousands of dependent steps: like the 256-wide path, cut it into chunks
+    // and value the observations of a finished chunk on the side stream while the next chunk rolls out.  Worth the extra
+    // launches only when the value pass is more than a few launches' worth of work.
+    const bool overlap = tile_kernel && tiles <= 192 && (size_t)T * N >= ((size_t)1 << 18);
+    const int chunk = overlap ? std::max(16, cdiv(T, 20)) : T;
     {
       ProfScope ps(e, MOBROB_K_ENV);
-      if (cdiv(N, 32) <= e->rollout64_tile_max) {  // one workgroup per tile while every tile gets a CU of its own
-        FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout64_tile<DPc>), dim3(cdiv(N, 32)), dim3(256), rollout64_tile_lds_bytes(Dp),
-                                                 e->stream, a));
-      } else {
-        FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout64_persistent<DPc>), dim3(cdiv(cdiv(N, 32), nwv)), dim3(nwv * 64),
-                                                 rollout64_lds_bytes(Dp), e->stream, a));
+      for (int t0 = 0; t0 < T; t0 += chunk) {
+        a.t0 = t0; a.t1 = std::min(T, t0 + chunk);
+        if (tile_kernel) {
+          FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout64_tile<DPc>), dim3(tiles), dim3(256), rollout64_tile_lds_bytes(Dp),
+                                                   e->stream, a));
+        } else {
+          FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout64_persistent<DPc>), dim3(cdiv(tiles, nwv)), dim3(nwv * 64),
+                                                   rollout64_lds_bytes(Dp), e->stream, a));
+        }
+        if (overlap && a.t1 < T) {  // observations [t0, t1) are final
+          hipEvent_t ev = e->ev_chunks[t0 / chunk];
+          HIPC(hipEventRecord(ev, e->stream));
+          HIPC(hipStreamWaitEvent(e->vstream, ev, 0));
+          fused_forward(e->fused, e->obs + (size_t)t0 * N * Dp, (a.t1 - t0) * N, false, nullptr, e->Ap, true, e->values + (size_t)t0 * N,
+                        e->vstream);
+        }
       }
     }
     hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, e->stream, e->ctr_dev, (uint32_t)T, (uint32_t)T);
     HIPC(hipMemcpyAsync(e->last_dones, e->prev_dones, (size_t)N * 4, hipMemcpyDeviceToDevice, e->stream));
     {
-      ProfScope ps(e, MOBROB_K_ACT);  // V(obs[0..T]) in one pass; values[T*N..] = last_values
-      forward(e, e->obs, (T + 1) * N, false, nullptr, true, e->values);
+      ProfScope ps(e, MOBROB_K_ACT);  // V of the last chunk and V(last_obs) (obs[T]; values[T*N..] = last_values)
+      const int done_rows = overlap ? ((T - 1) / chunk) * chunk * N : 0;
+      forward(e, e->obs + (size_t)done_rows * Dp, (T + 1) * N - done_rows, false, nullptr, true, e->values + done_rows);
+      if (overlap && done_rows > 0) {  // join the side stream before GAE
+        HIPC(hipEventRecord(e->ev_vdone, e->vstream));
+        HIPC(hipStreamWaitEvent(e->stream, e->ev_vdone, 0));
+      }
     }
     run_gae(e);
     return MOBROB_OK;

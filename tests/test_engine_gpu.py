@@ -891,7 +891,8 @@ def test_split_tile_kernel_is_bit_identical_to_the_block_kernel(cfg, monkeypatch
                                      (14, 2, 2, 80),       # point-ppo.yaml: two envs
                                      (43, 2, 37, 24),      # DP = 48, a ragged second tile
                                      (12, 18, 100, 24),    # drone: 18 actions
-                                     (26, 2, 1024, 16)])   # car, 32 tiles (BASELINE config 2's env count)
+                                     (26, 2, 1024, 16),    # car, 32 tiles (BASELINE config 2's env count)
+                                     (14, 2, 2048, 128)])  # 64 tiles x 128 steps: cut into chunks, value pass on the side stream
 def test_rollout64_tile_kernel_is_bit_identical_to_the_one_wave_kernel(kind, D, A, N, T, monkeypatch):
     """k_rollout64_tile (one workgroup per 32-env tile, forward split over two waves, weight fragments in registers)
     against k_rollout64_persistent (one wave per tile): every rollout buffer incl. the bootstrapped rewards, the
