@@ -820,30 +820,30 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
       for (int i = 0; i < 16; ++i) lds[o + crc(i) * FLDO] = acc[i];
     }
     __syncthreads();
-    // ---- Gaussian sample + log-prob (expressions and Philox counters of k_fused64_act), spread over the block ----
-    for (int i = tid; i < R * A; i += 256) {
-      const int rr_ = i / A, k = i - rr_ * A;
-      const int row = row0 + rr_;
-      if (row < N) {
-        const float m = (lds[L::DO + rr_ * FLDO + k] + lds[L::DO2 + rr_ * FLDO + k]) + lds[L::AC + 96 + k];
+    // ---- Gaussian sample + log-prob (expressions and Philox counters of k_fused64_act), then env.step(clipped actions) +
+    //      auto-reset: the SAME 8 threads serve a row in both (actions sub, sub + 8, ...; observation chunks sub, sub + 8):
+    //      they sit in one wave, so the row's clipped actions and log-prob terms are ordered by the wave's DS queue and no
+    //      workgroup barrier separates sampling from the env step ----
+    const int rr = tid >> 3, sub = tid & 7;
+    if (row0 + rr < N) {
+      for (int k = sub; k < A; k += 8) {
+        const float m = (lds[L::DO + rr * FLDO + k] + lds[L::DO2 + rr * FLDO + k]) + lds[L::AC + 96 + k];
         const float sd = lds[L::AC + k];
-        const float act = m + lds[L::ZN + rr_ * 32 + k] * sd;
+        const float act = m + lds[L::ZN + rr * 32 + k] * sd;
         const float d = act - m;
-        lds[L::TM + rr_ * 33 + k] = -(d * d) / lds[L::AC + 32 + k] - lds[L::AC + 64 + k] - 0.91893853320467274178f;
+        lds[L::TM + rr * 33 + k] = -(d * d) / lds[L::AC + 32 + k] - lds[L::AC + 64 + k] - 0.91893853320467274178f;
         const float ac = fminf(fmaxf(act, a.lo), a.hi);
-        a.actions[((size_t)t * N + row) * A + k] = act;
-        a.clip_act[(size_t)row * A + k] = ac;
-        lds[L::CA + rr_ * 33 + k] = ac;
+        a.actions[((size_t)t * N + row0 + rr) * A + k] = act;
+        a.clip_act[(size_t)(row0 + rr) * A + k] = ac;
+        lds[L::CA + rr * 33 + k] = ac;
       }
     }
-    __syncthreads();
-    if (tid < R && row0 + tid < N) {
+    __builtin_amdgcn_wave_barrier();  // the row's 8 lanes have issued their LDS writes (same wave: in-order DS queue)
+    if (sub == 0 && row0 + rr < N) {
       float lp = 0.f;
-      for (int k = 0; k < A; ++k) lp += lds[L::TM + tid * 33 + k];
-      a.logp[(size_t)t * N + row0 + tid] = lp;
+      for (int k = 0; k < A; ++k) lp += lds[L::TM + rr * 33 + k];
+      a.logp[(size_t)t * N + row0 + rr] = lp;
     }
-    // ---- env.step(clipped actions) + auto-reset: 8 threads per row (all in one wave), chunks sub, sub + 8 ----
-    const int rr = tid >> 3, sub = tid & 7;
     const int n = row0 + rr;
     const bool live = n < N;
     const uint32_t step = sbase + (uint32_t)t;
