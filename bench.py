@@ -167,6 +167,16 @@ def csrc_sha256():
     return h.hexdigest()
 
 
+def dominant_kernel_name(H, rows_per_launch, generic):
+    """Which gradient kernel the engine launches for this shape (engine.hip: fused64_minibatch_grad / fused_minibatch_grad)."""
+    if generic:
+        return "generic GEMM chain"
+    if H == 256:
+        return "k_fused_train (minibatch forward+loss+backward)"
+    tiles = -(-rows_per_launch // 32)
+    return ("k_split64_train (one workgroup per 32-row tile)" if tiles <= 64 else "k_pair64_train (two waves per tile, two per SIMD)") + ": minibatch forward+loss+backward"
+
+
 def measured_traffic(kernel_prefix):
     """(bytes per launch | None, note): PMC-counted HBM traffic of the dominant kernel from the newest committed
     profile -- only if that profile was taken on exactly these kernel sources; otherwise None (never a stale figure)."""
@@ -338,7 +348,7 @@ def bench_fleet(args, w, rank, local_rank, world, use_dp, force_dp):
                        "net_arch": [H, H], "n_steps": T, "n_epochs": E, "minibatch_per_gpu": B,
                        "env_source": "device-resident synthetic (Philox)", "parallelism": f"dp{world}",
                        "kernels": "generic" if args.generic else "fused"},
-            "roofline": {"bound": "mfma", "kernel": "k_fused64_train, all segments (their launches overlap on per-segment "
+            "roofline": {"bound": "mfma", "kernel": "k_pair64_train, all segments (their launches overlap on per-segment "
                                                     "streams, so per-launch durations include time sharing)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
@@ -537,7 +547,7 @@ def main():
                                       if host is not None else "device-resident synthetic (Philox)"),
                        "parallelism": f"dp{world}", "n_ranks_seen": dist.get_world_size() if use_dp else 1,
                        "kernels": "generic" if args.generic else "fused"},
-            "roofline": {"bound": "mfma", "kernel": "k_fused_train (minibatch forward+loss+backward)" if not args.generic else "generic GEMM chain",
+            "roofline": {"bound": "mfma", "kernel": dominant_kernel_name(H, B, args.generic),
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_note": traffic_note,
