@@ -102,13 +102,35 @@ class EngineBackend:
 
     # ---- the C loop ------------------------------------------------------------------------------------
     def ensure_comm(self, group=None):
-        """RCCL communicator of the engine over the ranks of `group` (collective, once)."""
-        if getattr(self, "_comm_ready", False):
-            return
-        box = [self.e.comm_unique_id() if dist.get_rank(group) == 0 else None]
+        """RCCL communicator of the engine over the ranks of `group` (collective, once).  Returns True when EVERY rank
+        has one; False (on every rank alike) when any rank could not create it -- the caller then runs the protocol
+        loop with torch.distributed's own collectives instead of failing the job."""
+        state = getattr(self, "_comm_ready", None)
+        if state is not None:
+            return state
+        ok = 1
+        try:
+            box = [self.e.comm_unique_id() if dist.get_rank(group) == 0 else None]
+        except Exception as ex:  # noqa: BLE001 - e.g. librccl not loadable from the engine
+            box, ok = [None], 0
+            self._comm_error = ex
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        self.e.comm_init(box[0])
-        self._comm_ready = True
+        if ok and box[0] is not None:
+            try:
+                self.e.comm_init(box[0])
+            except Exception as ex:  # noqa: BLE001
+                ok = 0
+                self._comm_error = ex
+        else:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        self._comm_ready = bool(int(flag.item()))
+        if not self._comm_ready and dist.get_rank(group) == 0:
+            import warnings
+            warnings.warn("engine-owned RCCL communicator unavailable (%r): falling back to torch.distributed all-reduces "
+                          "issued from Python, one per optimizer step" % (getattr(self, "_comm_error", "another rank failed"),))
+        return self._comm_ready
 
     def gloo_all_reduce(self, group=None):
         """All-reduce callback for `engine.train_dp` under a CPU process group: stage through the host."""
@@ -132,8 +154,11 @@ def train_data_parallel(backend, perms=None, group=None, force_collectives=False
     stream = getattr(backend, "stream", None)
     if isinstance(backend, EngineBackend) and comm and not python_loop:
         if dist.get_backend(group) == "nccl":
-            backend.ensure_comm(group)
-            backend.e.train_dp(perms)
+            if backend.ensure_comm(group):
+                backend.e.train_dp(perms)
+            else:
+                with torch.cuda.stream(stream):
+                    _update_loop(backend, perms, group, comm)
         else:
             backend.e.train_dp(perms, allreduce=backend.gloo_all_reduce(group))
     elif stream is not None:  # GPU backend, Python loop: collectives are issued with the engine's stream current

@@ -126,6 +126,19 @@ def test_ppo_learn_is_data_parallel_under_a_process_group(tmp_path):
     assert last[1] / max(last[0], 1) > first[1] / max(first[0], 1) + 0.2, (first, last)
 
 
+class _NoComm:
+    """An engine whose RCCL communicator cannot be created (librccl not loadable, version mismatch ...)."""
+
+    def __init__(self, e):
+        self._e = e
+
+    def __getattr__(self, name):
+        return getattr(self._e, name)
+
+    def comm_init(self, uid):
+        raise RuntimeError("ncclCommInitRank failed (simulated)")
+
+
 def _rccl_world1_worker(rank, world, port, out):
     """One rank, "nccl" backend: the C loop with the engine's own RCCL communicator (ncclCommInitRank from an id made
     by mobrob_ppo_comm_unique_id, ncclAllReduce on the engine's stream) against the single-rank C call and against
@@ -147,11 +160,19 @@ def _rccl_world1_worker(rank, world, port, out):
         e.load_rollout(buf, lv, dones)
         z = {k: np.zeros_like(v) for k, v in p.items()}
         be = EngineBackend(e)
-        for mode in ("single", "c_rccl", "python_torch"):
+        for mode in ("single", "c_rccl", "python_torch", "no_comm"):
             e.set_params(p)
             e.set_optimizer_state(z, z, 0)
             if mode == "single":
                 e.train(perms)
+            elif mode == "no_comm":  # the engine cannot create its communicator: every rank falls back to torch's collectives
+                import warnings
+                broken = EngineBackend(e)
+                broken.e = _NoComm(e)
+                with warnings.catch_warnings(record=True) as w:
+                    warnings.simplefilter("always")
+                    train_data_parallel(broken, perms, force_collectives=True)
+                assert any("falling back" in str(x.message) for x in w)
             else:
                 train_data_parallel(be, perms, force_collectives=True, python_loop=(mode == "python_torch"))
             torch.cuda.synchronize()
@@ -169,3 +190,4 @@ def test_c_loop_with_rccl_equals_the_single_rank_call(tmp_path):
     for case in ("h256", "h64"):
         assert np.array_equal(r[f"{case}/c_rccl"], r[f"{case}/single"]), case
         assert np.array_equal(r[f"{case}/python_torch"], r[f"{case}/single"]), case
+        assert np.array_equal(r[f"{case}/no_comm"], r[f"{case}/single"]), case   # fallback when the communicator is unavailable
