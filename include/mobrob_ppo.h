@@ -81,7 +81,7 @@ typedef struct mobrob_ppo_config {
   int32_t persistent_train;   /* 1: 64-wide nets with minibatches of <= 128 rows (the reference YAML shapes) run each
                                  epoch of PPO.train() as ONE persistent launch of two workgroups
                                  (kernels_train_small.h): bit-identical to the per-step path, measured SLOWER
-                                 (92 vs 60 us per optimizer step: DESIGN.md 4.1c), hence 0 by default */
+                                 (85-92 us per optimizer step against 24: DESIGN.md 4.1c / 4.1d), hence 0 by default */
   int32_t reserved[4];
 } mobrob_ppo_config_t;
 
