@@ -33,6 +33,8 @@ WORKLOADS = {
     # name: obs, act, hidden, envs/GPU, T, E, minibatch/GPU, p_term, time_limit
     "doggo-4096env-2x256": dict(D=58, A=12, H=256, N=4096, T=1000, E=5, B=65536, p_term=1 / 107.0, tl=1000),
     "point-1024env-2x64": dict(D=14, A=2, H=64, N=1024, T=2048, E=10, B=65536, p_term=1 / 119.0, tl=1000),
+    # the headline's env count and minibatch with the network the reference YAML actually uses for doggo (2x64)
+    "doggo-4096env-2x64": dict(D=58, A=12, H=64, N=4096, T=1000, E=5, B=65536, p_term=1 / 107.0, tl=1000),
     # BASELINE.md §3 B1 "reference-shaped": data/configs/doggo-ppo.yaml, CPU baseline on ONE thread (examples/train.py:13)
     "doggo-ref-16env-2x64": dict(D=58, A=12, H=64, N=16, T=1000, E=5, B=100, p_term=1 / 107.0, tl=1000, cpu_threads=1),
     # the headline shape with the environments on the HOST (native C goal env, pinned zero-copy staging): the
