@@ -1026,3 +1026,33 @@ def test_every_observation_width_up_to_64_runs_the_fused_kernels(D, A, H):
     for k in p:
         assert np.max(np.abs(got[k] - p[k])) < 1e-4, (k, float(np.max(np.abs(got[k] - p[k]))))
     e.close()
+
+
+@pytest.mark.parametrize("H", [64, 256])
+@pytest.mark.parametrize("D,A,N,T,B,E", [(1, 1, 1, 3, 2, 2),        # one env, one feature, one action, two-row minibatches
+                                         (64, 32, 5, 7, 16, 1),     # the widest observation / head the fused kernels take
+                                         (65, 3, 4, 6, 8, 1),       # one feature more: generic GEMM chain
+                                         (3, 1, 33, 2, 64, 2),      # minibatch of 64 rows, the second one 2 rows
+                                         (58, 12, 3, 1, 3, 1)])     # a single step of three envs
+def test_extreme_shapes_match_the_oracle_and_roll_out(D, A, N, T, B, E, H):
+    """Smallest and widest shapes the engine accepts: a whole train() equals the oracle, and the device rollout
+    (synthetic source, forced truncations) produces finite advantages twice in a row."""
+    rng = np.random.default_rng(1)
+    p0 = O.init_params(D, A, (H, H), (H, H), seed=2)
+    buf, lv, dones = _consistent_rollout(p0, T, N, D, A, seed=3)
+    h = O.Hyper(n_epochs=E, batch_size=B, ent_coef=0.01)
+    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, h.gamma, h.gae_lambda)
+    perms = np.stack([rng.permutation(T * N) for _ in range(E)])
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H), ent_coef=0.01)
+    e.set_params(p0)
+    e.load_rollout(buf, lv, dones)
+    e.train(perms)
+    got = e.get_params()
+    p = {k: v.copy() for k, v in p0.items()}
+    O.train(p, O.AdamState.zeros_like(p), buf, h, perms)
+    for k in p:
+        assert np.max(np.abs(got[k] - p[k])) < 1e-5, (k, float(np.max(np.abs(got[k] - p[k]))))
+    e.collect_synthetic(p_term=0.1, time_limit=5)
+    e.collect_synthetic(p_term=0.1, time_limit=5)
+    assert np.isfinite(e.read("advantages")).all() and np.isfinite(e.read("returns")).all()
+    e.close()
