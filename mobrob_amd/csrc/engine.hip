@@ -484,12 +484,13 @@ void fused64_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, floa
   }
   ProfScope pr(e, MOBROB_K_GRAD_REDUCE);
   Slab64ReduceArgs s{};
-  s.slabs = f.slabs; s.nblocks = split ? 2 * ntiles : (pair ? 2 * nseq : grid); s.group = split ? g_train_waves(e->Dp) : 1; s.grads = e->grads; s.P = e->P;
+  const int nbseq = (nseq + 1) / 2;  // k_pair64_train: one slab per workgroup of two pairs
+  s.slabs = f.slabs; s.nblocks = split ? 2 * ntiles : (pair ? 2 * nbseq : grid); s.group = split ? g_train_waves(e->Dp) : 1; s.grads = e->grads; s.P = e->P;
   for (int i = 0; i < 14; ++i) s.offs[i] = e->offs[i];
   s.D = e->D; s.A = e->A; s.ent_coef = (float)e->cfg.ent_coef; s.b_local = (float)B; s.inv_bg = inv_bg;
   s.sums = e->grads + e->P;
   s.rec_sum = e->use_norm_records ? e->norm_rec_sum : nullptr; s.rec_t = e->norm_rec_t;
-  if (pair && nseq > 128) hipLaunchKernelGGL(k_slab64_reduce_wide, dim3(cdiv(s64_size(), 256), 2), dim3(1024), 0, e->stream, s);
+  if (pair && nbseq > 128) hipLaunchKernelGGL(k_slab64_reduce_wide, dim3(cdiv(s64_size(), 256), 2), dim3(1024), 0, e->stream, s);
   else hipLaunchKernelGGL(k_slab64_reduce, dim3(cdiv(s64_size(), 256), 2), dim3(256), 0, e->stream, s);
 }
 

@@ -21,7 +21,8 @@
 // dL/d(mean), dL/d(log_std) per lane over all tiles, reducing over the 32 rows once at the end.
 //
 // Per tile and accumulator the MFMA sequence is the one of tile64_train; the accumulators run over the tiles of the pair
-// and are written once as the pair's slab (k_slab64_reduce_wide sums up to 512 slabs per network in fixed order).  The
+// and are written once, the two pairs of a workgroup added through LDS into ONE slab (k_slab64_reduce_wide sums up to 256
+// slabs per network in fixed order).  The
 // summation order over TILES therefore differs from k_fused64_train's, so the two kernels agree to rounding, not bit for
 // bit (tests: 1e-5 of each tensor's scale, both against the oracle); run to run the kernel is deterministic.
 // Measured (MI355X, 65 536-row minibatch, us per launch, block kernel -> this one): 14/2 76 -> 65, 26/2 106 -> 68,
@@ -52,7 +53,7 @@ constexpr int kPairsPerCu = 4;  // two workgroups of two pairs: two waves per SI
 // SIMD 0/1 only and left half of every CU idle).  The pairs of a workgroup share its barriers and nothing else.
 // grid: groups of 16 blocks -- 8 policy workgroups for block sequences 8g..8g+7, then 8 value workgroups for the SAME
 // sequences (blockIdx mod 8 = XCD: the workgroups that gather the same observation rows share an L2).  Pair p of block
-// sequence s owns tile sequence 2s + p: tiles 2s+p, 2s+p+nseq, ...  Slab index = 2 * tile sequence + network.
+// sequence s owns tile sequence 2s + p: tiles 2s+p, 2s+p+nseq, ...  One slab per workgroup: index 2 * block sequence + network.
 // NJ: action pairs the loss stage loops over (2 NJ >= A; the head tile's columns beyond A are exact zeros from the zero-padded
 // head pack, so nothing has to rewrite them): the loops are unrolled NJ times instead of 16 with 16 - NJ dead predicates.
 template <int DP, int NJ>
@@ -75,8 +76,6 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
   const int cnt = pair_on ? a.count : 0;  // a pair without tiles sees an empty minibatch
   const int ntiles = (a.count + GR - 1) / GR;
   const int niter = (ntiles - 2 * bseq + nseq - 1) / nseq;  // tiles of the workgroup's first pair: both pairs make this many rounds
-  float* slab = a.slabs + (size_t)(2 * seq + net) * s64_size();
-
   // ---- forward weight fragments of this wave's column block: registers for the whole launch ----
   // What a wave fetches from L2 in EVERY tile is what paces this kernel: a CU sustains ~14 GB/s of L1 misses (its
   // outstanding-miss window over the L2 latency), and 8 waves x 13 KB of fragments per tile round were 7 us of a 24 us
@@ -446,33 +445,16 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
   if (lane0 == 0 && pair_on)
     for (int k = 0; k < 16; ++k) atomicAdd(&a.stamps[16 * wave + k], st_acc[k]);
 #endif
-  if (!pair_on) return;
-  // ---- the pair's slab (fragment order of k_fused64_train; tiles t = ib*2 + jb) ----
+  // ---- ONE slab per workgroup (fragment order of k_fused64_train; tiles t = ib*2 + jb): the second pair lays its
+  //      contribution out as a slab in LDS (the tile regions are dead), the first pair adds its own on top and stores.
+  //      A pair without tiles contributes exact zeros. ----
   const int lane = lane0;
-  auto put = [&](int region, int t, const f32x16& acc) {
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd)
-      stg16(slab + region, (unsigned)((t * 4 + qd) * 64 + lane) * 16u, f32x4{acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]});
-  };
-  // dW2[n][j]: neuron block ib = which dz2 block (a: 0, b: 1), input block jb = wave
-  put(s64_w2(), 0 * 2 + wave, gW2a);
-  put(s64_w2(), 1 * 2 + wave, gW2b);
-  // dW1[n][j]: neuron block ib = wave, input block jb (a/b: 0, c/d: 1)
-  put(s64_w1(), wave * 2 + 0, gW1a);
-  if (two) put(s64_w1(), wave * 2 + 1, gW1c);
-  put(s64_w3(), wave, gW3);
-  if (lane < 32) {
-    slab[s64_b2() + 32 * wave + lane] = gb2;
-    slab[s64_b1() + 32 * wave + lane] = gb1;
-  }
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, out_m = 0.f, out_l = 0.f;
   if (wave == 0) {
-    const float t0 = wave_sum(s_pl), t1 = wave_sum(s_vl), t2 = wave_sum(s_kl), t3 = wave_sum(s_cf);
-    if (lane < 4) slab[s64_st() + lane] = lane == 0 ? t0 : (lane == 1 ? t1 : (lane == 2 ? t2 : t3));
-    // head-bias / log_std gradients: the lane's running sums over the rows with its (row mod 32, parity), reduced over
-    // the 32 lanes of equal parity; lane (r, q) stores action k = 2r + q (zero beyond the lane's NJ pairs)
-    if (kAccRegs) {
-      const int r = lane & 31, q = lane >> 5;
-      float out_m = 0.f, out_l = 0.f;
+    t0 = wave_sum(s_pl); t1 = wave_sum(s_vl); t2 = wave_sum(s_kl); t3 = wave_sum(s_cf);
+    // head-bias / log_std gradients -> lane (r, q) holds action k = 2r + q (r < 16)
+    const int r = lane & 31, q = lane >> 5;
+    if (kAccRegs) {  // the lane's running sums over its rows, reduced over the 32 lanes of equal parity
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
         float gm = acc_gm[j], gl = acc_gl[j];
@@ -483,13 +465,52 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
         }
         if (r == j) { out_m = gm; out_l = gl; }
       }
-      if (r < 16) {
-        slab[s64_b3() + 2 * r + q] = out_m;
-        slab[s64_ls() + 2 * r + q] = out_l;
+    } else if (r < 16) {
+      out_m = lds[lb + L::GACC + 2 * r + q];
+      out_l = lds[lb + L::GACC + 32 + 2 * r + q];
+    }
+  }
+  __syncthreads();  // every wave has read what it needs from its tile region
+  float* stage = &lds[0];  // [s64_size()] floats: spans the first pair's region and the head of the second one's
+  float* slab = a.slabs + (size_t)(2 * bseq + net) * s64_size();
+  auto put = [&](int region, int t, const f32x16& acc) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int o = region + ((t * 4 + qd) * 64 + lane) * 4;
+      f32x4 v = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
+      if (pr == 1) {
+        *reinterpret_cast<f32x4*>(&stage[o]) = v;
+      } else {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(&stage[o]);
+        stg16(slab, (unsigned)o * 4u, f32x4{v[0] + w[0], v[1] + w[1], v[2] + w[2], v[3] + w[3]});
       }
-    } else if (lane < 32) {
-      slab[s64_b3() + lane] = lds[lb + L::GACC + lane];
-      slab[s64_ls() + lane] = lds[lb + L::GACC + 32 + lane];
+    }
+  };
+  auto put1 = [&](int o, float v) {
+    if (pr == 1) stage[o] = v;
+    else slab[o] = v + stage[o];
+  };
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {  // pass 0: the second pair stages; pass 1: the first pair adds and stores
+    if (pass == 1) __syncthreads();
+    if (pr != 1 - pass) continue;
+    // dW2[n][j]: neuron block ib = which dz2 block (a: 0, b: 1), input block jb = wave
+    put(s64_w2(), 0 * 2 + wave, gW2a);
+    put(s64_w2(), 1 * 2 + wave, gW2b);
+    // dW1[n][j]: neuron block ib = wave, input block jb (a/b: 0, c/d: 1)
+    put(s64_w1(), wave * 2 + 0, gW1a);
+    if (two) put(s64_w1(), wave * 2 + 1, gW1c);
+    put(s64_w3(), wave, gW3);
+    if (lane < 32) {
+      put1(s64_b2() + 32 * wave + lane, gb2);
+      put1(s64_b1() + 32 * wave + lane, gb1);
+    }
+    if (wave == 0) {
+      if (lane < 4) put1(s64_st() + lane, lane == 0 ? t0 : (lane == 1 ? t1 : (lane == 2 ? t2 : t3)));
+      if ((lane & 31) < 16) {
+        put1(s64_b3() + 2 * (lane & 31) + (lane >> 5), out_m);
+        put1(s64_ls() + 2 * (lane & 31) + (lane >> 5), out_l);
+      }
     }
   }
 }
