@@ -37,6 +37,8 @@ WORKLOADS = {
     "doggo-4096env-2x64": dict(D=58, A=12, H=64, N=4096, T=1000, E=5, B=65536, p_term=1 / 107.0, tl=1000),
     # BASELINE.md §3 B1 "reference-shaped": data/configs/doggo-ppo.yaml, CPU baseline on ONE thread (examples/train.py:13)
     "doggo-ref-16env-2x64": dict(D=58, A=12, H=64, N=16, T=1000, E=5, B=100, p_term=1 / 107.0, tl=1000, cpu_threads=1),
+    # BASELINE configs[0]: data/configs/point-ppo.yaml as it stands (2 envs, n_steps 4000, batch 100, 10 epochs, 2x64)
+    "point-ref-2env-2x64": dict(D=14, A=2, H=64, N=2, T=4000, E=10, B=100, p_term=1 / 119.0, tl=1000, cpu_threads=1),
     # the headline shape with the environments on the HOST (native C goal env, pinned zero-copy staging): the
     # PCIe-inclusive rate of DESIGN.md -- never the headline `value`, which keeps its inputs resident in HBM
     "doggo-4096env-2x256-hostenv": dict(D=58, A=12, H=256, N=4096, T=1000, E=5, B=65536, p_term=1 / 107.0, tl=1000,

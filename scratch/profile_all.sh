@@ -20,6 +20,7 @@ python3 bench.py --workload point-1024env-2x64 --steps 3 --warmup 1 > $O/bench_p
 python3 bench.py --workload fleet-car-drone-turtlebot3-2x64 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_fleet.json 2>/dev/null
 python3 bench.py --workload doggo-4096env-2x64 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_doggo_4096env_2x64.json 2>/dev/null
 python3 bench.py --workload doggo-ref-16env-2x64 --steps 3 --warmup 1 > $O/bench_doggo_ref16.json 2>/dev/null
+python3 bench.py --workload point-ref-2env-2x64 --steps 3 --warmup 1 > $O/bench_point_ref2.json 2>/dev/null
 python3 bench.py --workload doggo-ref-16env-2x64 --steps 3 --warmup 1 --no-cpu-baseline --persistent-train > $O/bench_doggo_ref16_persistent.json 2>/dev/null
 python3 bench.py --workload doggo-4096env-2x256-hostenv --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_hostenv.json 2>/dev/null
 MOBROB_FORCE_DP=1 python3 bench.py --no-cpu-baseline > $O/bench_forced_dp_world1.json 2>/dev/null
@@ -30,7 +31,7 @@ for w in doggo-ref-16env-2x64 point-1024env-2x64; do
   python3 $R/scratch/trace_summary.py /tmp/p_tr/t_results.db 12 > $O/kernel_trace_$w.txt
 done
 cd $R
-for f in bench_final bench_final_phases bench_point_2x64 bench_fleet bench_doggo_4096env_2x64 bench_doggo_ref16 bench_doggo_ref16_persistent bench_hostenv bench_forced_dp_world1; do python3 -c "import sys,json; d=json.load(open('$O/$f.json')); print('$f', round(d['value']/1e6,3), round(d['ms_per_step'],2), round(d['roofline']['frac'],4), d['roofline']['avg_launch_ms'], d['roofline'].get('traffic'), d.get('cpu_baseline',{}).get('value'))"; done
+for f in bench_final bench_final_phases bench_point_2x64 bench_fleet bench_doggo_4096env_2x64 bench_doggo_ref16 bench_point_ref2 bench_doggo_ref16_persistent bench_hostenv bench_forced_dp_world1; do python3 -c "import sys,json; d=json.load(open('$O/$f.json')); print('$f', round(d['value']/1e6,3), round(d['ms_per_step'],2), round(d['roofline']['frac'],4), d['roofline']['avg_launch_ms'], d['roofline'].get('traffic'), d.get('cpu_baseline',{}).get('value'))"; done
 head -8 $O/fused_kernel_stats.csv | cut -c1-150
 python3 -c "
 import json; d=json.load(open('$O/hbm_traffic_pmc.json'))
