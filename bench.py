@@ -63,12 +63,13 @@ def init_params(D, A, H, seed):
 def _oracle_throughput(w, budget_s, threads=None):
     """The CPU oracle (SB3-semantics NumPy restatement) on a bounded sample of workload `w`."""
     from oracle import ppo_oracle as O
+    from mobrob_amd.envs.shm_vec_env import usable_cores
     limiter = None
-    try:
+    want = int(threads) if threads else usable_cores()  # never more BLAS threads than the cgroup grants: an
+    try:                                                 # oversubscribed pool (128 threads on a 16-core quota) is SLOWER
         from threadpoolctl import threadpool_info, threadpool_limits
-        if threads:
-            limiter = threadpool_limits(limits=int(threads))
-        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [os.cpu_count() or 1])
+        limiter = threadpool_limits(limits=want)
+        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [want])
     except Exception:
         cores = os.cpu_count() or 1
     D, A, H, N = w["D"], w["A"], w["H"], w["N"]
@@ -92,7 +93,6 @@ def _oracle_throughput(w, budget_s, threads=None):
             break
     if limiter is not None:
         limiter.restore_original_limits()
-    from mobrob_amd.envs.shm_vec_env import usable_cores
     return {"value": done_steps / el, "unit": "env-steps/s", "cores": int(min(cores, usable_cores())), "kind": "port",
             "threads": int(cores), "cpu_quota_cores": usable_cores(),
             "sample": f"{reps} x (rollout {Ts} steps x {N} envs + {h.n_epochs} epochs, minibatch {w['B']}) "
@@ -184,7 +184,7 @@ def dominant_kernel_name(H, rows_per_launch, generic):
 def measured_traffic(kernel_prefix):
     """(bytes per launch | None, note): PMC-counted HBM traffic of the dominant kernel from the newest committed
     profile -- only if that profile was taken on exactly these kernel sources; otherwise None (never a stale figure)."""
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         tj = os.path.join(ROOT, "profiles", rnd, "hbm_traffic_pmc.json")
         if not os.path.exists(tj):
             continue
@@ -203,7 +203,8 @@ def measured_traffic(kernel_prefix):
 
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` outside torchrun: start the N ranks as child processes (one per GPU, RCCL rendezvous
-    on 127.0.0.1) BEFORE this process touches the GPU, pass rank 0's JSON line through, fail if any rank fails."""
+    on 127.0.0.1) BEFORE this process touches the GPU, pass rank 0's JSON line through, fail if any rank fails (the
+    survivors -- possibly blocked in a collective -- are terminated, then killed, and reaped)."""
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -216,21 +217,30 @@ def launch_ranks(n, argv):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     rc = 0
     pending = set(range(n))
+    chunks = []
+    os.set_blocking(procs[0].stdout.fileno(), False)  # drain rank 0's pipe while polling: a full pipe must not block it
+
+    def drain():
+        try:
+            while True:
+                b = procs[0].stdout.read()
+                if not b:
+                    return
+                chunks.append(b)
+        except (BlockingIOError, ValueError):
+            return
+
     while pending and rc == 0:
         time.sleep(0.05)
+        drain()
         for r in list(pending):
             code = procs[r].poll()
-            if r == 0 and code is None:
-                continue
             if code is not None:
                 pending.discard(r)
                 if code != 0:
                     rc = code if code > 0 else 1
                     print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
-    line = b""
-    if rc == 0:
-        line = procs[0].stdout.read()
-    else:
+    if rc != 0:
         for r in pending:  # our own children, by handle
             procs[r].terminate()
         for r in pending:
@@ -238,11 +248,25 @@ def launch_ranks(n, argv):
                 procs[r].wait(timeout=10)
             except subprocess.TimeoutExpired:
                 procs[r].kill()
+                procs[r].wait()
+        print(f"bench.py: all {n} ranks reaped", file=sys.stderr)
+    drain()
+    line = b"".join(chunks) if rc == 0 else b""
     if rc == 0 and not line.strip():
         print("bench.py: rank 0 printed no result line", file=sys.stderr)
         rc = 1
     os.write(1, line)
     return rc
+
+
+def _fault_spec():
+    """MOBROB_BENCH_FAULT="<rank>:<nth all-reduce>" (tests): that rank dies without cleanup inside its nth all-reduce
+    of the timed run -- a rank killed mid-update."""
+    v = os.environ.get("MOBROB_BENCH_FAULT")
+    if not v:
+        return None
+    r, n = v.split(":")
+    return int(r), int(n)
 
 
 def dry_run_cpu(args, rank, world):
@@ -255,7 +279,15 @@ def dry_run_cpu(args, rank, world):
     if world > 1:
         dist.init_process_group("gloo")
     P = 2 * (w["D"] * w["H"] + w["H"] * w["H"] + 2 * w["H"]) + w["H"] * (w["A"] + 1) + 2 * w["A"] + 1
-    g = torch.full((P,), float(rank + 1))
+    g = torch.full((P + 8,), float(rank + 1))
+    fault, calls = _fault_spec(), [0]
+
+    def all_reduce(x):
+        calls[0] += 1
+        if fault and fault[0] == rank and calls[0] == fault[1]:
+            os._exit(17)
+        if world > 1:
+            dist.all_reduce(x)
 
     def fence():
         if world > 1:
@@ -268,8 +300,7 @@ def dry_run_cpu(args, rank, world):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         x = g.clone()
-        if world > 1:
-            dist.all_reduce(x)
+        all_reduce(x)
         assert float(x[0]) == world * (world + 1) / 2
     fence()
     dt = time.perf_counter() - t0
@@ -281,21 +312,90 @@ def dry_run_cpu(args, rank, world):
               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * float(tt) / max(args.steps, 1),
               "dry_run": "cpu/gloo launcher check: no PPO work, no throughput claim",
               "config": {"workload": args.workload, "parallelism": f"dp{world}",
-                         "n_ranks_seen": dist.get_world_size() if world > 1 else 1}})
+                         "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
+                         "n_ranks_source": "torch.distributed (gloo)"}})
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def bench_fleet(args, w, rank, local_rank, world, use_dp, force_dp):
+class Job:
+    """What a rank knows about the data-parallel job it is part of."""
+
+    def __init__(self, args, rank, local_rank, world):
+        self.rank, self.world = rank, world
+        # MOBROB_FORCE_DP=1 runs the data-parallel code path (process group, the C loop, all-reduces) even at world
+        # size 1 -- validates the multi-GPU plumbing on a single-GPU box.
+        self.force_dp = os.environ.get("MOBROB_FORCE_DP", "0") == "1"
+        # MOBROB_DP_SAME_DEVICE=1: REHEARSAL of an N-rank run on ONE GPU -- every rank uses device 0, the process
+        # group is gloo (RCCL refuses two ranks on one device) and the C loop mobrob_ppo_train_dp exchanges through
+        # the host-staged callback.  Everything but the transport of the sum is the code an N-GPU run executes; the
+        # ranks time-share the GPU, so no throughput is claimed (`value` null, "rehearsal" key).
+        self.same_device = os.environ.get("MOBROB_DP_SAME_DEVICE", "0") == "1" and world > 1
+        self.device_id = 0 if self.same_device else local_rank
+        self.use_dp = world > 1 or self.force_dp
+        self.backend_name = "gloo" if self.same_device else "nccl"
+
+    def init(self):
+        if not self.use_dp:
+            return
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if self.same_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.device_id))
+
+    def barrier(self):
+        if self.use_dp:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def max_over_ranks(self, x):
+        if not self.use_dp:
+            return x
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if self.same_device else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def replicas_identical(self, flat):
+        """Every rank holds the same parameter BITS (no broadcast ever happens: identical updates keep them so)."""
+        if not self.use_dp:
+            return True
+        import torch
+        import torch.distributed as dist
+        digest = np.frombuffer(hashlib.sha256(np.ascontiguousarray(flat).tobytes()).digest(), np.uint8).astype(np.int64)
+        mine = torch.from_numpy(digest.copy())
+        if not self.same_device:
+            mine = mine.cuda()
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return bool(torch.equal(lo, hi))
+
+    def finish(self):
+        if self.use_dp:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def bench_fleet(args, name, steps, warmup, job, phases):
     """Mixed-fleet workload: every rank holds all segments (N envs each); segments overlap on per-segment streams."""
     import torch
-    import torch.distributed as dist
-    from mobrob_amd.fleet import ROBOT_DIMS, MixedFleet, train_fleet_data_parallel
+    from mobrob_amd.fleet import MixedFleet, train_fleet_data_parallel
     from mobrob_amd.parallel import EngineBackend
+    w = WORKLOADS[name]
+    rank, world, use_dp = job.rank, job.world, job.use_dp
     H, N, T, E, B = w["H"], w["N"], w["T"], w["E"], w["B"]
     fleet = MixedFleet(w["segments"], n_envs=N, n_steps=T, batch_size=B * world, n_epochs=E, pi=(H, H), vf=(H, H),
-                       ent_coef=0.01, seed=0, device_id=local_rank, rank=rank, world_size=world,
+                       ent_coef=0.01, seed=0, device_id=job.device_id, rank=rank, world_size=world,
                        fast_kernels=not args.generic)
     for s in fleet.segments:
         s.engine.set_params(init_params(s.obs_dim, s.act_dim, H, seed=0))
@@ -310,7 +410,7 @@ def bench_fleet(args, w, rank, local_rank, world, use_dp, force_dp):
     def iteration():
         fleet.collect_synthetic(time_limit=w["tl"])
         if use_dp:
-            train_fleet_data_parallel(backends, streams, force_collectives=force_dp)
+            train_fleet_data_parallel(backends, streams, force_collectives=job.force_dp)
         else:
             fleet.train_enqueue()
 
@@ -318,35 +418,33 @@ def bench_fleet(args, w, rank, local_rank, world, use_dp, force_dp):
         fleet.synchronize()
         torch.cuda.synchronize()
         if use_dp:
-            dist.barrier()
+            job.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         iteration()
     fence()
     for s in fleet.segments:
-        s.engine.profile(True, only=None if args.phases else ["train_grad"])
+        s.engine.profile(True, only=None if phases else ["train_grad"])
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         iteration()
     fence()
     dt = time.perf_counter() - t0
     profs = [s.engine.profile_read() for s in fleet.segments]
-    if use_dp:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = job.max_over_ranks(dt)
+    out = None
     if rank == 0:
-        env_steps = fleet.env_steps_per_iteration * world * args.steps
+        env_steps = fleet.env_steps_per_iteration * world * steps
         ms = sum(p["train_grad"][0] for p in profs)
         calls = sum(p["train_grad"][1] for p in profs)
-        flops = sum(3.0 * f_fwd(s.obs_dim, H, s.act_dim) * float(N) * T * E * args.steps for s in fleet.segments)
+        flops = sum(3.0 * f_fwd(s.obs_dim, H, s.act_dim) * float(N) * T * E * steps for s in fleet.segments)
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         out = {
             "metric": "env-steps/sec (whole node)", "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload,
+            "config": {"workload": name,
                        "segments": [{"robot": s.name, "obs_dim": s.obs_dim, "act_dim": s.act_dim, "envs_per_gpu": s.n_envs,
                                      "arena_offset": s.offset, "arena_bytes": s.nbytes} for s in fleet.segments],
                        "net_arch": [H, H], "n_steps": T, "n_epochs": E, "minibatch_per_gpu": B,
@@ -357,103 +455,49 @@ def bench_fleet(args, w, rank, local_rank, world, use_dp, force_dp):
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                          "avg_launch_ms": ms / max(calls, 1), "launches": calls, "flops_per_launch": flops / max(calls, 1)},
-            "phases_bracketed": "all" if args.phases else "dominant kernel only",
-            "phase_ms_per_step": {k: sum(p[k][0] for p in profs) / args.steps for k in profs[0]
+            "phases_bracketed": "all" if phases else "dominant kernel only",
+            "phase_ms_per_step": {k: sum(p[k][0] for p in profs) / steps for k in profs[0]
                                   if sum(p[k][1] for p in profs) > 0},
         }
-        emit(out)
     fleet.close()
+    return out
 
 
-_RESULT_FD = None
-
-
-def emit(obj):
-    """The ONE JSON line of the contract, written to the process's original stdout."""
-    os.write(_RESULT_FD if _RESULT_FD is not None else 1, (json.dumps(obj) + "\n").encode())
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="doggo-4096env-2x256", choices=list(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--generic", action="store_true", help="force the generic (unfused) kernels")
-    ap.add_argument("--phases", action="store_true",
-                    help="bracket every phase with HIP events (phase_ms_per_step; costs ~4 %% of the throughput); "
-                         "by default only the dominant kernel is bracketed")
-    ap.add_argument("--host-python-loop", action="store_true",
-                    help="host-env workloads: drive the pipelined rollout from Python instead of mobrob_ppo_collect_host")
-    ap.add_argument("--host-parts", type=int, default=2,
-                    help="host-env workloads: row ranges of the pipelined rollout (1 = whole batch per step)")
-    ap.add_argument("--persistent-train", action="store_true",
-                    help="small-minibatch 2x64 workloads: one persistent launch per epoch (kernels_train_small.h) instead of "
-                         "four launches per optimizer step")
-    ap.add_argument("--dry-run-cpu", action="store_true",
-                    help="tests: exercise the rank launcher / rendezvous / one-line contract with gloo on CPU (no PPO work)")
-    args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # not under torchrun: start the ranks ourselves
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))      # (no GPU call has happened in this process)
-    # RCCL prints a version banner to the C stdout of every rank (flushed at exit, i.e. after the result line):
-    # keep the real stdout for the JSON line only and send everything else written to fd 1 to stderr.
-    global _RESULT_FD
-    sys.stdout.flush()
-    _RESULT_FD = os.dup(1)
-    os.dup2(2, 1)
-    w = WORKLOADS[args.workload]
-
+def bench_single(args, name, steps, warmup, job, phases):
+    """One learner per rank (every workload but the fleet): rank 0 returns the result object, the others None."""
     import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.dry_run_cpu:
-        return dry_run_cpu(args, rank, world)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    # MOBROB_FORCE_DP=1 runs the data-parallel code path (process group, zero-copy tensor views, all-reduces) even
-    # at world size 1 -- used to validate the multi-GPU plumbing on a single-GPU box.
-    force_dp = os.environ.get("MOBROB_FORCE_DP", "0") == "1"
-    use_dp = world > 1 or force_dp
-    if use_dp:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    import __graft_entry__
-    if rank == 0:
-        __graft_entry__.build()
-    if use_dp:
-        dist.barrier()
     from mobrob_amd.engine import PPOEngine
     from mobrob_amd.parallel import EngineBackend, train_data_parallel
-
-    if "segments" in w:
-        bench_fleet(args, w, rank, local_rank, world, use_dp, force_dp)
-        if use_dp:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+    w = WORKLOADS[name]
+    rank, world, use_dp, force_dp = job.rank, job.world, job.use_dp, job.force_dp
     D, A, H, N, T, E, B = w["D"], w["A"], w["H"], w["N"], w["T"], w["E"], w["B"]
     eng = PPOEngine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B * world, n_epochs=E, pi=(H, H), vf=(H, H),
-                    gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.01, seed=0, device_id=local_rank,
-                    rank=rank, world_size=world, fast_kernels=not args.generic,
-                    persistent_train=args.persistent_train)
+                    gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.01, seed=0, device_id=job.device_id,
+                    rank=rank, world_size=world, fast_kernels=not args.generic)
     eng.set_params(init_params(D, A, H, seed=0))  # identical replicas on every rank
     backend = EngineBackend(eng) if use_dp else None
+    fault, ar_calls = _fault_spec(), [0]
+    if use_dp and job.same_device and fault and fault[0] == rank:  # tests: this rank dies inside an all-reduce
+        inner = backend.gloo_all_reduce
+
+        def faulty(group=None):
+            fn = inner(group)
+
+            def reduce_in_place(ptr, count, dtype, stream):
+                ar_calls[0] += 1
+                if ar_calls[0] == fault[1]:
+                    os._exit(17)
+                fn(ptr, count, dtype, stream)
+            return reduce_in_place
+        backend.gloo_all_reduce = faulty
     if use_dp:  # the engine's own RCCL communicator (the update loop runs in C: mobrob_ppo_train_dp); RCCL sets up
         # channels / peer connections lazily at the first collective of a given size, so one full update is run
         # outside the timed region whatever --warmup is (its input is a throw-away rollout)
-        backend.ensure_comm()
-        eng.collect_synthetic(p_term=w["p_term"], time_limit=w["tl"])
-        train_data_parallel(backend, force_collectives=force_dp)
+        if not job.same_device:
+            backend.ensure_comm()
+        if not (fault and job.same_device):
+            eng.collect_synthetic(p_term=w["p_term"], time_limit=w["tl"])
+            train_data_parallel(backend, force_collectives=force_dp)
         p0 = init_params(D, A, H, seed=0)
         eng.set_params(p0)                                   # the timed region starts from the same replicas ...
         zeros = {k: np.zeros_like(v) for k, v in p0.items()}
@@ -507,49 +551,61 @@ def main():
         eng.synchronize()
         torch.cuda.synchronize()
         if use_dp:
-            dist.barrier()
+            job.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         iteration()
     fence()
-    # HIP events around every launch of the dominant kernel over the whole timed region (the roofline figure); the
-    # other phases only with --phases: an event pair costs GPU time at every launch boundary
-    eng.profile(True, only=None if args.phases else ["train_grad"])
+    # HIP events around every launch of the dominant kernel over the whole timed region (the roofline figure) and, in
+    # a data-parallel run, around every all-reduce (so that a scaling loss can be attributed); the other phases only
+    # with --phases: an event pair costs GPU time at every launch boundary
+    eng.profile(True, only=None if phases else (["train_grad", "allreduce"] if use_dp else ["train_grad"]))
+    eng.allreduce_counters(reset=True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         iteration()
     fence()
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile(False)
-    if use_dp:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    ar_n, ar_bytes = eng.allreduce_counters()
+    dt = job.max_over_ranks(dt)
+    identical = job.replicas_identical(eng.get_flat_params())
+    comm_n, _ = eng.comm_info()
 
+    out = None
     if rank == 0:
-        env_steps = N * T * world * args.steps
+        import torch.distributed as dist
+        env_steps = N * T * world * steps
         nmb = eng.n_minibatches
         ms, calls = prof["train_grad"]
         # ALGORITHMIC flops of the dominant kernel: forward + 2x backward = 3*F_fwd per sample, times
         # the samples one launch processes (T*N*E samples per iteration spread over its launches; the last
         # minibatch of an epoch is short when batch does not divide T*N)
-        flops_per_launch = 3.0 * f_fwd(D, H, A) * (float(N) * T * E * args.steps) / max(calls, 1)
+        flops_per_launch = 3.0 * f_fwd(D, H, A) * (float(N) * T * E * steps) / max(calls, 1)
         achieved = (flops_per_launch * calls / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
         traffic, traffic_note = None, "PMC traffic is profiled for the default workload on one GPU only"
-        if not args.generic and args.workload == "doggo-4096env-2x256" and not use_dp and not args.phases:
+        if not args.generic and name == "doggo-4096env-2x256" and not use_dp and not phases:
             traffic, traffic_note = measured_traffic("void mobrob::k_fused_train<64")
+        if comm_n > 0:      # the engine's own communicator carried the collectives: ITS size is what took part
+            ranks_seen, ranks_src = comm_n, "ncclCommCount of the engine's communicator"
+        elif use_dp:
+            ranks_seen, ranks_src = dist.get_world_size(), f"torch.distributed ({job.backend_name})"
+        else:
+            ranks_seen, ranks_src = 1, "single rank"
+        value = env_steps / dt
         out = {
-            "metric": "env-steps/sec (whole node), doggo PPO" if "doggo" in args.workload else "env-steps/sec (whole node)",
-            "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "env-steps/sec (whole node), doggo PPO" if "doggo" in name else "env-steps/sec (whole node)",
+            "value": None if job.same_device else value, "unit": "env-steps/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "obs_dim": D, "act_dim": A, "net_arch": [H, H], "envs_per_gpu": N,
+            "config": {"workload": name, "obs_dim": D, "act_dim": A, "net_arch": [H, H], "envs_per_gpu": N,
                        "n_steps": T, "n_epochs": E, "minibatch_per_gpu": B, "minibatches_per_epoch": nmb,
                        "env_source": (f"native host env (csrc/host_env.c, OpenMP), pinned zero-copy staging over PCIe, {args.host_parts} pipelined row ranges"
                                       if host is not None else "device-resident synthetic (Philox)"),
-                       "parallelism": f"dp{world}", "n_ranks_seen": dist.get_world_size() if use_dp else 1,
+                       "parallelism": f"dp{world}", "n_ranks_seen": ranks_seen, "n_ranks_source": ranks_src,
                        "kernels": "generic" if args.generic else "fused"},
             "roofline": {"bound": "mfma", "kernel": dominant_kernel_name(H, B, args.generic),
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -557,16 +613,106 @@ def main():
                          "traffic_note": traffic_note,
                          "avg_launch_ms": ms / max(calls, 1), "launches": calls,
                          "flops_per_launch": flops_per_launch},
-            "phases_bracketed": "all" if args.phases else "dominant kernel only",
-            "phase_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1] > 0},
+            "phases_bracketed": "all" if phases else ("dominant kernel + all-reduces" if use_dp else "dominant kernel only"),
+            "phase_ms_per_step": {k: v[0] / steps for k, v in prof.items() if v[1] > 0},
         }
-        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
+        if use_dp:
+            out["allreduces_per_step"] = ar_n / steps
+            out["allreduce_bytes"] = {"per_step": ar_bytes / steps, "gradient_message": (eng.P + 8) * 4,
+                                      "advantage_statistics_message": nmb * 4 * 8}
+            out["replicas_bit_identical"] = identical
+        if job.same_device:
+            out["rehearsal"] = {"what": f"{world} ranks time-sharing ONE GPU (MOBROB_DP_SAME_DEVICE=1): gloo process group, the C "
+                                        "loop mobrob_ppo_train_dp with the host-staged all-reduce callback; no throughput is "
+                                        "claimed",
+                                "env_steps_per_s_time_shared": value, "replicas_bit_identical": identical}
+    if use_dp and not identical:
+        raise SystemExit("bench.py: the replicas' parameters differ between ranks")
+    eng.close()
+    return out
+
+
+def also_measured(args, job):
+    """The other BASELINE configurations that fit one GPU, three steps each with the accounting of `value` (config 2,
+    the config-5 fleet, and the reference's own doggo YAML shape): the driver's record carries them too."""
+    res = {}
+    for name in ("point-1024env-2x64", "fleet-car-drone-turtlebot3-2x64", "doggo-ref-16env-2x64"):
+        fn = bench_fleet if "segments" in WORKLOADS[name] else bench_single
+        try:
+            o = fn(args, name, 3, 1, job, False)
+            res[name] = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": 3, "warmup": 1,
+                         "roofline": {k: o["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches")},
+                         "config": {k: v for k, v in o["config"].items() if k in ("envs_per_gpu", "n_steps", "n_epochs", "minibatch_per_gpu", "net_arch", "obs_dim", "act_dim")}}
+        except Exception as ex:  # noqa: BLE001 - the headline line must not die with a side measurement
+            res[name] = {"error": f"{type(ex).__name__}: {ex}"}
+    return res
+
+
+_RESULT_FD = None
+
+
+def emit(obj):
+    """The ONE JSON line of the contract, written to the process's original stdout."""
+    os.write(_RESULT_FD if _RESULT_FD is not None else 1, (json.dumps(obj) + "\n").encode())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="doggo-4096env-2x256", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the also_measured side configurations")
+    ap.add_argument("--generic", action="store_true", help="force the generic (unfused) kernels")
+    ap.add_argument("--phases", action="store_true",
+                    help="bracket every phase with HIP events (phase_ms_per_step; costs ~4 %% of the throughput); "
+                         "by default only the dominant kernel is bracketed")
+    ap.add_argument("--host-python-loop", action="store_true",
+                    help="host-env workloads: drive the pipelined rollout from Python instead of mobrob_ppo_collect_host")
+    ap.add_argument("--host-parts", type=int, default=2,
+                    help="host-env workloads: row ranges of the pipelined rollout (1 = whole batch per step)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="tests: exercise the rank launcher / rendezvous / one-line contract with gloo on CPU (no PPO work)")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # not under torchrun: start the ranks ourselves
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))      # (no GPU call has happened in this process)
+    # RCCL prints a version banner to the C stdout of every rank (flushed at exit, i.e. after the result line):
+    # keep the real stdout for the JSON line only and send everything else written to fd 1 to stderr.
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
+    w = WORKLOADS[args.workload]
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, rank, world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    job = Job(args, rank, local_rank, world)
+    torch.cuda.set_device(job.device_id)
+    job.init()
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    job.barrier()
+
+    fn = bench_fleet if "segments" in w else bench_single
+    out = fn(args, args.workload, args.steps, args.warmup, job, args.phases)
+    if rank == 0:
+        if world == 1 and not job.use_dp and args.workload == "doggo-4096env-2x256" and not args.no_also and not args.generic:
+            out["also_measured"] = also_measured(args, job)
+        if not args.no_cpu_baseline and world == 1 and "segments" not in w:  # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(w, workload_name=args.workload)
         emit(out)
-    if use_dp:
-        dist.barrier()
-        dist.destroy_process_group()
-    eng.close()
+    job.finish()
 
 
 if __name__ == "__main__":

@@ -244,7 +244,7 @@ typedef struct mobrob_ppo_train_stats {
 /* ---- data-parallel update: one process per GPU, rank r owns its envs and rollout shard ------------
  * PPO.train() of the reference (reached through PPOCtrl.learn, /root/reference/src/mobrob/rl_control/ppo.py:73-74)
  * across `cfg.world_size` ranks: per epoch ONE all-reduce of the [n_minibatches][4] float64 advantage statistics, per
- * optimizer step ONE all-reduce (sum) of the flat [P] float32 gradient, both enqueued on the engine's stream between
+ * optimizer step ONE all-reduce (sum) of the flat [P + 8] float32 gradient + loss sums, both enqueued on the engine's stream between
  * the kernels -- no host synchronisation and no interpreter in the loop.  Every rank then applies the identical
  * clip + Adam, so replicas stay bit-identical.  batch_size in the config is the GLOBAL minibatch.
  *   comm_unique_id  rank 0 makes the 128-byte RCCL id; the caller ships it to the other ranks (any side channel)
@@ -255,9 +255,23 @@ typedef struct mobrob_ppo_train_stats {
  *                   (tests: gloo between two ranks that share one GPU). */
 typedef int (*mobrob_allreduce_fn)(void* ctx, void* buf_dev, size_t count, int32_t dtype, void* hip_stream);
 int mobrob_ppo_comm_unique_id(uint8_t* out128);
+/* comm_prepare  LOCAL, non-collective half of comm_init: RCCL loadable, device selectable, no communicator yet.  Ranks
+ *               agree on its outcome (any side channel) BEFORE any of them enters the blocking ncclCommInitRank, so a
+ *               rank that cannot take part never leaves the others waiting for it.
+ * comm_init_rank  comm_init with the rank / size of the process (sub)group the communicator spans; nranks must equal
+ *               cfg.world_size (the minibatch split).  comm_init == comm_init_rank(cfg.rank, cfg.world_size).
+ * comm_info     ncclCommCount / ncclCommUserRank of the engine's communicator (0 / -1 without one): what a bench line
+ *               reports as the number of ranks that really took part in the collectives. */
+int mobrob_ppo_comm_prepare(mobrob_ppo_engine_t* e);
 int mobrob_ppo_comm_init(mobrob_ppo_engine_t* e, const uint8_t* id128);
+int mobrob_ppo_comm_init_rank(mobrob_ppo_engine_t* e, const uint8_t* id128, int32_t rank, int32_t nranks);
+int mobrob_ppo_comm_info(mobrob_ppo_engine_t* e, int32_t* nranks, int32_t* rank);
 int mobrob_ppo_comm_destroy(mobrob_ppo_engine_t* e);
+/* SB3's target_kl works under data parallel too: the minibatch's approx_kl sum travels with the gradient (the message
+ * is [P + 8] floats: gradient + loss sums), every rank reads the same global value and stops at the same step. */
 int mobrob_ppo_train_dp(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_allreduce_fn fn, void* ctx);
+/* all-reduces issued by train_dp since the last reset: how many, and their payload bytes (bench: allreduces_per_step) */
+int mobrob_ppo_allreduce_counters(mobrob_ppo_engine_t* e, int64_t* calls, int64_t* bytes, int32_t reset);
 
 /* ---- env-side controllers of the Bullet robots, batched over n robots on the device (csrc/robot_ctrl.h) ----------
  * In the reference the RL action of these two robots corrects controller GAINS and the controller runs inside
@@ -290,7 +304,7 @@ int mobrob_ctrl_drone_pid(mobrob_ppo_engine_t* e, int32_t n, int32_t dev_ptrs, c
  *   CLIP_RANGE_VF               value-function clipping: the loss uses old_value + clamp(value - old_value, +-c);
  *                               negative = None (default)
  *   TARGET_KL                   early stop: when a minibatch's approx_kl > 1.5 * target, its optimizer step and the rest
- *                               of train() are dropped (single-rank update); <= 0 = None (default)
+ *                               of train() are dropped (train and train_dp alike); <= 0 = None (default)
  *   ENT_COEF / VF_COEF          loss coefficients */
 enum {
   MOBROB_HYPER_LEARNING_RATE = 0, MOBROB_HYPER_CLIP_RANGE = 1, MOBROB_HYPER_CLIP_RANGE_VF = 2, MOBROB_HYPER_TARGET_KL = 3,
@@ -321,6 +335,10 @@ int mobrob_ppo_epoch_begin(mobrob_ppo_engine_t* e, const int64_t* perm /* T*N or
 int mobrob_ppo_num_minibatches(const mobrob_ppo_engine_t* e);
 int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb);
 int mobrob_ppo_minibatch_apply(mobrob_ppo_engine_t* e);
+/* minibatch_apply with SB3's target_kl check in front of the optimizer step (the approx_kl of the -- all-reduced --
+ * loss sums is read back, 4 bytes): *stopped = 1 means the step was NOT taken and the driver must end its train().
+ * minibatch_apply itself refuses (MOBROB_ERR_STATE) while target_kl is set, so that no step-wise driver ignores it. */
+int mobrob_ppo_minibatch_apply_checked(mobrob_ppo_engine_t* e, int32_t* stopped);
 /* per-minibatch stats of every optimizer step since the last call to this function:
  * rows of 8 floats [policy_loss, value_loss, entropy_loss, loss, approx_kl, clip_fraction,
  * grad_norm, 0]; returns rows written (<= max_rows) or a negative error. */
@@ -351,7 +369,9 @@ enum {
   MOBROB_BUF_TERMINAL_VALUES = 16, /* f32 [N] V(terminal_obs) of those rows (time-limit bootstrap)              */
   MOBROB_BUF_TRUNCATED = 17,       /* u8  [N] TimeLimit.truncated flags of the latest step                       */
   MOBROB_BUF_ENV_STATE = 18,       /* f32 [N][12] goal-env state: pos[3] vel[3] goal[3] return length pad         */
-  MOBROB_BUF_COUNT = 19
+  MOBROB_BUF_GRAD_EXCHANGE = 19,   /* f32 [P + 8]: the gradient followed by the eight loss sums of the minibatch (policy, value,
+                                      approx_kl, clip fraction, row count, ...) -- what a data-parallel step sums across ranks */
+  MOBROB_BUF_COUNT = 20
 };
 int mobrob_ppo_buffer_info(mobrob_ppo_engine_t* e, int32_t which, void** ptr_dev, size_t* bytes);
 /* copy with host layout [..][D] <-> device layout [..][Dp] handled for MOBROB_BUF_OBS */
@@ -375,7 +395,8 @@ enum {
   MOBROB_K_APPLY = 3,        /* grad-norm + clip + Adam                                         */
   MOBROB_K_ENV = 4,          /* synthetic env source (+ time-limit bootstrap)                   */
   MOBROB_K_GRAD_REDUCE = 5,  /* deterministic reduction of the per-workgroup gradient slabs     */
-  MOBROB_K_COUNT = 6
+  MOBROB_K_ALLREDUCE = 6,    /* data parallel: the all-reduces of train_dp (gradient + statistics) */
+  MOBROB_K_COUNT = 7
 };
 /* on: 0 = off, 1 = bracket every phase with HIP events, otherwise a mask with bit (MOBROB_K_x + 1) set for each phase
  * to bracket.  An event pair costs a few microseconds of GPU time per launch: bracketing all four launches of an

@@ -16,9 +16,9 @@ OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
 BUF = dict(obs=0, actions=1, rewards=2, episode_starts=3, values=4, log_probs=5, advantages=6, returns=7,
            params=8, grads=9, advstat=10, last_values=11, last_dones=12, clipped_actions=13, episode_start_state=14,
-           terminal_obs=15, terminal_values=16, truncated=17, env_state=18)
+           terminal_obs=15, terminal_values=16, truncated=17, env_state=18, grad_exchange=19)
 HYPER = dict(learning_rate=0, clip_range=1, clip_range_vf=2, target_kl=3, ent_coef=4, vf_coef=5)
-KERNEL_IDS = dict(act=0, gae=1, train_grad=2, apply=3, env=4, grad_reduce=5)
+KERNEL_IDS = dict(act=0, gae=1, train_grad=2, apply=3, env=4, grad_reduce=5, allreduce=6)
 
 
 class Config(C.Structure):
@@ -99,13 +99,18 @@ SYMBOLS = {
     "mobrob_ctrl_drone_pid": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(DroneParams), _F, _F, _F, _F, _F, _F]),
     "mobrob_ppo_last_train_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mobrob_ppo_comm_unique_id": (C.c_int, [_U8]),
+    "mobrob_ppo_comm_prepare": (C.c_int, [_P]),
     "mobrob_ppo_comm_init": (C.c_int, [_P, _U8]),
+    "mobrob_ppo_comm_init_rank": (C.c_int, [_P, _U8, C.c_int32, C.c_int32]),
+    "mobrob_ppo_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mobrob_ppo_allreduce_counters": (C.c_int, [_P, _I64, _I64, C.c_int32]),
     "mobrob_ppo_comm_destroy": (C.c_int, [_P]),
     "mobrob_ppo_train_dp": (C.c_int, [_P, _I64, _P, _P]),
     "mobrob_ppo_epoch_begin": (C.c_int, [_P, _I64]),
     "mobrob_ppo_num_minibatches": (C.c_int, [_P]),
     "mobrob_ppo_minibatch_grad": (C.c_int, [_P, C.c_int32]),
     "mobrob_ppo_minibatch_apply": (C.c_int, [_P]),
+    "mobrob_ppo_minibatch_apply_checked": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "mobrob_ppo_fetch_step_stats": (C.c_int, [_P, _F, C.c_int32]),
     "mobrob_ppo_predict": (C.c_int, [_P, _F, C.c_int32, C.c_int32, _F, _F, _F]),
     "mobrob_ppo_buffer_info": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_size_t)]),

@@ -132,6 +132,7 @@ struct mobrob_ppo_engine {
   double target_kl = -1.0;    // SB3 target_kl (< 0: None): early stop of PPO.train() when a minibatch's approx_kl > 1.5 target
   int last_epochs_started = 0, last_stopped_early = 0, last_steps_applied = 0;  // of the latest mobrob_ppo_train*
   ncclComm_t comm = nullptr;  // RCCL communicator of the data-parallel job (mobrob_ppo_comm_init)
+  int64_t allreduce_calls = 0, allreduce_bytes = 0;  // since the last mobrob_ppo_allreduce_counters(reset)
   // norm records of the reduction kernels (kernels_fused.h: block_norm_records): used inside mobrob_ppo_train only
   double* norm_rec_sum = nullptr; int* norm_rec_t = nullptr; int* fold_idx_dev = nullptr;
   int fold_start[14] = {0};
@@ -1674,13 +1675,47 @@ int apply_adam(mobrob_ppo_engine* e, const ApplyCtx& c) {
 }
 }  // namespace
 
-int mobrob_ppo_minibatch_apply(mobrob_ppo_engine_t* e) {
-  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
-  if (!e->grad_pending) return fail(MOBROB_ERR_STATE, "minibatch_apply without a pending gradient");
+namespace {
+// clip + Adam of the pending gradient, with SB3's target_kl check in front of it when that option is on: the
+// minibatch's approx_kl is known after the loss statistics; above 1.5 x target the optimizer step of THIS minibatch is
+// dropped (*stopped = 1; the caller drops the rest of train()).  One 4-byte read-back per step.  Under data parallel
+// the value is that of the union minibatch (its sum travelled with the gradient), bit-equal on every rank.
+int apply_checked(mobrob_ppo_engine* e, int32_t* stopped) {
+  *stopped = 0;
   ProfScope ps(e, MOBROB_K_APPLY);
   ApplyCtx c{};
   CHK(apply_norms(e, c));
+  if (e->target_kl > 0.0) {
+    float approx_kl = 0.f;
+    HIPC(hipMemcpyAsync(&approx_kl, c.stats_row + 4, sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPC(hipStreamSynchronize(e->stream));
+    if ((double)approx_kl > 1.5 * e->target_kl) {
+      *stopped = 1;
+      e->grad_pending = false;
+      // the row of the dropped step carries its losses (SB3 appends them before the check) but no gradient norm:
+      // all-ones bits = NaN, skipped by the averages
+      HIPC(hipMemsetAsync(c.stats_row + 6, 0xFF, sizeof(float), e->stream));
+      if (e->fused.enabled) HIPC(hipMemsetAsync(e->grads + e->P, 0, 8 * sizeof(float), e->stream));  // what k_adam_pack would have re-zeroed
+      return MOBROB_OK;
+    }
+  }
   return apply_adam(e, c);
+}
+}  // namespace
+
+int mobrob_ppo_minibatch_apply(mobrob_ppo_engine_t* e) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  if (!e->grad_pending) return fail(MOBROB_ERR_STATE, "minibatch_apply without a pending gradient");
+  if (e->target_kl > 0.0)
+    return fail(MOBROB_ERR_STATE, "target_kl is set: a step-wise driver must call mobrob_ppo_minibatch_apply_checked and honour its stop flag");
+  int32_t stopped = 0;
+  return apply_checked(e, &stopped);
+}
+
+int mobrob_ppo_minibatch_apply_checked(mobrob_ppo_engine_t* e, int32_t* stopped) {
+  if (!e || !stopped) return fail(MOBROB_ERR_INVALID, "minibatch_apply_checked: null argument");
+  if (!e->grad_pending) return fail(MOBROB_ERR_STATE, "minibatch_apply without a pending gradient");
+  return apply_checked(e, stopped);
 }
 
 int mobrob_ppo_set_hyper(mobrob_ppo_engine_t* e, int32_t which, double value) {
@@ -1768,72 +1803,7 @@ int train_small_epoch(mobrob_ppo_engine* e, int ep) {
 }
 }  // namespace
 
-int mobrob_ppo_train_enqueue(mobrob_ppo_engine_t* e, const int64_t* perms) {
-  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
-  if (e->cfg.world_size != 1)
-    return fail(MOBROB_ERR_STATE, "mobrob_ppo_train is the single-rank loop; data-parallel ranks drive epoch_begin/"
-                                  "minibatch_grad/[all-reduce]/minibatch_apply");
-  const size_t total = (size_t)e->N * e->T;
-  e->stats_n = 0;
-  const bool kl = e->target_kl > 0.0;
-  e->last_epochs_started = 0; e->last_stopped_early = 0; e->last_steps_applied = 0;
-  const bool small = train_small_ok(e) && !kl;
-  if (small) {  // Adam's bias corrections of every step of this call, in float64 on the host like the per-step path
-    e->sched_host.resize((size_t)2 * e->nmb * e->cfg.n_epochs);
-    const double b1 = e->cfg.adam_beta1, b2 = e->cfg.adam_beta2;
-    for (size_t k = 0; k < (size_t)e->nmb * e->cfg.n_epochs; ++k) {
-      const double step = (double)(e->adam_step + 1 + (int64_t)k);
-      e->sched_host[2 * k] = (float)(e->cfg.learning_rate / (1.0 - std::pow(b1, step)));
-      e->sched_host[2 * k + 1] = (float)std::sqrt(1.0 - std::pow(b2, step));
-    }
-    HIPC(hipMemcpyAsync(e->sched_dev, e->sched_host.data(), e->sched_host.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
-  }
-  // 64-wide nets only: ~90 records.  At 2x256 the table has 712 records, every k_adam_pack block pays for folding
-  // them and the reduction kernel for forming them: measured 12.9 instead of 11.4 ms per iteration (A/B on one box).
-  struct RecordsOn {  // nothing can touch the gradient between reduction and clip inside this loop
-    mobrob_ppo_engine* e;
-    explicit RecordsOn(mobrob_ppo_engine* e_) : e(e_) { e->use_norm_records = e->fused.enabled && e->fused.H == 64 && e->target_kl <= 0.0 && getenv("MOBROB_NO_NORM_RECORDS") == nullptr; }
-    ~RecordsOn() { e->use_norm_records = false; }
-  } records_on(e);
-  for (int ep = 0; ep < e->cfg.n_epochs; ++ep) {
-    CHK(mobrob_ppo_epoch_begin(e, perms ? perms + (size_t)ep * total : nullptr));
-    if (small) {
-      CHK(train_small_epoch(e, ep));
-      e->last_epochs_started = ep + 1;
-      e->last_steps_applied += e->nmb;
-      continue;
-    }
-    e->last_epochs_started = ep + 1;
-    if (ep == e->cfg.n_epochs - 1 || kl) e->stats_n = 0;  // the rows kept are those of the last epoch that ran
-    for (int mb = 0; mb < e->nmb && !e->last_stopped_early; ++mb) {
-      CHK(mobrob_ppo_minibatch_grad(e, mb));
-      if (!kl) {
-        CHK(mobrob_ppo_minibatch_apply(e));
-        e->last_steps_applied++;
-        continue;
-      }
-      // target_kl [SB3 PPO.train]: the minibatch's approx_kl is known after the loss statistics; above 1.5 x target
-      // the optimizer step of THIS minibatch and everything after it is dropped.  One 4-byte read-back per step.
-      ApplyCtx c{};
-      CHK(apply_norms(e, c));
-      float approx_kl = 0.f;
-      HIPC(hipMemcpyAsync(&approx_kl, c.stats_row + 4, sizeof(float), hipMemcpyDeviceToHost, e->stream));
-      HIPC(hipStreamSynchronize(e->stream));
-      if ((double)approx_kl > 1.5 * e->target_kl) {
-        e->last_stopped_early = 1;
-        e->grad_pending = false;
-        if (e->fused.enabled) HIPC(hipMemsetAsync(e->grads + e->P, 0, 8 * sizeof(float), e->stream));  // what k_adam_pack would have re-zeroed
-        break;
-      }
-      CHK(apply_adam(e, c));
-      e->last_steps_applied++;
-    }
-    if (e->last_stopped_early) break;
-  }
-  e->epoch_open = false;
-  return MOBROB_OK;
-}
-
+}  // extern "C"
 // ---- data parallel: the whole update loop in C, one RCCL all-reduce per optimizer step on the engine's stream ----
 namespace {
 struct RcclApi {
@@ -1843,6 +1813,8 @@ struct RcclApi {
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
 };
 RcclApi g_rccl;
 int rccl_load() {
@@ -1859,6 +1831,8 @@ int rccl_load() {
   RSYM(CommDestroy, "ncclCommDestroy")
   RSYM(AllReduce, "ncclAllReduce")
   RSYM(GetErrorString, "ncclGetErrorString")
+  RSYM(CommCount, "ncclCommCount")
+  RSYM(CommUserRank, "ncclCommUserRank")
 #undef RSYM
   g_rccl.lib = h;
   return MOBROB_OK;
@@ -1871,6 +1845,9 @@ int rccl_load() {
 
 // sum `count` elements (dtype 0 = f32, 1 = f64) in place across the ranks, ordered on the engine's stream
 int dp_all_reduce(mobrob_ppo_engine* e, void* buf, size_t count, int dtype, mobrob_allreduce_fn fn, void* ctx) {
+  ProfScope ps(e, MOBROB_K_ALLREDUCE);
+  e->allreduce_calls++;
+  e->allreduce_bytes += count * (dtype == 1 ? 8 : 4);
   if (fn) {
     const int r = fn(ctx, buf, count, dtype, (void*)e->stream);
     return r == 0 ? MOBROB_OK : fail(MOBROB_ERR_STATE, "all-reduce callback returned %d", r);
@@ -1880,7 +1857,76 @@ int dp_all_reduce(mobrob_ppo_engine* e, void* buf, size_t count, int dtype, mobr
 }
 }  // namespace
 
+namespace {
+// PPO.train() [SB3 ppo/ppo.py], single rank (dp == false) or data parallel (dp == true: the advantage statistics are
+// all-reduced once per epoch, the gradient TOGETHER WITH the eight loss sums behind it once per optimizer step, so the
+// logged statistics and the target_kl decision are those of the union minibatch on every rank alike).
+int train_loop(mobrob_ppo_engine* e, const int64_t* perms, bool dp, mobrob_allreduce_fn fn, void* ctx) {
+  const size_t total = (size_t)e->N * e->T;
+  e->stats_n = 0;
+  const bool kl = e->target_kl > 0.0;
+  e->last_epochs_started = 0; e->last_stopped_early = 0; e->last_steps_applied = 0;
+  const bool small = !dp && train_small_ok(e) && !kl;
+  if (small) {  // Adam's bias corrections of every step of this call, in float64 on the host like the per-step path
+    e->sched_host.resize((size_t)2 * e->nmb * e->cfg.n_epochs);
+    const double b1 = e->cfg.adam_beta1, b2 = e->cfg.adam_beta2;
+    for (size_t k = 0; k < (size_t)e->nmb * e->cfg.n_epochs; ++k) {
+      const double step = (double)(e->adam_step + 1 + (int64_t)k);
+      e->sched_host[2 * k] = (float)(e->cfg.learning_rate / (1.0 - std::pow(b1, step)));
+      e->sched_host[2 * k + 1] = (float)std::sqrt(1.0 - std::pow(b2, step));
+    }
+    HIPC(hipMemcpyAsync(e->sched_dev, e->sched_host.data(), e->sched_host.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  }
+  // 64-wide nets only: ~90 records.  At 2x256 the table has 712 records, every k_adam_pack block pays for folding
+  // them and the reduction kernel for forming them: measured 12.9 instead of 11.4 ms per iteration (A/B on one box).
+  // Never under data parallel: the records are norms of the LOCAL gradient, the clip needs those of the summed one.
+  struct RecordsOn {  // nothing can touch the gradient between reduction and clip inside this loop
+    mobrob_ppo_engine* e;
+    RecordsOn(mobrob_ppo_engine* e_, bool dp_) : e(e_) { e->use_norm_records = !dp_ && e->fused.enabled && e->fused.H == 64 && e->target_kl <= 0.0 && getenv("MOBROB_NO_NORM_RECORDS") == nullptr; }
+    ~RecordsOn() { e->use_norm_records = false; }
+  } records_on(e, dp);
+  for (int ep = 0; ep < e->cfg.n_epochs; ++ep) {
+    CHK(mobrob_ppo_epoch_begin(e, perms ? perms + (size_t)ep * total : nullptr));
+    // per-minibatch (sum, sum of squares, count) of the advantages: global statistics for the normalisation
+    if (dp) CHK(dp_all_reduce(e, e->advstat, (size_t)e->nmb * 4, 1, fn, ctx));
+    if (small) {
+      CHK(train_small_epoch(e, ep));
+      e->last_epochs_started = ep + 1;
+      e->last_steps_applied += e->nmb;
+      continue;
+    }
+    e->last_epochs_started = ep + 1;
+    if (ep == e->cfg.n_epochs - 1 || kl) e->stats_n = 0;  // the rows kept are those of the last epoch that ran
+    for (int mb = 0; mb < e->nmb && !e->last_stopped_early; ++mb) {
+      CHK(mobrob_ppo_minibatch_grad(e, mb));
+      // THE exchange step, one per optimizer step: [P] gradient + [8] loss sums (policy, value, approx_kl, clip
+      // fraction, row count ...) in one message
+      if (dp) CHK(dp_all_reduce(e, e->grads, (size_t)e->P + 8, 0, fn, ctx));
+      int32_t stopped = 0;  // target_kl [SB3 PPO.train]: this step and everything after it is dropped
+      CHK(apply_checked(e, &stopped));
+      if (stopped) {
+        e->last_stopped_early = 1;
+        break;
+      }
+      e->last_steps_applied++;
+    }
+    if (e->last_stopped_early) break;
+  }
+  e->epoch_open = false;
+  return MOBROB_OK;
+}
+}  // namespace
+
 extern "C" {
+
+int mobrob_ppo_train_enqueue(mobrob_ppo_engine_t* e, const int64_t* perms) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  if (e->cfg.world_size != 1)
+    return fail(MOBROB_ERR_STATE, "mobrob_ppo_train is the single-rank loop; data-parallel ranks call mobrob_ppo_train_dp "
+                                  "(or drive epoch_begin/minibatch_grad/[all-reduce]/minibatch_apply)");
+  return train_loop(e, perms, false, nullptr, nullptr);
+}
+
 int mobrob_ppo_comm_unique_id(uint8_t* out128) {
   if (!out128) return fail(MOBROB_ERR_INVALID, "comm_unique_id: null argument");
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
@@ -1890,14 +1936,37 @@ int mobrob_ppo_comm_unique_id(uint8_t* out128) {
   memcpy(out128, &id, sizeof id);
   return MOBROB_OK;
 }
-int mobrob_ppo_comm_init(mobrob_ppo_engine_t* e, const uint8_t* id128) {
-  if (!e || !id128) return fail(MOBROB_ERR_INVALID, "comm_init: null argument");
-  if (e->comm) return fail(MOBROB_ERR_STATE, "comm_init: the engine already has a communicator");
+int mobrob_ppo_comm_prepare(mobrob_ppo_engine_t* e) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "comm_prepare: null engine");
+  if (e->comm) return fail(MOBROB_ERR_STATE, "comm_prepare: the engine already has a communicator");
   CHK(rccl_load());
   HIPC(hipSetDevice(e->cfg.device_id));
+  return MOBROB_OK;
+}
+int mobrob_ppo_comm_init_rank(mobrob_ppo_engine_t* e, const uint8_t* id128, int32_t rank, int32_t nranks) {
+  if (!e || !id128) return fail(MOBROB_ERR_INVALID, "comm_init: null argument");
+  if (nranks != e->cfg.world_size)
+    return fail(MOBROB_ERR_INVALID, "comm_init: %d ranks, but the engine splits its minibatch for world_size %d", nranks, e->cfg.world_size);
+  if (rank < 0 || rank >= nranks) return fail(MOBROB_ERR_INVALID, "comm_init: rank %d of %d", rank, nranks);
+  CHK(mobrob_ppo_comm_prepare(e));
   ncclUniqueId id;
   memcpy(&id, id128, sizeof id);
-  NCCLC(g_rccl.CommInitRank(&e->comm, e->cfg.world_size, id, e->cfg.rank));
+  NCCLC(g_rccl.CommInitRank(&e->comm, nranks, id, rank));
+  return MOBROB_OK;
+}
+int mobrob_ppo_comm_init(mobrob_ppo_engine_t* e, const uint8_t* id128) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "comm_init: null argument");
+  return mobrob_ppo_comm_init_rank(e, id128, e->cfg.rank, e->cfg.world_size);
+}
+int mobrob_ppo_comm_info(mobrob_ppo_engine_t* e, int32_t* nranks, int32_t* rank) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  int n = 0, r = -1;
+  if (e->comm) {
+    NCCLC(g_rccl.CommCount(e->comm, &n));
+    NCCLC(g_rccl.CommUserRank(e->comm, &r));
+  }
+  if (nranks) *nranks = n;
+  if (rank) *rank = r;
   return MOBROB_OK;
 }
 int mobrob_ppo_comm_destroy(mobrob_ppo_engine_t* e) {
@@ -1913,25 +1982,15 @@ int mobrob_ppo_train_dp(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_all
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   if (!fn && !e->comm)
     return fail(MOBROB_ERR_STATE, "train_dp: no communicator (mobrob_ppo_comm_init) and no all-reduce callback");
-  if (e->target_kl > 0.0)
-    return fail(MOBROB_ERR_STATE, "target_kl is implemented for the single-rank update only (the stop decision needs the global approx_kl)");
-  const size_t total = (size_t)e->N * e->T;
-  e->stats_n = 0;
-  for (int ep = 0; ep < e->cfg.n_epochs; ++ep) {
-    CHK(mobrob_ppo_epoch_begin(e, perms ? perms + (size_t)ep * total : nullptr));
-    // per-minibatch (sum, sum of squares, count) of the advantages: global statistics for the normalisation
-    CHK(dp_all_reduce(e, e->advstat, (size_t)e->nmb * 4, 1, fn, ctx));
-    if (ep == e->cfg.n_epochs - 1) e->stats_n = 0;
-    for (int mb = 0; mb < e->nmb; ++mb) {
-      CHK(mobrob_ppo_minibatch_grad(e, mb));
-      CHK(dp_all_reduce(e, e->grads, (size_t)e->P, 0, fn, ctx));  // THE exchange step: one per optimizer step
-      CHK(mobrob_ppo_minibatch_apply(e));
-    }
-  }
-  e->epoch_open = false;
+  return train_loop(e, perms, true, fn, ctx);
+}
+int mobrob_ppo_allreduce_counters(mobrob_ppo_engine_t* e, int64_t* calls, int64_t* bytes, int32_t reset) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  if (calls) *calls = e->allreduce_calls;
+  if (bytes) *bytes = e->allreduce_bytes;
+  if (reset) { e->allreduce_calls = 0; e->allreduce_bytes = 0; }
   return MOBROB_OK;
 }
-}  // extern "C"
 
 int mobrob_ppo_train(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_ppo_train_stats_t* st) {
   CHK(mobrob_ppo_train_enqueue(e, perms));
@@ -1940,12 +1999,15 @@ int mobrob_ppo_train(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_ppo_tr
     const int n = mobrob_ppo_fetch_step_stats(e, rows.data(), e->nmb);
     if (n < 0) return n;
     double acc[7] = {0};
-    for (int i = 0; i < n; ++i)
-      for (int k = 0; k < 7; ++k) acc[k] += rows[(size_t)i * 8 + k];
+    int n_norm = 0;  // a step dropped by target_kl logs its losses but has no gradient norm (NaN)
+    for (int i = 0; i < n; ++i) {
+      for (int k = 0; k < 6; ++k) acc[k] += rows[(size_t)i * 8 + k];
+      if (!std::isnan(rows[(size_t)i * 8 + 6])) { acc[6] += rows[(size_t)i * 8 + 6]; n_norm++; }
+    }
     const double d = n > 0 ? n : 1;
     st->policy_loss = (float)(acc[0] / d); st->value_loss = (float)(acc[1] / d); st->entropy_loss = (float)(acc[2] / d);
     st->loss = (float)(acc[3] / d); st->approx_kl = (float)(acc[4] / d); st->clip_fraction = (float)(acc[5] / d);
-    st->grad_norm = (float)(acc[6] / d); st->n_minibatches = e->last_steps_applied;
+    st->grad_norm = (float)(acc[6] / (n_norm > 0 ? n_norm : 1)); st->n_minibatches = e->last_steps_applied;
   } else {
     HIPC(hipStreamSynchronize(e->stream));
   }
@@ -2010,6 +2072,7 @@ int mobrob_ppo_buffer_info(mobrob_ppo_engine_t* e, int32_t which, void** ptr, si
     case MOBROB_BUF_TERMINAL_VALUES: p = e->term_val; b = N * 4; break;
     case MOBROB_BUF_TRUNCATED: p = e->trunc_dev; b = N; break;
     case MOBROB_BUF_ENV_STATE: p = e->gstate[0]; b = N * kGoalStateFloats * 4; break;
+    case MOBROB_BUF_GRAD_EXCHANGE: p = e->grads; b = (size_t)(e->P + 8) * 4; break;
     default: return fail(MOBROB_ERR_INVALID, "unknown buffer id %d", which);
   }
   if (ptr) *ptr = p;

@@ -349,11 +349,32 @@ class PPOEngine:
         check(self.lib.mobrob_ppo_train(self._h, p, C.byref(st)))
         return {k: float(getattr(st, k)) for k in STAT_KEYS} | {"n_minibatches": int(st.n_minibatches)}
 
-    def comm_init(self, unique_id=None):
+    def comm_prepare(self):
+        """Local, non-collective half of comm_init (RCCL loadable, device selectable, no communicator yet): ranks agree
+        on its outcome before any of them enters the blocking collective."""
+        check(self.lib.mobrob_ppo_comm_prepare(self._h))
+
+    def comm_init(self, unique_id=None, rank=None, nranks=None):
         """Collective over the ranks of the job: build the engine's RCCL communicator.  Rank 0 calls
-        `PPOEngine.comm_unique_id()` and ships the 128 bytes to the others (parallel.py uses torch.distributed)."""
+        `PPOEngine.comm_unique_id()` and ships the 128 bytes to the others (parallel.py uses torch.distributed).
+        rank / nranks: position in the process (sub)group the communicator spans (default: the engine's config)."""
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
-        check(self.lib.mobrob_ppo_comm_init(self._h, buf))
+        if rank is None and nranks is None:
+            check(self.lib.mobrob_ppo_comm_init(self._h, buf))
+        else:
+            check(self.lib.mobrob_ppo_comm_init_rank(self._h, buf, int(rank), int(nranks)))
+
+    def comm_info(self):
+        """(ncclCommCount, ncclCommUserRank) of the engine's communicator; (0, -1) without one."""
+        n, r = C.c_int32(), C.c_int32()
+        check(self.lib.mobrob_ppo_comm_info(self._h, C.byref(n), C.byref(r)))
+        return int(n.value), int(r.value)
+
+    def allreduce_counters(self, reset=False):
+        """(calls, payload bytes) of the all-reduces train_dp issued since the last reset."""
+        c, b = C.c_int64(), C.c_int64()
+        check(self.lib.mobrob_ppo_allreduce_counters(self._h, C.byref(c), C.byref(b), int(bool(reset))))
+        return int(c.value), int(b.value)
 
     @staticmethod
     def comm_unique_id() -> bytes:
@@ -411,7 +432,12 @@ class PPOEngine:
     def train_stats(self):
         """Means over the last epoch's minibatches of the most recent update (waits for the stream)."""
         rows = self.fetch_step_stats(self.n_minibatches)
-        m = rows.astype(np.float64).mean(axis=0) if len(rows) else np.zeros(7)
+        m = np.zeros(7)
+        if len(rows):
+            r = rows.astype(np.float64)
+            m = r.mean(axis=0)
+            ok = ~np.isnan(r[:, 6])  # a step dropped by target_kl has no gradient norm
+            m[6] = r[ok, 6].mean() if ok.any() else 0.0
         return {k: float(m[i]) for i, k in enumerate(STAT_KEYS)}
 
     def epoch_begin(self, perm=None):
@@ -428,6 +454,12 @@ class PPOEngine:
 
     def minibatch_apply(self):
         check(self.lib.mobrob_ppo_minibatch_apply(self._h))
+
+    def minibatch_apply_checked(self):
+        """minibatch_apply behind SB3's target_kl check -> True when the step was DROPPED (the driver ends train())."""
+        stopped = C.c_int32()
+        check(self.lib.mobrob_ppo_minibatch_apply_checked(self._h, C.byref(stopped)))
+        return bool(stopped.value)
 
     def fetch_step_stats(self, max_rows=None):
         max_rows = int(max_rows or (self.n_minibatches * self.cfg.n_epochs))
@@ -459,7 +491,7 @@ class PPOEngine:
                 "grads": ((self.P,), F32), "advstat": ((self.n_minibatches, 4), np.float64),
                 "last_values": ((N,), F32), "last_dones": ((N,), F32), "clipped_actions": ((N, self.A), F32), "episode_start_state": ((N,), F32),
                 "terminal_obs": ((N, 16 * ((self.D + 15) // 16) if self.D <= 64 else 8 * ((self.D + 7) // 8)), F32), "terminal_values": ((N,), F32),
-                "truncated": ((N,), np.uint8), "env_state": ((N, 12), F32)}[name]
+                "truncated": ((N,), np.uint8), "env_state": ((N, 12), F32), "grad_exchange": ((self.P + 8,), F32)}[name]
 
     def read(self, name):
         shape, dt = self._buf_shape(name)
@@ -536,6 +568,7 @@ class PPOEngine:
         check(self.lib.mobrob_ppo_profile_enable(self._h, v))
 
     def profile_read(self):
-        ms, calls = (C.c_double * 6)(), (C.c_int64 * 6)()
+        n = len(_lib.KERNEL_IDS)  # MOBROB_K_COUNT
+        ms, calls = (C.c_double * n)(), (C.c_int64 * n)()
         check(self.lib.mobrob_ppo_profile_read(self._h, ms, calls))
         return {k: (float(ms[i]), int(calls[i])) for k, i in _lib.KERNEL_IDS.items()}

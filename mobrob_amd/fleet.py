@@ -178,4 +178,5 @@ def train_fleet_data_parallel(backends, streams, group=None, force_collectives=F
                     b.minibatch_grad(mb)
                     if comm:
                         dist.all_reduce(b.grad_tensor(), op=dist.ReduceOp.SUM, group=group)
-                    b.minibatch_apply()
+                    if b.minibatch_apply():
+                        raise NotImplementedError("target_kl is not supported by the interleaved fleet update")

@@ -19,8 +19,8 @@ can be exercised WITHOUT a GPU by the world_size-2 gloo tests on a NumPy backend
     backend.epoch_begin(perm_or_None)           -> local advantage partial sums ready
     backend.advstat_tensor()                    -> torch tensor [n_mb, 4] float64 (in-place all-reduce target)
     backend.minibatch_grad(mb)                  -> local gradient of the GLOBAL-mean loss
-    backend.grad_tensor()                       -> torch tensor [P] float32 (in-place all-reduce target)
-    backend.minibatch_apply()                   -> clip_grad_norm_ + Adam
+    backend.grad_tensor()                       -> torch tensor [P (+ 8 loss sums)] float32 (in-place all-reduce target)
+    backend.minibatch_apply()                   -> clip_grad_norm_ + Adam; truthy = SB3's target_kl dropped the step
     backend.n_minibatches, backend.n_epochs
 """
 from __future__ import annotations
@@ -78,7 +78,7 @@ class EngineBackend:
         cur = torch.cuda.current_stream(self.device)
         self.stream = cur if cur.cuda_stream != 0 else torch.cuda.Stream(self.device)
         self.e.set_stream(self.stream.cuda_stream)
-        gp, gb = engine.device_buffer("grads")
+        gp, gb = engine.device_buffer("grad_exchange")  # [P] gradient + [8] loss sums: one message per optimizer step
         ap, ab = engine.device_buffer("advstat")
         self._grad = device_tensor(gp, (gb // 4,), torch.float32, self.device)
         self._adv = device_tensor(ap, (ab // 32, 4), torch.float64, self.device)
@@ -98,7 +98,8 @@ class EngineBackend:
         return self._grad
 
     def minibatch_apply(self):
-        self.e.minibatch_apply()
+        """-> True when SB3's target_kl check dropped the step (the loop ends train() on every rank alike)."""
+        return self.e.minibatch_apply_checked()
 
     # ---- the C loop ------------------------------------------------------------------------------------
     def ensure_comm(self, group=None):
@@ -106,31 +107,9 @@ class EngineBackend:
         has one; False (on every rank alike) when any rank could not create it -- the caller then runs the protocol
         loop with torch.distributed's own collectives instead of failing the job."""
         state = getattr(self, "_comm_ready", None)
-        if state is not None:
-            return state
-        ok = 1
-        try:
-            box = [self.e.comm_unique_id() if dist.get_rank(group) == 0 else None]
-        except Exception as ex:  # noqa: BLE001 - e.g. librccl not loadable from the engine
-            box, ok = [None], 0
-            self._comm_error = ex
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        if ok and box[0] is not None:
-            try:
-                self.e.comm_init(box[0])
-            except Exception as ex:  # noqa: BLE001
-                ok = 0
-                self._comm_error = ex
-        else:
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        self._comm_ready = bool(int(flag.item()))
-        if not self._comm_ready and dist.get_rank(group) == 0:
-            import warnings
-            warnings.warn("engine-owned RCCL communicator unavailable (%r): falling back to torch.distributed all-reduces "
-                          "issued from Python, one per optimizer step" % (getattr(self, "_comm_error", "another rank failed"),))
-        return self._comm_ready
+        if state is None:
+            state = self._comm_ready = agree_and_init_comm(self.e, group, self.device)
+        return state
 
     def gloo_all_reduce(self, group=None):
         """All-reduce callback for `engine.train_dp` under a CPU process group: stage through the host."""
@@ -144,11 +123,60 @@ class EngineBackend:
         return reduce_in_place
 
 
+def agree_and_init_comm(engine, group=None, device=None):
+    """The engine-owned RCCL communicator, set up so that a rank which CANNOT take part never leaves the others
+    blocked inside ncclCommInitRank:
+
+      1. every rank runs the local, non-collective half (`engine.comm_prepare`: RCCL loadable, device selectable, no
+         communicator yet; rank 0 of the group also draws the unique id) and the group size is checked against the
+         engine's minibatch split;
+      2. ONE all-reduce(MIN) of the success flags -- any failure sends every rank to the fallback before a single
+         rank has entered the blocking collective;
+      3. the id is broadcast and every rank calls ncclCommInitRank with ITS RANK IN `group` (a sub-group of the job
+         gets a communicator of its own size, not of the engine config's);
+      4. a second MIN agrees on the outcome of the collective itself.
+
+    Returns True when every rank holds a communicator, False (on every rank alike) otherwise."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ok, uid, err = 1, None, None
+    try:
+        if world != int(engine.cfg.world_size):
+            raise ValueError(f"process group of {world} ranks, but the engine splits its minibatch for world_size "
+                             f"{int(engine.cfg.world_size)}")
+        engine.comm_prepare()
+        if rank == 0:
+            uid = engine.comm_unique_id()
+    except Exception as ex:  # noqa: BLE001 - e.g. librccl not loadable from the engine, an engine that already has one
+        ok, err = 0, ex
+
+    def agree(flag):
+        t = torch.tensor([flag], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return int(t.item())
+
+    if agree(ok):
+        box = [uid]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        try:
+            engine.comm_init(box[0], rank=rank, nranks=world)
+        except Exception as ex:  # noqa: BLE001
+            ok, err = 0, ex
+        ready = bool(agree(ok))
+    else:
+        ready = False
+    if not ready and rank == 0:
+        import warnings
+        warnings.warn("engine-owned RCCL communicator unavailable (%r): falling back to torch.distributed all-reduces "
+                      "issued from Python, one per optimizer step" % (err if err is not None else "another rank failed",))
+    return ready
+
+
 def train_data_parallel(backend, perms=None, group=None, force_collectives=False, python_loop=False):
     """PPO.train() across ranks.  perms: per-epoch LOCAL permutations ([n_epochs, T*N_local]) or None.
     force_collectives issues the all-reduces even at world size 1 (plumbing self-test).  An `EngineBackend` runs the
     loop in C (RCCL under an "nccl" group, the gloo callback otherwise); other backends, or python_loop=True, run the
-    protocol loop below with torch.distributed collectives."""
+    protocol loop below with torch.distributed collectives.
+    -> (epochs started, stopped early by target_kl, optimizer steps applied), identical on every rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     comm = world > 1 or (force_collectives and dist.is_initialized())
     stream = getattr(backend, "stream", None)
@@ -156,25 +184,29 @@ def train_data_parallel(backend, perms=None, group=None, force_collectives=False
         if dist.get_backend(group) == "nccl":
             if backend.ensure_comm(group):
                 backend.e.train_dp(perms)
-            else:
-                with torch.cuda.stream(stream):
-                    _update_loop(backend, perms, group, comm)
-        else:
-            backend.e.train_dp(perms, allreduce=backend.gloo_all_reduce(group))
-    elif stream is not None:  # GPU backend, Python loop: collectives are issued with the engine's stream current
+                return backend.e.last_train_info()
+            with torch.cuda.stream(stream):
+                return _update_loop(backend, perms, group, comm)
+        backend.e.train_dp(perms, allreduce=backend.gloo_all_reduce(group))
+        return backend.e.last_train_info()
+    if stream is not None:  # GPU backend, Python loop: collectives are issued with the engine's stream current
         with torch.cuda.stream(stream):
-            _update_loop(backend, perms, group, comm)
-    else:
-        _update_loop(backend, perms, group, comm)
+            return _update_loop(backend, perms, group, comm)
+    return _update_loop(backend, perms, group, comm)
 
 
 def _update_loop(backend, perms, group, comm):
+    """-> (epochs started, stopped early by target_kl, optimizer steps applied)."""
+    applied = 0
     for ep in range(backend.n_epochs):
         backend.epoch_begin(None if perms is None else perms[ep])
         if comm:
             dist.all_reduce(backend.advstat_tensor(), op=dist.ReduceOp.SUM, group=group)
         for mb in range(backend.n_minibatches):
             backend.minibatch_grad(mb)
-            if comm:
+            if comm:  # [P] gradient + [8] loss sums: the statistics and the target_kl decision are global
                 dist.all_reduce(backend.grad_tensor(), op=dist.ReduceOp.SUM, group=group)
-            backend.minibatch_apply()
+            if backend.minibatch_apply():  # SB3's target_kl: this step and the rest of train() are dropped
+                return ep + 1, True, applied
+            applied += 1
+    return backend.n_epochs, False, applied

@@ -409,21 +409,16 @@ class PPO:
                 self.clip_range_vf = float(self.clip_vf_schedule(p))
             self.engine.set_hyper(learning_rate=self.learning_rate, clip_range=self.clip_range, clip_range_vf=self.clip_range_vf)
         if self.world_size > 1:
-            import torch
-            import torch.distributed as dist
             from ..parallel import EngineBackend, train_data_parallel
             if self._backend is None:
                 self._backend = EngineBackend(self.engine)
-            train_data_parallel(self._backend)
+            epochs, stopped, applied = train_data_parallel(self._backend)
+            # the loss sums travel with the gradient in the per-step all-reduce: every rank logs the global means
             stats = self.engine.train_stats()
-            # every rank logged local sums / B_global: the sum over ranks is the global mean (grad_norm is already global)
-            keys = [k for k in stats if k != "grad_norm"]
-            t = torch.tensor([stats[k] for k in keys], dtype=torch.float64,
-                             device=self._backend.device if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(t)
-            stats.update({k: float(v) for k, v in zip(keys, t.tolist())})
-            stats["n_minibatches"] = self.n_epochs * self.engine.n_minibatches
-            self._n_updates += self.n_epochs
+            stats["n_minibatches"] = applied
+            self._n_updates += epochs
+            if stopped and self.verbose >= 1 and self.rank == 0:
+                print(f"Early stopping at step {epochs - 1} due to reaching max kl: {stats['approx_kl']:.2f}")
         else:
             stats = self.engine.train(None)
             epochs, stopped, _ = self.engine.last_train_info()

@@ -54,13 +54,25 @@ def test_bench_fails_when_a_rank_fails():
     assert "exited with code" in r.stderr
 
 
+def test_a_rank_killed_inside_an_all_reduce_fails_the_job_and_every_child_is_reaped():
+    """MOBROB_BENCH_FAULT=1:3: rank 1 dies (os._exit, no cleanup) inside its third all-reduce while the others sit in
+    the same collective.  The launcher must come back non-zero, without a result line, with every child reaped."""
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--steps", "6", "--warmup", "1", "--dry-run-cpu"],
+                       env=_clean_env(MOBROB_BENCH_FAULT="1:3"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert "rank 1 exited with code 17" in r.stderr and "all 3 ranks reaped" in r.stderr
+    assert time.time() - t0 < 120
+
+
 def test_traffic_figure_is_tied_to_the_kernel_sources():
     sys.path.insert(0, ROOT)
     import bench
     sha = bench.csrc_sha256()
     assert len(sha) == 64 and sha == bench.csrc_sha256()
     val, note = bench.measured_traffic("void mobrob::k_fused_train<64")
-    newest = next(r for r in ("r2", "r1") if os.path.exists(os.path.join(ROOT, "profiles", r, "hbm_traffic_pmc.json")))
+    newest = next(r for r in ("r3", "r2", "r1") if os.path.exists(os.path.join(ROOT, "profiles", r, "hbm_traffic_pmc.json")))
     recorded = json.load(open(os.path.join(ROOT, "profiles", newest, "hbm_traffic_pmc.json"))).get("csrc_sha256")
     if recorded == sha:
         assert isinstance(val, int) and val > 0

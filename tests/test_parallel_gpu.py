@@ -84,6 +84,88 @@ def test_two_engine_ranks_equal_single_process_union_batch(case, tmp_path):
     assert np.max(np.abs(ref - r[0])) < 1e-4, float(np.max(np.abs(ref - r[0])))
 
 
+def _kl_worker(rank, world, port, case, out, target):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mobrob_amd.engine import PPOEngine
+    from mobrob_amd.parallel import EngineBackend, train_data_parallel
+    c = CASES[case]
+    p, buf, lv, dones, h, perms = _rank_data(c, rank)
+    H = c["H"]
+    e = PPOEngine(obs_dim=c["D"], act_dim=c["A"], n_envs=c["N"], n_steps=c["T"], batch_size=c["B"], n_epochs=c["E"],
+                  pi=(H, H), vf=(H, H), ent_coef=h.ent_coef, learning_rate=3e-3, device_id=0, rank=rank, world_size=world)
+    e.set_hyper(target_kl=target)
+    e.set_params(p)
+    e.load_rollout(buf, lv, dones)
+    be = EngineBackend(e)
+    res = {}
+    for mode in ("c_loop",):
+        e.set_params(p)
+        z = {k: np.zeros_like(v) for k, v in p.items()}
+        e.set_optimizer_state(z, z, 0)
+        info = train_data_parallel(be, perms, python_loop=(mode == "python_loop"))
+        torch.cuda.synchronize()
+        st = e.train_stats()
+        res[mode + "/flat"] = e.get_flat_params()
+        res[mode + "/info"] = np.array(info, dtype=np.int64)
+        res[mode + "/adam_step"] = e.get_optimizer_state()[2]
+        res[mode + "/stats"] = np.array([st[k] for k in ("policy_loss", "value_loss", "approx_kl", "clip_fraction", "grad_norm")])
+    np.savez(out.format(rank=rank), **res)
+    e.close()
+    dist.destroy_process_group()
+
+
+def _union_run(c, world, target, lr):
+    data = [_rank_data(c, i) for i in range(world)]
+    p = {k: v.copy() for k, v in data[0][0].items()}
+    st = O.AdamState.zeros_like(p)
+    h = O.Hyper(n_epochs=c["E"], batch_size=c["B"], ent_coef=0.01, learning_rate=lr, target_kl=target)
+    bl, total, rows = c["B"] // world, c["T"] * c["N"], []
+    for ep in range(c["E"]):
+        rows_ep = []
+        for mb in range(-(-total // bl)):
+            parts = [O.gather_minibatch(data[i][1], data[i][5][ep][mb * bl:(mb + 1) * bl]) for i in range(world)]
+            batch = tuple(np.concatenate([parts[i][j] for i in range(world)]) for j in range(6))
+            s = O.train_minibatch(p, st, batch, h)
+            rows_ep.append(s)
+            rows.append(s)
+            if s.get("early_stop"):
+                return p, st, rows, rows_ep, ep + 1
+    return p, st, rows, rows_ep, c["E"]
+
+
+@pytest.mark.parametrize("case", ["h256", "h64"])
+def test_target_kl_and_logged_statistics_are_global_under_data_parallel(case, tmp_path):
+    """SB3's target_kl with two ranks: the approx_kl sum travels with the gradient, so both ranks stop at the step at
+    which single-process SB3 arithmetic on the UNION minibatch stops, and the logged statistics are the union's."""
+    import torch.multiprocessing as mp
+    c, world = CASES[case], 2
+    _, _, rows, _, _ = _union_run(c, world, None, 3e-3)
+    kls = [float(r["approx_kl"]) for r in rows]
+    first = next(i for i in range(2, len(kls)) if kls[i] > 1.2 * max(kls[:i]))
+    target = (max(kls[:first]) + kls[first]) / 2 / 1.5
+    p_ref, st_ref, rows, rows_ep, epochs = _union_run(c, world, target, 3e-3)
+    assert st_ref.step == first and len(rows) == first + 1
+    out = str(tmp_path / "kl{rank}.npz")
+    mp.spawn(_kl_worker, args=(world, _free_port(), case, out, target), nprocs=world, join=True)
+    r = [np.load(out.format(rank=i)) for i in range(world)]
+    ref = O.flatten_params(p_ref)
+    for mode in ("c_loop",):
+        for i in range(world):
+            assert r[i][mode + "/info"].tolist() == [epochs, 1, first], (mode, r[i][mode + "/info"])
+            assert int(r[i][mode + "/adam_step"]) == first
+        assert np.array_equal(r[0][mode + "/flat"], r[1][mode + "/flat"])
+        assert np.max(np.abs(ref - r[0][mode + "/flat"])) < 1e-4
+        # statistics of the last epoch that ran: union-batch values on BOTH ranks (the dropped step has no grad norm)
+        want = [np.mean([float(s[k]) for s in rows_ep]) for k in ("policy_loss", "value_loss", "approx_kl", "clip_fraction")]
+        want.append(np.mean([float(s["grad_norm"]) for s in rows_ep if not s.get("early_stop")]) if len(rows_ep) > 1 else 0.0)
+        for i in range(world):
+            got = r[i][mode + "/stats"]
+            assert np.allclose(got, want, rtol=2e-3, atol=2e-4), (mode, i, got, want)
+
+
 def _learn_worker(rank, world, port, out):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -135,7 +217,7 @@ class _NoComm:
     def __getattr__(self, name):
         return getattr(self._e, name)
 
-    def comm_init(self, uid):
+    def comm_init(self, uid, rank=None, nranks=None):
         raise RuntimeError("ncclCommInitRank failed (simulated)")
 
 
@@ -177,6 +259,25 @@ def _rccl_world1_worker(rank, world, port, out):
                 train_data_parallel(be, perms, force_collectives=True, python_loop=(mode == "python_torch"))
             torch.cuda.synchronize()
             res[f"{case}/{mode}"] = e.get_flat_params()
+            if mode == "c_rccl":   # ncclCommCount / ncclCommUserRank of the engine's own communicator, and the C loop's counters
+                assert e.comm_info() == (1, 0)
+                nmb = e.n_minibatches
+                assert e.last_train_info() == (c["E"], False, c["E"] * nmb)
+                calls, nbytes = e.allreduce_counters(reset=True)
+                assert calls == c["E"] * (nmb + 1) and nbytes == c["E"] * (nmb * (e.P + 8) * 4 + nmb * 32)
+        # SB3's target_kl through all three drivers: same stop step, same bits
+        e.set_hyper(target_kl=1e-7, learning_rate=3e-3)     # far below any minibatch's approx_kl after the first step
+        for mode in ("single", "c_rccl", "python_torch"):
+            e.set_params(p)
+            e.set_optimizer_state(z, z, 0)
+            if mode == "single":
+                e.train(perms)
+                info = e.last_train_info()
+            else:
+                info = train_data_parallel(be, perms, force_collectives=True, python_loop=(mode == "python_torch"))
+            torch.cuda.synchronize()
+            res[f"{case}/kl/{mode}"] = e.get_flat_params()
+            res[f"{case}/kl/{mode}/info"] = np.array(info, dtype=np.int64)
         e.close()
     np.savez(out, **res)
     dist.destroy_process_group()
@@ -191,3 +292,8 @@ def test_c_loop_with_rccl_equals_the_single_rank_call(tmp_path):
         assert np.array_equal(r[f"{case}/c_rccl"], r[f"{case}/single"]), case
         assert np.array_equal(r[f"{case}/python_torch"], r[f"{case}/single"]), case
         assert np.array_equal(r[f"{case}/no_comm"], r[f"{case}/single"]), case   # fallback when the communicator is unavailable
+        info = r[f"{case}/kl/single/info"].tolist()
+        assert info[1] == 1 and 1 <= info[2] < 8, info         # the first step has approx_kl == 0 and is always applied
+        for mode in ("c_rccl", "python_torch"):
+            assert r[f"{case}/kl/{mode}/info"].tolist() == info, (case, mode)
+            assert np.array_equal(r[f"{case}/kl/{mode}"], r[f"{case}/kl/single"]), (case, mode)
