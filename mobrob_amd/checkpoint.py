@@ -144,17 +144,36 @@ class _BoxStandIn:
         self.__dict__.update(state)
 
 
+# Exactly the globals the blobs of an SB3 2.0.0 checkpoint reference (listed from the five reference zips with
+# pickletools) plus what this module's own writer emits: array / dtype / scalar reconstructors, the PCG64 generator state
+# a gymnasium Box carries, the deque of Monitor records.  Nothing else resolves -- in particular none of numpy's file or
+# nested-pickle entry points (numpy.load / save / fromfile ...), which a "numpy.*" prefix rule would let a crafted blob
+# REDUCE into.
+_ALLOWED_GLOBALS = {
+    ("numpy", "dtype"), ("numpy", "ndarray"),
+    ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    ("numpy.random._pickle", "__generator_ctor"), ("numpy.random._pickle", "__bit_generator_ctor"),
+    ("numpy.random._pickle", "__randomstate_ctor"),
+    ("numpy.random._pcg64", "PCG64"), ("numpy.random._generator", "Generator"),
+    ("numpy.random.bit_generator", "SeedSequence"), ("numpy.random._mt19937", "MT19937"),
+    ("collections", "deque"), ("collections", "OrderedDict"),
+}
+
+
 class _SpaceUnpickler(pickle.Unpickler):
-    """Restricted: only NumPy's array / dtype / random-generator reconstructors and the Box stand-in."""
+    """Restricted unpickler for EVERY blob of a checkpoint's `data` JSON: an exact (module, name) allow-list and the Box
+    stand-in.  Blobs that need anything else (SB3's cloudpickled schedules, `policy_class`) are not decoded at all."""
 
     def find_class(self, module, name):
         if (module, name) == ("gymnasium.spaces.box", "Box"):
             return _BoxStandIn
-        if module == "numpy" or module.startswith(("numpy.core", "numpy._core", "numpy.random")):
+        if (module, name) in _ALLOWED_GLOBALS:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 return super().find_class(module, name)
-        raise pickle.UnpicklingError(f"{module}.{name} is not allowed in a space blob")
+        raise pickle.UnpicklingError(f"{module}.{name} is not allowed in a checkpoint blob")
 
 
 def unpickle_box(entry) -> dict:
@@ -167,9 +186,11 @@ def unpickle_box(entry) -> dict:
 
 
 def _unblob(entry):
+    """`_last_obs`, `_last_episode_starts`, `ep_info_buffer` ...: arrays and deques of plain records, through the same
+    allow-list as the spaces (a checkpoint is not trusted more in one entry than in another)."""
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return pickle.loads(base64.b64decode(entry[":serialized:"]))
+        return _SpaceUnpickler(io.BytesIO(base64.b64decode(entry[":serialized:"]))).load()
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -1450,8 +1450,7 @@ int mobrob_ppo_episode_records(mobrob_ppo_engine_t* e, float* out, int32_t max_r
   if (written - first > (uint64_t)max_records) first = written - max_records;   // the caller wants the newest
   int n = 0;
   for (uint64_t k = first; k < written; ++k, ++n) {
-    out[2 * n] = (float)h[5 + 2 * (k % kEpRing)];
-    out[2 * n + 1] = (float)h[6 + 2 * (k % kEpRing)];
+    memcpy(&out[2 * n], &h[5 + k % kEpRing], 2 * sizeof(float));  // one 64-bit record = (return, length) as two floats
   }
   e->ep_ring_read = written;
   return n;

@@ -36,7 +36,8 @@ typedef struct mobrob_hostenv {
   /* Monitor statistics since the last read */
   int64_t episodes, goals;
   int64_t ring_written, ring_read;   /* Monitor ring: (return, length) of the last EP_RING finished episodes */
-  double ring[2 * 128];
+  uint64_t ring[128];                /* one 64-bit word per record (two floats): written with ONE store, so records of
+                                        two threads that wrap onto the same slot replace each other but never mix */
   double ret_sum, len_sum;
 } mobrob_hostenv;
 
@@ -225,8 +226,13 @@ int32_t mobrob_hostenv_step_range(mobrob_hostenv* e, int32_t i0, int32_t i1, con
         int64_t k;
 #pragma omp atomic capture
         k = e->ring_written++;
-        e->ring[2 * (k % 128)] = s->ep_ret;
-        e->ring[2 * (k % 128) + 1] = (double)s->ep_len;
+        {
+          const float rl[2] = {(float)s->ep_ret, (float)s->ep_len};
+          uint64_t rec;
+          memcpy(&rec, rl, sizeof rec);
+#pragma omp atomic write
+          e->ring[k % 128] = rec;
+        }
       }
       reset_env(e, s, reached);
     }
@@ -259,8 +265,10 @@ int32_t mobrob_hostenv_episode_records(mobrob_hostenv* e, double* out, int32_t m
   if (e->ring_written - first > max_records) first = e->ring_written - max_records;
   int32_t n = 0;
   for (int64_t k = first; k < e->ring_written; ++k, ++n) {
-    out[2 * n] = e->ring[2 * (k % 128)];
-    out[2 * n + 1] = e->ring[2 * (k % 128) + 1];
+    float rl[2];
+    memcpy(rl, &e->ring[k % 128], sizeof rl);
+    out[2 * n] = rl[0];
+    out[2 * n + 1] = rl[1];
   }
   e->ring_read = e->ring_written;
   return n;

@@ -28,14 +28,19 @@ struct GoalEnvParams {
   float mix[3][32];          // velocity command = mix . clip(action)
 };
 
-// Monitor ring: the last kEpRing finished episodes (return, length) in completion order.  ep_stats[4] counts the
-// records ever written (a double, like its neighbours: one atomic per finished episode), slot = count mod kEpRing.
+// Monitor ring: (return, length) of finished episodes.  ep_stats[4] counts the records ever written (a double, like its
+// neighbours: one atomic per finished episode), slot = count mod kEpRing.  A record is ONE 64-bit word (two floats) and
+// goes out as one 8-byte store: a rollout finishes far more than kEpRing episodes, so pushes k and k + kEpRing land on the
+// same slot from different workgroups -- with one store per record they can replace each other but never pair one
+// episode's return with another's length.  Slot order is the order of the atomics across independently running
+// workgroups, i.e. the ring is a SAMPLE of recently finished episodes (all envs, roughly the last ones), not SB3's
+// strictly newest-100 deque.
 constexpr int kEpRing = 128;
-constexpr int kEpStatsDoubles = 5 + 2 * kEpRing;
+constexpr int kEpStatsDoubles = 5 + kEpRing;
 __device__ __forceinline__ void ep_ring_push(double* ep_stats, float ep_ret, float ep_len) {
   const unsigned slot = (unsigned)((unsigned long long)atomicAdd(&ep_stats[4], 1.0) % (unsigned)kEpRing);
-  ep_stats[5 + 2 * slot] = (double)ep_ret;
-  ep_stats[6 + 2 * slot] = (double)ep_len;
+  const unsigned long long rec = (unsigned long long)__float_as_uint(ep_ret) | ((unsigned long long)__float_as_uint(ep_len) << 32);
+  reinterpret_cast<unsigned long long*>(ep_stats)[5 + slot] = rec;
 }
 
 struct GoalEnvArgs {
@@ -47,7 +52,7 @@ struct GoalEnvArgs {
   float* obs_next; float* term_obs;
   const float* prev_dones; float* next_dones; uint8_t* trunc; float* rew_out; float* es_out;
   double* ep_stats;                    // [4] finished episodes, sum of returns, sum of lengths, goals reached;
-                                       // then the Monitor ring: [4] records written so far, [5 + 2k] return / length
+                                       // then the Monitor ring: [4] records written so far, [5 + k] = (return, length) as two floats
 };
 
 struct GoalState {

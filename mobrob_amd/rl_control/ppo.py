@@ -601,7 +601,10 @@ class PPOCtrl:
                 import functools
                 from ..envs.shm_vec_env import usable_cores
                 world, _, _ = distributed_context(init=False)
-                cls = functools.partial(SubprocVecEnv, n_workers=max(1, usable_cores() // max(1, world)))
+                # MOBROB_ENV_WORKERS overrides the one-worker-per-usable-core default; either way the
+                # ranks of a data-parallel job on one node share the host cores
+                workers = int(os.environ.get("MOBROB_ENV_WORKERS", 0) or usable_cores())
+                cls = functools.partial(SubprocVecEnv, n_workers=max(1, workers // max(1, world)))
             vec_env = make_vec_env(get_env, n_envs=n_env,
                                    env_kwargs={"env_name": env_name, "enable_gui": enable_gui,
                                                "terminate_on_goal": True, "time_limit": time_limit},

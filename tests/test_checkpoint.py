@@ -139,3 +139,33 @@ def test_zip_keeps_the_observation_bounds_of_the_robot(tmp_path):
 
 def test_ndarray_pickle_round_trip():
     assert pickle.loads(ck.pickle_ndarray(np.array([[1.5, 2.5]], np.float32))).tolist() == [[1.5, 2.5]]
+
+
+def test_checkpoint_blobs_resolve_only_an_exact_allow_list():
+    """A blob may name only the reconstructors SB3 checkpoints really use: `numpy.load`, `numpy.save`, `os.system` ... do
+    not resolve, whichever entry of the zip carries them (spaces and `_last_obs`-style blobs go through the same unpickler)."""
+    import base64
+    import pickle
+    from mobrob_amd import checkpoint as ck
+
+    class _Evil:
+        def __init__(self, fn, *args):
+            self.fn, self.args = fn, args
+
+        def __reduce__(self):
+            return self.fn, self.args
+
+    import os as _os
+    for fn, args in ((np.load, ("/etc/passwd",)), (np.save, ("/tmp/x", 1)), (np.fromfile, ("/etc/passwd",)), (_os.system, ("true",))):
+        blob = pickle.dumps(_Evil(fn, *args))
+        entry = {":serialized:": base64.b64encode(blob).decode()}
+        with pytest.raises(pickle.UnpicklingError):
+            ck.unpickle_box(entry)
+        with pytest.raises(pickle.UnpicklingError):
+            ck._unblob(entry)
+    # what the reference zips do contain still decodes: arrays, deques of Monitor records
+    from collections import deque
+    ok = {":serialized:": base64.b64encode(pickle.dumps(deque([{"r": 1.5, "l": 7, "t": 0.1}], maxlen=100))).decode()}
+    assert list(ck._unblob(ok)) == [{"r": 1.5, "l": 7, "t": 0.1}]
+    arr = {":serialized:": base64.b64encode(pickle.dumps(np.arange(6, dtype=np.float32).reshape(2, 3))).decode()}
+    assert ck._unblob(arr).tolist() == [[0.0, 1.0, 2.0], [3.0, 4.0, 5.0]]

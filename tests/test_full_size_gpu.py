@@ -173,6 +173,9 @@ def _check_grad(e, p, buf, idx, h, mb, tag):
     lo, hi = 1.0 - h.clip_range, 1.0 + h.clip_range
     near = (np.abs(aux["ratio"] - lo) < 2e-5) | (np.abs(aux["ratio"] - hi) < 2e-5)
     if near.any():
+        # the test adapts its own input here: keep that to the handful of rows the argument above predicts (a 4e-5-wide
+        # band around two boundaries holds ~1e-4 of the rows of a minibatch whose ratios spread over ~0.5)
+        assert int(near.sum()) <= 16, f"{tag}: {int(near.sum())} rows within 2e-5 of a clip boundary -- not a rounding artefact"
         t, n = O.flat_to_tn(idx[near], buf["rewards"].shape[0])
         buf["log_probs"][t, n] -= np.float32(0.01)
         e.write("log_probs", buf["log_probs"])

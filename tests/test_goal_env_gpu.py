@@ -160,6 +160,11 @@ def test_policy_trained_on_the_device_env_solves_the_host_env(tmp_path, monkeypa
         lengths.append(t + 1)
     assert reached >= 10, (reached, lengths)          # an untrained policy reaches ~40 % of the goals within 200 steps
     assert np.mean(lengths) < 120, lengths
+    # the evaluation script itself (examples/control.py, the reference's protocol: 1000 steps per epoch, reset and go on at
+    # every goal): a policy that reaches a goal in < 120 steps collects >= 8 arrival bonuses of +5 per epoch
+    from tests.test_control_cli import _load_script
+    rewards = _load_script().simulate("point", "ppo", epochs=2)
+    assert len(rewards) == 2 and min(rewards) > 30.0, rewards
 
 
 def test_ppo_learns_with_the_native_host_env_through_pinned_staging():
