@@ -78,11 +78,8 @@ typedef struct mobrob_ppo_config {
   int32_t rollout_graph;      /* 1: the per-step device rollout (2 launches per step) is replayed as one
                                  captured hipGraph; the persistent rollout needs no graph          */
   int32_t rollout_persistent; /* 1: run the device-resident rollout as one persistent kernel (fused widths) */
-  int32_t persistent_train;   /* 1: 64-wide nets with minibatches of <= 128 rows (the reference YAML shapes) run each
-                                 epoch of PPO.train() as ONE persistent launch of two workgroups
-                                 (kernels_train_small.h): bit-identical to the per-step path, measured SLOWER
-                                 (85-92 us per optimizer step against 24: DESIGN.md 4.1c / 4.1d), hence 0 by default */
-  int32_t reserved[4];
+  int32_t reserved[5];        /* zero ([0] used to select a persistent small-batch update kernel that lost to the per-step
+                                 path and now lives in scratch/kernels_train_small.h) */
 } mobrob_ppo_config_t;
 
 /* Fill `cfg` with SB3 2.0.0 defaults (Appendix A.1).  Replaces PPO.__init__'s default kwargs. */

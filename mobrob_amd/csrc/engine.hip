@@ -140,12 +140,6 @@ struct mobrob_ppo_engine {
   int rollout64_tile_max = 256;  // rollouts of up to this many 32-env tiles use k_rollout64_tile (MOBROB_ROLLOUT64_TILE_MAX)
   int pair64_min_tiles = 65;     // minibatches of at least this many tiles use k_pair64_train (MOBROB_PAIR64_MIN_TILES; 0: never)
   int split64_max_tiles = 64;  // minibatches of up to this many 32-row tiles use k_split64_train (MOBROB_SPLIT64_MAX_TILES)
-  // persistent small-batch update (kernels_train_small.h): one launch per epoch for 64-wide nets, minibatch <= 160 rows
-  float* sched_dev = nullptr;              // [nmb][2] per-step Adam scalars of the epoch being enqueued
-  unsigned long long* mail = nullptr;      // [2][2][16] hand-off words of the two workgroups
-  int* small_err = nullptr;                // raised by the kernel when a hand-off times out
-  std::vector<float> sched_host;           // [n_epochs][nmb][2], kept alive until the copies have run
-  unsigned long long small_steps = 0;      // optimizer steps ever enqueued through the persistent kernel (hand-off ids)
   // generic-path workspace
   float *Xg = nullptr, *actg = nullptr, *lpg = nullptr, *advg = nullptr, *retg = nullptr, *oldvg = nullptr;
   float *h1p = nullptr, *h2p = nullptr, *h1v = nullptr, *h2v = nullptr, *mu = nullptr, *vout = nullptr;
@@ -610,7 +604,6 @@ void mobrob_ppo_default_config(mobrob_ppo_config_t* c) {
   c->normalize_advantage = 1; c->seed = 0; c->device_id = 0; c->rank = 0; c->world_size = 1; c->fast_kernels = 1;
   c->rollout_graph = 1;
   c->rollout_persistent = 1;
-  c->persistent_train = 0;  // opt-in: see kernels_train_small.h (bit-identical, but two CUs lose to four wide launches)
 }
 
 void* mobrob_ppo_host_alloc(size_t bytes) {
@@ -693,9 +686,6 @@ int engine_alloc(mobrob_ppo_engine* e) {
   CHK(dalloc(e, &e->trunc_dev, N)); CHK(dalloc(e, &e->dones_u8, N)); CHK(dalloc(e, &e->ep_len, N)); CHK(dalloc(e, &e->ep_len2, N)); CHK(dalloc(e, &e->ctr_dev, 2));
   CHK(dalloc(e, &e->rows, T * N)); CHK(dalloc(e, &e->perm_dev, T * N)); CHK(dalloc(e, &e->advstat, (size_t)e->nmb * 4)); CHK(dalloc(e, &e->advpart, (size_t)e->nmb * kAdvParts * 2));
   CHK(dalloc(e, &e->stats, (size_t)e->stats_cap * 8));
-  CHK(dalloc(e, &e->sched_dev, (size_t)2 * e->nmb * std::max(1, e->cfg.n_epochs)));
-  CHK(dalloc(e, &e->mail, 64));
-  CHK(dalloc(e, &e->small_err, 4));
   CHK(dalloc(e, &e->Xg, Bl * Dp)); CHK(dalloc(e, &e->actg, Bl * A)); CHK(dalloc(e, &e->lpg, Bl));
   CHK(dalloc(e, &e->advg, Bl)); CHK(dalloc(e, &e->retg, Bl)); CHK(dalloc(e, &e->oldvg, Bl));
   CHK(dalloc(e, &e->h1p, R * e->H1)); CHK(dalloc(e, &e->h2p, R * e->H2)); CHK(dalloc(e, &e->h1v, R * e->G1));
@@ -1750,57 +1740,10 @@ int mobrob_ppo_fetch_step_stats(mobrob_ppo_engine_t* e, float* out, int32_t max_
   if (n > 0) {
     HIPC(hipMemcpyAsync(out, e->stats + (size_t)(e->stats_n - n) * 8, (size_t)n * 32, hipMemcpyDeviceToHost, e->stream));
   }
-  int small_err = 0;
-  HIPC(hipMemcpyAsync(&small_err, e->small_err, sizeof small_err, hipMemcpyDeviceToHost, e->stream));
   HIPC(hipStreamSynchronize(e->stream));
   e->stats_n = 0;
-  if (small_err != 0) {
-    (void)hipMemsetAsync(e->small_err, 0, sizeof(int), e->stream);
-    return fail(MOBROB_ERR_HIP, "persistent update kernel: a hand-off between its two workgroups timed out");
-  }
   return n;
 }
-
-namespace {
-// One launch per epoch instead of four per optimizer step: 64-wide nets, single rank, a minibatch of at most one
-// 32-row tile per wave (the bit-identity condition of kernels_train_small.h), and enough steps to be worth it.
-bool train_small_ok(const mobrob_ppo_engine* e) {
-  if (!e->fused.enabled || e->fused.H != 64 || e->cfg.world_size != 1 || e->cfg.persistent_train == 0) return false;
-  // <= one tile per wave, and at most one tile beyond the first block of the per-step path: then both paths add the
-  // tiles of a minibatch in the same order ((t0 + t1 + ...) + t_last) and stay bit-identical
-  const int ntiles = cdiv(e->Bl, GR);
-  return ntiles >= 2 && ntiles <= train_small_max_waves(e->Dp) && ntiles <= g_train_waves(e->Dp) + 1 && e->nmb >= 2 &&
-         e->nmb <= e->stats_cap && e->nchunks <= 16;
-}
-int train_small_epoch(mobrob_ppo_engine* e, int ep) {
-  FusedState& f = e->fused;
-  ProfScope ps(e, MOBROB_K_TRAIN_GRAD);
-  TrainSmallArgs a{};
-  Fused64TrainArgs& t = a.t;
-  t.net[0] = f.net[0]; t.net[1] = f.net[1];
-  t.wpack[0] = reinterpret_cast<const float*>(f.net[0].W1f);
-  t.wpack[1] = reinterpret_cast<const float*>(f.net[1].W1f);
-  t.obs = e->obs; t.actions = e->actions; t.A = e->A; t.old_logp = e->logp; t.adv = e->adv; t.ret = e->ret;
-  t.log_std = e->params + e->offs[T_LOGSTD]; t.normalize = e->cfg.normalize_advantage;
-  t.clip = (float)e->cfg.clip_range; t.vf_coef = (float)e->cfg.vf_coef; t.ent_coef = (float)e->cfg.ent_coef;
-  t.clip_vf = (float)e->clip_vf; t.old_values = e->values;
-  a.rows = e->rows; a.total = e->N * e->T; a.Bl = e->Bl; a.nmb = e->nmb; a.nw = cdiv(e->Bl, GR);
-  a.advstat = e->advstat;
-  fill_adam_pack_args(e, a.pk);
-  a.pk.g_out = e->grads;
-  a.pk.stats_row = nullptr; a.pk.loss_sums_zero = nullptr;
-  a.chunks = e->chunks_dev; a.nchunks = e->nchunks;
-  a.sched = e->sched_dev + (size_t)2 * e->nmb * ep;
-  a.stats = e->stats;
-  a.mail = e->mail; a.step0 = e->small_steps + 1; a.error = e->small_err;
-  train_small_launch(f, a, e->stream);
-  HIPC(hipGetLastError());
-  e->small_steps += (unsigned long long)e->nmb;
-  e->adam_step += e->nmb;
-  e->stats_n = e->nmb;
-  return MOBROB_OK;
-}
-}  // namespace
 
 }  // extern "C"
 // ---- data parallel: the whole update loop in C, one RCCL all-reduce per optimizer step on the engine's stream ----
@@ -1865,17 +1808,6 @@ int train_loop(mobrob_ppo_engine* e, const int64_t* perms, bool dp, mobrob_allre
   e->stats_n = 0;
   const bool kl = e->target_kl > 0.0;
   e->last_epochs_started = 0; e->last_stopped_early = 0; e->last_steps_applied = 0;
-  const bool small = !dp && train_small_ok(e) && !kl;
-  if (small) {  // Adam's bias corrections of every step of this call, in float64 on the host like the per-step path
-    e->sched_host.resize((size_t)2 * e->nmb * e->cfg.n_epochs);
-    const double b1 = e->cfg.adam_beta1, b2 = e->cfg.adam_beta2;
-    for (size_t k = 0; k < (size_t)e->nmb * e->cfg.n_epochs; ++k) {
-      const double step = (double)(e->adam_step + 1 + (int64_t)k);
-      e->sched_host[2 * k] = (float)(e->cfg.learning_rate / (1.0 - std::pow(b1, step)));
-      e->sched_host[2 * k + 1] = (float)std::sqrt(1.0 - std::pow(b2, step));
-    }
-    HIPC(hipMemcpyAsync(e->sched_dev, e->sched_host.data(), e->sched_host.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
-  }
   // 64-wide nets only: ~90 records.  At 2x256 the table has 712 records, every k_adam_pack block pays for folding
   // them and the reduction kernel for forming them: measured 12.9 instead of 11.4 ms per iteration (A/B on one box).
   // Never under data parallel: the records are norms of the LOCAL gradient, the clip needs those of the summed one.
@@ -1888,12 +1820,6 @@ int train_loop(mobrob_ppo_engine* e, const int64_t* perms, bool dp, mobrob_allre
     CHK(mobrob_ppo_epoch_begin(e, perms ? perms + (size_t)ep * total : nullptr));
     // per-minibatch (sum, sum of squares, count) of the advantages: global statistics for the normalisation
     if (dp) CHK(dp_all_reduce(e, e->advstat, (size_t)e->nmb * 4, 1, fn, ctx));
-    if (small) {
-      CHK(train_small_epoch(e, ep));
-      e->last_epochs_started = ep + 1;
-      e->last_steps_applied += e->nmb;
-      continue;
-    }
     e->last_epochs_started = ep + 1;
     if (ep == e->cfg.n_epochs - 1 || kl) e->stats_n = 0;  // the rows kept are those of the last epoch that ran
     for (int mb = 0; mb < e->nmb && !e->last_stopped_early; ++mb) {

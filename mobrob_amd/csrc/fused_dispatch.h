@@ -3,7 +3,6 @@
 #include "kernels_fused.h"
 #include "kernels_fused64.h"
 #include "kernels_rollout.h"
-#include "kernels_train_small.h"
 #include "kernels_split64.h"
 #include "kernels_pair64.h"
 
@@ -57,10 +56,6 @@ inline void pair64_launch_train(FusedState& f, Fused64TrainArgs& a, int nseq, hi
   const int grid = 16 * ((nbseq + 7) / 8);
   FUSED_DISPATCH_DP(f.Dp, FUSED64_DISPATCH_NJ(f.A, hipLaunchKernelGGL((k_pair64_train<DPc, NJc>), dim3(grid), dim3(256), pair64_lds_bytes(f.Dp), st, a, nseq)));
 }
-inline void train_small_launch(FusedState& f, TrainSmallArgs& a, hipStream_t st) {
-  const int threads = std::max(a.nw, 4) * 64;  // the norm reduction runs on 256 threads like k_sqnorm_chunks
-  FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_train_small<DPc>), dim3(2), dim3(threads), train_small_lds_bytes(f.Dp, a.nw), st, a));
-}
 inline hipError_t fused_set_lds_attr(FusedState& f) {
   hipError_t e = hipSuccess;
   if (f.H == 64) {
@@ -72,9 +67,6 @@ inline hipError_t fused_set_lds_attr(FusedState& f) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout64_persistent<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rollout64_lds_bytes(f.Dp));
       if (e == hipSuccess)
         FUSED64_DISPATCH_NJ(f.A, e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair64_train<DPc, NJc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair64_lds_bytes(f.Dp)));
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_small<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)train_small_lds_bytes(f.Dp, train_small_max_waves(f.Dp)));
     });
   } else {
     FUSED_DISPATCH_DP(f.Dp, {

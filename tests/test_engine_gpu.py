@@ -775,57 +775,6 @@ def test_fused_gradients_are_run_to_run_deterministic():
 
 
 # ------------------------------------------------------------------------------------------------
-# persistent small-batch update (kernels_train_small.h): the reference's own shapes, one launch per epoch
-# ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("cfg", [dict(D=58, A=12, T=100, N=16, B=100, E=3),    # data/configs/doggo-ppo.yaml shape (shorter rollout)
-                                 dict(D=14, A=2, T=450, N=2, B=100, E=2),      # point-ppo.yaml: 2 envs
-                                 dict(D=58, A=12, T=70, N=15, B=100, E=2),     # 1050 rows: short last minibatch (50 rows)
-                                 dict(D=43, A=2, T=40, N=16, B=128, E=2),      # turtlebot3 (DP=48), 4 full tile waves
-                                 dict(D=14, A=2, T=100, N=8, B=160, E=2),      # point (DP=16): 5 tile waves
-                                 dict(D=26, A=2, T=64, N=4, B=64, E=2),        # car (DP=32), SB3's default batch: 2 tile waves
-                                 dict(D=12, A=18, T=50, N=16, B=100, E=2)])    # drone: 18 actions (head > 16)
-def test_persistent_small_batch_update_is_bit_identical_to_the_per_step_path(cfg):
-    """One launch per epoch (two co-operating workgroups, in-kernel clip + Adam) against four launches per optimizer
-    step: parameters, both Adam moments, the step counter and every logged statistic must be the same BITS; and both
-    agree with the oracle."""
-    D, A, T, N, B, E = (cfg[k] for k in "DATNBE")
-    H = 64
-    rng = np.random.default_rng(5)
-    p0 = O.init_params(D, A, (H, H), (H, H), seed=8)
-    p0["log_std"] = rng.normal(-0.2, 0.2, A).astype(np.float32)
-    p0["action_net.weight"] *= 20
-    buf, lv, dones = _consistent_rollout(p0, T, N, D, A, seed=4)
-    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=E, batch_size=B, learning_rate=3e-4)
-    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, h.gamma, h.gae_lambda)
-    perms = np.stack([rng.permutation(T * N) for _ in range(E)])
-    m0 = {k: rng.normal(0, 1e-3, v.shape).astype(np.float32) for k, v in p0.items()}
-    v0 = {k: (1e-6 * (0.5 + rng.random(v.shape))).astype(np.float32) for k, v in p0.items()}
-    out = {}
-    for persistent in (True, False):
-        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H),
-                        ent_coef=h.ent_coef, learning_rate=h.learning_rate, persistent_train=persistent)
-        e.set_params(p0)
-        e.set_optimizer_state(m0, v0, 37)
-        e.load_rollout(buf, lv, dones)
-        stats = e.train(perms)
-        out[persistent] = (e.get_flat_params(), e.get_optimizer_state(), stats)
-        e.train(perms)                      # a second call continues the hand-off ids and the Adam schedule
-        out[persistent] += (e.get_flat_params(),)
-        e.close()
-    (pa, (ma, va, sa), sta, pa2), (pb, (mb_, vb, sb), stb, pb2) = out[True], out[False]
-    assert sa == sb == 37 + E * (-(-T * N // B))
-    assert np.array_equal(pa, pb) and np.array_equal(pa2, pb2)
-    for k in ma:
-        assert np.array_equal(ma[k], mb_[k]) and np.array_equal(va[k], vb[k]), k
-    assert sta == stb, (sta, stb)
-    p = {k: v.copy() for k, v in p0.items()}
-    st = O.AdamState(type(p0)((k, v.copy()) for k, v in m0.items()), type(p0)((k, v.copy()) for k, v in v0.items()), 37)
-    O.train(p, st, buf, h, perms)
-    ref = O.flatten_params(p)
-    assert np.max(np.abs(pa - ref)) < 1e-4, float(np.max(np.abs(pa - ref)))
-
-
-# ------------------------------------------------------------------------------------------------
 # one workgroup per tile for small minibatches (kernels_split64.h) against the one-wave-per-tile block kernel
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cfg", [dict(D=58, A=12, T=100, N=16, B=100, E=2),    # data/configs/doggo-ppo.yaml: four tiles
