@@ -267,6 +267,22 @@ int mobrob_ppo_comm_destroy(mobrob_ppo_engine_t* e);
 /* SB3's target_kl works under data parallel too: the minibatch's approx_kl sum travels with the gradient (the message
  * is [P + 8] floats: gradient + loss sums), every rank reads the same global value and stops at the same step. */
 int mobrob_ppo_train_dp(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_allreduce_fn fn, void* ctx);
+/* ---- one-shot all-reduce over peer-mapped memory (opt-in; RCCL stays the default) ------------------------------------
+ * The gradient message of a PPO step is 645 KB: latency-bound on the xGMI mesh, where a direct exchange (every rank
+ * reads every peer's contribution and adds them up itself, IN RANK ORDER -> the same bits on every rank, deterministic
+ * run to run) beats a ring.  Every rank exports an exchange buffer with hipIpcGetMemHandle; the handles travel over any
+ * side channel; every rank opens the others' (hipIpcOpenMemHandle: over xGMI between GPUs, the same physical memory for
+ * two ranks that share a device).  Afterwards train_dp(fn == NULL) exchanges through it instead of RCCL: one launch per
+ * message, per-16-KB-chunk sequence flags with system-scope release / acquire (csrc/oneshot_allreduce.h).  A peer that
+ * never publishes raises an error at the next synchronising call (MOBROB_ONESHOT_TIMEOUT_MS, default 20 s) instead of
+ * hanging the device.
+ *   oneshot_export  allocate the exchange buffer (once) and write its IPC handle (MOBROB_IPC_HANDLE_BYTES bytes)
+ *   oneshot_open    handles = [nranks][MOBROB_IPC_HANDLE_BYTES] in rank order (the own entry is ignored)
+ *   oneshot_close   unmap the peers, free the buffer (also done by destroy) */
+#define MOBROB_IPC_HANDLE_BYTES 64
+int mobrob_ppo_oneshot_export(mobrob_ppo_engine_t* e, uint8_t* handle64);
+int mobrob_ppo_oneshot_open(mobrob_ppo_engine_t* e, const uint8_t* handles, int32_t rank, int32_t nranks);
+int mobrob_ppo_oneshot_close(mobrob_ppo_engine_t* e);
 /* all-reduces issued by train_dp since the last reset: how many, and their payload bytes (bench: allreduces_per_step) */
 int mobrob_ppo_allreduce_counters(mobrob_ppo_engine_t* e, int64_t* calls, int64_t* bytes, int32_t reset);
 

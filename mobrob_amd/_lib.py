@@ -104,6 +104,9 @@ SYMBOLS = {
     "mobrob_ppo_comm_init_rank": (C.c_int, [_P, _U8, C.c_int32, C.c_int32]),
     "mobrob_ppo_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mobrob_ppo_allreduce_counters": (C.c_int, [_P, _I64, _I64, C.c_int32]),
+    "mobrob_ppo_oneshot_export": (C.c_int, [_P, _U8]),
+    "mobrob_ppo_oneshot_open": (C.c_int, [_P, _U8, C.c_int32, C.c_int32]),
+    "mobrob_ppo_oneshot_close": (C.c_int, [_P]),
     "mobrob_ppo_comm_destroy": (C.c_int, [_P]),
     "mobrob_ppo_train_dp": (C.c_int, [_P, _I64, _P, _P]),
     "mobrob_ppo_epoch_begin": (C.c_int, [_P, _I64]),

@@ -22,6 +22,7 @@
 #include "kernels_env.h"
 #include "kernels_rollout.h"
 #include "robot_ctrl.h"
+#include "oneshot_allreduce.h"
 #ifdef MOBROB_VALUE8  // experiment, see scratch/value8.py
 #include "../../scratch/kernels_fused8.h"
 #endif
@@ -133,6 +134,16 @@ struct mobrob_ppo_engine {
   int last_epochs_started = 0, last_stopped_early = 0, last_steps_applied = 0;  // of the latest mobrob_ppo_train*
   ncclComm_t comm = nullptr;  // RCCL communicator of the data-parallel job (mobrob_ppo_comm_init)
   int64_t allreduce_calls = 0, allreduce_bytes = 0;  // since the last mobrob_ppo_allreduce_counters(reset)
+  struct OneShot {  // peer-mapped exchange buffers of the one-shot all-reduce (oneshot_allreduce.h)
+    char* xbuf = nullptr;                 // own: [2 slots][payload] + [kOneShotMaxChunks] u64 flags (a hipMalloc of its own: IPC exports whole allocations)
+    size_t payload = 0;
+    char* peer[kOneShotMaxRanks] = {nullptr};  // every rank's buffer as mapped here (peer[rank] == xbuf)
+    int world = 0, rank = -1;
+    bool ready = false;
+    unsigned long long seq = 0;           // messages exchanged so far: the same number on every rank
+    int* error = nullptr;                 // pinned host word the kernel raises when a peer never arrived
+    long long timeout_ticks = 0;
+  } oneshot;
   // norm records of the reduction kernels (kernels_fused.h: block_norm_records): used inside mobrob_ppo_train only
   double* norm_rec_sum = nullptr; int* norm_rec_t = nullptr; int* fold_idx_dev = nullptr;
   int fold_start[14] = {0};
@@ -172,6 +183,8 @@ struct mobrob_ppo_engine {
 };
 
 namespace {
+
+int check_async_error(mobrob_ppo_engine* e);  // defined with the one-shot all-reduce
 
 constexpr size_t kArenaAlign = 256;
 
@@ -789,6 +802,7 @@ void mobrob_ppo_destroy(mobrob_ppo_engine_t* e) {
   if (!e) return;
   (void)hipStreamSynchronize(e->stream);
   (void)mobrob_ppo_comm_destroy(e);
+  (void)mobrob_ppo_oneshot_close(e);
   prof_resolve(e);
   if (e->cstream) {
     (void)hipStreamSynchronize(e->cstream);
@@ -835,7 +849,7 @@ int mobrob_ppo_set_stream(mobrob_ppo_engine_t* e, void* s) {
 int mobrob_ppo_synchronize(mobrob_ppo_engine_t* e) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   HIPC(hipStreamSynchronize(e->stream));
-  return MOBROB_OK;
+  return check_async_error(e);
 }
 
 int64_t mobrob_ppo_param_count(const mobrob_ppo_engine_t* e) { return e ? e->P : -1; }
@@ -1742,6 +1756,7 @@ int mobrob_ppo_fetch_step_stats(mobrob_ppo_engine_t* e, float* out, int32_t max_
   }
   HIPC(hipStreamSynchronize(e->stream));
   e->stats_n = 0;
+  CHK(check_async_error(e));
   return n;
 }
 
@@ -1785,6 +1800,39 @@ int rccl_load() {
     if (_r != ncclSuccess) return fail(MOBROB_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(_r)); \
   } while (0)
 
+size_t oneshot_payload_bytes(const mobrob_ppo_engine* e) {
+  const size_t need = std::max((size_t)(e->P + 8) * sizeof(float), (size_t)e->nmb * 4 * sizeof(double));
+  return (need + 255) / 256 * 256;
+}
+int oneshot_all_reduce(mobrob_ppo_engine* e, void* buf, size_t count, int dtype) {
+  auto& o = e->oneshot;
+  const size_t bytes = count * (dtype == 1 ? sizeof(double) : sizeof(float));
+  if (bytes > o.payload) return fail(MOBROB_ERR_INVALID, "one-shot all-reduce: message of %zu bytes, exchange slot of %zu", bytes, o.payload);
+  o.seq++;
+  OneShotArgs a{};
+  const size_t slot = (size_t)(o.seq & 1) * o.payload;
+  a.local = buf; a.mine = o.xbuf + slot; a.my_flags = reinterpret_cast<unsigned long long*>(o.xbuf + 2 * o.payload);
+  for (int r = 0; r < o.world; ++r) {
+    a.peer[r] = o.peer[r] + slot;
+    a.peer_flags[r] = reinterpret_cast<const unsigned long long*>(o.peer[r] + 2 * o.payload);
+  }
+  a.world = o.world; a.rank = o.rank; a.bytes = bytes; a.seq = o.seq; a.error = o.error; a.timeout_ticks = o.timeout_ticks;
+  const int chunks = cdiv((int)bytes, kOneShotChunkBytes);
+  if (dtype == 1) hipLaunchKernelGGL(k_oneshot_allreduce<double>, dim3(chunks), dim3(256), 0, e->stream, a);
+  else hipLaunchKernelGGL(k_oneshot_allreduce<float>, dim3(chunks), dim3(256), 0, e->stream, a);
+  HIPC(hipGetLastError());
+  return MOBROB_OK;
+}
+// raised by a one-shot all-reduce whose peer never published (dead rank): reported at the next synchronising call
+int check_async_error(mobrob_ppo_engine* e) {
+  if (e->oneshot.error && *(volatile int*)e->oneshot.error != 0) {
+    const int v = *(volatile int*)e->oneshot.error;
+    *(volatile int*)e->oneshot.error = 0;
+    return fail(MOBROB_ERR_STATE, "one-shot all-reduce: a peer rank never published message %d (dead or stalled rank)", v - 1);
+  }
+  return MOBROB_OK;
+}
+
 // sum `count` elements (dtype 0 = f32, 1 = f64) in place across the ranks, ordered on the engine's stream
 int dp_all_reduce(mobrob_ppo_engine* e, void* buf, size_t count, int dtype, mobrob_allreduce_fn fn, void* ctx) {
   ProfScope ps(e, MOBROB_K_ALLREDUCE);
@@ -1794,6 +1842,7 @@ int dp_all_reduce(mobrob_ppo_engine* e, void* buf, size_t count, int dtype, mobr
     const int r = fn(ctx, buf, count, dtype, (void*)e->stream);
     return r == 0 ? MOBROB_OK : fail(MOBROB_ERR_STATE, "all-reduce callback returned %d", r);
   }
+  if (e->oneshot.ready) return oneshot_all_reduce(e, buf, count, dtype);
   NCCLC(g_rccl.AllReduce(buf, buf, count, dtype == 1 ? ncclDouble : ncclFloat, ncclSum, e->comm, e->stream));
   return MOBROB_OK;
 }
@@ -1903,10 +1952,69 @@ int mobrob_ppo_comm_destroy(mobrob_ppo_engine_t* e) {
   }
   return MOBROB_OK;
 }
+int mobrob_ppo_oneshot_export(mobrob_ppo_engine_t* e, uint8_t* handle64) {
+  if (!e || !handle64) return fail(MOBROB_ERR_INVALID, "oneshot_export: null argument");
+  static_assert(sizeof(hipIpcMemHandle_t) == MOBROB_IPC_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+  auto& o = e->oneshot;
+  HIPC(hipSetDevice(e->cfg.device_id));
+  if (!o.xbuf) {
+    o.payload = oneshot_payload_bytes(e);
+    if (cdiv((int)o.payload, kOneShotChunkBytes) > kOneShotMaxChunks)
+      return fail(MOBROB_ERR_INVALID, "one-shot all-reduce: a %zu-byte message needs more than %d chunks", o.payload, kOneShotMaxChunks);
+    const size_t total = 2 * o.payload + kOneShotMaxChunks * sizeof(unsigned long long);
+    HIPC(hipMalloc((void**)&o.xbuf, total));
+    HIPC(hipMemset(o.xbuf, 0, total));  // flags = 0 < every sequence number; synchronous: peers may poll as soon as they hold the handle
+    HIPC(hipHostMalloc((void**)&o.error, sizeof(int), hipHostMallocDefault));
+    *o.error = 0;
+    const char* t = getenv("MOBROB_ONESHOT_TIMEOUT_MS");
+    o.timeout_ticks = (long long)(t ? atoll(t) : 20000) * 100000;  // wall_clock64 counts at 100 MHz
+  }
+  hipIpcMemHandle_t h;
+  HIPC(hipIpcGetMemHandle(&h, o.xbuf));
+  memcpy(handle64, &h, sizeof h);
+  return MOBROB_OK;
+}
+int mobrob_ppo_oneshot_open(mobrob_ppo_engine_t* e, const uint8_t* handles, int32_t rank, int32_t nranks) {
+  if (!e || !handles) return fail(MOBROB_ERR_INVALID, "oneshot_open: null argument");
+  auto& o = e->oneshot;
+  if (!o.xbuf) return fail(MOBROB_ERR_STATE, "oneshot_open before oneshot_export");
+  if (o.ready) return fail(MOBROB_ERR_STATE, "oneshot_open: the exchange is already open");
+  if (nranks != e->cfg.world_size || nranks > kOneShotMaxRanks || rank < 0 || rank >= nranks)
+    return fail(MOBROB_ERR_INVALID, "oneshot_open: rank %d of %d (engine world_size %d, at most %d ranks)", rank, nranks, e->cfg.world_size, kOneShotMaxRanks);
+  HIPC(hipSetDevice(e->cfg.device_id));
+  for (int r = 0; r < nranks; ++r) {
+    if (r == rank) { o.peer[r] = o.xbuf; continue; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handles + (size_t)r * MOBROB_IPC_HANDLE_BYTES, sizeof h);
+    void* p = nullptr;
+    hipError_t er = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (er != hipSuccess) {
+      (void)hipGetLastError();
+      for (int q = 0; q < r; ++q)
+        if (q != rank && o.peer[q]) { (void)hipIpcCloseMemHandle(o.peer[q]); o.peer[q] = nullptr; }
+      return fail(MOBROB_ERR_HIP, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(er));
+    }
+    o.peer[r] = static_cast<char*>(p);
+  }
+  o.world = nranks; o.rank = rank; o.seq = 0; o.ready = true;
+  return MOBROB_OK;
+}
+int mobrob_ppo_oneshot_close(mobrob_ppo_engine_t* e) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  auto& o = e->oneshot;
+  if (!o.xbuf) return MOBROB_OK;
+  (void)hipStreamSynchronize(e->stream);
+  for (int r = 0; r < o.world; ++r)
+    if (r != o.rank && o.peer[r]) (void)hipIpcCloseMemHandle(o.peer[r]);
+  (void)hipFree(o.xbuf);
+  (void)hipHostFree(o.error);
+  o = mobrob_ppo_engine::OneShot{};
+  return MOBROB_OK;
+}
 int mobrob_ppo_train_dp(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_allreduce_fn fn, void* ctx) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
-  if (!fn && !e->comm)
-    return fail(MOBROB_ERR_STATE, "train_dp: no communicator (mobrob_ppo_comm_init) and no all-reduce callback");
+  if (!fn && !e->comm && !e->oneshot.ready)
+    return fail(MOBROB_ERR_STATE, "train_dp: no communicator (mobrob_ppo_comm_init), no one-shot exchange (mobrob_ppo_oneshot_open) and no all-reduce callback");
   return train_loop(e, perms, true, fn, ctx);
 }
 int mobrob_ppo_allreduce_counters(mobrob_ppo_engine_t* e, int64_t* calls, int64_t* bytes, int32_t reset) {

@@ -369,6 +369,23 @@ class PPOEngine:
         check(self.lib.mobrob_ppo_comm_info(self._h, C.byref(n), C.byref(r)))
         return int(n.value), int(r.value)
 
+    def oneshot_export(self) -> bytes:
+        """IPC handle of this rank's exchange buffer of the one-shot all-reduce (mobrob_ppo_oneshot_export)."""
+        buf = (C.c_uint8 * 64)()
+        check(self.lib.mobrob_ppo_oneshot_export(self._h, buf))
+        return bytes(buf)
+
+    def oneshot_open(self, handles, rank, nranks):
+        """handles: the ranks' export handles in rank order; afterwards train_dp() exchanges through peer-mapped memory."""
+        blob = b"".join(bytes(h) for h in handles)
+        if len(blob) != 64 * int(nranks):
+            raise ValueError(f"expected {nranks} handles of 64 bytes")
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        check(self.lib.mobrob_ppo_oneshot_open(self._h, buf, int(rank), int(nranks)))
+
+    def oneshot_close(self):
+        check(self.lib.mobrob_ppo_oneshot_close(self._h))
+
     def allreduce_counters(self, reset=False):
         """(calls, payload bytes) of the all-reduces train_dp issued since the last reset."""
         c, b = C.c_int64(), C.c_int64()

@@ -111,6 +111,39 @@ class EngineBackend:
             state = self._comm_ready = agree_and_init_comm(self.e, group, self.device)
         return state
 
+    def ensure_oneshot(self, group=None):
+        """The engine's ONE-SHOT all-reduce over peer-mapped exchange buffers (opt-in: MOBROB_ONESHOT_AR=1): every rank
+        exports its buffer's IPC handle, the handles are all-gathered over `group` (any backend), every rank maps the
+        others'.  True when every rank is set up; False on every rank alike otherwise (RCCL / the callback then carry
+        the sums)."""
+        state = getattr(self, "_oneshot_ready", None)
+        if state is not None:
+            return state
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ok, handle = 1, None
+        try:
+            handle = self.e.oneshot_export()
+        except Exception as ex:  # noqa: BLE001
+            ok, self._oneshot_error = 0, ex
+        handles = [None] * world
+        dist.all_gather_object(handles, handle, group=group)
+        if ok and all(h is not None for h in handles):
+            try:
+                self.e.oneshot_open(handles, rank, world)
+            except Exception as ex:  # noqa: BLE001
+                ok, self._oneshot_error = 0, ex
+        else:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        self._oneshot_ready = bool(int(flag.item()))
+        if not self._oneshot_ready:
+            self.e.oneshot_close()
+            if rank == 0:
+                import warnings
+                warnings.warn("one-shot all-reduce unavailable (%r): using the default exchange" % (getattr(self, "_oneshot_error", "another rank failed"),))
+        return self._oneshot_ready
+
     def gloo_all_reduce(self, group=None):
         """All-reduce callback for `engine.train_dp` under a CPU process group: stage through the host."""
         def reduce_in_place(ptr, count, dtype, _stream):
@@ -181,6 +214,10 @@ def train_data_parallel(backend, perms=None, group=None, force_collectives=False
     comm = world > 1 or (force_collectives and dist.is_initialized())
     stream = getattr(backend, "stream", None)
     if isinstance(backend, EngineBackend) and comm and not python_loop:
+        import os
+        if os.environ.get("MOBROB_ONESHOT_AR", "0") == "1" and world <= 8 and backend.ensure_oneshot(group):
+            backend.e.train_dp(perms)        # the C loop, sums through peer-mapped memory (csrc/oneshot_allreduce.h)
+            return backend.e.last_train_info()
         if dist.get_backend(group) == "nccl":
             if backend.ensure_comm(group):
                 backend.e.train_dp(perms)

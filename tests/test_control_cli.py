@@ -37,12 +37,28 @@ class _OraclePolicy:
         return np.clip(mean[0], -1.0, 1.0), None
 
 
-class _CountingEnv:
+class _GoalSeeker:
+    """Scripted policy for the kinematic stand-in: observation[:2] is the unit vector to the goal, the simulator's command
+    is a fixed linear read-out of the action -> drive straight at the goal (guarantees the reset-and-continue branch runs)."""
+
     def __init__(self, env):
-        self.env, self.resets, self.steps, self.terminations, self.log = env, 0, 0, 0, []
+        self.pinv, self.calls = np.linalg.pinv(env.env._mix), 0
+
+    def predict(self, obs, deterministic=False):
+        assert deterministic is True
+        self.calls += 1
+        a = self.pinv @ np.asarray(obs[:2], np.float64)
+        return (a / max(1.0, np.max(np.abs(a)))).astype(np.float32), None
+
+
+class _CountingEnv:
+    def __init__(self, env, seed=7):
+        self.env, self.resets, self.steps, self.terminations, self.log, self._seed = env, 0, 0, 0, [], seed
 
     def reset(self, *a, **k):
         self.resets += 1
+        if self.resets == 1:          # the script resets without a seed, like the reference: fix the draw sequence here
+            k.setdefault("seed", self._seed)
         return self.env.reset(*a, **k)
 
     def step(self, action):
@@ -57,13 +73,21 @@ def test_evaluation_protocol_is_the_reference_scripts(capsys):
     from mobrob_amd import get_env
     cli = _load_script()
     assert cli.STEPS_PER_EPOCH == 1000
+    # (a) the reference's point checkpoint through the loop: 1000 predict calls per epoch whatever the episodes do
     policy = _OraclePolicy(golden_params(load_golden("point")))
     env = _CountingEnv(get_env("point", enable_gui=False, terminate_on_goal=True))
+    assert len(cli.simulate("point", epochs=2, env=env, policy=policy)) == 2
+    assert policy.calls == 2 * 1000 and env.steps == 2 * 1000 and env.resets == 2 + env.terminations
+    capsys.readouterr()
+    # (b) a policy that does reach goals: every goal restarts the episode and the epoch goes on accumulating
+    raw = get_env("point", enable_gui=False, terminate_on_goal=True)
+    policy, env = _GoalSeeker(raw), _CountingEnv(raw)
     epochs = 3
     rewards = cli.simulate("point", epochs=epochs, env=env, policy=policy)
     assert policy.calls == epochs * 1000 and env.steps == epochs * 1000      # never cut short by a termination
-    assert env.terminations >= 1                                               # the stand-in robot does reach goals ...
+    assert env.terminations >= 3 * epochs                                      # the robot reaches goal after goal ...
     assert env.resets == epochs + env.terminations                             # ... and every one restarts the episode
+    assert min(rewards) > 5.0 * 3                                              # several +5 arrival bonuses in ONE epoch figure
     per_epoch = np.array(env.log).reshape(epochs, 1000).sum(axis=1)
     assert np.allclose(rewards, per_epoch)                                     # cumulative over the epoch, goal bonuses included
     out = capsys.readouterr().out.strip().splitlines()

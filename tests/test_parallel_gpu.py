@@ -297,3 +297,108 @@ def test_c_loop_with_rccl_equals_the_single_rank_call(tmp_path):
         for mode in ("c_rccl", "python_torch"):
             assert r[f"{case}/kl/{mode}/info"].tolist() == info, (case, mode)
             assert np.array_equal(r[f"{case}/kl/{mode}"], r[f"{case}/kl/single"]), (case, mode)
+
+
+# ---- one-shot all-reduce over peer-mapped memory (csrc/oneshot_allreduce.h), validated WITHOUT a second GPU -----------
+def _oneshot_worker(rank, world, port, case, out):
+    """Two ranks on cuda:0: each exports its exchange buffer (hipIpcGetMemHandle), maps the other's (hipIpcOpenMemHandle)
+    and runs the C loop with the one-shot exchange; then the same update through the gloo-callback path."""
+    import time
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      MOBROB_ONESHOT_TIMEOUT_MS="15000")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mobrob_amd.engine import PPOEngine
+    from mobrob_amd.parallel import EngineBackend, train_data_parallel
+    c = CASES[case]
+    p, buf, lv, dones, h, perms = _rank_data(c, rank)
+    H = c["H"]
+    e = PPOEngine(obs_dim=c["D"], act_dim=c["A"], n_envs=c["N"], n_steps=c["T"], batch_size=c["B"], n_epochs=c["E"],
+                  pi=(H, H), vf=(H, H), ent_coef=h.ent_coef, device_id=0, rank=rank, world_size=world)
+    e.load_rollout(buf, lv, dones)
+    be = EngineBackend(e)
+    z = {k: np.zeros_like(v) for k, v in p.items()}
+    res = {}
+    for mode in ("callback", "oneshot"):
+        os.environ["MOBROB_ONESHOT_AR"] = "1" if mode == "oneshot" else "0"
+        ms = []
+        for rep in range(3):            # repetitions: sequence numbers, slot reuse and flag monotonicity over many messages
+            e.set_params(p)
+            e.set_optimizer_state(z, z, 0)
+            dist.barrier()
+            t0 = time.perf_counter()
+            train_data_parallel(be, perms)
+            e.synchronize()
+            ms.append(1e3 * (time.perf_counter() - t0))
+            if rep == 0:
+                res[mode + "/flat"] = e.get_flat_params()
+                res[mode + "/stats"] = np.array(list(e.train_stats().values()))
+            else:
+                assert np.array_equal(res[mode + "/flat"], e.get_flat_params()), (mode, rep)
+        res[mode + "/ms"] = np.array(ms)
+        if mode == "oneshot":
+            assert be._oneshot_ready is True
+            calls, _ = e.allreduce_counters()
+            assert calls == 2 * 3 * c["E"] * (e.n_minibatches + 1)
+    np.savez(out.format(rank=rank), **res)
+    e.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["h256", "h64"])
+def test_oneshot_all_reduce_through_ipc_equals_the_callback_path(case, tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    out = str(tmp_path / "os{rank}.npz")
+    mp.spawn(_oneshot_worker, args=(world, _free_port(), case, out), nprocs=world, join=True)
+    r = [np.load(out.format(rank=i)) for i in range(world)]
+    assert np.array_equal(r[0]["oneshot/flat"], r[1]["oneshot/flat"])            # replicas bit-identical
+    assert np.array_equal(r[0]["oneshot/flat"], r[0]["callback/flat"])           # x0 + x1 is the same sum in any transport
+    assert np.array_equal(r[0]["oneshot/stats"], r[0]["callback/stats"])
+    print(f"\n[{case}] world-2 update on one device, ms per train(): host-staged gloo callback "
+          f"{np.min(r[0]['callback/ms']):.2f}, one-shot peer exchange {np.min(r[0]['oneshot/ms']):.2f}")
+    rec = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(rec):
+        import json
+        with open(os.path.join(rec, f"oneshot_vs_callback_{case}.json"), "w") as f:
+            json.dump({"case": CASES[case], "world": world, "device": "both ranks on cuda:0",
+                       "ms_per_train_callback": r[0]["callback/ms"].tolist(), "ms_per_train_oneshot": r[0]["oneshot/ms"].tolist()}, f)
+
+
+def _oneshot_dead_peer_worker(rank, world, port, out):
+    """Rank 1 sets the exchange up and then never trains: rank 0's kernel must give up after the timeout and the engine
+    must report it, not hang the device."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      MOBROB_ONESHOT_TIMEOUT_MS="300", MOBROB_ONESHOT_AR="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mobrob_amd._lib import EngineError
+    from mobrob_amd.engine import PPOEngine
+    from mobrob_amd.parallel import EngineBackend, train_data_parallel
+    c = CASES["h64"]
+    p, buf, lv, dones, h, perms = _rank_data(c, rank)
+    e = PPOEngine(obs_dim=c["D"], act_dim=c["A"], n_envs=c["N"], n_steps=c["T"], batch_size=c["B"], n_epochs=1,
+                  pi=(64, 64), vf=(64, 64), device_id=0, rank=rank, world_size=world)
+    e.set_params(p)
+    e.load_rollout(buf, lv, dones)
+    be = EngineBackend(e)
+    assert be.ensure_oneshot()
+    msg = ""
+    if rank == 0:
+        try:
+            train_data_parallel(be, perms[:1])
+            e.synchronize()
+        except EngineError as ex:
+            msg = str(ex)
+    dist.barrier()
+    np.savez(out.format(rank=rank), msg=msg)
+    e.close()
+    dist.destroy_process_group()
+
+
+def test_oneshot_all_reduce_reports_a_peer_that_never_arrives(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "dead{rank}.npz")
+    mp.spawn(_oneshot_dead_peer_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert "never published" in str(np.load(out.format(rank=0))["msg"])
