@@ -595,6 +595,16 @@ def bench_single(args, name, steps, warmup, job, phases):
         else:
             ranks_seen, ranks_src = 1, "single rank"
         value = env_steps / dt
+        if not use_dp:
+            exchange = None
+        elif getattr(backend, "_oneshot_ready", False):
+            exchange = "one-shot all-reduce over peer-mapped buffers (hipIpc, csrc/oneshot_allreduce.h), C loop"
+        elif comm_n > 0:
+            exchange = "ncclAllReduce on the engine's own RCCL communicator, C loop"
+        elif job.same_device:
+            exchange = "host-staged gloo all-reduce callback, C loop"
+        else:
+            exchange = "torch.distributed all-reduce, Python loop (fallback)"
         out = {
             "metric": "env-steps/sec (whole node), doggo PPO" if "doggo" in name else "env-steps/sec (whole node)",
             "value": None if job.same_device else value, "unit": "env-steps/s", "n_gpus": world, "steps": steps,
@@ -621,6 +631,7 @@ def bench_single(args, name, steps, warmup, job, phases):
             out["allreduce_bytes"] = {"per_step": ar_bytes / steps, "gradient_message": (eng.P + 8) * 4,
                                       "advantage_statistics_message": nmb * 4 * 8}
             out["replicas_bit_identical"] = identical
+            out["config"]["exchange"] = exchange
         if job.same_device:
             out["rehearsal"] = {"what": f"{world} ranks time-sharing ONE GPU (MOBROB_DP_SAME_DEVICE=1): gloo process group, the C "
                                         "loop mobrob_ppo_train_dp with the host-staged all-reduce callback; no throughput is "
