@@ -560,7 +560,7 @@ def bench_single(args, name, steps, warmup, job, phases):
     # HIP events around every launch of the dominant kernel over the whole timed region (the roofline figure) and, in
     # a data-parallel run, around every all-reduce (so that a scaling loss can be attributed); the other phases only
     # with --phases: an event pair costs GPU time at every launch boundary
-    eng.profile(True, only=None if phases else (["train_grad", "allreduce"] if use_dp else ["train_grad"]))
+    eng.profile(True, only=None if phases else (["train_grad", "allreduce"] if use_dp and not args.no_allreduce_phase else ["train_grad"]))
     eng.allreduce_counters(reset=True)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -679,6 +679,9 @@ def main():
     ap.add_argument("--phases", action="store_true",
                     help="bracket every phase with HIP events (phase_ms_per_step; costs ~4 %% of the throughput); "
                          "by default only the dominant kernel is bracketed")
+    ap.add_argument("--no-allreduce-phase", action="store_true",
+                    help="data-parallel runs: do not bracket the all-reduces with HIP events (640 event records per iteration "
+                         "at the headline shape)")
     ap.add_argument("--host-python-loop", action="store_true",
                     help="host-env workloads: drive the pipelined rollout from Python instead of mobrob_ppo_collect_host")
     ap.add_argument("--host-parts", type=int, default=2,
