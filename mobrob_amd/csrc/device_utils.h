@@ -147,6 +147,22 @@ __host__ __device__ __forceinline__ uint64_t feistel_perm(uint64_t i, uint64_t n
   } while (v >= n);
   return v;
 }
+// inverse of feistel_perm: the position i with feistel_perm(i) == v (rounds run backwards; the cycle walk of a value < n
+// through the inverse round function visits the same cycle in the opposite direction)
+__host__ __device__ __forceinline__ uint64_t feistel_perm_inv(uint64_t v, uint64_t n, int half_bits, uint32_t k0,
+                                                              uint32_t k1) {
+  const uint32_t mask = (uint32_t)((1ull << half_bits) - 1ull);
+  do {
+    uint32_t l = (uint32_t)(v >> half_bits) & mask, r = (uint32_t)v & mask;
+#pragma unroll
+    for (int rnd = 5; rnd >= 0; --rnd) {
+      const uint32_t pl = r ^ feistel_rf(l, rnd, k0, k1, mask);
+      r = l; l = pl;
+    }
+    v = ((uint64_t)l << half_bits) | r;
+  } while (v >= n);
+  return v;
+}
 __host__ __device__ inline int feistel_half_bits(uint64_t n) {
   int bits = 0;
   uint64_t m = n > 1 ? n - 1 : 1;

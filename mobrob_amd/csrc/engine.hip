@@ -122,8 +122,9 @@ struct mobrob_ppo_engine {
   int* rows = nullptr;          // [T*N] device row index per permuted position
   int64_t* perm_dev = nullptr;  // [T*N]
   double* advstat = nullptr;    // [nmb][4]
-  double* advpart = nullptr;    // [nmb][kAdvParts][2] partial sums of k_adv_stats
+  unsigned long long* advbins = nullptr;  // [nmb][2] fixed-point sums of k_adv_stats_stream (+ 1 word: max |adv| bits)
   uint64_t perm_counter = 0;
+  unsigned adv_pass = 0;        // epoch_begin calls so far: which of the two max-|adv| words is live
   bool epoch_open = false;
   float* stats = nullptr;  // [stats_cap][8]
   int stats_cap = 0, stats_n = 0;
@@ -697,7 +698,7 @@ int engine_alloc(mobrob_ppo_engine* e) {
   CHK(dalloc(e, &e->dones_tmp, N)); CHK(dalloc(e, &e->clip_act, N * A)); CHK(dalloc(e, &e->rew_tmp, N));
   CHK(dalloc(e, &e->term_obs, N * Dp)); CHK(dalloc(e, &e->term_val, N)); CHK(dalloc(e, &e->eps_dev, R * A));
   CHK(dalloc(e, &e->trunc_dev, N)); CHK(dalloc(e, &e->dones_u8, N)); CHK(dalloc(e, &e->ep_len, N)); CHK(dalloc(e, &e->ep_len2, N)); CHK(dalloc(e, &e->ctr_dev, 2));
-  CHK(dalloc(e, &e->rows, T * N)); CHK(dalloc(e, &e->perm_dev, T * N)); CHK(dalloc(e, &e->advstat, (size_t)e->nmb * 4)); CHK(dalloc(e, &e->advpart, (size_t)e->nmb * kAdvParts * 2));
+  CHK(dalloc(e, &e->rows, T * N)); CHK(dalloc(e, &e->perm_dev, T * N)); CHK(dalloc(e, &e->advstat, (size_t)e->nmb * 4)); CHK(dalloc(e, &e->advbins, (size_t)e->nmb * 2 + 1));  // + two 32-bit max words
   CHK(dalloc(e, &e->stats, (size_t)e->stats_cap * 8));
   CHK(dalloc(e, &e->Xg, Bl * Dp)); CHK(dalloc(e, &e->actg, Bl * A)); CHK(dalloc(e, &e->lpg, Bl));
   CHK(dalloc(e, &e->advg, Bl)); CHK(dalloc(e, &e->retg, Bl)); CHK(dalloc(e, &e->oldvg, Bl));
@@ -1538,19 +1539,30 @@ int mobrob_ppo_epoch_begin(mobrob_ppo_engine_t* e, const int64_t* perm) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   if (!e->rollout_ready) return fail(MOBROB_ERR_STATE, "epoch_begin: rollout not finished (finish_rollout / collect first)");
   const int total = e->N * e->T;
+  AdvStatArgs as{};
+  as.adv = e->adv; as.total = total; as.T = e->T; as.N = e->N; as.bl = e->Bl; as.nmb = e->nmb;
+  as.bins = e->advbins;
+  unsigned* maxw = reinterpret_cast<unsigned*>(e->advbins + (size_t)2 * e->nmb);  // two words, used alternately
+  as.absmax_bits = maxw + (e->adv_pass & 1); as.absmax_next = maxw + ((e->adv_pass + 1) & 1);
+  e->adv_pass++;
   if (perm) {
     HIPC(hipMemcpyAsync(e->perm_dev, perm, (size_t)total * 8, hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(k_perm_from_host, dim3(cdiv(total, 256)), dim3(256), 0, e->stream, e->perm_dev, total, e->T,
-                       e->N, e->rows);
+                       e->N, e->Bl, e->rows);
+    as.mb_of_row = reinterpret_cast<const int*>(e->perm_dev);
   } else {
     const uint64_t key = (e->cfg.seed * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(e->cfg.rank + 1) << 48) ^ (e->perm_counter + 1);
     e->perm_counter++;
+    as.half_bits = feistel_half_bits((uint64_t)total); as.k0 = (uint32_t)key; as.k1 = (uint32_t)(key >> 32);
     hipLaunchKernelGGL(k_perm_feistel, dim3(cdiv(total, 256)), dim3(256), 0, e->stream, total, e->T, e->N,
-                       feistel_half_bits((uint64_t)total), (uint32_t)key, (uint32_t)(key >> 32), e->rows,
-                       (int64_t*)nullptr);
+                       as.half_bits, as.k0, as.k1, e->rows, (int64_t*)nullptr);
   }
-  hipLaunchKernelGGL(k_adv_stats, dim3(e->nmb, kAdvParts), dim3(1024), 0, e->stream, e->adv, e->rows, total, e->Bl, e->advpart);
-  hipLaunchKernelGGL(k_adv_fold, dim3(cdiv(e->nmb, 64)), dim3(64), 0, e->stream, e->advpart, e->nmb, total, e->Bl, e->advstat);
+  // advantage statistics: one coalesced pass in storage order, order-independent integer sums (kernels_generic.h)
+  const int sgrid = std::max(1, std::min(1024, cdiv(total, 4 * 256)));
+  const size_t slds = e->nmb <= kAdvLdsMinibatches ? (size_t)2 * e->nmb * sizeof(unsigned long long) : 0;
+  hipLaunchKernelGGL(k_adv_absmax, dim3(sgrid), dim3(256), 0, e->stream, as);
+  hipLaunchKernelGGL(k_adv_stats_stream, dim3(sgrid), dim3(256), slds, e->stream, as);
+  hipLaunchKernelGGL(k_adv_fold, dim3(cdiv(e->nmb, 64)), dim3(64), 0, e->stream, as, e->advstat);
   HIPC(hipGetLastError());
   e->epoch_open = true;
   return MOBROB_OK;

@@ -479,13 +479,16 @@ __global__ __launch_bounds__(kGaeThreads) void k_gae(const float* __restrict__ r
 // ------------------------------------------------------------------------------------------------
 // Minibatch index construction.  SB3 flat index is env-major (flat = n*T + t); device rows are t*N + n.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_perm_from_host(const int64_t* __restrict__ perm, int total, int T, int N,
+// `perm` holds int64 flat indices < 2^30: only the LOW words are read, and the HIGH word of entry `row` receives the
+// minibatch the row belongs to (k_adv_stats_stream reads it back in storage order) -- no second [T*N] array.
+__global__ void k_perm_from_host(int64_t* __restrict__ perm, int total, int T, int N, int bl,
                                  int* __restrict__ rows) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int64_t f = perm[i];
-  const int n = (int)(f / T), t = (int)(f - (int64_t)n * T);
+  const int f = reinterpret_cast<const int*>(perm)[2 * (size_t)i];
+  const int n = f / T, t = f - n * T;
   rows[i] = t * N + n;
+  reinterpret_cast<int*>(perm)[2 * (size_t)(t * N + n) + 1] = i / bl;
 }
 __global__ void k_perm_feistel(int total, int T, int N, int half_bits, uint32_t k0, uint32_t k1,
                                int* __restrict__ rows, int64_t* __restrict__ flat_out) {
@@ -499,40 +502,105 @@ __global__ void k_perm_feistel(int total, int T, int N, int half_bits, uint32_t 
   }
 }
 
-// per-minibatch (sum, sumsq, count) of the advantages in float64.  The gathers through the permutation are HBM line
-// fetches (4 bytes used of each), one block per minibatch left most CUs idle: kAdvParts blocks per minibatch take a
-// contiguous quarter each (grid.y), k_adv_fold adds the quarters in fixed order -> still reproducible run to run.
-constexpr int kAdvParts = 4;
-__global__ __launch_bounds__(1024) void k_adv_stats(const float* __restrict__ adv, const int* __restrict__ rows,
-                                                    int total, int bl, double* __restrict__ part) {
-  __shared__ double sc[16];
-  const int mb = blockIdx.x, q = blockIdx.y;
-  const int s0 = mb * bl, e0 = min(s0 + bl, total);
-  const int per = (e0 - s0 + kAdvParts - 1) / kAdvParts;
-  const int s = s0 + q * per, e = min(s + per, e0);
-  double a = 0.0, b = 0.0;
-  for (int i = s + threadIdx.x; i < e; i += blockDim.x) {
-    const double x = (double)adv[rows[i]];
-    a += x;
-    b += x * x;
+// ------------------------------------------------------------------------------------------------
+// Per-minibatch (sum, sum of squares, count) of the advantages (normalize_advantage).
+//
+// Round 1-2 gathered adv[rows[i]] minibatch by minibatch: 4.1 M four-byte gathers pull 419 MB of lines for 16 MB of
+// data.  Now the advantages are STREAMED once in storage order (coalesced 16-byte loads, 16 MB) and every element finds
+// its minibatch itself: position = inverse permutation of its env-major index (the Feistel permutation is invertible in
+// registers: feistel_perm_inv; a host-supplied permutation leaves the minibatch id beside each row, k_perm_from_host),
+// minibatch = position / batch.  Elements of one minibatch therefore arrive in arbitrary order on arbitrary workgroups,
+// so the sums are taken in INTEGERS -- fixed point, scaled by a power of two chosen from max |adv| so that neither sum
+// can overflow 63 bits -- whose addition is associative: the result does not depend on the order, the launch geometry
+// or the atomics' timing, and is reproducible bit for bit.  Resolution: 2^-45 of max |adv| per element (float32
+// carries 2^-24); the sums equal the exact ones to ~1e-12 relative.
+//   k_adv_absmax   max |adv| (bits of a non-negative float order like unsigned integers) + zeroes the bins
+//   k_adv_stats_stream   the pass: LDS bins per workgroup (ds_add_u64), one global 64-bit atomic per bin and workgroup
+//   k_adv_fold     integers -> (sum, sumsq, count) in float64
+// ------------------------------------------------------------------------------------------------
+constexpr int kAdvLdsMinibatches = 2048;  // LDS bins (32 KB); beyond that the adds go straight to the global bins
+struct AdvStatArgs {
+  const float* adv; int total, T, N, bl, nmb;
+  int half_bits; uint32_t k0, k1;       // Feistel permutation of this epoch ...
+  const int* mb_of_row;                 // ... or (host permutation) the minibatch of storage row r at [2r + 1]
+  unsigned* absmax_bits;                // max |adv| of THIS epoch's pass (zero on entry) ...
+  unsigned* absmax_next;                // ... and the word the next epoch will use, zeroed by this one
+  unsigned long long* bins;             // [nmb][2] two's-complement sums
+};
+__global__ __launch_bounds__(256) void k_adv_absmax(AdvStatArgs a) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  for (int i = tid; i < 2 * a.nmb; i += nth) a.bins[i] = 0ull;
+  if (tid == 0) *a.absmax_next = 0u;
+  float m = 0.f;
+  const int n4 = a.total >> 2;
+  for (int i = tid; i < n4; i += nth) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(a.adv)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
-  const double sa = block_sum_d(a, sc);
-  const double sb = block_sum_d(b, sc);
-  if (threadIdx.x == 0) {
-    part[(mb * kAdvParts + q) * 2 + 0] = sa;
-    part[(mb * kAdvParts + q) * 2 + 1] = sb;
+  for (int i = 4 * n4 + tid; i < a.total; i += nth) m = fmaxf(m, fabsf(a.adv[i]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(a.absmax_bits, __float_as_uint(m));
+}
+// power-of-two scales: |adv| < 2^e, so |adv * 2^(s1)| < 2^(61 - log2ceil(bl)) and a minibatch of bl elements sums below 2^61
+__device__ __forceinline__ void adv_scales(unsigned absmax_bits, int bl, int& s1, int& s2) {
+  const int e = (int)((absmax_bits >> 23) & 0xff) - 127 + 1;  // |adv| < 2^e (0 for an all-zero rollout: any scale works)
+  int lb = 0;
+  while ((1ll << lb) < (long long)bl) ++lb;
+  s1 = 61 - lb - e;
+  s2 = 61 - lb - 2 * e;
+}
+__global__ __launch_bounds__(256) void k_adv_stats_stream(AdvStatArgs a) {
+  extern __shared__ unsigned long long adv_bins_lds[];
+  const bool use_lds = a.nmb <= kAdvLdsMinibatches;
+  if (use_lds)
+    for (int i = threadIdx.x; i < 2 * a.nmb; i += blockDim.x) adv_bins_lds[i] = 0ull;
+  int s1, s2;
+  adv_scales(*a.absmax_bits, a.bl, s1, s2);
+  const double f1 = ldexp(1.0, s1), f2 = ldexp(1.0, s2);
+  __syncthreads();
+  unsigned long long* bins = use_lds ? adv_bins_lds : a.bins;
+  auto add = [&](int row, float x) {
+    int mb;
+    if (a.mb_of_row) {
+      mb = a.mb_of_row[2 * (size_t)row + 1];
+    } else {
+      const int t = row / a.N, n = row - t * a.N;
+      mb = (int)(feistel_perm_inv((uint64_t)n * (uint64_t)a.T + (uint64_t)t, (uint64_t)a.total, a.half_bits, a.k0, a.k1) / (uint64_t)a.bl);
+    }
+    const double xd = (double)x;
+    const long long q1 = __double2ll_rn(xd * f1), q2 = __double2ll_rn(xd * xd * f2);
+    atomicAdd(&bins[2 * mb], (unsigned long long)q1);
+    atomicAdd(&bins[2 * mb + 1], (unsigned long long)q2);
+  };
+  // contiguous quads of storage rows per workgroup (coalesced 16-byte loads), grid-strided
+  const int n4 = a.total >> 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(a.adv)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) add(4 * i + j, v[j]);
+  }
+  if (blockIdx.x == 0)
+    for (int i = 4 * n4 + threadIdx.x; i < a.total; i += blockDim.x) add(i, a.adv[i]);
+  if (use_lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * a.nmb; i += blockDim.x) {
+      const unsigned long long v = adv_bins_lds[i];
+      if (v != 0ull) atomicAdd(&a.bins[i], v);
+    }
   }
 }
-__global__ void k_adv_fold(const double* __restrict__ part, int nmb, int total, int bl, double* __restrict__ out) {
+__global__ void k_adv_fold(AdvStatArgs a, double* __restrict__ out) {
   const int mb = blockIdx.x * blockDim.x + threadIdx.x;
-  if (mb >= nmb) return;
-  const double* p = part + (size_t)mb * kAdvParts * 2;
-  out[4 * mb + 0] = ((p[0] + p[2]) + p[4]) + p[6];
-  out[4 * mb + 1] = ((p[1] + p[3]) + p[5]) + p[7];
-  out[4 * mb + 2] = (double)(min(mb * bl + bl, total) - mb * bl);
-  out[4 * mb + 3] = 0.0;
+  int s1, s2;
+  adv_scales(*a.absmax_bits, a.bl, s1, s2);
+  if (mb < a.nmb) {
+    out[4 * mb + 0] = ldexp((double)(long long)a.bins[2 * mb], -s1);
+    out[4 * mb + 1] = ldexp((double)(long long)a.bins[2 * mb + 1], -s2);
+    out[4 * mb + 2] = (double)(min(mb * a.bl + a.bl, a.total) - mb * a.bl);
+    out[4 * mb + 3] = 0.0;
+  }
 }
-
 // gather the minibatch rows into contiguous work arrays (generic path)
 __global__ void k_gather(const int* __restrict__ rows, int count, const float* __restrict__ obs, int Dp,
                          const float* __restrict__ actions, int A, const float* __restrict__ logp,

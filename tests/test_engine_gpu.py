@@ -166,6 +166,62 @@ def test_feistel_bit_exact():
     e.close()
 
 
+@pytest.mark.parametrize("T,N,B", [(64, 40, 100),        # ragged: 2560 rows, 26 minibatches, the last one 60 rows
+                                   (37, 5, 64),           # 185 rows: not a multiple of four, three minibatches
+                                   (250, 128, 4096),      # 32 000 rows, several workgroups per minibatch
+                                   (16, 300, 2),          # 2400 minibatches: more than the LDS bins hold -> global adds
+                                   (3, 3, 64)])           # one short minibatch
+def test_advantage_statistics_are_streamed_exactly_and_reproducibly(T, N, B):
+    """k_adv_stats_stream: one coalesced pass in storage order, every element finds its minibatch through the INVERSE
+    permutation, sums in fixed-point integers -> equal to float64 sums to 1e-12 and the same bits on every run, for the
+    device-drawn Feistel permutation and for a host-supplied one."""
+    from tests.test_full_size_gpu import _device_perm_key
+    rng = np.random.default_rng(T * N)
+    adv = (rng.standard_normal((T, N)) * rng.choice([1e-3, 1.0, 40.0])).astype(np.float32)
+    adv[rng.integers(0, T), rng.integers(0, N)] = 173.25                       # an outlier sets the fixed-point scale
+    total, nmb = T * N, -(-T * N // B)
+    flat = adv.T.reshape(-1)                                                    # SB3's env-major flat order: n * T + t
+
+    def expected(perm):
+        out = np.zeros((nmb, 4))
+        for mb in range(nmb):
+            x = flat[perm[mb * B:(mb + 1) * B]].astype(np.float64)
+            out[mb] = [x.sum(), (x * x).sum(), len(x), 0.0]
+        return out
+
+    seed = 11
+    runs = []
+    for rep in range(2):
+        e = make_engine(obs_dim=4, act_dim=2, n_envs=N, n_steps=T, batch_size=B, n_epochs=1, seed=seed)
+        e.write("advantages", adv)
+        e.mark_rollout_ready()
+        got = []
+        for draw in range(2):                                                   # two device-drawn permutations ...
+            e.epoch_begin(None)
+            e.synchronize()
+            got.append(e.read("advstat"))
+            want = expected(O.feistel_permutation(total, _device_perm_key(seed, draw)))
+            assert np.allclose(got[-1], want, rtol=1e-11, atol=1e-9 * float(np.abs(adv).max()) ** 2), (draw, np.abs(got[-1] - want).max())
+        perm = rng.permutation(total) if rep == 0 else runs[0][2]
+        e.epoch_begin(perm)                                                     # ... and a host-supplied one
+        e.synchronize()
+        got.append(e.read("advstat"))
+        assert np.allclose(got[-1], expected(perm), rtol=1e-11, atol=1e-9 * float(np.abs(adv).max()) ** 2)
+        assert not np.array_equal(got[0], got[1])                               # the draws differ
+        runs.append((got[0], got[1], perm, got[2]))
+        e.close()
+    for k in (0, 1, 3):
+        assert np.array_equal(runs[0][k], runs[1][k])                          # bit-reproducible, whatever the atomics' order
+    # all-zero advantages (a scale with nothing to scale) stay zero
+    e = make_engine(obs_dim=4, act_dim=2, n_envs=N, n_steps=T, batch_size=B, n_epochs=1)
+    e.write("advantages", np.zeros((T, N), np.float32))
+    e.mark_rollout_ready()
+    e.epoch_begin(None)
+    st = e.read("advstat")
+    assert np.all(st[:, :2] == 0.0) and st[:, 2].sum() == total
+    e.close()
+
+
 def test_host_rollout_matches_oracle():
     """act/store/finish_rollout through the host path == oracle collect_rollout on the same env stream,
     including a time-limit truncation with bootstrap."""
