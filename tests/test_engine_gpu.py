@@ -207,7 +207,7 @@ def test_advantage_statistics_are_streamed_exactly_and_reproducibly(T, N, B):
         e.synchronize()
         got.append(e.read("advstat"))
         assert np.allclose(got[-1], expected(perm), rtol=1e-11, atol=1e-9 * float(np.abs(adv).max()) ** 2)
-        assert not np.array_equal(got[0], got[1])                               # the draws differ
+        assert nmb == 1 or not np.array_equal(got[0], got[1])                   # the draws differ (one minibatch: order-free sums agree exactly)
         runs.append((got[0], got[1], perm, got[2]))
         e.close()
     for k in (0, 1, 3):
