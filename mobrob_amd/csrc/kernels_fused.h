@@ -629,8 +629,13 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   // of tile t -- 13 us of MFMAs fed from LDS only, no global load to wait for -- row indices at its start, the
   // dependent rows at its mid-point; here: the first tile (exposed once per launch).
   constexpr int NJ = H16 ? 4 : 8;  // action columns per lane (4 lanes per row)
+  // Wide heads on wide observations (A > 16, D > 32: none of the reference robots) are out of registers with eight
+  // action values per lane held across the dW2 phase: they keep the ROW INDEX instead and load the actions in the loss
+  // stage itself (an exposed gather per tile instead of register spills).
+  constexpr bool kActAhead = H16 || DP <= 32;
   float l_adv = 0.f, l_old = 0.f, l_act[NJ];
-  auto gather_loss = [&](int src_or_neg, int lq_) {  // one load per destination register, each after its zero init
+  int l_src = -1;
+  auto load_actions = [&](int src_or_neg, int lq_) {
     const bool live = src_or_neg >= 0, pol = net == 0;
     const unsigned src = live ? (unsigned)src_or_neg : 0u;
     const unsigned aoff = (src * (unsigned)a.A + (unsigned)lq_) * 4u;
@@ -639,6 +644,12 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
       l_act[j] = (pol && 4 * j + lq_ < a.A && live)
                      ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.actions) + (aoff + 16u * j))
                      : 0.f;
+  };
+  auto gather_loss = [&](int src_or_neg, int lq_) {  // one load per destination register, each after its zero init
+    const bool live = src_or_neg >= 0, pol = net == 0;
+    const unsigned src = live ? (unsigned)src_or_neg : 0u;
+    if constexpr (kActAhead) load_actions(src_or_neg, lq_);
+    else l_src = src_or_neg;
     const float* old_or_ret = pol ? a.old_logp : a.ret;  // policy: old log-prob; value net: return target
     l_old = live ? old_or_ret[src] : 0.f;
     l_adv = live ? (pol ? a.adv[src] : (a.clip_vf >= 0.f ? a.old_values[src] : 0.f)) : 0.f;  // value net: old value (vf clipping)
@@ -685,6 +696,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
       const int gb = opaque(L::GACC + wave * 64 + q);
       const int A = a.A;
       if (net == 0) {
+        if constexpr (!kActAhead) load_actions(l_src, q);
         float lp = 0.f;
         float dk[NJ];
 #pragma unroll

@@ -152,7 +152,7 @@ __global__ void k_sample(const float* __restrict__ mu, int ldmu, const float* __
   if (row >= n) return;
   const uint32_t draw = draw_rel + (draw_base ? *draw_base : 0u);
   float lp = 0.f;
-  float z[4];
+  float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;  // (selects, not a dynamically indexed array: that lives in scratch memory)
   for (int a = 0; a < A; ++a) {
     float e;
     if (eps != nullptr) {
@@ -161,9 +161,12 @@ __global__ void k_sample(const float* __restrict__ mu, int ldmu, const float* __
       if ((a & 3) == 0) {
         const Philox4 rr = philox4x32_10((uint32_t)(row + row0), (uint32_t)(a >> 2), draw, kStreamEps, (uint32_t)seed,
                                          (uint32_t)(seed >> 32));
+        float z[4];
         box_muller4(rr, z);
+        z0 = z[0]; z1 = z[1]; z2 = z[2]; z3 = z[3];
       }
-      e = z[a & 3];
+      const int q = a & 3;
+      e = q == 0 ? z0 : (q == 1 ? z1 : (q == 2 ? z2 : z3));
     }
     const float ls = log_std[a];
     const float sd = expf(ls);

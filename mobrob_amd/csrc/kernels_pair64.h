@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
   constexpr bool kF2Resident = DP <= 32;  // wider observations need the registers (next tile's rows, a fifth accumulator tile)
   Frags<8> f2;
   if (kF2Resident) f2 = load_frags<8>(W.W2f + (size_t)wave * 8 * 64, lane0);
-  constexpr bool kFhResident = DP < 64;
+  // (register budget of two waves per SIMD: the combinations below were the ones the compiler spilled on)
+  constexpr bool kFhResident = DP < 48 && !(DP == 32 && NJ > 6);
   Frags<4> fh;  // head k-groups wave, wave + 2, wave + 4, wave + 6 (tile64_forward's chains `acc` / `acc2`)
   if (kFhResident) {
 #pragma unroll
@@ -96,9 +97,10 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
   Frags<NKG1> f1;
   Frags<4> b3;
   constexpr int W2B_LDS = 2 * L::END;  // [2 blocks][8 k-groups][64 lanes][4]
+  constexpr bool kB3Resident = kSmall && !(DP == 32 && NJ > 10);
   if (kSmall) {
     f1 = load_frags<NKG1>(W.W1f + (size_t)wave * NKG1 * 64, lane0);
-    b3 = load_frags<4>(W.W3b + (size_t)wave * 4 * 64, lane0, nkh);
+    if (kB3Resident) b3 = load_frags<4>(W.W3b + (size_t)wave * 4 * 64, lane0, nkh);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       reinterpret_cast<f32x4*>(&lds[W2B_LDS])[threadIdx.x + u * 256] = W.W2b[threadIdx.x + u * 256];
@@ -348,10 +350,8 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
     }
     // backward weight fragments (L2) and the next tile's observation rows: in flight during the backward phases
     Frags<8> b2;
-    if (!kSmall) {
-      b3 = load_frags<4>(W.W3b + (size_t)wave * 4 * 64, lane, nkh);
-      b2 = load_frags<8>(W.W2b + (size_t)wave * 8 * 64, lane);
-    }
+    if (!kB3Resident) b3 = load_frags<4>(W.W3b + (size_t)wave * 4 * 64, lane, nkh);
+    if (!kSmall) b2 = load_frags<8>(W.W2b + (size_t)wave * 8 * 64, lane);
 #pragma unroll
     for (int u = 0; u < NG; ++u) {
       const int c = (tid0 + u * 128) % per;

@@ -62,3 +62,26 @@ def test_product_never_imports_the_oracle():
         p = os.path.join(ROOT, f)
         if os.path.exists(p):
             assert "oracle" not in open(p).read()
+
+
+def test_build_fails_on_register_spills():
+    """__graft_entry__.build() parses hipcc's kernel-resource-usage remarks and refuses a library in which any kernel spills
+    a vector register or touches scratch memory; the audit of the shipped binary sits beside it."""
+    import __graft_entry__ as g
+    ok = ("engine.hip:10:1: remark: Function Name: _Zk_good [-Rpass-analysis=kernel-resource-usage]\n"
+          "engine.hip:10:1: remark:     SGPRs: 40 [-Rpass-analysis=kernel-resource-usage]\n"
+          "engine.hip:10:1: remark:     VGPRs: 242 [-Rpass-analysis=kernel-resource-usage]\n"
+          "engine.hip:10:1: remark:     AGPRs: 256 [-Rpass-analysis=kernel-resource-usage]\n"
+          "engine.hip:10:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]\n"
+          "engine.hip:10:1: remark:     Occupancy [waves/SIMD]: 1 [-Rpass-analysis=kernel-resource-usage]\n"
+          "engine.hip:10:1: remark:     SGPRs Spill: 12 [-Rpass-analysis=kernel-resource-usage]\n"
+          "engine.hip:10:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]\n")
+    rows = g.check_kernel_resources(ok)
+    assert rows == [("_Zk_good", 242, 256, 0, 12, 0, 1)]
+    for bad in (ok.replace("VGPRs Spill: 0", "VGPRs Spill: 7"), ok.replace("ScratchSize [bytes/lane]: 0", "ScratchSize [bytes/lane]: 32")):
+        with pytest.raises(RuntimeError, match="_Zk_good"):
+            g.check_kernel_resources(bad)
+    audit = os.path.join(ROOT, "mobrob_amd", "kernel_resources.txt")
+    if os.path.exists(audit):     # written by the build that produced the shipped library
+        lines = open(audit).read().strip().splitlines()
+        assert len(lines) > 100 and any("k_fused_train" in l for l in lines)
