@@ -1869,12 +1869,14 @@ int train_loop(mobrob_ppo_engine* e, const int64_t* perms, bool dp, mobrob_allre
   e->stats_n = 0;
   const bool kl = e->target_kl > 0.0;
   e->last_epochs_started = 0; e->last_stopped_early = 0; e->last_steps_applied = 0;
-  // 64-wide nets only: ~90 records.  At 2x256 the table has 712 records, every k_adam_pack block pays for folding
-  // them and the reduction kernel for forming them: measured 12.9 instead of 11.4 ms per iteration (A/B on one box).
-  // Never under data parallel: the records are norms of the LOCAL gradient, the clip needs those of the summed one.
+  // The reduction kernel leaves per-block (tensor, sum of squares) records and k_adam_pack folds them: no
+  // k_sqnorm_chunks launch.  (Round 2 had this for 64-wide nets only: at 2x256 the table has 712 records and the fold
+  // was one serial chain per tensor in every k_adam_pack block, 12.9 instead of 11.4 ms per iteration; the fold is now
+  // four wave reductions.)  Never under data parallel: the records are norms of the LOCAL gradient, the clip needs
+  // those of the summed one.
   struct RecordsOn {  // nothing can touch the gradient between reduction and clip inside this loop
     mobrob_ppo_engine* e;
-    RecordsOn(mobrob_ppo_engine* e_, bool dp_) : e(e_) { e->use_norm_records = !dp_ && e->fused.enabled && e->fused.H == 64 && e->target_kl <= 0.0 && getenv("MOBROB_NO_NORM_RECORDS") == nullptr; }
+    RecordsOn(mobrob_ppo_engine* e_, bool dp_) : e(e_) { e->use_norm_records = !dp_ && e->fused.enabled && e->target_kl <= 0.0 && getenv("MOBROB_NO_NORM_RECORDS") == nullptr; }
     ~RecordsOn() { e->use_norm_records = false; }
   } records_on(e, dp);
   for (int ep = 0; ep < e->cfg.n_epochs; ++ep) {

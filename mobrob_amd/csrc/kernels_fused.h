@@ -370,6 +370,9 @@ struct Lay {
 #define MOBROB_SKIP 0
 #endif
 #define PHASE_ON(bit) (!((MOBROB_SKIP) & (bit)))
+#ifndef MOBROB_DW3_INSIDE_DH2   // A/B switch: 0 = dW3 and dh2 as two phases (rounds 1-2)
+#define MOBROB_DW3_INSIDE_DH2 1
+#endif
 #ifdef MOBROB_STAMPS
 // The deltas are accumulated in (scalar) registers and flushed once at the end of the kernel: a global atomic per
 // stamp would sit in the in-order vmcnt queue in front of the next phase's weight-fragment loads and charge its own
@@ -762,25 +765,31 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     __syncthreads();
     STAMP(9)
 
-    // ---- dW3 += dout^T . h2  (M = 32 or 16 head rows, this wave's 64 columns, K = 64 rows) ----
-    if (PHASE_ON(32)) {
-      if constexpr (H16) {
-        // lane group g = lane>>4 takes batch rows kk + 4g (kk = 16s + j): LDS bank offset 16g -> conflict-free
-        const int i16 = lane & 15, g4 = 4 * (lane >> 4);
-        const int ao = opaque(L::DO + g4 * FLDO + i16);              // A[i=a][k=row] = dout[row][a]
-        const int bo = opaque(L::H2 + g4 * FLDH + 64 * wave + i16);  // B[k=row][j]  = h2[row][j], 4 column tiles
-        float x = lds[ao], y0 = lds[bo], y1 = lds[bo + 16], y2 = lds[bo + 32], y3 = lds[bo + 48];
+    // ---- dW3 += dout^T . h2  (M = 32 or 16 head rows, this wave's 64 columns, K = 64 rows) and
+    //      dh2 = dout . W3 (K = 16 or 32), then dz2 = dh2 * (1 - h2^2) in place ----
+    // Narrow heads (H16): the dh2 GEMM is two k-groups of 16 MFMAs, too short to cover the L2 latency of its own second
+    // weight fragment, and dW3 is fed from LDS only.  They are therefore issued as ONE phase: dh2 k-group 0 (fragment
+    // prefetched before the loss stage) -> request k-group 1's fragment -> the whole dW3 loop -> dh2 k-group 1, whose
+    // fragment has had 2 000 MFMA cycles to arrive (as separate phases: dW3 + dh2 ran at ~63 % of the MFMA rate).
+    auto dw3_h16 = [&]() {
+      // lane group g = lane>>4 takes batch rows kk + 4g (kk = 16s + j): LDS bank offset 16g -> conflict-free
+      const int i16 = lane & 15, g4 = 4 * (lane >> 4);
+      const int ao = opaque(L::DO + g4 * FLDO + i16);              // A[i=a][k=row] = dout[row][a]
+      const int bo = opaque(L::H2 + g4 * FLDH + 64 * wave + i16);  // B[k=row][j]  = h2[row][j], 4 column tiles
+      float x = lds[ao], y0 = lds[bo], y1 = lds[bo + 16], y2 = lds[bo + 32], y3 = lds[bo + 48];
 #pragma unroll 5
-        for (int t = 1; t < 16; ++t) {
-          const int kk = (t >> 2) * 16 + (t & 3);
-          const float xn = lds[ao + kk * FLDO];
-          const float* bk = &lds[bo + kk * FLDH];
-          const float y0n = bk[0], y1n = bk[16], y2n = bk[32], y3n = bk[48];
-          mfma16_x1y4(gW3h0, gW3h1, gW3h2, gW3h3, x, y0, y1, y2, y3);
-          x = xn; y0 = y0n; y1 = y1n; y2 = y2n; y3 = y3n;
-        }
+      for (int t = 1; t < 16; ++t) {
+        const int kk = (t >> 2) * 16 + (t & 3);
+        const float xn = lds[ao + kk * FLDO];
+        const float* bk = &lds[bo + kk * FLDH];
+        const float y0n = bk[0], y1n = bk[16], y2n = bk[32], y3n = bk[48];
         mfma16_x1y4(gW3h0, gW3h1, gW3h2, gW3h3, x, y0, y1, y2, y3);
-      } else {
+        x = xn; y0 = y0n; y1 = y1n; y2 = y2n; y3 = y3n;
+      }
+      mfma16_x1y4(gW3h0, gW3h1, gW3h2, gW3h3, x, y0, y1, y2, y3);
+    };
+    if (PHASE_ON(32)) {
+      if constexpr (!H16) {
         const int ao = opaque(L::DO + h * FLDO + r);              // A[i=a][k=row] = dout[row][a]
         const int bo = opaque(L::H2 + h * FLDH + 64 * wave + r);  // B[k=row][j]  = h2[row][j]
         float x = lds[ao], y0 = lds[bo], y1 = lds[bo + 32];
@@ -791,16 +800,34 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
           x = xn; y0 = y0n; y1 = y1n;
         }
         mfma_x1y2(gW3a, gW3b, x, y0, y1);
+      } else if (!MOBROB_DW3_INSIDE_DH2) {
+        dw3_h16();
       }
     }
     STAMP(10)
-    // ---- dh2 = dout . W3 (K = 16 or 32), then dz2 = dh2 * (1 - h2^2) in place ----
     {
       f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
-      if (PHASE_ON(64))
-        gemm_lds_packed<FLDO>(L::DO, W.W3b + (size_t)(2 * wave) * 4 * 64, W.W3b + (size_t)(2 * wave + 1) * 4 * 64,
-                              H16 ? 2 : 4,  // k-groups of 8: head columns beyond `head` are zero padding
-                              c00, c01, c10, c11, lane, fh2);
+      if (PHASE_ON(64)) {
+        if constexpr (H16 && MOBROB_DW3_INSIDE_DH2) {
+          const f32x4* Bp0 = W.W3b + (size_t)(2 * wave) * 4 * 64;
+          const f32x4* Bp1 = W.W3b + (size_t)(2 * wave + 1) * 4 * 64;
+          const int ab = 4 * opaque((L::DO + r * FLDO + 4 * h) >> 2);
+          const unsigned bo = opaque_u((unsigned)lane * 16u);
+          const f32x4 pA = fh2.p, qA = fh2.q;
+          const f32x4 pB = ldg16(Bp0, bo + 1024u), qB = ldg16(Bp1, bo + 1024u);
+          const f32x4 uA = *reinterpret_cast<const f32x4*>(&lds[ab]);
+          const f32x4 vA = *reinterpret_cast<const f32x4*>(&lds[ab + 32 * FLDO]);
+          const f32x4 uB = *reinterpret_cast<const f32x4*>(&lds[ab + 8]);
+          const f32x4 vB = *reinterpret_cast<const f32x4*>(&lds[ab + 32 * FLDO + 8]);
+          MFMA_KG(uA, vA, pA, qA)
+          if (PHASE_ON(32)) dw3_h16();
+          MFMA_KG(uB, vB, pB, qB)
+        } else {
+          gemm_lds_packed<FLDO>(L::DO, W.W3b + (size_t)(2 * wave) * 4 * 64, W.W3b + (size_t)(2 * wave + 1) * 4 * 64,
+                                H16 ? 2 : 4,  // k-groups of 8: head columns beyond `head` are zero padding
+                                c00, c01, c10, c11, lane, fh2);
+        }
+      }
       STAMP(11)
       __syncthreads();  // every wave is done reading h2 (dW3) before it is overwritten
       STAMP(12)
@@ -1546,13 +1573,15 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
   if (i < a.P) { g_in = a.g[i]; m_in = a.m[i]; v_in = a.v[i]; p_in = a.p[i]; }
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.st.stats_row != nullptr) stats_row_from_sums(a.st);  // pre-update log_std
   if (a.fold_idx != nullptr) {  // norm records of the reduction kernel, listed per tensor by the host
-    const int nrec = a.fold_start[13];
-    for (int c = threadIdx.x; c < nrec; c += blockDim.x) part[c] = a.partial[a.fold_idx[c]];
-    __syncthreads();
-    if (threadIdx.x < 13) {
+    // Wave w folds tensors w, w + 4, w + 8, w + 12: lane l adds records l, l + 64, ... of the tensor's list in list order,
+    // then a fixed butterfly over the lanes -- one fixed summation tree per tensor, so the norm is reproducible, and
+    // hundreds of records (2 x 256: 712) cost four short wave reductions instead of a 256-long serial chain.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int t = wv; t < 13; t += 4) {
       double ts = 0.0;
-      for (int c = a.fold_start[threadIdx.x]; c < a.fold_start[threadIdx.x + 1]; ++c) ts += part[c];
-      nts[threadIdx.x] = (float)sqrt(ts);
+      for (int c = a.fold_start[t] + lane; c < a.fold_start[t + 1]; c += 64) ts += a.partial[a.fold_idx[c]];
+      ts = wave_sum_d(ts);
+      if (lane == 0) nts[t] = (float)sqrt(ts);
     }
   } else {
     for (int c = threadIdx.x; c < a.nchunks; c += blockDim.x) {  // one parallel round trip; the serial fold below is LDS only
