@@ -32,6 +32,16 @@
 
 namespace mobrob {
 
+// timing-only ablation (never in the product build): -DPAIR_SKIP=<mask>
+//   1 loss operands are constants (no actions / advantage / old log-prob gathers)   2 no exp / division in the loss stage
+//   4 no loss stage at all (dL/d(head) = head)   8 no exp / rcp in the tanh epilogues   16 no observation gathers
+//   32 no weight-gradient MFMAs (dW3, dW2, dW1)   64 no bias-gradient column sums   128 no dtanh read-modify-write
+//   256 no tile loop (fixed cost of a launch)   512 no slab staging / stores at the end
+#ifndef PAIR_SKIP
+#define PAIR_SKIP 0
+#endif
+#define PAIR_ON(bit) (!((PAIR_SKIP) & (bit)))
+
 template <int DP>
 struct LayP64 {
   static constexpr int LDX = DP + 4;
@@ -86,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
   Frags<8> f2;
   if (kF2Resident) f2 = load_frags<8>(W.W2f + (size_t)wave * 8 * 64, lane0);
   // (register budget of two waves per SIMD: the combinations below were the ones the compiler spilled on)
-  constexpr bool kFhResident = DP < 48 && !(DP == 32 && NJ > 6);
+  constexpr bool kFhResident = DP < 48 && NJ <= 10 && !(DP == 32 && NJ > 4);
   Frags<4> fh;  // head k-groups wave, wave + 2, wave + 4, wave + 6 (tile64_forward's chains `acc` / `acc2`)
   if (kFhResident) {
 #pragma unroll
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
 #else
 #define PSTAMP(k)
 #endif
-  for (int it = 0, tile = seq; it < niter; ++it, tile += nseq) {  // a tile >= ntiles has no live row: it adds exact zeros
+  for (int it = 0, tile = seq; it < (PAIR_ON(256) ? niter : 0); ++it, tile += nseq) {  // a tile >= ntiles has no live row: it adds exact zeros
     const int lane = opaque(lane0) & 63;
     const int r = lane & 31, h = lane >> 5;
     const int row0 = tile * GR, nrow0 = (tile + nseq) * GR;
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
       gemm_one<ldx, NKG1>(lb + L::X, f1, c, lane);
       const int o = opaque(lb + L::H1 + 4 * h * GLDH + 32 * wave + r);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) lds[o + crc(i) * GLDH] = fast_tanh_scaled(c[i]);
+      for (int i = 0; i < 16; ++i) lds[o + crc(i) * GLDH] = PAIR_ON(8) ? fast_tanh_scaled(c[i]) : 0.25f * c[i];
     }
     PSTAMP(12)  // layer 1 alone
     // operands of the loss stage (wave 0, two lanes per row; the row index came one tile ahead): in flight during layer 2 and the head
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
     // one): a select on a loaded value would make the wave wait for HBM right here; the loss stage masks by itself.
     float l_adv = 0.f, l_old = 0.f, l_act[NJ];
     int lsrc_next = 0;
-    if (wave == 0) {
+    if (wave == 0 && PAIR_ON(1)) {
       const unsigned src = llive ? (unsigned)lsrc : 0u;
       if (net == 0) {
         const float* arow = a.actions + (size_t)src * a.A;
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
       gemm_one<GLDH, 8>(lb + L::H1, f2, c, lane);
       const int o = opaque(lb + L::H2 + 4 * h * GLDH + 32 * wave + r);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) lds[o + crc(i) * GLDH] = fast_tanh_scaled(c[i]);
+      for (int i = 0; i < 16; ++i) lds[o + crc(i) * GLDH] = PAIR_ON(8) ? fast_tanh_scaled(c[i]) : 0.25f * c[i];
     }
     __syncthreads();
     PSTAMP(3)  // barrier after layer 2
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
     PSTAMP(4)  // head
     __syncthreads();
     PSTAMP(5)
-    if (wave == 0) {  // loss: two lanes per row (q = action parity); dL/d(head) -> DO, zero padded   (tile64_train's stage)
+    if (wave == 0 && PAIR_ON(4)) {  // loss: two lanes per row (q = action parity); dL/d(head) -> DO, zero padded   (tile64_train's stage)
       const int rr = r, q = h;
       const bool live = llive;
       const int db = opaque(lb + L::DO + rr * FLDO + q);
@@ -292,9 +302,9 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
         float g_logp = 0.f;
         if (live) {
           float adv = l_adv;
-          if (a.normalize && adv_on) adv = (adv - adv_mean) / (adv_sd + 1e-8f);
+          if (a.normalize && adv_on && PAIR_ON(2)) adv = (adv - adv_mean) / (adv_sd + 1e-8f);
           const float log_ratio = lp - l_old;
-          const float ratio = expf(log_ratio);
+          const float ratio = PAIR_ON(2) ? expf(log_ratio) : 1.0f + log_ratio;
           const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
           const float s1 = adv * ratio, s2 = adv * fminf(fmaxf(ratio, lo), hi);
           if (q == 0) {
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
     for (int u = 0; u < NG; ++u) {
       const int c = (tid0 + u * 128) % per;
       xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (nsrc[u] >= 0) xr[u] = ldg16(a.obs, (unsigned)nsrc[u] * (unsigned)(DP * 4) + (unsigned)(c * 16));
+      if (nsrc[u] >= 0 && PAIR_ON(16)) xr[u] = ldg16(a.obs, (unsigned)nsrc[u] * (unsigned)(DP * 4) + (unsigned)(c * 16));
     }
     PSTAMP(6)  // loss (wave 0) + backward fragment / next-row loads
     __syncthreads();
@@ -366,20 +376,21 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
       const int ao = opaque(lb + L::DO + h * FLDO + r);
       const int bo = opaque(lb + L::H2 + h * GLDH + 32 * wave + r);
 #pragma unroll 4
-      for (int k = 0; k < GR; k += 2) gW3 = MFMA32(lds[ao + k * FLDO], lds[bo + k * GLDH], gW3);
+      for (int k = 0; k < (PAIR_ON(32) ? GR : 0); k += 2) gW3 = MFMA32(lds[ao + k * FLDO], lds[bo + k * GLDH], gW3);
       f32x16 c = zero16();
       gemm_one<FLDO, 4>(lb + L::DO, b3, c, lane, nkh);
       const int o = opaque(lb + L::H2 + 4 * h * GLDH + 32 * wave + r);
+      // bias gradient of layer 2 (column 32*wave + r): the lane holds 16 of the column's 32 rows of dz2 in registers
+      // right here -- summed in four chains as they are produced, the two row halves added across lanes; no LDS re-read
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float hv = lds[o + crc(i) * GLDH];
-        lds[o + crc(i) * GLDH] = c[i] * (1.0f - hv * hv);
+        const float hv = PAIR_ON(128) ? lds[o + crc(i) * GLDH] : 0.5f;
+        const float dz = c[i] * (1.0f - hv * hv);
+        lds[o + crc(i) * GLDH] = dz;
+        if (PAIR_ON(64)) { if ((i & 3) == 0) s0 += dz; else if ((i & 3) == 1) s1 += dz; else if ((i & 3) == 2) s2 += dz; else s3 += dz; }
       }
-      // bias gradient of layer 2: column 32*wave + r; half h takes the rows of its parity, the halves are added
-      const int ob = opaque(lb + L::H2 + h * GLDH + 32 * wave + r);
-      float s = 0.f;
-#pragma unroll 4
-      for (int rr = 0; rr < GR; rr += 2) s += lds[ob + rr * GLDH];
+      float s = (s0 + s1) + (s2 + s3);
       s += __shfl_xor(s, 32, 64);
       gb2 += s;
     }
@@ -390,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
       const int ao = opaque(lb + L::H2 + h * GLDH + r);
       const int bo = opaque(lb + L::H1 + h * GLDH + 32 * wave + r);
 #pragma unroll 4
-      for (int k = 0; k < GR; k += 2) {
+      for (int k = 0; k < (PAIR_ON(32) ? GR : 0); k += 2) {
         const float y = lds[bo + k * GLDH];
         gW2a = MFMA32(lds[ao + k * GLDH], y, gW2a);
         gW2b = MFMA32(lds[ao + k * GLDH + 32], y, gW2b);
@@ -410,15 +421,16 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
         gemm_one<GLDH, 8>(lb + L::H2, b2, c, lane);
       }
       const int o = opaque(lb + L::H1 + 4 * h * GLDH + 32 * wave + r);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // bias gradient of layer 1, from registers like layer 2's
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const float hv = lds[o + crc(i) * GLDH];
-        lds[o + crc(i) * GLDH] = c[i] * (1.0f - hv * hv);
+        const float dz = c[i] * (1.0f - hv * hv);
+        lds[o + crc(i) * GLDH] = dz;
+        if (PAIR_ON(64)) { if ((i & 3) == 0) s0 += dz; else if ((i & 3) == 1) s1 += dz; else if ((i & 3) == 2) s2 += dz; else s3 += dz; }
       }
       const int ob = opaque(lb + L::H1 + h * GLDH + 32 * wave + r);
-      float s = 0.f;
-#pragma unroll 4
-      for (int rr = 0; rr < GR; rr += 2) s += lds[ob + rr * GLDH];
+      float s = (s0 + s1) + (s2 + s3);
       s += __shfl_xor(s, 32, 64);
       gb1 += s;
       // dW1: own dz1 block x (X columns 0..31 | 32..)
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
       const int c1 = (32 + r < DP) ? 32 + r : c0;
       const int x0 = opaque(lb + L::X + h * ldx + c0), x1 = opaque(lb + L::X + h * ldx + c1);
 #pragma unroll 4
-      for (int k = 0; k < GR; k += 2) {
+      for (int k = 0; k < (PAIR_ON(32) ? GR : 0); k += 2) {
         const float xv = lds[ob + k * GLDH];
         gW1a = MFMA32(xv, lds[x0 + k * ldx], gW1a);
         if (two) gW1c = MFMA32(xv, lds[x1 + k * ldx], gW1c);
@@ -473,12 +485,17 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
   __syncthreads();  // every wave has read what it needs from its tile region
   float* stage = &lds[0];  // [s64_size()] floats: spans the first pair's region and the head of the second one's
   float* slab = a.slabs + (size_t)(2 * bseq + net) * s64_size();
-  auto put = [&](int region, int t, const f32x16& acc) {
+  // Each pair FINALISES half of the slab: pair 0 the dW2 tiles of dz2 block 0, the dW1 tiles of input block 0 and the
+  // small vectors; pair 1 the dW2 tiles of dz2 block 1, the second dW1 tiles and dW3.  Pass 0: every pair lays the half it
+  // does NOT finalise out in LDS (slab layout); pass 1: it adds what the other pair staged to its own registers and stores.
+  // Both pairs work in both passes (round 2: the second pair staged everything while the first waited, then the first
+  // added and stored everything: 5.5 us of a 12 us fixed cost per launch).  own + staged is the same sum as before.
+  auto put = [&](bool stage_it, int region, int t, const f32x16& acc) {
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       const int o = region + ((t * 4 + qd) * 64 + lane) * 4;
       f32x4 v = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
-      if (pr == 1) {
+      if (stage_it) {
         *reinterpret_cast<f32x4*>(&stage[o]) = v;
       } else {
         const f32x4 w = *reinterpret_cast<const f32x4*>(&stage[o]);
@@ -486,31 +503,33 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
       }
     }
   };
-  auto put1 = [&](int o, float v) {
-    if (pr == 1) stage[o] = v;
+  auto put1 = [&](bool stage_it, int o, float v) {
+    if (stage_it) stage[o] = v;
     else slab[o] = v + stage[o];
   };
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {  // pass 0: the second pair stages; pass 1: the first pair adds and stores
+  for (int pass = 0; pass < (PAIR_ON(512) ? 2 : 0); ++pass) {
     if (pass == 1) __syncthreads();
-    if (pr != 1 - pass) continue;
-    // dW2[n][j]: neuron block ib = which dz2 block (a: 0, b: 1), input block jb = wave
-    put(s64_w2(), 0 * 2 + wave, gW2a);
-    put(s64_w2(), 1 * 2 + wave, gW2b);
-    // dW1[n][j]: neuron block ib = wave, input block jb (a/b: 0, c/d: 1)
-    put(s64_w1(), wave * 2 + 0, gW1a);
-    if (two) put(s64_w1(), wave * 2 + 1, gW1c);
-    put(s64_w3(), wave, gW3);
-    if (lane < 32) {
-      put1(s64_b2() + 32 * wave + lane, gb2);
-      put1(s64_b1() + 32 * wave + lane, gb1);
-    }
-    if (wave == 0) {
-      if (lane < 4) put1(s64_st() + lane, lane == 0 ? t0 : (lane == 1 ? t1 : (lane == 2 ? t2 : t3)));
-      if ((lane & 31) < 16) {
-        put1(s64_b3() + 2 * (lane & 31) + (lane >> 5), out_m);
-        put1(s64_ls() + 2 * (lane & 31) + (lane >> 5), out_l);
+    // half A (finalised by pair 0) is staged by pair 1 in pass 0; half B the other way round
+    const bool doA = (pass == 0) == (pr == 1), st = pass == 0;
+    if (doA) {
+      put(st, s64_w2(), 0 * 2 + wave, gW2a);   // dW2[n][j]: neuron block ib = which dz2 block (a: 0, b: 1), input block jb = wave
+      put(st, s64_w1(), wave * 2 + 0, gW1a);   // dW1[n][j]: neuron block ib = wave, input block jb (a: 0, c: 1)
+      if (lane < 32) {
+        put1(st, s64_b2() + 32 * wave + lane, gb2);
+        put1(st, s64_b1() + 32 * wave + lane, gb1);
       }
+      if (wave == 0) {
+        if (lane < 4) put1(st, s64_st() + lane, lane == 0 ? t0 : (lane == 1 ? t1 : (lane == 2 ? t2 : t3)));
+        if ((lane & 31) < 16) {
+          put1(st, s64_b3() + 2 * (lane & 31) + (lane >> 5), out_m);
+          put1(st, s64_ls() + 2 * (lane & 31) + (lane >> 5), out_l);
+        }
+      }
+    } else {
+      put(st, s64_w2(), 1 * 2 + wave, gW2b);
+      if (two) put(st, s64_w1(), wave * 2 + 1, gW1c);
+      put(st, s64_w3(), wave, gW3);
     }
   }
 }
