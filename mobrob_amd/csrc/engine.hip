@@ -1275,7 +1275,7 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
     ProfScope ps(e, MOBROB_K_ENV);
     for (int t0 = 0; t0 < T; t0 += chunk) {
       a.t0 = t0; a.t1 = std::min(T, t0 + chunk);
-      FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout_persistent<DPc>), dim3(rblocks), dim3(FTHREADS),
+      FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout_persistent<DPc>), dim3(rblocks), dim3(kRolloutThreads),
                                                rollout_lds_bytes(Dp), e->stream, a));
       if (overlap && a.t1 < T) {  // observations [t0, t1) are final: value them on the side stream
         hipEvent_t ev = e->ev_chunks[t0 / chunk];

@@ -56,19 +56,28 @@ struct LayRo {
   static constexpr int AC = BL + 4 + 64;    // per-action constants: sd[32] | 2 sd^2 [32] | log sd [32] | b3[32]
   static constexpr int ZN = AC + 128;       // [32][32] standard normals of the current step
   static constexpr int TM = ZN + 32 * 32;   // [32][33] log-prob terms of the current step
-  static constexpr int END = TM + 32 * 33;
+  static constexpr int EN = TM + 32 * 33;   // [32][DP] standard normals of the env phase (observation noise) ...
+  static constexpr int ET = EN + 32 * DP;   // [32][DP] ... and of the reset observation of rows that finish an episode
+  static constexpr int END = ET + 32 * DP;
 };
 inline size_t rollout_lds_bytes(int Dp) {
-  return fused_lds_act_bytes(Dp) + (size_t)(32 * 33 + 32 * 16 + 68 + 128 + 32 * 32 + 32 * 33) * sizeof(float);
+  return fused_lds_act_bytes(Dp) + (size_t)(32 * 33 + 32 * 16 + 68 + 128 + 32 * 32 + 32 * 33 + 2 * 32 * Dp) * sizeof(float);
 }
+// The workgroup is EIGHT waves: four run the policy forward / sampling / env rules of the tile (one per SIMD, as before),
+// four "noise waves" (the second wave of every SIMD) draw the step's random numbers -- Philox4x32-10 + Box-Muller for
+// the sampling normals and for the observation noise of the env phase, 1 100 draws per step and tile -- into LDS
+// while the matrix pipe runs the hidden-layer GEMMs of the same step.  Same counters, same values as before (and as the
+// per-step kernels); the draws used to sit in front of the GEMMs and inside the env phase: 2.9 of 15.2 us per step.
+constexpr int kRolloutThreads = 2 * FTHREADS;
 
 template <int DP>
-__global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs a) {
+__global__ __launch_bounds__(kRolloutThreads) void k_rollout_persistent(RolloutArgs a) {
   using L = LayRo<DP>;
   using LB = Lay32<DP>;
   constexpr int ldx = LB::LDX, per = DP / 4, R = 32;
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const bool noise_wave = wave >= 4;  // wave-uniform
   const FusedNet W = a.pi;
   const int row0 = blockIdx.x * R;
   const int N = a.N, A = a.A, D = a.D;
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
     lds[L::AC + 64 + tid0] = logf(sd);
     lds[L::AC + 96 + tid0] = bb;
   }
-  for (int i = tid0; i < R * per; i += FTHREADS) {
+  for (int i = tid0; i < R * per; i += kRolloutThreads) {
     const int rr = i / per, c = i - rr * per;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (row0 + rr < N)
@@ -112,17 +121,39 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
   for (int t = a.t0; t < a.t1; ++t) {
     const int tid = opaque(tid0), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
-    if (ROLL_ON(1)) {  // standard normals of this step (independent of the forward pass: drawn first, consumed after the head)
-      const int ngrp = (A + 3) >> 2;
-      for (int i = tid; i < R * ngrp; i += FTHREADS) {
-        const int rr_ = i / ngrp, gq = i - rr_ * ngrp;
-        float z[4];
-        box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)gq, (uint32_t)t + dbase, 0x45505331u, (uint32_t)a.seed,
-                                  (uint32_t)(a.seed >> 32)), z);
+    if (noise_wave) {  // the step's random numbers, under the GEMMs of the other four waves; then keep the barriers' count
+      const int hid = tid - FTHREADS;
+      const uint32_t step = sbase + (uint32_t)t;
+      if (ROLL_ON(1)) {  // standard normals of the sampling stage (consumed after the head)
+        const int ngrp = (A + 3) >> 2;
+        for (int i = hid; i < R * ngrp; i += FTHREADS) {
+          const int rr_ = i / ngrp, gq = i - rr_ * ngrp;
+          float z[4];
+          box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)gq, (uint32_t)t + dbase, 0x45505331u, (uint32_t)a.seed,
+                                    (uint32_t)(a.seed >> 32)), z);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds[L::ZN + rr_ * 32 + 4 * gq + j] = z[j];
+          for (int j = 0; j < 4; ++j) lds[L::ZN + rr_ * 32 + 4 * gq + j] = z[j];
+        }
       }
-    }
+      __syncthreads();  // (1) after layer 1: the env phase of the previous step has long finished reading EN / ET
+      if (ROLL_ON(16)) {  // observation noise of the env phase: the step's draw and the reset draw of rows that end an episode
+        for (int i = hid; i < R * per; i += FTHREADS) {
+          const int rr_ = i / per, c = i - rr_ * per;
+          if (row0 + rr_ < N) {
+            float z[4];
+            box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)c, step, kStreamEnvObs, ek0, ek1), z);
+            *reinterpret_cast<f32x4*>(&lds[L::EN + rr_ * DP + 4 * c]) = f32x4{z[0], z[1], z[2], z[3]};
+            box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
+            *reinterpret_cast<f32x4*>(&lds[L::ET + rr_ * DP + 4 * c]) = f32x4{z[0], z[1], z[2], z[3]};
+          }
+        }
+      }
+      __syncthreads();  // (2) after layer 2
+      __syncthreads();  // (3) after the head
+      __syncthreads();  // (4) after the sampling stage
+      __syncthreads();  // (5) after the env phase
+      __syncthreads();  // (6) after the state update
+    } else {
     {  // layer 1
       f32x16 c0 = splat16(W.b1s[64 * wave + r]), c1 = splat16(W.b1s[64 * wave + 32 + r]);
       constexpr int nkg = DP / 8;
@@ -220,15 +251,14 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
         done = term || tr;
         ep_len_new = done ? 0 : len;
         for (int c = sub; c < per; c += 8) {
-          float z[4];
-          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, ek0, ek1), z);
+          f32x4 z = *reinterpret_cast<const f32x4*>(&lds[L::EN + rr * DP + 4 * c]);  // drawn by the noise waves
           f32x4 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
           if (tr) {
             reinterpret_cast<f32x4*>(a.term_obs)[(size_t)n * per + c] = o;
             *reinterpret_cast<f32x4*>(&trow[4 * c]) = o;
-            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
+            z = *reinterpret_cast<const f32x4*>(&lds[L::ET + rr * DP + 4 * c]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
           }
@@ -249,14 +279,18 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
         if (done) goal_reset(gn, a.goal, o.reached, (uint32_t)n, step, ek0, ek1);
         for (int c = sub; c < per; c += 8) {
           float z[4];
-          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, ek0, ek1), z);
+          {
+            const f32x4 zz = *reinterpret_cast<const f32x4*>(&lds[L::EN + rr * DP + 4 * c]);  // drawn by the noise waves
+            z[0] = zz[0]; z[1] = zz[1]; z[2] = zz[2]; z[3] = zz[3];
+          }
           f32x4 ob = goal_features(g, a.goal.P, D, c, z, a.goal.noise);
           if (done) {
             if (tr) {
               reinterpret_cast<f32x4*>(a.term_obs)[(size_t)n * per + c] = ob;
               *reinterpret_cast<f32x4*>(&trow[4 * c]) = ob;
             }
-            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
+            const f32x4 zz = *reinterpret_cast<const f32x4*>(&lds[L::ET + rr * DP + 4 * c]);
+            z[0] = zz[0]; z[1] = zz[1]; z[2] = zz[2]; z[3] = zz[3];
             ob = goal_features(gn, a.goal.P, D, c, z, a.goal.noise);
           }
           if (ROLL_ON(128)) reinterpret_cast<f32x4*>(a.obs)[onext + c] = ob;
@@ -289,7 +323,9 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_rollout_persistent(RolloutArgs 
       }
     }
     __syncthreads();
-    // ---- time-limit bootstrap of the (rare) truncated rows: r += gamma * V(terminal_obs) ----
+    }  // (policy waves)
+    // ---- time-limit bootstrap of the (rare) truncated rows: r += gamma * V(terminal_obs).  All eight waves (the value MLP
+    //      of a row is a block-wide routine with its own barriers; the noise waves hold no hidden unit and add zeros) ----
     const int m = *cnt;
     for (int q = 0; q < m; ++q) {
       const int br = lrow[q];
