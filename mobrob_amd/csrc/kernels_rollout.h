@@ -56,18 +56,18 @@ struct LayRo {
   static constexpr int AC = BL + 4 + 64;    // per-action constants: sd[32] | 2 sd^2 [32] | log sd [32] | b3[32]
   static constexpr int ZN = AC + 128;       // [32][32] standard normals of the current step
   static constexpr int TM = ZN + 32 * 32;   // [32][33] log-prob terms of the current step
-  static constexpr int EN = TM + 32 * 33;   // [32][DP] standard normals of the env phase (observation noise) ...
-  static constexpr int ET = EN + 32 * DP;   // [32][DP] ... and of the reset observation of rows that finish an episode
-  static constexpr int END = ET + 32 * DP;
+  static constexpr int EN = TM + 32 * 33;   // [32][DP] standard normals of the env phase (observation noise)
+  static constexpr int END = EN + 32 * DP;
 };
 inline size_t rollout_lds_bytes(int Dp) {
-  return fused_lds_act_bytes(Dp) + (size_t)(32 * 33 + 32 * 16 + 68 + 128 + 32 * 32 + 32 * 33 + 2 * 32 * Dp) * sizeof(float);
+  return fused_lds_act_bytes(Dp) + (size_t)(32 * 33 + 32 * 16 + 68 + 128 + 32 * 32 + 32 * 33 + 32 * Dp) * sizeof(float);
 }
 // The workgroup is EIGHT waves: four run the policy forward / sampling / env rules of the tile (one per SIMD, as before),
 // four "noise waves" (the second wave of every SIMD) draw the step's random numbers -- Philox4x32-10 + Box-Muller for
-// the sampling normals and for the observation noise of the env phase, 1 100 draws per step and tile -- into LDS
+// the sampling normals and for the observation noise of the env phase, 600 draws per step and tile -- into LDS
 // while the matrix pipe runs the hidden-layer GEMMs of the same step.  Same counters, same values as before (and as the
 // per-step kernels); the draws used to sit in front of the GEMMs and inside the env phase: 2.9 of 15.2 us per step.
+// (The second draw of a row that ends an episode -- its reset observation -- stays with the policy waves: rare.)
 constexpr int kRolloutThreads = 2 * FTHREADS;
 
 template <int DP>
@@ -136,15 +136,13 @@ __global__ __launch_bounds__(kRolloutThreads) void k_rollout_persistent(RolloutA
         }
       }
       __syncthreads();  // (1) after layer 1: the env phase of the previous step has long finished reading EN / ET
-      if (ROLL_ON(16)) {  // observation noise of the env phase: the step's draw and the reset draw of rows that end an episode
+      if (ROLL_ON(16)) {  // observation noise of the env phase
         for (int i = hid; i < R * per; i += FTHREADS) {
           const int rr_ = i / per, c = i - rr_ * per;
           if (row0 + rr_ < N) {
             float z[4];
             box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)c, step, kStreamEnvObs, ek0, ek1), z);
             *reinterpret_cast<f32x4*>(&lds[L::EN + rr_ * DP + 4 * c]) = f32x4{z[0], z[1], z[2], z[3]};
-            box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
-            *reinterpret_cast<f32x4*>(&lds[L::ET + rr_ * DP + 4 * c]) = f32x4{z[0], z[1], z[2], z[3]};
           }
         }
       }
@@ -258,9 +256,10 @@ __global__ __launch_bounds__(kRolloutThreads) void k_rollout_persistent(RolloutA
           if (tr) {
             reinterpret_cast<f32x4*>(a.term_obs)[(size_t)n * per + c] = o;
             *reinterpret_cast<f32x4*>(&trow[4 * c]) = o;
-            z = *reinterpret_cast<const f32x4*>(&lds[L::ET + rr * DP + 4 * c]);
+            float zt[4];
+            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), zt);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
+            for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? zt[j] : 0.f;
           }
           if (ROLL_ON(128)) reinterpret_cast<f32x4*>(a.obs)[onext + c] = o;
           *reinterpret_cast<f32x4*>(&xrow[4 * c]) = o;
@@ -289,8 +288,7 @@ __global__ __launch_bounds__(kRolloutThreads) void k_rollout_persistent(RolloutA
               reinterpret_cast<f32x4*>(a.term_obs)[(size_t)n * per + c] = ob;
               *reinterpret_cast<f32x4*>(&trow[4 * c]) = ob;
             }
-            const f32x4 zz = *reinterpret_cast<const f32x4*>(&lds[L::ET + rr * DP + 4 * c]);
-            z[0] = zz[0]; z[1] = zz[1]; z[2] = zz[2]; z[3] = zz[3];
+            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
             ob = goal_features(gn, a.goal.P, D, c, z, a.goal.noise);
           }
           if (ROLL_ON(128)) reinterpret_cast<f32x4*>(a.obs)[onext + c] = ob;
