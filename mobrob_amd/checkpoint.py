@@ -247,7 +247,7 @@ def load_zip(path):
 # ---------------------------------------------------------------------------------------------------
 def save_zip(path, *, params, optimizer, hyper, obs_dim, act_dim, net_arch=None, counters=None, last_obs=None,
              last_episode_starts=None, ep_info_buffer=None, action_low=-1.0, action_high=1.0, verbose=1, seed=0,
-             tensorboard_log=None, obs_low=None, obs_high=None):
+             tensorboard_log=None, obs_low=None, obs_high=None, extra_policy_kwargs=None):
     """Write an SB3-2.0.0-layout zip.  `hyper` carries n_steps, batch_size, n_epochs, gamma, gae_lambda,
     ent_coef, vf_coef, max_grad_norm, learning_rate, clip_range, n_envs; `optimizer` = dict(exp_avg, exp_avg_sq,
     step, lr, betas, eps) with per-key arrays.  obs_low / obs_high: the bounds of `env.observation_space` (what
@@ -268,6 +268,7 @@ def save_zip(path, *, params, optimizer, hyper, obs_dim, act_dim, net_arch=None,
     if last_episode_starts is None:
         last_episode_starts = np.zeros((n_envs,), bool)
     policy_kwargs = {} if net_arch is None else {"net_arch": {"pi": list(net_arch[0]), "vf": list(net_arch[1])}}
+    policy_kwargs.update(extra_policy_kwargs or {})  # JSON-able ones the user passed: log_std_init, ortho_init, optimizer_kwargs
     data = OrderedDict()
     data["policy_class"] = _blob("<class 'abc.ABCMeta'>", pickle_policy_class(),
                                  __module__="stable_baselines3.common.policies")

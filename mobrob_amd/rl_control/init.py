@@ -21,6 +21,28 @@ def _orthogonal(rng, rows, cols, gain):
     return (gain * q[:rows, :cols]).astype(np.float32)
 
 
+def default_linear_init(rng, rows, cols):
+    """torch.nn.Linear.reset_parameters (what SB3 leaves in place with `ortho_init=False`): kaiming_uniform_(a=sqrt(5)) on
+    the weight and U(-1/sqrt(fan_in), 1/sqrt(fan_in)) on the bias -- both U(-b, b) with b = 1/sqrt(fan_in)."""
+    b = 1.0 / math.sqrt(cols)
+    return (rng.uniform(-b, b, (rows, cols)).astype(np.float32), rng.uniform(-b, b, rows).astype(np.float32))
+
+
+def policy_init(obs_dim, act_dim, pi=(64, 64), vf=(64, 64), seed=0, log_std_init=0.0, ortho_init=True):
+    """ActorCriticPolicy._build: `ortho_init=True` (SB3's default) -> orthogonal_policy_init; False -> torch's default
+    nn.Linear initialisation of every layer.  `log_std_init` fills the state-independent log standard deviation."""
+    if ortho_init:
+        return orthogonal_policy_init(obs_dim, act_dim, pi, vf, seed, log_std_init)
+    rng = np.random.default_rng(seed)
+    p = OrderedDict()
+    p["log_std"] = np.full((act_dim,), log_std_init, np.float32)
+    for name, rows, cols in (("mlp_extractor.policy_net.0", pi[0], obs_dim), ("mlp_extractor.policy_net.2", pi[1], pi[0]),
+                             ("mlp_extractor.value_net.0", vf[0], obs_dim), ("mlp_extractor.value_net.2", vf[1], vf[0]),
+                             ("action_net", act_dim, pi[1]), ("value_net", 1, vf[1])):
+        p[name + ".weight"], p[name + ".bias"] = default_linear_init(rng, rows, cols)
+    return p
+
+
 def orthogonal_policy_init(obs_dim, act_dim, pi=(64, 64), vf=(64, 64), seed=0, log_std_init=0.0):
     rng = np.random.default_rng(seed)
     p = OrderedDict()

@@ -27,7 +27,7 @@ from ..envs.native_env import NativeGoalVecEnv
 from ..envs.shm_vec_env import ShmVecEnv
 from ..envs.wrapper import ROBOT_DIMS, get_env
 from ..utils import DATA_DIR
-from .init import orthogonal_policy_init
+from .init import orthogonal_policy_init, policy_init
 
 try:
     import tensorboard  # noqa: F401
@@ -200,10 +200,31 @@ class PPO:
         if isinstance(net_arch, (list, tuple)):
             net_arch = dict(pi=list(net_arch), vf=list(net_arch))
         self.net_arch = (tuple(net_arch.get("pi", [64, 64])), tuple(net_arch.get("vf", [64, 64])))
-        unknown = set(self.policy_kwargs) - {"net_arch"}
+        # SB3 ActorCriticPolicy keyword arguments beyond the reference YAMLs' `net_arch` (the reference splats
+        # `ppo_kwargs` into PPO verbatim, /root/reference/src/mobrob/rl_control/ppo.py:58):
+        #   log_std_init     initial value of the state-independent log standard deviation (default 0.0)
+        #   ortho_init       True (default): orthogonal weights with SB3's gains; False: torch's nn.Linear default
+        #   optimizer_kwargs Adam's `eps` / `betas` (SB3 passes eps=1e-5 itself); `optimizer_class` must stay Adam
+        #   activation_fn    Tanh only (nn.Tanh or its name): every kernel's epilogue is tanh
+        self.log_std_init = float(self.policy_kwargs.get("log_std_init", 0.0))
+        self.ortho_init = bool(self.policy_kwargs.get("ortho_init", True))
+        opt_kw = dict(self.policy_kwargs.get("optimizer_kwargs") or {})
+        self.adam_eps = float(opt_kw.pop("eps", 1e-5))
+        self.adam_betas = tuple(float(b) for b in opt_kw.pop("betas", (0.9, 0.999)))
+        if opt_kw.pop("weight_decay", 0.0) or opt_kw.pop("amsgrad", False) or opt_kw:
+            raise NotImplementedError("optimizer_kwargs other than `eps` and `betas` are not supported (Adam without weight "
+                                      "decay or amsgrad, SB3's default optimiser)")
+        act = self.policy_kwargs.get("activation_fn")
+        if act is not None and getattr(act, "__name__", str(act)).lower() not in ("tanh",):
+            raise NotImplementedError(f"activation_fn {act!r}: only Tanh (SB3's default for MlpPolicy) is implemented")
+        oc = self.policy_kwargs.get("optimizer_class")
+        if oc is not None and getattr(oc, "__name__", str(oc)) != "Adam":
+            raise NotImplementedError(f"optimizer_class {oc!r}: only Adam is implemented")
+        unknown = set(self.policy_kwargs) - {"net_arch", "log_std_init", "ortho_init", "optimizer_kwargs", "activation_fn",
+                                             "optimizer_class"}
         if unknown:
-            raise NotImplementedError(f"policy_kwargs {sorted(unknown)} are not supported (MlpPolicy with tanh, "
-                                      "ortho_init, two hidden layers per network)")
+            raise NotImplementedError(f"policy_kwargs {sorted(unknown)} are not supported (MlpPolicy, two hidden layers per "
+                                      "network)")
         self.num_timesteps = 0
         self._total_timesteps = 0
         self._num_timesteps_at_start = 0
@@ -243,7 +264,8 @@ class PPO:
                   batch_size=self.batch_size, n_epochs=self.n_epochs, pi=self.net_arch[0], vf=self.net_arch[1],
                   gamma=self.gamma, gae_lambda=self.gae_lambda, clip_range=self.clip_range, ent_coef=self.ent_coef,
                   vf_coef=self.vf_coef, max_grad_norm=self.max_grad_norm, learning_rate=self.learning_rate,
-                  normalize_advantage=self.normalize_advantage, seed=0 if self.seed is None else int(self.seed))
+                  normalize_advantage=self.normalize_advantage, seed=0 if self.seed is None else int(self.seed),
+                  adam_betas=self.adam_betas, adam_eps=self.adam_eps)
         # data parallel: under torchrun / an initialised process group every rank owns its n_envs
         # environments and rollout shard; batch_size stays SB3's GLOBAL minibatch and must divide by the world size
         from ..parallel import distributed_context
@@ -254,8 +276,9 @@ class PPO:
         self.engine = PPOEngine(**kw)
         self.engine.set_hyper(clip_range_vf=self.clip_range_vf, target_kl=self.target_kl)
         self._backend = None
-        self.engine.set_params(orthogonal_policy_init(self.obs_dim, self.act_dim, self.net_arch[0], self.net_arch[1],
-                                                      seed=0 if self.seed is None else int(self.seed)))
+        self.engine.set_params(policy_init(self.obs_dim, self.act_dim, self.net_arch[0], self.net_arch[1],
+                                           seed=0 if self.seed is None else int(self.seed),
+                                           log_std_init=self.log_std_init, ortho_init=self.ortho_init))
         self.policy = ActorCriticPolicyHandle(self)
 
     def get_env(self):
@@ -517,7 +540,7 @@ class PPO:
             os.makedirs(d, exist_ok=True)
         explicit_arch = "net_arch" in self.policy_kwargs
         save_zip(path, params=self.engine.get_params(),
-                 optimizer=dict(exp_avg=m, exp_avg_sq=v, step=step, lr=self.learning_rate, betas=(0.9, 0.999), eps=1e-5),
+                 optimizer=dict(exp_avg=m, exp_avg_sq=v, step=step, lr=self.learning_rate, betas=self.adam_betas, eps=self.adam_eps),
                  hyper=self._hyper(), obs_dim=self.obs_dim, act_dim=self.act_dim,
                  net_arch=self.net_arch if explicit_arch else None,
                  counters=dict(num_timesteps=self.num_timesteps, _total_timesteps=self._total_timesteps,
@@ -528,7 +551,9 @@ class PPO:
                  ep_info_buffer=list(self.ep_info_buffer), verbose=self.verbose, seed=self.seed,
                  tensorboard_log=self.tensorboard_log,
                  obs_low=None if self.obs_bounds is None else self.obs_bounds[0],
-                 obs_high=None if self.obs_bounds is None else self.obs_bounds[1])
+                 obs_high=None if self.obs_bounds is None else self.obs_bounds[1],
+                 extra_policy_kwargs={k: (list(v) if isinstance(v, tuple) else v) for k, v in self.policy_kwargs.items()
+                                      if k in ("log_std_init", "ortho_init", "optimizer_kwargs")})
 
     @classmethod
     def load(cls, path, env=None, device="auto", custom_objects=None, print_system_info=False, force_reset=True,

@@ -71,3 +71,22 @@ def test_synthetic_vec_env_statistics():
         n_done += dones.sum()
         n_trunc += sum(1 for i in np.nonzero(dones)[0] if infos[i]["TimeLimit.truncated"])
     assert 0.5 < n_done / (200 * 256 / 40.0) < 1.5 and n_trunc > 0
+
+
+def test_policy_init_variants():
+    """ActorCriticPolicy._build options reachable through `policy_kwargs` (the reference splats ppo_kwargs into SB3's PPO,
+    /root/reference/src/mobrob/rl_control/ppo.py:58): `log_std_init`, `ortho_init`."""
+    import numpy as np
+    from mobrob_amd.rl_control.init import policy_init
+    p = policy_init(14, 2, (64, 64), (64, 64), seed=3, log_std_init=-0.7, ortho_init=True)
+    assert np.allclose(p["log_std"], -0.7) and not p["mlp_extractor.policy_net.0.bias"].any()
+    w = p["mlp_extractor.policy_net.2.weight"].astype(np.float64)
+    assert np.allclose(w @ w.T, 2.0 * np.eye(64), atol=1e-5)                  # orthogonal, gain sqrt(2)
+    q = policy_init(14, 2, (64, 64), (64, 64), seed=3, log_std_init=0.25, ortho_init=False)
+    assert list(q) == list(p) and np.allclose(q["log_std"], 0.25)
+    for k, v in q.items():                                                     # torch's nn.Linear default: U(-1/sqrt(fan_in), +)
+        if k == "log_std":
+            continue
+        fan_in = q[k.replace("bias", "weight")].shape[1]
+        assert np.abs(v).max() <= 1.0 / np.sqrt(fan_in) + 1e-7 and (v.size < 16 or np.abs(v).max() > 0.5 / np.sqrt(fan_in)), k
+    assert q["mlp_extractor.value_net.0.bias"].any()

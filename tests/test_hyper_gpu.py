@@ -137,3 +137,42 @@ def test_schedules_and_kwargs_through_ppo(tmp_path):
         PPO("MlpPolicy", env, clip_range_vf=-1.0)
     with pytest.raises(NotImplementedError):
         PPO("MlpPolicy", env, use_sde=True)
+
+
+def test_policy_kwargs_beyond_net_arch(tmp_path):
+    """`policy_kwargs` of SB3's ActorCriticPolicy that the HIP engine honours: log_std_init, ortho_init, optimizer_kwargs
+    (Adam's eps / betas reach the kernel: one update follows the oracle with the same values), and a save / load round trip
+    keeps them.  Anything the kernels cannot do is refused by name."""
+    from mobrob_amd.envs.vec_env import DeviceGoalVecEnv
+    from mobrob_amd.rl_control.ppo import PPO
+    env = DeviceGoalVecEnv.for_robot("point", 32, time_limit=50)
+    pk = dict(net_arch=dict(pi=[64, 64], vf=[64, 64]), log_std_init=-0.5, ortho_init=False,
+              optimizer_kwargs=dict(eps=1e-3, betas=(0.8, 0.95)), activation_fn="Tanh")
+    ppo = PPO("MlpPolicy", env, n_steps=16, batch_size=128, n_epochs=2, policy_kwargs=pk, seed=4)
+    p0 = ppo.engine.get_params()
+    assert np.allclose(p0["log_std"], -0.5) and p0["mlp_extractor.policy_net.0.bias"].any()     # not the zero-bias ortho init
+    assert abs(ppo.engine.cfg.adam_eps - 1e-3) < 1e-12 and abs(ppo.engine.cfg.adam_beta1 - 0.8) < 1e-12
+    # one update on an injected rollout: the engine's Adam uses the given eps / betas (oracle with the same ones agrees,
+    # the oracle with SB3's defaults does not)
+    D, A, T, N = ppo.obs_dim, ppo.act_dim, 16, 32
+    buf, lv, dones = _consistent_rollout(p0, T, N, D, A, seed=9)
+    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, 0.99, 0.95)
+    ppo.engine.load_rollout(buf, lv, dones)
+    perms = np.stack([np.random.default_rng(e).permutation(T * N) for e in range(2)])
+    ppo.engine.train(perms)
+    got = ppo.engine.get_params()
+    want = {k: v.copy() for k, v in p0.items()}
+    O.train(want, O.AdamState.zeros_like(want), buf, O.Hyper(n_epochs=2, batch_size=128, adam_eps=1e-3, beta1=0.8, beta2=0.95), perms)
+    other = {k: v.copy() for k, v in p0.items()}
+    O.train(other, O.AdamState.zeros_like(other), buf, O.Hyper(n_epochs=2, batch_size=128), perms)
+    err = max(float(np.max(np.abs(got[k] - want[k]))) for k in want)
+    assert err < 1e-4 and max(float(np.max(np.abs(got[k] - other[k]))) for k in want) > 10 * max(err, 1e-6)
+    path = str(tmp_path / "kw.zip")
+    ppo.save(path)
+    again = PPO.load(path)
+    assert again.log_std_init == -0.5 and again.ortho_init is False and again.adam_eps == 1e-3 and again.adam_betas == (0.8, 0.95)
+    assert all(np.array_equal(again.engine.get_params()[k], got[k]) for k in got)
+    for bad in (dict(activation_fn="ReLU"), dict(optimizer_kwargs=dict(weight_decay=0.1)), dict(optimizer_class="SGD"),
+                dict(share_features_extractor=False)):
+        with pytest.raises(NotImplementedError):
+            PPO("MlpPolicy", env, policy_kwargs=bad)
