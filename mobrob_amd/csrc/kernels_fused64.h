@@ -741,52 +741,54 @@ __global__ __launch_bounds__(256) void k_slab64_reduce(Slab64ReduceArgs s) {
   }
 }
 
-// The same reduction for MANY slabs per network (k_pair64_train: up to 512): four groups of 256 threads take a quarter
-// of the slabs each (sixteen loads in flight per thread), the quarters are added in fixed order, and the first group
-// finishes as k_slab64_reduce does (entropy term, store, norm records: same 256 positions per block, same record table).
+// The same reduction for MANY slabs per network (k_pair64_train: up to 256 per network).  82 workgroups cover the slab, so
+// what matters is the number of BYTES each of them keeps in flight: sixteen groups of 64 threads split the slabs sixteen ways,
+// every thread owns four consecutive positions and issues 16-byte loads (round 2: four groups of 256 threads with 4-byte
+// loads, 2.2 TB/s = the latency bound of 64 outstanding 256-byte wave loads per wave; now 4x the bytes per load).  The
+// sixteen partial sums of a position are added in group order, then threads 0..255 finish as k_slab64_reduce does
+// (entropy term, store, norm records: same 256 positions per block, same record table).
 __global__ __launch_bounds__(1024) void k_slab64_reduce_wide(Slab64ReduceArgs s) {
-  __shared__ float part[4][256];
-  const int tp = threadIdx.x & 255, q = threadIdx.x >> 8;
-  const int p = blockIdx.x * 256 + tp;
+  __shared__ float part[16][256];
+  const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int net = blockIdx.y;
-  if (p == 0 && net == 0 && q == 0) s.sums[4] = s.b_local;
-  const int dst = p < s64_size() ? slab64_to_canonical(s, net, p) : -1;
-  float sum = 0.f;
-  if (dst >= 0) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const float* src = s.slabs + (size_t)net * s64_size() + p;
-    const size_t stride = 2 * (size_t)s64_size();
-    const int nslabs = (s.nblocks - net + 1) / 2;
-    const int per = (nslabs + 3) / 4;
-    int w = q * per;
-    const int n = min(nslabs, w + per);
-    for (; w + 16 <= n; w += 16) {
-      float x[16];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && net == 0) s.sums[4] = s.b_local;
+  {
+    const int p4 = blockIdx.x * 256 + 4 * l;  // s64_size() is a multiple of 4: a quad is inside the slab or outside it
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    if (p4 < s64_size()) {
+      const float* src = s.slabs + (size_t)net * s64_size() + p4;
+      const size_t stride = 2 * (size_t)s64_size();
+      const int nslabs = (s.nblocks - net + 1) / 2;
+      const int per = (nslabs + 15) / 16;
+      int w = g * per;
+      const int n = min(nslabs, w + per);
+      for (; w + 8 <= n; w += 8) {
+        f32x4 x[8];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) x[u] = src[(size_t)(w + u) * stride];
+        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(w + u) * stride);
 #pragma unroll
-      for (int u = 0; u < 16; u += 4) {
-        a0 += x[u];
-        a1 += x[u + 1];
-        a2 += x[u + 2];
-        a3 += x[u + 3];
+        for (int u = 0; u < 8; u += 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a0[e] += x[u][e]; a1[e] += x[u + 1][e]; }
+        }
+      }
+      for (; w < n; ++w) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(src + (size_t)w * stride);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a0[e] += x[e];
       }
     }
-    for (; w + 4 <= n; w += 4) {
-      a0 += src[(size_t)w * stride];
-      a1 += src[(size_t)(w + 1) * stride];
-      a2 += src[(size_t)(w + 2) * stride];
-      a3 += src[(size_t)(w + 3) * stride];
-    }
-    for (; w < n; ++w) a0 += src[(size_t)w * stride];
-    sum = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[g][4 * l + e] = a0[e] + a1[e];
   }
-  part[q][tp] = sum;
   __syncthreads();
-  if (q > 0) return;  // waves 4..15 are done; the barrier inside block_norm_records counts the four that remain
+  if (threadIdx.x >= 256) return;  // waves 4..15 are done; the barrier inside block_norm_records counts the four that remain
+  const int tp = threadIdx.x, p = blockIdx.x * 256 + tp;
+  const int dst = p < s64_size() ? slab64_to_canonical(s, net, p) : -1;
   float acc = 0.f;
   if (dst >= 0) {
-    acc = ((part[0][tp] + part[1][tp]) + part[2][tp]) + part[3][tp];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc += part[q][tp];
     if (dst < s.offs[1]) acc += s.ent_coef * (-s.b_local) * s.inv_bg;
     s.grads[dst] = acc;
   }
