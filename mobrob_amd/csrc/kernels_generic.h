@@ -530,7 +530,10 @@ struct AdvStatArgs {
   unsigned* absmax_next;                // ... and the word the next epoch will use, zeroed by this one
   unsigned long long* bins;             // [nmb][2] two's-complement sums
 };
-__global__ __launch_bounds__(256) void k_adv_absmax(AdvStatArgs a) {
+// (one atomic per WORKGROUP on the max word and per non-empty bin: atomics on one address retire at ~12 ns each, so the
+//  grids are at most one workgroup per CU -- 4 096 wave-level atomicMax calls were 49 us of a 50 us kernel)
+__global__ __launch_bounds__(1024) void k_adv_absmax(AdvStatArgs a) {
+  __shared__ float wmax[16];
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
   for (int i = tid; i < 2 * a.nmb; i += nth) a.bins[i] = 0ull;
   if (tid == 0) *a.absmax_next = 0u;
@@ -543,7 +546,12 @@ __global__ __launch_bounds__(256) void k_adv_absmax(AdvStatArgs a) {
   for (int i = 4 * n4 + tid; i < a.total; i += nth) m = fmaxf(m, fabsf(a.adv[i]));
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(a.absmax_bits, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, wmax[w]);
+    if (m > 0.f) atomicMax(a.absmax_bits, __float_as_uint(m));
+  }
 }
 // power-of-two scales: |adv| < 2^e, so |adv * 2^(s1)| < 2^(61 - log2ceil(bl)) and a minibatch of bl elements sums below 2^61
 __device__ __forceinline__ void adv_scales(unsigned absmax_bits, int bl, int& s1, int& s2) {
@@ -553,7 +561,7 @@ __device__ __forceinline__ void adv_scales(unsigned absmax_bits, int bl, int& s1
   s1 = 61 - lb - e;
   s2 = 61 - lb - 2 * e;
 }
-__global__ __launch_bounds__(256) void k_adv_stats_stream(AdvStatArgs a) {
+__global__ __launch_bounds__(1024) void k_adv_stats_stream(AdvStatArgs a) {
   extern __shared__ unsigned long long adv_bins_lds[];
   const bool use_lds = a.nmb <= kAdvLdsMinibatches;
   if (use_lds)
