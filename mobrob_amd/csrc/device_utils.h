@@ -163,6 +163,22 @@ __host__ __device__ __forceinline__ uint64_t feistel_perm_inv(uint64_t v, uint64
   } while (v >= n);
   return v;
 }
+// the same in 32-bit arithmetic for domains of at most 2^30 positions (half_bits <= 15): what the streaming
+// advantage-statistics pass runs per element
+__host__ __device__ __forceinline__ uint32_t feistel_perm_inv32(uint32_t v, uint32_t n, int half_bits, uint32_t k0,
+                                                                uint32_t k1) {
+  const uint32_t mask = (1u << half_bits) - 1u;
+  do {
+    uint32_t l = (v >> half_bits) & mask, r = v & mask;
+#pragma unroll
+    for (int rnd = 5; rnd >= 0; --rnd) {
+      const uint32_t pl = r ^ feistel_rf(l, rnd, k0, k1, mask);
+      r = l; l = pl;
+    }
+    v = (l << half_bits) | r;
+  } while (v >= n);
+  return v;
+}
 __host__ __device__ inline int feistel_half_bits(uint64_t n) {
   int bits = 0;
   uint64_t m = n > 1 ? n - 1 : 1;

@@ -571,13 +571,15 @@ __global__ __launch_bounds__(1024) void k_adv_stats_stream(AdvStatArgs a) {
   const double f1 = ldexp(1.0, s1), f2 = ldexp(1.0, s2);
   __syncthreads();
   unsigned long long* bins = use_lds ? adv_bins_lds : a.bins;
-  auto add = [&](int row, float x) {
+  // (the pass is VALU bound, not memory bound: everything per element is 32-bit -- total <= 2^30 -- and the storage row
+  //  is split into (step, env) once per quad of consecutive rows)
+  auto add = [&](int row, int t, int n, float x) {
     int mb;
     if (a.mb_of_row) {
       mb = a.mb_of_row[2 * (size_t)row + 1];
     } else {
-      const int t = row / a.N, n = row - t * a.N;
-      mb = (int)(feistel_perm_inv((uint64_t)n * (uint64_t)a.T + (uint64_t)t, (uint64_t)a.total, a.half_bits, a.k0, a.k1) / (uint64_t)a.bl);
+      const uint32_t pos = feistel_perm_inv32((uint32_t)n * (uint32_t)a.T + (uint32_t)t, (uint32_t)a.total, a.half_bits, a.k0, a.k1);
+      mb = (int)(pos / (uint32_t)a.bl);
     }
     const double xd = (double)x;
     const long long q1 = __double2ll_rn(xd * f1), q2 = __double2ll_rn(xd * xd * f2);
@@ -588,11 +590,15 @@ __global__ __launch_bounds__(1024) void k_adv_stats_stream(AdvStatArgs a) {
   const int n4 = a.total >> 2;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
     const f32x4 v = reinterpret_cast<const f32x4*>(a.adv)[i];
+    int t = (int)((uint32_t)(4 * i) / (uint32_t)a.N), n = 4 * i - t * a.N;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) add(4 * i + j, v[j]);
+    for (int j = 0; j < 4; ++j) {
+      add(4 * i + j, t, n, v[j]);
+      if (++n == a.N) { n = 0; ++t; }
+    }
   }
   if (blockIdx.x == 0)
-    for (int i = 4 * n4 + threadIdx.x; i < a.total; i += blockDim.x) add(i, a.adv[i]);
+    for (int i = 4 * n4 + threadIdx.x; i < a.total; i += blockDim.x) add(i, i / a.N, i % a.N, a.adv[i]);
   if (use_lds) {
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * a.nmb; i += blockDim.x) {

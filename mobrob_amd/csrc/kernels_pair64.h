@@ -42,6 +42,16 @@ namespace mobrob {
 #endif
 #define PAIR_ON(bit) (!((PAIR_SKIP) & (bit)))
 
+// Head fragments resident in registers for the launch?  256 registers per wave is the budget of two waves per SIMD; the
+// exceptions are the (observation width, action pairs) combinations the compiler spilled on with them resident
+// (__graft_entry__.build() fails on a spill, so this table is checked by every build).
+constexpr bool pair64_fh_resident(int DP, int NJ) {
+  if (DP >= 64) return false;
+  if (DP == 48) return NJ == 1 || NJ == 4 || NJ >= 10;
+  if (DP == 32) return NJ <= 4;
+  return NJ <= 10;
+}
+
 template <int DP>
 struct LayP64 {
   static constexpr int LDX = DP + 4;
@@ -95,8 +105,7 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
   constexpr bool kF2Resident = DP <= 32;  // wider observations need the registers (next tile's rows, a fifth accumulator tile)
   Frags<8> f2;
   if (kF2Resident) f2 = load_frags<8>(W.W2f + (size_t)wave * 8 * 64, lane0);
-  // (register budget of two waves per SIMD: the combinations below were the ones the compiler spilled on)
-  constexpr bool kFhResident = DP < 48 && NJ <= 10 && !(DP == 32 && NJ > 4);
+  constexpr bool kFhResident = pair64_fh_resident(DP, NJ);
   Frags<4> fh;  // head k-groups wave, wave + 2, wave + 4, wave + 6 (tile64_forward's chains `acc` / `acc2`)
   if (kFhResident) {
 #pragma unroll
