@@ -745,10 +745,12 @@ __global__ __launch_bounds__(256) void k_slab64_reduce(Slab64ReduceArgs s) {
 // what matters is the number of BYTES each of them keeps in flight: sixteen groups of 64 threads split the slabs sixteen ways,
 // every thread owns four consecutive positions and issues 16-byte loads (round 2: four groups of 256 threads with 4-byte
 // loads, 2.2 TB/s = the latency bound of 64 outstanding 256-byte wave loads per wave; now 4x the bytes per load).  The
-// sixteen partial sums of a position are added in group order, then threads 0..255 finish as k_slab64_reduce does
-// (entropy term, store, norm records: same 256 positions per block, same record table).
+// sixteen partial sums of a position are added in a fixed order -- groups g and g + 8 first, then the eight pairs in
+// group order -- then threads 0..255 finish as k_slab64_reduce does (entropy term, store, norm records: same 256 positions
+// per block, same record table).  8 KB of LDS, not 16: beside two k_pair64_train workgroups of ANOTHER fleet segment
+// (152 KB of a CU's 160) a 16 KB block does not fit, and the fleet's three update streams stopped overlapping (+5 %).
 __global__ __launch_bounds__(1024) void k_slab64_reduce_wide(Slab64ReduceArgs s) {
-  __shared__ float part[16][256];
+  __shared__ float part[8][256];
   const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int net = blockIdx.y;
   if (blockIdx.x == 0 && threadIdx.x == 0 && net == 0) s.sums[4] = s.b_local;
@@ -778,8 +780,15 @@ __global__ __launch_bounds__(1024) void k_slab64_reduce_wide(Slab64ReduceArgs s)
         for (int e = 0; e < 4; ++e) a0[e] += x[e];
       }
     }
+    if (g >= 8) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) part[g][4 * l + e] = a0[e] + a1[e];
+      for (int e = 0; e < 4; ++e) part[g - 8][4 * l + e] = a0[e] + a1[e];
+    }
+    __syncthreads();
+    if (g < 8) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part[g][4 * l + e] = (a0[e] + a1[e]) + part[g][4 * l + e];
+    }
   }
   __syncthreads();
   if (threadIdx.x >= 256) return;  // waves 4..15 are done; the barrier inside block_norm_records counts the four that remain
@@ -788,7 +797,7 @@ __global__ __launch_bounds__(1024) void k_slab64_reduce_wide(Slab64ReduceArgs s)
   float acc = 0.f;
   if (dst >= 0) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc += part[q][tp];
+    for (int q = 0; q < 8; ++q) acc += part[q][tp];
     if (dst < s.offs[1]) acc += s.ent_coef * (-s.b_local) * s.inv_bg;
     s.grads[dst] = acc;
   }
