@@ -1559,7 +1559,7 @@ int mobrob_ppo_epoch_begin(mobrob_ppo_engine_t* e, const int64_t* perm) {
   }
   // advantage statistics: one coalesced pass in storage order, order-independent integer sums (kernels_generic.h)
   const int sgrid = std::max(1, std::min(256, cdiv(total, 4 * 1024)));  // at most one workgroup per CU (see k_adv_absmax)
-  const size_t slds = e->nmb <= kAdvLdsMinibatches ? (size_t)2 * e->nmb * sizeof(unsigned long long) : 0;
+  const size_t slds = e->nmb <= kAdvLdsMinibatches ? (size_t)2 * e->nmb * adv_bin_replicas(e->nmb) * sizeof(unsigned long long) : 0;
   hipLaunchKernelGGL(k_adv_absmax, dim3(sgrid), dim3(1024), 0, e->stream, as);
   hipLaunchKernelGGL(k_adv_stats_stream, dim3(sgrid), dim3(1024), slds, e->stream, as);
   hipLaunchKernelGGL(k_adv_fold, dim3(cdiv(e->nmb, 64)), dim3(64), 0, e->stream, as, e->advstat);

@@ -1573,15 +1573,26 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
   if (i < a.P) { g_in = a.g[i]; m_in = a.m[i]; v_in = a.v[i]; p_in = a.p[i]; }
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.st.stats_row != nullptr) stats_row_from_sums(a.st);  // pre-update log_std
   if (a.fold_idx != nullptr) {  // norm records of the reduction kernel, listed per tensor by the host
-    // Wave w folds tensors w, w + 4, w + 8, w + 12: lane l adds records l, l + 64, ... of the tensor's list in list order,
-    // then a fixed butterfly over the lanes -- one fixed summation tree per tensor, so the norm is reproducible, and
-    // hundreds of records (2 x 256: 712) cost four short wave reductions instead of a 256-long serial chain.
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int t = wv; t < 13; t += 4) {
-      double ts = 0.0;
-      for (int c = a.fold_start[t] + lane; c < a.fold_start[t + 1]; c += 64) ts += a.partial[a.fold_idx[c]];
-      ts = wave_sum_d(ts);
-      if (lane == 0) nts[t] = (float)sqrt(ts);
+    const int nrec = a.fold_start[13];
+    if (nrec <= 128) {  // 64-wide nets (~90 records): one lane per tensor, thirteen short serial folds side by side
+      for (int c = threadIdx.x; c < nrec; c += blockDim.x) part[c] = a.partial[a.fold_idx[c]];
+      __syncthreads();
+      if (threadIdx.x < 13) {
+        double ts = 0.0;
+        for (int c = a.fold_start[threadIdx.x]; c < a.fold_start[threadIdx.x + 1]; ++c) ts += part[c];
+        nts[threadIdx.x] = (float)sqrt(ts);
+      }
+    } else {
+      // 2 x 256 (712 records): wave w folds tensors w, w + 4, w + 8, w + 12 -- lane l adds records l, l + 64, ... of the
+      // tensor's list in list order, then a fixed butterfly over the lanes: one fixed summation tree per tensor, and four
+      // short wave reductions instead of a 256-long serial chain (what made this lose to k_sqnorm_chunks in round 2).
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      for (int t = wv; t < 13; t += 4) {
+        double ts = 0.0;
+        for (int c = a.fold_start[t] + lane; c < a.fold_start[t + 1]; c += 64) ts += a.partial[a.fold_idx[c]];
+        ts = wave_sum_d(ts);
+        if (lane == 0) nts[t] = (float)sqrt(ts);
+      }
     }
   } else {
     for (int c = threadIdx.x; c < a.nchunks; c += blockDim.x) {  // one parallel round trip; the serial fold below is LDS only

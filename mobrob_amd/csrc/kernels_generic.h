@@ -522,6 +522,9 @@ __global__ void k_perm_feistel(int total, int T, int N, int half_bits, uint32_t 
 //   k_adv_fold     integers -> (sum, sumsq, count) in float64
 // ------------------------------------------------------------------------------------------------
 constexpr int kAdvLdsMinibatches = 2048;  // LDS bins (32 KB); beyond that the adds go straight to the global bins
+// LDS atomics on ONE address serialise, and 64 lanes that fall into 32-63 minibatches collide on almost every instruction:
+// the bins are replicated, lane l adds to replica l & (R - 1) (integer sums: any split adds up to the same bits)
+__host__ __device__ inline int adv_bin_replicas(int nmb) { return nmb <= 256 ? 8 : 1; }
 struct AdvStatArgs {
   const float* adv; int total, T, N, bl, nmb;
   int half_bits; uint32_t k0, k1;       // Feistel permutation of this epoch ...
@@ -564,13 +567,14 @@ __device__ __forceinline__ void adv_scales(unsigned absmax_bits, int bl, int& s1
 __global__ __launch_bounds__(1024) void k_adv_stats_stream(AdvStatArgs a) {
   extern __shared__ unsigned long long adv_bins_lds[];
   const bool use_lds = a.nmb <= kAdvLdsMinibatches;
+  const int R = adv_bin_replicas(a.nmb);
   if (use_lds)
-    for (int i = threadIdx.x; i < 2 * a.nmb; i += blockDim.x) adv_bins_lds[i] = 0ull;
+    for (int i = threadIdx.x; i < 2 * a.nmb * R; i += blockDim.x) adv_bins_lds[i] = 0ull;
   int s1, s2;
   adv_scales(*a.absmax_bits, a.bl, s1, s2);
   const double f1 = ldexp(1.0, s1), f2 = ldexp(1.0, s2);
   __syncthreads();
-  unsigned long long* bins = use_lds ? adv_bins_lds : a.bins;
+  unsigned long long* bins = use_lds ? adv_bins_lds + (size_t)(threadIdx.x & (R - 1)) * 2 * a.nmb : a.bins;
   // (the pass is VALU bound, not memory bound: everything per element is 32-bit -- total <= 2^30 -- and the storage row
   //  is split into (step, env) once per quad of consecutive rows)
   auto add = [&](int row, int t, int n, float x) {
@@ -602,7 +606,8 @@ __global__ __launch_bounds__(1024) void k_adv_stats_stream(AdvStatArgs a) {
   if (use_lds) {
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * a.nmb; i += blockDim.x) {
-      const unsigned long long v = adv_bins_lds[i];
+      unsigned long long v = 0ull;
+      for (int q = 0; q < R; ++q) v += adv_bins_lds[(size_t)q * 2 * a.nmb + i];
       if (v != 0ull) atomicAdd(&a.bins[i], v);
     }
   }
