@@ -1639,7 +1639,7 @@ void fill_adam_pack_args(mobrob_ppo_engine* e, AdamPackArgs& a) {
     a.fW3f[n] = on ? (float*)e->fused.net[n].W3f : nullptr;
     a.fW2b[n] = on ? (float*)e->fused.net[n].W2b : nullptr;
     a.fW3b[n] = on ? (float*)e->fused.net[n].W3b : nullptr;
-    a.fW3h[n] = (on && e->fused.H == FH && (n == 1 || e->fused.A <= 16)) ? (float*)e->fused.net[n].W3h : nullptr;
+    a.fW3h[n] = (on && (n == 1 || e->fused.A <= 16)) ? (float*)e->fused.net[n].W3h : nullptr;
     a.fb1s[n] = on ? (float*)e->fused.net[n].b1s : nullptr;
     a.fb2s[n] = on ? (float*)e->fused.net[n].b2s : nullptr;
   }

@@ -1674,7 +1674,7 @@ inline void fused_repack(FusedState& f, const float* params, const int* offs, hi
     fwd(params + offs[w1[n]], H, D, D, f.net[n].W1f, H / 32, Dp / 8, kTanhScale);
     fwd(params + offs[w2[n]], H, H, H, f.net[n].W2f, H / 32, H / 8, kTanhScale);
     fwd(params + offs[w3[n]], heads[n], H, H, f.net[n].W3f, 1, H / 8, 1.0f);
-    if (H == FH && heads[n] <= 16)
+    if (heads[n] <= 16)  // 16x16x4 pack of narrow heads: k_fused_train<.., true> and k_pair64_train (NJ <= 6)
       hipLaunchKernelGGL(k_pack_h16, dim3(H / 16), dim3(256), 0, st, params + offs[w3[n]], heads[n], H, (float*)f.net[n].W3h);
     hipLaunchKernelGGL(k_scale_copy, dim3(1), dim3(256), 0, st, params + offs[w1[n] + 1], (float*)f.net[n].b1s, H, kTanhScale);
     hipLaunchKernelGGL(k_scale_copy, dim3(1), dim3(256), 0, st, params + offs[w2[n] + 1], (float*)f.net[n].b2s, H, kTanhScale);

@@ -106,11 +106,18 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
   Frags<8> f2;
   if (kF2Resident) f2 = load_frags<8>(W.W2f + (size_t)wave * 8 * 64, lane0);
   constexpr bool kFhResident = pair64_fh_resident(DP, NJ);
-  Frags<4> fh;  // head k-groups wave, wave + 2, wave + 4, wave + 6 (tile64_forward's chains `acc` / `acc2`)
-  if (kFhResident) {
+  // Heads of <= 12 outputs (NJ <= 6; the value head has one): head GEMM and dW3 on v_mfma_f32_16x16x4_f32 -- wave w
+  // computes head rows 16w..16w+15 over the full K = 64 (no partial tile of the partner to add), dW3 is two 16x16 tiles
+  // per wave: half the matrix cycles of the zero-padded 32-wide tiles (16 of a wave's 160 MFMA32-equivalents per tile).
+  constexpr bool kH16 = NJ <= 6;
+  Frags<4> fh;  // kH16: the four 16-wide k-groups of the 16x16x4 head pack; else head k-groups wave, wave + 2, wave + 4, wave + 6
+  auto load_fh = [&](int ln) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fh.f[j] = ldg16(W.W3f, (unsigned)lane0 * 16u + (unsigned)(2 * j + wave) * 1024u);
-  }
+    for (int j = 0; j < 4; ++j)
+      fh.f[j] = kH16 ? ldg16(W.W3h, (unsigned)ln * 16u + (unsigned)j * 1024u)
+                     : ldg16(W.W3f, (unsigned)ln * 16u + (unsigned)(2 * j + wave) * 1024u);
+  };
+  if (kFhResident) load_fh(lane0);
   const float bias1 = W.b1s[32 * wave + (lane0 & 31)], bias2 = W.b2s[32 * wave + (lane0 & 31)];
   const int nkh = W.head <= 16 ? 2 : 4;
   Frags<NKG1> f1;
@@ -139,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
 
   // weight-gradient accumulators of this wave: dW2 (x0, x1) x y_wave | dW3 x y_wave | dW1 x_wave x (y0, y1)
   f32x16 gW2a = zero16(), gW2b = zero16(), gW3 = zero16(), gW1a = zero16(), gW1c = zero16();
+  f32x4 gW3h0 = {0.f, 0.f, 0.f, 0.f}, gW3h1 = gW3h0;  // kH16: dW3 [16 head rows][own 32 columns] as two 16x16 tiles
   float gb2 = 0.f, gb1 = 0.f, s_pl = 0.f, s_vl = 0.f, s_kl = 0.f, s_cf = 0.f;
   // loss stage (role 0, lane = (row r, action parity q)): per-action constants of the lane's actions k = 2j + q, and its
   // running sums of dL/d(mean) / dL/d(log_std) over the rows it has seen (reduced over the 32 rows at the end)
@@ -251,10 +259,7 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
 #pragma unroll
       for (int j = 0; j < NJ; ++j) l_act[j] = 0.f;
     }
-    if (!kFhResident) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fh.f[j] = ldg16(W.W3f, (unsigned)lane * 16u + (unsigned)(2 * j + wave) * 1024u);
-    }
+    if (!kFhResident) load_fh(lane);
     PSTAMP(1)
     __syncthreads();
     PSTAMP(2)
@@ -267,7 +272,24 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
     }
     __syncthreads();
     PSTAMP(3)  // barrier after layer 2
-    {  // head: wave 0 the even k-groups, wave 1 the odd ones; the loss stage adds the two partial tiles
+    if constexpr (kH16) {  // head rows 16 wave .. 16 wave + 15, full K, two accumulation chains
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc;
+      const int i16 = lane & 15, g = lane >> 4;
+      const int ab = 4 * opaque((lb + L::H2 + (16 * wave + i16) * GLDH + 4 * g) >> 2);
+#pragma unroll
+      for (int kg = 0; kg < 4; kg += 2) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[ab + 16 * kg]);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[ab + 16 * kg + 16]);
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+          acc = MFMA16(a0[s_], fh.f[kg][s_], acc);
+          acc2 = MFMA16(a1[s_], fh.f[kg + 1][s_], acc2);
+        }
+      }
+      const int o = opaque(lb + L::DO + (16 * wave + 4 * g) * FLDO + i16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lds[o + e * FLDO] = acc[e] + acc2[e];
+    } else {  // head: wave 0 the even k-groups, wave 1 the odd ones; the loss stage adds the two partial tiles
       f32x16 acc = zero16();
       const int ab = 4 * opaque((lb + L::H2 + r * GLDH + 4 * h) >> 2);
 #pragma unroll
@@ -302,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const float on = (2 * j + q < A && live) ? 1.f : 0.f;
-          const float d = on * (l_act[j] - ((lds[db + 2 * j] + lds[d2 + 2 * j]) + BB(j)));
+          const float d = on * (l_act[j] - ((kH16 ? lds[db + 2 * j] : lds[db + 2 * j] + lds[d2 + 2 * j]) + BB(j)));
           lp += on * (-(d * d) * (0.5f * IV(j)) - LC(j));
           dk[j] = d;
         }
@@ -352,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
         float dv = 0.f;
         if (live && q == 0) {
           float sq, gv_;
-          value_loss_terms((lds[db] + lds[d2]) + BB(0), l_old, l_adv, a.clip_vf, sq, gv_);
+          value_loss_terms((kH16 ? lds[db] : lds[db] + lds[d2]) + BB(0), l_old, l_adv, a.clip_vf, sq, gv_);
           s_vl += sq;
           dv = a.vf_coef * gv_ * a.inv_bg;
         }
@@ -384,8 +406,21 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
     {  // dW3 (own h2 block), then dh2 -> dz2 over the own block of h2 (nobody else reads that block)
       const int ao = opaque(lb + L::DO + h * FLDO + r);
       const int bo = opaque(lb + L::H2 + h * GLDH + 32 * wave + r);
+      if constexpr (kH16) {  // lane group g = lane >> 4 takes batch rows kk + 4 g: all 32 rows in eight k-steps of four
+        const int i16 = lane & 15, g4 = 4 * (lane >> 4);
+        const int a16 = opaque(lb + L::DO + g4 * FLDO + i16);               // A[i = a][k = row] = dout[row][a]
+        const int b16 = opaque(lb + L::H2 + g4 * GLDH + 32 * wave + i16);   // B[k = row][j] = h2[row][32 wave + 16 b + j]
 #pragma unroll 4
-      for (int k = 0; k < (PAIR_ON(32) ? GR : 0); k += 2) gW3 = MFMA32(lds[ao + k * FLDO], lds[bo + k * GLDH], gW3);
+        for (int t = 0; t < (PAIR_ON(32) ? 8 : 0); ++t) {
+          const int kk = (t >> 2) * 16 + (t & 3);
+          const float x = lds[a16 + kk * FLDO];
+          gW3h0 = MFMA16(x, lds[b16 + kk * GLDH], gW3h0);
+          gW3h1 = MFMA16(x, lds[b16 + kk * GLDH + 16], gW3h1);
+        }
+      } else {
+#pragma unroll 4
+        for (int k = 0; k < (PAIR_ON(32) ? GR : 0); k += 2) gW3 = MFMA32(lds[ao + k * FLDO], lds[bo + k * GLDH], gW3);
+      }
       f32x16 c = zero16();
       gemm_one<FLDO, 4>(lb + L::DO, b3, c, lane, nkh);
       const int o = opaque(lb + L::H2 + 4 * h * GLDH + 32 * wave + r);
@@ -492,6 +527,22 @@ __global__ __launch_bounds__(256, 2) void k_pair64_train(Fused64TrainArgs a, int
     }
   }
   __syncthreads();  // every wave has read what it needs from its tile region
+  if constexpr (kH16) {  // dW3 from its two 16x16 tiles into the 32x32 tile layout the slab uses (rows 16..31 are zero)
+    float* sc = &lds[lb + L::H1 + wave * (16 * 33)];  // [16 head rows][32 own columns], private to the wave
+    const int i16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sc[(4 * g + e) * 33 + i16] = gW3h0[e];
+      sc[(4 * g + e) * 33 + 16 + i16] = gW3h1[e];
+    }
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = crc(i) + 4 * h;        // compile-time crc(i): rows 0..3 | 8..11 | 16.. | 24.. (+4 for the upper lanes)
+      gW3[i] = crc(i) < 16 ? sc[row * 33 + r] : 0.f;
+    }
+    __syncthreads();  // the staging below overwrites these scratch rows
+  }
   float* stage = &lds[0];  // [s64_size()] floats: spans the first pair's region and the head of the second one's
   float* slab = a.slabs + (size_t)(2 * bseq + net) * s64_size();
   // Each pair FINALISES half of the slab: pair 0 the dW2 tiles of dz2 block 0, the dW1 tiles of input block 0 and the
