@@ -1529,6 +1529,9 @@ __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, fl
   a.m[i] = m;
   a.v[i] = v;
   a.p[i] = pn;
+#ifdef ADAM_NO_PACK  // timing-only ablation: what the scattered pack stores cost
+  return;
+#endif
   int t = 0;
 #pragma unroll
   for (int k = 1; k < 13; ++k) t += (i >= a.offs[k]) ? 1 : 0;

@@ -101,3 +101,49 @@ def test_fleet_errors():
         MixedFleet(["car", "submarine"], n_envs=4, **KW)
     with pytest.raises(ValueError):
         MixedFleet([], **KW)
+
+
+def test_full_size_fleet_arena_equals_standalone_engines_and_the_oracle():
+    """BASELINE config 5 at the size bench.py runs it (3 x 1024 envs x 2048 steps, 2x64 nets, minibatch 65 536, one 1.75 GB
+    arena): after a rollout and one epoch on three overlapping streams every segment holds the same BITS as a stand-alone
+    engine with the same arguments, and its first full-size minibatch gradient follows the oracle (float64 accumulation)."""
+    from mobrob_amd.engine import PPOEngine
+    from mobrob_amd.fleet import ROBOT_DIMS, ROBOT_P_TERM, MixedFleet
+    kw = dict(n_steps=2048, batch_size=65536, n_epochs=1, ent_coef=0.01)
+    f = MixedFleet(NAMES, n_envs=1024, seed=7, **kw)
+    assert f.arena_bytes > 1.5e9
+    ps = []
+    for i, s in enumerate(f.segments):
+        p = O.init_params(s.obs_dim, s.act_dim, seed=30 + i)
+        p["log_std"] = np.full(s.act_dim, -0.3, np.float32)
+        ps.append(p)
+        s.engine.set_params(p)
+    f.collect_synthetic(time_limit=1000)
+    f.synchronize()
+    h = O.Hyper(n_epochs=1, batch_size=65536, ent_coef=0.01)
+    rng = np.random.default_rng(2)
+    for i, s in enumerate(f.segments):                       # one full-size minibatch gradient per segment vs the oracle
+        e = s.engine
+        T, N = e.T, e.N
+        buf = {k: e.read(k) for k in ("actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns")}
+        buf["obs"] = e.read("obs")[:T]
+        perm = rng.permutation(T * N)
+        e.epoch_begin(perm)
+        e.minibatch_grad(0)
+        got = e.unflatten(e.read("grads"))
+        _, og, _ = O.loss_and_grads(ps[i], *O.gather_minibatch(buf, perm[:65536]), h, acc=np.float64)
+        for k in og:
+            assert scaled_err(got[k], og[k]) < 1e-4, (s.name, k, scaled_err(got[k], og[k]))
+        e.set_params(ps[i])                                  # (re-packs the weights; the pending gradient is dropped by the next epoch)
+    f.train_enqueue()                                        # the three updates overlap on their streams
+    f.synchronize()
+    for i, s in enumerate(f.segments):
+        d, a = ROBOT_DIMS[s.name]
+        e = PPOEngine(obs_dim=d, act_dim=a, n_envs=1024, seed=7 + i, **kw)
+        e.set_params(ps[i])
+        e.collect_synthetic(p_term=ROBOT_P_TERM[s.name], time_limit=1000)
+        assert np.array_equal(e.read("advantages"), s.engine.read("advantages")), s.name
+        e.train(None)                                        # (a host permutation does not advance the device draw counter)
+        assert np.array_equal(e.get_flat_params(), s.engine.get_flat_params()), s.name
+        e.close()
+    f.close()
