@@ -68,16 +68,52 @@ inline size_t rollout_lds_bytes(int Dp) {
 // while the matrix pipe runs the hidden-layer GEMMs of the same step.  Same counters, same values as before (and as the
 // per-step kernels); the draws used to sit in front of the GEMMs and inside the env phase: 2.9 of 15.2 us per step.
 // (The second draw of a row that ends an episode -- its reset observation -- stays with the policy waves: rare.)
-constexpr int kRolloutThreads = 2 * FTHREADS;
+// MOBROB_ROLLOUT_STATIONARY (default 1): the other plan for the same kernel -- FOUR waves, one per SIMD with all 512 registers
+// of a lane, and the policy's weights STATIONARY in them for the whole launch: wave w holds the fragment packs of its 64
+// columns of W1 (2 x DP/8 x 4 registers), W2 (2 x 32 x 4 = 256) and its K-slice of the head (32): no weight byte crosses the
+// L2 <-> CU path in the step loop (round 1-2: 340 KB of fragments per tile and step, 2.9 TB/s chip-wide, and a latency the
+// 4-deep prefetch ring only just covered).  Same MFMA sequence per accumulator, same bits.  The noise waves need the second
+// wave slot of every SIMD and therefore exclude this plan; A/B in DESIGN.md 4.2.
+#ifndef MOBROB_ROLLOUT_STATIONARY
+#define MOBROB_ROLLOUT_STATIONARY 1
+#endif
+constexpr bool kRolloutStationary = MOBROB_ROLLOUT_STATIONARY != 0;
+constexpr int kRolloutThreads = kRolloutStationary ? FTHREADS : 2 * FTHREADS;
+template <int N>
+struct RFrags { f32x4 f[N]; };
+template <int N>
+__device__ __forceinline__ RFrags<N> rfrags_load(const f32x4* __restrict__ Bp, int lane) {
+  RFrags<N> w;
+  const unsigned bo = (unsigned)lane * 16u;
+#pragma unroll
+  for (int kg = 0; kg < N; ++kg) w.f[kg] = ldg16(Bp, bo + (unsigned)kg * 1024u);
+  return w;
+}
+// c0 / c1 += A[32 x 8 NKG] (LDS) . (two 32-column blocks whose fragments sit in registers); k order of gemm_lds_packed_r32
+template <int LDA, int NKG>
+__device__ __forceinline__ void gemm_two_resident(int a_off, const RFrags<NKG>& wa, const RFrags<NKG>& wb, f32x16& c0, f32x16& c1,
+                                                  int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int ab = 4 * opaque((a_off + r * LDA + 4 * h) >> 2);
+#pragma unroll
+  for (int kg = 0; kg < NKG; ++kg) {
+    const f32x4 u = *reinterpret_cast<const f32x4*>(&lds[ab + 8 * kg]);
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      c0 = MFMA32(u[s_], wa.f[kg][s_], c0);
+      c1 = MFMA32(u[s_], wb.f[kg][s_], c1);
+    }
+  }
+}
 
 template <int DP>
-__global__ __launch_bounds__(kRolloutThreads) void k_rollout_persistent(RolloutArgs a) {
+__global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(RolloutArgs a) {
   using L = LayRo<DP>;
   using LB = Lay32<DP>;
   constexpr int ldx = LB::LDX, per = DP / 4, R = 32;
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-  const bool noise_wave = wave >= 4;  // wave-uniform
+  const bool noise_wave = !kRolloutStationary && wave >= 4;  // wave-uniform
   const FusedNet W = a.pi;
   const int row0 = blockIdx.x * R;
   const int N = a.N, A = a.A, D = a.D;
@@ -118,11 +154,24 @@ __global__ __launch_bounds__(kRolloutThreads) void k_rollout_persistent(RolloutA
   const uint32_t ek0 = (uint32_t)a.env_seed, ek1 = (uint32_t)(a.env_seed >> 32);
 
   double es_n = 0.0, es_ret = 0.0, es_len = 0.0, es_goal = 0.0;  // finished episodes of this thread's row
+  constexpr int NKG1 = DP / 8;
+  RFrags<NKG1> w1a, w1b;
+  RFrags<32> w2a, w2b;
+  RFrags<8> w3s;
+  if (kRolloutStationary) {  // this wave's columns 64 wave .. 64 wave + 63 of both hidden layers, K-slice [64 wave, +64) of the head
+    const int l0 = tid0 & 63;
+    w1a = rfrags_load<NKG1>(W.W1f + (size_t)(2 * wave) * NKG1 * 64, l0);
+    w1b = rfrags_load<NKG1>(W.W1f + (size_t)(2 * wave + 1) * NKG1 * 64, l0);
+    w2a = rfrags_load<32>(W.W2f + (size_t)(2 * wave) * 32 * 64, l0);
+    w2b = rfrags_load<32>(W.W2f + (size_t)(2 * wave + 1) * 32 * 64, l0);
+    w3s = rfrags_load<8>(W.W3f + (size_t)(wave * 8) * 64, l0);
+  }
   for (int t = a.t0; t < a.t1; ++t) {
     const int tid = opaque(tid0), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
-    if (noise_wave) {  // the step's random numbers, under the GEMMs of the other four waves; then keep the barriers' count
-      const int hid = tid - FTHREADS;
+    if (noise_wave || kRolloutStationary) {  // the step's random numbers: by the noise waves under the GEMMs of the other
+      // four (then they only keep the barriers' count), or -- weights-stationary plan -- by the four waves themselves, first
+      const int hid = kRolloutStationary ? tid : tid - FTHREADS;
       const uint32_t step = sbase + (uint32_t)t;
       if (ROLL_ON(1)) {  // standard normals of the sampling stage (consumed after the head)
         const int ngrp = (A + 3) >> 2;
@@ -135,7 +184,7 @@ __global__ __launch_bounds__(kRolloutThreads) void k_rollout_persistent(RolloutA
           for (int j = 0; j < 4; ++j) lds[L::ZN + rr_ * 32 + 4 * gq + j] = z[j];
         }
       }
-      __syncthreads();  // (1) after layer 1: the env phase of the previous step has long finished reading EN / ET
+      if (!kRolloutStationary) __syncthreads();  // (1) after layer 1: the env phase of the previous step has long finished reading EN
       if (ROLL_ON(16)) {  // observation noise of the env phase
         for (int i = hid; i < R * per; i += FTHREADS) {
           const int rr_ = i / per, c = i - rr_ * per;
@@ -146,18 +195,23 @@ __global__ __launch_bounds__(kRolloutThreads) void k_rollout_persistent(RolloutA
           }
         }
       }
-      __syncthreads();  // (2) after layer 2
-      __syncthreads();  // (3) after the head
-      __syncthreads();  // (4) after the sampling stage
-      __syncthreads();  // (5) after the env phase
-      __syncthreads();  // (6) after the state update
-    } else {
+      if (!kRolloutStationary) {
+        __syncthreads();  // (2) after layer 2
+        __syncthreads();  // (3) after the head
+        __syncthreads();  // (4) after the sampling stage
+        __syncthreads();  // (5) after the env phase
+        __syncthreads();  // (6) after the state update
+      }
+    }
+    if (!noise_wave) {
     {  // layer 1
       f32x16 c0 = splat16(W.b1s[64 * wave + r]), c1 = splat16(W.b1s[64 * wave + 32 + r]);
       constexpr int nkg = DP / 8;
-      if (ROLL_ON(2))
-        gemm_lds_packed_r32<ldx>(LB::X, W.W1f + (size_t)(2 * wave) * nkg * 64, W.W1f + (size_t)(2 * wave + 1) * nkg * 64, nkg,
-                                 c0, c1, lane);
+      if (ROLL_ON(2)) {
+        if (kRolloutStationary) gemm_two_resident<ldx, NKG1>(LB::X, w1a, w1b, c0, c1, lane);
+        else gemm_lds_packed_r32<ldx>(LB::X, W.W1f + (size_t)(2 * wave) * nkg * 64, W.W1f + (size_t)(2 * wave + 1) * nkg * 64, nkg,
+                                      c0, c1, lane);
+      }
       const int o = opaque(LB::H1 + 4 * h * FLDH + 64 * wave + r);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -169,9 +223,11 @@ __global__ __launch_bounds__(kRolloutThreads) void k_rollout_persistent(RolloutA
     {  // layer 2
       f32x16 c0 = splat16(W.b2s[64 * wave + r]), c1 = splat16(W.b2s[64 * wave + 32 + r]);
       constexpr int nkg = FH / 8;
-      if (ROLL_ON(4))
-        gemm_lds_packed_r32_deep<FLDH>(LB::H1, W.W2f + (size_t)(2 * wave) * nkg * 64,
-                                       W.W2f + (size_t)(2 * wave + 1) * nkg * 64, nkg, c0, c1, lane);
+      if (ROLL_ON(4)) {
+        if (kRolloutStationary) gemm_two_resident<FLDH, 32>(LB::H1, w2a, w2b, c0, c1, lane);
+        else gemm_lds_packed_r32_deep<FLDH>(LB::H1, W.W2f + (size_t)(2 * wave) * nkg * 64,
+                                            W.W2f + (size_t)(2 * wave + 1) * nkg * 64, nkg, c0, c1, lane);
+      }
       const int o = opaque(LB::H2 + 4 * h * FLDH + 64 * wave + r);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -187,7 +243,8 @@ __global__ __launch_bounds__(kRolloutThreads) void k_rollout_persistent(RolloutA
       const unsigned bo = opaque_u((unsigned)lane * 16u);
 #pragma unroll
       for (int kg = 0; kg < (ROLL_ON(64) ? 8 : 0); kg += 2) {
-        const f32x4 b0 = ldg16(bp, bo + kg * 1024u), b1 = ldg16(bp, bo + (kg + 1) * 1024u);
+        const f32x4 b0 = kRolloutStationary ? w3s.f[kg] : ldg16(bp, bo + kg * 1024u);
+        const f32x4 b1 = kRolloutStationary ? w3s.f[kg + 1] : ldg16(bp, bo + (kg + 1) * 1024u);
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8]);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8 + 8]);
 #pragma unroll
