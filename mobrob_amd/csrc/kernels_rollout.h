@@ -68,14 +68,16 @@ inline size_t rollout_lds_bytes(int Dp) {
 // while the matrix pipe runs the hidden-layer GEMMs of the same step.  Same counters, same values as before (and as the
 // per-step kernels); the draws used to sit in front of the GEMMs and inside the env phase: 2.9 of 15.2 us per step.
 // (The second draw of a row that ends an episode -- its reset observation -- stays with the policy waves: rare.)
-// MOBROB_ROLLOUT_STATIONARY (default 1): the other plan for the same kernel -- FOUR waves, one per SIMD with all 512 registers
+// MOBROB_ROLLOUT_STATIONARY (default 0: measured SLOWER, kept as a switch): the other plan for the same kernel -- FOUR waves, one per SIMD with all 512 registers
 // of a lane, and the policy's weights STATIONARY in them for the whole launch: wave w holds the fragment packs of its 64
 // columns of W1 (2 x DP/8 x 4 registers), W2 (2 x 32 x 4 = 256) and its K-slice of the head (32): no weight byte crosses the
 // L2 <-> CU path in the step loop (round 1-2: 340 KB of fragments per tile and step, 2.9 TB/s chip-wide, and a latency the
 // 4-deep prefetch ring only just covered).  Same MFMA sequence per accumulator, same bits.  The noise waves need the second
-// wave slot of every SIMD and therefore exclude this plan; A/B in DESIGN.md 4.2.
+// wave slot of every SIMD and therefore exclude this plan.  A/B on one box: 15.49 ms per 1000-step rollout of
+// 4096 envs against 14.69 ms with streamed fragments + noise waves (15.07 ms in round 2) -- the weight stream was never
+// what paced the step; 352 resident registers cost v_accvgpr_read copies in front of the MFMAs instead.
 #ifndef MOBROB_ROLLOUT_STATIONARY
-#define MOBROB_ROLLOUT_STATIONARY 1
+#define MOBROB_ROLLOUT_STATIONARY 0
 #endif
 constexpr bool kRolloutStationary = MOBROB_ROLLOUT_STATIONARY != 0;
 constexpr int kRolloutThreads = kRolloutStationary ? FTHREADS : 2 * FTHREADS;
