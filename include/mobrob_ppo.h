@@ -37,6 +37,7 @@ extern "C" {
 #endif
 
 #define MOBROB_PPO_ABI_VERSION 1
+enum { MOBROB_ACT_TANH = 0, MOBROB_ACT_RELU = 1 };
 
 enum {
   MOBROB_OK = 0,
@@ -78,8 +79,9 @@ typedef struct mobrob_ppo_config {
   int32_t rollout_graph;      /* 1: the per-step device rollout (2 launches per step) is replayed as one
                                  captured hipGraph; the persistent rollout needs no graph          */
   int32_t rollout_persistent; /* 1: run the device-resident rollout as one persistent kernel (fused widths) */
-  int32_t reserved[5];        /* zero ([0] used to select a persistent small-batch update kernel that lost to the per-step
-                                 path and now lives in scratch/kernels_train_small.h) */
+  int32_t activation;         /* hidden activation of both networks: MOBROB_ACT_TANH (0; SB3's default for MlpPolicy, every
+                                 reference YAML) or MOBROB_ACT_RELU (policy_kwargs activation_fn=nn.ReLU; generic GEMM chain) */
+  int32_t reserved[4];
 } mobrob_ppo_config_t;
 
 /* Fill `cfg` with SB3 2.0.0 defaults (Appendix A.1).  Replaces PPO.__init__'s default kwargs. */

@@ -159,6 +159,8 @@ _ALLOWED_GLOBALS = {
     ("numpy.random._pcg64", "PCG64"), ("numpy.random._generator", "Generator"),
     ("numpy.random.bit_generator", "SeedSequence"), ("numpy.random._mt19937", "MT19937"),
     ("collections", "deque"), ("collections", "OrderedDict"),
+    # `policy_kwargs` holding an activation class is cloudpickled as a whole by SB3: the class travels by reference
+    ("torch.nn.modules.activation", "Tanh"), ("torch.nn.modules.activation", "ReLU"),
 }
 
 
@@ -213,6 +215,14 @@ def load_zip(path):
                         data[k] = _unblob(v)
                     except Exception:  # blobs that need gymnasium/SB3/py3.11 code objects are skipped, like SB3 does
                         data[k] = None
+                elif k == "policy_kwargs":  # a dict with a class in it (activation_fn) is ONE blob in SB3's JSON
+                    try:
+                        pk = dict(_unblob(v))
+                        if "activation_fn" in pk:
+                            pk["activation_fn"] = getattr(pk["activation_fn"], "__name__", str(pk["activation_fn"]))
+                        data[k] = pk
+                    except Exception:  # noqa: BLE001 - something this build cannot rebuild: keep the readable side
+                        data[k] = {kk: vv for kk, vv in v.items() if not kk.startswith(":")}
                 elif k in ("observation_space", "action_space"):
                     try:
                         st = unpickle_box(v)
@@ -269,6 +279,12 @@ def save_zip(path, *, params, optimizer, hyper, obs_dim, act_dim, net_arch=None,
         last_episode_starts = np.zeros((n_envs,), bool)
     policy_kwargs = {} if net_arch is None else {"net_arch": {"pi": list(net_arch[0]), "vf": list(net_arch[1])}}
     policy_kwargs.update(extra_policy_kwargs or {})  # JSON-able ones the user passed: log_std_init, ortho_init, optimizer_kwargs
+    act = policy_kwargs.get("activation_fn")
+    if act is not None:  # SB3 pickles a policy_kwargs dict that holds a class as ONE blob (the class by reference) + readable keys
+        cls = getattr(torch.nn, {"relu": "ReLU", "tanh": "Tanh"}[str(act).lower()])
+        real = dict(policy_kwargs, activation_fn=cls)
+        readable = {k: (str(cls) if k == "activation_fn" else v) for k, v in policy_kwargs.items()}
+        policy_kwargs = _blob("<class 'dict'>", pickle.dumps(real, protocol=4), **readable)
     data = OrderedDict()
     data["policy_class"] = _blob("<class 'abc.ABCMeta'>", pickle_policy_class(),
                                  __module__="stable_baselines3.common.policies")

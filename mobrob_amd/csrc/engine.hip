@@ -262,6 +262,7 @@ void linear_fwd(mobrob_ppo_engine* e, const float* X, int ldx, const float* W, i
                 int ldy, int M, int Nn, int K, bool tanh_) {
   GemmArgs g{};
   g.A = X; g.B = W; g.C = Y; g.M = M; g.N = Nn; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldy; g.bias = bias;
+  g.relu = e->cfg.activation == MOBROB_ACT_RELU;
   if (tanh_) launch_gemm<MODE_NT, EPI_BIAS_TANH>(e, g);
   else launch_gemm<MODE_NT, EPI_BIAS>(e, g);
 }
@@ -270,7 +271,7 @@ void linear_bwd_input(mobrob_ppo_engine* e, const float* dY, int ldd, const floa
                       float* dZ, int ldz, float* bias_grad, int M, int Nn, int K) {
   GemmArgs g{};
   g.A = dY; g.B = W; g.C = dZ; g.M = M; g.N = Nn; g.K = K; g.lda = ldd; g.ldb = ldw; g.ldc = ldz;
-  g.Hact = H; g.ldh = ldh; g.colsum = bias_grad;
+  g.Hact = H; g.ldh = ldh; g.colsum = bias_grad; g.relu = e->cfg.activation == MOBROB_ACT_RELU;
   launch_gemm<MODE_NN, EPI_DTANH_COLSUM>(e, g);
 }
 // dW[M x Nn] += dY[rows x M]^T . X[rows x Nn]
@@ -324,7 +325,7 @@ void value_flagged(mobrob_ppo_engine* e, const float* obs_rows, const uint8_t* f
   const size_t sm = (size_t)(e->D + e->G1 + e->G2 + 16) * sizeof(float);
   hipLaunchKernelGGL(k_value_flagged, dim3(e->N), dim3(256), sm, e->stream, obs_rows, e->Dp, flags, Pp(e, T_VW1),
                      Pp(e, T_VB1), Pp(e, T_VW2), Pp(e, T_VB2), Pp(e, T_VW), Pp(e, T_VB), e->D, e->G1, e->G2, out,
-                     bootstrap_rewards, (float)e->cfg.gamma);
+                     bootstrap_rewards, (float)e->cfg.gamma, (int)(e->cfg.activation == MOBROB_ACT_RELU));
 }
 
 // Philox key of the action-noise stream: data-parallel ranks must not share it
@@ -375,7 +376,8 @@ int upload_obs(mobrob_ppo_engine* e, const float* host, float* dev_rows, int row
 
 int fused_init(mobrob_ppo_engine* e) {
   FusedState& f = e->fused;
-  f.enabled = e->cfg.fast_kernels && fused_shape_ok(e->D, e->A, e->H1, e->H2, e->G1, e->G2);
+  // (every fused kernel's epilogue is tanh: ReLU networks run the generic GEMM chain)
+  f.enabled = e->cfg.fast_kernels && e->cfg.activation == MOBROB_ACT_TANH && fused_shape_ok(e->D, e->A, e->H1, e->H2, e->G1, e->G2);
   if (!f.enabled) return MOBROB_OK;
   f.D = e->D; f.Dp = e->Dp; f.A = e->A; f.H = e->H1;
   if ((uint64_t)(e->T + 1) * e->N * e->Dp * 4ull >= (1ull << 32) || (uint64_t)e->T * e->N * e->A * 4ull >= (1ull << 32)) {
@@ -595,6 +597,7 @@ int check_cfg(const mobrob_ppo_config_t* c) {
   if (c->world_size < 1 || c->rank < 0 || c->rank >= c->world_size) return fail(MOBROB_ERR_INVALID, "bad rank/world_size");
   if (c->batch_size % c->world_size) return fail(MOBROB_ERR_INVALID, "batch_size must be divisible by world_size");
   if ((int64_t)c->n_envs * c->n_steps > (int64_t)1 << 30) return fail(MOBROB_ERR_INVALID, "rollout too large");
+  if (c->activation != MOBROB_ACT_TANH && c->activation != MOBROB_ACT_RELU) return fail(MOBROB_ERR_INVALID, "activation must be MOBROB_ACT_TANH or MOBROB_ACT_RELU");
   return MOBROB_OK;
 }
 
@@ -1079,6 +1082,7 @@ int mobrob_ppo_store_part(mobrob_ppo_engine_t* e, int32_t part, int32_t nparts, 
   a.trunc = any ? truncated + r0 : nullptr; a.term_obs = any ? terminal_obs + (size_t)r0 * e->D : nullptr;
   a.W1 = Pp(e, T_VW1); a.b1 = Pp(e, T_VB1); a.W2 = Pp(e, T_VW2); a.b2 = Pp(e, T_VB2); a.Wv = Pp(e, T_VW); a.bv = Pp(e, T_VB);
   a.D = e->D; a.Dp = e->Dp; a.G1 = e->G1; a.G2 = e->G2; a.n = n; a.gamma = (float)e->cfg.gamma;
+  a.relu = e->cfg.activation == MOBROB_ACT_RELU;
   a.prev_dones = e->prev_dones + r0; a.rew_out = e->rewards + o; a.es_out = e->es + o; a.term_val = e->term_val + r0;
   if (next_obs) {  // slot t+1 exists for every t < T (slot T holds the last observations)
     a.next_obs = next_obs + (size_t)r0 * e->D;
@@ -1203,7 +1207,7 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
   a.kind = sp.kind; a.env_seed = env_seed_of(e); a.step_base = e->ctr_dev + 1;
   a.p_term = sp.p_term; a.time_limit = sp.time_limit; a.goal = sp.goal;
   a.bt = BootArgs{Pp(e, T_VW1), Pp(e, T_VB1), Pp(e, T_VW2), Pp(e, T_VB2), Pp(e, T_VW), Pp(e, T_VB), e->G1, e->G2,
-                  (float)e->cfg.gamma, e->term_val};
+                  (float)e->cfg.gamma, e->term_val, 0};  // (fused path: tanh networks only)
   a.N = N; a.D = e->D; a.A = e->A;
   a.obs = e->obs; a.actions = e->actions; a.logp = e->logp; a.rewards = e->rewards; a.es = e->es;
   a.term_obs = e->term_obs; a.trunc = e->trunc_dev; a.clip_act = e->clip_act;
@@ -1308,7 +1312,7 @@ int enqueue_rollout(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& 
   // the previous rollout's last observation is this rollout's first
   HIPC(hipMemcpyAsync(e->obs, e->obs + (size_t)e->T * slot, slot * 4, hipMemcpyDeviceToDevice, e->stream));
   BootArgs bt{Pp(e, T_VW1), Pp(e, T_VB1), Pp(e, T_VW2), Pp(e, T_VB2), Pp(e, T_VW), Pp(e, T_VB), e->G1, e->G2,
-              (float)e->cfg.gamma, e->term_val};
+              (float)e->cfg.gamma, e->term_val, (int)(e->cfg.activation == MOBROB_ACT_RELU)};
   const size_t sm = env_step_lds_bytes(Dp, e->G1, e->G2);
   for (int t = 0; t < e->T; ++t) {
     act_slot(e, t, nullptr, true);

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_goal_env_step_store(GoalEnvArgs a, Boot
       for (int j = 0; j < 4; ++j) x[4 * c + j] = ob[j];
     }
     __syncthreads();
-    const float v = value_row_lds(x, h1, h2, red, bt.W1, bt.b1, bt.W2, bt.b2, bt.Wv, bt.bv, a.D, bt.G1, bt.G2);
+    const float v = value_row_lds(x, h1, h2, red, bt.W1, bt.b1, bt.W2, bt.b2, bt.Wv, bt.bv, a.D, bt.G1, bt.G2, bt.relu);
     if (threadIdx.x == 0) {
       bt.term_val[n] = v;
       a.rew_out[n] = (float)((double)lrew[q] + (double)__fmul_rn(bt.gamma, v));

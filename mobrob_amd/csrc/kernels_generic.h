@@ -30,6 +30,7 @@ struct GemmArgs {
   const float* Hact;    // EPI_DTANH_COLSUM: activation h (same shape as C), ld = ldh
   int ldh;
   float* colsum;        // EPI_DTANH_COLSUM: [N] += column sums of the stored tile (bias gradient)
+  int relu;             // hidden activation: 0 tanh (SB3's default for MlpPolicy), 1 ReLU (policy_kwargs activation_fn=nn.ReLU)
   int kchunk;           // MODE_TN: batch rows per blockIdx.z
 };
 
@@ -103,10 +104,10 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
       if (EPI == EPI_BIAS) {
         g.C[(size_t)row * g.ldc + col] = v + bias;
       } else if (EPI == EPI_BIAS_TANH) {
-        g.C[(size_t)row * g.ldc + col] = tanhf(v + bias);
+        g.C[(size_t)row * g.ldc + col] = g.relu ? fmaxf(v + bias, 0.f) : tanhf(v + bias);
       } else if (EPI == EPI_DTANH_COLSUM) {
         const float hv = g.Hact[(size_t)row * g.ldh + col];
-        v = v * (1.0f - hv * hv);
+        v = g.relu ? (hv > 0.f ? v : 0.f) : v * (1.0f - hv * hv);  // relu'(z) = [z > 0] = [h > 0] (torch: 0 at z = 0)
         g.C[(size_t)row * g.ldc + col] = v;
         csum += v;
       } else {
@@ -235,17 +236,17 @@ __device__ __forceinline__ float value_row_lds(const float* x, float* h1, float*
                                                const float* __restrict__ W1, const float* __restrict__ b1,
                                                const float* __restrict__ W2, const float* __restrict__ b2,
                                                const float* __restrict__ Wv, const float* __restrict__ bv, int D, int G1,
-                                               int G2) {
+                                               int G2, int relu = 0) {
   for (int j = threadIdx.x; j < G1; j += blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < D; ++k) s = fmaf(x[k], W1[(size_t)j * D + k], s);
-    h1[j] = tanhf(s + b1[j]);
+    h1[j] = relu ? fmaxf(s + b1[j], 0.f) : tanhf(s + b1[j]);
   }
   __syncthreads();
   for (int j = threadIdx.x; j < G2; j += blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < G1; ++k) s = fmaf(h1[k], W2[(size_t)j * G1 + k], s);
-    h2[j] = tanhf(s + b2[j]);
+    h2[j] = relu ? fmaxf(s + b2[j], 0.f) : tanhf(s + b2[j]);
   }
   __syncthreads();
   float p = 0.f;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256) void k_value_flagged(const float* __restrict__
                                                        const float* __restrict__ W2, const float* __restrict__ b2,
                                                        const float* __restrict__ Wv, const float* __restrict__ bv,
                                                        int D, int G1, int G2, float* __restrict__ out,
-                                                       float* __restrict__ rew_inout, float gamma) {
+                                                       float* __restrict__ rew_inout, float gamma, int relu) {
   const int row = blockIdx.x;
   if (!flags[row]) return;
   extern __shared__ float sm[];  // x[D] | h1[G1] | h2[G2] | red[16]
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void k_value_flagged(const float* __restrict__
   float* red = h2 + G2;
   for (int i = threadIdx.x; i < D; i += blockDim.x) x[i] = obs[(size_t)row * ldo + i];
   __syncthreads();
-  const float v = value_row_lds(x, h1, h2, red, W1, b1, W2, b2, Wv, bv, D, G1, G2);
+  const float v = value_row_lds(x, h1, h2, red, W1, b1, W2, b2, Wv, bv, D, G1, G2, relu);
   if (threadIdx.x == 0) {
     out[row] = v;
     if (rew_inout != nullptr)  // rewards[idx] += gamma * V(terminal_obs)  [oracle bootstrap_reward]
@@ -294,6 +295,7 @@ struct StorePullArgs {
   float gamma;
   float *prev_dones, *rew_out, *es_out, *term_val;
   const float* next_obs; float* obs_slot;  // null: no pull
+  int relu;                                // hidden activation of the value network
 };
 __global__ __launch_bounds__(256) void k_store_pull_part(StorePullArgs a) {
   extern __shared__ float sm[];  // x[D] | h1[G1] | h2[G2] | red[16] | tv[16]
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256) void k_store_pull_part(StorePullArgs a) {
       if (i >= a.n || !a.trunc[i]) continue;  // block-uniform
       for (int k = tid; k < a.D; k += blockDim.x) x[k] = a.term_obs[(size_t)i * a.D + k];
       __syncthreads();
-      const float v = value_row_lds(x, h1, h2, red, a.W1, a.b1, a.W2, a.b2, a.Wv, a.bv, a.D, a.G1, a.G2);
+      const float v = value_row_lds(x, h1, h2, red, a.W1, a.b1, a.W2, a.b2, a.Wv, a.bv, a.D, a.G1, a.G2, a.relu);
       if (tid == 0) tv[r] = v;
       __syncthreads();
     }
@@ -761,6 +763,7 @@ struct BootArgs {  // value network (canonical parameters) for the in-kernel tim
   int G1, G2;
   float gamma;
   float* term_val;  // [N] V(terminal_obs) of truncated rows (diagnostics / tests)
+  int relu;         // hidden activation of the value network (0 tanh, 1 ReLU)
 };
 constexpr int kBootMaxEnvs = 72;  // envs whose chunk-0 thread can live in one 256-thread block (Dp >= 16: <= 65)
 inline size_t env_step_lds_bytes(int Dp, int G1, int G2) { return (size_t)(Dp + G1 + G2 + 16 + 4 + 2 * kBootMaxEnvs) * 4; }
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(256) void k_env_step_store(uint64_t seed, uint32_t 
       for (int j = 0; j < 4; ++j) x[4 * c + j] = (4 * c + j < D) ? z[j] : 0.f;
     }
     __syncthreads();
-    const float v = value_row_lds(x, h1, h2, red, bt.W1, bt.b1, bt.W2, bt.b2, bt.Wv, bt.bv, D, bt.G1, bt.G2);
+    const float v = value_row_lds(x, h1, h2, red, bt.W1, bt.b1, bt.W2, bt.b2, bt.Wv, bt.bv, D, bt.G1, bt.G2, bt.relu);
     if (threadIdx.x == 0) {
       bt.term_val[n] = v;
       rew_out[n] = (float)((double)lrew[q] + (double)__fmul_rn(bt.gamma, v));

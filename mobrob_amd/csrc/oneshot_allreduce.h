@@ -79,7 +79,10 @@ __global__ __launch_bounds__(256) void k_oneshot_allreduce(OneShotArgs a) {
         __builtin_amdgcn_s_sleep(8);
       }
     }
-    if (!good) atomicExch(a.error, (int)(a.seq & 0x3fffffff) + 1);
+    if (!good) {  // pinned host word: a plain store (device atomics on host memory need PCIe atomics), pushed out by the fence below
+      *reinterpret_cast<volatile int*>(a.error) = (int)(a.seq & 0x3fffffff) + 1;
+      __threadfence_system();
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ok = good;

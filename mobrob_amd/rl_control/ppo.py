@@ -205,7 +205,8 @@ class PPO:
         #   log_std_init     initial value of the state-independent log standard deviation (default 0.0)
         #   ortho_init       True (default): orthogonal weights with SB3's gains; False: torch's nn.Linear default
         #   optimizer_kwargs Adam's `eps` / `betas` (SB3 passes eps=1e-5 itself); `optimizer_class` must stay Adam
-        #   activation_fn    Tanh only (nn.Tanh or its name): every kernel's epilogue is tanh
+        #   activation_fn    nn.Tanh (default) or nn.ReLU, as a class or by name; ReLU networks run the generic GEMM chain
+        #                    (the fused kernels' epilogues are tanh)
         self.log_std_init = float(self.policy_kwargs.get("log_std_init", 0.0))
         self.ortho_init = bool(self.policy_kwargs.get("ortho_init", True))
         opt_kw = dict(self.policy_kwargs.get("optimizer_kwargs") or {})
@@ -215,8 +216,9 @@ class PPO:
             raise NotImplementedError("optimizer_kwargs other than `eps` and `betas` are not supported (Adam without weight "
                                       "decay or amsgrad, SB3's default optimiser)")
         act = self.policy_kwargs.get("activation_fn")
-        if act is not None and getattr(act, "__name__", str(act)).lower() not in ("tanh",):
-            raise NotImplementedError(f"activation_fn {act!r}: only Tanh (SB3's default for MlpPolicy) is implemented")
+        self.activation = "tanh" if act is None else getattr(act, "__name__", str(act)).lower()
+        if self.activation not in ("tanh", "relu"):
+            raise NotImplementedError(f"activation_fn {act!r}: Tanh (SB3's default for MlpPolicy) and ReLU are implemented")
         oc = self.policy_kwargs.get("optimizer_class")
         if oc is not None and getattr(oc, "__name__", str(oc)) != "Adam":
             raise NotImplementedError(f"optimizer_class {oc!r}: only Adam is implemented")
@@ -265,7 +267,7 @@ class PPO:
                   gamma=self.gamma, gae_lambda=self.gae_lambda, clip_range=self.clip_range, ent_coef=self.ent_coef,
                   vf_coef=self.vf_coef, max_grad_norm=self.max_grad_norm, learning_rate=self.learning_rate,
                   normalize_advantage=self.normalize_advantage, seed=0 if self.seed is None else int(self.seed),
-                  adam_betas=self.adam_betas, adam_eps=self.adam_eps)
+                  adam_betas=self.adam_betas, adam_eps=self.adam_eps, activation=self.activation)
         # data parallel: under torchrun / an initialised process group every rank owns its n_envs
         # environments and rollout shard; batch_size stays SB3's GLOBAL minibatch and must divide by the world size
         from ..parallel import distributed_context
@@ -553,7 +555,8 @@ class PPO:
                  obs_low=None if self.obs_bounds is None else self.obs_bounds[0],
                  obs_high=None if self.obs_bounds is None else self.obs_bounds[1],
                  extra_policy_kwargs={k: (list(v) if isinstance(v, tuple) else v) for k, v in self.policy_kwargs.items()
-                                      if k in ("log_std_init", "ortho_init", "optimizer_kwargs")})
+                                      if k in ("log_std_init", "ortho_init", "optimizer_kwargs")}
+                 | ({"activation_fn": self.activation} if self.activation != "tanh" else {}))
 
     @classmethod
     def load(cls, path, env=None, device="auto", custom_objects=None, print_system_info=False, force_reset=True,

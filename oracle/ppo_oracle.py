@@ -156,20 +156,27 @@ def _linear(x, w, b, acc=None):
     return (_mm(x, w.T, acc) + b).astype(F32)
 
 
-def mlp_latents(p, obs, acc=None):
+def _activate(z, activation):
+    """`activation_fn` of SB3's MlpExtractor: nn.Tanh (default) or nn.ReLU [torch: relu(z) = max(z, 0)]."""
+    if activation == "relu":
+        return np.maximum(z, F32(0.0)).astype(F32)
+    return np.tanh(z).astype(F32)
+
+
+def mlp_latents(p, obs, acc=None, activation="tanh"):
     """Returns (per-layer activations of the policy net, of the value net); index 0 is the input."""
     x = np.asarray(obs).astype(F32)  # FlattenExtractor + obs.float()
     acts_pi, acts_vf = [x], [x]
     for w, b in _net_layers(p, "mlp_extractor.policy_net"):
-        acts_pi.append(np.tanh(_linear(acts_pi[-1], w, b, acc)).astype(F32))
+        acts_pi.append(_activate(_linear(acts_pi[-1], w, b, acc), activation))
     for w, b in _net_layers(p, "mlp_extractor.value_net"):
-        acts_vf.append(np.tanh(_linear(acts_vf[-1], w, b, acc)).astype(F32))
+        acts_vf.append(_activate(_linear(acts_vf[-1], w, b, acc), activation))
     return acts_pi, acts_vf
 
 
-def policy_outputs(p, obs):
+def policy_outputs(p, obs, activation="tanh"):
     """mean actions [N,A] and values [N]."""
-    acts_pi, acts_vf = mlp_latents(p, obs)
+    acts_pi, acts_vf = mlp_latents(p, obs, activation=activation)
     mean = _linear(acts_pi[-1], p["action_net.weight"], p["action_net.bias"])
     value = _linear(acts_vf[-1], p["value_net.weight"], p["value_net.bias"])[:, 0]
     return mean, value
@@ -334,6 +341,7 @@ class Hyper:
     batch_size: int = 64
     clip_range_vf: float | None = None   # SB3 default None: no value-function clipping
     target_kl: float | None = None       # SB3 default None: no early stop
+    activation: str = "tanh"             # policy_kwargs activation_fn: "tanh" (SB3's MlpPolicy default) or "relu"
 
 
 def normalize_advantages(adv, acc=None):
@@ -366,7 +374,7 @@ def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, return
     actions = np.asarray(actions, F32)
     B = obs.shape[0]
     Bg = F32(B if denom is None else denom)
-    acts_pi, acts_vf = mlp_latents(p, obs, acc)
+    acts_pi, acts_vf = mlp_latents(p, obs, acc, activation=h.activation)
     mean = _linear(acts_pi[-1], p["action_net.weight"], p["action_net.bias"], acc)
     values = _linear(acts_vf[-1], p["value_net.weight"], p["value_net.bias"], acc)[:, 0]
     log_std = p["log_std"].astype(F32)
@@ -427,7 +435,10 @@ def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, return
         layers = _net_layers(p, prefix)
         for li in reversed(range(len(layers))):
             w, _ = layers[li]
-            g_z = (g_h * (F32(1.0) - acts[li + 1] * acts[li + 1])).astype(F32)
+            if h.activation == "relu":   # torch's threshold_backward: the gradient passes where the input was > 0
+                g_z = (g_h * (acts[li + 1] > 0)).astype(F32)
+            else:
+                g_z = (g_h * (F32(1.0) - acts[li + 1] * acts[li + 1])).astype(F32)
             grads[f"{prefix}.{2 * li}.weight"] = _mm(g_z.T, acts[li], acc)
             grads[f"{prefix}.{2 * li}.bias"] = _colsum(g_z, acc)
             g_h = _mm(g_z, w, acc)

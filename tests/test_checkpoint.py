@@ -169,3 +169,25 @@ def test_checkpoint_blobs_resolve_only_an_exact_allow_list():
     assert list(ck._unblob(ok)) == [{"r": 1.5, "l": 7, "t": 0.1}]
     arr = {":serialized:": base64.b64encode(pickle.dumps(np.arange(6, dtype=np.float32).reshape(2, 3))).decode()}
     assert ck._unblob(arr).tolist() == [[0.0, 1.0, 2.0], [3.0, 4.0, 5.0]]
+
+
+def test_policy_kwargs_with_an_activation_class_round_trip(tmp_path):
+    """SB3 pickles a `policy_kwargs` dict that holds a class (activation_fn=nn.ReLU) as ONE blob with the class by
+    reference; the writer emits that form and the reader gets net_arch / activation name back (allow-listed globals only)."""
+    import base64
+    import pickle
+    import torch
+    p = O.init_params(14, 2, seed=0)
+    zeros = OrderedDict((k, np.zeros_like(v)) for k, v in p.items())
+    hyper = dict(n_envs=2, n_steps=8, gamma=0.99, gae_lambda=0.95, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, batch_size=4,
+                 n_epochs=1, clip_range=0.2, learning_rate=3e-4)
+    path = str(tmp_path / "relu.zip")
+    ck.save_zip(path, params=p, optimizer=dict(exp_avg=zeros, exp_avg_sq=zeros, step=0, lr=3e-4, betas=(0.9, 0.999), eps=1e-5),
+                hyper=hyper, obs_dim=14, act_dim=2, net_arch=((64, 64), (64, 64)),
+                extra_policy_kwargs={"activation_fn": "relu", "log_std_init": -0.5})
+    raw = json.loads(zipfile.ZipFile(path).read("data"))["policy_kwargs"]
+    assert raw[":type:"] == "<class 'dict'>" and "ReLU" in raw["activation_fn"]
+    real = pickle.loads(base64.b64decode(raw[":serialized:"]))          # what real SB3 would rebuild
+    assert real["activation_fn"] is torch.nn.ReLU and real["net_arch"] == {"pi": [64, 64], "vf": [64, 64]}
+    back = ck.load_zip(path)["data"]["policy_kwargs"]
+    assert back["activation_fn"] == "ReLU" and back["log_std_init"] == -0.5 and back["net_arch"] == {"pi": [64, 64], "vf": [64, 64]}

@@ -8,6 +8,7 @@ import pytest
 
 from oracle import ppo_oracle as O
 from tests.test_engine_gpu import _consistent_rollout, make_engine
+from tests.util import synthetic_rollout
 
 pytestmark = pytest.mark.gpu
 
@@ -172,7 +173,73 @@ def test_policy_kwargs_beyond_net_arch(tmp_path):
     again = PPO.load(path)
     assert again.log_std_init == -0.5 and again.ortho_init is False and again.adam_eps == 1e-3 and again.adam_betas == (0.8, 0.95)
     assert all(np.array_equal(again.engine.get_params()[k], got[k]) for k in got)
-    for bad in (dict(activation_fn="ReLU"), dict(optimizer_kwargs=dict(weight_decay=0.1)), dict(optimizer_class="SGD"),
+    for bad in (dict(activation_fn="GELU"), dict(optimizer_kwargs=dict(weight_decay=0.1)), dict(optimizer_class="SGD"),
                 dict(share_features_extractor=False)):
         with pytest.raises(NotImplementedError):
             PPO("MlpPolicy", env, policy_kwargs=bad)
+
+
+@pytest.mark.parametrize("H,D,A", [(64, 14, 2), (256, 58, 12), (40, 26, 2)])
+def test_relu_networks_match_the_oracle(H, D, A, tmp_path):
+    """policy_kwargs activation_fn=nn.ReLU: rollout-time forward, one minibatch gradient and a whole update of ReLU networks
+    (generic GEMM chain: the fused kernels are tanh) against the oracle; the option survives save / load."""
+    import torch
+    from mobrob_amd.envs.vec_env import DeviceGoalVecEnv
+    from mobrob_amd.rl_control.ppo import PPO
+    T, N, B, E = 12, 30, 120, 2
+    rng = np.random.default_rng(H + D)
+    p0 = O.init_params(D, A, (H, H), (H, H), seed=3)
+    p0["log_std"] = rng.normal(-0.3, 0.2, A).astype(np.float32)
+    buf, lv, dones = synthetic_rollout(T, N, D, A, seed=5)
+    mean, val = O.policy_outputs(p0, buf["obs"].reshape(T * N, D), activation="relu")
+    buf["log_probs"] = (O.gaussian_log_prob(mean, p0["log_std"], buf["actions"].reshape(T * N, A))
+                        + rng.normal(0, 0.05, T * N)).astype(np.float32).reshape(T, N)
+    buf["values"] = val.reshape(T, N)
+    h = O.Hyper(n_epochs=E, batch_size=B, ent_coef=0.01, activation="relu")
+    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, h.gamma, h.gae_lambda)
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H), ent_coef=0.01,
+                    activation="relu")
+    e.set_params(p0)
+    obs = buf["obs"][0]
+    eps = rng.standard_normal((N, A)).astype(np.float32)
+    e.rollout_begin()
+    a_raw, a_clip, v, lp = e.act(obs, eps)
+    m0, v0 = O.policy_outputs(p0, obs, activation="relu")
+    assert np.max(np.abs(v - v0)) < 1e-4 * max(1.0, float(np.abs(v0).max()))
+    assert np.max(np.abs(a_raw - (m0 + np.exp(p0["log_std"]) * eps))) < 1e-4
+    e.load_rollout(buf, lv, dones)
+    perms = np.stack([rng.permutation(T * N) for _ in range(E)])
+    e.epoch_begin(perms[0])
+    e.minibatch_grad(0)
+    got = e.unflatten(e.read("grads"))
+    _, og, _ = O.loss_and_grads(p0, *O.gather_minibatch(buf, perms[0][:B]), h)
+    for k in og:
+        assert np.max(np.abs(got[k] - og[k])) < 1e-4 * max(1.0, float(np.abs(og[k]).max())), k
+    _, og_tanh, _ = O.loss_and_grads(p0, *O.gather_minibatch(buf, perms[0][:B]), O.Hyper(n_epochs=E, batch_size=B, ent_coef=0.01))
+    assert np.max(np.abs(og_tanh["mlp_extractor.policy_net.2.weight"] - og["mlp_extractor.policy_net.2.weight"])) > 1e-4
+    e.minibatch_apply()
+    e.set_params(p0)
+    z = {k: np.zeros_like(v_) for k, v_ in p0.items()}
+    e.set_optimizer_state(z, z, 0)
+    e.train(perms)
+    q = {k: v_.copy() for k, v_ in p0.items()}
+    O.train(q, O.AdamState.zeros_like(q), buf, h, perms)
+    newp = e.get_params()
+    for k in q:
+        assert np.max(np.abs(newp[k] - q[k])) < 1e-4, k
+    e.close()
+    if H == 64:   # through PPO(...): class or name, learn a little on the device goal env, save / load keeps the option
+        env = DeviceGoalVecEnv.for_robot("point", 32, time_limit=50)
+        ppo = PPO("MlpPolicy", env, n_steps=16, batch_size=128, n_epochs=2, policy_kwargs=dict(activation_fn=torch.nn.ReLU), seed=2)
+        assert ppo.activation == "relu" and ppo.engine.cfg.activation == 1
+        ppo.learn(total_timesteps=2 * 16 * 32)
+        obs1 = np.asarray(ppo._last_obs[:4], np.float32)
+        act1, _ = ppo.predict(obs1, deterministic=True)
+        m1, _ = O.policy_outputs(ppo.engine.get_params(), obs1, activation="relu")
+        assert np.max(np.abs(act1 - np.clip(m1, -1, 1))) < 1e-4
+        path = str(tmp_path / "relu.zip")
+        ppo.save(path)
+        again = PPO.load(path)
+        assert again.activation == "relu"
+        act2, _ = again.predict(obs1, deterministic=True)
+        assert np.array_equal(act1, act2)

@@ -215,3 +215,40 @@ def test_target_kl_stops_before_the_offending_optimizer_step():
     out = O.train(p2, st2, buf, O.Hyper(n_epochs=3, batch_size=B, target_kl=target), perms)
     assert len(out) == first + 1 and out[-1].get("early_stop") and st2.step == first
     assert all(abs(float(a["approx_kl"]) - float(b["approx_kl"])) < 1e-7 for a, b in zip(out, free))
+
+
+def test_relu_networks_match_torch_autograd():
+    """`policy_kwargs=dict(activation_fn=nn.ReLU)` (an SB3 keyword the reference passes through, ppo.py:58): the oracle's
+    forward and hand-written backward with ReLU hidden layers against torch autograd on the same loss."""
+    import torch
+    rng = np.random.default_rng(0)
+    D, A, H, B = 7, 3, 16, 40
+    p = O.init_params(D, A, (H, H), (H, H), seed=1)
+    obs = rng.standard_normal((B, D)).astype(np.float32)
+    act = rng.standard_normal((B, A)).astype(np.float32)
+    oldv, adv, ret = (rng.standard_normal(B).astype(np.float32) for _ in range(3))
+    oldlp = (-3 + 0.1 * rng.standard_normal(B)).astype(np.float32)
+    h = O.Hyper(activation="relu", ent_coef=0.01)
+    stats, g, _ = O.loss_and_grads(p, obs, act, oldv, oldlp, adv, ret, h)
+    tp = {k: torch.tensor(v, requires_grad=True) for k, v in p.items()}
+    x = torch.tensor(obs)
+
+    def net(pre):
+        h1 = torch.relu(x @ tp[pre + ".0.weight"].T + tp[pre + ".0.bias"])
+        return torch.relu(h1 @ tp[pre + ".2.weight"].T + tp[pre + ".2.bias"])
+    mean = net("mlp_extractor.policy_net") @ tp["action_net.weight"].T + tp["action_net.bias"]
+    val = (net("mlp_extractor.value_net") @ tp["value_net.weight"].T + tp["value_net.bias"])[:, 0]
+    dist = torch.distributions.Normal(mean, torch.ones_like(mean) * tp["log_std"].exp())
+    lp, ent = dist.log_prob(torch.tensor(act)).sum(1), dist.entropy().sum(1)
+    a = torch.tensor(adv)
+    a = (a - a.mean()) / (a.std() + 1e-8)
+    ratio = torch.exp(lp - torch.tensor(oldlp))
+    loss = (-torch.min(a * ratio, a * torch.clamp(ratio, 0.8, 1.2)).mean() + 0.01 * (-ent.mean())
+            + 0.5 * torch.nn.functional.mse_loss(torch.tensor(ret), val))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(stats["loss"])) < 1e-6
+    for k in g:
+        assert np.max(np.abs(tp[k].grad.numpy() - g[k])) < 1e-6, k
+    m_t, v_t = O.policy_outputs(p, obs, activation="tanh")
+    m_r, v_r = O.policy_outputs(p, obs, activation="relu")
+    assert np.max(np.abs(m_r - mean.detach().numpy())) < 1e-6 and np.max(np.abs(m_t - m_r)) > 1e-3
