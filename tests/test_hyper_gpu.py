@@ -233,7 +233,7 @@ def test_relu_networks_match_the_oracle(H, D, A, tmp_path):
         ppo = PPO("MlpPolicy", env, n_steps=16, batch_size=128, n_epochs=2, policy_kwargs=dict(activation_fn=torch.nn.ReLU), seed=2)
         assert ppo.activation == "relu" and ppo.engine.cfg.activation == 1
         ppo.learn(total_timesteps=2 * 16 * 32)
-        obs1 = np.asarray(ppo._last_obs[:4], np.float32)
+        obs1 = np.asarray(ppo.engine.read("obs")[0][:4], np.float32)   # (the device env keeps its observations in HBM)
         act1, _ = ppo.predict(obs1, deterministic=True)
         m1, _ = O.policy_outputs(ppo.engine.get_params(), obs1, activation="relu")
         assert np.max(np.abs(act1 - np.clip(m1, -1, 1))) < 1e-4
