@@ -388,6 +388,10 @@ enum {
                                       approx_kl, clip fraction, row count, ...) -- what a data-parallel step sums across ranks */
   MOBROB_BUF_COUNT = 20
 };
+/* Device pointer and size of a buffer.  Asking for the POINTER of ACTIONS / VALUES / LOG_PROBS / ADVANTAGES / RETURNS tells the
+ * engine that the caller may write those arrays behind its back: the packed per-row training records the 256-wide gradient
+ * kernel reads are then re-packed before every gradient launch instead of once per rollout (ptr_dev == NULL
+ * queries the size only and changes nothing).  write_buffer needs no such care: it invalidates the records itself. */
 int mobrob_ppo_buffer_info(mobrob_ppo_engine_t* e, int32_t which, void** ptr_dev, size_t* bytes);
 /* copy with host layout [..][D] <-> device layout [..][Dp] handled for MOBROB_BUF_OBS */
 int mobrob_ppo_read_buffer(mobrob_ppo_engine_t* e, int32_t which, void* host_out, size_t bytes);

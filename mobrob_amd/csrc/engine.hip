@@ -118,6 +118,10 @@ struct mobrob_ppo_engine {
   uint32_t env_step_counter = 0;
   int t = 0;
   bool rollout_ready = false;
+  // training records of the H = 256 gradient kernel (kernels_fused.h, k_build_train_records): rebuilt before the next
+  // gradient launch whenever one of the five arrays they are packed from may have changed
+  bool train_rec_valid = false;
+  bool train_rec_external = false;  // a device pointer to one of those arrays was handed out (buffer_info): never trusted again
   // update
   int* rows = nullptr;          // [T*N] device row index per permuted position
   int64_t* perm_dev = nullptr;  // [T*N]
@@ -417,6 +421,7 @@ int fused_init(mobrob_ppo_engine* e) {
   } else {
     f.slab_floats = slab_size(e->Dp);
     CHK(dalloc(e, &f.slabs, (size_t)f.max_grid * f.slab_floats));
+    CHK(dalloc(e, &f.train_rec, (size_t)e->N * e->T * train_rec_width(e->A)));
     f.lds_bytes = fused_lds_bytes(e->Dp);
     f.lds_act_bytes = fused_lds_act_bytes(e->Dp);
   }
@@ -510,11 +515,11 @@ void fused_minibatch_grad(mobrob_ppo_engine* e, int mb, int start, int B, float 
   FusedState& f = e->fused;
   FusedTrainArgs a{};
   a.net[0] = f.net[0]; a.net[1] = f.net[1];
-  a.obs = e->obs; a.Dp = e->Dp; a.actions = e->actions; a.A = e->A; a.old_logp = e->logp; a.adv = e->adv; a.ret = e->ret;
+  a.obs = e->obs; a.Dp = e->Dp; a.A = e->A; a.rec = f.train_rec; a.RW = train_rec_width(e->A);
   a.rows = e->rows + start; a.count = B; a.log_std = e->params + e->offs[T_LOGSTD];
   a.advstat = e->advstat + 4 * (size_t)mb; a.normalize = e->cfg.normalize_advantage;
   a.clip = (float)e->cfg.clip_range; a.vf_coef = (float)e->cfg.vf_coef; a.ent_coef = (float)e->cfg.ent_coef;
-  a.clip_vf = (float)e->clip_vf; a.old_values = e->values;
+  a.clip_vf = (float)e->clip_vf;
   a.inv_bg = inv_bg; a.slabs = f.slabs; a.slab_floats = f.slab_floats; a.sums = e->grads + e->P;
   a.stamps = f.stamps;
   const int ntiles = cdiv(B, FR);
@@ -892,7 +897,7 @@ int mobrob_ppo_set_optimizer_state(mobrob_ppo_engine_t* e, const float* m, const
 int mobrob_ppo_rollout_begin(mobrob_ppo_engine_t* e) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   e->t = 0;
-  e->rollout_ready = false;
+  e->rollout_ready = false; e->train_rec_valid = false;
   e->nparts = 0;
   for (auto& q : e->pinned_seen) q = nullptr;
   e->pinned_seen_n = 0;
@@ -1151,7 +1156,7 @@ int mobrob_ppo_finish_rollout(mobrob_ppo_engine_t* e, const float* last_obs, con
   forward(e, slot, e->N, false, nullptr, true, e->last_values);
   run_gae(e);
   HIPC(hipStreamSynchronize(e->stream));
-  e->rollout_ready = true;
+  e->rollout_ready = true; e->train_rec_valid = false;
   return MOBROB_OK;
 }
 
@@ -1159,13 +1164,13 @@ int mobrob_ppo_compute_gae(mobrob_ppo_engine_t* e) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   run_gae(e);
   HIPC(hipStreamSynchronize(e->stream));
-  e->rollout_ready = true;
+  e->rollout_ready = true; e->train_rec_valid = false;
   return MOBROB_OK;
 }
 
 int mobrob_ppo_mark_rollout_ready(mobrob_ppo_engine_t* e) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
-  e->rollout_ready = true;
+  e->rollout_ready = true; e->train_rec_valid = false;
   e->t = e->T;
   return MOBROB_OK;
 }
@@ -1366,7 +1371,7 @@ int collect_device(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& s
     HIPC(hipStreamSynchronize(e->stream));
     e->env_started = sp.kind;
   }
-  e->rollout_ready = false;
+  e->rollout_ready = false; e->train_rec_valid = false;
   if (rollout_persistent_ok(e)) CHK(rollout_side_stream_init(e));
   // Graph replay: every kernel argument of the T-step loop is fixed (slot pointers, ping-pong buffers with even T,
   // counters relative to device-resident bases), so the loop is captured once and replayed per rollout.
@@ -1391,7 +1396,7 @@ int collect_device(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& s
         CHK(enqueue_rollout(e, sp));
         HIPC(hipGetLastError());
         e->t = e->T;
-        e->rollout_ready = true;
+        e->rollout_ready = true; e->train_rec_valid = false;
         return MOBROB_OK;
       }
       const int rc = enqueue_rollout(e, sp);
@@ -1407,7 +1412,7 @@ int collect_device(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& s
   }
   HIPC(hipGetLastError());
   e->t = e->T;
-  e->rollout_ready = true;
+  e->rollout_ready = true; e->train_rec_valid = false;
   return MOBROB_OK;
 }
 }  // namespace
@@ -1539,10 +1544,25 @@ int mobrob_ctrl_drone_pid(mobrob_ppo_engine_t* e, int32_t n, int32_t dev_ptrs, c
 // ---- update ----------------------------------------------------------------------------------------
 int mobrob_ppo_num_minibatches(const mobrob_ppo_engine_t* e) { return e ? e->nmb : -1; }
 
+// The training records (kernels_fused.h) are packed once per rollout: every call that can change actions / values /
+// log-probs / advantages / returns clears train_rec_valid (rollouts, GAE, write_buffer); a caller that obtained a device
+// pointer to one of them (buffer_info) can write without the engine seeing it, so from then on they are re-packed before
+// every gradient launch.
+static void ensure_train_records(mobrob_ppo_engine* e) {
+  if (!e->fused.train_rec || (e->train_rec_valid && !e->train_rec_external)) return;
+  TrainRecArgs r{};
+  r.actions = e->actions; r.old_logp = e->logp; r.adv = e->adv; r.ret = e->ret; r.values = e->values;
+  r.A = e->A; r.RW = train_rec_width(e->A); r.rows = e->N * e->T; r.rec = e->fused.train_rec;
+  const long long items = (long long)r.rows * (r.RW / 4);
+  hipLaunchKernelGGL(k_build_train_records, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, e->stream, r);
+  e->train_rec_valid = true;
+}
+
 int mobrob_ppo_epoch_begin(mobrob_ppo_engine_t* e, const int64_t* perm) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   if (!e->rollout_ready) return fail(MOBROB_ERR_STATE, "epoch_begin: rollout not finished (finish_rollout / collect first)");
   const int total = e->N * e->T;
+  ensure_train_records(e);
   AdvStatArgs as{};
   as.adv = e->adv; as.total = total; as.T = e->T; as.N = e->N; as.bl = e->Bl; as.nmb = e->nmb;
   as.bins = e->advbins;
@@ -1583,7 +1603,10 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
   e->cur_count = B;
   if (e->fused.enabled) {
     if (e->fused.H == 64) fused64_minibatch_grad(e, mb, start, B, inv_bg);
-    else fused_minibatch_grad(e, mb, start, B, inv_bg);
+    else {
+      ensure_train_records(e);
+      fused_minibatch_grad(e, mb, start, B, inv_bg);
+    }
     HIPC(hipGetLastError());
     e->grad_pending = true;
     return MOBROB_OK;
@@ -2098,7 +2121,12 @@ int mobrob_ppo_predict(mobrob_ppo_engine_t* e, const float* obs, int32_t n, int3
 }
 
 // ---- buffers ----------------------------------------------------------------------------------------
-int mobrob_ppo_buffer_info(mobrob_ppo_engine_t* e, int32_t which, void** ptr, size_t* bytes) {
+static bool feeds_train_records(int32_t which) {
+  return which == MOBROB_BUF_ACTIONS || which == MOBROB_BUF_VALUES || which == MOBROB_BUF_LOG_PROBS ||
+         which == MOBROB_BUF_ADVANTAGES || which == MOBROB_BUF_RETURNS;
+}
+
+static int buffer_lookup(mobrob_ppo_engine* e, int32_t which, void** ptr, size_t* bytes) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   const size_t N = e->N, T = e->T;
   void* p = nullptr;
@@ -2131,10 +2159,16 @@ int mobrob_ppo_buffer_info(mobrob_ppo_engine_t* e, int32_t which, void** ptr, si
   return MOBROB_OK;
 }
 
+int mobrob_ppo_buffer_info(mobrob_ppo_engine_t* e, int32_t which, void** ptr, size_t* bytes) {
+  CHK(buffer_lookup(e, which, ptr, bytes));
+  if (ptr && feeds_train_records(which)) e->train_rec_external = true;  // see ensure_train_records
+  return MOBROB_OK;
+}
+
 int mobrob_ppo_read_buffer(mobrob_ppo_engine_t* e, int32_t which, void* host, size_t bytes) {
   if (!e || !host) return fail(MOBROB_ERR_INVALID, "read_buffer: null argument");
   void* p; size_t b;
-  CHK(mobrob_ppo_buffer_info(e, which, &p, &b));
+  CHK(buffer_lookup(e, which, &p, &b));
   if (which == MOBROB_BUF_OBS) {  // host layout [T+1][N][D]
     const size_t rows = (size_t)(e->T + 1) * e->N;
     if (bytes != rows * e->D * 4) return fail(MOBROB_ERR_INVALID, "read_buffer(OBS): expected %zu bytes", rows * e->D * 4);
@@ -2150,7 +2184,8 @@ int mobrob_ppo_read_buffer(mobrob_ppo_engine_t* e, int32_t which, void* host, si
 int mobrob_ppo_write_buffer(mobrob_ppo_engine_t* e, int32_t which, const void* host, size_t bytes) {
   if (!e || !host) return fail(MOBROB_ERR_INVALID, "write_buffer: null argument");
   void* p; size_t b;
-  CHK(mobrob_ppo_buffer_info(e, which, &p, &b));
+  CHK(buffer_lookup(e, which, &p, &b));
+  if (feeds_train_records(which)) e->train_rec_valid = false;
   if (which == MOBROB_BUF_OBS) {
     const size_t rows = (size_t)(e->T + 1) * e->N;
     if (bytes != rows * e->D * 4) return fail(MOBROB_ERR_INVALID, "write_buffer(OBS): expected %zu bytes", rows * e->D * 4);

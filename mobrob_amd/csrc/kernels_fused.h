@@ -38,20 +38,51 @@ struct FusedTrainArgs {
   FusedNet net[2];               // 0 = policy, 1 = value
   // rollout storage
   const float* obs; int Dp;
-  const float* actions; int A;
-  const float* old_logp; const float* adv; const float* ret;
+  int A;
+  const float* rec; int RW;      // training records [T*N][RW]: what the loss stage reads of a row, on one line (train_rec_*)
   const int* rows;               // permuted row indices of this minibatch
   int count;                     // rows in this minibatch (local)
   const float* log_std;
   const double* advstat;         // (sum, sumsq, n, -) of the GLOBAL minibatch
   int normalize;
   float clip, vf_coef, ent_coef, inv_bg;
-  float clip_vf; const float* old_values;  // clip_range_vf (< 0: none) and the rollout's value predictions
+  float clip_vf;                 // clip_range_vf (< 0: none)
   float* slabs;                  // [gridDim.x][slab_floats]
   int slab_floats;
   float* sums;                   // [8] loss statistics (written by k_slab_reduce from the slabs' loss entries)
   unsigned long long* stamps;    // diagnostic build only (MOBROB_STAMPS): per-phase cycle sums
 };
+
+// Training records.  The loss stage needs, of every row of a minibatch, the action taken, the old log-probability, the
+// advantage, the return and the old value prediction: five arrays, i.e. five random cache lines per row for 64 useful
+// bytes (the PMC passes of rounds 1-2 counted 2 x 30.6 MB fetched per launch against 19 MB of rows).  They are packed
+// once per train() into one record per row, a whole number of 64-byte lines:
+//   [0, A) action | zeros | [RW-4] old log-prob | [RW-3] advantage | [RW-2] return | [RW-1] old value
+__host__ __device__ inline int train_rec_width(int A) { return (A + 4 + 15) / 16 * 16; }
+struct TrainRecArgs {
+  const float* actions; const float* old_logp; const float* adv; const float* ret; const float* values;
+  int A, RW, rows;
+  float* rec;
+};
+__global__ __launch_bounds__(256) void k_build_train_records(TrainRecArgs a) {
+  const int per = a.RW / 4;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)a.rows * per) return;
+  const int row = (int)(i / per), g = (int)(i - (long long)row * per);
+  f32x4 v;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int col = 4 * g + c;
+    float x = 0.f;
+    if (col < a.A) x = a.actions[(size_t)row * a.A + col];
+    else if (col == a.RW - 4) x = a.old_logp[row];
+    else if (col == a.RW - 3) x = a.adv[row];
+    else if (col == a.RW - 2) x = a.ret[row];
+    else if (col == a.RW - 1) x = a.values[row];
+    v[c] = x;
+  }
+  *reinterpret_cast<f32x4*>(a.rec + (size_t)row * a.RW + 4 * g) = v;
+}
 
 // slab layout (floats): dW2 [H][H] | dW1 [H][64] | dW3 [32][H] | db2 [H] | db1 [H] | db3 [32] | dls [32] | loss sums [8]
 // The three weight regions are stored in MFMA *fragment order* (the slab is private scratch, only k_slab_reduce
@@ -641,11 +672,11 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   auto load_actions = [&](int src_or_neg, int lq_) {
     const bool live = src_or_neg >= 0, pol = net == 0;
     const unsigned src = live ? (unsigned)src_or_neg : 0u;
-    const unsigned aoff = (src * (unsigned)a.A + (unsigned)lq_) * 4u;
+    const unsigned aoff = (src * (unsigned)a.RW + (unsigned)lq_) * 4u;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
       l_act[j] = (pol && 4 * j + lq_ < a.A && live)
-                     ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.actions) + (aoff + 16u * j))
+                     ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.rec) + (aoff + 16u * j))
                      : 0.f;
   };
   auto gather_loss = [&](int src_or_neg, int lq_) {  // one load per destination register, each after its zero init
@@ -653,9 +684,9 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     const unsigned src = live ? (unsigned)src_or_neg : 0u;
     if constexpr (kActAhead) load_actions(src_or_neg, lq_);
     else l_src = src_or_neg;
-    const float* old_or_ret = pol ? a.old_logp : a.ret;  // policy: old log-prob; value net: return target
-    l_old = live ? old_or_ret[src] : 0.f;
-    l_adv = live ? (pol ? a.adv[src] : (a.clip_vf >= 0.f ? a.old_values[src] : 0.f)) : 0.f;  // value net: old value (vf clipping)
+    const float* tail = a.rec + (size_t)src * a.RW + (a.RW - 4);  // [old log-prob, advantage, return, old value]
+    l_old = live ? tail[pol ? 0 : 2] : 0.f;                        // policy: old log-prob; value net: return target
+    l_adv = live ? (pol ? tail[1] : (a.clip_vf >= 0.f ? tail[3] : 0.f)) : 0.f;  // value net: old value (vf clipping)
   };
   {
     const int lrr0 = tid0 >> 2;
@@ -1640,6 +1671,7 @@ struct FusedState {
   size_t packed_floats = 0;
   FusedNet net[2];
   float* slabs = nullptr;
+  float* train_rec = nullptr;   // H = 256: [T*N][train_rec_width(A)] (k_build_train_records)
   unsigned long long* stamps = nullptr;  // diagnostic build only
   int slab_floats = 0, max_grid = 0;
   int pair_nseq_max = 0;  // 64-wide nets: two-wave workgroups per network of k_pair64_train (slabs are sized for them)

@@ -830,6 +830,55 @@ def test_fused_gradients_are_run_to_run_deterministic():
     e.close()
 
 
+def test_training_records_follow_every_write_to_the_arrays_they_pack():
+    """k_fused_train reads actions / old log-prob / advantage / return / old value of a row from ONE packed record
+    (kernels_fused.h, k_build_train_records) built once per rollout.  The arrays stay writable through the C ABI after
+    epoch_begin: write_buffer must be seen by the next gradient launch, and so must a write through a device pointer
+    obtained from buffer_info (the engine cannot see that one, it re-packs before every launch from then on)."""
+    import torch
+    from mobrob_amd.parallel import device_tensor
+    D, A, T, N, B, H = 58, 12, 16, 64, 1024, 256
+    p = O.init_params(D, A, (H, H), (H, H), seed=1)
+    buf, lv, dones = _consistent_rollout(p, T, N, D, A, seed=2)
+    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, 0.99, 0.95)
+    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=1, batch_size=B, learning_rate=3e-4)
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=1, pi=(H, H), vf=(H, H),
+                    gamma=h.gamma, gae_lambda=h.gae_lambda, ent_coef=h.ent_coef, learning_rate=h.learning_rate)
+    e.set_params(p)
+    e.load_rollout(buf, lv, dones)
+    idx = np.arange(T * N)
+    e.epoch_begin(idx)
+
+    def check(tag):
+        e.minibatch_grad(0)
+        got = e.unflatten(e.read("grads"))
+        _, og, _ = O.loss_and_grads(p, *O.gather_minibatch(buf, idx[:B]), h, acc=np.float64)
+        errs = {k: scaled_err(got[k], og[k]) for k in og}
+        assert max(errs.values()) < 1e-4, (tag, errs)
+        return got
+
+    g0 = check("as loaded")
+    rng = np.random.default_rng(3)
+    buf["log_probs"] = buf["log_probs"] + rng.normal(0, 0.1, buf["log_probs"].shape).astype(np.float32)
+    e.write("log_probs", buf["log_probs"])                      # after epoch_begin
+    g1 = check("write_buffer after epoch_begin")
+    assert scaled_err(g1["mlp_extractor.policy_net.2.weight"], g0["mlp_extractor.policy_net.2.weight"]) > 1e-3
+    ptr, nbytes = e.device_buffer("advantages")                  # a raw device pointer leaves the library
+    adv = device_tensor(ptr, (T, N), torch.float32, torch.device("cuda:0"))
+    buf["advantages"] = (buf["advantages"] + rng.normal(0, 0.5, buf["advantages"].shape)).astype(np.float32)  # not affine: survives normalisation
+    adv.copy_(torch.from_numpy(buf["advantages"]))
+    torch.cuda.synchronize()
+    e.epoch_begin(idx)   # the normalisation statistics of a minibatch are taken here; the engine saw no write
+    g2 = check("write through the device pointer")
+    assert scaled_err(g2["mlp_extractor.policy_net.2.weight"], g1["mlp_extractor.policy_net.2.weight"]) > 1e-3
+    ret = device_tensor(e.device_buffer("returns")[0], (T, N), torch.float32, torch.device("cuda:0"))
+    buf["returns"] = (buf["returns"] + np.float32(0.25)).astype(np.float32)
+    ret.copy_(torch.from_numpy(buf["returns"]))
+    torch.cuda.synchronize()
+    check("second write through a device pointer, no engine call in between")
+    e.close()
+
+
 # ------------------------------------------------------------------------------------------------
 # one workgroup per tile for small minibatches (kernels_split64.h) against the one-wave-per-tile block kernel
 # ------------------------------------------------------------------------------------------------
