@@ -1192,6 +1192,10 @@ __host__ __device__ __forceinline__ int slab_to_canonical(const SlabReduceArgs& 
   return mine ? s.P + k : -1;
 }
 
+#ifndef MOBROB_SLAB_REDUCE_UNROLL
+#define MOBROB_SLAB_REDUCE_UNROLL 8
+#endif
+constexpr int kSlabReduceUnroll = MOBROB_SLAB_REDUCE_UNROLL;
 // grid = (ceil(slab_floats / 256), 2 networks): thread p sums slab position p over the slabs of its network
 // (coalesced reads, fixed order) and scatters the total to the canonical gradient vector.
 __global__ __launch_bounds__(256) void k_slab_reduce(SlabReduceArgs s) {
@@ -1204,16 +1208,29 @@ __global__ __launch_bounds__(256) void k_slab_reduce(SlabReduceArgs s) {
     const float* src = s.slabs + (size_t)net * s.slab_floats + p;
     const size_t stride = 2 * (size_t)s.slab_floats;
     const int n = (s.nslabs - net + 1) / 2;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // Eight loads in flight per lane (A/B on one box, 93 MB per launch: 4-deep 20.4 us, 8-deep 18.8, 16-deep 19.3, 32-deep
+    // 20.3 per launch incl. its event bracket; the kernel streams at ~5.5 of the ~6.1 TB/s a sweep reaches on this part).
+    // Slab w is added to accumulator w mod 8, the accumulators by a fixed tree: one summation order whatever the grid.
+    constexpr int U = kSlabReduceUnroll;
+    float ac[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) ac[k] = 0.f;
     int w = 0;
-    for (; w + 4 <= n; w += 4) {
-      a0 += src[(size_t)w * stride];
-      a1 += src[(size_t)(w + 1) * stride];
-      a2 += src[(size_t)(w + 2) * stride];
-      a3 += src[(size_t)(w + 3) * stride];
+    for (; w + U <= n; w += U) {
+      float v[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) v[k] = src[(size_t)(w + k) * stride];
+#pragma unroll
+      for (int k = 0; k < U; ++k) ac[k] += v[k];
     }
-    for (; w < n; ++w) a0 += src[(size_t)w * stride];
-    acc = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+      if (w + k < n) ac[k] += src[(size_t)(w + k) * stride];
+#pragma unroll
+    for (int d = U / 2; d >= 1; d >>= 1)
+#pragma unroll
+      for (int k = 0; k < d; ++k) ac[k] += ac[k + d];
+    acc = ac[0];
     if (dst < s.offs[1]) acc += s.ent_coef * (-s.b_local) * s.inv_bg;  // entropy bonus gradient on log_std
     s.grads[dst] = acc;
   }
@@ -1620,10 +1637,20 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
       // 2 x 256 (712 records): wave w folds tensors w, w + 4, w + 8, w + 12 -- lane l adds records l, l + 64, ... of the
       // tensor's list in list order, then a fixed butterfly over the lanes: one fixed summation tree per tensor, and four
       // short wave reductions instead of a 256-long serial chain (what made this lose to k_sqnorm_chunks in round 2).
+      // The records come through LDS: ONE round of global loads by all threads, then the four folds of a wave read LDS
+      // (fetched inside the per-tensor loop, each tensor of a wave paid its own two dependent global round trips).
       const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      const bool staged = nrec <= 1024;
+      if (staged) {
+        for (int c = threadIdx.x; c < nrec; c += blockDim.x) part[c] = a.partial[a.fold_idx[c]];
+        __syncthreads();
+      }
       for (int t = wv; t < 13; t += 4) {
         double ts = 0.0;
-        for (int c = a.fold_start[t] + lane; c < a.fold_start[t + 1]; c += 64) ts += a.partial[a.fold_idx[c]];
+        if (staged)
+          for (int c = a.fold_start[t] + lane; c < a.fold_start[t + 1]; c += 64) ts += part[c];
+        else
+          for (int c = a.fold_start[t] + lane; c < a.fold_start[t + 1]; c += 64) ts += a.partial[a.fold_idx[c]];
         ts = wave_sum_d(ts);
         if (lane == 0) nts[t] = (float)sqrt(ts);
       }
