@@ -15,6 +15,32 @@
 #include <string>
 #include <vector>
 
+#ifdef MOBROB_POISON_LDS
+// Diagnostic build (scratch/build_variant.sh poison -DMOBROB_POISON_LDS; never the product library): every kernel launch is
+// preceded by one that fills the LDS of every CU with 0xFFFFFFFF (a NaN as float, -1 as an index).  LDS is not cleared
+// between kernels, so a kernel that reads a word it did not write sees whatever the previous tenant of the CU left there:
+// right on most runs, wrong once in a while.  Under this build it is wrong every time (tests/README: GPU suite with
+// MOBROB_PPO_LIB=scratch/lib_poison.so).
+namespace mobrob {
+__global__ __launch_bounds__(1024) void k_poison_lds() {
+  extern __shared__ unsigned poison_words[];
+  volatile unsigned* w = poison_words;
+  for (int i = threadIdx.x; i < 160 * 256; i += 1024) w[i] = 0xFFFFFFFFu;
+}
+inline void poison_lds(hipStream_t st) {
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void*)k_poison_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  k_poison_lds<<<dim3(512), dim3(1024), 160 * 1024, st>>>();
+}
+}  // namespace mobrob
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, nb, nt, mem, st, ...)                    \
+  do {                                                                          \
+    mobrob::poison_lds(st);                                                     \
+    hipLaunchKernelGGLInternal((kernelName), nb, nt, mem, st, __VA_ARGS__);     \
+  } while (0)
+#endif
+
 #include "../../include/mobrob_ppo.h"
 #include "kernels_generic.h"
 #include "kernels_fused.h"
