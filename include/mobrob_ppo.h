@@ -399,6 +399,12 @@ int mobrob_ppo_write_buffer(mobrob_ppo_engine_t* e, int32_t which, const void* h
 /* mark the rollout as complete (tests that inject a rollout with write_buffer) */
 int mobrob_ppo_mark_rollout_ready(mobrob_ppo_engine_t* e);
 
+/* train/explained_variance as SB3's PPO.train logs it (stable_baselines3 2.0.0 ppo.py: explained_variance(rollout_buffer.values.flatten(),
+ * rollout_buffer.returns.flatten()) = 1 - Var[returns - values] / Var[returns], NaN when the returns do not vary), over the rollout
+ * in the buffer; reached from the reference through PPOCtrl.learn (src/mobrob/rl_control/ppo.py:73-74) with verbose / tensorboard_log
+ * (ppo.py:52-56).  Synchronises the engine's stream. */
+int mobrob_ppo_explained_variance(mobrob_ppo_engine_t* e, double* out);
+
 /* GAE on the buffers as they are (after write_buffer of rewards/values/episode_starts/
  * last_values/last_dones): RolloutBuffer.compute_returns_and_advantage in isolation. */
 int mobrob_ppo_compute_gae(mobrob_ppo_engine_t* e);

@@ -152,6 +152,7 @@ struct mobrob_ppo_engine {
   int* rows = nullptr;          // [T*N] device row index per permuted position
   int64_t* perm_dev = nullptr;  // [T*N]
   double* advstat = nullptr;    // [nmb][4]
+  double* expvar_part = nullptr;  // [kEvBlocks][4] partial sums of mobrob_ppo_explained_variance
   unsigned long long* advbins = nullptr;  // [nmb][2] fixed-point sums of k_adv_stats_stream (+ 1 word: max |adv| bits)
   uint64_t perm_counter = 0;
   unsigned adv_pass = 0;        // epoch_begin calls so far: which of the two max-|adv| words is live
@@ -732,7 +733,7 @@ int engine_alloc(mobrob_ppo_engine* e) {
   CHK(dalloc(e, &e->dones_tmp, N)); CHK(dalloc(e, &e->clip_act, N * A)); CHK(dalloc(e, &e->rew_tmp, N));
   CHK(dalloc(e, &e->term_obs, N * Dp)); CHK(dalloc(e, &e->term_val, N)); CHK(dalloc(e, &e->eps_dev, R * A));
   CHK(dalloc(e, &e->trunc_dev, N)); CHK(dalloc(e, &e->dones_u8, N)); CHK(dalloc(e, &e->ep_len, N)); CHK(dalloc(e, &e->ep_len2, N)); CHK(dalloc(e, &e->ctr_dev, 2));
-  CHK(dalloc(e, &e->rows, T * N)); CHK(dalloc(e, &e->perm_dev, T * N)); CHK(dalloc(e, &e->advstat, (size_t)e->nmb * 4)); CHK(dalloc(e, &e->advbins, (size_t)e->nmb * 2 + 1));  // + two 32-bit max words
+  CHK(dalloc(e, &e->rows, T * N)); CHK(dalloc(e, &e->perm_dev, T * N)); CHK(dalloc(e, &e->advstat, (size_t)e->nmb * 4)); CHK(dalloc(e, &e->advbins, (size_t)e->nmb * 2 + 1)); CHK(dalloc(e, &e->expvar_part, (size_t)kEvBlocks * 4));  // + two 32-bit max words
   CHK(dalloc(e, &e->stats, (size_t)e->stats_cap * 8));
   CHK(dalloc(e, &e->Xg, Bl * Dp)); CHK(dalloc(e, &e->actg, Bl * A)); CHK(dalloc(e, &e->lpg, Bl));
   CHK(dalloc(e, &e->advg, Bl)); CHK(dalloc(e, &e->retg, Bl)); CHK(dalloc(e, &e->oldvg, Bl));
@@ -1191,6 +1192,22 @@ int mobrob_ppo_compute_gae(mobrob_ppo_engine_t* e) {
   run_gae(e);
   HIPC(hipStreamSynchronize(e->stream));
   e->rollout_ready = true; e->train_rec_valid = false;
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_explained_variance(mobrob_ppo_engine_t* e, double* out) {
+  if (!e || !out) return fail(MOBROB_ERR_INVALID, "explained_variance: null argument");
+  if (!e->rollout_ready) return fail(MOBROB_ERR_STATE, "explained_variance: rollout not finished");
+  const int n = e->N * e->T;
+  hipLaunchKernelGGL(k_explained_variance_partials, dim3(kEvBlocks), dim3(256), 0, e->stream, e->values, e->ret, n, e->expvar_part);
+  double part[kEvBlocks * 4];
+  HIPC(hipMemcpyAsync(part, e->expvar_part, sizeof part, hipMemcpyDeviceToHost, e->stream));
+  HIPC(hipStreamSynchronize(e->stream));
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int b = 0; b < kEvBlocks; ++b)
+    for (int k = 0; k < 4; ++k) s[k] += part[b * 4 + k];
+  const double var_y = s[1] / n - (s[0] / n) * (s[0] / n), var_d = s[3] / n - (s[2] / n) * (s[2] / n);
+  *out = var_y > 0.0 ? 1.0 - var_d / var_y : NAN;  // SB3: nan when the returns do not vary
   return MOBROB_OK;
 }
 

@@ -863,4 +863,28 @@ __global__ void k_env_reset(uint64_t seed, int N, int D, int Dp, float* __restri
   if (c == 0) ep_len[n] = 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// train/explained_variance of SB3's PPO.train (explained_variance(values, returns) = 1 - Var[returns - values] / Var[returns]
+// over the whole rollout buffer): per-block float64 partial sums (n is implied) of y, y^2, d = y - v, d^2 in a fixed order;
+// the host adds the blocks in block order.  A logging quantity, called once per logged iteration.
+// ------------------------------------------------------------------------------------------------
+constexpr int kEvBlocks = 256;
+__global__ __launch_bounds__(256) void k_explained_variance_partials(const float* __restrict__ values, const float* __restrict__ returns,
+                                                                     int n, double* __restrict__ out) {
+  __shared__ double red[4][256];
+  double sy = 0.0, syy = 0.0, sd = 0.0, sdd = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const double y = returns[i], d = (double)returns[i] - (double)values[i];
+    sy += y; syy += y * y; sd += d; sdd += d * d;
+  }
+  red[0][threadIdx.x] = sy; red[1][threadIdx.x] = syy; red[2][threadIdx.x] = sd; red[3][threadIdx.x] = sdd;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) out[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+
 }  // namespace mobrob

@@ -335,6 +335,12 @@ class PPOEngine:
     def compute_gae(self):
         check(self.lib.mobrob_ppo_compute_gae(self._h))
 
+    def explained_variance(self):
+        """1 - Var[returns - values] / Var[returns] over the rollout in the buffer (SB3's train/explained_variance)."""
+        out = C.c_double()
+        check(self.lib.mobrob_ppo_explained_variance(self._h, C.byref(out)))
+        return float(out.value)
+
     def mark_rollout_ready(self):
         check(self.lib.mobrob_ppo_mark_rollout_ready(self._h))
 

@@ -452,6 +452,8 @@ class PPO:
                 print(f"Early stopping at step {epochs - 1} due to reaching max kl: {stats['approx_kl']:.2f}")
         return stats
 
+    _tb = None   # event-file writer of the learn() call in progress (tensorboard_log)
+
     def learn(self, total_timesteps, callback=None, log_interval=1, tb_log_name="PPO", reset_num_timesteps=True,
               progress_bar=False):
         if self.env is None:
@@ -488,6 +490,10 @@ class PPO:
             except ImportError:
                 bar = None
         iteration = 0
+        self._tb = None
+        if self.tensorboard_log is not None and self.rank == 0:   # SB3 configure_logger: <tensorboard_log>/<tb_log_name>_<run id>
+            from ..tb_events import EventFileWriter, next_run_dir
+            self._tb = EventFileWriter(next_run_dir(self.tensorboard_log, tb_log_name, continue_latest=not reset_num_timesteps))
         while self.num_timesteps < total_timesteps:
             before = self.num_timesteps
             if not self._collect_rollouts(callback):
@@ -497,10 +503,15 @@ class PPO:
             stats = self.train()
             if bar is not None:
                 bar.update(self.num_timesteps - before)
-            if self.verbose >= 1 and log_interval is not None and iteration % log_interval == 0:
+            # SB3 dumps its logger every `log_interval` iterations whatever `verbose` is: stdout for verbose >= 1, the
+            # event file whenever tensorboard_log is set
+            if log_interval is not None and iteration % log_interval == 0 and (self.verbose >= 1 or self._tb is not None):
                 self._log(iteration, stats)
         if bar is not None:
             bar.close()
+        if self._tb is not None:
+            self._tb.close()
+            self._tb = None
         callback.on_training_end()
         return self
 
@@ -515,8 +526,19 @@ class PPO:
                  ("time/total_timesteps", self.num_timesteps), ("train/approx_kl", stats["approx_kl"]),
                  ("train/clip_fraction", stats["clip_fraction"]), ("train/clip_range", self.clip_range),
                  ("train/entropy_loss", stats["entropy_loss"]), ("train/learning_rate", self.learning_rate),
+                 ("train/explained_variance", self.engine.explained_variance()),
                  ("train/loss", stats["loss"]), ("train/n_updates", self._n_updates),
-                 ("train/policy_gradient_loss", stats["policy_loss"]), ("train/value_loss", stats["value_loss"])]
+                 ("train/policy_gradient_loss", stats["policy_loss"]),
+                 ("train/std", float(np.mean(np.exp(self.engine.get_params()["log_std"])))),
+                 ("train/value_loss", stats["value_loss"])]
+        if self.clip_range_vf is not None and not callable(self.clip_range_vf):
+            rows.append(("train/clip_range_vf", float(self.clip_range_vf)))
+        if self._tb is not None:   # SB3 keeps these three out of the event file (logger.record(..., exclude="tensorboard"))
+            skip = ("time/iterations", "time/time_elapsed", "time/total_timesteps")
+            self._tb.add_scalars([(k, v) for k, v in rows if k not in skip], self.num_timesteps)
+        if self.verbose < 1 or self.rank != 0:
+            return
+        rows.sort()
         w = max(len(k) for k, _ in rows)
         print("-" * (w + 20))
         for k, v in rows:

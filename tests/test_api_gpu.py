@@ -112,6 +112,49 @@ def test_device_env_learn_and_engine_backend_equivalence():
     assert np.array_equal(be.grad_tensor().cpu().numpy()[:e.P], e.read("grads"))  # zero-copy view of the engine buffer
 
 
+def test_tensorboard_log_writes_sb3_style_event_files(tmp_path, capsys):
+    """PPO(tensorboard_log=...) as the reference configures it (src/mobrob/rl_control/ppo.py:52-56): one run directory per
+    learn() call, `<log>/<tb_log_name>_<n>`, one event per logged iteration at step = num_timesteps with SB3's scalar
+    names; `time/iterations`, `time/time_elapsed`, `time/total_timesteps` go to stdout only.  train/explained_variance
+    (C-ABI mobrob_ppo_explained_variance) against numpy on the buffers."""
+    from mobrob_amd import tb_events as tb
+    from mobrob_amd.rl_control.ppo import PPOCtrl
+    log = str(tmp_path / "tensorboard")
+    cfg = _config("point", n_envs=8, vec_env_type="device", ppo_kwargs=dict(n_steps=64, batch_size=128, n_epochs=2, verbose=1))
+    ctrl = PPOCtrl.from_config(cfg)
+    ctrl.ppo.tensorboard_log = log          # PPOCtrl sets it only when the tensorboard package is importable, as the reference does
+    ctrl.learn(total_timesteps=3 * 8 * 64)
+    runs = sorted(os.listdir(log))
+    assert runs == ["PPO_1"]
+    files = os.listdir(os.path.join(log, "PPO_1"))
+    assert len(files) == 1 and files[0].startswith("events.out.tfevents.")
+    ev = tb.read_events(os.path.join(log, "PPO_1", files[0]))
+    assert ev[0]["file_version"] == "brain.Event:2"
+    assert [e["step"] for e in ev[1:]] == [512, 1024, 1536]
+    want = {"time/fps", "train/approx_kl", "train/clip_fraction", "train/clip_range", "train/entropy_loss",
+            "train/explained_variance", "train/learning_rate", "train/loss", "train/n_updates",
+            "train/policy_gradient_loss", "train/std", "train/value_loss"}
+    for e in ev[1:]:
+        assert want <= set(e["scalars"]) and not {"time/iterations", "time/time_elapsed", "time/total_timesteps"} & set(e["scalars"])
+    assert [e["scalars"]["train/n_updates"] for e in ev[1:]] == [2.0, 4.0, 6.0]
+    out = capsys.readouterr().out
+    assert "time/total_timesteps" in out and "train/explained_variance" in out and "train/std" in out
+    # the numbers: explained variance and std of the last logged iteration against the buffers / parameters as they stand
+    eng = ctrl.ppo.engine
+    y, v = eng.read("returns").ravel().astype(np.float64), eng.read("values").ravel().astype(np.float64)
+    ref = 1.0 - np.var(y - v) / np.var(y)
+    assert abs(eng.explained_variance() - ref) < 1e-9 * max(1.0, abs(ref))
+    assert abs(ev[-1]["scalars"]["train/explained_variance"] - ref) < 1e-5 * max(1.0, abs(ref))
+    assert abs(ev[-1]["scalars"]["train/std"] - float(np.mean(np.exp(eng.get_params()["log_std"])))) < 1e-6
+    # a second learn() call opens run 2; continuing (reset_num_timesteps=False) appends to the latest run directory
+    ctrl.learn(total_timesteps=8 * 64)
+    ctrl.ppo.learn(total_timesteps=8 * 64, reset_num_timesteps=False)
+    assert sorted(os.listdir(log)) == ["PPO_1", "PPO_2"] and len(os.listdir(os.path.join(log, "PPO_2"))) >= 1
+    # returns that do not vary: NaN, as SB3's explained_variance gives
+    eng.write("returns", np.ones((64, 8), np.float32))
+    assert np.isnan(eng.explained_variance())
+
+
 def test_torch_ops_between_grad_and_apply_are_stream_ordered_with_the_engine():
     """The data-parallel loop relies on torch ops (the RCCL all-reduce) being ordered between minibatch_grad and
     minibatch_apply on the backend's stream.  Stand-in for the collective: zero / double the gradient in place."""

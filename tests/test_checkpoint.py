@@ -191,3 +191,36 @@ def test_policy_kwargs_with_an_activation_class_round_trip(tmp_path):
     assert real["activation_fn"] is torch.nn.ReLU and real["net_arch"] == {"pi": [64, 64], "vf": [64, 64]}
     back = ck.load_zip(path)["data"]["policy_kwargs"]
     assert back["activation_fn"] == "ReLU" and back["log_std_init"] == -0.5 and back["net_arch"] == {"pi": [64, 64], "vf": [64, 64]}
+
+
+def test_event_file_writer_round_trip(tmp_path):
+    """tensorboard_log without the tensorboard package (mobrob_amd/tb_events.py): CRC-32C known answer, SB3's run-directory
+    numbering, and a write / parse round trip with every record CRC checked."""
+    from mobrob_amd import tb_events as tb
+    assert tb.crc32c(b"123456789") == 0xE3069283          # the check value of CRC-32C (Castagnoli)
+    assert tb.crc32c(b"") == 0
+    root = str(tmp_path / "tensorboard")
+    first = tb.next_run_dir(root, "PPO")
+    assert first.endswith("PPO_1")
+    w = tb.EventFileWriter(first)
+    w.add_scalars([("train/loss", 0.25), ("time/fps", 1234), ("train/explained_variance", float("nan"))], 4096)
+    w.add_scalars([("train/loss", -1.5)], 8192)
+    w.close()
+    assert tb.next_run_dir(root, "PPO").endswith("PPO_2") and tb.next_run_dir(root, "PPO", continue_latest=True).endswith("PPO_1")
+    assert tb.next_run_dir(root, "other").endswith("other_1")
+    ev = tb.read_events(w.path)
+    assert ev[0]["file_version"] == "brain.Event:2" and ev[0]["step"] == 0
+    assert ev[1]["step"] == 4096 and ev[1]["scalars"] == {"train/loss": 0.25, "time/fps": 1234.0}   # the NaN is not written
+    assert ev[2]["step"] == 8192 and ev[2]["scalars"] == {"train/loss": -1.5}
+    # the framing is TFRecord's: a flipped payload byte is caught by the payload CRC
+    raw = bytearray(open(w.path, "rb").read())
+    raw[30] ^= 1
+    bad = tmp_path / "bad"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(ValueError):
+        tb.read_events(str(bad))
+    # the exact bytes of one event, written out from the protobuf wire format by hand: Event{wall_time=1.5, step=3,
+    # summary{value{tag="a", simple_value=2.0}}}
+    want = bytes([0x09]) + __import__("struct").pack("<d", 1.5) + bytes([0x10, 0x03, 0x2A, 0x0A, 0x0A, 0x08, 0x0A, 0x01, 0x61, 0x15]) \
+        + __import__("struct").pack("<f", 2.0)
+    assert tb.encode_event(1.5, 3, [("a", 2.0)]) == want
