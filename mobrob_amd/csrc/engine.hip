@@ -19,7 +19,7 @@
 // Diagnostic build (scratch/build_variant.sh poison -DMOBROB_POISON_LDS; never the product library): every kernel launch is
 // preceded by one that fills the LDS of every CU with 0xFFFFFFFF (a NaN as float, -1 as an index).  LDS is not cleared
 // between kernels, so a kernel that reads a word it did not write sees whatever the previous tenant of the CU left there:
-// right on most runs, wrong once in a while.  Under this build it is wrong every time (tests/README: GPU suite with
+// right on most runs, wrong once in a while.  Under this build it is wrong every time (scratch/README.md: GPU suite with
 // MOBROB_PPO_LIB=scratch/lib_poison.so).
 namespace mobrob {
 __global__ __launch_bounds__(1024) void k_poison_lds() {
