@@ -81,7 +81,12 @@ typedef struct mobrob_ppo_config {
   int32_t rollout_persistent; /* 1: run the device-resident rollout as one persistent kernel (fused widths) */
   int32_t activation;         /* hidden activation of both networks: MOBROB_ACT_TANH (0; SB3's default for MlpPolicy, every
                                  reference YAML) or MOBROB_ACT_RELU (policy_kwargs activation_fn=nn.ReLU; generic GEMM chain) */
-  int32_t reserved[4];
+  int32_t forward_x3;         /* 1 (default): the forward-only kernels of 256-wide nets (rollout policy forward, batched value pass)
+                                 multiply on the bf16 matrix pipe with every float32 operand split into three bf16 pieces and six
+                                 piece products kept, float32 accumulation -- float32 results (error against float64 not larger than
+                                 v_mfma_f32's) at 1.7x the rate; 0: v_mfma_f32_32x32x2_f32 everywhere.  The gradient
+                                 kernels are on the f32 pipe either way. */
+  int32_t reserved[3];
 } mobrob_ppo_config_t;
 
 /* Fill `cfg` with SB3 2.0.0 defaults (Appendix A.1).  Replaces PPO.__init__'s default kwargs. */

@@ -435,6 +435,7 @@ int fused_init(mobrob_ppo_engine* e) {
     f.net[n].W3h = reinterpret_cast<const f32x4*>(p); p += nW3h;  // last: the H = 64 kernels mirror [W1f, b2s] as one block
     f.net[n].b3 = e->params + e->offs[bias_ids[n][2]];
     f.net[n].head = n == 0 ? e->A : 1;
+    f.net[n].W1x = nullptr; f.net[n].W2x = nullptr;
   }
   f.max_grid = 256;
   if (H == 64) {
@@ -448,6 +449,15 @@ int fused_init(mobrob_ppo_engine* e) {
   } else {
     f.slab_floats = slab_size(e->Dp);
     CHK(dalloc(e, &f.slabs, (size_t)f.max_grid * f.slab_floats));
+    if (e->cfg.forward_x3 && e->cfg.activation == MOBROB_ACT_TANH && getenv("MOBROB_NO_X3") == nullptr) {
+      // x3 packs of the hidden layers of both networks (kernels_fused.h, gemm_x3_r32): rebuilt at the start of every rollout
+      for (int n = 0; n < 2; ++n) {
+        unsigned* w1 = nullptr; unsigned* w2 = nullptr;
+        CHK(dalloc(e, &w1, (size_t)(H / 32) * (e->Dp / 16) * 192 * 4));
+        CHK(dalloc(e, &w2, (size_t)(H / 32) * (H / 16) * 192 * 4));
+        f.net[n].W1x = w1; f.net[n].W2x = w2;
+      }
+    }
     CHK(dalloc(e, &f.train_rec, (size_t)e->N * e->T * train_rec_width(e->A)));
     f.lds_bytes = fused_lds_bytes(e->Dp);
     f.lds_act_bytes = fused_lds_act_bytes(e->Dp);
@@ -653,6 +663,7 @@ void mobrob_ppo_default_config(mobrob_ppo_config_t* c) {
   c->normalize_advantage = 1; c->seed = 0; c->device_id = 0; c->rank = 0; c->world_size = 1; c->fast_kernels = 1;
   c->rollout_graph = 1;
   c->rollout_persistent = 1;
+  c->forward_x3 = 1;
 }
 
 void* mobrob_ppo_host_alloc(size_t bytes) {
@@ -1306,6 +1317,16 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
   // The rollout blocks (32 envs each, ~100 KB of LDS) leave CUs idle when N < 32 * 256; the value pass of the steps
   // already finished runs there at the same time: the rollout is cut into chunks, chunk c's value pass is enqueued
   // on a second stream behind an event and overlaps the rollout of chunk c+1.
+  if (e->fused.net[0].W2x != nullptr) {  // the parameters may have changed since the last rollout (train, set_params)
+    const int w1[2] = {T_PW1, T_VW1}, w2[2] = {T_PW2, T_VW2};
+    for (int n = 0; n < 2; ++n) {
+      const int H = FH, KS1 = Dp / 16, KS2 = FH / 16;
+      hipLaunchKernelGGL(k_pack_x3, dim3(cdiv((H / 32) * KS1 * 512, 256)), dim3(256), 0, e->stream, Pp(e, w1[n]), H, e->D, e->D,
+                         kTanhScale, reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W1x)), H / 32, KS1);
+      hipLaunchKernelGGL(k_pack_x3, dim3(cdiv((H / 32) * KS2 * 512, 256)), dim3(256), 0, e->stream, Pp(e, w2[n]), H, H, H,
+                         kTanhScale, reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2x)), H / 32, KS2);
+    }
+  }
   const int rblocks = cdiv(N, 32);
   const bool overlap = rblocks <= 192;                      // otherwise the rollout itself fills the device
   const int chunk = overlap ? std::max(16, cdiv(T, 20)) : T;

@@ -117,6 +117,11 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const bool noise_wave = !kRolloutStationary && wave >= 4;  // wave-uniform
   const FusedNet W = a.pi;
+  // hidden layers on the bf16 matrix pipe with three-way split float32 operands (kernels_fused.h, gemm_x3_r32) when the engine
+  // maintains the x3 packs; block-uniform
+  const bool x3 = W.W2x != nullptr;
+  const u32x4* W1x = reinterpret_cast<const u32x4*>(W.W1x);
+  const u32x4* W2x = reinterpret_cast<const u32x4*>(W.W2x);
   const int row0 = blockIdx.x * R;
   const int N = a.N, A = a.A, D = a.D;
   int* cnt = reinterpret_cast<int*>(&lds[L::BL]);
@@ -211,6 +216,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       constexpr int nkg = DP / 8;
       if (ROLL_ON(2)) {
         if (kRolloutStationary) gemm_two_resident<ldx, NKG1>(LB::X, w1a, w1b, c0, c1, lane);
+        else if (x3) gemm_x3_r32<ldx, DP / 16>(LB::X, W1x + (size_t)(2 * wave) * (DP / 16) * 192, W1x + (size_t)(2 * wave + 1) * (DP / 16) * 192, c0, c1, lane);
         else gemm_lds_packed_r32<ldx>(LB::X, W.W1f + (size_t)(2 * wave) * nkg * 64, W.W1f + (size_t)(2 * wave + 1) * nkg * 64, nkg,
                                       c0, c1, lane);
       }
@@ -227,6 +233,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       constexpr int nkg = FH / 8;
       if (ROLL_ON(4)) {
         if (kRolloutStationary) gemm_two_resident<FLDH, 32>(LB::H1, w2a, w2b, c0, c1, lane);
+        else if (x3) gemm_x3_r32<FLDH, FH / 16>(LB::H1, W2x + (size_t)(2 * wave) * (FH / 16) * 192, W2x + (size_t)(2 * wave + 1) * (FH / 16) * 192, c0, c1, lane);
         else gemm_lds_packed_r32_deep<FLDH>(LB::H1, W.W2f + (size_t)(2 * wave) * nkg * 64,
                                             W.W2f + (size_t)(2 * wave + 1) * nkg * 64, nkg, c0, c1, lane);
       }
@@ -464,7 +471,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_value_batch(FusedNet W, const f
         xr[u] = ldg16(X, (unsigned)(nt * FR + rr) * (unsigned)(DP * 4) + (unsigned)(c * 16));
     }
     __syncthreads();
-    const Frag2 f3 = tile_layers<DP, true>(W, wave, lane, f1 STAMP_ARGS);
+    const Frag2 f3 = W.W2x != nullptr ? tile_layers_x3<DP>(W, wave, lane) : tile_layers<DP, true>(W, wave, lane, f1 STAMP_ARGS);
     tile_head16<DP>(W, wave, lane, f3);  // wave w writes head rows 16w..16w+15, read back by the same wave below
     if (lane < 16) {
       const int rr = 16 * wave + lane, row = tile * FR + rr;

@@ -128,7 +128,7 @@ class PPOEngine:
                     gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
                     learning_rate=3e-4, adam_betas=(0.9, 0.999), adam_eps=1e-5, normalize_advantage=True,
                     action_low=-1.0, action_high=1.0, seed=0, device_id=0, rank=0, world_size=1, fast_kernels=True,
-                    rollout_graph=True, rollout_persistent=True, activation="tanh") -> Config:
+                    rollout_graph=True, rollout_persistent=True, activation="tanh", forward_x3=True) -> Config:
         """PPO(...) keyword arguments -> `mobrob_ppo_config_t` (SB3 defaults, Appendix A.1)."""
         if len(pi) != 2 or len(vf) != 2:
             raise ValueError("net_arch must have exactly two hidden layers per network (pi=[h1,h2], vf=[h1,h2])")
@@ -151,6 +151,7 @@ class PPOEngine:
         if str(activation).lower() not in ("tanh", "relu"):
             raise ValueError(f"activation {activation!r}: 'tanh' or 'relu'")
         cfg.activation = 1 if str(activation).lower() == "relu" else 0
+        cfg.forward_x3 = int(bool(forward_x3))
         return cfg
 
     @staticmethod

@@ -534,8 +534,10 @@ def test_persistent_rollout_equals_per_step_rollout(kind, H, D, A, N, T):
     p["value_net.bias"] = np.array([2.0], np.float32)
     res = {}
     for persistent in (True, False):
+        # forward_x3=False: both kernels on the f32 matrix pipe (the persistent kernel's default is the split-bf16 form of the
+        # hidden layers, equal to rounding only: test_x3_forward_kernels_are_float32_accurate)
         e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=256, n_epochs=1, pi=(H, H), vf=(H, H), seed=21,
-                        rollout_persistent=persistent)
+                        rollout_persistent=persistent, forward_x3=False)
         e.set_params(p)
         out = []
         for _ in range(2):
@@ -555,6 +557,51 @@ def test_persistent_rollout_equals_per_step_rollout(kind, H, D, A, N, T):
         assert np.max(np.abs(a["values"] - b["values"])) < 1e-4 and np.max(np.abs(a["last_values"] - b["last_values"])) < 1e-4
         assert np.max(np.abs(a["advantages"] - b["advantages"])) < 1e-3
         assert a["episode_starts"][1:].sum() > 0  # the comparison covers resets and truncations
+
+
+@pytest.mark.parametrize("D,A,N,T", [(58, 12, 200, 24), (26, 2, 64, 24), (12, 18, 33, 24), (43, 2, 300, 18)])
+def test_x3_forward_kernels_are_float32_accurate(D, A, N, T):
+    """The persistent rollout and the batched value pass of 256-wide nets multiply on the bf16 matrix pipe: float32 operands
+    split into three bf16 pieces, six piece products, float32 accumulation (`forward_x3`, kernels_fused.h gemm_x3_r32 /
+    gemm_x3_r64).  Claim: float32 RESULTS -- against a float64 evaluation of the same network on the stored observations the
+    stored log-probs and values are as close as those of the f32-pipe kernels (same noise, so the actions are compared too)."""
+    H = 256
+    p = O.init_params(D, A, (H, H), (H, H), seed=8)
+    rng = np.random.default_rng(3)
+    p["log_std"] = rng.normal(-0.3, 0.2, A).astype(np.float32)
+    p["action_net.weight"] *= 30          # means of order one
+    p["value_net.weight"] *= 5
+    p64 = type(p)((k, v.astype(np.float64)) for k, v in p.items())
+    res = {}
+    for x3 in (True, False):
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=256, n_epochs=1, pi=(H, H), vf=(H, H), seed=21,
+                        forward_x3=x3)
+        e.set_params(p)
+        e.collect_synthetic(p_term=0.05, time_limit=9)
+        e.synchronize()
+        buf = {k: e.read(k) for k in ("obs", "actions", "log_probs", "values")}
+        e.close()
+        obs = buf["obs"][:T].reshape(T * N, D).astype(np.float64)
+
+        def mlp64(net):                                              # float64 reference, written out
+            h = np.tanh(obs @ p64[f"mlp_extractor.{net}.0.weight"].T + p64[f"mlp_extractor.{net}.0.bias"])
+            return np.tanh(h @ p64[f"mlp_extractor.{net}.2.weight"].T + p64[f"mlp_extractor.{net}.2.bias"])
+        mean = mlp64("policy_net") @ p64["action_net.weight"].T + p64["action_net.bias"]
+        val = (mlp64("value_net") @ p64["value_net.weight"].T + p64["value_net.bias"])[:, 0]
+        sd = np.exp(p64["log_std"])
+        d = buf["actions"].reshape(T * N, A).astype(np.float64) - mean
+        lp = np.sum(-(d * d) / (2.0 * sd * sd) - np.log(sd) - 0.5 * np.log(2.0 * np.pi), axis=1)
+        res[x3] = dict(buf=buf, lp_err=float(np.max(np.abs(buf["log_probs"].ravel() - lp))),
+                       v_err=float(np.max(np.abs(buf["values"][:T].ravel() - val))),
+                       v_scale=float(np.max(np.abs(val))), lp_scale=float(np.max(np.abs(lp))))
+    a, b = res[True], res[False]
+    # synthetic observations do not depend on the actions: both runs saw the same inputs and drew the same noise
+    assert np.array_equal(a["buf"]["obs"], b["buf"]["obs"])
+    assert np.max(np.abs(a["buf"]["actions"] - b["buf"]["actions"])) < 2e-5 * max(1.0, float(np.max(np.abs(b["buf"]["actions"]))))
+    # accuracy against float64: the x3 kernels are held to the bound the f32-pipe kernels meet, and to 1.5x their actual error
+    for key, scale in (("lp_err", "lp_scale"), ("v_err", "v_scale")):
+        assert a[key] < 1e-5 * max(1.0, a[scale]), (key, a[key], a[scale])
+        assert a[key] <= 1.5 * b[key] + 1e-7 * max(1.0, a[scale]), (key, a[key], b[key])
 
 
 def test_rollouts_beyond_4gib_use_the_64bit_generic_kernels():

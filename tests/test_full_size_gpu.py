@@ -245,8 +245,13 @@ def test_benchmarked_epoch_matches_oracle(shape):
     assert stats["n_minibatches"] == nmb
     ostats = O.train(p, st, buf, h, perm[None])
     newp = e.get_params()
+    # 63 (32) dependent optimizer steps move a parameter by up to 0.02.  The clipped surrogate is discontinuous at the clip
+    # boundaries (see _check_grad): over a whole epoch the largest deviation is bimodal in the DATA -- 2e-7 ... 2e-5 when no
+    # row's ratio falls within rounding of a boundary in any step, ~2e-4 when one does (scratch/epoch_margin.py over three
+    # seeds, with the rollout on the f32 pipe and on the split-bf16 pipe alike: which seeds are the lucky ones changes, the
+    # two levels do not).  The bound holds for both; single steps are held to 1e-5 by the minibatch test above.
     for k in p:
-        assert np.max(np.abs(newp[k] - p[k])) < 1e-4, (k, float(np.max(np.abs(newp[k] - p[k]))))
+        assert np.max(np.abs(newp[k] - p[k])) < 5e-4, (k, float(np.max(np.abs(newp[k] - p[k]))))
     for k in STAT_KEYS + ("grad_norm",):
         ref = float(np.mean([float(s[k]) for s in ostats]))
         assert abs(stats[k] - ref) < 2e-4 * max(1.0, abs(ref)), (k, stats[k], ref)
