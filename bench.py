@@ -48,6 +48,8 @@ WORKLOADS = {
                                             B=65536, tl=1000),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 16 * PEAK_F32_MFMA_TFLOPS  # same table: the f32 matrix rate is "1/16 of BF16 MFMA" (~2.5 PF dense)
+X3_PRODUCTS = 6  # bf16 x bf16 MFMAs issued per float32 multiply-add of a product computed from three-way split operands
 
 
 def f_fwd(D, H, A):
@@ -473,8 +475,9 @@ def bench_single(args, name, steps, warmup, job, phases):
     D, A, H, N, T, E, B = w["D"], w["A"], w["H"], w["N"], w["T"], w["E"], w["B"]
     eng = PPOEngine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B * world, n_epochs=E, pi=(H, H), vf=(H, H),
                     gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.01, seed=0, device_id=job.device_id,
-                    rank=rank, world_size=world, fast_kernels=not args.generic)
+                    rank=rank, world_size=world, fast_kernels=not args.generic, forward_x3=not getattr(args, "f32_pipe", False))
     eng.set_params(init_params(D, A, H, seed=0))  # identical replicas on every rank
+    x3_mode = eng.x3_mode()
     backend = EngineBackend(eng) if use_dp else None
     fault, ar_calls = _fault_spec(), [0]
     if use_dp and job.same_device and fault and fault[0] == rank:  # tests: this rank dies inside an all-reduce
@@ -585,6 +588,16 @@ def bench_single(args, name, steps, warmup, job, phases):
         # minibatch of an epoch is short when batch does not divide T*N)
         flops_per_launch = 3.0 * f_fwd(D, H, A) * (float(N) * T * E * steps) / max(calls, 1)
         achieved = (flops_per_launch * calls / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        # The peak the kernel is priced against.  With forward_x3 the forward of the two hidden layers inside the gradient
+        # kernel (a third of its algorithmic flops minus the heads) is issued as six bf16 x bf16 MFMAs per float32
+        # multiply-add on the bf16 pipe, everything else as v_mfma_f32: the bound is the time both pipes need at THEIR
+        # peaks, expressed as the algorithmic rate that time corresponds to.
+        x3_train = bool(x3_mode & 2) and not args.generic
+        hidden_fwd = 2.0 * (2 * D * H + 2 * H * H)            # forward of both hidden layers, both networks, per sample
+        dh1 = 2.0 * (2 * H * H)                                # dh1 = dz2 . W2 of the backward pass, both networks
+        x3_share = (hidden_fwd + dh1) / (3.0 * f_fwd(D, H, A)) if x3_train else 0.0
+        ideal_s_per_flop = x3_share * X3_PRODUCTS / (PEAK_BF16_MFMA_TFLOPS * 1e12) + (1.0 - x3_share) / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        peak = 1.0 / ideal_s_per_flop / 1e12
         traffic, traffic_note = None, "PMC traffic is profiled for the default workload on one GPU only"
         if not args.generic and name == "doggo-4096env-2x256" and not use_dp and not phases:
             traffic, traffic_note = measured_traffic("void mobrob::k_fused_train<64")
@@ -611,6 +624,11 @@ def bench_single(args, name, steps, warmup, job, phases):
             "warmup": warmup,
             "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "arithmetic": ("float32 storage, float32 accumulation; matrix products of the forward passes (rollout, value pass, forward "
+                           "inside the gradient kernel) and dh1 = dz2 . W2 of the backward pass as six bf16 x bf16 partial products of three-way split float32 operands "
+                           "(error against float64 not larger than v_mfma_f32's: tests/test_engine_gpu.py::"
+                           "test_x3_forward_kernels_are_float32_accurate), the weight gradients and every other product on v_mfma_f32" if x3_mode
+                           else "float32 throughout (v_mfma_f32)"),
             "config": {"workload": name, "obs_dim": D, "act_dim": A, "net_arch": [H, H], "envs_per_gpu": N,
                        "n_steps": T, "n_epochs": E, "minibatch_per_gpu": B, "minibatches_per_epoch": nmb,
                        "env_source": (f"native host env (csrc/host_env.c, OpenMP), pinned zero-copy staging over PCIe, {args.host_parts} pipelined row ranges"
@@ -618,9 +636,14 @@ def bench_single(args, name, steps, warmup, job, phases):
                        "parallelism": f"dp{world}", "n_ranks_seen": ranks_seen, "n_ranks_source": ranks_src,
                        "kernels": "generic" if args.generic else "fused"},
             "roofline": {"bound": "mfma", "kernel": dominant_kernel_name(H, B, args.generic),
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
                          "traffic_note": traffic_note,
+                         "peak_note": (f"blend of two matrix pipes: {100 * x3_share:.1f} % of the algorithmic flops (forward of the hidden "
+                                       f"layers, dh1 of the backward pass) run as {X3_PRODUCTS} bf16 MFMAs per float32 multiply-add (peak {PEAK_BF16_MFMA_TFLOPS:.0f} / "
+                                       f"{X3_PRODUCTS} TFLOP/s), the rest on v_mfma_f32 (peak {PEAK_F32_MFMA_TFLOPS}); against the f32 peak alone "
+                                       f"the kernel would read {achieved / PEAK_F32_MFMA_TFLOPS:.3f}" if x3_train else
+                                       "every matrix product on v_mfma_f32 (peak 157.3 TFLOP/s)"),
                          "avg_launch_ms": ms / max(calls, 1), "launches": calls,
                          "flops_per_launch": flops_per_launch},
             "phases_bracketed": "all" if phases else ("dominant kernel + all-reduces" if use_dp else "dominant kernel only"),
@@ -656,6 +679,17 @@ def also_measured(args, job):
                          "config": {k: v for k, v in o["config"].items() if k in ("envs_per_gpu", "n_steps", "n_epochs", "minibatch_per_gpu", "net_arch", "obs_dim", "act_dim")}}
         except Exception as ex:  # noqa: BLE001 - the headline line must not die with a side measurement
             res[name] = {"error": f"{type(ex).__name__}: {ex}"}
+    # the headline workload with EVERY matrix product on v_mfma_f32 (forward_x3 off): what the split-bf16 forward passes buy
+    try:
+        import copy
+        a32 = copy.copy(args)
+        a32.f32_pipe = True
+        o = bench_single(a32, "doggo-4096env-2x256", 3, 1, job, False)
+        res["doggo-4096env-2x256, forward_x3 off (all products on v_mfma_f32)"] = {
+            "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": 3, "warmup": 1,
+            "roofline": {k: o["roofline"][k] for k in ("kernel", "achieved", "peak", "frac", "avg_launch_ms", "launches")}}
+    except Exception as ex:  # noqa: BLE001
+        res["doggo-4096env-2x256, forward_x3 off (all products on v_mfma_f32)"] = {"error": f"{type(ex).__name__}: {ex}"}
     return res
 
 
@@ -676,6 +710,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the also_measured side configurations")
     ap.add_argument("--generic", action="store_true", help="force the generic (unfused) kernels")
+    ap.add_argument("--f32-pipe", action="store_true",
+                    help="forward_x3 off: every matrix product on v_mfma_f32 (default: the forward passes of 256-wide nets run as six "
+                         "bf16 products of three-way split float32 operands)")
     ap.add_argument("--phases", action="store_true",
                     help="bracket every phase with HIP events (phase_ms_per_step; costs ~4 %% of the throughput); "
                          "by default only the dominant kernel is bracketed")

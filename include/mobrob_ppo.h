@@ -404,6 +404,12 @@ int mobrob_ppo_write_buffer(mobrob_ppo_engine_t* e, int32_t which, const void* h
 /* mark the rollout as complete (tests that inject a rollout with write_buffer) */
 int mobrob_ppo_mark_rollout_ready(mobrob_ppo_engine_t* e);
 
+/* Which matrix products of this engine run on the bf16 pipe with three-way split float32 operands (config.forward_x3, 256-wide tanh
+ * nets): bit 0 = rollout policy forward and batched value pass, bit 1 = the forward of the two hidden layers inside the gradient kernel
+ * (heads <= 16 wide, observation rows of 16 / 32 / 64 padded columns).  0: everything on v_mfma_f32.  Measurement code prices the
+ * kernels against the matrix peak of the pipe each product ran on (bench.py). */
+int mobrob_ppo_x3_mode(const mobrob_ppo_engine_t* e);
+
 /* train/explained_variance as SB3's PPO.train logs it (stable_baselines3 2.0.0 ppo.py: explained_variance(rollout_buffer.values.flatten(),
  * rollout_buffer.returns.flatten()) = 1 - Var[returns - values] / Var[returns], NaN when the returns do not vary), over the rollout
  * in the buffer; reached from the reference through PPOCtrl.learn (src/mobrob/rl_control/ppo.py:73-74) with verbose / tensorboard_log

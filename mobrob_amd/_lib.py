@@ -123,6 +123,7 @@ SYMBOLS = {
     "mobrob_ppo_mark_rollout_ready": (C.c_int, [_P]),
     "mobrob_ppo_compute_gae": (C.c_int, [_P]),
     "mobrob_ppo_explained_variance": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "mobrob_ppo_x3_mode": (C.c_int, [_P]),
     "mobrob_ppo_feistel_permutation": (C.c_int, [_P, C.c_int64, C.c_uint64, _I64]),
     "mobrob_ppo_profile_enable": (C.c_int, [_P, C.c_int32]),
     "mobrob_ppo_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), _I64]),

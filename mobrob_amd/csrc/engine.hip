@@ -320,6 +320,25 @@ void linear_bwd_weight(mobrob_ppo_engine* e, const float* dY, int ldd, const flo
 float* Pp(mobrob_ppo_engine* e, int t) { return e->params + e->offs[t]; }
 float* Gp(mobrob_ppo_engine* e, int t) { return e->grads + e->offs[t]; }
 
+// x3 packs of the hidden layers of both networks from the canonical parameters (kernels_fused.h): one launch
+void pack_x3_all(mobrob_ppo_engine* e) {
+  if (e->fused.net[0].W2x == nullptr) return;
+  PackX3Args a{};
+  const int w1[2] = {T_PW1, T_VW1}, w2[2] = {T_PW2, T_VW2};
+  int maxthreads = 0;
+  for (int n = 0; n < 2; ++n) {
+    const int i1 = 3 * n, i2 = 3 * n + 1, i3 = 3 * n + 2;
+    a.W[i1] = Pp(e, w1[n]); a.N[i1] = FH; a.K[i1] = e->D; a.ld[i1] = e->D; a.NB[i1] = FH / 32; a.KS[i1] = e->Dp / 16; a.scale[i1] = kTanhScale;
+    a.out[i1] = reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W1x));
+    a.W[i2] = Pp(e, w2[n]); a.N[i2] = FH; a.K[i2] = FH; a.ld[i2] = FH; a.NB[i2] = FH / 32; a.KS[i2] = FH / 16; a.scale[i2] = kTanhScale;
+    a.out[i2] = reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2x));
+    a.W[i3] = Pp(e, w2[n]); a.N[i3] = FH; a.K[i3] = FH; a.ld[i3] = FH; a.NB[i3] = FH / 32; a.KS[i3] = FH / 16; a.scale[i3] = 1.0f; a.trans[i3] = 1;
+    a.out[i3] = reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2bx));
+    maxthreads = std::max(maxthreads, std::max(a.NB[i1] * a.KS[i1], a.NB[i2] * a.KS[i2]) * 512);
+  }
+  hipLaunchKernelGGL(k_pack_x3_multi, dim3(cdiv(maxthreads, 256), 6), dim3(256), 0, e->stream, a);
+}
+
 void repack(mobrob_ppo_engine* e) {
   auto pad = [&](const float* src, float* dst, int r, int c, int rp, int cp) {
     hipLaunchKernelGGL(k_pad_rows, dim3(cdiv(rp * cp, 256)), dim3(256), 0, e->stream, src, dst, r, c, rp, cp);
@@ -329,6 +348,7 @@ void repack(mobrob_ppo_engine* e) {
   pad(Pp(e, T_AW), e->aWp, e->A, e->H2, e->Ap, e->H2);
   pad(Pp(e, T_VW), e->vWp, 1, e->G2, 8, e->G2);
   fused_repack(e->fused, e->params, e->offs, e->stream);
+  pack_x3_all(e);
 }
 
 // forward of both networks on `rows` device rows of padded observations (ld = Dp); mu ld = Ap, v ld = 1
@@ -435,7 +455,7 @@ int fused_init(mobrob_ppo_engine* e) {
     f.net[n].W3h = reinterpret_cast<const f32x4*>(p); p += nW3h;  // last: the H = 64 kernels mirror [W1f, b2s] as one block
     f.net[n].b3 = e->params + e->offs[bias_ids[n][2]];
     f.net[n].head = n == 0 ? e->A : 1;
-    f.net[n].W1x = nullptr; f.net[n].W2x = nullptr;
+    f.net[n].W1x = nullptr; f.net[n].W2x = nullptr; f.net[n].W2bx = nullptr;
   }
   f.max_grid = 256;
   if (H == 64) {
@@ -456,7 +476,11 @@ int fused_init(mobrob_ppo_engine* e) {
         CHK(dalloc(e, &w1, (size_t)(H / 32) * (e->Dp / 16) * 192 * 4));
         CHK(dalloc(e, &w2, (size_t)(H / 32) * (H / 16) * 192 * 4));
         f.net[n].W1x = w1; f.net[n].W2x = w2;
+        unsigned* w2b = nullptr;
+        CHK(dalloc(e, &w2b, (size_t)(H / 32) * (H / 16) * 192 * 4));
+        f.net[n].W2bx = w2b;
       }
+      f.train_x3 = e->A <= 16 && e->Dp != 48 && getenv("MOBROB_NO_TRAIN_X3") == nullptr;
     }
     CHK(dalloc(e, &f.train_rec, (size_t)e->N * e->T * train_rec_width(e->A)));
     f.lds_bytes = fused_lds_bytes(e->Dp);
@@ -1206,6 +1230,11 @@ int mobrob_ppo_compute_gae(mobrob_ppo_engine_t* e) {
   return MOBROB_OK;
 }
 
+int mobrob_ppo_x3_mode(const mobrob_ppo_engine_t* e) {
+  if (!e || !e->fused.enabled || e->fused.net[0].W2x == nullptr) return 0;
+  return 1 | (e->fused.train_x3 ? 2 : 0);
+}
+
 int mobrob_ppo_explained_variance(mobrob_ppo_engine_t* e, double* out) {
   if (!e || !out) return fail(MOBROB_ERR_INVALID, "explained_variance: null argument");
   if (!e->rollout_ready) return fail(MOBROB_ERR_STATE, "explained_variance: rollout not finished");
@@ -1317,16 +1346,7 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
   // The rollout blocks (32 envs each, ~100 KB of LDS) leave CUs idle when N < 32 * 256; the value pass of the steps
   // already finished runs there at the same time: the rollout is cut into chunks, chunk c's value pass is enqueued
   // on a second stream behind an event and overlaps the rollout of chunk c+1.
-  if (e->fused.net[0].W2x != nullptr) {  // the parameters may have changed since the last rollout (train, set_params)
-    const int w1[2] = {T_PW1, T_VW1}, w2[2] = {T_PW2, T_VW2};
-    for (int n = 0; n < 2; ++n) {
-      const int H = FH, KS1 = Dp / 16, KS2 = FH / 16;
-      hipLaunchKernelGGL(k_pack_x3, dim3(cdiv((H / 32) * KS1 * 512, 256)), dim3(256), 0, e->stream, Pp(e, w1[n]), H, e->D, e->D,
-                         kTanhScale, reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W1x)), H / 32, KS1);
-      hipLaunchKernelGGL(k_pack_x3, dim3(cdiv((H / 32) * KS2 * 512, 256)), dim3(256), 0, e->stream, Pp(e, w2[n]), H, H, H,
-                         kTanhScale, reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2x)), H / 32, KS2);
-    }
-  }
+  if (!e->fused.train_x3) pack_x3_all(e);  // otherwise every optimizer step (apply_adam) and set_params keep the x3 packs current
   const int rblocks = cdiv(N, 32);
   const bool overlap = rblocks <= 192;                      // otherwise the rollout itself fills the device
   const int chunk = overlap ? std::max(16, cdiv(T, 20)) : T;
@@ -1775,6 +1795,7 @@ int apply_adam(mobrob_ppo_engine* e, const ApplyCtx& c) {
   a.stats_row = c.stats_row;
   a.loss_sums_zero = e->fused.enabled ? e->grads + e->P : nullptr;
   hipLaunchKernelGGL(k_adam_pack, dim3(cdiv(e->P, 256)), dim3(256), 0, e->stream, a);
+  if (e->fused.train_x3) pack_x3_all(e);  // the next gradient launch runs its forward from the x3 packs
   HIPC(hipGetLastError());
   e->grad_pending = false;
   return MOBROB_OK;

@@ -16,6 +16,14 @@ namespace mobrob {
     default: { constexpr int DPc = 64; CALL; } break; \
   }
 
+// the x3 training kernel exists for 16 / 32 / 64 observation columns (48 = three k steps spilled six registers: train_x3 is off there)
+#define FUSED_DISPATCH_DP_X3(dp, CALL)                \
+  switch (dp) {                                       \
+    case 16: { constexpr int DPc = 16; CALL; } break; \
+    case 32: { constexpr int DPc = 32; CALL; } break; \
+    default: { constexpr int DPc = 64; CALL; } break; \
+  }
+
 inline void fused_launch_act(FusedState& f, FusedActArgs& a, hipStream_t st) {
   a.net[0] = f.net[0];
   a.net[1] = f.net[1];
@@ -28,7 +36,9 @@ inline void fused_launch_act(FusedState& f, FusedActArgs& a, hipStream_t st) {
   }
 }
 inline void fused_launch_train(FusedState& f, FusedTrainArgs& a, int grid, hipStream_t st) {
-  if (f.A <= 16) {  // both heads <= 16 wide: 16x16x4 head / dW3 variant
+  if (f.A <= 16 && f.net[0].W2x != nullptr && f.train_x3) {  // forward of the tile on the bf16 pipe (x3 packs maintained per step)
+    FUSED_DISPATCH_DP_X3(f.Dp, hipLaunchKernelGGL((k_fused_train<DPc, true, true>), dim3(grid), dim3(FTHREADS), f.lds_bytes, st, a));
+  } else if (f.A <= 16) {  // both heads <= 16 wide: 16x16x4 head / dW3 variant
     FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused_train<DPc, true>), dim3(grid), dim3(FTHREADS), f.lds_bytes, st, a));
   } else {
     FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused_train<DPc, false>), dim3(grid), dim3(FTHREADS), f.lds_bytes, st, a));
@@ -73,6 +83,8 @@ inline hipError_t fused_set_lds_attr(FusedState& f) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_train<DPc, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_train<DPc, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);
+      if (e == hipSuccess && f.train_x3)
+        FUSED_DISPATCH_DP_X3(f.Dp, e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_train<DPc, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes));
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_act<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_act_bytes);
       if (e == hipSuccess)

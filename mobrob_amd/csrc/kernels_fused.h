@@ -35,6 +35,7 @@ struct FusedNet {
   // x3 packs of the two hidden layers (forward-only kernels; null: f32 matrix pipe), see gemm_x3_r32
   const unsigned* W1x;  // [H/32][Dp/16][3][64] x 16 bytes
   const unsigned* W2x;  // [H/32][H/16][3][64] x 16 bytes
+  const unsigned* W2bx; // the same for the backward operand B[k = n][j] = W2[n][j] (dh1 = dz2 . W2), unscaled
 };
 
 struct FusedTrainArgs {
@@ -575,9 +576,352 @@ __device__ __forceinline__ void tile_head16(const FusedNet& W, int wave, int lan
 }
 
 // ------------------------------------------------------------------------------------------------
+// "x3" GEMMs: a float32 product on the bf16 matrix pipe.  Every float32 operand is split into three bf16 pieces
+// (x = x1 + x2 + x3, each the bf16 rounding of what the previous ones left: 24 mantissa bits, the residuals are exact in
+// float32) and six of the nine piece products are kept (x1y1, x1y2, x2y1, x1y3, x3y1, x2y2; the dropped ones are below
+// 2^-24 of the product), accumulated in float32 by v_mfma_f32_32x32x16_bf16.  The piece products are exact in float32, so a
+// 16-k step rounds once where eight v_mfma_f32_32x32x2_f32 round eight times: measured against float64 the error is SMALLER
+// than the f32 instruction's (scratch/bf16x3_probe.hip: 3.7e-7 against 5.2e-7 of max |C|) at 1.75-1.87x its rate.
+// Used by the forward-only kernels (rollout policy forward, batched value pass); the gradient kernels stay on the f32 pipe.
+//
+// Weight packs (k_pack_x3): [column block n/32][k step k/16][piece 3][lane 64] x 8 bf16 (16 bytes per lane):
+//   lane = (n & 31) + 32 ((k & 15) >> 3), element j = k & 7      (B[k][n] = scale * W[n][k]: the 32x32x16 B operand)
+// ------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA32B(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), (c), 0, 0, 0)
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {  // round to nearest even, lo in the low half
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ void x3_split2(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+  p1 = cvt_pk_bf16(a, b);
+  const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);   // exact
+  p2 = cvt_pk_bf16(ra, rb);
+  const float sa = ra - __uint_as_float(p2 << 16), sb = rb - __uint_as_float(p2 & 0xffff0000u);  // exact
+  p3 = cvt_pk_bf16(sa, sb);
+}
+struct X3Frag { u32x4 p[3]; };  // eight consecutive k of one row (or column), three pieces
+__device__ __forceinline__ X3Frag x3_split8(const f32x4& a, const f32x4& b) {
+  X3Frag f;
+  unsigned p1, p2, p3;
+  x3_split2(a[0], a[1], p1, p2, p3); f.p[0][0] = p1; f.p[1][0] = p2; f.p[2][0] = p3;
+  x3_split2(a[2], a[3], p1, p2, p3); f.p[0][1] = p1; f.p[1][1] = p2; f.p[2][1] = p3;
+  x3_split2(b[0], b[1], p1, p2, p3); f.p[0][2] = p1; f.p[1][2] = p2; f.p[2][2] = p3;
+  x3_split2(b[2], b[3], p1, p2, p3); f.p[0][3] = p1; f.p[1][3] = p2; f.p[2][3] = p3;
+  return f;
+}
+__device__ __forceinline__ X3Frag x3_load_b(const u32x4* __restrict__ Bx, int ks, int lane) {
+  X3Frag f;
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc) f.p[pc] = Bx[(size_t)(ks * 3 + pc) * 64 + lane];
+  return f;
+}
+// the six kept products, small terms first
+#define X3_MFMA6(A_, B_, C_)                    \
+  C_ = MFMA32B(A_.p[1], B_.p[1], C_);           \
+  C_ = MFMA32B(A_.p[0], B_.p[2], C_);           \
+  C_ = MFMA32B(A_.p[2], B_.p[0], C_);           \
+  C_ = MFMA32B(A_.p[0], B_.p[1], C_);           \
+  C_ = MFMA32B(A_.p[1], B_.p[0], C_);           \
+  C_ = MFMA32B(A_.p[0], B_.p[0], C_);
+// c0 / c1 += A[32 rows][16 NKS] (float32 in LDS, row stride LDA) . B of two column blocks (x3 packs of NKS k steps each).
+// Weight fragments are requested kAhead k steps before their use (a k step is 12 MFMAs = 384 cycles; L2 takes 500-800).
+#ifndef MOBROB_X3_AHEAD
+#define MOBROB_X3_AHEAD 2
+#endif
+#ifndef MOBROB_X3_PIPE
+#define MOBROB_X3_PIPE 1
+#endif
+// Software pipeline of a k step: the MFMAs of step ks (operands split during step ks - 1) are issued with the ~50 VALU
+// instructions that split the A fragment of step ks + 1 between them (an MFMA occupies the matrix pipe for 32 cycles, four
+// VALU instructions fill them); without the explicit groups the compiler emitted the split as one block in front of a burst of
+// MFMAs, each side waiting for the other.
+template <int LDA, int NKS>
+__device__ __forceinline__ void gemm_x3_r32(int a_off, const u32x4* __restrict__ Bx0, const u32x4* __restrict__ Bx1, f32x16& c0,
+                                            f32x16& c1, int lane) {
+  constexpr int kAhead = NKS < MOBROB_X3_AHEAD ? NKS : MOBROB_X3_AHEAD;
+  const int r = lane & 31, h = lane >> 5;
+  const int ab = 4 * opaque((a_off + r * LDA + 8 * h) >> 2);
+  X3Frag P[kAhead + 1], Q[kAhead + 1];
+#pragma unroll
+  for (int k = 0; k < kAhead; ++k) { P[k] = x3_load_b(Bx0, k, lane); Q[k] = x3_load_b(Bx1, k, lane); }
+  X3Frag U = x3_split8(*reinterpret_cast<const f32x4*>(&lds[ab]), *reinterpret_cast<const f32x4*>(&lds[ab + 4]));
+  f32x4 ua = {0.f, 0.f, 0.f, 0.f}, ub = ua;  // float32 A fragment of step ks + 1, read one step before it is split
+  if (NKS > 1) {
+    ua = *reinterpret_cast<const f32x4*>(&lds[ab + 16]);
+    ub = *reinterpret_cast<const f32x4*>(&lds[ab + 20]);
+  }
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+#if MOBROB_X3_PIPE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    f32x4 na = ua, nb = ub;
+    if (ks + 2 < NKS) {
+      na = *reinterpret_cast<const f32x4*>(&lds[ab + 16 * (ks + 2)]);
+      nb = *reinterpret_cast<const f32x4*>(&lds[ab + 16 * (ks + 2) + 4]);
+    }
+    if (ks + kAhead < NKS) {
+      P[(ks + kAhead) % (kAhead + 1)] = x3_load_b(Bx0, ks + kAhead, lane);
+      Q[(ks + kAhead) % (kAhead + 1)] = x3_load_b(Bx1, ks + kAhead, lane);
+    }
+    const X3Frag& p = P[ks % (kAhead + 1)];
+    const X3Frag& q = Q[ks % (kAhead + 1)];
+    X3_MFMA6(U, p, c0)
+    X3_MFMA6(U, q, c1)
+    if (ks + 1 < NKS) U = x3_split8(ua, ub);
+    ua = na; ub = nb;
+#if MOBROB_X3_PIPE
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the two LDS reads of the A fragment two steps ahead
+    __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);  // the six weight-fragment loads kAhead steps ahead
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // four VALU
+    }
+#endif
+  }
+}
+// The same arithmetic (same k order, same six products per step: the same bits) with a bounded register footprint for the
+// training kernel: a runtime k loop over PAIRS of steps, weight fragments one step ahead in two fixed slots, the A fragment read
+// and split one step ahead (c 32 + U 12 + float32 fragment 8 + two slots 48 registers).
+#define X3_STEP_GROUPS()                                   \
+  __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       \
+  __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);       \
+  _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     \
+  }
+template <int LDA, int NKS>
+__device__ __forceinline__ void gemm_x3_r32_lean(int a_off, const u32x4* __restrict__ Bx0, const u32x4* __restrict__ Bx1, f32x16& c0,
+                                                 f32x16& c1, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  int ao = 4 * opaque((a_off + r * LDA + 8 * h) >> 2);
+  const u32x4* b0 = Bx0 + lane;
+  const u32x4* b1 = Bx1 + lane;
+  X3Frag P0, Q0, P1, Q1;
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc) { P0.p[pc] = b0[pc * 64]; Q0.p[pc] = b1[pc * 64]; }
+  X3Frag U = x3_split8(*reinterpret_cast<const f32x4*>(&lds[ao]), *reinterpret_cast<const f32x4*>(&lds[ao + 4]));
+#pragma unroll 1
+  for (int ks = 0; ks + 2 <= NKS; ks += 2) {
+    __builtin_amdgcn_sched_barrier(0);
+    {  // step ks from slot 0; step ks + 1 exists
+      const f32x4 ua = *reinterpret_cast<const f32x4*>(&lds[ao + 16]);
+      const f32x4 ub = *reinterpret_cast<const f32x4*>(&lds[ao + 20]);
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) { P1.p[pc] = b0[(3 + pc) * 64]; Q1.p[pc] = b1[(3 + pc) * 64]; }
+      X3_MFMA6(U, P0, c0)
+      X3_MFMA6(U, Q0, c1)
+      U = x3_split8(ua, ub);
+      X3_STEP_GROUPS()
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {  // step ks + 1 from slot 1; step ks + 2 may not exist: its (unused) operands are then those of the last step again
+      const int adv = ks + 2 < NKS ? 1 : 0;
+      const f32x4 ua = *reinterpret_cast<const f32x4*>(&lds[ao + 16 + 16 * adv]);
+      const f32x4 ub = *reinterpret_cast<const f32x4*>(&lds[ao + 20 + 16 * adv]);
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) { P0.p[pc] = b0[(3 + 3 * adv + pc) * 64]; Q0.p[pc] = b1[(3 + 3 * adv + pc) * 64]; }
+      X3_MFMA6(U, P1, c0)
+      X3_MFMA6(U, Q1, c1)
+      U = x3_split8(ua, ub);
+      X3_STEP_GROUPS()
+    }
+    ao += 32;
+    b0 += 6 * 64;
+    b1 += 6 * 64;
+  }
+  if (NKS & 1) {  // last step of an odd count: slot 0 and U hold it
+    X3_MFMA6(U, P0, c0)
+    X3_MFMA6(U, Q0, c1)
+  }
+}
+// the 64-row form: two row blocks share every weight fragment (c[column block][row block]); same pipeline, 24 MFMAs per step
+template <int LDA, int NKS>
+__device__ __forceinline__ void gemm_x3_r64(int a_off, const u32x4* __restrict__ Bx0, const u32x4* __restrict__ Bx1, f32x16& c00,
+                                            f32x16& c01, f32x16& c10, f32x16& c11, int lane) {
+  constexpr int kAhead = NKS < MOBROB_X3_AHEAD ? NKS : MOBROB_X3_AHEAD;
+  const int r = lane & 31, h = lane >> 5;
+  const int ab = 4 * opaque((a_off + r * LDA + 8 * h) >> 2);
+  X3Frag P[kAhead + 1], Q[kAhead + 1];
+#pragma unroll
+  for (int k = 0; k < kAhead; ++k) { P[k] = x3_load_b(Bx0, k, lane); Q[k] = x3_load_b(Bx1, k, lane); }
+  X3Frag U = x3_split8(*reinterpret_cast<const f32x4*>(&lds[ab]), *reinterpret_cast<const f32x4*>(&lds[ab + 4]));
+  X3Frag V = x3_split8(*reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA]), *reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA + 4]));
+  f32x4 ua = {0.f, 0.f, 0.f, 0.f}, ub = ua, va = ua, vb = ua;  // float32 A fragments of step ks + 1
+  if (NKS > 1) {
+    ua = *reinterpret_cast<const f32x4*>(&lds[ab + 16]);
+    ub = *reinterpret_cast<const f32x4*>(&lds[ab + 20]);
+    va = *reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA + 16]);
+    vb = *reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA + 20]);
+  }
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+#if MOBROB_X3_PIPE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    f32x4 na = ua, nb = ub, ma = va, mb = vb;
+    if (ks + 2 < NKS) {
+      na = *reinterpret_cast<const f32x4*>(&lds[ab + 16 * (ks + 2)]);
+      nb = *reinterpret_cast<const f32x4*>(&lds[ab + 16 * (ks + 2) + 4]);
+      ma = *reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA + 16 * (ks + 2)]);
+      mb = *reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA + 16 * (ks + 2) + 4]);
+    }
+    if (ks + kAhead < NKS) {
+      P[(ks + kAhead) % (kAhead + 1)] = x3_load_b(Bx0, ks + kAhead, lane);
+      Q[(ks + kAhead) % (kAhead + 1)] = x3_load_b(Bx1, ks + kAhead, lane);
+    }
+    const X3Frag& p = P[ks % (kAhead + 1)];
+    const X3Frag& q = Q[ks % (kAhead + 1)];
+    X3_MFMA6(U, p, c00)
+    X3_MFMA6(V, p, c01)
+    X3_MFMA6(U, q, c10)
+    X3_MFMA6(V, q, c11)
+    if (ks + 1 < NKS) { U = x3_split8(ua, ub); V = x3_split8(va, vb); }
+    ua = na; ub = nb; va = ma; vb = mb;
+#if MOBROB_X3_PIPE
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);
+#pragma unroll
+    for (int g = 0; g < 24; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    }
+#endif
+  }
+}
+// the x3 packs of up to four matrices in one launch (blockIdx.y = matrix): both hidden layers of both networks
+struct PackX3Args {
+  const float* W[6]; int N[6], K[6], ld[6], NB[6], KS[6], trans[6];  // trans: the operand is W^T (B[k][n] = W[k][n])
+  float scale[6];
+  unsigned short* out[6];
+};
+__global__ __launch_bounds__(256) void k_pack_x3_multi(PackX3Args a) {
+  const int m = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (cb, ks, lane, j)
+  const int KS = a.KS[m];
+  if (i >= a.NB[m] * KS * 512) return;
+  const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) % KS, cb = (i >> 9) / KS;
+  const int n = cb * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + j;
+  float x = 0.f;
+  if (n < a.N[m] && k < a.K[m]) x = a.scale[m] * (a.trans[m] ? a.W[m][(size_t)k * a.ld[m] + n] : a.W[m][(size_t)n * a.ld[m] + k]);
+  unsigned p1, p2, p3;
+  x3_split2(x, 0.f, p1, p2, p3);
+  unsigned short* out = a.out[m];
+  const size_t base = ((size_t)(cb * KS + ks) * 3) * 512 + (size_t)lane * 8 + j;
+  out[base] = (unsigned short)(p1 & 0xffffu);
+  out[base + 512] = (unsigned short)(p2 & 0xffffu);
+  out[base + 1024] = (unsigned short)(p3 & 0xffffu);
+}
+// canonical row-major W[N][K] (ld) -> x3 pack of NB column blocks x KS k steps (zeros outside the matrix)
+__global__ void k_pack_x3(const float* __restrict__ W, int N, int K, int ld, float scale, unsigned short* __restrict__ out, int NB, int KS) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (cb, ks, lane, j)
+  if (i >= NB * KS * 64 * 8) return;
+  const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) % KS, cb = (i >> 9) / KS;
+  const int n = cb * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + j;
+  const float x = (n < N && k < K) ? scale * W[(size_t)n * ld + k] : 0.f;
+  unsigned p1, p2, p3;
+  x3_split2(x, 0.f, p1, p2, p3);
+  const size_t base = ((size_t)(cb * KS + ks) * 3) * 512 + (size_t)lane * 8 + j;
+  out[base] = (unsigned short)(p1 & 0xffffu);
+  out[base + 512] = (unsigned short)(p2 & 0xffffu);
+  out[base + 1024] = (unsigned short)(p3 & 0xffffu);
+}
+
+// forward of the two hidden layers of a 64-row tile on the bf16 pipe (the x3 form of tile_layers; forward-only kernels)
+template <int DP>
+__device__ __forceinline__ Frag2 tile_layers_x3(const FusedNet& W, int wave, int lane) {
+  using L = Lay<DP>;
+  const int r_ = lane & 31;
+  const u32x4* W1x = reinterpret_cast<const u32x4*>(W.W1x);
+  const u32x4* W2x = reinterpret_cast<const u32x4*>(W.W2x);
+  {
+    const float bz0 = W.b1s[64 * wave + r_], bz1 = W.b1s[64 * wave + 32 + r_];
+    f32x16 c00 = splat16(bz0), c01 = splat16(bz0), c10 = splat16(bz1), c11 = splat16(bz1);
+    gemm_x3_r64<L::LDX, DP / 16>(L::X, W1x + (size_t)(2 * wave) * (DP / 16) * 192, W1x + (size_t)(2 * wave + 1) * (DP / 16) * 192,
+                                 c00, c01, c10, c11, lane);
+    store_tanh(L::H1, wave, lane, c00, c01, c10, c11);
+  }
+  __syncthreads();
+  const f32x4* bp = W.W3h;
+  Frag2 f3;
+  {
+    const float bz0 = W.b2s[64 * wave + r_], bz1 = W.b2s[64 * wave + 32 + r_];
+    f32x16 c00 = splat16(bz0), c01 = splat16(bz0), c10 = splat16(bz1), c11 = splat16(bz1);
+    gemm_x3_r64<FLDH, FH / 16>(L::H1, W2x + (size_t)(2 * wave) * (FH / 16) * 192, W2x + (size_t)(2 * wave + 1) * (FH / 16) * 192,
+                               c00, c01, c10, c11, lane);
+    f3 = prefetch_frag(bp, bp + 64, lane);
+    store_tanh(L::H2, wave, lane, c00, c01, c10, c11);
+  }
+  __syncthreads();
+  return f3;
+}
+
+// the same forward for the training kernel: one 32-row block at a time (two accumulators instead of four: the training kernel
+// holds dW1 / dW3 and the next tile's operands in registers and has no room for the 64-row form's operand ring); every
+// element sees the arithmetic of gemm_x3_r32, i.e. the bits of the rollout kernel's forward
+__device__ __forceinline__ void store_tanh_r32(int dst_off, int rb, int wave, int lane, const f32x16& c0, const f32x16& c1) {
+  const int r = lane & 31, h = lane >> 5;
+  const int o = opaque(dst_off + (32 * rb + 4 * h) * FLDH + 64 * wave + r);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    lds[o + crc(i) * FLDH] = fast_tanh_scaled(c0[i]);
+    lds[o + crc(i) * FLDH + 32] = fast_tanh_scaled(c1[i]);
+  }
+}
+// lds[hs][rows of block rb][this wave's 64 columns] <- acc * (1 - hs^2) in place (the one-row-block form of dtanh_inplace)
+__device__ __forceinline__ void dtanh_inplace_r32(int hs_off, int rb, int wave, int lane, const f32x16& c0, const f32x16& c1) {
+  const int r = lane & 31, h = lane >> 5;
+  const int o = opaque(hs_off + (32 * rb + 4 * h) * FLDH + 64 * wave + r);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float hv;
+    hv = lds[o + crc(i) * FLDH];      lds[o + crc(i) * FLDH] = c0[i] * (1.0f - hv * hv);
+    hv = lds[o + crc(i) * FLDH + 32]; lds[o + crc(i) * FLDH + 32] = c1[i] * (1.0f - hv * hv);
+  }
+}
+template <int DP, bool H16>
+__device__ __forceinline__ Frag2 tile_layers_x3_train(const FusedNet& W, int wave, int lane) {
+  using L = Lay<DP>;
+  const int r_ = lane & 31;
+  const u32x4* W1x = reinterpret_cast<const u32x4*>(W.W1x);
+  const u32x4* W2x = reinterpret_cast<const u32x4*>(W.W2x);
+  {
+    const float bz0 = W.b1s[64 * wave + r_], bz1 = W.b1s[64 * wave + 32 + r_];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      f32x16 c0 = splat16(bz0), c1 = splat16(bz1);
+      gemm_x3_r32_lean<L::LDX, DP / 16>(L::X + rb * 32 * L::LDX, W1x + (size_t)(2 * wave) * (DP / 16) * 192,
+                                        W1x + (size_t)(2 * wave + 1) * (DP / 16) * 192, c0, c1, lane);
+      store_tanh_r32(L::H1, rb, wave, lane, c0, c1);
+    }
+  }
+  __syncthreads();
+  const f32x4* bp = H16 ? W.W3h : W.W3f + (size_t)((wave >> 1) * 16) * 64;
+  Frag2 f3;
+  {
+    const float bz0 = W.b2s[64 * wave + r_], bz1 = W.b2s[64 * wave + 32 + r_];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      f32x16 c0 = splat16(bz0), c1 = splat16(bz1);
+      gemm_x3_r32_lean<FLDH, FH / 16>(L::H1 + rb * 32 * FLDH, W2x + (size_t)(2 * wave) * (FH / 16) * 192,
+                                      W2x + (size_t)(2 * wave + 1) * (FH / 16) * 192, c0, c1, lane);
+      if (rb == 1) f3 = prefetch_frag(bp, bp + 64, lane);
+      store_tanh_r32(L::H2, rb, wave, lane, c0, c1);
+    }
+  }
+  __syncthreads();
+  return f3;
+}
+
+// ------------------------------------------------------------------------------------------------
 // The training kernel.  H16: both heads are <= 16 wide (A <= 16) -> 16x16x4 head / dW3, dh2 over K = 16.
 // ------------------------------------------------------------------------------------------------
-template <int DP, bool H16>
+template <int DP, bool H16, bool X3 = false>
 __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
   using L = Lay<DP>;
   constexpr int ldx = L::LDX, per = DP / 4;
@@ -701,8 +1045,9 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     const int tid = opaque(tid0), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     const int row0 = tile * FR;
-    const Frag2 f1 = prefetch_frag(W.W1f + (size_t)(2 * wave) * (DP / 8) * 64,
-                                   W.W1f + (size_t)(2 * wave + 1) * (DP / 8) * 64, lane);
+    Frag2 f1;
+    if constexpr (!X3) f1 = prefetch_frag(W.W1f + (size_t)(2 * wave) * (DP / 8) * 64,
+                                          W.W1f + (size_t)(2 * wave + 1) * (DP / 8) * 64, lane);
     // ---- the observation rows of this tile were fetched during the previous tile's backward pass ----
 #pragma unroll
     for (int u = 0; u < NG; ++u) {
@@ -715,7 +1060,9 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     const bool llive = row0 + lrr < a.count;
     __syncthreads();
     STAMP(0)
-    const Frag2 f3 = tile_layers<DP, H16>(W, wave, lane, f1 STAMP_ARGS);
+    Frag2 f3;
+    if constexpr (X3) f3 = tile_layers_x3_train<DP, H16>(W, wave, lane);  // forward on the bf16 pipe (float32 operands split three ways)
+    else f3 = tile_layers<DP, H16>(W, wave, lane, f1 STAMP_ARGS);
     if (PHASE_ON(8)) {
       if constexpr (H16) tile_head16<DP>(W, wave, lane, f3);
       else tile_head<DP>(W, wave, lane, f3 STAMP_ARGS);
@@ -872,7 +1219,8 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     __syncthreads();
     STAMP(14)
     // ---- dW2 += dz2^T . h1  (this wave: 64 neurons x 256 inputs, K = 64 rows) ----
-    const Frag2 fh1 = prefetch_frag(W.W2b + (size_t)(2 * wave) * (FH / 8) * 64, W.W2b + (size_t)(2 * wave + 1) * (FH / 8) * 64, lane);
+    Frag2 fh1;
+    if constexpr (!X3) fh1 = prefetch_frag(W.W2b + (size_t)(2 * wave) * (FH / 8) * 64, W.W2b + (size_t)(2 * wave + 1) * (FH / 8) * 64, lane);
     if (PHASE_ON(128)) {
       const int ao = opaque(L::H2 + h * FLDH + 64 * wave + r);
       const int bo = opaque(L::H1 + h * FLDH + r);
@@ -936,7 +1284,17 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
       gb2 += column_sum(L::H2, tid);
     }
     // ---- dh1 = dz2 . W2 (K = 256), then dz1 = dh1 * (1 - h1^2) in place ----
-    {
+    if constexpr (X3) {  // on the bf16 pipe, one 32-row block at a time (gemm_x3_r32_lean)
+      const u32x4* W2bx = reinterpret_cast<const u32x4*>(W.W2bx);
+#pragma unroll 1
+      for (int rb = 0; rb < 2; ++rb) {
+        f32x16 c0 = zero16(), c1 = zero16();
+        gemm_x3_r32_lean<FLDH, FH / 16>(L::H2 + rb * 32 * FLDH, W2bx + (size_t)(2 * wave) * (FH / 16) * 192,
+                                        W2bx + (size_t)(2 * wave + 1) * (FH / 16) * 192, c0, c1, lane);
+        if (rb == 0) __syncthreads();  // dW2 reads of h1 complete everywhere
+        dtanh_inplace_r32(L::H1, rb, wave, lane, c0, c1);
+      }
+    } else {
       f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
       constexpr int nkg = FH / 8;
       if (PHASE_ON(256))
@@ -1375,214 +1733,6 @@ __device__ __forceinline__ void gemm_lds_packed_r32_deep(int a_off, const f32x4*
   MFMA_KG1(uB, p3, q3)
 }
 
-// ------------------------------------------------------------------------------------------------
-// "x3" GEMMs: a float32 product on the bf16 matrix pipe.  Every float32 operand is split into three bf16 pieces
-// (x = x1 + x2 + x3, each the bf16 rounding of what the previous ones left: 24 mantissa bits, the residuals are exact in
-// float32) and six of the nine piece products are kept (x1y1, x1y2, x2y1, x1y3, x3y1, x2y2; the dropped ones are below
-// 2^-24 of the product), accumulated in float32 by v_mfma_f32_32x32x16_bf16.  The piece products are exact in float32, so a
-// 16-k step rounds once where eight v_mfma_f32_32x32x2_f32 round eight times: measured against float64 the error is SMALLER
-// than the f32 instruction's (scratch/bf16x3_probe.hip: 3.7e-7 against 5.2e-7 of max |C|) at 1.75-1.87x its rate.
-// Used by the forward-only kernels (rollout policy forward, batched value pass); the gradient kernels stay on the f32 pipe.
-//
-// Weight packs (k_pack_x3): [column block n/32][k step k/16][piece 3][lane 64] x 8 bf16 (16 bytes per lane):
-//   lane = (n & 31) + 32 ((k & 15) >> 3), element j = k & 7      (B[k][n] = scale * W[n][k]: the 32x32x16 B operand)
-// ------------------------------------------------------------------------------------------------
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#define MFMA32B(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), (c), 0, 0, 0)
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {  // round to nearest even, lo in the low half
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-__device__ __forceinline__ void x3_split2(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
-  p1 = cvt_pk_bf16(a, b);
-  const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);   // exact
-  p2 = cvt_pk_bf16(ra, rb);
-  const float sa = ra - __uint_as_float(p2 << 16), sb = rb - __uint_as_float(p2 & 0xffff0000u);  // exact
-  p3 = cvt_pk_bf16(sa, sb);
-}
-struct X3Frag { u32x4 p[3]; };  // eight consecutive k of one row (or column), three pieces
-__device__ __forceinline__ X3Frag x3_split8(const f32x4& a, const f32x4& b) {
-  X3Frag f;
-  unsigned p1, p2, p3;
-  x3_split2(a[0], a[1], p1, p2, p3); f.p[0][0] = p1; f.p[1][0] = p2; f.p[2][0] = p3;
-  x3_split2(a[2], a[3], p1, p2, p3); f.p[0][1] = p1; f.p[1][1] = p2; f.p[2][1] = p3;
-  x3_split2(b[0], b[1], p1, p2, p3); f.p[0][2] = p1; f.p[1][2] = p2; f.p[2][2] = p3;
-  x3_split2(b[2], b[3], p1, p2, p3); f.p[0][3] = p1; f.p[1][3] = p2; f.p[2][3] = p3;
-  return f;
-}
-__device__ __forceinline__ X3Frag x3_load_b(const u32x4* __restrict__ Bx, int ks, int lane) {
-  X3Frag f;
-#pragma unroll
-  for (int pc = 0; pc < 3; ++pc) f.p[pc] = Bx[(size_t)(ks * 3 + pc) * 64 + lane];
-  return f;
-}
-// the six kept products, small terms first
-#define X3_MFMA6(A_, B_, C_)                    \
-  C_ = MFMA32B(A_.p[1], B_.p[1], C_);           \
-  C_ = MFMA32B(A_.p[0], B_.p[2], C_);           \
-  C_ = MFMA32B(A_.p[2], B_.p[0], C_);           \
-  C_ = MFMA32B(A_.p[0], B_.p[1], C_);           \
-  C_ = MFMA32B(A_.p[1], B_.p[0], C_);           \
-  C_ = MFMA32B(A_.p[0], B_.p[0], C_);
-// c0 / c1 += A[32 rows][16 NKS] (float32 in LDS, row stride LDA) . B of two column blocks (x3 packs of NKS k steps each).
-// Weight fragments are requested kAhead k steps before their use (a k step is 12 MFMAs = 384 cycles; L2 takes 500-800).
-#ifndef MOBROB_X3_AHEAD
-#define MOBROB_X3_AHEAD 2
-#endif
-#ifndef MOBROB_X3_PIPE
-#define MOBROB_X3_PIPE 1
-#endif
-// Software pipeline of a k step: the MFMAs of step ks (operands split during step ks - 1) are issued with the ~50 VALU
-// instructions that split the A fragment of step ks + 1 between them (an MFMA occupies the matrix pipe for 32 cycles, four
-// VALU instructions fill them); without the explicit groups the compiler emitted the split as one block in front of a burst of
-// MFMAs, each side waiting for the other.
-template <int LDA, int NKS>
-__device__ __forceinline__ void gemm_x3_r32(int a_off, const u32x4* __restrict__ Bx0, const u32x4* __restrict__ Bx1, f32x16& c0,
-                                            f32x16& c1, int lane) {
-  constexpr int kAhead = NKS < MOBROB_X3_AHEAD ? NKS : MOBROB_X3_AHEAD;
-  const int r = lane & 31, h = lane >> 5;
-  const int ab = 4 * opaque((a_off + r * LDA + 8 * h) >> 2);
-  X3Frag P[kAhead + 1], Q[kAhead + 1];
-#pragma unroll
-  for (int k = 0; k < kAhead; ++k) { P[k] = x3_load_b(Bx0, k, lane); Q[k] = x3_load_b(Bx1, k, lane); }
-  X3Frag U = x3_split8(*reinterpret_cast<const f32x4*>(&lds[ab]), *reinterpret_cast<const f32x4*>(&lds[ab + 4]));
-  f32x4 ua = {0.f, 0.f, 0.f, 0.f}, ub = ua;  // float32 A fragment of step ks + 1, read one step before it is split
-  if (NKS > 1) {
-    ua = *reinterpret_cast<const f32x4*>(&lds[ab + 16]);
-    ub = *reinterpret_cast<const f32x4*>(&lds[ab + 20]);
-  }
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-#if MOBROB_X3_PIPE
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-    f32x4 na = ua, nb = ub;
-    if (ks + 2 < NKS) {
-      na = *reinterpret_cast<const f32x4*>(&lds[ab + 16 * (ks + 2)]);
-      nb = *reinterpret_cast<const f32x4*>(&lds[ab + 16 * (ks + 2) + 4]);
-    }
-    if (ks + kAhead < NKS) {
-      P[(ks + kAhead) % (kAhead + 1)] = x3_load_b(Bx0, ks + kAhead, lane);
-      Q[(ks + kAhead) % (kAhead + 1)] = x3_load_b(Bx1, ks + kAhead, lane);
-    }
-    const X3Frag& p = P[ks % (kAhead + 1)];
-    const X3Frag& q = Q[ks % (kAhead + 1)];
-    X3_MFMA6(U, p, c0)
-    X3_MFMA6(U, q, c1)
-    if (ks + 1 < NKS) U = x3_split8(ua, ub);
-    ua = na; ub = nb;
-#if MOBROB_X3_PIPE
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the two LDS reads of the A fragment two steps ahead
-    __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);  // the six weight-fragment loads kAhead steps ahead
-#pragma unroll
-    for (int g = 0; g < 12; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // four VALU
-    }
-#endif
-  }
-}
-// the 64-row form: two row blocks share every weight fragment (c[column block][row block]); same pipeline, 24 MFMAs per step
-template <int LDA, int NKS>
-__device__ __forceinline__ void gemm_x3_r64(int a_off, const u32x4* __restrict__ Bx0, const u32x4* __restrict__ Bx1, f32x16& c00,
-                                            f32x16& c01, f32x16& c10, f32x16& c11, int lane) {
-  constexpr int kAhead = NKS < MOBROB_X3_AHEAD ? NKS : MOBROB_X3_AHEAD;
-  const int r = lane & 31, h = lane >> 5;
-  const int ab = 4 * opaque((a_off + r * LDA + 8 * h) >> 2);
-  X3Frag P[kAhead + 1], Q[kAhead + 1];
-#pragma unroll
-  for (int k = 0; k < kAhead; ++k) { P[k] = x3_load_b(Bx0, k, lane); Q[k] = x3_load_b(Bx1, k, lane); }
-  X3Frag U = x3_split8(*reinterpret_cast<const f32x4*>(&lds[ab]), *reinterpret_cast<const f32x4*>(&lds[ab + 4]));
-  X3Frag V = x3_split8(*reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA]), *reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA + 4]));
-  f32x4 ua = {0.f, 0.f, 0.f, 0.f}, ub = ua, va = ua, vb = ua;  // float32 A fragments of step ks + 1
-  if (NKS > 1) {
-    ua = *reinterpret_cast<const f32x4*>(&lds[ab + 16]);
-    ub = *reinterpret_cast<const f32x4*>(&lds[ab + 20]);
-    va = *reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA + 16]);
-    vb = *reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA + 20]);
-  }
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-#if MOBROB_X3_PIPE
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-    f32x4 na = ua, nb = ub, ma = va, mb = vb;
-    if (ks + 2 < NKS) {
-      na = *reinterpret_cast<const f32x4*>(&lds[ab + 16 * (ks + 2)]);
-      nb = *reinterpret_cast<const f32x4*>(&lds[ab + 16 * (ks + 2) + 4]);
-      ma = *reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA + 16 * (ks + 2)]);
-      mb = *reinterpret_cast<const f32x4*>(&lds[ab + 32 * LDA + 16 * (ks + 2) + 4]);
-    }
-    if (ks + kAhead < NKS) {
-      P[(ks + kAhead) % (kAhead + 1)] = x3_load_b(Bx0, ks + kAhead, lane);
-      Q[(ks + kAhead) % (kAhead + 1)] = x3_load_b(Bx1, ks + kAhead, lane);
-    }
-    const X3Frag& p = P[ks % (kAhead + 1)];
-    const X3Frag& q = Q[ks % (kAhead + 1)];
-    X3_MFMA6(U, p, c00)
-    X3_MFMA6(V, p, c01)
-    X3_MFMA6(U, q, c10)
-    X3_MFMA6(V, q, c11)
-    if (ks + 1 < NKS) { U = x3_split8(ua, ub); V = x3_split8(va, vb); }
-    ua = na; ub = nb; va = ma; vb = mb;
-#if MOBROB_X3_PIPE
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);
-#pragma unroll
-    for (int g = 0; g < 24; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-    }
-#endif
-  }
-}
-// canonical row-major W[N][K] (ld) -> x3 pack of NB column blocks x KS k steps (zeros outside the matrix)
-__global__ void k_pack_x3(const float* __restrict__ W, int N, int K, int ld, float scale, unsigned short* __restrict__ out, int NB, int KS) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (cb, ks, lane, j)
-  if (i >= NB * KS * 64 * 8) return;
-  const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) % KS, cb = (i >> 9) / KS;
-  const int n = cb * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + j;
-  const float x = (n < N && k < K) ? scale * W[(size_t)n * ld + k] : 0.f;
-  unsigned p1, p2, p3;
-  x3_split2(x, 0.f, p1, p2, p3);
-  const size_t base = ((size_t)(cb * KS + ks) * 3) * 512 + (size_t)lane * 8 + j;
-  out[base] = (unsigned short)(p1 & 0xffffu);
-  out[base + 512] = (unsigned short)(p2 & 0xffffu);
-  out[base + 1024] = (unsigned short)(p3 & 0xffffu);
-}
-
-// forward of the two hidden layers of a 64-row tile on the bf16 pipe (the x3 form of tile_layers; forward-only kernels)
-template <int DP>
-__device__ __forceinline__ Frag2 tile_layers_x3(const FusedNet& W, int wave, int lane) {
-  using L = Lay<DP>;
-  const int r_ = lane & 31;
-  const u32x4* W1x = reinterpret_cast<const u32x4*>(W.W1x);
-  const u32x4* W2x = reinterpret_cast<const u32x4*>(W.W2x);
-  {
-    const float bz0 = W.b1s[64 * wave + r_], bz1 = W.b1s[64 * wave + 32 + r_];
-    f32x16 c00 = splat16(bz0), c01 = splat16(bz0), c10 = splat16(bz1), c11 = splat16(bz1);
-    gemm_x3_r64<L::LDX, DP / 16>(L::X, W1x + (size_t)(2 * wave) * (DP / 16) * 192, W1x + (size_t)(2 * wave + 1) * (DP / 16) * 192,
-                                 c00, c01, c10, c11, lane);
-    store_tanh(L::H1, wave, lane, c00, c01, c10, c11);
-  }
-  __syncthreads();
-  const f32x4* bp = W.W3h;
-  Frag2 f3;
-  {
-    const float bz0 = W.b2s[64 * wave + r_], bz1 = W.b2s[64 * wave + 32 + r_];
-    f32x16 c00 = splat16(bz0), c01 = splat16(bz0), c10 = splat16(bz1), c11 = splat16(bz1);
-    gemm_x3_r64<FLDH, FH / 16>(L::H1, W2x + (size_t)(2 * wave) * (FH / 16) * 192, W2x + (size_t)(2 * wave + 1) * (FH / 16) * 192,
-                               c00, c01, c10, c11, lane);
-    f3 = prefetch_frag(bp, bp + 64, lane);
-    store_tanh(L::H2, wave, lane, c00, c01, c10, c11);
-  }
-  __syncthreads();
-  return f3;
-}
-
 // LDS carve-up of the 32-row rollout kernel
 template <int DP>
 struct Lay32 {
@@ -1910,6 +2060,7 @@ struct FusedState {
   FusedNet net[2];
   float* slabs = nullptr;
   float* train_rec = nullptr;   // H = 256: [T*N][train_rec_width(A)] (k_build_train_records)
+  bool train_x3 = false;        // k_fused_train<.., X3 = true>: x3 packs refreshed after every optimizer step
   unsigned long long* stamps = nullptr;  // diagnostic build only
   int slab_floats = 0, max_grid = 0;
   int pair_nseq_max = 0;  // 64-wide nets: two-wave workgroups per network of k_pair64_train (slabs are sized for them)

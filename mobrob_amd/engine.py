@@ -336,6 +336,10 @@ class PPOEngine:
     def compute_gae(self):
         check(self.lib.mobrob_ppo_compute_gae(self._h))
 
+    def x3_mode(self):
+        """Bit 0: rollout / value forward on the bf16 pipe with split float32 operands; bit 1: the gradient kernel's forward too."""
+        return int(self.lib.mobrob_ppo_x3_mode(self._h))
+
     def explained_variance(self):
         """1 - Var[returns - values] / Var[returns] over the rollout in the buffer (SB3's train/explained_variance)."""
         out = C.c_double()
