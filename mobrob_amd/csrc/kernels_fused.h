@@ -918,6 +918,50 @@ __device__ __forceinline__ Frag2 tile_layers_x3_train(const FusedNet& W, int wav
   return f3;
 }
 
+// dW2 += dz2^T . h1 on the bf16 pipe: one product (A piece, B piece) of the tile pair (neuron block 0 / 1, input block jb); the
+// accumulators stay pinned in AGPRs ("+a") like those of dw2_kstep.  Two MFMAs per statement so that the VALU work that
+// splits the next operands can sit between the statements.
+#define DW2X_MFMA(ia, ib)                                                               \
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\t"                            \
+               "v_mfma_f32_32x32x16_bf16 %1, %3, %4, %1"                                \
+               : "+a"(g0), "+a"(g1)                                                     \
+               : "v"(A0.p[ia]), "v"(A1.p[ia]), "v"(B.p[ib]))
+// eight consecutive batch rows of one column: the float32 side of an x3 fragment of a TRANSPOSED operand (k = batch row)
+struct ColFrag { float v[8]; };
+__device__ __forceinline__ ColFrag col_frag_load(int off) {
+  ColFrag f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = lds[off + j * FLDH];
+  return f;
+}
+__device__ __forceinline__ void col_frag_split_pair(const ColFrag& f, int jp, X3Frag& out) {  // elements 2 jp, 2 jp + 1
+  unsigned p1, p2, p3;
+  x3_split2(f.v[2 * jp], f.v[2 * jp + 1], p1, p2, p3);
+  out.p[0][jp] = p1; out.p[1][jp] = p2; out.p[2][jp] = p3;
+}
+__device__ __forceinline__ X3Frag col_frag_split(const ColFrag& f) {
+  X3Frag o;
+#pragma unroll
+  for (int jp = 0; jp < 4; ++jp) col_frag_split_pair(f, jp, o);
+  return o;
+}
+// the tile pair of input block jb for one 16-row k step; meanwhile the fragment of the next input block is split
+// (four pair-splits between the six two-MFMA statements) and the one after it is read from LDS
+__device__ __forceinline__ void dw2_x3_block(f32x16& g0, f32x16& g1, const X3Frag& A0, const X3Frag& A1, const X3Frag& B,
+                                             const ColFrag& next_raw, X3Frag& next_split) {
+  asm volatile("s_nop 1");  // VALU-written operand -> MFMA
+  DW2X_MFMA(1, 1);
+  col_frag_split_pair(next_raw, 0, next_split);
+  DW2X_MFMA(0, 2);
+  col_frag_split_pair(next_raw, 1, next_split);
+  DW2X_MFMA(2, 0);
+  col_frag_split_pair(next_raw, 2, next_split);
+  DW2X_MFMA(0, 1);
+  col_frag_split_pair(next_raw, 3, next_split);
+  DW2X_MFMA(1, 0);
+  DW2X_MFMA(0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // The training kernel.  H16: both heads are <= 16 wide (A <= 16) -> 16x16x4 head / dW3, dh2 over K = 16.
 // ------------------------------------------------------------------------------------------------
@@ -1220,8 +1264,49 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     STAMP(14)
     // ---- dW2 += dz2^T . h1  (this wave: 64 neurons x 256 inputs, K = 64 rows) ----
     Frag2 fh1;
+    int nsrc_x[NG], lsrc_next_x = -1;  // X3: row indices of the next tile (loaded in the dW2 phase, used at the start of dW1)
     if constexpr (!X3) fh1 = prefetch_frag(W.W2b + (size_t)(2 * wave) * (FH / 8) * 64, W.W2b + (size_t)(2 * wave + 1) * (FH / 8) * 64, lane);
-    if (PHASE_ON(128)) {
+    if constexpr (X3) {
+      // On the bf16 pipe: four k steps of 16 batch rows.  Both operands are TRANSPOSED reads of LDS tiles (k = batch row): a
+      // lane's fragment is eight rows of one column (col_frag_load: eight ds_read_b32, the same number of LDS reads per row
+      // as the f32 loop), split into three bf16 pieces in registers.  Per step: the two neuron-block fragments of dz2, then
+      // for each of the eight input blocks of h1 twelve MFMAs (two tiles x six products) with the next block's split
+      // between them.  The bias gradient gb2 and the next tile's gathers ride in the loop as in the f32 form.
+      const int ao = opaque(L::H2 + 8 * h * FLDH + 64 * wave + r);
+      const int bo = opaque(L::H1 + 8 * h * FLDH + r);
+      const int co = opaque(L::H2 + tid);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      // level 1 of the next tile's gathers (row indices) here; level 2 (the rows) at the start of the dW1 phase: held from
+      // the middle of this phase, as the f32 form does, the sixteen registers of the rows spilled at DP = 64
+#pragma unroll
+      for (int u = 0; u < NG; ++u) {
+        const int rr = (tid + u * FTHREADS) / per;
+        nsrc_x[u] = (has_next && nrow0 + rr < a.count) ? a.rows[nrow0 + rr] : -1;
+      }
+      lsrc_next_x = (has_next && nrow0 + lrr < a.count) ? a.rows[nrow0 + lrr] : -1;
+#pragma unroll 1
+      for (int ks = 0; ks < FR / 16; ++ks) {
+        const int ro = 16 * ks * FLDH;
+        const X3Frag A0 = col_frag_split(col_frag_load(ao + ro)), A1 = col_frag_split(col_frag_load(ao + ro + 32));
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) {  // rows = 0..3 (mod 4) -> s0..s3: column_sum()'s order
+          s0 += lds[co + ro + j * FLDH];
+          s1 += lds[co + ro + (j + 1) * FLDH];
+          s2 += lds[co + ro + (j + 2) * FLDH];
+          s3 += lds[co + ro + (j + 3) * FLDH];
+        }
+        X3Frag B = col_frag_split(col_frag_load(bo + ro));
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+          X3Frag Bn;
+          __builtin_amdgcn_sched_barrier(0);  // one block's reads at a time (hoisted, the eight blocks' 64 values spilled at DP = 64)
+          const ColFrag raw = col_frag_load(bo + ro + 32 * (jb + 1 < 8 ? jb + 1 : 7));  // the next input block
+          dw2_x3_block(gW2[jb], gW2[8 + jb], A0, A1, B, raw, Bn);
+          B = Bn;
+        }
+      }
+      gb2 += (s0 + s1) + (s2 + s3);
+    } else if (PHASE_ON(128)) {
       const int ao = opaque(L::H2 + h * FLDH + 64 * wave + r);
       const int bo = opaque(L::H1 + h * FLDH + r);
       // The bias gradient gb2 (sum of column `tid` of dz2 over the 64 rows) rides in this loop like gb1 rides in the
@@ -1310,6 +1395,15 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     __syncthreads();
     STAMP(19)
     // ---- dW1 += dz1^T . X  (this wave: 64 neurons x DP inputs, K = 64 rows) ----
+    if constexpr (X3) {  // level 2 of the next tile's gathers: in flight under this phase's MFMAs (LDS operands only)
+#pragma unroll
+      for (int u = 0; u < NG; ++u) {
+        const int c = (tid + u * FTHREADS) % per;
+        xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (nsrc_x[u] >= 0) xr[u] = ldg16(a.obs, (unsigned)nsrc_x[u] * (unsigned)(DP * 4) + (unsigned)(c * 16));
+      }
+      gather_loss(lsrc_next_x, lq);
+    }
     if (PHASE_ON(512)) {
       constexpr bool two = DP > 32;
       const int ao = opaque(L::H1 + h * FLDH + 64 * wave + r);
