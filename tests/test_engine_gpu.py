@@ -604,6 +604,41 @@ def test_x3_forward_kernels_are_float32_accurate(D, A, N, T):
         assert a[key] <= 1.5 * b[key] + 1e-7 * max(1.0, a[scale]), (key, a[key], b[key])
 
 
+@pytest.mark.parametrize("D,A", [(58, 12), (26, 2), (14, 2)])
+def test_x3_gradient_kernel_is_float32_accurate(D, A):
+    """k_fused_train<.., X3>: forward of the hidden layers, dh1 and dW2 as six bf16 products of three-way split float32
+    operands.  Against the oracle's float64-accumulated gradient of the same minibatch its error (scaled by the tensor's largest
+    entry) is held to 2e-5 like the all-f32 kernel's and stays within a small factor of that kernel's actual error (both are ~1e-6:
+    the rounding noise of 8192-term float32 sums), tensor by tensor."""
+    H, T, N, B = 256, 32, 256, 8192
+    rng = np.random.default_rng(11)
+    p = O.init_params(D, A, (H, H), (H, H), seed=3)
+    p["log_std"] = rng.normal(-0.3, 0.2, A).astype(np.float32)
+    p["action_net.weight"] *= 30
+    buf, lv, dones = _consistent_rollout(p, T, N, D, A, seed=9)
+    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=1, batch_size=B, learning_rate=3e-4)
+    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, h.gamma, h.gae_lambda)
+    idx = rng.permutation(T * N)
+    _, og, aux = O.loss_and_grads(p, *O.gather_minibatch(buf, idx[:B]), h, acc=np.float64)
+    lo, hi = 1.0 - h.clip_range, 1.0 + h.clip_range
+    assert not ((np.abs(aux["ratio"] - lo) < 2e-5) | (np.abs(aux["ratio"] - hi) < 2e-5)).any()  # no row on a clip boundary
+    errs = {}
+    for x3 in (True, False):
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=1, pi=(H, H), vf=(H, H),
+                        gamma=h.gamma, gae_lambda=h.gae_lambda, ent_coef=h.ent_coef, learning_rate=h.learning_rate, forward_x3=x3)
+        assert e.x3_mode() == (3 if x3 else 0)
+        e.set_params(p)
+        e.load_rollout(buf, lv, dones)
+        e.epoch_begin(idx)
+        e.minibatch_grad(0)
+        got = e.unflatten(e.read("grads"))
+        errs[x3] = {k: scaled_err(got[k], og[k]) for k in og}
+        e.close()
+    for k in og:
+        assert errs[True][k] < 2e-5, (k, errs[True][k])
+        assert errs[True][k] <= 4.0 * errs[False][k] + 1e-6, (k, errs[True][k], errs[False][k])  # both ~1e-6: rounding noise of 8192-term sums
+
+
 def test_rollouts_beyond_4gib_use_the_64bit_generic_kernels():
     """Maximum sizes: the fused kernels address rollout rows with 32-bit byte offsets; an observation buffer of
     >= 4 GiB must fall back to the generic (64-bit indexed) kernels and still match the oracle."""
