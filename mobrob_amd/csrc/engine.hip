@@ -1753,6 +1753,10 @@ void fill_adam_pack_args(mobrob_ppo_engine* e, AdamPackArgs& a) {
     a.fW3h[n] = (on && (n == 1 || e->fused.A <= 16)) ? (float*)e->fused.net[n].W3h : nullptr;
     a.fb1s[n] = on ? (float*)e->fused.net[n].b1s : nullptr;
     a.fb2s[n] = on ? (float*)e->fused.net[n].b2s : nullptr;
+    const bool x3 = on && e->fused.train_x3;  // the gradient kernel reads the x3 packs every step: k_adam_pack keeps them current
+    a.xW1[n] = x3 ? reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W1x)) : nullptr;
+    a.xW2[n] = x3 ? reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2x)) : nullptr;
+    a.xW2b[n] = x3 ? reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2bx)) : nullptr;
   }
 }
 }  // namespace
@@ -1795,7 +1799,6 @@ int apply_adam(mobrob_ppo_engine* e, const ApplyCtx& c) {
   a.stats_row = c.stats_row;
   a.loss_sums_zero = e->fused.enabled ? e->grads + e->P : nullptr;
   hipLaunchKernelGGL(k_adam_pack, dim3(cdiv(e->P, 256)), dim3(256), 0, e->stream, a);
-  if (e->fused.train_x3) pack_x3_all(e);  // the next gradient launch runs its forward from the x3 packs
   HIPC(hipGetLastError());
   e->grad_pending = false;
   return MOBROB_OK;

@@ -809,6 +809,7 @@ __global__ __launch_bounds__(256) void k_pack_x3_multi(PackX3Args a) {
   const int n = cb * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + j;
   float x = 0.f;
   if (n < a.N[m] && k < a.K[m]) x = a.scale[m] * (a.trans[m] ? a.W[m][(size_t)k * a.ld[m] + n] : a.W[m][(size_t)n * a.ld[m] + k]);
+  asm volatile("" : "+v"(x));  // the rounded float32 product is what gets split (see x3_pack_store)
   unsigned p1, p2, p3;
   x3_split2(x, 0.f, p1, p2, p3);
   unsigned short* out = a.out[m];
@@ -2004,6 +2005,7 @@ struct AdamPackArgs {
   float* pW1p; float* vW1p; float* aWp; float* vWp;
   // fused-path packs (null when the fused path is disabled)
   float* fW1f[2]; float* fW2f[2]; float* fW3f[2]; float* fW3h[2]; float* fW2b[2]; float* fW3b[2]; float* fb1s[2]; float* fb2s[2];
+  unsigned short* xW1[2]; unsigned short* xW2[2]; unsigned short* xW2b[2];  // x3 packs kept current per step (null: not maintained here)
   float* stats_row;  // [6] <- total gradient norm
   float* loss_sums_zero;  // fused path: the 8 loss accumulators are re-zeroed here instead of by a memset launch
   StatsArgs st;           // st.stats_row != null: this kernel also writes the step's loss statistics (no k_sqnorm_chunks launch)
@@ -2016,6 +2018,18 @@ __device__ __forceinline__ int pack_bwd_idx(int krow, int j, int KG) {
   return (((j >> 5) * KG + (krow >> 3)) * 64 + (j & 31) + 32 * ((krow >> 2) & 1)) * 4 + (krow & 3);
 }
 
+// element (column-block index n, k) of an x3 pack of KS k steps <- the three bf16 pieces of x (layout: k_pack_x3_multi)
+__device__ __forceinline__ void x3_pack_store(unsigned short* out, int n, int k, int KS, float x) {
+  // x arrives as a product (scale * parameter): without this the compiler contracts it into the first residual of the split
+  // (fma(scale, p, -piece1)), i.e. splits the UNROUNDED product -- not the bits k_pack_x3_multi produces from the stored parameter
+  asm volatile("" : "+v"(x));
+  unsigned p1, p2, p3;
+  x3_split2(x, 0.f, p1, p2, p3);
+  const size_t base = ((size_t)((n >> 5) * KS + (k >> 4)) * 3) * 512 + (size_t)((n & 31) + 32 * ((k & 15) >> 3)) * 8 + (k & 7);
+  out[base] = (unsigned short)(p1 & 0xffffu);
+  out[base + 512] = (unsigned short)(p2 & 0xffffu);
+  out[base + 1024] = (unsigned short)(p3 & 0xffffu);
+}
 // clip + Adam of canonical parameter i and its scatter into the padded copies / fragment packs [torch 2.0.1
 // single-tensor Adam; oracle adam_step].  Shared by k_adam_pack and the persistent small-batch kernel.
 __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, float graw, float m0, float v0, float p0, float coef);
@@ -2044,6 +2058,7 @@ __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, fl
       const int net = t == 5, n = e / a.D, k = e - n * a.D;
       (net ? a.vW1p : a.pW1p)[n * a.Dp + k] = pn;
       if (a.fW1f[net]) a.fW1f[net][pack_fwd_idx(n, k, a.Dp / 8)] = kTanhScale * pn;
+      if (a.xW1[net]) x3_pack_store(a.xW1[net], n, k, a.Dp / 16, kTanhScale * pn);
     } break;
     case 3: case 7: {  // W2 [H2][H1]
       const int net = t == 7;
@@ -2051,6 +2066,10 @@ __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, fl
         const int K = net ? a.G1 : a.H1, n = e / K, k = e - n * K;
         a.fW2f[net][pack_fwd_idx(n, k, K / 8)] = kTanhScale * pn;
         a.fW2b[net][pack_bwd_idx(n, k, (net ? a.G2 : a.H2) / 8)] = pn;
+        if (a.xW2[net]) {
+          x3_pack_store(a.xW2[net], n, k, K / 16, kTanhScale * pn);               // forward operand B[k][n] = scale W2[n][k]
+          x3_pack_store(a.xW2b[net], k, n, (net ? a.G2 : a.H2) / 16, pn);          // backward operand B[n][k] = W2[n][k]
+        }
       }
     } break;
     case 9: case 11: {  // head [A or 1][H2]
