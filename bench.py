@@ -596,7 +596,8 @@ def bench_single(args, name, steps, warmup, job, phases):
         hidden_fwd = 2.0 * (2 * D * H + 2 * H * H)            # forward of both hidden layers, both networks, per sample
         dh1 = 2.0 * (2 * H * H)                                # dh1 = dz2 . W2 of the backward pass, both networks
         dw2 = 2.0 * (2 * H * H)                                # dW2 = dz2^T . h1
-        x3_share = (hidden_fwd + dh1 + dw2) / (3.0 * f_fwd(D, H, A)) if x3_train else 0.0
+        dw1 = 2.0 * (2 * D * H)                                # dW1 = dz1^T . x
+        x3_share = (hidden_fwd + dh1 + dw2 + dw1) / (3.0 * f_fwd(D, H, A)) if x3_train else 0.0
         ideal_s_per_flop = x3_share * X3_PRODUCTS / (PEAK_BF16_MFMA_TFLOPS * 1e12) + (1.0 - x3_share) / (PEAK_F32_MFMA_TFLOPS * 1e12)
         peak = 1.0 / ideal_s_per_flop / 1e12
         traffic, traffic_note = None, "PMC traffic is profiled for the default workload on one GPU only"
@@ -626,9 +627,9 @@ def bench_single(args, name, steps, warmup, job, phases):
             "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "arithmetic": ("float32 storage, float32 accumulation; matrix products of the forward passes (rollout, value pass, forward "
-                           "inside the gradient kernel) and of the 256 x 256 layer's backward pass (dh1, dW2) as six bf16 x bf16 partial products of three-way split float32 operands "
+                           "inside the gradient kernel) and of the hidden layers' backward pass (dh1, dW2, dW1) as six bf16 x bf16 partial products of three-way split float32 operands "
                            "(error against float64 not larger than v_mfma_f32's: tests/test_engine_gpu.py::"
-                           "test_x3_forward_kernels_are_float32_accurate), dW1, the heads and their gradients on v_mfma_f32" if x3_mode
+                           "test_x3_forward_kernels_are_float32_accurate), the heads and their gradients on v_mfma_f32" if x3_mode
                            else "float32 throughout (v_mfma_f32)"),
             "config": {"workload": name, "obs_dim": D, "act_dim": A, "net_arch": [H, H], "envs_per_gpu": N,
                        "n_steps": T, "n_epochs": E, "minibatch_per_gpu": B, "minibatches_per_epoch": nmb,
@@ -641,7 +642,7 @@ def bench_single(args, name, steps, warmup, job, phases):
                          "frac": achieved / peak, "traffic": traffic,
                          "traffic_note": traffic_note,
                          "peak_note": (f"blend of two matrix pipes: {100 * x3_share:.1f} % of the algorithmic flops (forward of the hidden "
-                                       f"layers, dh1 and dW2 of the backward pass) run as {X3_PRODUCTS} bf16 MFMAs per float32 multiply-add (peak {PEAK_BF16_MFMA_TFLOPS:.0f} / "
+                                       f"layers, their dh1 / dW2 / dW1 of the backward pass) run as {X3_PRODUCTS} bf16 MFMAs per float32 multiply-add (peak {PEAK_BF16_MFMA_TFLOPS:.0f} / "
                                        f"{X3_PRODUCTS} TFLOP/s), the rest on v_mfma_f32 (peak {PEAK_F32_MFMA_TFLOPS}); against the f32 peak alone "
                                        f"the kernel would read {achieved / PEAK_F32_MFMA_TFLOPS:.3f}" if x3_train else
                                        "every matrix product on v_mfma_f32 (peak 157.3 TFLOP/s)"),

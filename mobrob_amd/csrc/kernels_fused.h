@@ -927,12 +927,26 @@ __device__ __forceinline__ Frag2 tile_layers_x3_train(const FusedNet& W, int wav
                "v_mfma_f32_32x32x16_bf16 %1, %3, %4, %1"                                \
                : "+a"(g0), "+a"(g1)                                                     \
                : "v"(A0.p[ia]), "v"(A1.p[ia]), "v"(B.p[ib]))
+// dW1 += dz1^T . X on the bf16 pipe: one product for the four (two) tiles; accumulators in arch VGPRs ("+v") like mfma_x2y2's
+#define DW1X_MFMA4(ia, ib)                                                              \
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %6, %0\n\t"                            \
+               "v_mfma_f32_32x32x16_bf16 %1, %5, %6, %1\n\t"                            \
+               "v_mfma_f32_32x32x16_bf16 %2, %4, %7, %2\n\t"                            \
+               "v_mfma_f32_32x32x16_bf16 %3, %5, %7, %3"                                \
+               : "+v"(gW1a), "+v"(gW1b), "+v"(gW1c), "+v"(gW1d)                         \
+               : "v"(A0.p[ia]), "v"(A1.p[ia]), "v"(B0.p[ib]), "v"(B1.p[ib]))
+#define DW1X_MFMA2(ia, ib)                                                              \
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\t"                            \
+               "v_mfma_f32_32x32x16_bf16 %1, %3, %4, %1"                                \
+               : "+v"(gW1a), "+v"(gW1b)                                                 \
+               : "v"(A0.p[ia]), "v"(A1.p[ia]), "v"(B0.p[ib]))
 // eight consecutive batch rows of one column: the float32 side of an x3 fragment of a TRANSPOSED operand (k = batch row)
 struct ColFrag { float v[8]; };
+template <int LD = FLDH>
 __device__ __forceinline__ ColFrag col_frag_load(int off) {
   ColFrag f;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) f.v[j] = lds[off + j * FLDH];
+  for (int j = 0; j < 8; ++j) f.v[j] = lds[off + j * LD];
   return f;
 }
 __device__ __forceinline__ void col_frag_split_pair(const ColFrag& f, int jp, X3Frag& out) {  // elements 2 jp, 2 jp + 1
@@ -1405,7 +1419,37 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
       }
       gather_loss(lsrc_next_x, lq);
     }
-    if (PHASE_ON(512)) {
+    if constexpr (X3) {  // four k steps of 16 batch rows on the bf16 pipe; both operands are column fragments (dz1, X)
+      constexpr bool two = DP > 32;
+      const int ao = opaque(L::H1 + 8 * h * FLDH + 64 * wave + r);
+      const int c0 = (r < DP) ? r : 0;
+      const int c1 = (32 + r < DP) ? 32 + r : c0;  // clamped columns are never read back
+      const int b0o = opaque(L::X + 8 * h * ldx + c0), b1o = opaque(L::X + 8 * h * ldx + c1);
+      const int co = opaque(L::H1 + tid);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 1
+      for (int ks = 0; ks < FR / 16; ++ks) {
+        const int ro = 16 * ks * FLDH, rx = 16 * ks * ldx;
+        const X3Frag A0 = col_frag_split(col_frag_load(ao + ro)), A1 = col_frag_split(col_frag_load(ao + ro + 32));
+        const X3Frag B0 = col_frag_split(col_frag_load<ldx>(b0o + rx));
+        X3Frag B1 = B0;
+        if (two) B1 = col_frag_split(col_frag_load<ldx>(b1o + rx));
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) {  // gb1: rows = 0..3 (mod 4) -> s0..s3, column_sum()'s order
+          s0 += lds[co + ro + j * FLDH];
+          s1 += lds[co + ro + (j + 1) * FLDH];
+          s2 += lds[co + ro + (j + 2) * FLDH];
+          s3 += lds[co + ro + (j + 3) * FLDH];
+        }
+        asm volatile("s_nop 1");
+        if (two) {
+          DW1X_MFMA4(1, 1); DW1X_MFMA4(0, 2); DW1X_MFMA4(2, 0); DW1X_MFMA4(0, 1); DW1X_MFMA4(1, 0); DW1X_MFMA4(0, 0);
+        } else {
+          DW1X_MFMA2(1, 1); DW1X_MFMA2(0, 2); DW1X_MFMA2(2, 0); DW1X_MFMA2(0, 1); DW1X_MFMA2(1, 0); DW1X_MFMA2(0, 0);
+        }
+      }
+      gb1 += (s0 + s1) + (s2 + s3);
+    } else if (PHASE_ON(512)) {
       constexpr bool two = DP > 32;
       const int ao = opaque(L::H1 + h * FLDH + 64 * wave + r);
       const int c0 = (r < DP) ? r : 0;
