@@ -173,12 +173,13 @@ def csrc_sha256():
     return h.hexdigest()
 
 
-def dominant_kernel_name(H, rows_per_launch, generic):
+def dominant_kernel_name(H, rows_per_launch, generic, x3_train=False):
     """Which gradient kernel the engine launches for this shape (engine.hip: fused64_minibatch_grad / fused_minibatch_grad)."""
     if generic:
         return "generic GEMM chain"
     if H == 256:
-        return "k_fused_train (minibatch forward+loss+backward)"
+        return ("k_fused_train<.., X3> (minibatch forward+loss+backward; hidden-layer products on the bf16 pipe, split float32 operands)"
+                if x3_train else "k_fused_train (minibatch forward+loss+backward)")
     tiles = -(-rows_per_launch // 32)
     return ("k_split64_train (one workgroup per 32-row tile)" if tiles <= 64 else "k_pair64_train (two waves per tile, two per SIMD)") + ": minibatch forward+loss+backward"
 
@@ -637,7 +638,7 @@ def bench_single(args, name, steps, warmup, job, phases):
                                       if host is not None else "device-resident synthetic (Philox)"),
                        "parallelism": f"dp{world}", "n_ranks_seen": ranks_seen, "n_ranks_source": ranks_src,
                        "kernels": "generic" if args.generic else "fused"},
-            "roofline": {"bound": "mfma", "kernel": dominant_kernel_name(H, B, args.generic),
+            "roofline": {"bound": "mfma", "kernel": dominant_kernel_name(H, B, args.generic, x3_train),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "traffic_note": traffic_note,
