@@ -688,12 +688,36 @@ __device__ __forceinline__ void gemm_x3_r32(int a_off, const u32x4* __restrict__
 // The same arithmetic (same k order, same six products per step: the same bits) with a bounded register footprint for the
 // training kernel: a runtime k loop over PAIRS of steps, weight fragments one step ahead in two fixed slots, the A fragment read
 // and split one step ahead (c 32 + U 12 + float32 fragment 8 + two slots 48 registers).
-#define X3_STEP_GROUPS()                                   \
-  __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       \
-  __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);       \
-  _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {      \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
-    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     \
+// one product of the step for both column blocks: c0 += U[ia] . P[ib], c1 += U[ia] . Q[ib]  (accumulators in arch VGPRs)
+#define X3R32_MFMA(Uf, Pf, Qf, ia, ib)                                                  \
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\t"                            \
+               "v_mfma_f32_32x32x16_bf16 %1, %2, %4, %1"                                \
+               : "+v"(c0), "+v"(c1)                                                     \
+               : "v"(Uf.p[ia]), "v"(Pf.p[ib]), "v"(Qf.p[ib]))
+#define X3_SPLIT_PAIR(dst, jp, lo, hi)                                                  \
+  {                                                                                     \
+    unsigned p1_, p2_, p3_;                                                             \
+    x3_split2(lo, hi, p1_, p2_, p3_);                                                   \
+    dst.p[0][jp] = p1_; dst.p[1][jp] = p2_; dst.p[2][jp] = p3_;                         \
+  }
+// a step: the twelve MFMAs in six statements, the four pair-splits of the NEXT A fragment between the first five (an MFMA
+// holds the matrix pipe for 32 cycles; a pair-split is 11 VALU instructions) -- written out by hand: left to the scheduler
+// (sched_group_barrier), the first step of every call came out as a burst of MFMAs followed by a block of splits
+#define X3R32_STEP(Pf, Qf)                                   \
+  {                                                          \
+    X3Frag Un_;                                              \
+    asm volatile("s_nop 1");                                 \
+    X3R32_MFMA(U, Pf, Qf, 1, 1);                             \
+    X3_SPLIT_PAIR(Un_, 0, ua[0], ua[1])                      \
+    X3R32_MFMA(U, Pf, Qf, 0, 2);                             \
+    X3_SPLIT_PAIR(Un_, 1, ua[2], ua[3])                      \
+    X3R32_MFMA(U, Pf, Qf, 2, 0);                             \
+    X3_SPLIT_PAIR(Un_, 2, ub[0], ub[1])                      \
+    X3R32_MFMA(U, Pf, Qf, 0, 1);                             \
+    X3_SPLIT_PAIR(Un_, 3, ub[2], ub[3])                      \
+    X3R32_MFMA(U, Pf, Qf, 1, 0);                             \
+    X3R32_MFMA(U, Pf, Qf, 0, 0);                             \
+    U = Un_;                                                 \
   }
 template <int LDA, int NKS>
 __device__ __forceinline__ void gemm_x3_r32_lean(int a_off, const u32x4* __restrict__ Bx0, const u32x4* __restrict__ Bx1, f32x16& c0,
@@ -708,37 +732,34 @@ __device__ __forceinline__ void gemm_x3_r32_lean(int a_off, const u32x4* __restr
   X3Frag U = x3_split8(*reinterpret_cast<const f32x4*>(&lds[ao]), *reinterpret_cast<const f32x4*>(&lds[ao + 4]));
 #pragma unroll 1
   for (int ks = 0; ks + 2 <= NKS; ks += 2) {
-    __builtin_amdgcn_sched_barrier(0);
     {  // step ks from slot 0; step ks + 1 exists
       const f32x4 ua = *reinterpret_cast<const f32x4*>(&lds[ao + 16]);
       const f32x4 ub = *reinterpret_cast<const f32x4*>(&lds[ao + 20]);
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) { P1.p[pc] = b0[(3 + pc) * 64]; Q1.p[pc] = b1[(3 + pc) * 64]; }
-      X3_MFMA6(U, P0, c0)
-      X3_MFMA6(U, Q0, c1)
-      U = x3_split8(ua, ub);
-      X3_STEP_GROUPS()
+      X3R32_STEP(P0, Q0)
     }
-    __builtin_amdgcn_sched_barrier(0);
     {  // step ks + 1 from slot 1; step ks + 2 may not exist: its (unused) operands are then those of the last step again
       const int adv = ks + 2 < NKS ? 1 : 0;
       const f32x4 ua = *reinterpret_cast<const f32x4*>(&lds[ao + 16 + 16 * adv]);
       const f32x4 ub = *reinterpret_cast<const f32x4*>(&lds[ao + 20 + 16 * adv]);
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) { P0.p[pc] = b0[(3 + 3 * adv + pc) * 64]; Q0.p[pc] = b1[(3 + 3 * adv + pc) * 64]; }
-      X3_MFMA6(U, P1, c0)
-      X3_MFMA6(U, Q1, c1)
-      U = x3_split8(ua, ub);
-      X3_STEP_GROUPS()
+      X3R32_STEP(P1, Q1)
     }
     ao += 32;
     b0 += 6 * 64;
     b1 += 6 * 64;
   }
   if (NKS & 1) {  // last step of an odd count: slot 0 and U hold it
-    X3_MFMA6(U, P0, c0)
-    X3_MFMA6(U, Q0, c1)
+    asm volatile("s_nop 1");
+    X3R32_MFMA(U, P0, Q0, 1, 1); X3R32_MFMA(U, P0, Q0, 0, 2); X3R32_MFMA(U, P0, Q0, 2, 0);
+    X3R32_MFMA(U, P0, Q0, 0, 1); X3R32_MFMA(U, P0, Q0, 1, 0); X3R32_MFMA(U, P0, Q0, 0, 0);
   }
+  // The MFMAs above are opaque statements: the compiler's hazard recognizer does not know that c0 / c1 were written by the
+  // matrix pipe, and the caller's epilogue reads them with VALU instructions right away (XDL write -> VALU read needs up to 19
+  // wait states for a 16-pass instruction).
+  asm volatile("s_nop 15\n\ts_nop 7" : "+v"(c0), "+v"(c1));
 }
 // the 64-row form: two row blocks share every weight fragment (c[column block][row block]); same pipeline, 24 MFMAs per step
 template <int LDA, int NKS>
@@ -1448,6 +1469,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
           DW1X_MFMA2(1, 1); DW1X_MFMA2(0, 2); DW1X_MFMA2(2, 0); DW1X_MFMA2(0, 1); DW1X_MFMA2(1, 0); DW1X_MFMA2(0, 0);
         }
       }
+      asm volatile("s_nop 15\n\ts_nop 7");  // opaque MFMA statements: after the last tile the slab store reads gW1 (XDL write -> VMEM read)
       gb1 += (s0 + s1) + (s2 + s3);
     } else if (PHASE_ON(512)) {
       constexpr bool two = DP > 32;
