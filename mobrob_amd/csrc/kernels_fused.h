@@ -1404,6 +1404,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
     } else if (PHASE_ON(2048)) {
       gb2 += column_sum(L::H2, tid);
     }
+    STAMP(15)
     // ---- dh1 = dz2 . W2 (K = 256), then dz1 = dh1 * (1 - h1^2) in place ----
     if constexpr (X3) {  // on the bf16 pipe, one 32-row block at a time (gemm_x3_r32_lean)
       const u32x4* W2bx = reinterpret_cast<const u32x4*>(W.W2bx);
@@ -1415,6 +1416,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
         if (rb == 0) __syncthreads();  // dW2 reads of h1 complete everywhere
         dtanh_inplace_r32(L::H1, rb, wave, lane, c0, c1);
       }
+      STAMP(16)
     } else {
       f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
       constexpr int nkg = FH / 8;
