@@ -584,7 +584,7 @@ __device__ __forceinline__ void tile_head16(const FusedNet& W, int wave, int lan
 // than the f32 instruction's (scratch/bf16x3_probe.hip: 3.7e-7 against 5.2e-7 of max |C|) at 1.75-1.87x its rate.
 // Used by the forward-only kernels (rollout policy forward, batched value pass); the gradient kernels stay on the f32 pipe.
 //
-// Weight packs (k_pack_x3): [column block n/32][k step k/16][piece 3][lane 64] x 8 bf16 (16 bytes per lane):
+// Weight packs (k_pack_x3_multi, kept current by k_adam_pack): [column block n/32][k step k/16][piece 3][lane 64] x 8 bf16 (16 bytes per lane):
 //   lane = (n & 31) + 32 ((k & 15) >> 3), element j = k & 7      (B[k][n] = scale * W[n][k]: the 32x32x16 B operand)
 // ------------------------------------------------------------------------------------------------
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -834,20 +834,6 @@ __global__ __launch_bounds__(256) void k_pack_x3_multi(PackX3Args a) {
   unsigned p1, p2, p3;
   x3_split2(x, 0.f, p1, p2, p3);
   unsigned short* out = a.out[m];
-  const size_t base = ((size_t)(cb * KS + ks) * 3) * 512 + (size_t)lane * 8 + j;
-  out[base] = (unsigned short)(p1 & 0xffffu);
-  out[base + 512] = (unsigned short)(p2 & 0xffffu);
-  out[base + 1024] = (unsigned short)(p3 & 0xffffu);
-}
-// canonical row-major W[N][K] (ld) -> x3 pack of NB column blocks x KS k steps (zeros outside the matrix)
-__global__ void k_pack_x3(const float* __restrict__ W, int N, int K, int ld, float scale, unsigned short* __restrict__ out, int NB, int KS) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (cb, ks, lane, j)
-  if (i >= NB * KS * 64 * 8) return;
-  const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) % KS, cb = (i >> 9) / KS;
-  const int n = cb * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + j;
-  const float x = (n < N && k < K) ? scale * W[(size_t)n * ld + k] : 0.f;
-  unsigned p1, p2, p3;
-  x3_split2(x, 0.f, p1, p2, p3);
   const size_t base = ((size_t)(cb * KS + ks) * 3) * 512 + (size_t)lane * 8 + j;
   out[base] = (unsigned short)(p1 & 0xffffu);
   out[base + 512] = (unsigned short)(p2 & 0xffffu);
