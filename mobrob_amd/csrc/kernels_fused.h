@@ -1318,13 +1318,15 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_fused_train(FusedTrainArgs a) {
           s3 += lds[co + ro + (j + 3) * FLDH];
         }
         X3Frag B = col_frag_split(col_frag_load(bo + ro));
+        ColFrag raw = col_frag_load(bo + ro + 32);
 #pragma unroll
         for (int jb = 0; jb < 8; ++jb) {
           X3Frag Bn;
           __builtin_amdgcn_sched_barrier(0);  // one block's reads at a time (hoisted, the eight blocks' 64 values spilled at DP = 64)
-          const ColFrag raw = col_frag_load(bo + ro + 32 * (jb + 1 < 8 ? jb + 1 : 7));  // the next input block
+          const ColFrag raw2 = col_frag_load(bo + ro + 32 * (jb + 2 < 8 ? jb + 2 : 7));  // two input blocks ahead: no LDS wait in front of the splits
           dw2_x3_block(gW2[jb], gW2[8 + jb], A0, A1, B, raw, Bn);
           B = Bn;
+          raw = raw2;
         }
       }
       gb2 += (s0 + s1) + (s2 + s3);
