@@ -81,11 +81,12 @@ typedef struct mobrob_ppo_config {
   int32_t rollout_persistent; /* 1: run the device-resident rollout as one persistent kernel (fused widths) */
   int32_t activation;         /* hidden activation of both networks: MOBROB_ACT_TANH (0; SB3's default for MlpPolicy, every
                                  reference YAML) or MOBROB_ACT_RELU (policy_kwargs activation_fn=nn.ReLU; generic GEMM chain) */
-  int32_t forward_x3;         /* 1 (default): the forward-only kernels of 256-wide nets (rollout policy forward, batched value pass)
-                                 multiply on the bf16 matrix pipe with every float32 operand split into three bf16 pieces and six
-                                 piece products kept, float32 accumulation -- float32 results (error against float64 not larger than
-                                 v_mfma_f32's) at 1.7x the rate; 0: v_mfma_f32_32x32x2_f32 everywhere.  The gradient
-                                 kernels are on the f32 pipe either way. */
+  int32_t forward_x3;         /* 1 (default): the hidden-layer matrix products of 256-wide tanh nets -- rollout policy forward, batched value
+                                 pass, and inside the gradient kernel the forward, dh1, dW2, dW1 -- run on the bf16 matrix pipe with every
+                                 float32 operand split into three bf16 pieces and six piece products kept, float32 accumulation: float32
+                                 RESULTS (error against float64 not larger than v_mfma_f32's, not bit-equal to it) at up to
+                                 16/6 of the f32 matrix rate.  0: v_mfma_f32 everywhere.  Heads, loss, GAE, clip and Adam are plain float32
+                                 either way; so are the 64-wide kernel families and the generic GEMM chain. */
   int32_t reserved[3];
 } mobrob_ppo_config_t;
 
@@ -405,9 +406,9 @@ int mobrob_ppo_write_buffer(mobrob_ppo_engine_t* e, int32_t which, const void* h
 int mobrob_ppo_mark_rollout_ready(mobrob_ppo_engine_t* e);
 
 /* Which matrix products of this engine run on the bf16 pipe with three-way split float32 operands (config.forward_x3, 256-wide tanh
- * nets): bit 0 = rollout policy forward and batched value pass, bit 1 = the forward of the two hidden layers inside the gradient kernel
- * (heads <= 16 wide, observation rows of 16 / 32 / 64 padded columns).  0: everything on v_mfma_f32.  Measurement code prices the
- * kernels against the matrix peak of the pipe each product ran on (bench.py). */
+ * nets): bit 0 = rollout policy forward and batched value pass, bit 1 = the hidden-layer products inside the gradient kernel (forward,
+ * dh1, dW2, dW1; heads <= 16 wide, observation rows of 16 / 32 / 64 padded columns).  0: everything on v_mfma_f32.  Measurement code
+ * prices the kernels against the matrix peak of the pipe each product ran on (bench.py). */
 int mobrob_ppo_x3_mode(const mobrob_ppo_engine_t* e);
 
 /* train/explained_variance as SB3's PPO.train logs it (stable_baselines3 2.0.0 ppo.py: explained_variance(rollout_buffer.values.flatten(),
