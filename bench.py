@@ -173,6 +173,23 @@ def csrc_sha256():
     return h.hexdigest()
 
 
+def blended_peak(D, H, A, x3_train):
+    """(peak in TFLOP/s algorithmic, share of the algorithmic flops on the bf16 pipe) for the gradient kernel of a 2xH net.
+    With forward_x3 the hidden-layer products of the gradient kernel (forward of both layers, dh1, dW2, dW1 -- everything but
+    the heads and the never-computed input gradient that the 3*F_fwd convention counts) are issued as X3_PRODUCTS bf16 x bf16
+    MFMAs per float32 multiply-add on the bf16 pipe, the rest as v_mfma_f32: the bound is the time both pipes need at THEIR
+    peaks, expressed as the algorithmic rate that time corresponds to."""
+    if not x3_train:
+        return PEAK_F32_MFMA_TFLOPS, 0.0
+    hidden_fwd = 2.0 * (2 * D * H + 2 * H * H)            # forward of both hidden layers, both networks, per sample
+    dh1 = 2.0 * (2 * H * H)                                # dh1 = dz2 . W2 of the backward pass, both networks
+    dw2 = 2.0 * (2 * H * H)                                # dW2 = dz2^T . h1
+    dw1 = 2.0 * (2 * D * H)                                # dW1 = dz1^T . x
+    x3_share = (hidden_fwd + dh1 + dw2 + dw1) / (3.0 * f_fwd(D, H, A))
+    ideal_s_per_flop = x3_share * X3_PRODUCTS / (PEAK_BF16_MFMA_TFLOPS * 1e12) + (1.0 - x3_share) / (PEAK_F32_MFMA_TFLOPS * 1e12)
+    return 1.0 / ideal_s_per_flop / 1e12, x3_share
+
+
 def dominant_kernel_name(H, rows_per_launch, generic, x3_train=False):
     """Which gradient kernel the engine launches for this shape (engine.hip: fused64_minibatch_grad / fused_minibatch_grad)."""
     if generic:
@@ -594,13 +611,7 @@ def bench_single(args, name, steps, warmup, job, phases):
         # multiply-add on the bf16 pipe, everything else as v_mfma_f32: the bound is the time both pipes need at THEIR
         # peaks, expressed as the algorithmic rate that time corresponds to.
         x3_train = bool(x3_mode & 2) and not args.generic
-        hidden_fwd = 2.0 * (2 * D * H + 2 * H * H)            # forward of both hidden layers, both networks, per sample
-        dh1 = 2.0 * (2 * H * H)                                # dh1 = dz2 . W2 of the backward pass, both networks
-        dw2 = 2.0 * (2 * H * H)                                # dW2 = dz2^T . h1
-        dw1 = 2.0 * (2 * D * H)                                # dW1 = dz1^T . x
-        x3_share = (hidden_fwd + dh1 + dw2 + dw1) / (3.0 * f_fwd(D, H, A)) if x3_train else 0.0
-        ideal_s_per_flop = x3_share * X3_PRODUCTS / (PEAK_BF16_MFMA_TFLOPS * 1e12) + (1.0 - x3_share) / (PEAK_F32_MFMA_TFLOPS * 1e12)
-        peak = 1.0 / ideal_s_per_flop / 1e12
+        peak, x3_share = blended_peak(D, H, A, x3_train)
         traffic, traffic_note = None, "PMC traffic is profiled for the default workload on one GPU only"
         if not args.generic and name == "doggo-4096env-2x256" and not use_dp and not phases:
             traffic, traffic_note = measured_traffic("void mobrob::k_fused_train<64")

@@ -78,3 +78,14 @@ def test_traffic_figure_is_tied_to_the_kernel_sources():
         assert isinstance(val, int) and val > 0
     else:
         assert val is None and "not reported" in note
+
+
+def test_blended_matrix_peak_of_the_x3_gradient_kernel():
+    """roofline.peak of bench.py for the headline shape: 91.9 % of 3 * F_fwd on the bf16 pipe at six MFMAs per multiply-add,
+    the rest on v_mfma_f32; without x3 the f32 matrix peak."""
+    import bench
+    assert bench.blended_peak(58, 256, 12, False) == (157.3, 0.0)
+    peak, share = bench.blended_peak(58, 256, 12, True)
+    assert abs(share - 905216.0 / 984576.0) < 1e-12 and abs(share - 0.919) < 1e-3
+    ideal = share * 6 / (16 * 157.3) + (1 - share) / 157.3
+    assert abs(peak - 1.0 / ideal) < 1e-9 and 369.0 < peak < 370.5
