@@ -36,7 +36,9 @@
 extern "C" {
 #endif
 
-#define MOBROB_PPO_ABI_VERSION 1
+/* 2: config slot `persistent_train` became `activation`, `forward_x3` added, MOBROB_K_COUNT 6 -> 7 (profile_read arrays),
+ *    MOBROB_BUF_COUNT / reserved[] resized -- a binding built against 1 must not load this library */
+#define MOBROB_PPO_ABI_VERSION 2
 enum { MOBROB_ACT_TANH = 0, MOBROB_ACT_RELU = 1 };
 
 enum {

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MOBROB_PPO_LIB: another build of the same library (A/B timing of a compile-time switch, stamp / ablation builds)
 LIB_PATH = os.environ.get("MOBROB_PPO_LIB") or os.path.join(_HERE, "libmobrob_ppo.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 

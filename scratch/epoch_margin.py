@@ -1,19 +1,18 @@
-"""How close is test_benchmarked_epoch_matches_oracle[doggo] to its 1e-4 bound, with and without the x3 forward kernels?"""
-import os, sys
-import numpy as np
+"""Margins of tests/test_full_size_gpu.py::test_benchmarked_epoch_matches_oracle: a whole epoch of the bench workloads on both
+matrix pipes against the oracle, several seeds, with the band inside which rows are moved off the clip boundaries as a
+parameter (0 = leave every row where it is: shows the bimodal deviation the band removes).
+    python scratch/epoch_margin.py [band ...] > profiles/r4/epoch_margin.txt"""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import ppo_oracle as O
-from tests.test_full_size_gpu import _bench_like_engine, _device_perm_key
+from tests.test_full_size_gpu import run_epoch_against_oracle
 
-for seed, rs in ((23, 6), (24, 7), (25, 8)):
-    D, A, H, n_envs, T, B = 58, 12, 256, 4096, 1000, 65536
-    rng = np.random.default_rng(rs)
-    e, p, st, buf, h = _bench_like_engine(D, A, H, n_envs, T, B, seed, rng)
-    perm = O.feistel_permutation(T * n_envs, _device_perm_key(seed, 0))
-    e.train(None)
-    O.train(p, st, buf, h, perm[None])
-    newp = e.get_params()
-    errs = {k: float(np.max(np.abs(newp[k] - p[k]))) for k in p}
-    worst = max(errs, key=errs.get)
-    print("x3" if not os.environ.get("MOBROB_NO_X3") else "f32", "seed", seed, "worst", worst, f"{errs[worst]:.2e}", "log_std", f"{errs['log_std']:.2e}", flush=True)
-    e.close()
+bands = [float(b) for b in sys.argv[1:]] or [2e-5, 0.0]
+shapes = [dict(name="doggo-4096env-2x256", D=58, A=12, H=256, N=4096, T=1000), dict(name="point-1024env-2x64", D=14, A=2, H=64, N=1024, T=2048)]
+for band in bands:
+    for shape in shapes:
+        for seed, rs in ((23, 6), (24, 7), (25, 8)):
+            t0 = time.time()
+            errs, _, _, moved, passes = run_epoch_against_oracle(shape, seed, rs, band=band if band > 0 else 1e-30, log=lambda s: None)
+            line = "  ".join(f"{pipe}: worst {max(e, key=e.get).replace('mlp_extractor.', '')} {max(e.values()):.2e} log_std {e['log_std']:.2e}"
+                             for pipe, e in errs.items())
+            print(f"band {band:g}  {shape['name']}  seed {seed}  moved {len(moved)} rows in {passes} pass(es)  {line}  ({time.time() - t0:.0f} s)", flush=True)

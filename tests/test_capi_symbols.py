@@ -34,7 +34,7 @@ def test_config_struct_layout_matches_header():
     lib = _lib.load()
     cfg = _lib.Config()
     lib.mobrob_ppo_default_config(ctypes.byref(cfg))
-    assert (cfg.abi_version, cfg.n_steps, cfg.batch_size, cfg.n_epochs) == (1, 2048, 64, 10)
+    assert (cfg.abi_version, cfg.n_steps, cfg.batch_size, cfg.n_epochs) == (2, 2048, 64, 10)
     assert (cfg.gamma, cfg.gae_lambda, cfg.clip_range, cfg.vf_coef, cfg.max_grad_norm) == (0.99, 0.95, 0.2, 0.5, 0.5)
     assert (cfg.learning_rate, cfg.adam_eps, cfg.action_low, cfg.action_high) == (3e-4, 1e-5, -1.0, 1.0)
     assert (cfg.world_size, cfg.fast_kernels, cfg.normalize_advantage) == (1, 1, 1)
@@ -85,3 +85,30 @@ def test_build_fails_on_register_spills():
     if os.path.exists(audit):     # written by the build that produced the shipped library
         lines = open(audit).read().strip().splitlines()
         assert len(lines) > 100 and any("k_fused_train" in l for l in lines)
+
+
+def test_build_reuse_is_keyed_on_a_hash_of_the_sources(tmp_path):
+    """build() reuses a library only while the sidecar beside it holds the sha256 of csrc/ + include/ + the compile flags
+    (VERDICT r3 #11): a changed source, a changed flag or a missing sidecar force a compile; mtimes play no part."""
+    import time
+    import __graft_entry__ as G
+    src, lib = tmp_path / "a.hip", str(tmp_path / "lib.so")
+    src.write_text("int f() { return 1; }\n")
+    flags = ["-O3"]
+    assert G.needs_build(lib, [str(src)], flags)                 # nothing built yet
+    open(lib, "wb").write(b"\x7fELF")
+    assert G.needs_build(lib, [str(src)], flags)                 # a library without a sidecar is not trusted
+    G._stamp(lib, [str(src)], flags)
+    assert not G.needs_build(lib, [str(src)], flags)
+    os.utime(src, (time.time() + 100, time.time() + 100))         # touched, content unchanged: still current
+    assert not G.needs_build(lib, [str(src)], flags)
+    src.write_text("int f() { return 2; }\n")
+    os.utime(src, (1, 1))                                         # changed content with an OLD mtime (a reverted edit): rebuild
+    assert G.needs_build(lib, [str(src)], flags)
+    src.write_text("int f() { return 1; }\n")
+    assert not G.needs_build(lib, [str(src)], flags)
+    assert G.needs_build(lib, [str(src)], flags + ["-g"])        # the flags are part of the key
+    # the shipped libraries carry their sidecars and they match the tree
+    G.build()
+    assert not G.needs_build(G.LIB, G.engine_sources(), G.HIPCC_FLAGS)
+    assert not G.needs_build(G.ENV_LIB, [G.ENV_SRC], G.ENV_FLAGS)
