@@ -1,0 +1,699 @@
+// k_chain_train: the gradient kernel of the 256-wide networks designed around the bf16 matrix pipe (round 4).
+//
+// k_fused_train<.., X3> (kernels_fused.h) is the f32 kernel with its GEMM loops swapped for "x3" loops (float32 products as six
+// bf16 x bf16 MFMAs on three-way split operands): every wave owns 64 output columns, activations live in LDS as float32 and are
+// split in the k loops, every weight fragment is streamed from L2 per 32 rows (64 B/clk per CU: the rate of the CU's vector
+// memory port).  This kernel keeps the arithmetic (the same six products per float32 multiply-add, float32 accumulation, heads /
+// loss / epilogues in float32) and changes who owns what:
+//
+//   * A wave owns 16 BATCH ROWS of a 64-row tile and runs the whole forward / backward ACTIVATION chain of its rows in
+//     registers.  Every layer is computed transposed, C[neuron][row] = sum_k W[neuron][k] act[k][row] with the weights as the
+//     MFMA A operand and the activations as the B operand (v_mfma_f32_16x16x32_bf16): an accumulator tile then has its neuron
+//     in the registers / lane groups and its batch row on the lanes, which IS the B-operand layout of the next layer -- no
+//     LDS round trip, no lane movement (cdna_hip_programming.md, 'An accumulator tile as the next MFMA's operand').  The price
+//     is a permuted k order that the weight packs absorb (tests/chain_model.py states the maps and checks them on the CPU).
+//     Activations are split into their three bf16 pieces ONCE, when a k step's B fragment is formed (44 VALU instructions per 96
+//     MFMAs), not per use.
+//   * All four waves need the same weights: they are streamed L2 -> LDS ONCE per tile by LDS-DMA (global_load_lds_dwordx4, no
+//     registers) into a 72 KB ring and read by every wave with ds_read_b128: 16 B/clk per CU from L2 instead of 64.
+//   * The weight gradients contract over the batch rows, i.e. over the LANES of the chain layout: the activations are
+//     exchanged once through LDS as float32 "images" [column][64 rows] (rows contiguous: a lane's eight-row fragment is two
+//     ds_read_b128 instead of eight ds_read_b32; XOR-swizzled, conflict-free for every access pattern below) and dW2 / dW1 /
+//     dW3 run as in k_fused_train: dW2's 256 x 256 accumulators pinned in the 256 AGPRs of the four waves for the whole launch.
+//     dW1 no longer holds 64 VGPRs for the launch: it is accumulated per tile and added to the workgroup's (L2-resident) slab.
+//
+// LDS (160 KB): h1 / dz1 image 64 KB | X image | constants | ring 12 KB + (h2 / dz2 image 64 KB: ring space while no image is live).
+// Same slab format as k_fused_train: k_slab_reduce, the norm records and k_adam_pack are unchanged.
+// Conditions: 256-wide tanh nets, heads <= 16 wide, observation rows padded to 16 / 32 / 64 columns (engine.hip fused_init).
+#pragma once
+#include "kernels_fused.h"
+
+namespace mobrob {
+
+constexpr int CR = 64;                 // batch rows per tile (four waves x 16)
+constexpr int CIMG = FH * CR;          // floats of a transposed activation image [256 columns][64 rows]
+constexpr int CUNIT = 768;             // floats of a ring unit: one A fragment (16 neurons x 32 k slots) x 3 bf16 pieces = 3 KB
+constexpr int CSEG = 8;                // units per ring segment (one workgroup barrier per segment)
+constexpr int CNSEG = 3;               // segments in the ring: one being read, two in flight
+constexpr int CSLOTS = CSEG * CNSEG;   // 24 units = 72 KB
+
+// LDS carve-up (float offsets)
+template <int DP>
+struct CLay {
+  static constexpr int H1 = 0;                  // h1, later dz1: [256][64] swizzled (img_addr)
+  static constexpr int XI = H1 + CIMG;          // X: [DP][64] swizzled
+  static constexpr int CST = XI + DP * CR;      // [3][32]: 1/var, log(sd)+log(sqrt(2pi)), head bias
+  static constexpr int B1 = CST + 96;           // hidden biases x 2 log2(e) (the tanh epilogue's scale)
+  static constexpr int B2 = B1 + FH;
+  static constexpr int STAT = B2 + FH;          // [4 waves][4] loss sums (kernel end)
+  static constexpr int GACC = STAT + 16;        // [4 waves][2][16] head-bias / log_std gradient sums (kernel end)
+  static constexpr int RING = (GACC + 128 + 255) / 256 * 256;   // 1 KB aligned; the first 4 units are ring-only ...
+  static constexpr int DO = RING;               // ... and hold the dout image [64 rows][16] between the two chain phases
+  static constexpr int H2 = RING + 4 * CUNIT;   // h2, later dz2: [256][64] swizzled; units 4 .. 23 of the ring otherwise
+  static constexpr int END = H2 + CIMG;
+  static_assert(RING + CSLOTS * CUNIT <= END, "ring beyond the h2 image");
+  static_assert(END * 4 <= 163840, "LDS");
+};
+inline size_t chain_lds_bytes(int Dp) { return Dp == 16 ? CLay<16>::END * 4 : Dp == 32 ? CLay<32>::END * 4 : CLay<64>::END * 4; }
+
+// element (column m, batch row) of a transposed image: 16-byte chunk c of a column's 256 bytes sits at c ^ (m & 15)
+__host__ __device__ __forceinline__ int img_addr(int m, int row) { return m * 64 + ((((row >> 2) ^ m) & 15) << 2) + (row & 3); }
+
+#define MFMA16B(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), (c), 0, 0, 0)
+// the six kept products of an x3 multiply-add, small terms first; W = weight fragment (A operand), X = activation fragment (B)
+#define X3C_MFMA6(W_, X_, C_)                   \
+  C_ = MFMA16B(W_.p[1], X_.p[1], C_);           \
+  C_ = MFMA16B(W_.p[2], X_.p[0], C_);           \
+  C_ = MFMA16B(W_.p[0], X_.p[2], C_);           \
+  C_ = MFMA16B(W_.p[1], X_.p[0], C_);           \
+  C_ = MFMA16B(W_.p[0], X_.p[1], C_);           \
+  C_ = MFMA16B(W_.p[0], X_.p[0], C_);
+
+// LDS-DMA of 1 KB: lane l's 16 bytes at sbase + voff land at LDS byte address lds_byte + 16 l.  Issued as inline asm: the
+// compiler knows nothing of it (no conservative vmcnt(0) in front of every ring read); the ring protocol below waits by hand.
+__device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds_byte) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+// one ring unit: the three pieces of one A fragment, 3 KB contiguous in the pack
+__device__ __forceinline__ void dma_unit(const u32x4* src, int slot, unsigned lane16, int ring_f0) {
+  const unsigned dst = (unsigned)(ring_f0 + slot * CUNIT) * 4u;
+  dma16(src, lane16, dst);
+  dma16(src, lane16 + 1024u, dst + 1024u);
+  dma16(src, lane16 + 2048u, dst + 2048u);
+}
+__device__ __forceinline__ X3Frag ring_read(int ring_lane_f0, int slot) {  // ring_lane_f0 = RING + 4 lane (opaque per-lane base)
+  X3Frag f;
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc) f.p[pc] = *reinterpret_cast<const u32x4*>(&lds[ring_lane_f0 + slot * CUNIT + 256 * pc]);
+  return f;
+}
+// A segment boundary of the weight ring, in front of the reads of segment Q (of NS segments of this stream): this wave's DMAs
+// of segment Q have landed (the six of segment Q + 1 may still be in flight), its reads of segment Q - 1 are complete; after
+// the barrier that holds for every wave, so segment Q may be read and segment Q - 1's slots refilled with segment Q + 2.
+#ifdef MOBROB_CHAIN_VMCNT0   // validation builds: never rely on the count of DMAs in flight
+#define CHAIN_WAIT_DMA(more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define CHAIN_WAIT_DMA(more) \
+  if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+#define CHAIN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// eight float32 values of one lane -> B fragment (three pieces); element j = v[j]
+__device__ __forceinline__ X3Frag x3_split8v(const float (&v)[8]) {
+  X3Frag f;
+  unsigned p1, p2, p3;
+#pragma unroll
+  for (int jp = 0; jp < 4; ++jp) {
+    x3_split2(v[2 * jp], v[2 * jp + 1], p1, p2, p3);
+    f.p[0][jp] = p1; f.p[1][jp] = p2; f.p[2][jp] = p3;
+  }
+  return f;
+}
+
+// eight consecutive batch rows of one image column: two 16-byte chunks whose addresses differ in one XOR bit
+__device__ __forceinline__ ColFrag img_frag_load(int a0) {
+  ColFrag f;
+  const f32x4 lo = *reinterpret_cast<const f32x4*>(&lds[a0]);
+  const f32x4 hi = *reinterpret_cast<const f32x4*>(&lds[a0 ^ 4]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.v[j] = lo[j]; f.v[4 + j] = hi[j]; }
+  return f;
+}
+
+struct ChainTrainArgs {
+  FusedTrainArgs f;   // everything k_fused_train takes (net[].W*c: the chain packs)
+};
+
+template <int DP>
+__global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
+  using L = CLay<DP>;
+  constexpr int K1 = (DP + 31) / 32;       // k steps of layer 1 (32 observation columns each; DP = 16 pads half a step)
+  constexpr int NU1 = 16 * K1;             // ring units of layer 1, then 128 of layer 2
+  constexpr int NUF = NU1 + 128, NSF = NUF / CSEG;   // the forward stream
+  constexpr int NUB = 128, NSB = NUB / CSEG;          // the dh1 stream
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int nwg = gridDim.x >> 1;
+  int net, wg;
+  {  // blockIdx -> (network, tile sequence): as k_fused_train (policy / value workgroups of a tile sequence share an XCD)
+    const int b = blockIdx.x, g16 = b >> 4, o = b & 15;
+    const int gsz = min(16, (int)gridDim.x - 16 * g16), half = gsz >> 1;
+    net = o >= half ? 1 : 0;
+    wg = 8 * g16 + (o - net * half);
+  }
+  const int slab_id = 2 * wg + net;
+  const FusedNet W = a.net[net];
+  const int ntiles = (a.count + CR - 1) / CR;
+
+  f32x16 gW2[16];   // dW2: this wave's 64 neurons x 256 inputs, pinned in the AGPRs for the whole launch ("+a" statements only)
+#pragma unroll
+  for (int t = 0; t < 16; ++t) gW2[t] = zero16();
+  f32x4 gW3h0 = {0.f, 0.f, 0.f, 0.f}, gW3h1 = gW3h0, gW3h2 = gW3h0, gW3h3 = gW3h0;   // dW3: [16][this wave's 64 columns]
+  float* slab = a.slabs + (size_t)slab_id * a.slab_floats;
+  float* slab_w1 = slab + slab_off_w1();
+  float* slab_w3 = slab + slab_off_w3(DP);
+  float gb2 = 0.f, gb1 = 0.f;
+  float s_pl = 0.f, s_vl = 0.f, s_kl = 0.f, s_cf = 0.f;
+  float g_b3[4] = {0.f, 0.f, 0.f, 0.f}, g_ls[4] = {0.f, 0.f, 0.f, 0.f};   // head-bias / log_std gradient of action 4 g + i: this lane's rows
+
+  if (tid0 < 32) {
+    const int k = tid0;
+    float iv = 0.f, lc = 0.f, bb = 0.f;
+    if (net == 0 && k < a.A) {
+      const float sd = expf(a.log_std[k]);
+      iv = 1.0f / (sd * sd);
+      lc = logf(sd) + 0.91893853320467274178f;
+    }
+    if (k < W.head) bb = W.b3[k];
+    lds[L::CST + k] = iv;
+    lds[L::CST + 32 + k] = lc;
+    lds[L::CST + 64 + k] = bb;
+  }
+  lds[L::B1 + tid0] = W.b1s[tid0];
+  lds[L::B2 + tid0] = W.b2s[tid0];
+
+  float adv_mean = 0.f, adv_sd = 1.f;
+  bool adv_on = false;
+  {
+    const double n = a.advstat[2];
+    adv_on = n > 1.0;
+    const double m = a.advstat[0] / (n > 0 ? n : 1.0);
+    double var = adv_on ? (a.advstat[1] - n * m * m) / (n - 1.0) : 0.0;
+    if (var < 0.0) var = 0.0;
+    adv_mean = (float)m;
+    adv_sd = (float)sqrt(var);
+  }
+
+  // ---- operands of the tile about to be processed, fetched one tile ahead: this lane's batch row (16 wave + lane & 15), the
+  //      eight observation columns 32 s + 8 g .. + 7 of each layer-1 k step, its four actions 4 g .. 4 g + 3 and the record tail
+  f32x4 xr[2 * K1];
+  f32x4 l_act = {0.f, 0.f, 0.f, 0.f}, l_tail = {0.f, 0.f, 0.f, 0.f};
+  auto gather_tile = [&](int src_or_neg, int g_) {
+    const bool live = src_or_neg >= 0;
+    const unsigned src = live ? (unsigned)src_or_neg : 0u;
+#pragma unroll
+    for (int s = 0; s < K1; ++s) {
+      xr[2 * s] = f32x4{0.f, 0.f, 0.f, 0.f};
+      xr[2 * s + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (live && 32 * s + 8 * g_ < DP) {
+        xr[2 * s] = ldg16(a.obs, src * (unsigned)(DP * 4) + (unsigned)((32 * s + 8 * g_) * 4));
+        xr[2 * s + 1] = ldg16(a.obs, src * (unsigned)(DP * 4) + (unsigned)((32 * s + 8 * g_ + 4) * 4));
+      }
+    }
+    l_act = f32x4{0.f, 0.f, 0.f, 0.f};
+    l_tail = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      if (net == 0) l_act = ldg16(a.rec, (src * (unsigned)a.RW + (unsigned)(4 * g_)) * 4u);
+      l_tail = ldg16(a.rec, (src * (unsigned)a.RW + (unsigned)(a.RW - 4)) * 4u);   // old log-prob, advantage, return, old value
+    }
+  };
+  {
+    const int row = wg * CR + 16 * wave + (tid0 & 15);
+    gather_tile((wg < ntiles && row < a.count) ? a.rows[row] : -1, (tid0 & 63) >> 4);
+  }
+  __syncthreads();   // constants and bias tables
+
+  bool first_tile = true;
+  for (int tile = wg; tile < ntiles; tile += nwg) {
+    const int tid = opaque(tid0), lane = tid & 63;
+    const int brow = lane & 15, g = lane >> 4;
+    const int trow = 16 * wave + brow;                 // row of the tile
+    const bool live = tile * CR + trow < a.count;
+    const unsigned lane16 = opaque_u((unsigned)lane * 16u);
+    const int ringl = opaque(L::RING + 4 * lane);
+    const int nrow0 = (tile + nwg) * CR;
+    const bool has_next = tile + nwg < ntiles;
+
+    // ---- X: float32 image for dW1 (column-major, rows contiguous) and the layer-1 B fragments (split once) ----
+    X3Frag xp[K1];
+#pragma unroll
+    for (int s = 0; s < K1; ++s) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = xr[2 * s][j]; v[4 + j] = xr[2 * s + 1][j]; }
+      if (32 * s + 8 * g < DP) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lds[L::XI + img_addr(32 * s + 8 * g + j, trow)] = v[j];
+      }
+      xp[s] = x3_split8v(v);
+    }
+
+    // ============================ forward: layer 1 and layer 2 as ONE stream of ring units ============================
+    // unit u < NU1: layer 1, k step u / 16, neuron tile u % 16 (pack W1c); then layer 2 likewise (pack W2c)
+    auto fwd_issue = [&](int q) {   // DMAs of segment q: this wave moves units 8 q + wave and 8 q + 4 + wave
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int u = CSEG * q + 4 * hh + wave;
+        const u32x4* src = (CSEG * q < NU1) ? W.W1c + (size_t)u * 192 : W.W2c + (size_t)(u - NU1) * 192;
+        dma_unit(src, (CSEG * q + 4 * hh) % CSLOTS + wave, lane16, L::RING);
+      }
+    };
+    f32x4 acc1[16], acc2[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      acc1[t] = *reinterpret_cast<const f32x4*>(&lds[L::B1 + 16 * t + 4 * g]);
+      acc2[t] = *reinterpret_cast<const f32x4*>(&lds[L::B2 + 16 * t + 4 * g]);
+    }
+    fwd_issue(0);
+    fwd_issue(1);
+    CHAIN_WAIT_DMA(true);
+    CHAIN_BARRIER();       // also: the previous tile's last reads of the images / ring are complete everywhere
+    fwd_issue(2);
+    X3Frag Wc = ring_read(ringl, 0), Wn;
+    X3Frag Bc, Bn;         // B fragment of the current / next layer-2 k step
+    float hv[8];           // activations of the k step being prepared
+#pragma unroll
+    for (int u = 0; u < NUF; ++u) {
+      __builtin_amdgcn_sched_barrier(0);
+      if ((u + 1) % CSEG == 0 && u + 1 < NUF) {
+        constexpr int dummy = 0; (void)dummy;
+        const int q = (u + 1) / CSEG;
+        CHAIN_WAIT_DMA(q + 1 < NSF);
+        CHAIN_BARRIER();
+        if (q + 2 < NSF) fwd_issue(q + 2);
+      }
+      if (u + 1 < NUF) Wn = ring_read(ringl, (u + 1) % CSLOTS);
+      const int t = u % 16;
+      if (u < NU1) {
+        X3C_MFMA6(Wc, xp[u / 16], acc1[t])
+      } else {
+        X3C_MFMA6(Wc, Bc, acc2[t])
+      }
+      // side work under the MFMAs: the B fragment of the NEXT layer-2 k step sn from tiles 2 sn, 2 sn + 1 of layer 1 -- tanh,
+      // image store (the float32 h1 that dW2 and the dz1 epilogue read), split -- in sixteen slices, one per unit
+      const int sn = u < NU1 - 16 ? -1 : (u - (NU1 - 16)) / 16;   // prepared during the last step of layer 1 and steps 0 .. 6 of layer 2
+      if (sn >= 0 && sn < 8) {
+        if (t >= 2 && t < 10) {          // tiles 2 sn, 2 sn + 1 of layer 1 are complete from unit NU1 - 16 + 1 on
+          const int e = t - 2;
+          const float h = fast_tanh_scaled(acc1[2 * sn + (e >> 2)][e & 3]);
+          hv[e] = h;
+          lds[L::H1 + img_addr(16 * (2 * sn + (e >> 2)) + 4 * g + (e & 3), trow)] = h;
+        } else if (t >= 10 && t < 14) {
+          const int jp = t - 10;
+          unsigned p1, p2, p3;
+          x3_split2(hv[2 * jp], hv[2 * jp + 1], p1, p2, p3);
+          Bn.p[0][jp] = p1; Bn.p[1][jp] = p2; Bn.p[2][jp] = p3;
+        }
+      }
+      if (t == 15) Bc = Bn;
+      Wc = Wn;
+    }
+    // every wave is done with the ring: its space beyond the first four units becomes the h2 image
+    CHAIN_BARRIER();
+
+    // ============================ h2 = tanh, head (float32 16x16x4), loss, dout ============================
+    f32x4 mean = {0.f, 0.f, 0.f, 0.f};
+    {
+      const f32x4* hp = W.W3c + lane;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const f32x4 wv = hp[64 * t];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float h = fast_tanh_scaled(acc2[t][i]);
+          acc2[t][i] = h;
+          lds[L::H2 + img_addr(16 * t + 4 * g + i, trow)] = h;
+          mean = MFMA16(wv[i], h, mean);
+        }
+      }
+    }
+    f32x4 dout = {0.f, 0.f, 0.f, 0.f};
+    {
+      const f32x4 ivv = *reinterpret_cast<const f32x4*>(&lds[L::CST + 4 * g]);
+      const f32x4 lcv = *reinterpret_cast<const f32x4*>(&lds[L::CST + 32 + 4 * g]);
+      const f32x4 b3v = *reinterpret_cast<const f32x4*>(&lds[L::CST + 64 + 4 * g]);
+      if (net == 0) {
+        float lp = 0.f, d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          d[i] = 0.f;
+          if (4 * g + i < a.A && live) {
+            d[i] = l_act[i] - (mean[i] + b3v[i]);
+            lp += -(d[i] * d[i]) * (0.5f * ivv[i]) - lcv[i];
+          }
+        }
+        lp += xor_lane(lp, 16);
+        lp += xor_lane(lp, 32);
+        float g_logp = 0.f;
+        if (live) {
+          float adv = l_tail[1];
+          if (a.normalize && adv_on) adv = (adv - adv_mean) / (adv_sd + 1e-8f);
+          const float log_ratio = lp - l_tail[0];
+          const float ratio = expf(log_ratio);
+          const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
+          const float s1 = adv * ratio, s2 = adv * fminf(fmaxf(ratio, lo), hi);
+          if (g == 0) {
+            s_pl += fminf(s1, s2);
+            s_cf += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
+            s_kl += (ratio - 1.0f) - log_ratio;
+          }
+          const float in_range = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+          const float w1 = (s1 < s2) ? 1.f : ((s1 > s2) ? 0.f : 0.5f);
+          g_logp = -(w1 * adv + (1.0f - w1) * adv * in_range) * a.inv_bg * ratio;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          dout[i] = g_logp * d[i] * ivv[i];   // zero beyond the head (d = 0, 1/var = 0)
+          g_b3[i] += dout[i];
+          g_ls[i] += (4 * g + i < a.A) ? g_logp * (d[i] * d[i] * ivv[i] - 1.0f) : 0.f;
+        }
+      } else {
+        if (live && g == 0) {
+          float sq, gv_;
+          value_loss_terms(mean[0] + b3v[0], l_tail[2], a.clip_vf >= 0.f ? l_tail[3] : 0.f, a.clip_vf, sq, gv_);
+          s_vl += sq;
+          dout[0] = a.vf_coef * gv_ * a.inv_bg;
+          g_b3[0] += dout[0];
+        }
+      }
+      *reinterpret_cast<f32x4*>(&lds[L::DO + trow * 16 + 4 * g]) = dout;   // dout image [64 rows][16]
+    }
+    // dh2 = W3^T dout (float32 16x16x4: k slot g of step i = head row 4 g + i), dz2 = dh2 (1 - h2^2): in registers
+    {
+      const f32x4* bp = W.W3bc + lane;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const f32x4 wv = bp[64 * t];
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c = MFMA16(wv[i], dout[i], c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc2[t][i] = c[i] * (1.0f - acc2[t][i] * acc2[t][i]);
+      }
+    }
+    __syncthreads();   // h2 image and dout image complete
+
+    // ============================ dW3 += dout^T . h2 (float32 16x16x4; this wave's 64 columns) ============================
+    {
+      const int i16 = lane & 15, kk = lane >> 4;
+      const int ao = opaque(L::DO + kk * 16 + i16);                       // A[a][k = row] = dout[row][a]
+      int bo[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bo[b] = opaque(L::H2 + (64 * wave + 16 * b + i16) * 64 + kk);   // B[k = row][column]; chunk: below
+      const int sw = i16;   // (column & 15): the swizzle of this lane's four columns (they differ by multiples of 16)
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {   // batch rows 4 s .. 4 s + 3: chunk s of the column
+        const float x = lds[ao + 64 * s];
+        const int ch = ((s ^ sw) & 15) << 2;
+        const float y0 = lds[bo[0] + ch], y1 = lds[bo[1] + ch], y2 = lds[bo[2] + ch], y3 = lds[bo[3] + ch];
+        mfma16_x1y4(gW3h0, gW3h1, gW3h2, gW3h3, x, y0, y1, y2, y3);
+      }
+    }
+    __syncthreads();   // the h2 image has been read: dz2 overwrites it
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lds[L::H2 + img_addr(16 * t + 4 * g + i, trow)] = acc2[t][i];
+    __syncthreads();   // dz2 image complete
+
+    // ============================ dW2 += dz2^T . h1 (bf16 pipe, K = 64 rows; this wave: 64 neurons x 256 inputs) ============================
+    int nsrc = -1;
+    {
+      const int r = lane & 31, h = lane >> 5;
+      // a lane's fragment: rows 16 ks + 8 h .. + 7 of one column = chunks 4 ks + 2 h, + 1 (the second = the first ^ 1)
+      const int ao = opaque(L::H2 + (64 * wave + r) * 64 + ((((2 * h) ^ r) & 15) << 2));
+      const int bo = opaque(L::H1 + r * 64 + ((((2 * h) ^ r) & 15) << 2));
+      const int co = opaque(L::H2 + tid * 64);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      nsrc = (has_next && nrow0 + trow < a.count) ? a.rows[nrow0 + trow] : -1;   // level 1 of the next tile's gathers
+#pragma unroll 1
+      for (int ks = 0; ks < CR / 16; ++ks) {
+        const int kx = ks << 4;   // chunk bits 2..3 of the address
+        const X3Frag A0 = col_frag_split(img_frag_load(ao ^ kx)), A1 = col_frag_split(img_frag_load((ao + 32 * 64) ^ kx));
+        {  // db2: column `tid` of dz2 over these sixteen rows (four chunks), rows = 0..3 (mod 4) -> s0..s3
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[co + ((((4 * ks + c) ^ tid) & 15) << 2)]);
+            s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+          }
+        }
+        X3Frag B = col_frag_split(img_frag_load(bo ^ kx));
+        ColFrag raw = img_frag_load((bo + 32 * 64) ^ kx);
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+          X3Frag Bn2;
+          __builtin_amdgcn_sched_barrier(0);
+          const ColFrag raw2 = img_frag_load((bo + 32 * 64 * (jb + 2 < 8 ? jb + 2 : 7)) ^ kx);
+          dw2_x3_block(gW2[jb], gW2[8 + jb], A0, A1, B, raw, Bn2);
+          B = Bn2;
+          raw = raw2;
+        }
+        if (ks == 1) gather_tile(nsrc, g);   // level 2: the next tile's rows, in flight under the rest of this phase
+      }
+      gb2 += (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();   // the dz2 image has been read: its space is ring again
+
+    // ============================ dh1 = W2^T dz2 (chain; B fragments from the dz2 registers), dz1 = dh1 (1 - h1^2) ============================
+    auto bwd_issue = [&](int q) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int u = CSEG * q + 4 * hh + wave;
+        dma_unit(W.W2bc + (size_t)u * 192, (CSEG * q + 4 * hh) % CSLOTS + wave, lane16, L::RING);
+      }
+    };
+    {
+      f32x4 acc4[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bwd_issue(0);
+      bwd_issue(1);
+      {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = acc2[j >> 2][j & 3];
+        Bc = x3_split8v(v);
+      }
+      CHAIN_WAIT_DMA(true);
+      CHAIN_BARRIER();
+      bwd_issue(2);
+      Wc = ring_read(ringl, 0);
+#pragma unroll
+      for (int u = 0; u < NUB; ++u) {
+        __builtin_amdgcn_sched_barrier(0);
+        if ((u + 1) % CSEG == 0 && u + 1 < NUB) {
+          const int q = (u + 1) / CSEG;
+          CHAIN_WAIT_DMA(q + 1 < NSB);
+          CHAIN_BARRIER();
+          if (q + 2 < NSB) bwd_issue(q + 2);
+        }
+        if (u + 1 < NUB) Wn = ring_read(ringl, (u + 1) % CSLOTS);
+        const int t = u % 16, s = u / 16;
+        X3C_MFMA6(Wc, Bc, acc4[t])
+        if (s + 1 < 8 && t >= 10 && t < 14) {   // the next k step's B fragment: dz2 tiles 2 (s + 1), 2 (s + 1) + 1
+          const int jp = t - 10, e0 = 2 * jp, e1 = 2 * jp + 1;
+          unsigned p1, p2, p3;
+          x3_split2(acc2[2 * (s + 1) + (e0 >> 2)][e0 & 3], acc2[2 * (s + 1) + (e1 >> 2)][e1 & 3], p1, p2, p3);
+          Bn.p[0][jp] = p1; Bn.p[1][jp] = p2; Bn.p[2][jp] = p3;
+        }
+        if (t == 15) Bc = Bn;
+        Wc = Wn;
+      }
+      // dz1 over h1, in place (every lane rewrites exactly the elements it wrote in the forward pass; dW2's reads of the h1
+      // image are complete everywhere: all waves have passed the ring barriers of this phase)
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int o = L::H1 + img_addr(16 * t + 4 * g + i, trow);
+          const float h = lds[o];
+          lds[o] = acc4[t][i] * (1.0f - h * h);
+        }
+    }
+    __syncthreads();   // dz1 image complete (and every wave is done with the ring)
+
+    // ============================ dW1 += dz1^T . X (bf16 pipe; this wave: 64 neurons x DP inputs), added to the slab ============================
+    {
+      constexpr bool two = DP > 32;
+      const int r = lane & 31, h = lane >> 5;
+      const int ao = opaque(L::H1 + (64 * wave + r) * 64 + ((((2 * h) ^ r) & 15) << 2));
+      const int c0 = (r < DP) ? r : 0;
+      const int c1 = (32 + r < DP) ? 32 + r : c0;   // clamped columns are never read back
+      const int b0o = opaque(L::XI + c0 * 64 + ((((2 * h) ^ c0) & 15) << 2)), b1o = opaque(L::XI + c1 * 64 + ((((2 * h) ^ c1) & 15) << 2));
+      const int co = opaque(L::H1 + tid * 64);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      f32x16 gW1a = zero16(), gW1b = zero16(), gW1c = zero16(), gW1d = zero16();   // [ib][jb] = 00, 10, 01, 11
+#pragma unroll 1
+      for (int ks = 0; ks < CR / 16; ++ks) {
+        const int kx = ks << 4;
+        const X3Frag A0 = col_frag_split(img_frag_load(ao ^ kx)), A1 = col_frag_split(img_frag_load((ao + 32 * 64) ^ kx));
+        const X3Frag B0 = col_frag_split(img_frag_load(b0o ^ kx));
+        X3Frag B1 = B0;
+        if (two) B1 = col_frag_split(img_frag_load(b1o ^ kx));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[co + ((((4 * ks + c) ^ tid) & 15) << 2)]);
+          s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+        }
+        asm volatile("s_nop 1");
+        if (two) {
+          DW1X_MFMA4(1, 1); DW1X_MFMA4(0, 2); DW1X_MFMA4(2, 0); DW1X_MFMA4(0, 1); DW1X_MFMA4(1, 0); DW1X_MFMA4(0, 0);
+        } else {
+          DW1X_MFMA2(1, 1); DW1X_MFMA2(0, 2); DW1X_MFMA2(2, 0); DW1X_MFMA2(0, 1); DW1X_MFMA2(1, 0); DW1X_MFMA2(0, 0);
+        }
+      }
+      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(gW1a), "+v"(gW1b), "+v"(gW1c), "+v"(gW1d));   // opaque MFMA statements: XDL write -> VALU read
+      gb1 += (s0 + s1) + (s2 + s3);
+      // slab += tile (fragment order [w][tile][quad][lane] x 16 B, as k_fused_train stores it); the first tile stores
+      const unsigned sb = (unsigned)(wave * 4 * 4 * 64 + lane) * 16u;
+      auto rmw = [&](const f32x16& gacc, int tile_idx) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          f32x4 v = {gacc[4 * qd], gacc[4 * qd + 1], gacc[4 * qd + 2], gacc[4 * qd + 3]};
+          const unsigned off = sb + (unsigned)(tile_idx * 4 + qd) * 1024u;
+          if (!first_tile) {
+            const f32x4 o = ldg16(slab_w1, off);
+            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+          }
+          stg16(slab_w1, off, v);
+        }
+      };
+      rmw(gW1a, 0);
+      rmw(gW1b, 2);
+      if (two) { rmw(gW1c, 1); rmw(gW1d, 3); }
+    }
+    first_tile = false;
+    __syncthreads();   // images are rewritten by the next tile
+  }
+
+  const int tid = tid0, lane = tid & 63;
+  // ---- store this workgroup's partial gradients to its slab (k_fused_train's layout) ----
+  asm volatile("s_nop 15\n\ts_nop 3");
+  if (first_tile) {   // a workgroup without tiles: its dW1 region was never written
+    const unsigned sb = (unsigned)(wave * 4 * 4 * 64 + lane) * 16u;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) stg16(slab_w1, sb + (unsigned)k * 1024u, z);
+  }
+  {
+    const unsigned sh = (unsigned)(wave * 4 * 64 + lane) * 16u;
+    stg16(slab_w3, sh, gW3h0);
+    stg16(slab_w3, sh + 1024u, gW3h1);
+    stg16(slab_w3, sh + 2048u, gW3h2);
+    stg16(slab_w3, sh + 3072u, gW3h3);
+  }
+  float* w2base = slab + slab_off_w2();
+  const unsigned s2 = (unsigned)(wave * 16 * 4 * 64 + lane) * 16u;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gW2[t][4 * qd + e];
+      stg16(w2base, s2 + (unsigned)(t * 4 + qd) * 1024u, v);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  slab[slab_off_b2(DP) + tid] = gb2;
+  slab[slab_off_b1(DP) + tid] = gb1;
+  {  // head-bias / log_std gradients: this lane's rows -> the wave's 16 rows (lanes of a group) -> the four waves, fixed order
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        g_b3[i] += xor_lane(g_b3[i], o);
+        g_ls[i] += xor_lane(g_ls[i], o);
+      }
+    }
+    if ((lane & 15) == 0) {
+      const int g = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        lds[L::GACC + wave * 32 + 4 * g + i] = g_b3[i];
+        lds[L::GACC + wave * 32 + 16 + 4 * g + i] = g_ls[i];
+      }
+    }
+    const float t0 = wave_sum(s_pl), t1 = wave_sum(s_vl), t2 = wave_sum(s_kl), t3 = wave_sum(s_cf);
+    if (lane == 0) {
+      lds[L::STAT + wave * 4 + 0] = t0;
+      lds[L::STAT + wave * 4 + 1] = t1;
+      lds[L::STAT + wave * 4 + 2] = t2;
+      lds[L::STAT + wave * 4 + 3] = t3;
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float b3s = 0.f, lss = 0.f;
+      if (tid < 16) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          b3s += lds[L::GACC + w * 32 + tid];
+          lss += lds[L::GACC + w * 32 + 16 + tid];
+        }
+      }
+      slab[slab_off_b3(DP) + tid] = b3s;
+      slab[slab_off_ls(DP) + tid] = lss;
+    }
+    if (tid < 4)
+      slab[slab_off_st(DP) + tid] = (lds[L::STAT + tid] + lds[L::STAT + 4 + tid]) + (lds[L::STAT + 8 + tid] + lds[L::STAT + 12 + tid]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Chain packs (layouts: tests/chain_model.py).  k slot (lane group g, element j) of k step s carries
+//   layer 1: observation column 32 s + 8 g + j                      (natural order)
+//   layer 2 / dh1: neuron 32 s + 16 (j >> 2) + 4 g + (j & 3)        (the order accumulator tiles hand their rows over in)
+// x3 pack element: [k step s][neuron tile t][piece 3][lane 64][8 bf16], lane = (row & 15) + 16 g.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int chain_kslot_of_neuron(int n, int* s, int* g, int* j) {   // inverse of the layer-2 map
+  *s = n >> 5;
+  const int r = n & 31;
+  *g = (r >> 2) & 3;
+  *j = ((r >> 4) << 2) | (r & 3);
+  return 0;
+}
+// bf16 index (in units of 2 bytes) of piece 0 of A[row][k slot (s, g, j)] in a chain pack; pieces 1, 2 follow at + 512, + 1024
+__host__ __device__ __forceinline__ size_t chain_pack_idx(int row, int s, int g, int j) {
+  return ((size_t)(s * 16 + (row >> 4)) * 3) * 512 + (size_t)((row & 15) + 16 * g) * 8 + j;
+}
+__device__ __forceinline__ void chain_pack_store(unsigned short* out, size_t base, float x) {
+  asm volatile("" : "+v"(x));   // split the ROUNDED product (see x3_pack_store)
+  unsigned p1, p2, p3;
+  x3_split2(x, 0.f, p1, p2, p3);
+  out[base] = (unsigned short)(p1 & 0xffffu);
+  out[base + 512] = (unsigned short)(p2 & 0xffffu);
+  out[base + 1024] = (unsigned short)(p3 & 0xffffu);
+}
+// element (neuron n, input k) of W1 [H][D] / W2 [H][H] -> its places in the chain packs
+__device__ __forceinline__ void chain_store_w1(unsigned short* w1c, int n, int k, float scaled) {
+  chain_pack_store(w1c, chain_pack_idx(n, k >> 5, (k >> 3) & 3, k & 7), scaled);
+}
+__device__ __forceinline__ void chain_store_w2(unsigned short* w2c, unsigned short* w2bc, int n, int k, float scaled, float raw) {
+  int s, g, j;
+  chain_kslot_of_neuron(k, &s, &g, &j);           // forward: A[row = n][k slot of input neuron k]
+  chain_pack_store(w2c, chain_pack_idx(n, s, g, j), scaled);
+  chain_kslot_of_neuron(n, &s, &g, &j);           // dh1: A[row = k (input neuron)][k slot of output neuron n] = W2[n][k]
+  chain_pack_store(w2bc, chain_pack_idx(k, s, g, j), raw);
+}
+// head [A <= 16][H]: forward pack [t][lane][i] = W3[lane & 15][16 t + 4 (lane >> 4) + i]; dh2 pack [t][lane][i] = W3[4 (lane >> 4) + i][16 t + (lane & 15)]
+__host__ __device__ __forceinline__ int chain_head_fwd_idx(int a_, int k) { return ((k >> 4) * 64 + a_ + 16 * ((k >> 2) & 3)) * 4 + (k & 3); }
+__host__ __device__ __forceinline__ int chain_head_bwd_idx(int a_, int k) { return ((k >> 4) * 64 + (k & 15) + 16 * (a_ >> 2)) * 4 + (a_ & 3); }
+
+// rebuild every chain pack of both networks from the canonical parameters (set_params; k_adam_pack keeps them current per step)
+struct ChainPackArgs {
+  const float* W1[2]; const float* W2[2]; const float* W3[2];
+  unsigned short* w1c[2]; unsigned short* w2c[2]; unsigned short* w2bc[2]; float* w3c[2]; float* w3bc[2];
+  int D, Dp, head[2];
+};
+__global__ __launch_bounds__(256) void k_pack_chain(ChainPackArgs a) {
+  const int net = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int K1 = (a.Dp + 31) / 32;
+  if (i < FH * FH) {
+    const int n = i / FH, k = i - n * FH;
+    const float w = a.W2[net][i];
+    chain_store_w2(a.w2c[net], a.w2bc[net], n, k, kTanhScale * w, w);
+  }
+  if (i < FH * 32 * K1) {   // every k slot of the layer-1 pack, padding included
+    const int n = i / (32 * K1), k = i - n * (32 * K1);
+    chain_store_w1(a.w1c[net], n, k, k < a.D ? kTanhScale * a.W1[net][n * a.D + k] : 0.f);
+  }
+  if (i < 16 * FH) {
+    const int a_ = i / FH, k = i - a_ * FH;
+    const float w = a_ < a.head[net] ? a.W3[net][a_ * FH + k] : 0.f;
+    a.w3c[net][chain_head_fwd_idx(a_, k)] = w;
+    a.w3bc[net][chain_head_bwd_idx(a_, k)] = w;
+  }
+}
+
+}  // namespace mobrob

@@ -132,14 +132,15 @@ def _device_perm_key(seed, draw, rank=0):
     return ((seed * GOLDEN_RATIO) & (2 ** 64 - 1)) ^ ((rank + 1) << 48) ^ (draw + 1)
 
 
-def _bench_like_engine(D, A, H, n_envs, T, B, seed, rng):
+def _bench_like_engine(D, A, H, n_envs, T, B, seed, rng, clip_range=0.2):
     """Engine + oracle state set up the way bench.py leaves them after a rollout, with two changes that make the
     comparison bite: stored log-probs are perturbed so the ratios straddle the clip range (an on-policy first
     minibatch has ratio == 1 in every row), and the optimizer starts from a non-zero Adam state."""
     from mobrob_amd.engine import PPOEngine
-    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=1, batch_size=B, learning_rate=3e-4)
+    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=1, batch_size=B, learning_rate=3e-4, clip_range=clip_range)
     e = PPOEngine(obs_dim=D, act_dim=A, n_envs=n_envs, n_steps=T, batch_size=B, n_epochs=1, pi=(H, H), vf=(H, H),
-                  gamma=h.gamma, gae_lambda=h.gae_lambda, ent_coef=h.ent_coef, learning_rate=h.learning_rate, seed=seed)
+                  gamma=h.gamma, gae_lambda=h.gae_lambda, ent_coef=h.ent_coef, learning_rate=h.learning_rate,
+                  clip_range=clip_range, seed=seed)
     p = O.init_params(D, A, (H, H), (H, H), seed=seed)
     p["log_std"] = rng.normal(-0.3, 0.2, A).astype(np.float32)
     p["action_net.weight"] *= 30
@@ -229,19 +230,26 @@ def test_benchmarked_minibatch_matches_oracle(shape):
     e.close()
 
 
-def run_epoch_against_oracle(shape, seed, rng_seed, band=2e-5, log=print):
-    """One whole epoch of the bench workload through the single C call (`mobrob_ppo_train`: 63 / 32 launches incl. the short
-    last one) on BOTH matrix pipes (x3 kernels and `forward_x3 = 0`; the 64-wide nets have one) against the oracle following
-    every optimizer step in float32 BLAS (SB3-CPU's arithmetic).  Rows whose ratio comes within `band` of a clip boundary at
-    the step that consumes them are moved off it first (tests/util.py::oracle_epoch_off_clip_boundaries: the gradient is
-    discontinuous there, so such a row measures the last bit of a log-prob, not an implementation).
-    -> dict(pipe -> max |parameter - oracle| per tensor), the oracle's per-step stats, the engines' TrainStats, rows moved."""
+def _second_engine(shape, h, seed, B, buf, last_values, last_dones, **kw):
+    """An engine on the same buffers as the one that rolled out (same seed -> the same device-drawn permutations)."""
     from mobrob_amd.engine import PPOEngine
-    from tests.util import oracle_epoch_off_clip_boundaries
+    D, A, H, n_envs, T = (shape[k] for k in "DAHNT")
+    e = PPOEngine(obs_dim=D, act_dim=A, n_envs=n_envs, n_steps=T, batch_size=B, n_epochs=1, pi=(H, H), vf=(H, H),
+                  gamma=h.gamma, gae_lambda=h.gae_lambda, ent_coef=h.ent_coef, learning_rate=h.learning_rate,
+                  clip_range=h.clip_range, seed=seed, **kw)
+    e.load_rollout(buf, last_values, last_dones)
+    return e
+
+
+def run_epoch_free(shape, seed, rng_seed, clip_range):
+    """One whole epoch of the bench workload through the single C call (`mobrob_ppo_train`: 63 / 32 launches incl. the short
+    last one), free running, on BOTH matrix pipes (x3 kernels and `forward_x3 = 0`; the 64-wide nets have one), against the
+    oracle following every optimizer step in float32 BLAS (SB3-CPU's arithmetic).
+    -> ({pipe: {tensor: max |parameter - oracle|}}, the oracle's per-step stats, {pipe: TrainStats})."""
     D, A, H, n_envs, T = (shape[k] for k in "DAHNT")
     B = 65536
     rng = np.random.default_rng(rng_seed)
-    e, p, st, buf, h = _bench_like_engine(D, A, H, n_envs, T, B, seed, rng)
+    e, p, st, buf, h = _bench_like_engine(D, A, H, n_envs, T, B, seed, rng, clip_range=clip_range)
     total = T * n_envs
     nmb = -(-total // B)
     perm = O.feistel_permutation(total, _device_perm_key(seed, 0))
@@ -250,21 +258,17 @@ def run_epoch_against_oracle(shape, seed, rng_seed, band=2e-5, log=print):
     v0 = type(p)((k, v.copy()) for k, v in st.exp_avg_sq.items())
     step0 = st.step
     last_values, last_dones = e.read("last_values"), e.read("last_dones") > 0
-    ostats, moved, passes = oracle_epoch_off_clip_boundaries(p, st, buf, h, perm, band=band, log=log)
+    ostats = O.train(p, st, buf, h, perm[None])
     assert st.step == step0 + nmb
     out, stats = {}, {}
     pipes = ("x3", "f32") if H == 256 else ("f32",)
     for pipe in pipes:
         if pipe == pipes[0]:
-            eng = e                                           # the engine that rolled out: only the moved rows change
-            eng.write("log_probs", buf["log_probs"])
+            eng = e                                           # the engine that rolled out
         else:                                                 # a second engine on the other pipe, same buffers, same seed
-            eng = PPOEngine(obs_dim=D, act_dim=A, n_envs=n_envs, n_steps=T, batch_size=B, n_epochs=1, pi=(H, H), vf=(H, H),
-                            gamma=h.gamma, gae_lambda=h.gae_lambda, ent_coef=h.ent_coef, learning_rate=h.learning_rate,
-                            seed=seed, forward_x3=False)
+            eng = _second_engine(shape, h, seed, B, buf, last_values, last_dones, forward_x3=False)
             eng.set_params(p0)
             eng.set_optimizer_state(m0, v0, step0)
-            eng.load_rollout(buf, last_values, last_dones)
         assert eng.x3_mode() == (3 if pipe == "x3" else 0)
         stats[pipe] = eng.train(None)                         # device-drawn permutation, as in bench.py
         assert stats[pipe]["n_minibatches"] == nmb
@@ -273,25 +277,118 @@ def run_epoch_against_oracle(shape, seed, rng_seed, band=2e-5, log=print):
         assert step == st.step
         out[pipe] = {k: float(np.max(np.abs(newp[k] - p[k]))) for k in p}
         eng.close()
-    return out, ostats, stats, moved, passes
+    return out, ostats, stats
 
 
-@pytest.mark.parametrize("shape,seed,rng_seed", [
-    (dict(name="doggo-4096env-2x256", D=58, A=12, H=256, N=4096, T=1000), 23, 6),
-    (dict(name="doggo-4096env-2x256", D=58, A=12, H=256, N=4096, T=1000), 24, 7),
-    (dict(name="point-1024env-2x64", D=14, A=2, H=64, N=1024, T=2048), 23, 6),
-    (dict(name="point-1024env-2x64", D=14, A=2, H=64, N=1024, T=2048), 24, 7),
-    (dict(name="point-1024env-2x64", D=14, A=2, H=64, N=1024, T=2048), 25, 8)])
-def test_benchmarked_epoch_matches_oracle(shape, seed, rng_seed):
-    """63 (32) dependent optimizer steps move a parameter by up to 0.02; after them every parameter is within 1e-4 (north_star)
-    of the oracle's, on the x3 kernels AND with every product on `v_mfma_f32`.  (More seeds, both pipes, and the margins:
-    scratch/epoch_margin.py -> profiles/r4/epoch_margin.txt.)"""
-    errs, ostats, stats, moved, passes = run_epoch_against_oracle(shape, seed, rng_seed)
-    print(f"{shape['name']} seed {seed}: {len(moved)} row(s) of {shape['N'] * shape['T']} moved off a clip boundary in {passes} oracle pass(es); "
-          + "; ".join(f"{pipe}: worst {max(e.values()):.2e}" for pipe, e in errs.items()))
+SHAPES = [dict(name="doggo-4096env-2x256", D=58, A=12, H=256, N=4096, T=1000),
+          dict(name="point-1024env-2x64", D=14, A=2, H=64, N=1024, T=2048)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: s["name"])
+def test_benchmarked_epoch_step_by_step_matches_oracle(shape):
+    """EVERY optimizer step of an epoch of the bench workload, on both matrix pipes, against the oracle at the north_star
+    bounds: the gradient of the step's 65536-row minibatch (13 tensors <= 1e-4 of scale, six loss scalars), then clip + Adam
+    (parameters <= 1e-5, moments <= 1e-4) -- all 63 (32) steps incl. the short last one, with the clip range at SB3's 0.2.
+
+    The engines are put on the oracle's state before every step (set_params / set_optimizer_state) instead of running free.
+    Why: PPO's clipped surrogate has a gradient that is DISCONTINUOUS in the ratio at 1 +- clip, one row is ~1/sqrt(B) of a
+    minibatch gradient, and an epoch consumes ~300 rows whose ratio lies within 2e-5 of a boundary (measured:
+    profiles/r4/epoch_margin.txt) -- so two correct float32 implementations, e.g. this oracle with float32 and with float64
+    accumulation, leave the same boundary row on different sides sooner or later, after which the trajectories differ by
+    ~1e-4 in the parameters and every later step sees different ratios (the effect compounds: moving the flagged rows off the
+    boundaries moves the later steps' ratios by 1e-6 .. 1e-5 and flags as many new rows).  What CAN be held to 1e-4 / 1e-5 is
+    every step from a common state, with the rows that sit on a boundary AT that state moved off it (<= 16 per step, printed):
+    that is what this test does, 63 times.  The free-running epoch is covered twice below: with the clip range opened (no
+    discontinuity: 1e-4 holds after 63 free steps on both pipes) and at 0.2 with the bound the discontinuity allows."""
+    D, A, H, n_envs, T = (shape[k] for k in "DAHNT")
+    B, seed = 65536, 23
+    rng = np.random.default_rng(6)
+    e, p, st, buf, h = _bench_like_engine(D, A, H, n_envs, T, B, seed, rng)
+    total = T * n_envs
+    nmb = -(-total // B)
+    perm = O.feistel_permutation(total, _device_perm_key(seed, 0))
+    engines = {"x3" if H == 256 else "f32": e}
+    if H == 256:
+        engines["f32"] = _second_engine(shape, h, seed, B, buf, e.read("last_values"), e.read("last_dones") > 0, forward_x3=False)
+        assert engines["x3"].x3_mode() == 3 and engines["f32"].x3_mode() == 0
+    for eng in engines.values():
+        eng.epoch_begin(None)                             # device-drawn permutation, as in bench.py
+    lo, hi = 1.0 - h.clip_range, 1.0 + h.clip_range
+    moved_total, worst_g, worst_p = 0, 0.0, 0.0
+    for mb in range(nmb):
+        idx = perm[mb * B:(mb + 1) * B]
+        stats, og, aux = O.loss_and_grads(p, *O.gather_minibatch(buf, idx), h, acc=np.float64)
+        near = (np.abs(aux["ratio"] - lo) < 2e-5) | (np.abs(aux["ratio"] - hi) < 2e-5)
+        if near.any():
+            assert int(near.sum()) <= 16, f"step {mb}: {int(near.sum())} rows within 2e-5 of a clip boundary -- not a rounding artefact"
+            moved_total += int(near.sum())
+            t, n = O.flat_to_tn(idx[near], T)
+            buf["log_probs"][t, n] -= np.float32(0.01)
+            stats, og, aux = O.loss_and_grads(p, *O.gather_minibatch(buf, idx), h, acc=np.float64)
+        clipped, total_norm = O.clip_grad_norm(og, h.max_grad_norm)
+        p_before = type(p)((k, v.copy()) for k, v in p.items())
+        m_before = type(p)((k, v.copy()) for k, v in st.exp_avg.items())
+        v_before = type(p)((k, v.copy()) for k, v in st.exp_avg_sq.items())
+        step_before = st.step
+        O.adam_step(p, clipped, st, h.learning_rate, h.beta1, h.beta2, h.adam_eps)
+        for pipe, eng in engines.items():
+            tag = f"{shape['name']}/{pipe}/step{mb}"
+            if mb > 0:                                    # common state: the oracle's
+                eng.set_params(p_before)
+                eng.set_optimizer_state(m_before, v_before, step_before)
+            if near.any():
+                eng.write("log_probs", buf["log_probs"])
+            eng.minibatch_grad(mb)
+            got = eng.unflatten(eng.read("grads"))
+            errs = {k: scaled_err(got[k], og[k]) for k in og}
+            worst_g = max(worst_g, max(errs.values()))
+            assert max(errs.values()) < 1e-4, (tag, {k: f"{v:.2e}" for k, v in errs.items()})
+            eng.minibatch_apply()
+            row = eng.fetch_step_stats(1)[0]
+            for i, k in enumerate(STAT_KEYS):
+                ref = float(stats[k])
+                assert abs(float(row[i]) - ref) < 1e-4 * max(1.0, abs(ref)), (tag, k, float(row[i]), ref)
+            assert abs(float(row[6]) - float(total_norm)) < 1e-4 * max(1.0, float(total_norm)), (tag, "grad_norm")
+            newp = eng.get_params()
+            m, v, step = eng.get_optimizer_state()
+            assert step == st.step
+            for k in p:
+                d = float(np.max(np.abs(newp[k] - p[k])))
+                worst_p = max(worst_p, d)
+                assert d < 1e-5, (tag, k, d)
+                assert scaled_err(m[k], st.exp_avg[k]) < 1e-4 and scaled_err(v[k], st.exp_avg_sq[k]) < 1e-4, (tag, k)
+    print(f"{shape['name']}: {nmb} steps x {list(engines)}: worst gradient error {worst_g:.2e} of scale, worst parameter "
+          f"difference after a step {worst_p:.2e}; {moved_total} row(s) of {total} moved off a clip boundary")
+    for eng in engines.values():
+        eng.close()
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: s["name"])
+def test_benchmarked_epoch_free_running_without_the_clip_discontinuity(shape):
+    """63 (32) FREE-RUNNING optimizer steps through `mobrob_ppo_train` with the clip range opened to 1e9 (the surrogate is then
+    smooth: -mean(adv * ratio)): rounding is all that separates the trajectories, and after the whole epoch every parameter is
+    within 1e-4 (north_star) of the oracle's on the x3 kernels AND with every product on `v_mfma_f32`."""
+    errs, ostats, stats = run_epoch_free(shape, 23, 6, clip_range=1e9)
+    print(shape["name"], "; ".join(f"{pipe}: worst {max(e.values()):.2e}" for pipe, e in errs.items()))
     for pipe, e in errs.items():
         for k, v in e.items():
             assert v < 1e-4, (pipe, k, v)
+        for k in STAT_KEYS + ("grad_norm",):
+            ref = float(np.mean([float(s[k]) for s in ostats]))
+            assert abs(stats[pipe][k] - ref) < 2e-4 * max(1.0, abs(ref)), (pipe, k, stats[pipe][k], ref)
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: s["name"])
+def test_benchmarked_epoch_matches_oracle(shape):
+    """The same free-running epoch at SB3's clip range 0.2.  The largest parameter deviation is bimodal in the DATA: 2e-7 ..
+    2e-5 when no row's ratio falls within rounding of a clip boundary in any step, ~2e-4 when one does -- for this engine on
+    either pipe and for the oracle against itself (float32 vs float64 accumulation): profiles/r4/epoch_margin.txt.  5e-4 is
+    the bound the discontinuity allows; the 1e-4 / 1e-5 bounds are enforced step by step above."""
+    errs, ostats, stats = run_epoch_free(shape, 23, 6, clip_range=0.2)
+    print(shape["name"], "; ".join(f"{pipe}: worst {max(e.values()):.2e}" for pipe, e in errs.items()))
+    for pipe, e in errs.items():
+        for k, v in e.items():
+            assert v < 5e-4, (pipe, k, v)
         for k in STAT_KEYS + ("grad_norm",):
             ref = float(np.mean([float(s[k]) for s in ostats]))
             assert abs(stats[pipe][k] - ref) < 2e-4 * max(1.0, abs(ref)), (pipe, k, stats[pipe][k], ref)
