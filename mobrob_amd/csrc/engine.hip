@@ -337,6 +337,20 @@ void pack_x3_all(mobrob_ppo_engine* e) {
     maxthreads = std::max(maxthreads, std::max(a.NB[i1] * a.KS[i1], a.NB[i2] * a.KS[i2]) * 512);
   }
   hipLaunchKernelGGL(k_pack_x3_multi, dim3(cdiv(maxthreads, 256), 6), dim3(256), 0, e->stream, a);
+  if (e->fused.train_chain) {  // chain packs of k_chain_train (kernels_chain.h)
+    ChainPackArgs c{};
+    const int w3[2] = {T_AW, T_VW};
+    for (int n = 0; n < 2; ++n) {
+      c.W1[n] = Pp(e, w1[n]); c.W2[n] = Pp(e, w2[n]); c.W3[n] = Pp(e, w3[n]);
+      c.w1c[n] = reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W1c));
+      c.w2c[n] = reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2c));
+      c.w2bc[n] = reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2bc));
+      c.w3c[n] = const_cast<float*>(e->fused.net[n].W3c); c.w3bc[n] = const_cast<float*>(e->fused.net[n].W3bc);
+      c.head[n] = n == 0 ? e->A : 1;
+    }
+    c.D = e->D; c.Dp = e->Dp;
+    hipLaunchKernelGGL(k_pack_chain, dim3(FH * FH / 256, 2), dim3(256), 0, e->stream, c);
+  }
 }
 
 void repack(mobrob_ppo_engine* e) {
@@ -456,6 +470,7 @@ int fused_init(mobrob_ppo_engine* e) {
     f.net[n].b3 = e->params + e->offs[bias_ids[n][2]];
     f.net[n].head = n == 0 ? e->A : 1;
     f.net[n].W1x = nullptr; f.net[n].W2x = nullptr; f.net[n].W2bx = nullptr;
+    f.net[n].W1c = nullptr; f.net[n].W2c = nullptr; f.net[n].W2bc = nullptr; f.net[n].W3c = nullptr; f.net[n].W3bc = nullptr;
   }
   f.max_grid = 256;
   if (H == 64) {
@@ -481,6 +496,21 @@ int fused_init(mobrob_ppo_engine* e) {
         f.net[n].W2bx = w2b;
       }
       f.train_x3 = e->A <= 16 && e->Dp != 48 && getenv("MOBROB_NO_TRAIN_X3") == nullptr;
+      // the register-chained gradient kernel (kernels_chain.h) takes the same shapes; MOBROB_NO_CHAIN=1 keeps k_fused_train<.., X3>
+      f.train_chain = f.train_x3 && getenv("MOBROB_NO_CHAIN") == nullptr;
+      if (f.train_chain) {
+        const int K1 = (e->Dp + 31) / 32;
+        for (int n = 0; n < 2; ++n) {
+          unsigned* w1 = nullptr; unsigned* w2 = nullptr; unsigned* w2b = nullptr; float* w3 = nullptr; float* w3b = nullptr;
+          CHK(dalloc(e, &w1, (size_t)K1 * 16 * 768));       // [k step][tile 16][3 pieces][64 lanes] x 16 bytes
+          CHK(dalloc(e, &w2, (size_t)8 * 16 * 768));
+          CHK(dalloc(e, &w2b, (size_t)8 * 16 * 768));
+          CHK(dalloc(e, &w3, (size_t)16 * 64 * 4));
+          CHK(dalloc(e, &w3b, (size_t)16 * 64 * 4));
+          f.net[n].W1c = w1; f.net[n].W2c = w2; f.net[n].W2bc = w2b; f.net[n].W3c = w3; f.net[n].W3bc = w3b;
+        }
+        f.lds_chain_bytes = chain_lds_bytes(e->Dp);
+      }
     }
     CHK(dalloc(e, &f.train_rec, (size_t)e->N * e->T * train_rec_width(e->A)));
     f.lds_bytes = fused_lds_bytes(e->Dp);
@@ -1757,6 +1787,12 @@ void fill_adam_pack_args(mobrob_ppo_engine* e, AdamPackArgs& a) {
     a.xW1[n] = x3 ? reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W1x)) : nullptr;
     a.xW2[n] = x3 ? reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2x)) : nullptr;
     a.xW2b[n] = x3 ? reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2bx)) : nullptr;
+    const bool ch = on && e->fused.train_chain;  // likewise the chain packs of k_chain_train
+    a.cW1[n] = ch ? reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W1c)) : nullptr;
+    a.cW2[n] = ch ? reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2c)) : nullptr;
+    a.cW2b[n] = ch ? reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2bc)) : nullptr;
+    a.cW3[n] = ch ? const_cast<float*>(e->fused.net[n].W3c) : nullptr;
+    a.cW3b[n] = ch ? const_cast<float*>(e->fused.net[n].W3bc) : nullptr;
   }
 }
 }  // namespace

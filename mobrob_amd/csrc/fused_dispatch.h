@@ -1,6 +1,7 @@
 // Host-side dispatch of the fused kernel families (hidden width 256: kernels_fused.h, 64: kernels_fused64.h).
 #pragma once
 #include "kernels_fused.h"
+#include "kernels_chain.h"
 #include "kernels_fused64.h"
 #include "kernels_rollout.h"
 #include "kernels_split64.h"
@@ -36,7 +37,9 @@ inline void fused_launch_act(FusedState& f, FusedActArgs& a, hipStream_t st) {
   }
 }
 inline void fused_launch_train(FusedState& f, FusedTrainArgs& a, int grid, hipStream_t st) {
-  if (f.A <= 16 && f.net[0].W2x != nullptr && f.train_x3) {  // forward of the tile on the bf16 pipe (x3 packs maintained per step)
+  if (f.train_chain) {  // the register-chained kernel (kernels_chain.h): chain packs maintained per step
+    FUSED_DISPATCH_DP_X3(f.Dp, hipLaunchKernelGGL((k_chain_train<DPc>), dim3(grid), dim3(FTHREADS), f.lds_chain_bytes, st, a));
+  } else if (f.A <= 16 && f.net[0].W2x != nullptr && f.train_x3) {  // forward of the tile on the bf16 pipe (x3 packs maintained per step)
     FUSED_DISPATCH_DP_X3(f.Dp, hipLaunchKernelGGL((k_fused_train<DPc, true, true>), dim3(grid), dim3(FTHREADS), f.lds_bytes, st, a));
   } else if (f.A <= 16) {  // both heads <= 16 wide: 16x16x4 head / dW3 variant
     FUSED_DISPATCH_DP(f.Dp, hipLaunchKernelGGL((k_fused_train<DPc, true>), dim3(grid), dim3(FTHREADS), f.lds_bytes, st, a));
@@ -85,6 +88,8 @@ inline hipError_t fused_set_lds_attr(FusedState& f) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_train<DPc, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);
       if (e == hipSuccess && f.train_x3)
         FUSED_DISPATCH_DP_X3(f.Dp, e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_train<DPc, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes));
+      if (e == hipSuccess && f.train_chain)
+        FUSED_DISPATCH_DP_X3(f.Dp, e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_train<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_chain_bytes));
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_act<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_act_bytes);
       if (e == hipSuccess)

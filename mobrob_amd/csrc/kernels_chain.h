@@ -26,6 +26,7 @@
 // Same slab format as k_fused_train: k_slab_reduce, the norm records and k_adam_pack are unchanged.
 // Conditions: 256-wide tanh nets, heads <= 16 wide, observation rows padded to 16 / 32 / 64 columns (engine.hip fused_init).
 #pragma once
+#include <type_traits>
 #include "kernels_fused.h"
 
 namespace mobrob {
@@ -98,6 +99,27 @@ __device__ __forceinline__ X3Frag ring_read(int ring_lane_f0, int slot) {  // ri
 #endif
 #define CHAIN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// wave-uniform values re-materialised per tile: without it LICM hoists the ~300 scalar DMA addresses of a tile (all functions
+// of the wave index and the pack pointers) out of the tile loop and parks them in VGPR lanes
+__device__ __forceinline__ int opaque_s(int x) {
+  asm volatile("" : "+s"(x));
+  return x;
+}
+template <class T>
+__device__ __forceinline__ const T* opaque_sp(const T* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// straight-line code for a compile-time range (a `#pragma unroll` loop of this size is refused by the unroller)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 // eight float32 values of one lane -> B fragment (three pieces); element j = v[j]
 __device__ __forceinline__ X3Frag x3_split8v(const float (&v)[8]) {
   X3Frag f;
@@ -120,10 +142,6 @@ __device__ __forceinline__ ColFrag img_frag_load(int a0) {
   return f;
 }
 
-struct ChainTrainArgs {
-  FusedTrainArgs f;   // everything k_fused_train takes (net[].W*c: the chain packs)
-};
-
 template <int DP>
 __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
   using L = CLay<DP>;
@@ -143,6 +161,9 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
   }
   const int slab_id = 2 * wg + net;
   const FusedNet W = a.net[net];
+  const u32x4* W1c = reinterpret_cast<const u32x4*>(W.W1c);
+  const u32x4* W2c = reinterpret_cast<const u32x4*>(W.W2c);
+  const u32x4* W2bc = reinterpret_cast<const u32x4*>(W.W2bc);
   const int ntiles = (a.count + CR - 1) / CR;
 
   f32x16 gW2[16];   // dW2: this wave's 64 neurons x 256 inputs, pinned in the AGPRs for the whole launch ("+a" statements only)
@@ -221,6 +242,10 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
     const bool live = tile * CR + trow < a.count;
     const unsigned lane16 = opaque_u((unsigned)lane * 16u);
     const int ringl = opaque(L::RING + 4 * lane);
+    const int wv = opaque_s(wave);
+    const u32x4* W1c_ = opaque_sp(W1c);
+    const u32x4* W2c_ = opaque_sp(W2c);
+    const u32x4* W2bc_ = opaque_sp(W2bc);
     const int nrow0 = (tile + nwg) * CR;
     const bool has_next = tile + nwg < ntiles;
 
@@ -239,80 +264,97 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
     }
 
     // ============================ forward: layer 1 and layer 2 as ONE stream of ring units ============================
-    // unit u < NU1: layer 1, k step u / 16, neuron tile u % 16 (pack W1c); then layer 2 likewise (pack W2c)
+    // unit u < NU1: layer 1, neuron tile u / K1, k step u % K1 (pack W1c, [tile][k step]: a tile is complete after K1 units, its
+    // tanh goes to the h1 image under the next tile's MFMAs and its accumulator dies -- layer 1 holds four registers, not 64);
+    // then layer 2, k step (u - NU1) / 16, neuron tile (u - NU1) % 16 (pack W2c), whose B fragments are this lane's own eight
+    // elements of the h1 image, read back and split one k step ahead.
     auto fwd_issue = [&](int q) {   // DMAs of segment q: this wave moves units 8 q + wave and 8 q + 4 + wave
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        const int u = CSEG * q + 4 * hh + wave;
-        const u32x4* src = (CSEG * q < NU1) ? W.W1c + (size_t)u * 192 : W.W2c + (size_t)(u - NU1) * 192;
-        dma_unit(src, (CSEG * q + 4 * hh) % CSLOTS + wave, lane16, L::RING);
+        const int u = CSEG * q + 4 * hh + wv;
+        const u32x4* src = (CSEG * q < NU1) ? W1c_ + (size_t)u * 192 : W2c_ + (size_t)(u - NU1) * 192;
+        dma_unit(src, (CSEG * q + 4 * hh) % CSLOTS + wv, lane16, L::RING);
       }
     };
-    f32x4 acc1[16], acc2[16];
+    // this lane's elements of an image: column 16 t + 4 g + i, row trow -> hb[i] + 1024 t
+    int hb1[4], hb2[4];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      acc1[t] = *reinterpret_cast<const f32x4*>(&lds[L::B1 + 16 * t + 4 * g]);
-      acc2[t] = *reinterpret_cast<const f32x4*>(&lds[L::B2 + 16 * t + 4 * g]);
+    for (int i = 0; i < 4; ++i) {
+      hb1[i] = opaque(L::H1 + img_addr(4 * g + i, trow));
+      hb2[i] = opaque(L::H2 + img_addr(4 * g + i, trow));
     }
+    f32x4 acc2[16];
     fwd_issue(0);
     fwd_issue(1);
     CHAIN_WAIT_DMA(true);
-    CHAIN_BARRIER();       // also: the previous tile's last reads of the images / ring are complete everywhere
+    CHAIN_BARRIER();       // also: the previous tile's last reads of the images are complete everywhere
     fwd_issue(2);
     X3Frag Wc = ring_read(ringl, 0), Wn;
     X3Frag Bc, Bn;         // B fragment of the current / next layer-2 k step
-    float hv[8];           // activations of the k step being prepared
-#pragma unroll
-    for (int u = 0; u < NUF; ++u) {
+    float hv[8];           // float32 elements of the B fragment being prepared
+    f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, pend = c1;   // layer 1: the tile being accumulated / the finished tile awaiting its tanh
+    static_for<0, NUF>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
       __builtin_amdgcn_sched_barrier(0);
-      if ((u + 1) % CSEG == 0 && u + 1 < NUF) {
-        constexpr int dummy = 0; (void)dummy;
-        const int q = (u + 1) / CSEG;
+      if constexpr ((u + 1) % CSEG == 0 && u + 1 < NUF) {
+        constexpr int q = (u + 1) / CSEG;
         CHAIN_WAIT_DMA(q + 1 < NSF);
         CHAIN_BARRIER();
-        if (q + 2 < NSF) fwd_issue(q + 2);
+        if constexpr (q + 2 < NSF) fwd_issue(q + 2);
       }
-      if (u + 1 < NUF) Wn = ring_read(ringl, (u + 1) % CSLOTS);
-      const int t = u % 16;
-      if (u < NU1) {
-        X3C_MFMA6(Wc, xp[u / 16], acc1[t])
+      if constexpr (u + 1 < NUF) Wn = ring_read(ringl, (u + 1) % CSLOTS);
+      if constexpr (u < NU1) {
+        constexpr int t = u / K1, ks = u % K1;
+        if constexpr (ks == 0) c1 = *reinterpret_cast<const f32x4*>(&lds[L::B1 + 16 * t + 4 * g]);
+        X3C_MFMA6(Wc, xp[ks], c1)
+        if constexpr (t > 0 && ks == 0) {   // the previous tile: tanh -> h1 image
+#pragma unroll
+          for (int i = 0; i < 4; ++i) lds[hb1[i] + 1024 * (t - 1)] = fast_tanh_scaled(pend[i]);
+        }
+        if constexpr (ks == K1 - 1) pend = c1;
       } else {
+        constexpr int v = u - NU1, t = v % 16, ks = v / 16;
+        if constexpr (v == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) lds[hb1[i] + 1024 * 15] = fast_tanh_scaled(pend[i]);
+        }
+        if constexpr (ks == 0) acc2[t] = *reinterpret_cast<const f32x4*>(&lds[L::B2 + 16 * t + 4 * g]);
         X3C_MFMA6(Wc, Bc, acc2[t])
       }
-      // side work under the MFMAs: the B fragment of the NEXT layer-2 k step sn from tiles 2 sn, 2 sn + 1 of layer 1 -- tanh,
-      // image store (the float32 h1 that dW2 and the dz1 epilogue read), split -- in sixteen slices, one per unit
-      const int sn = u < NU1 - 16 ? -1 : (u - (NU1 - 16)) / 16;   // prepared during the last step of layer 1 and steps 0 .. 6 of layer 2
-      if (sn >= 0 && sn < 8) {
-        if (t >= 2 && t < 10) {          // tiles 2 sn, 2 sn + 1 of layer 1 are complete from unit NU1 - 16 + 1 on
-          const int e = t - 2;
-          const float h = fast_tanh_scaled(acc1[2 * sn + (e >> 2)][e & 3]);
-          hv[e] = h;
-          lds[L::H1 + img_addr(16 * (2 * sn + (e >> 2)) + 4 * g + (e & 3), trow)] = h;
-        } else if (t >= 10 && t < 14) {
-          const int jp = t - 10;
+      // side work: the B fragment of layer-2 k step sn, prepared in the sixteen units in front of it (sn = 0: the last sixteen
+      // units of layer 1, by which time tiles 0 and 1 of h1 are in the image): eight reads, then four pair-splits
+      constexpr int w0 = u - (NU1 - 16);          // position in the windows of sixteen units
+      if constexpr (w0 >= 0 && w0 / 16 < 8) {
+        constexpr int sn = w0 / 16, c = w0 % 16;
+        if constexpr (c >= 4 && c < 12) {
+          constexpr int e = c - 4;
+          hv[e] = lds[hb1[e & 3] + 1024 * (2 * sn + (e >> 2))];
+        } else if constexpr (c >= 12) {
+          constexpr int jp = c - 12;
           unsigned p1, p2, p3;
           x3_split2(hv[2 * jp], hv[2 * jp + 1], p1, p2, p3);
           Bn.p[0][jp] = p1; Bn.p[1][jp] = p2; Bn.p[2][jp] = p3;
         }
+        if constexpr (c == 15) Bc = Bn;
       }
-      if (t == 15) Bc = Bn;
       Wc = Wn;
-    }
+    });
     // every wave is done with the ring: its space beyond the first four units becomes the h2 image
     CHAIN_BARRIER();
 
     // ============================ h2 = tanh, head (float32 16x16x4), loss, dout ============================
     f32x4 mean = {0.f, 0.f, 0.f, 0.f};
     {
-      const f32x4* hp = W.W3c + lane;
+      const f32x4* hp = reinterpret_cast<const f32x4*>(W.W3c) + lane;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
+        if (t % 4 == 0) __builtin_amdgcn_sched_barrier(0);   // four tiles' pack loads at a time (hoisted together: 64 registers)
         const f32x4 wv = hp[64 * t];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float h = fast_tanh_scaled(acc2[t][i]);
           acc2[t][i] = h;
-          lds[L::H2 + img_addr(16 * t + 4 * g + i, trow)] = h;
+          lds[hb2[i] + 1024 * t] = h;
           mean = MFMA16(wv[i], h, mean);
         }
       }
@@ -370,9 +412,10 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
     }
     // dh2 = W3^T dout (float32 16x16x4: k slot g of step i = head row 4 g + i), dz2 = dh2 (1 - h2^2): in registers
     {
-      const f32x4* bp = W.W3bc + lane;
+      const f32x4* bp = reinterpret_cast<const f32x4*>(W.W3bc) + lane;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
+        if (t % 4 == 0) __builtin_amdgcn_sched_barrier(0);
         const f32x4 wv = bp[64 * t];
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -403,7 +446,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
 #pragma unroll
     for (int t = 0; t < 16; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) lds[L::H2 + img_addr(16 * t + 4 * g + i, trow)] = acc2[t][i];
+      for (int i = 0; i < 4; ++i) lds[hb2[i] + 1024 * t] = acc2[t][i];
     __syncthreads();   // dz2 image complete
 
     // ============================ dW2 += dz2^T . h1 (bf16 pipe, K = 64 rows; this wave: 64 neurons x 256 inputs) ============================
@@ -438,24 +481,23 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
           B = Bn2;
           raw = raw2;
         }
-        if (ks == 1) gather_tile(nsrc, g);   // level 2: the next tile's rows, in flight under the rest of this phase
       }
       gb2 += (s0 + s1) + (s2 + s3);
     }
     __syncthreads();   // the dz2 image has been read: its space is ring again
 
     // ============================ dh1 = W2^T dz2 (chain; B fragments from the dz2 registers), dz1 = dh1 (1 - h1^2) ============================
+    // Two passes over the k steps, eight neuron tiles of dh1 each (pack W2bc: [half][k step][tile of the half]): 32 accumulator
+    // registers instead of 64 next to the 64 of dz2.  B fragment of k step s: dz2 tiles 2 s, 2 s + 1, split one step ahead.
     auto bwd_issue = [&](int q) {
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        const int u = CSEG * q + 4 * hh + wave;
-        dma_unit(W.W2bc + (size_t)u * 192, (CSEG * q + 4 * hh) % CSLOTS + wave, lane16, L::RING);
+        const int u = CSEG * q + 4 * hh + wv;
+        dma_unit(W2bc_ + (size_t)u * 192, (CSEG * q + 4 * hh) % CSLOTS + wv, lane16, L::RING);
       }
     };
     {
-      f32x4 acc4[16];
-#pragma unroll
-      for (int t = 0; t < 16; ++t) acc4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 acc4[8];
       bwd_issue(0);
       bwd_issue(1);
       {
@@ -468,38 +510,44 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
       CHAIN_BARRIER();
       bwd_issue(2);
       Wc = ring_read(ringl, 0);
-#pragma unroll
-      for (int u = 0; u < NUB; ++u) {
+      static_for<0, NUB>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
         __builtin_amdgcn_sched_barrier(0);
-        if ((u + 1) % CSEG == 0 && u + 1 < NUB) {
-          const int q = (u + 1) / CSEG;
+        if constexpr ((u + 1) % CSEG == 0 && u + 1 < NUB) {
+          constexpr int q = (u + 1) / CSEG;
           CHAIN_WAIT_DMA(q + 1 < NSB);
           CHAIN_BARRIER();
-          if (q + 2 < NSB) bwd_issue(q + 2);
+          if constexpr (q + 2 < NSB) bwd_issue(q + 2);
         }
-        if (u + 1 < NUB) Wn = ring_read(ringl, (u + 1) % CSLOTS);
-        const int t = u % 16, s = u / 16;
-        X3C_MFMA6(Wc, Bc, acc4[t])
-        if (s + 1 < 8 && t >= 10 && t < 14) {   // the next k step's B fragment: dz2 tiles 2 (s + 1), 2 (s + 1) + 1
-          const int jp = t - 10, e0 = 2 * jp, e1 = 2 * jp + 1;
+        if constexpr (u + 1 < NUB) Wn = ring_read(ringl, (u + 1) % CSLOTS);
+        constexpr int half = u / 64, ks = (u % 64) / 8, t8 = u % 8;
+        if constexpr (ks == 0) acc4[t8] = f32x4{0.f, 0.f, 0.f, 0.f};
+        X3C_MFMA6(Wc, Bc, acc4[t8])
+        constexpr int sn = (ks + 1) % 8;           // the next k step (the second pass starts over at 0)
+        if constexpr (u + 1 < NUB && t8 >= 4) {
+          constexpr int jp = t8 - 4, e0 = 2 * jp, e1 = 2 * jp + 1;
           unsigned p1, p2, p3;
-          x3_split2(acc2[2 * (s + 1) + (e0 >> 2)][e0 & 3], acc2[2 * (s + 1) + (e1 >> 2)][e1 & 3], p1, p2, p3);
+          x3_split2(acc2[2 * sn + (e0 >> 2)][e0 & 3], acc2[2 * sn + (e1 >> 2)][e1 & 3], p1, p2, p3);
           Bn.p[0][jp] = p1; Bn.p[1][jp] = p2; Bn.p[2][jp] = p3;
+          if constexpr (t8 == 7) Bc = Bn;
         }
-        if (t == 15) Bc = Bn;
         Wc = Wn;
-      }
-      // dz1 over h1, in place (every lane rewrites exactly the elements it wrote in the forward pass; dW2's reads of the h1
-      // image are complete everywhere: all waves have passed the ring barriers of this phase)
+        if constexpr (u % 64 == 63) {
+          // dz1 over h1, in place, for the eight tiles of this pass (every lane rewrites exactly the elements it wrote in the
+          // forward pass; dW2's reads of the h1 image are complete everywhere: all waves have passed this phase's first barrier)
 #pragma unroll
-      for (int t = 0; t < 16; ++t)
+          for (int tt = 0; tt < 8; ++tt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int o = L::H1 + img_addr(16 * t + 4 * g + i, trow);
-          const float h = lds[o];
-          lds[o] = acc4[t][i] * (1.0f - h * h);
+            for (int i = 0; i < 4; ++i) {
+              const int o = hb1[i] + 1024 * (8 * half + tt);
+              const float h = lds[o];
+              lds[o] = acc4[tt][i] * (1.0f - h * h);
+            }
         }
+      });
     }
+    // level 2 of the next tile's gathers: in flight under dW1 (LDS operands only)
+    gather_tile(nsrc, g);
     __syncthreads();   // dz1 image complete (and every wave is done with the ring)
 
     // ============================ dW1 += dz1^T . X (bf16 pipe; this wave: 64 neurons x DP inputs), added to the slab ============================
@@ -534,23 +582,36 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
       }
       asm volatile("s_nop 15\n\ts_nop 7" : "+v"(gW1a), "+v"(gW1b), "+v"(gW1c), "+v"(gW1d));   // opaque MFMA statements: XDL write -> VALU read
       gb1 += (s0 + s1) + (s2 + s3);
-      // slab += tile (fragment order [w][tile][quad][lane] x 16 B, as k_fused_train stores it); the first tile stores
+      // slab += tile (fragment order [w][tile][quad][lane] x 16 B, as k_fused_train stores it); the first tile stores.  The loads
+      // bypass the vector L1 (sc1): the line was written by this lane one tile ago.
       const unsigned sb = (unsigned)(wave * 4 * 4 * 64 + lane) * 16u;
-      auto rmw = [&](const f32x16& gacc, int tile_idx) {
+      constexpr int NT1 = two ? 4 : 2;
+      f32x4 old[NT1 * 4];
+      if (!first_tile) {
+#pragma unroll
+        for (int k = 0; k < NT1 * 4; ++k) {
+          const int tile_idx = two ? (k >> 2) : 2 * (k >> 2);   // tiles 0 1 2 3, or 0 2 (one input block)
+          asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(old[k]) : "v"(sb + (unsigned)(tile_idx * 4 + (k & 3)) * 1024u), "s"(slab_w1) : "memory");
+        }
+        if constexpr (two)
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]), "+v"(old[7]),
+                       "+v"(old[8]), "+v"(old[9]), "+v"(old[10]), "+v"(old[11]), "+v"(old[12]), "+v"(old[13]), "+v"(old[14]), "+v"(old[15]) :: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]), "+v"(old[7]) :: "memory");
+      } else {
+#pragma unroll
+        for (int k = 0; k < NT1 * 4; ++k) old[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      auto rmw = [&](const f32x16& gacc, int tile_idx, int k0) {
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
-          f32x4 v = {gacc[4 * qd], gacc[4 * qd + 1], gacc[4 * qd + 2], gacc[4 * qd + 3]};
-          const unsigned off = sb + (unsigned)(tile_idx * 4 + qd) * 1024u;
-          if (!first_tile) {
-            const f32x4 o = ldg16(slab_w1, off);
-            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-          }
-          stg16(slab_w1, off, v);
+          const f32x4 o = old[k0 + qd];
+          const f32x4 v = {gacc[4 * qd] + o[0], gacc[4 * qd + 1] + o[1], gacc[4 * qd + 2] + o[2], gacc[4 * qd + 3] + o[3]};
+          stg16(slab_w1, sb + (unsigned)(tile_idx * 4 + qd) * 1024u, v);
         }
       };
-      rmw(gW1a, 0);
-      rmw(gW1b, 2);
-      if (two) { rmw(gW1c, 1); rmw(gW1d, 3); }
+      if constexpr (two) { rmw(gW1a, 0, 0); rmw(gW1c, 1, 4); rmw(gW1b, 2, 8); rmw(gW1d, 3, 12); }
+      else { rmw(gW1a, 0, 0); rmw(gW1b, 2, 4); }
     }
     first_tile = false;
     __syncthreads();   // images are rewritten by the next tile
@@ -629,46 +690,6 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Chain packs (layouts: tests/chain_model.py).  k slot (lane group g, element j) of k step s carries
-//   layer 1: observation column 32 s + 8 g + j                      (natural order)
-//   layer 2 / dh1: neuron 32 s + 16 (j >> 2) + 4 g + (j & 3)        (the order accumulator tiles hand their rows over in)
-// x3 pack element: [k step s][neuron tile t][piece 3][lane 64][8 bf16], lane = (row & 15) + 16 g.
-// ------------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ int chain_kslot_of_neuron(int n, int* s, int* g, int* j) {   // inverse of the layer-2 map
-  *s = n >> 5;
-  const int r = n & 31;
-  *g = (r >> 2) & 3;
-  *j = ((r >> 4) << 2) | (r & 3);
-  return 0;
-}
-// bf16 index (in units of 2 bytes) of piece 0 of A[row][k slot (s, g, j)] in a chain pack; pieces 1, 2 follow at + 512, + 1024
-__host__ __device__ __forceinline__ size_t chain_pack_idx(int row, int s, int g, int j) {
-  return ((size_t)(s * 16 + (row >> 4)) * 3) * 512 + (size_t)((row & 15) + 16 * g) * 8 + j;
-}
-__device__ __forceinline__ void chain_pack_store(unsigned short* out, size_t base, float x) {
-  asm volatile("" : "+v"(x));   // split the ROUNDED product (see x3_pack_store)
-  unsigned p1, p2, p3;
-  x3_split2(x, 0.f, p1, p2, p3);
-  out[base] = (unsigned short)(p1 & 0xffffu);
-  out[base + 512] = (unsigned short)(p2 & 0xffffu);
-  out[base + 1024] = (unsigned short)(p3 & 0xffffu);
-}
-// element (neuron n, input k) of W1 [H][D] / W2 [H][H] -> its places in the chain packs
-__device__ __forceinline__ void chain_store_w1(unsigned short* w1c, int n, int k, float scaled) {
-  chain_pack_store(w1c, chain_pack_idx(n, k >> 5, (k >> 3) & 3, k & 7), scaled);
-}
-__device__ __forceinline__ void chain_store_w2(unsigned short* w2c, unsigned short* w2bc, int n, int k, float scaled, float raw) {
-  int s, g, j;
-  chain_kslot_of_neuron(k, &s, &g, &j);           // forward: A[row = n][k slot of input neuron k]
-  chain_pack_store(w2c, chain_pack_idx(n, s, g, j), scaled);
-  chain_kslot_of_neuron(n, &s, &g, &j);           // dh1: A[row = k (input neuron)][k slot of output neuron n] = W2[n][k]
-  chain_pack_store(w2bc, chain_pack_idx(k, s, g, j), raw);
-}
-// head [A <= 16][H]: forward pack [t][lane][i] = W3[lane & 15][16 t + 4 (lane >> 4) + i]; dh2 pack [t][lane][i] = W3[4 (lane >> 4) + i][16 t + (lane & 15)]
-__host__ __device__ __forceinline__ int chain_head_fwd_idx(int a_, int k) { return ((k >> 4) * 64 + a_ + 16 * ((k >> 2) & 3)) * 4 + (k & 3); }
-__host__ __device__ __forceinline__ int chain_head_bwd_idx(int a_, int k) { return ((k >> 4) * 64 + (k & 15) + 16 * (a_ >> 2)) * 4 + (a_ & 3); }
-
 // rebuild every chain pack of both networks from the canonical parameters (set_params; k_adam_pack keeps them current per step)
 struct ChainPackArgs {
   const float* W1[2]; const float* W2[2]; const float* W3[2];
@@ -686,7 +707,7 @@ __global__ __launch_bounds__(256) void k_pack_chain(ChainPackArgs a) {
   }
   if (i < FH * 32 * K1) {   // every k slot of the layer-1 pack, padding included
     const int n = i / (32 * K1), k = i - n * (32 * K1);
-    chain_store_w1(a.w1c[net], n, k, k < a.D ? kTanhScale * a.W1[net][n * a.D + k] : 0.f);
+    chain_store_w1(a.w1c[net], n, k, K1, k < a.D ? kTanhScale * a.W1[net][n * a.D + k] : 0.f);
   }
   if (i < 16 * FH) {
     const int a_ = i / FH, k = i - a_ * FH;

@@ -36,6 +36,13 @@ struct FusedNet {
   const unsigned* W1x;  // [H/32][Dp/16][3][64] x 16 bytes
   const unsigned* W2x;  // [H/32][H/16][3][64] x 16 bytes
   const unsigned* W2bx; // the same for the backward operand B[k = n][j] = W2[n][j] (dh1 = dz2 . W2), unscaled
+  // chain packs (k_chain_train, kernels_chain.h; null: not maintained): A operands of v_mfma_f32_16x16x32_bf16 in the
+  // permuted k order of the register chain, [k step][neuron tile 16][piece 3][lane 64] x 16 bytes
+  const unsigned* W1c;  // layer 1 (scaled)
+  const unsigned* W2c;  // layer 2 (scaled)
+  const unsigned* W2bc; // dh1 = W2^T dz2
+  const float* W3c;     // head forward, float32 16x16x4: [tile 16][lane 64][4]
+  const float* W3bc;    // dh2 = W3^T dout, float32 16x16x4: [tile 16][lane 64][4]
 };
 
 struct FusedTrainArgs {
@@ -2062,6 +2069,7 @@ struct AdamPackArgs {
   // fused-path packs (null when the fused path is disabled)
   float* fW1f[2]; float* fW2f[2]; float* fW3f[2]; float* fW3h[2]; float* fW2b[2]; float* fW3b[2]; float* fb1s[2]; float* fb2s[2];
   unsigned short* xW1[2]; unsigned short* xW2[2]; unsigned short* xW2b[2];  // x3 packs kept current per step (null: not maintained here)
+  unsigned short* cW1[2]; unsigned short* cW2[2]; unsigned short* cW2b[2]; float* cW3[2]; float* cW3b[2];  // chain packs (null: not maintained)
   float* stats_row;  // [6] <- total gradient norm
   float* loss_sums_zero;  // fused path: the 8 loss accumulators are re-zeroed here instead of by a memset launch
   StatsArgs st;           // st.stats_row != null: this kernel also writes the step's loss statistics (no k_sqnorm_chunks launch)
@@ -2086,6 +2094,47 @@ __device__ __forceinline__ void x3_pack_store(unsigned short* out, int n, int k,
   out[base + 512] = (unsigned short)(p2 & 0xffffu);
   out[base + 1024] = (unsigned short)(p3 & 0xffffu);
 }
+// ---- chain packs (k_chain_train, kernels_chain.h; layouts stated and checked in tests/chain_model.py) ----
+// k slot (lane group g, element j) of k step s carries
+//   layer 1:       observation column 32 s + 8 g + j                      (natural order)
+//   layer 2 / dh1: neuron 32 s + 16 (j >> 2) + 4 g + (j & 3)              (the order accumulator tiles hand their rows over in)
+__host__ __device__ __forceinline__ void chain_kslot_of_neuron(int n, int* s, int* g, int* j) {
+  *s = n >> 5;
+  const int r = n & 31;
+  *g = (r >> 2) & 3;
+  *j = ((r >> 4) << 2) | (r & 3);
+}
+// bf16 index of piece 0 of element (row & 15, k slot (g, j)) of ring unit `unit` (3 KB each, in the order the kernel consumes
+// them); pieces 1, 2 follow at + 512, + 1024
+__host__ __device__ __forceinline__ size_t chain_pack_idx(int unit, int row, int g, int j) {
+  return ((size_t)unit * 3) * 512 + (size_t)((row & 15) + 16 * g) * 8 + j;
+}
+// unit order of the three packs: layer 1 [neuron tile][k step]; layer 2 [k step][neuron tile]; dh1 [half of the tiles][k step][tile of the half]
+__host__ __device__ __forceinline__ int chain_unit_w1(int tile, int s, int K1) { return tile * K1 + s; }
+__host__ __device__ __forceinline__ int chain_unit_w2(int tile, int s) { return s * 16 + tile; }
+__host__ __device__ __forceinline__ int chain_unit_w2b(int tile, int s) { return (tile >> 3) * 64 + s * 8 + (tile & 7); }
+__device__ __forceinline__ void chain_pack_store(unsigned short* out, size_t base, float x) {
+  asm volatile("" : "+v"(x));   // split the ROUNDED product (see x3_pack_store)
+  unsigned p1, p2, p3;
+  x3_split2(x, 0.f, p1, p2, p3);
+  out[base] = (unsigned short)(p1 & 0xffffu);
+  out[base + 512] = (unsigned short)(p2 & 0xffffu);
+  out[base + 1024] = (unsigned short)(p3 & 0xffffu);
+}
+__device__ __forceinline__ void chain_store_w1(unsigned short* w1c, int n, int k, int K1, float scaled) {
+  chain_pack_store(w1c, chain_pack_idx(chain_unit_w1(n >> 4, k >> 5, K1), n, (k >> 3) & 3, k & 7), scaled);
+}
+__device__ __forceinline__ void chain_store_w2(unsigned short* w2c, unsigned short* w2bc, int n, int k, float scaled, float raw) {
+  int s, g, j;
+  chain_kslot_of_neuron(k, &s, &g, &j);           // forward: A[row = n][k slot of input neuron k] = scale W2[n][k]
+  chain_pack_store(w2c, chain_pack_idx(chain_unit_w2(n >> 4, s), n, g, j), scaled);
+  chain_kslot_of_neuron(n, &s, &g, &j);           // dh1: A[row = k (input neuron)][k slot of output neuron n] = W2[n][k]
+  chain_pack_store(w2bc, chain_pack_idx(chain_unit_w2b(k >> 4, s), k, g, j), raw);
+}
+// head [A <= 16][H]: forward pack [t][lane][i] = W3[lane & 15][16 t + 4 (lane >> 4) + i]; dh2 pack [t][lane][i] = W3[4 (lane >> 4) + i][16 t + (lane & 15)]
+__host__ __device__ __forceinline__ int chain_head_fwd_idx(int a_, int k) { return ((k >> 4) * 64 + a_ + 16 * ((k >> 2) & 3)) * 4 + (k & 3); }
+__host__ __device__ __forceinline__ int chain_head_bwd_idx(int a_, int k) { return ((k >> 4) * 64 + (k & 15) + 16 * (a_ >> 2)) * 4 + (a_ & 3); }
+
 // clip + Adam of canonical parameter i and its scatter into the padded copies / fragment packs [torch 2.0.1
 // single-tensor Adam; oracle adam_step].  Shared by k_adam_pack and the persistent small-batch kernel.
 __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, float graw, float m0, float v0, float p0, float coef);
@@ -2115,6 +2164,7 @@ __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, fl
       (net ? a.vW1p : a.pW1p)[n * a.Dp + k] = pn;
       if (a.fW1f[net]) a.fW1f[net][pack_fwd_idx(n, k, a.Dp / 8)] = kTanhScale * pn;
       if (a.xW1[net]) x3_pack_store(a.xW1[net], n, k, a.Dp / 16, kTanhScale * pn);
+      if (a.cW1[net]) chain_store_w1(a.cW1[net], n, k, (a.Dp + 31) / 32, kTanhScale * pn);
     } break;
     case 3: case 7: {  // W2 [H2][H1]
       const int net = t == 7;
@@ -2126,6 +2176,7 @@ __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, fl
           x3_pack_store(a.xW2[net], n, k, K / 16, kTanhScale * pn);               // forward operand B[k][n] = scale W2[n][k]
           x3_pack_store(a.xW2b[net], k, n, (net ? a.G2 : a.H2) / 16, pn);          // backward operand B[n][k] = W2[n][k]
         }
+        if (a.cW2[net]) chain_store_w2(a.cW2[net], a.cW2b[net], n, k, kTanhScale * pn, pn);
       }
     } break;
     case 9: case 11: {  // head [A or 1][H2]
@@ -2135,6 +2186,7 @@ __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, fl
         a.fW3f[net][pack_fwd_idx(n, k, K / 8)] = pn;
         a.fW3b[net][pack_bwd_idx(n, k, 4)] = pn;
         if (a.fW3h[net] && n < 16) a.fW3h[net][pack_h16_idx(n, k)] = pn;
+        if (a.cW3[net] && n < 16) { a.cW3[net][chain_head_fwd_idx(n, k)] = pn; a.cW3b[net][chain_head_bwd_idx(n, k)] = pn; }
       }
     } break;
     case 2: case 6: if (a.fb1s[t == 6]) a.fb1s[t == 6][e] = kTanhScale * pn; break;  // hidden biases (scaled copies)
@@ -2230,6 +2282,8 @@ struct FusedState {
   float* slabs = nullptr;
   float* train_rec = nullptr;   // H = 256: [T*N][train_rec_width(A)] (k_build_train_records)
   bool train_x3 = false;        // k_fused_train<.., X3 = true>: x3 packs refreshed after every optimizer step
+  bool train_chain = false;     // k_chain_train (kernels_chain.h) instead: chain packs refreshed after every optimizer step
+  size_t lds_chain_bytes = 0;
   unsigned long long* stamps = nullptr;  // diagnostic build only
   int slab_floats = 0, max_grid = 0;
   int pair_nseq_max = 0;  // 64-wide nets: two-wave workgroups per network of k_pair64_train (slabs are sized for them)

@@ -333,7 +333,7 @@ def test_benchmarked_epoch_step_by_step_matches_oracle(shape):
         O.adam_step(p, clipped, st, h.learning_rate, h.beta1, h.beta2, h.adam_eps)
         for pipe, eng in engines.items():
             tag = f"{shape['name']}/{pipe}/step{mb}"
-            if mb > 0:                                    # common state: the oracle's
+            if mb > 0 or eng is not e:                    # common state: the oracle's
                 eng.set_params(p_before)
                 eng.set_optimizer_state(m_before, v_before, step_before)
             if near.any():

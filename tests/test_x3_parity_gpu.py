@@ -232,9 +232,9 @@ def _adversarial_case(kind, D, A, rng):
 @pytest.mark.parametrize("kind", ["spread", "cancel", "tiny", "subnormal"])
 def test_x3_gradient_kernel_on_adversarial_operands(kind, D, A):
     """Gradient tensors and loss scalars of one minibatch against the float64-accumulated oracle, x3 kernel and f32-pipe kernel
-    side by side.  Errors are scaled by the tensor's largest entry.  Bar: over all tensors the x3 kernel's worst error is at
-    most 1.5x the f32-pipe kernel's worst (+ 5e-7: both sit at the rounding noise of 1024-term float32 sums, whose order
-    differs between the kernels), and no single tensor is worse than 4x + 1e-6 (the bound of
+    side by side, and NumPy's float32 BLAS beside them.  Errors are scaled by the tensor's largest entry.  Bar: over all tensors
+    the x3 kernel's worst error is at most 1.5x the worst of the other two float32 evaluations (+ 5e-7: all sit at the rounding
+    noise of 1024-term float32 sums, whose order differs), and no single tensor is worse than 4x + 1e-6 (the bound of
     test_x3_gradient_kernel_is_float32_accurate).  The clip range is opened wide (1e9): the surrogate's gradient is
     discontinuous at 1 +- clip and the cancelling case puts 1e-4-level noise on the ratios by construction, so with clipping on
     the test would count clip-boundary flips, not matrix products (those are covered at full size with the boundary rows
@@ -246,7 +246,12 @@ def test_x3_gradient_kernel_on_adversarial_operands(kind, D, A):
     h = O.Hyper(ent_coef=0.01, n_epochs=1, batch_size=B, clip_range=1e9)
     idx = rng.permutation(B)
     stats, og, aux = _f64_grads(p, buf, idx, h)
-    errs, scal = {}, {}
+    # the same gradient in float32 BLAS (NumPy's sgemm; the reference's arithmetic is torch-CPU's sgemm): its error is part of the
+    # yardstick.  A sequential fma chain (v_mfma_f32) profits when cancelling terms are NEIGHBOURS in k -- its partial sums stay
+    # small --, a blocked / vectorised summation (BLAS, and the x3 products, whose truncation is relative to the single products)
+    # does not; neither is "more float32" than the other.
+    _, og32, _ = O.loss_and_grads(p, *O.gather_minibatch(buf, idx), h)
+    errs, scal = {"blas": {k: scaled_err(og32[k], og[k]) for k in og}}, {}
     for x3 in (True, False):
         e = PPOEngine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=1, pi=(H, H), vf=(H, H),
                       ent_coef=h.ent_coef, clip_range=h.clip_range, forward_x3=x3)
@@ -261,8 +266,9 @@ def test_x3_gradient_kernel_on_adversarial_operands(kind, D, A):
         e.minibatch_apply()
         scal[x3] = e.fetch_step_stats()[-1]
         e.close()
-    report = {k.replace("mlp_extractor.", ""): (f"{errs[True][k]:.1e}", f"{errs[False][k]:.1e}") for k in og}
-    worst_x3, worst_f32 = max(errs[True].values()), max(errs[False].values())
+    ref = {k: max(errs[False][k], errs["blas"][k]) for k in og}      # the better-known float32 evaluations of the same gradient
+    report = {k.replace("mlp_extractor.", ""): (f"{errs[True][k]:.1e}", f"{errs[False][k]:.1e}", f"{errs['blas'][k]:.1e}") for k in og}
+    worst_x3, worst_f32 = max(errs[True].values()), max(ref.values())
     if kind == "subnormal":
         # documented limit: operands below 2^-110 keep two of their three pieces (16 significant bits, 1.5e-5 relative per
         # product) -- the north_star bar still holds
@@ -270,10 +276,10 @@ def test_x3_gradient_kernel_on_adversarial_operands(kind, D, A):
         return
     assert worst_x3 <= 1.5 * worst_f32 + 5e-7, (kind, worst_x3, worst_f32, report)
     for k in og:
-        assert errs[True][k] <= 4.0 * errs[False][k] + 1e-6, (kind, k, report)
+        assert errs[True][k] <= 4.0 * ref[k] + 1e-6, (kind, k, report)
         # and to the north_star bar wherever float32 arithmetic itself meets it (the cancelling case is ill-conditioned by
-        # construction: there both pipes sit at the conditioning of the data and only the comparisons above are meaningful)
-        assert errs[True][k] < max(1e-4, 1.5 * errs[False][k]), (kind, k, report)
+        # construction: there every float32 evaluation sits at the conditioning of the data and only the comparisons above mean something)
+        assert errs[True][k] < max(1e-4, 1.5 * ref[k]), (kind, k, report)
     for i, k in enumerate(["policy_loss", "value_loss", "entropy_loss", "loss", "approx_kl"]):
         ref = float(stats[k])
         ex, ef = abs(float(scal[True][i]) - ref), abs(float(scal[False][i]) - ref)
