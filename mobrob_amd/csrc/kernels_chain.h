@@ -70,17 +70,46 @@ __host__ __device__ __forceinline__ int img_addr(int m, int row) { return m * 64
   C_ = MFMA16B(W_.p[0], X_.p[1], C_);           \
   C_ = MFMA16B(W_.p[0], X_.p[0], C_);
 
+// One ring unit: acc += W . X as six products, ordered so that the weight pieces die early -- piece 2 after the first MFMA, piece 1
+// after the third -- and the NEXT unit's pieces are read into the freed registers right behind their last use (piece 0, needed
+// to the end, alternates between two registers by unit parity).  Every read is then issued 3 .. 6 MFMAs (48 .. 96 cycles) before
+// the MFMA that needs it: with all three pieces read in one burst late in the unit (the first version) every unit started with
+// an LDS wait.  Magnitudes: (2,0) (1,1) ~2^-16, (1,0) ~2^-8, (0,2) ~2^-16, (0,1) ~2^-8, (0,0) ~1 of the product.
+struct RingW { u32x4 p0[2], p1, p2; };
+__device__ __forceinline__ u32x4 ring_read_piece(int ring_lane_f0, int slot, int pc) {
+  return *reinterpret_cast<const u32x4*>(&lds[ring_lane_f0 + slot * CUNIT + 256 * pc]);
+}
+#define CHAIN_UNIT(Wr, par, X_, C_, have_next, nslot)                                        \
+  if (have_next) Wr.p0[(par) ^ 1] = ring_read_piece(ringl, nslot, 0);                        \
+  C_ = MFMA16B(Wr.p2, X_.p[0], C_);                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                         \
+  if (have_next) Wr.p2 = ring_read_piece(ringl, nslot, 2);                                   \
+  C_ = MFMA16B(Wr.p1, X_.p[1], C_);                                                          \
+  C_ = MFMA16B(Wr.p1, X_.p[0], C_);                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                         \
+  if (have_next) Wr.p1 = ring_read_piece(ringl, nslot, 1);                                   \
+  C_ = MFMA16B(Wr.p0[par], X_.p[2], C_);                                                     \
+  C_ = MFMA16B(Wr.p0[par], X_.p[1], C_);                                                     \
+  C_ = MFMA16B(Wr.p0[par], X_.p[0], C_);
+
 // LDS-DMA of 1 KB: lane l's 16 bytes at sbase + voff land at LDS byte address lds_byte + 16 l.  Issued as inline asm: the
 // compiler knows nothing of it (no conservative vmcnt(0) in front of every ring read); the ring protocol below waits by hand.
+#ifndef MOBROB_CHAIN_SKIP     // timing-only ablation builds (outputs wrong by construction; never in the product library)
+#define MOBROB_CHAIN_SKIP 0
+#endif
 __device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds_byte) {
+  if (MOBROB_CHAIN_SKIP & 1) return;
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte), "v"(voff), "s"(sbase) : "memory", "m0");
 }
-// one ring unit: the three pieces of one A fragment, 3 KB contiguous in the pack
+// one ring unit: the three pieces of one A fragment, 3 KB contiguous in the pack and in the ring.  The instruction offset of
+// global_load_lds moves the global AND the LDS address (scratch/dma_offset_probe.hip, profiles/r4): one M0 write per unit.
 __device__ __forceinline__ void dma_unit(const u32x4* src, int slot, unsigned lane16, int ring_f0) {
+  if (MOBROB_CHAIN_SKIP & 1) return;
   const unsigned dst = (unsigned)(ring_f0 + slot * CUNIT) * 4u;
-  dma16(src, lane16, dst);
-  dma16(src, lane16 + 1024u, dst + 1024u);
-  dma16(src, lane16 + 2048u, dst + 2048u);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:2048" ::"s"(dst), "v"(lane16), "s"(src) : "memory", "m0");
 }
 __device__ __forceinline__ X3Frag ring_read(int ring_lane_f0, int slot) {  // ring_lane_f0 = RING + 4 lane (opaque per-lane base)
   X3Frag f;
@@ -91,13 +120,22 @@ __device__ __forceinline__ X3Frag ring_read(int ring_lane_f0, int slot) {  // ri
 // A segment boundary of the weight ring, in front of the reads of segment Q (of NS segments of this stream): this wave's DMAs
 // of segment Q have landed (the six of segment Q + 1 may still be in flight), its reads of segment Q - 1 are complete; after
 // the barrier that holds for every wave, so segment Q may be read and segment Q - 1's slots refilled with segment Q + 2.
-#ifdef MOBROB_CHAIN_VMCNT0   // validation builds: never rely on the count of DMAs in flight
+#if MOBROB_CHAIN_SKIP & 4
+#define CHAIN_WAIT_DMA(more)
+#elif defined(MOBROB_CHAIN_VMCNT0)   // validation builds: never rely on the count of DMAs in flight
 #define CHAIN_WAIT_DMA(more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #else
 #define CHAIN_WAIT_DMA(more) \
   if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() is a workgroup-scope fence as well: it drains vmcnt, i.e. it waits for the
+// next tile's gathers (HBM latency) and for the slab stores at every barrier of the tile -- 2-3 k cycles each.
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#if MOBROB_CHAIN_SKIP & 2
+#define CHAIN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
 #define CHAIN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 
 // wave-uniform values re-materialised per tile: without it LICM hoists the ~300 scalar DMA addresses of a tile (all functions
 // of the wave index and the pack pointers) out of the tile loop and parks them in VGPR lanes
@@ -110,6 +148,10 @@ __device__ __forceinline__ const T* opaque_sp(const T* p) {
   asm volatile("" : "+s"(p));
   return p;
 }
+
+// per-lane LDS base that is provably 16-byte aligned (x is a multiple of 4 floats): without the proof every f32x4 access becomes
+// ds_read2_b32 pairs -- 4-way bank conflicts at a 16-byte lane stride (the first version of this kernel ran 4.5x off its MFMA bound)
+__device__ __forceinline__ int opaque4(int x) { return 4 * opaque(x >> 2); }
 
 // straight-line code for a compile-time range (a `#pragma unroll` loop of this size is refused by the unroller)
 template <int I, int N, class F>
@@ -132,6 +174,74 @@ __device__ __forceinline__ X3Frag x3_split8v(const float (&v)[8]) {
   return f;
 }
 
+// ---- weight-gradient loops: ONE MFMA per statement, half a pair-split (5 / 6 VALU instructions) behind each ----
+// One wave per SIMD hides at most ~5 single-issue instructions per v_mfma_f32_32x32x16_bf16 (24 of its 32 cycles; MI355X_MICROARCH.md,
+// 'single-issue instructions HIDDEN per gap').  k_fused_train's x3 loops put a whole pair-split (11 instructions) behind every
+// SECOND MFMA (two-MFMA statements): one gap empty, the next 20 cycles over budget -- its x3 phases ran at 55-65 % of the matrix
+// rate.  Here every gap carries half a split.
+struct SplitMid { unsigned p1; float ra, rb; };
+__device__ __forceinline__ void split_half1(float lo, float hi, SplitMid& m) {
+  m.p1 = cvt_pk_bf16(lo, hi);
+  m.ra = lo - __uint_as_float(m.p1 << 16);
+  m.rb = hi - __uint_as_float(m.p1 & 0xffff0000u);
+}
+__device__ __forceinline__ void split_half2(const SplitMid& m, int jp, X3Frag& out) {
+  const unsigned p2 = cvt_pk_bf16(m.ra, m.rb);
+  const float sa = m.ra - __uint_as_float(p2 << 16), sb = m.rb - __uint_as_float(p2 & 0xffff0000u);
+  out.p[0][jp] = m.p1; out.p[1][jp] = p2; out.p[2][jp] = cvt_pk_bf16(sa, sb);
+}
+#define MFMA_A1(acc, a_, b_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a_), "v"(b_))
+#define MFMA_V1(acc, a_, b_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a_), "v"(b_))
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+// the tile pair (neuron block 0 / 1) x input block of one 16-row k step: twelve MFMAs; the fragment `raw` (the next input block's,
+// or nothing) is split behind the first eight
+template <bool SPLIT>
+__device__ __forceinline__ void dw2_block(f32x16& g0, f32x16& g1, const X3Frag& A0, const X3Frag& A1, const X3Frag& B, const ColFrag& raw,
+                                          X3Frag& out) {
+  SplitMid m;
+  asm volatile("s_nop 1");  // VALU-written operand -> MFMA
+  MFMA_A1(g0, A0.p[1], B.p[1]); if (SPLIT) split_half1(raw.v[0], raw.v[1], m); PIN();
+  MFMA_A1(g1, A1.p[1], B.p[1]); if (SPLIT) split_half2(m, 0, out); PIN();
+  MFMA_A1(g0, A0.p[0], B.p[2]); if (SPLIT) split_half1(raw.v[2], raw.v[3], m); PIN();
+  MFMA_A1(g1, A1.p[0], B.p[2]); if (SPLIT) split_half2(m, 1, out); PIN();
+  MFMA_A1(g0, A0.p[2], B.p[0]); if (SPLIT) split_half1(raw.v[4], raw.v[5], m); PIN();
+  MFMA_A1(g1, A1.p[2], B.p[0]); if (SPLIT) split_half2(m, 2, out); PIN();
+  MFMA_A1(g0, A0.p[0], B.p[1]); if (SPLIT) split_half1(raw.v[6], raw.v[7], m); PIN();
+  MFMA_A1(g1, A1.p[0], B.p[1]); if (SPLIT) split_half2(m, 3, out); PIN();
+  MFMA_A1(g0, A0.p[1], B.p[0]);
+  MFMA_A1(g1, A1.p[1], B.p[0]);
+  MFMA_A1(g0, A0.p[0], B.p[0]);
+  MFMA_A1(g1, A1.p[0], B.p[0]);
+}
+// the same with TWO fragments split (the next k step's dz2 operands): a half behind each of the first eight MFMAs, two behind the last four
+__device__ __forceinline__ void dw2_block2(f32x16& g0, f32x16& g1, const X3Frag& A0, const X3Frag& A1, const X3Frag& B,
+                                           const ColFrag& r0, X3Frag& n0, const ColFrag& r1, X3Frag& n1) {
+  SplitMid m, m2;
+  asm volatile("s_nop 1");
+  MFMA_A1(g0, A0.p[1], B.p[1]); split_half1(r0.v[0], r0.v[1], m); PIN();
+  MFMA_A1(g1, A1.p[1], B.p[1]); split_half2(m, 0, n0); PIN();
+  MFMA_A1(g0, A0.p[0], B.p[2]); split_half1(r0.v[2], r0.v[3], m); PIN();
+  MFMA_A1(g1, A1.p[0], B.p[2]); split_half2(m, 1, n0); PIN();
+  MFMA_A1(g0, A0.p[2], B.p[0]); split_half1(r0.v[4], r0.v[5], m); PIN();
+  MFMA_A1(g1, A1.p[2], B.p[0]); split_half2(m, 2, n0); PIN();
+  MFMA_A1(g0, A0.p[0], B.p[1]); split_half1(r0.v[6], r0.v[7], m); PIN();
+  MFMA_A1(g1, A1.p[0], B.p[1]); split_half2(m, 3, n0); PIN();
+  MFMA_A1(g0, A0.p[1], B.p[0]); split_half1(r1.v[0], r1.v[1], m); split_half1(r1.v[2], r1.v[3], m2); PIN();
+  MFMA_A1(g1, A1.p[1], B.p[0]); split_half2(m, 0, n1); split_half2(m2, 1, n1); PIN();
+  MFMA_A1(g0, A0.p[0], B.p[0]); split_half1(r1.v[4], r1.v[5], m); split_half1(r1.v[6], r1.v[7], m2); PIN();
+  MFMA_A1(g1, A1.p[0], B.p[0]); split_half2(m, 2, n1); split_half2(m2, 3, n1);
+}
+
+// the same with the k-step XOR already applied to the base (a0 = base ^ kx) and a constant column-block offset on top: the offset
+// folds into the DS instruction's immediate
+__device__ __forceinline__ ColFrag img_frag_load_at(int a0, int a1, int off) {
+  ColFrag f;
+  const f32x4 lo = *reinterpret_cast<const f32x4*>(&lds[a0 + off]);
+  const f32x4 hi = *reinterpret_cast<const f32x4*>(&lds[a1 + off]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.v[j] = lo[j]; f.v[4 + j] = hi[j]; }
+  return f;
+}
 // eight consecutive batch rows of one image column: two 16-byte chunks whose addresses differ in one XOR bit
 __device__ __forceinline__ ColFrag img_frag_load(int a0) {
   ColFrag f;
@@ -209,39 +319,44 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
   //      eight observation columns 32 s + 8 g .. + 7 of each layer-1 k step, its four actions 4 g .. 4 g + 3 and the record tail
   f32x4 xr[2 * K1];
   f32x4 l_act = {0.f, 0.f, 0.f, 0.f}, l_tail = {0.f, 0.f, 0.f, 0.f};
+  // Every wave issues the same 2 K1 + 2 vector loads whatever its rows are (dead rows read row 0 and are zeroed afterwards): the
+  // weight-gradient phase counts on that number being in flight behind its own loads (s_waitcnt vmcnt(NGL)).
   auto gather_tile = [&](int src_or_neg, int g_) {
     const bool live = src_or_neg >= 0;
     const unsigned src = live ? (unsigned)src_or_neg : 0u;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < K1; ++s) {
-      xr[2 * s] = f32x4{0.f, 0.f, 0.f, 0.f};
-      xr[2 * s + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (live && 32 * s + 8 * g_ < DP) {
-        xr[2 * s] = ldg16(a.obs, src * (unsigned)(DP * 4) + (unsigned)((32 * s + 8 * g_) * 4));
-        xr[2 * s + 1] = ldg16(a.obs, src * (unsigned)(DP * 4) + (unsigned)((32 * s + 8 * g_ + 4) * 4));
-      }
+      const unsigned col = (32 * s + 8 * g_ < DP) ? (unsigned)(32 * s + 8 * g_) : 0u;   // DP = 16: lane groups 2, 3 hold padding
+      const f32x4 lo = ldg16(a.obs, src * (unsigned)(DP * 4) + col * 4u);
+      const f32x4 hi = ldg16(a.obs, src * (unsigned)(DP * 4) + (col + 4u) * 4u);
+      const bool on = live && 32 * s + 8 * g_ < DP;
+      xr[2 * s] = on ? lo : z4;
+      xr[2 * s + 1] = on ? hi : z4;
     }
-    l_act = f32x4{0.f, 0.f, 0.f, 0.f};
-    l_tail = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (live) {
-      if (net == 0) l_act = ldg16(a.rec, (src * (unsigned)a.RW + (unsigned)(4 * g_)) * 4u);
-      l_tail = ldg16(a.rec, (src * (unsigned)a.RW + (unsigned)(a.RW - 4)) * 4u);   // old log-prob, advantage, return, old value
-    }
+    const f32x4 la = ldg16(a.rec, (src * (unsigned)a.RW + (unsigned)(4 * g_)) * 4u);
+    const f32x4 lt = ldg16(a.rec, (src * (unsigned)a.RW + (unsigned)(a.RW - 4)) * 4u);   // old log-prob, advantage, return, old value
+    l_act = (live && net == 0) ? la : z4;
+    l_tail = live ? lt : z4;
   };
   {
     const int row = wg * CR + 16 * wave + (tid0 & 15);
     gather_tile((wg < ntiles && row < a.count) ? a.rows[row] : -1, (tid0 & 63) >> 4);
   }
   __syncthreads();   // constants and bias tables
+#ifdef MOBROB_STAMPS
+  unsigned long long* stamps_ = a.stamps;
+#endif
+  STAMP_INIT()
 
-  bool first_tile = true;
+  bool first_tile = true, primed = false;
   for (int tile = wg; tile < ntiles; tile += nwg) {
     const int tid = opaque(tid0), lane = tid & 63;
     const int brow = lane & 15, g = lane >> 4;
     const int trow = 16 * wave + brow;                 // row of the tile
     const bool live = tile * CR + trow < a.count;
     const unsigned lane16 = opaque_u((unsigned)lane * 16u);
-    const int ringl = opaque(L::RING + 4 * lane);
+    const int ringl = opaque4(L::RING + 4 * lane);
     const int wv = opaque_s(wave);
     const u32x4* W1c_ = opaque_sp(W1c);
     const u32x4* W2c_ = opaque_sp(W2c);
@@ -263,6 +378,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
       xp[s] = x3_split8v(v);
     }
 
+    STAMP(0)
     // ============================ forward: layer 1 and layer 2 as ONE stream of ring units ============================
     // unit u < NU1: layer 1, neuron tile u / K1, k step u % K1 (pack W1c, [tile][k step]: a tile is complete after K1 units, its
     // tanh goes to the h1 image under the next tile's MFMAs and its accumulator dies -- layer 1 holds four registers, not 64);
@@ -284,29 +400,44 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
       hb2[i] = opaque(L::H2 + img_addr(4 * g + i, trow));
     }
     f32x4 acc2[16];
-    fwd_issue(0);
-    fwd_issue(1);
+    f32x4 hw[16];          // float32 fragments of the head (forward), then of dh2: [tile][lane] x 16 bytes
+    const f32x4* hp = reinterpret_cast<const f32x4*>(W.W3c) + lane;
+    const f32x4* bp = reinterpret_cast<const f32x4*>(W.W3bc) + lane;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc2[t] = *reinterpret_cast<const f32x4*>(&lds[L::B2 + 16 * t + 4 * g]);
+    if (!primed) {         // (the first tile; later tiles had their first two segments started under the previous tile's dW1 phase)
+      fwd_issue(0);
+      fwd_issue(1);
+    }
     CHAIN_WAIT_DMA(true);
     CHAIN_BARRIER();       // also: the previous tile's last reads of the images are complete everywhere
+    STAMP(18)
     fwd_issue(2);
-    X3Frag Wc = ring_read(ringl, 0), Wn;
+    RingW Wr;
+    Wr.p0[0] = ring_read_piece(ringl, 0, 0); Wr.p1 = ring_read_piece(ringl, 0, 1); Wr.p2 = ring_read_piece(ringl, 0, 2);
     X3Frag Bc, Bn;         // B fragment of the current / next layer-2 k step
     float hv[8];           // float32 elements of the B fragment being prepared
     f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, pend = c1;   // layer 1: the tile being accumulated / the finished tile awaiting its tanh
+    f32x4 cn = *reinterpret_cast<const f32x4*>(&lds[L::B1 + 4 * g]);   // the bias the next tile starts from, read one unit ahead
     static_for<0, NUF>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (u == NU1) { STAMP(1) }
+      if constexpr (u == NUF - 2 * CSEG) {   // the head's weight fragments (16 KB from L2): two ring segments ahead of their use
+#pragma unroll
+        for (int t = 0; t < 16; ++t) hw[t] = hp[64 * t];
+      }
       if constexpr ((u + 1) % CSEG == 0 && u + 1 < NUF) {
         constexpr int q = (u + 1) / CSEG;
         CHAIN_WAIT_DMA(q + 1 < NSF);
         CHAIN_BARRIER();
         if constexpr (q + 2 < NSF) fwd_issue(q + 2);
       }
-      if constexpr (u + 1 < NUF) Wn = ring_read(ringl, (u + 1) % CSLOTS);
       if constexpr (u < NU1) {
         constexpr int t = u / K1, ks = u % K1;
-        if constexpr (ks == 0) c1 = *reinterpret_cast<const f32x4*>(&lds[L::B1 + 16 * t + 4 * g]);
-        X3C_MFMA6(Wc, xp[ks], c1)
+        if constexpr (ks == 0) c1 = cn;
+        if constexpr (ks == K1 - 1 && t + 1 < 16) cn = *reinterpret_cast<const f32x4*>(&lds[L::B1 + 16 * (t + 1) + 4 * g]);
+        CHAIN_UNIT(Wr, u & 1, xp[ks], c1, u + 1 < NUF, (u + 1) % CSLOTS)
         if constexpr (t > 0 && ks == 0) {   // the previous tile: tanh -> h1 image
 #pragma unroll
           for (int i = 0; i < 4; ++i) lds[hb1[i] + 1024 * (t - 1)] = fast_tanh_scaled(pend[i]);
@@ -318,8 +449,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) lds[hb1[i] + 1024 * 15] = fast_tanh_scaled(pend[i]);
         }
-        if constexpr (ks == 0) acc2[t] = *reinterpret_cast<const f32x4*>(&lds[L::B2 + 16 * t + 4 * g]);
-        X3C_MFMA6(Wc, Bc, acc2[t])
+        CHAIN_UNIT(Wr, u & 1, Bc, acc2[t], u + 1 < NUF, (u + 1) % CSLOTS)
       }
       // side work: the B fragment of layer-2 k step sn, prepared in the sixteen units in front of it (sn = 0: the last sixteen
       // units of layer 1, by which time tiles 0 and 1 of h1 are in the image): eight reads, then four pair-splits
@@ -337,27 +467,30 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
         }
         if constexpr (c == 15) Bc = Bn;
       }
-      Wc = Wn;
     });
     // every wave is done with the ring: its space beyond the first four units becomes the h2 image
     CHAIN_BARRIER();
+    STAMP(2)
 
     // ============================ h2 = tanh, head (float32 16x16x4), loss, dout ============================
     f32x4 mean = {0.f, 0.f, 0.f, 0.f};
     {
-      const f32x4* hp = reinterpret_cast<const f32x4*>(W.W3c) + lane;
+      f32x4 mean2 = mean;   // two accumulation chains (even / odd tiles): a dependent v_mfma_f32_16x16x4_f32 waits 40 cycles, an independent one 32
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        if (t % 4 == 0) __builtin_amdgcn_sched_barrier(0);   // four tiles' pack loads at a time (hoisted together: 64 registers)
-        const f32x4 wv = hp[64 * t];
+        const f32x4 wv = hw[t];
+        hw[t] = bp[64 * t];                      // dh2's fragment of this tile takes the register the head's just left
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float h = fast_tanh_scaled(acc2[t][i]);
           acc2[t][i] = h;
           lds[hb2[i] + 1024 * t] = h;
-          mean = MFMA16(wv[i], h, mean);
+          if (t & 1) mean2 = MFMA16(wv[i], h, mean2);
+          else mean = MFMA16(wv[i], h, mean);
         }
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mean[i] += mean2[i];
     }
     f32x4 dout = {0.f, 0.f, 0.f, 0.f};
     {
@@ -408,15 +541,14 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
           g_b3[0] += dout[0];
         }
       }
-      *reinterpret_cast<f32x4*>(&lds[L::DO + trow * 16 + 4 * g]) = dout;   // dout image [64 rows][16]
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lds[L::DO + img_addr(4 * g + i, trow)] = dout[i];   // dout image [16 head rows][64 batch rows], swizzled like the others
     }
     // dh2 = W3^T dout (float32 16x16x4: k slot g of step i = head row 4 g + i), dz2 = dh2 (1 - h2^2): in registers
     {
-      const f32x4* bp = reinterpret_cast<const f32x4*>(W.W3bc) + lane;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        if (t % 4 == 0) __builtin_amdgcn_sched_barrier(0);
-        const f32x4 wv = bp[64 * t];
+        const f32x4 wv = hw[t];
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) c = MFMA16(wv[i], dout[i], c);
@@ -424,45 +556,58 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
         for (int i = 0; i < 4; ++i) acc2[t][i] = c[i] * (1.0f - acc2[t][i] * acc2[t][i]);
       }
     }
-    __syncthreads();   // h2 image and dout image complete
+    STAMP(3)
+    LDS_BARRIER();   // h2 image and dout image complete
+    STAMP(4)
 
     // ============================ dW3 += dout^T . h2 (float32 16x16x4; this wave's 64 columns) ============================
     {
+      // k slot kk of MFMA step s carries batch row 16 kk + s: a lane's sixteen steps are sixteen CONSECUTIVE rows of its columns, i.e.
+      // four 16-byte chunks each of the transposed images (the first version read row 4 s + kk: five ds_read_b32 per step, 2-way conflicts)
       const int i16 = lane & 15, kk = lane >> 4;
-      const int ao = opaque(L::DO + kk * 16 + i16);                       // A[a][k = row] = dout[row][a]
-      int bo[4];
+      const int ao = opaque4(L::DO + i16 * 64);                                   // A[a][k] = dout[row][a]: column a = i16 of the dout image
+      const int bo = opaque4(L::H2 + (64 * wave + i16) * 64);                      // B[k][column 64 wave + 16 b + i16] = h2[row][column]
 #pragma unroll
-      for (int b = 0; b < 4; ++b) bo[b] = opaque(L::H2 + (64 * wave + 16 * b + i16) * 64 + kk);   // B[k = row][column]; chunk: below
-      const int sw = i16;   // (column & 15): the swizzle of this lane's four columns (they differ by multiples of 16)
-#pragma unroll 4
-      for (int s = 0; s < 16; ++s) {   // batch rows 4 s .. 4 s + 3: chunk s of the column
-        const float x = lds[ao + 64 * s];
-        const int ch = ((s ^ sw) & 15) << 2;
-        const float y0 = lds[bo[0] + ch], y1 = lds[bo[1] + ch], y2 = lds[bo[2] + ch], y3 = lds[bo[3] + ch];
-        mfma16_x1y4(gW3h0, gW3h1, gW3h2, gW3h3, x, y0, y1, y2, y3);
+      for (int q = 0; q < 4; ++q) {                                               // rows 16 kk + 4 q .. + 3 = chunk 4 kk + q
+        const int ch = (((4 * kk + q) ^ i16) & 15) << 2;
+        const f32x4 xa = *reinterpret_cast<const f32x4*>(&lds[ao + ch]);
+        const f32x4 y0 = *reinterpret_cast<const f32x4*>(&lds[bo + ch]);
+        const f32x4 y1 = *reinterpret_cast<const f32x4*>(&lds[bo + 16 * 64 + ch]);
+        const f32x4 y2 = *reinterpret_cast<const f32x4*>(&lds[bo + 32 * 64 + ch]);
+        const f32x4 y3 = *reinterpret_cast<const f32x4*>(&lds[bo + 48 * 64 + ch]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mfma16_x1y4(gW3h0, gW3h1, gW3h2, gW3h3, xa[e], y0[e], y1[e], y2[e], y3[e]);
       }
     }
-    __syncthreads();   // the h2 image has been read: dz2 overwrites it
+    STAMP(5)
+    LDS_BARRIER();   // the h2 image has been read: dz2 overwrites it
 #pragma unroll
     for (int t = 0; t < 16; ++t)
 #pragma unroll
       for (int i = 0; i < 4; ++i) lds[hb2[i] + 1024 * t] = acc2[t][i];
-    __syncthreads();   // dz2 image complete
+    LDS_BARRIER();   // dz2 image complete
+    STAMP(6)
 
     // ============================ dW2 += dz2^T . h1 (bf16 pipe, K = 64 rows; this wave: 64 neurons x 256 inputs) ============================
     int nsrc = -1;
     {
       const int r = lane & 31, h = lane >> 5;
       // a lane's fragment: rows 16 ks + 8 h .. + 7 of one column = chunks 4 ks + 2 h, + 1 (the second = the first ^ 1)
-      const int ao = opaque(L::H2 + (64 * wave + r) * 64 + ((((2 * h) ^ r) & 15) << 2));
-      const int bo = opaque(L::H1 + r * 64 + ((((2 * h) ^ r) & 15) << 2));
-      const int co = opaque(L::H2 + tid * 64);
+      const int ao = opaque4(L::H2 + (64 * wave + r) * 64 + ((((2 * h) ^ r) & 15) << 2));
+      const int bo = opaque4(L::H1 + r * 64 + ((((2 * h) ^ r) & 15) << 2));
+      const int co = opaque4(L::H2 + tid * 64);
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
       nsrc = (has_next && nrow0 + trow < a.count) ? a.rows[nrow0 + trow] : -1;   // level 1 of the next tile's gathers
+      // The two dz2 fragments of k step ks + 1 are read at the top of step ks and split between the MFMAs of its last two input
+      // blocks (jb = 6, 7 carry no h1 split of their own: the fragment ring of h1 ends there) -- the first version split them in
+      // front of every step, 600 cycles with the matrix pipe idle.
+      X3Frag A0 = col_frag_split(img_frag_load(ao)), A1 = col_frag_split(img_frag_load(ao + 32 * 64));
 #pragma unroll 1
       for (int ks = 0; ks < CR / 16; ++ks) {
         const int kx = ks << 4;   // chunk bits 2..3 of the address
-        const X3Frag A0 = col_frag_split(img_frag_load(ao ^ kx)), A1 = col_frag_split(img_frag_load((ao + 32 * 64) ^ kx));
+        const int kn = (ks + 1 < CR / 16 ? ks + 1 : ks) << 4;
+        const ColFrag rA0 = img_frag_load(ao ^ kn), rA1 = img_frag_load((ao + 32 * 64) ^ kn);
+        X3Frag nA0, nA1;
         {  // db2: column `tid` of dz2 over these sixteen rows (four chunks), rows = 0..3 (mod 4) -> s0..s3
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
@@ -470,25 +615,52 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
             s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
           }
         }
-        X3Frag B = col_frag_split(img_frag_load(bo ^ kx));
-        ColFrag raw = img_frag_load((bo + 32 * 64) ^ kx);
+        const int b0x = bo ^ kx, b1x = b0x ^ 4;   // (the k-step bits 4, 5 of the address and the column-block offsets, multiples of 2048, do not interact)
+        X3Frag B = col_frag_split(img_frag_load_at(b0x, b1x, 0));
+        ColFrag raw = img_frag_load_at(b0x, b1x, 32 * 64);
 #pragma unroll
         for (int jb = 0; jb < 8; ++jb) {
           X3Frag Bn2;
           __builtin_amdgcn_sched_barrier(0);
-          const ColFrag raw2 = img_frag_load((bo + 32 * 64 * (jb + 2 < 8 ? jb + 2 : 7)) ^ kx);
-          dw2_x3_block(gW2[jb], gW2[8 + jb], A0, A1, B, raw, Bn2);
-          B = Bn2;
-          raw = raw2;
+          if (jb < 6) {
+            const ColFrag raw2 = img_frag_load_at(b0x, b1x, 32 * 64 * (jb + 2));
+            dw2_block<true>(gW2[jb], gW2[8 + jb], A0, A1, B, raw, Bn2);
+            B = Bn2;
+            raw = raw2;
+          } else if (jb == 6) {
+            dw2_block<true>(gW2[jb], gW2[8 + jb], A0, A1, B, raw, Bn2);   // splits the last h1 fragment of this step
+            B = Bn2;
+          } else {
+            dw2_block2(gW2[jb], gW2[8 + jb], A0, A1, B, rA0, nA0, rA1, nA1);   // splits the next step's two dz2 fragments
+          }
         }
+        A0 = nA0; A1 = nA1;
       }
       gb2 += (s0 + s1) + (s2 + s3);
     }
-    __syncthreads();   // the dz2 image has been read: its space is ring again
+    STAMP(7)
+    LDS_BARRIER();   // the dz2 image has been read: its space is ring again
+    STAMP(8)
 
     // ============================ dh1 = W2^T dz2 (chain; B fragments from the dz2 registers), dz1 = dh1 (1 - h1^2) ============================
     // Two passes over the k steps, eight neuron tiles of dh1 each (pack W2bc: [half][k step][tile of the half]): 32 accumulator
     // registers instead of 64 next to the 64 of dz2.  B fragment of k step s: dz2 tiles 2 s, 2 s + 1, split one step ahead.
+    // dW1's accumulators START from the workgroup's running sums in its slab (no registers held across tiles, none for a copy):
+    // loaded behind the last MFMA of this phase (sc1: past the vector L1 -- the lines were written by this lane one tile ago), due
+    // at the first MFMA of the dW1 phase.
+    constexpr bool two_ = DP > 32;
+    constexpr int NGL = 2 * K1 + 2;   // vector loads of gather_tile, issued behind the slab loads and allowed to stay in flight
+    const unsigned sb1 = (unsigned)(wave * 4 * 4 * 64 + lane) * 16u;
+    f32x16 gW1a = zero16(), gW1b = zero16(), gW1c = zero16(), gW1d = zero16();   // [ib][jb] = 00, 10, 01, 11 -> slab tiles 0, 2, 1, 3
+    auto slab_w1_load = [&](f32x16& acc, int tile_idx) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        f32x4 v;
+        asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(v) : "v"(sb1 + (unsigned)(tile_idx * 4 + qd) * 1024u), "s"(slab_w1) : "memory");
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * qd + e] = v[e];
+      }
+    };
     auto bwd_issue = [&](int q) {
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
@@ -508,8 +680,9 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
       }
       CHAIN_WAIT_DMA(true);
       CHAIN_BARRIER();
+      STAMP(16)
       bwd_issue(2);
-      Wc = ring_read(ringl, 0);
+      Wr.p0[0] = ring_read_piece(ringl, 0, 0); Wr.p1 = ring_read_piece(ringl, 0, 1); Wr.p2 = ring_read_piece(ringl, 0, 2);
       static_for<0, NUB>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         __builtin_amdgcn_sched_barrier(0);
@@ -519,10 +692,9 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
           CHAIN_BARRIER();
           if constexpr (q + 2 < NSB) bwd_issue(q + 2);
         }
-        if constexpr (u + 1 < NUB) Wn = ring_read(ringl, (u + 1) % CSLOTS);
         constexpr int half = u / 64, ks = (u % 64) / 8, t8 = u % 8;
         if constexpr (ks == 0) acc4[t8] = f32x4{0.f, 0.f, 0.f, 0.f};
-        X3C_MFMA6(Wc, Bc, acc4[t8])
+        CHAIN_UNIT(Wr, u & 1, Bc, acc4[t8], u + 1 < NUB, (u + 1) % CSLOTS)
         constexpr int sn = (ks + 1) % 8;           // the next k step (the second pass starts over at 0)
         if constexpr (u + 1 < NUB && t8 >= 4) {
           constexpr int jp = t8 - 4, e0 = 2 * jp, e1 = 2 * jp + 1;
@@ -531,7 +703,14 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
           Bn.p[0][jp] = p1; Bn.p[1][jp] = p2; Bn.p[2][jp] = p3;
           if constexpr (t8 == 7) Bc = Bn;
         }
-        Wc = Wn;
+        if constexpr (u == NUB - 1) {
+          STAMP(17)
+          if (!first_tile && !(MOBROB_CHAIN_SKIP & 16)) {
+            slab_w1_load(gW1a, 0);
+            slab_w1_load(gW1b, 2);
+            if constexpr (two_) { slab_w1_load(gW1c, 1); slab_w1_load(gW1d, 3); }
+          }
+        }
         if constexpr (u % 64 == 63) {
           // dz1 over h1, in place, for the eight tiles of this pass (every lane rewrites exactly the elements it wrote in the
           // forward pass; dW2's reads of the h1 image are complete everywhere: all waves have passed this phase's first barrier)
@@ -546,76 +725,102 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
         }
       });
     }
-    // level 2 of the next tile's gathers: in flight under dW1 (LDS operands only)
-    gather_tile(nsrc, g);
-    __syncthreads();   // dz1 image complete (and every wave is done with the ring)
+    STAMP(9)
+    // level 2 of the next tile's gathers: in flight under dW1 (LDS operands only) and into the next tile
+    if (!(MOBROB_CHAIN_SKIP & 32)) gather_tile(nsrc, g);
+    LDS_BARRIER();   // dz1 image complete (and every wave is done with the ring)
+    STAMP(10)
+    primed = has_next;
+    if (primed) {      // the next tile's first two ring segments: their L2 latency runs under this tile's dW1 phase
+      fwd_issue(0);
+      fwd_issue(1);
+    }
 
     // ============================ dW1 += dz1^T . X (bf16 pipe; this wave: 64 neurons x DP inputs), added to the slab ============================
     {
       constexpr bool two = DP > 32;
       const int r = lane & 31, h = lane >> 5;
-      const int ao = opaque(L::H1 + (64 * wave + r) * 64 + ((((2 * h) ^ r) & 15) << 2));
+      const int ao = opaque4(L::H1 + (64 * wave + r) * 64 + ((((2 * h) ^ r) & 15) << 2));
       const int c0 = (r < DP) ? r : 0;
       const int c1 = (32 + r < DP) ? 32 + r : c0;   // clamped columns are never read back
-      const int b0o = opaque(L::XI + c0 * 64 + ((((2 * h) ^ c0) & 15) << 2)), b1o = opaque(L::XI + c1 * 64 + ((((2 * h) ^ c1) & 15) << 2));
-      const int co = opaque(L::H1 + tid * 64);
+      const int b0o = opaque4(L::XI + c0 * 64 + ((((2 * h) ^ c0) & 15) << 2)), b1o = opaque4(L::XI + c1 * 64 + ((((2 * h) ^ c1) & 15) << 2));
+      const int co = opaque4(L::H1 + tid * 64);
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      f32x16 gW1a = zero16(), gW1b = zero16(), gW1c = zero16(), gW1d = zero16();   // [ib][jb] = 00, 10, 01, 11
+      // Software pipeline over the four k steps of sixteen rows: while the six MFMA statements of step ks run (four MFMAs each at
+      // DP = 64), the fragments of step ks + 1 -- read from LDS at the top of the step -- are split pair by pair between them
+      // (the first version split everything in front of the MFMAs: 12.5 k cycles per tile for 3 k of matrix time).
+      X3Frag A0 = col_frag_split(img_frag_load(ao)), A1 = col_frag_split(img_frag_load(ao + 32 * 64));
+      X3Frag B0 = col_frag_split(img_frag_load(b0o)), B1 = B0;
+      if (two) B1 = col_frag_split(img_frag_load(b1o));
+      STAMP(13)
+      // the slab loads have landed (the gathers behind them, and the twelve ring DMAs of a primed next tile, may still be in flight)
+      if (primed) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(gW1a), "+v"(gW1b), "+v"(gW1c), "+v"(gW1d) : "n"(NGL + 12) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(gW1a), "+v"(gW1b), "+v"(gW1c), "+v"(gW1d) : "n"(NGL) : "memory");
+      STAMP(14)
 #pragma unroll 1
       for (int ks = 0; ks < CR / 16; ++ks) {
-        const int kx = ks << 4;
-        const X3Frag A0 = col_frag_split(img_frag_load(ao ^ kx)), A1 = col_frag_split(img_frag_load((ao + 32 * 64) ^ kx));
-        const X3Frag B0 = col_frag_split(img_frag_load(b0o ^ kx));
-        X3Frag B1 = B0;
-        if (two) B1 = col_frag_split(img_frag_load(b1o ^ kx));
+        const int kn = (ks + 1 < CR / 16 ? ks + 1 : ks) << 4;   // the last step re-reads its own rows (unused)
+        const ColFrag rA0 = img_frag_load(ao ^ kn), rA1 = img_frag_load((ao + 32 * 64) ^ kn);
+        const ColFrag rB0 = img_frag_load(b0o ^ kn);
+        ColFrag rB1 = rB0;
+        if (two) rB1 = img_frag_load(b1o ^ kn);
+        X3Frag nA0, nA1, nB0, nB1;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[co + ((((4 * ks + c) ^ tid) & 15) << 2)]);
           s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
         }
         asm volatile("s_nop 1");
+        // 24 (12) MFMAs, a half-split behind each: 16 (12) pair-splits = 32 (24) halves; the surplus of the wide case doubles up at the end
+        SplitMid m, m2;
+#define DW1_Q(ia, ib, S0, S1, S2, S3)                                              \
+        MFMA_V1(gW1a, A0.p[ia], B0.p[ib]); S0; PIN();                              \
+        MFMA_V1(gW1b, A1.p[ia], B0.p[ib]); S1; PIN();                              \
+        if (two) { MFMA_V1(gW1c, A0.p[ia], B1.p[ib]); S2; PIN();                   \
+                   MFMA_V1(gW1d, A1.p[ia], B1.p[ib]); S3; PIN(); }
         if (two) {
-          DW1X_MFMA4(1, 1); DW1X_MFMA4(0, 2); DW1X_MFMA4(2, 0); DW1X_MFMA4(0, 1); DW1X_MFMA4(1, 0); DW1X_MFMA4(0, 0);
+          DW1_Q(1, 1, split_half1(rA0.v[0], rA0.v[1], m), split_half2(m, 0, nA0), split_half1(rA0.v[2], rA0.v[3], m), split_half2(m, 1, nA0))
+          DW1_Q(0, 2, split_half1(rA0.v[4], rA0.v[5], m), split_half2(m, 2, nA0), split_half1(rA0.v[6], rA0.v[7], m), split_half2(m, 3, nA0))
+          DW1_Q(2, 0, split_half1(rA1.v[0], rA1.v[1], m), split_half2(m, 0, nA1), split_half1(rA1.v[2], rA1.v[3], m), split_half2(m, 1, nA1))
+          DW1_Q(0, 1, split_half1(rA1.v[4], rA1.v[5], m), split_half2(m, 2, nA1), split_half1(rA1.v[6], rA1.v[7], m), split_half2(m, 3, nA1))
+          DW1_Q(1, 0, (split_half1(rB0.v[0], rB0.v[1], m), split_half1(rB0.v[2], rB0.v[3], m2)), (split_half2(m, 0, nB0), split_half2(m2, 1, nB0)),
+                (split_half1(rB0.v[4], rB0.v[5], m), split_half1(rB0.v[6], rB0.v[7], m2)), (split_half2(m, 2, nB0), split_half2(m2, 3, nB0)))
+          DW1_Q(0, 0, (split_half1(rB1.v[0], rB1.v[1], m), split_half1(rB1.v[2], rB1.v[3], m2)), (split_half2(m, 0, nB1), split_half2(m2, 1, nB1)),
+                (split_half1(rB1.v[4], rB1.v[5], m), split_half1(rB1.v[6], rB1.v[7], m2)), (split_half2(m, 2, nB1), split_half2(m2, 3, nB1)))
         } else {
-          DW1X_MFMA2(1, 1); DW1X_MFMA2(0, 2); DW1X_MFMA2(2, 0); DW1X_MFMA2(0, 1); DW1X_MFMA2(1, 0); DW1X_MFMA2(0, 0);
+          DW1_Q(1, 1, (split_half1(rA0.v[0], rA0.v[1], m), split_half1(rA0.v[2], rA0.v[3], m2)), (split_half2(m, 0, nA0), split_half2(m2, 1, nA0)), (void)0, (void)0)
+          DW1_Q(0, 2, (split_half1(rA0.v[4], rA0.v[5], m), split_half1(rA0.v[6], rA0.v[7], m2)), (split_half2(m, 2, nA0), split_half2(m2, 3, nA0)), (void)0, (void)0)
+          DW1_Q(2, 0, (split_half1(rA1.v[0], rA1.v[1], m), split_half1(rA1.v[2], rA1.v[3], m2)), (split_half2(m, 0, nA1), split_half2(m2, 1, nA1)), (void)0, (void)0)
+          DW1_Q(0, 1, (split_half1(rA1.v[4], rA1.v[5], m), split_half1(rA1.v[6], rA1.v[7], m2)), (split_half2(m, 2, nA1), split_half2(m2, 3, nA1)), (void)0, (void)0)
+          DW1_Q(1, 0, (split_half1(rB0.v[0], rB0.v[1], m), split_half1(rB0.v[2], rB0.v[3], m2)), (split_half2(m, 0, nB0), split_half2(m2, 1, nB0)), (void)0, (void)0)
+          DW1_Q(0, 0, (split_half1(rB0.v[4], rB0.v[5], m), split_half1(rB0.v[6], rB0.v[7], m2)), (split_half2(m, 2, nB0), split_half2(m2, 3, nB0)), (void)0, (void)0)
+          nB1 = nB0;
         }
+#undef DW1_Q
+        A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
       }
       asm volatile("s_nop 15\n\ts_nop 7" : "+v"(gW1a), "+v"(gW1b), "+v"(gW1c), "+v"(gW1d));   // opaque MFMA statements: XDL write -> VALU read
+      STAMP(15)
       gb1 += (s0 + s1) + (s2 + s3);
-      // slab += tile (fragment order [w][tile][quad][lane] x 16 B, as k_fused_train stores it); the first tile stores.  The loads
-      // bypass the vector L1 (sc1): the line was written by this lane one tile ago.
-      const unsigned sb = (unsigned)(wave * 4 * 4 * 64 + lane) * 16u;
-      constexpr int NT1 = two ? 4 : 2;
-      f32x4 old[NT1 * 4];
-      if (!first_tile) {
-#pragma unroll
-        for (int k = 0; k < NT1 * 4; ++k) {
-          const int tile_idx = two ? (k >> 2) : 2 * (k >> 2);   // tiles 0 1 2 3, or 0 2 (one input block)
-          asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(old[k]) : "v"(sb + (unsigned)(tile_idx * 4 + (k & 3)) * 1024u), "s"(slab_w1) : "memory");
-        }
-        if constexpr (two)
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]), "+v"(old[7]),
-                       "+v"(old[8]), "+v"(old[9]), "+v"(old[10]), "+v"(old[11]), "+v"(old[12]), "+v"(old[13]), "+v"(old[14]), "+v"(old[15]) :: "memory");
-        else
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]), "+v"(old[7]) :: "memory");
-      } else {
-#pragma unroll
-        for (int k = 0; k < NT1 * 4; ++k) old[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      auto rmw = [&](const f32x16& gacc, int tile_idx, int k0) {
+      // the new running sums go back to the slab (fragment order [w][tile][quad][lane] x 16 B, as k_fused_train stores it)
+      auto put = [&](const f32x16& gacc, int tile_idx) {
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
-          const f32x4 o = old[k0 + qd];
-          const f32x4 v = {gacc[4 * qd] + o[0], gacc[4 * qd + 1] + o[1], gacc[4 * qd + 2] + o[2], gacc[4 * qd + 3] + o[3]};
-          stg16(slab_w1, sb + (unsigned)(tile_idx * 4 + qd) * 1024u, v);
+          const f32x4 v = {gacc[4 * qd], gacc[4 * qd + 1], gacc[4 * qd + 2], gacc[4 * qd + 3]};
+          if (!(MOBROB_CHAIN_SKIP & 8)) stg16(slab_w1, sb1 + (unsigned)(tile_idx * 4 + qd) * 1024u, v);
+          else asm volatile("" :: "v"(v));
         }
       };
-      if constexpr (two) { rmw(gW1a, 0, 0); rmw(gW1c, 1, 4); rmw(gW1b, 2, 8); rmw(gW1d, 3, 12); }
-      else { rmw(gW1a, 0, 0); rmw(gW1b, 2, 4); }
+      put(gW1a, 0);
+      put(gW1b, 2);
+      if constexpr (two) { put(gW1c, 1); put(gW1d, 3); }
     }
     first_tile = false;
-    __syncthreads();   // images are rewritten by the next tile
+    STAMP(11)
+    LDS_BARRIER();   // images are rewritten by the next tile
+    STAMP(12)
   }
+  STAMP_FLUSH()
 
   const int tid = tid0, lane = tid & 63;
   // ---- store this workgroup's partial gradients to its slab (k_fused_train's layout) ----

@@ -1,0 +1,75 @@
+// Probe (not a product path): what paces the unit loop of k_chain_train -- six v_mfma_f32_16x16x32_bf16 per unit into one of sixteen
+// accumulator tiles, the unit's three weight pieces read from LDS by all four waves.  Variants:
+//   0: MFMAs only, one accumulator chain of six per unit (operands in registers)      1: the same, two units interleaved (a b a b ..)
+//   2: variant 0 + the three ds_read_b128 of the next unit                            3: variant 1 + reads
+//   4: variant 2 with 32x32x16 MFMAs instead (three per unit: same flops per unit... reference for the issue budget)
+//   hipcc --offload-arch=gfx950 -O3 -o scratch/chain_loop_probe scratch/chain_loop_probe.hip && scratch/chain_loop_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+extern __shared__ __attribute__((aligned(16))) float lds[];
+#define M16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), (c), 0, 0, 0)
+template <int V>
+__global__ __launch_bounds__(256, 1) void k(int iters, float* out, unsigned long long* cyc) {
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < 24 * 768; i += 256) lds[i] = 1e-3f * (float)(i & 1023);
+  __syncthreads();
+  f32x4 acc[16];
+  for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 x0, x1, x2, w0, w1, w2, n0, n1, n2;
+  for (int i = 0; i < 4; ++i) { x0[i] = 0x3f803f80u + lane; x1[i] = 0x3c003c00u; x2[i] = 0x38003800u; w0[i] = 0x3f003f00u + i; w1[i] = 0x3b003b00u; w2[i] = 0x37003700u; }
+  n0 = w0; n1 = w1; n2 = w2;
+  int base = 4 * lane;
+  asm volatile("" : "+v"(base));
+  base = 4 * (base >> 2);
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 16; u += (V & 1) ? 2 : 1) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (V & 2) {
+        const int slot = (u + 1 + 16 * (it & 1)) % 24;
+        n0 = *reinterpret_cast<const u32x4*>(&lds[base + slot * 768]);
+        n1 = *reinterpret_cast<const u32x4*>(&lds[base + slot * 768 + 256]);
+        n2 = *reinterpret_cast<const u32x4*>(&lds[base + slot * 768 + 512]);
+      }
+      if (V & 1) {
+        f32x4 &a = acc[u], &b = acc[u + 1];
+        a = M16(w2, x0, a); b = M16(w2, x0, b); a = M16(w1, x1, a); b = M16(w1, x1, b); a = M16(w1, x0, a); b = M16(w1, x0, b);
+        a = M16(w0, x2, a); b = M16(w0, x2, b); a = M16(w0, x1, a); b = M16(w0, x1, b); a = M16(w0, x0, a); b = M16(w0, x0, b);
+      } else {
+        f32x4& a = acc[u];
+        a = M16(w2, x0, a); a = M16(w1, x1, a); a = M16(w1, x0, a); a = M16(w0, x2, a); a = M16(w0, x1, a); a = M16(w0, x0, a);
+      }
+      if (V & 2) { w0 = n0; w1 = n1; w2 = n2; }
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int t = 0; t < 16; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+template <int V>
+void run(const char* name, float* out, unsigned long long* cyc) {
+  const int iters = 2000;
+  hipFuncSetAttribute((const void*)k<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 768 * 4);
+  hipLaunchKernelGGL((k<V>), dim3(256), dim3(256), 24 * 768 * 4, 0, 10, out, cyc);
+  hipDeviceSynchronize();
+  hipLaunchKernelGGL((k<V>), dim3(256), dim3(256), 24 * 768 * 4, 0, iters, out, cyc);
+  hipDeviceSynchronize();
+  unsigned long long h; hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+  printf("%-72s %.1f cycles per unit of six MFMAs (96 = the matrix pipe's own time)\n", name, (double)h / (16.0 * iters));
+}
+int main() {
+  float* out; unsigned long long* cyc;
+  hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 8);
+  run<0>("six dependent 16x16x32 MFMAs per unit, operands in registers", out, cyc);
+  run<1>("two units interleaved (independent neighbours), operands in registers", out, cyc);
+  run<2>("six dependent MFMAs + the next unit's three ds_read_b128", out, cyc);
+  run<3>("two units interleaved + reads (one weight fragment feeds both: not the kernel's data flow)", out, cyc);
+  return 0;
+}
