@@ -82,11 +82,9 @@ __device__ __forceinline__ u32x4 ring_read_piece(int ring_lane_f0, int slot, int
 #define CHAIN_UNIT(Wr, par, X_, C_, have_next, nslot)                                        \
   if (have_next) Wr.p0[(par) ^ 1] = ring_read_piece(ringl, nslot, 0);                        \
   C_ = MFMA16B(Wr.p2, X_.p[0], C_);                                                          \
-  __builtin_amdgcn_sched_barrier(0);                                                         \
   if (have_next) Wr.p2 = ring_read_piece(ringl, nslot, 2);                                   \
   C_ = MFMA16B(Wr.p1, X_.p[1], C_);                                                          \
   C_ = MFMA16B(Wr.p1, X_.p[0], C_);                                                          \
-  __builtin_amdgcn_sched_barrier(0);                                                         \
   if (have_next) Wr.p1 = ring_read_piece(ringl, nslot, 1);                                   \
   C_ = MFMA16B(Wr.p0[par], X_.p[2], C_);                                                     \
   C_ = MFMA16B(Wr.p0[par], X_.p[1], C_);                                                     \
@@ -180,15 +178,17 @@ __device__ __forceinline__ X3Frag x3_split8v(const float (&v)[8]) {
 // SECOND MFMA (two-MFMA statements): one gap empty, the next 20 cycles over budget -- its x3 phases ran at 55-65 % of the matrix
 // rate.  Here every gap carries half a split.
 struct SplitMid { unsigned p1; float ra, rb; };
+template <bool NATIVE = false>   // NATIVE: the conversion as the compiler's own instruction (chain side work), else the asm statement (kernels_fused.h cvt_pk_bf16)
 __device__ __forceinline__ void split_half1(float lo, float hi, SplitMid& m) {
-  m.p1 = cvt_pk_bf16(lo, hi);
+  m.p1 = NATIVE ? cvt_pk_bf16_native(lo, hi) : cvt_pk_bf16(lo, hi);
   m.ra = lo - __uint_as_float(m.p1 << 16);
   m.rb = hi - __uint_as_float(m.p1 & 0xffff0000u);
 }
+template <bool NATIVE = false>
 __device__ __forceinline__ void split_half2(const SplitMid& m, int jp, X3Frag& out) {
-  const unsigned p2 = cvt_pk_bf16(m.ra, m.rb);
+  const unsigned p2 = NATIVE ? cvt_pk_bf16_native(m.ra, m.rb) : cvt_pk_bf16(m.ra, m.rb);
   const float sa = m.ra - __uint_as_float(p2 << 16), sb = m.rb - __uint_as_float(p2 & 0xffff0000u);
-  out.p[0][jp] = m.p1; out.p[1][jp] = p2; out.p[2][jp] = cvt_pk_bf16(sa, sb);
+  out.p[0][jp] = m.p1; out.p[1][jp] = p2; out.p[2][jp] = NATIVE ? cvt_pk_bf16_native(sa, sb) : cvt_pk_bf16(sa, sb);
 }
 #define MFMA_A1(acc, a_, b_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a_), "v"(b_))
 #define MFMA_V1(acc, a_, b_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a_), "v"(b_))
@@ -284,8 +284,8 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
   float* slab_w1 = slab + slab_off_w1();
   float* slab_w3 = slab + slab_off_w3(DP);
   float gb2 = 0.f, gb1 = 0.f;
-  float s_pl = 0.f, s_vl = 0.f, s_kl = 0.f, s_cf = 0.f;
-  float g_b3[4] = {0.f, 0.f, 0.f, 0.f}, g_ls[4] = {0.f, 0.f, 0.f, 0.f};   // head-bias / log_std gradient of action 4 g + i: this lane's rows
+  // (loss sums and head-bias / log_std gradient sums are folded per tile over the wave's sixteen rows and kept in LDS -- STAT, GACC:
+  //  twelve registers that would otherwise live, unused, through every other phase of the tile)
 
   if (tid0 < 32) {
     const int k = tid0;
@@ -302,6 +302,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
   }
   lds[L::B1 + tid0] = W.b1s[tid0];
   lds[L::B2 + tid0] = W.b2s[tid0];
+  if (tid0 < 128 + 16) lds[L::STAT + tid0] = 0.f;   // STAT [4][4] and GACC [4][2][16] are adjacent
 
   float adv_mean = 0.f, adv_sd = 1.f;
   bool adv_on = false;
@@ -314,6 +315,9 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
     adv_mean = (float)m;
     adv_sd = (float)sqrt(var);
   }
+  // wave-uniform: kept as scalar registers (bit patterns), made vector values only where the loss stage uses them
+  const int adv_mean_s = __builtin_amdgcn_readfirstlane(__float_as_int(adv_mean));
+  const int adv_sd_s = __builtin_amdgcn_readfirstlane(__float_as_int(adv_sd + 1e-8f));
 
   // ---- operands of the tile about to be processed, fetched one tile ahead: this lane's batch row (16 wave + lane & 15), the
   //      eight observation columns 32 s + 8 g .. + 7 of each layer-1 k step, its four actions 4 g .. 4 g + 3 and the record tail
@@ -393,16 +397,11 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
       }
     };
     // this lane's elements of an image: column 16 t + 4 g + i, row trow -> hb[i] + 1024 t
-    int hb1[4], hb2[4];
+    int hb1[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      hb1[i] = opaque(L::H1 + img_addr(4 * g + i, trow));
-      hb2[i] = opaque(L::H2 + img_addr(4 * g + i, trow));
-    }
+    for (int i = 0; i < 4; ++i) hb1[i] = opaque(L::H1 + img_addr(4 * g + i, trow));
     f32x4 acc2[16];
-    f32x4 hw[16];          // float32 fragments of the head (forward), then of dh2: [tile][lane] x 16 bytes
-    const f32x4* hp = reinterpret_cast<const f32x4*>(W.W3c) + lane;
-    const f32x4* bp = reinterpret_cast<const f32x4*>(W.W3bc) + lane;
+    f32x4 hw[8];           // rolling window over the float32 fragments of the head (forward: 16 tiles), then of dh2 (16 tiles): [tile][lane] x 16 bytes
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc2[t] = *reinterpret_cast<const f32x4*>(&lds[L::B2 + 16 * t + 4 * g]);
     if (!primed) {         // (the first tile; later tiles had their first two segments started under the previous tile's dW1 phase)
@@ -417,6 +416,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
     Wr.p0[0] = ring_read_piece(ringl, 0, 0); Wr.p1 = ring_read_piece(ringl, 0, 1); Wr.p2 = ring_read_piece(ringl, 0, 2);
     X3Frag Bc, Bn;         // B fragment of the current / next layer-2 k step
     float hv[8];           // float32 elements of the B fragment being prepared
+    SplitMid sm;           // a pair-split between its two halves
     f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, pend = c1;   // layer 1: the tile being accumulated / the finished tile awaiting its tanh
     f32x4 cn = *reinterpret_cast<const f32x4*>(&lds[L::B1 + 4 * g]);   // the bias the next tile starts from, read one unit ahead
     static_for<0, NUF>([&](auto uc) {
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
       if constexpr (u == NU1) { STAMP(1) }
       if constexpr (u == NUF - 2 * CSEG) {   // the head's weight fragments (16 KB from L2): two ring segments ahead of their use
 #pragma unroll
-        for (int t = 0; t < 16; ++t) hw[t] = hp[64 * t];
+        for (int t = 0; t < 8; ++t) hw[t] = ldg16(W.W3c, lane16 + 1024u * t);   // uniform base + per-lane 32-bit offset: no 64-bit pointer registers
       }
       if constexpr ((u + 1) % CSEG == 0 && u + 1 < NUF) {
         constexpr int q = (u + 1) / CSEG;
@@ -459,11 +459,13 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
         if constexpr (c >= 4 && c < 12) {
           constexpr int e = c - 4;
           hv[e] = lds[hb1[e & 3] + 1024 * (2 * sn + (e >> 2))];
-        } else if constexpr (c >= 12) {
-          constexpr int jp = c - 12;
-          unsigned p1, p2, p3;
-          x3_split2(hv[2 * jp], hv[2 * jp + 1], p1, p2, p3);
-          Bn.p[0][jp] = p1; Bn.p[1][jp] = p2; Bn.p[2][jp] = p3;
+        }
+        // pair jp (elements 2 jp, 2 jp + 1, read in slices 4 + 2 jp, 5 + 2 jp) is split in two halves, slices 6 + 2 jp and 7 + 2 jp:
+        // five or six VALU instructions per unit, not eleven in every fourth
+        if constexpr (c >= 6 && c < 14) {
+          constexpr int jp = (c - 6) >> 1;
+          if constexpr (((c - 6) & 1) == 0) split_half1<true>(hv[2 * jp], hv[2 * jp + 1], sm);
+          else split_half2<true>(sm, jp, Bn);
         }
         if constexpr (c == 15) Bc = Bn;
       }
@@ -473,13 +475,17 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
     STAMP(2)
 
     // ============================ h2 = tanh, head (float32 16x16x4), loss, dout ============================
+    int hb2[4];            // the same elements of the h2 / dz2 image (derived here: four registers that need not live through the ring phases)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hb2[i] = opaque(hb1[i] + (L::H2 - L::H1));
     f32x4 mean = {0.f, 0.f, 0.f, 0.f};
     {
       f32x4 mean2 = mean;   // two accumulation chains (even / odd tiles): a dependent v_mfma_f32_16x16x4_f32 waits 40 cycles, an independent one 32
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        const f32x4 wv = hw[t];
-        hw[t] = bp[64 * t];                      // dh2's fragment of this tile takes the register the head's just left
+        const f32x4 wv = hw[t & 7];
+        // the register the head's fragment just left takes the fragment needed eight tiles later: the head's own for t < 8, then dh2's
+        hw[t & 7] = t < 8 ? ldg16(W.W3c, lane16 + 1024u * (t + 8)) : ldg16(W.W3bc, lane16 + 1024u * (t - 8));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float h = fast_tanh_scaled(acc2[t][i]);
@@ -509,18 +515,21 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
         }
         lp += xor_lane(lp, 16);
         lp += xor_lane(lp, 32);
-        float g_logp = 0.f;
+        float g_logp = 0.f, t_pl = 0.f, t_cf = 0.f, t_kl = 0.f;
+        float am, asd;   // fresh vector copies of the two scalar registers (not hoistable: as loop-carried vector registers one was spilled)
+        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(am), "=v"(asd) : "s"(adv_mean_s), "s"(adv_sd_s));
         if (live) {
           float adv = l_tail[1];
-          if (a.normalize && adv_on) adv = (adv - adv_mean) / (adv_sd + 1e-8f);
+          if (a.normalize && adv_on)   // (scalar registers, re-read here: as loop-carried vector registers one of them was spilled)
+            adv = (adv - am) / asd;
           const float log_ratio = lp - l_tail[0];
           const float ratio = expf(log_ratio);
           const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
           const float s1 = adv * ratio, s2 = adv * fminf(fmaxf(ratio, lo), hi);
           if (g == 0) {
-            s_pl += fminf(s1, s2);
-            s_cf += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
-            s_kl += (ratio - 1.0f) - log_ratio;
+            t_pl = fminf(s1, s2);
+            t_cf = (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
+            t_kl = (ratio - 1.0f) - log_ratio;
           }
           const float in_range = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
           const float w1 = (s1 < s2) ? 1.f : ((s1 > s2) ? 0.f : 0.5f);
@@ -529,16 +538,35 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           dout[i] = g_logp * d[i] * ivv[i];   // zero beyond the head (d = 0, 1/var = 0)
-          g_b3[i] += dout[i];
-          g_ls[i] += (4 * g + i < a.A) ? g_logp * (d[i] * d[i] * ivv[i] - 1.0f) : 0.f;
+          float gm = dout[i], gl = (4 * g + i < a.A) ? g_logp * (d[i] * d[i] * ivv[i] - 1.0f) : 0.f;
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { gm += xor_lane(gm, o); gl += xor_lane(gl, o); }   // over the wave's sixteen rows (lanes of a group)
+          if (brow == 0) {
+            lds[L::GACC + wave * 32 + 4 * g + i] += gm;
+            lds[L::GACC + wave * 32 + 16 + 4 * g + i] += gl;
+          }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { t_pl += xor_lane(t_pl, o); t_cf += xor_lane(t_cf, o); t_kl += xor_lane(t_kl, o); }
+        if (lane == 0) {
+          lds[L::STAT + wave * 4 + 0] += t_pl;
+          lds[L::STAT + wave * 4 + 2] += t_kl;
+          lds[L::STAT + wave * 4 + 3] += t_cf;
         }
       } else {
+        float t_vl = 0.f;
         if (live && g == 0) {
           float sq, gv_;
           value_loss_terms(mean[0] + b3v[0], l_tail[2], a.clip_vf >= 0.f ? l_tail[3] : 0.f, a.clip_vf, sq, gv_);
-          s_vl += sq;
+          t_vl = sq;
           dout[0] = a.vf_coef * gv_ * a.inv_bg;
-          g_b3[0] += dout[0];
+        }
+        float gm = dout[0];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { gm += xor_lane(gm, o); t_vl += xor_lane(t_vl, o); }
+        if (lane == 0) {
+          lds[L::GACC + wave * 32] += gm;
+          lds[L::STAT + wave * 4 + 1] += t_vl;
         }
       }
 #pragma unroll
@@ -548,7 +576,8 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
     {
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        const f32x4 wv = hw[t];
+        const f32x4 wv = hw[t & 7];
+        if (t < 8) hw[t] = ldg16(W.W3bc, lane16 + 1024u * (t + 8));
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) c = MFMA16(wv[i], dout[i], c);
@@ -696,11 +725,10 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
         if constexpr (ks == 0) acc4[t8] = f32x4{0.f, 0.f, 0.f, 0.f};
         CHAIN_UNIT(Wr, u & 1, Bc, acc4[t8], u + 1 < NUB, (u + 1) % CSLOTS)
         constexpr int sn = (ks + 1) % 8;           // the next k step (the second pass starts over at 0)
-        if constexpr (u + 1 < NUB && t8 >= 4) {
-          constexpr int jp = t8 - 4, e0 = 2 * jp, e1 = 2 * jp + 1;
-          unsigned p1, p2, p3;
-          x3_split2(acc2[2 * sn + (e0 >> 2)][e0 & 3], acc2[2 * sn + (e1 >> 2)][e1 & 3], p1, p2, p3);
-          Bn.p[0][jp] = p1; Bn.p[1][jp] = p2; Bn.p[2][jp] = p3;
+        if constexpr (u + 1 < NUB) {               // its B fragment: pair jp in units 2 jp (first half) and 2 jp + 1 (second half) of this step
+          constexpr int jp = t8 >> 1, e0 = 2 * jp, e1 = 2 * jp + 1;
+          if constexpr ((t8 & 1) == 0) split_half1<true>(acc2[2 * sn + (e0 >> 2)][e0 & 3], acc2[2 * sn + (e1 >> 2)][e1 & 3], sm);
+          else split_half2<true>(sm, jp, Bn);
           if constexpr (t8 == 7) Bc = Bn;
         }
         if constexpr (u == NUB - 1) {
@@ -714,14 +742,17 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
         if constexpr (u % 64 == 63) {
           // dz1 over h1, in place, for the eight tiles of this pass (every lane rewrites exactly the elements it wrote in the
           // forward pass; dW2's reads of the h1 image are complete everywhere: all waves have passed this phase's first barrier)
+          // (all thirty-two h1 values are read first: a read-modify-write per element is a chain of dependent LDS round trips --
+          //  every read waits behind the previous write, which may alias it as far as the compiler knows: 4 k cycles per pass)
+          float h1v[32];
 #pragma unroll
           for (int tt = 0; tt < 8; ++tt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int o = hb1[i] + 1024 * (8 * half + tt);
-              const float h = lds[o];
-              lds[o] = acc4[tt][i] * (1.0f - h * h);
-            }
+            for (int i = 0; i < 4; ++i) h1v[4 * tt + i] = lds[hb1[i] + 1024 * (8 * half + tt)];
+#pragma unroll
+          for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lds[hb1[i] + 1024 * (8 * half + tt)] = acc4[tt][i] * (1.0f - h1v[4 * tt + i] * h1v[4 * tt + i]);
         }
       });
     }
@@ -853,31 +884,8 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
   }
   slab[slab_off_b2(DP) + tid] = gb2;
   slab[slab_off_b1(DP) + tid] = gb1;
-  {  // head-bias / log_std gradients: this lane's rows -> the wave's 16 rows (lanes of a group) -> the four waves, fixed order
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        g_b3[i] += xor_lane(g_b3[i], o);
-        g_ls[i] += xor_lane(g_ls[i], o);
-      }
-    }
-    if ((lane & 15) == 0) {
-      const int g = lane >> 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        lds[L::GACC + wave * 32 + 4 * g + i] = g_b3[i];
-        lds[L::GACC + wave * 32 + 16 + 4 * g + i] = g_ls[i];
-      }
-    }
-    const float t0 = wave_sum(s_pl), t1 = wave_sum(s_vl), t2 = wave_sum(s_kl), t3 = wave_sum(s_cf);
-    if (lane == 0) {
-      lds[L::STAT + wave * 4 + 0] = t0;
-      lds[L::STAT + wave * 4 + 1] = t1;
-      lds[L::STAT + wave * 4 + 2] = t2;
-      lds[L::STAT + wave * 4 + 3] = t3;
-    }
-    __syncthreads();
+  {  // head-bias / log_std gradients and loss sums: the four waves' running sums (LDS), added in fixed order
+    LDS_BARRIER();
     if (tid < 32) {
       float b3s = 0.f, lss = 0.f;
       if (tid < 16) {

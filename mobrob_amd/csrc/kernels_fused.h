@@ -598,10 +598,19 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA32B(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), (c), 0, 0, 0)
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {  // round to nearest even, lo in the low half
   unsigned r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
+}
+// The same instruction selected by the compiler from a plain conversion.  Measured (round 4, profiles/r4/chain_variants.txt): in the
+// MFMA-dense weight-gradient loops the asm form is the faster one -- with the conversion visible the compiler recomputes single
+// conversions for the residuals and SLP-packs the subtractions into v_pk_add_f32, which is slow beside MFMAs (dW2 16.3 k -> 21.4 k
+// cycles per tile) --, in the side work of the chain loops (few instructions between v_mfma_f32_16x16x32_bf16) the native form (dh1 25.0 k -> 23.3 k).
+__device__ __forceinline__ unsigned cvt_pk_bf16_native(float lo, float hi) {
+  const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
 }
 __device__ __forceinline__ void x3_split2(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
   p1 = cvt_pk_bf16(a, b);
