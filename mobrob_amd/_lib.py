@@ -108,6 +108,7 @@ SYMBOLS = {
     "mobrob_ppo_oneshot_export": (C.c_int, [_P, _U8]),
     "mobrob_ppo_oneshot_open": (C.c_int, [_P, _U8, C.c_int32, C.c_int32]),
     "mobrob_ppo_oneshot_close": (C.c_int, [_P]),
+    "mobrob_ppo_exchange_selfcheck": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32)]),
     "mobrob_ppo_comm_destroy": (C.c_int, [_P]),
     "mobrob_ppo_train_dp": (C.c_int, [_P, _I64, _P, _P]),
     "mobrob_ppo_epoch_begin": (C.c_int, [_P, _I64]),

@@ -445,8 +445,9 @@ int fused_init(mobrob_ppo_engine* e) {
   f.enabled = e->cfg.fast_kernels && e->cfg.activation == MOBROB_ACT_TANH && fused_shape_ok(e->D, e->A, e->H1, e->H2, e->G1, e->G2);
   if (!f.enabled) return MOBROB_OK;
   f.D = e->D; f.Dp = e->Dp; f.A = e->A; f.H = e->H1;
-  if ((uint64_t)(e->T + 1) * e->N * e->Dp * 4ull >= (1ull << 32) || (uint64_t)e->T * e->N * e->A * 4ull >= (1ull << 32)) {
-    f.enabled = false;  // the fused kernels address rollout rows with 32-bit byte offsets
+  if ((uint64_t)(e->T + 1) * e->N * e->Dp * 4ull >= (1ull << 32) || (uint64_t)e->T * e->N * e->A * 4ull >= (1ull << 32) ||
+      (uint64_t)e->T * e->N * train_rec_width(e->A) * 4ull >= (1ull << 32)) {
+    f.enabled = false;  // the fused kernels address rollout rows and training records with 32-bit byte offsets
     return MOBROB_OK;
   }
   const int H = f.H;
@@ -1684,6 +1685,17 @@ int mobrob_ppo_epoch_begin(mobrob_ppo_engine_t* e, const int64_t* perm) {
   as.absmax_bits = maxw + (e->adv_pass & 1); as.absmax_next = maxw + ((e->adv_pass + 1) & 1);
   e->adv_pass++;
   if (perm) {
+    // a caller's permutation is checked before a kernel scatters through it (k_perm_from_host writes rows[] and the
+    // minibatch-of-row table at the indices it holds): every flat index once, none out of range
+    std::vector<uint64_t> seen(((size_t)total + 63) / 64, 0);
+    for (int i = 0; i < total; ++i) {
+      const int64_t v = perm[i];
+      if (v < 0 || v >= total) return fail(MOBROB_ERR_INVALID, "epoch_begin: perm[%d] = %lld is outside [0, %d)", i, (long long)v, total);
+      uint64_t& w = seen[(size_t)v >> 6];
+      const uint64_t bit = 1ull << (v & 63);
+      if (w & bit) return fail(MOBROB_ERR_INVALID, "epoch_begin: perm holds index %lld twice (not a permutation of [0, %d))", (long long)v, total);
+      w |= bit;
+    }
     HIPC(hipMemcpyAsync(e->perm_dev, perm, (size_t)total * 8, hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(k_perm_from_host, dim3(cdiv(total, 256)), dim3(256), 0, e->stream, e->perm_dev, total, e->T,
                        e->N, e->Bl, e->rows);
@@ -1980,6 +1992,7 @@ int oneshot_all_reduce(mobrob_ppo_engine* e, void* buf, size_t count, int dtype)
     a.peer_flags[r] = reinterpret_cast<const unsigned long long*>(o.peer[r] + 2 * o.payload);
   }
   a.world = o.world; a.rank = o.rank; a.bytes = bytes; a.seq = o.seq; a.error = o.error; a.timeout_ticks = o.timeout_ticks;
+  a.fence_form = getenv("MOBROB_ONESHOT_FENCE") != nullptr && atoi(getenv("MOBROB_ONESHOT_FENCE")) != 0;
   const int chunks = cdiv((int)bytes, kOneShotChunkBytes);
   if (dtype == 1) hipLaunchKernelGGL(k_oneshot_allreduce<double>, dim3(chunks), dim3(256), 0, e->stream, a);
   else hipLaunchKernelGGL(k_oneshot_allreduce<float>, dim3(chunks), dim3(256), 0, e->stream, a);
@@ -2128,7 +2141,10 @@ int mobrob_ppo_oneshot_export(mobrob_ppo_engine_t* e, uint8_t* handle64) {
       return fail(MOBROB_ERR_INVALID, "one-shot all-reduce: a %zu-byte message needs more than %d chunks", o.payload, kOneShotMaxChunks);
     const size_t total = 2 * o.payload + kOneShotMaxChunks * sizeof(unsigned long long);
     HIPC(hipMalloc((void**)&o.xbuf, total));
-    HIPC(hipMemset(o.xbuf, 0, total));  // flags = 0 < every sequence number; synchronous: peers may poll as soon as they hold the handle
+    // flags = 0 < every sequence number, complete before a peer can hold the handle: ordered on the engine's stream and waited for
+    // (hipMemset on device memory is neither guaranteed host-synchronous nor ordered against a non-blocking stream)
+    HIPC(hipMemsetAsync(o.xbuf, 0, total, e->stream));
+    HIPC(hipStreamSynchronize(e->stream));
     HIPC(hipHostMalloc((void**)&o.error, sizeof(int), hipHostMallocDefault));
     *o.error = 0;
     const char* t = getenv("MOBROB_ONESHOT_TIMEOUT_MS");
@@ -2180,7 +2196,75 @@ int mobrob_ppo_train_dp(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_all
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   if (!fn && !e->comm && !e->oneshot.ready)
     return fail(MOBROB_ERR_STATE, "train_dp: no communicator (mobrob_ppo_comm_init), no one-shot exchange (mobrob_ppo_oneshot_open) and no all-reduce callback");
-  return train_loop(e, perms, true, fn, ctx);
+  CHK(train_loop(e, perms, true, fn, ctx));
+  if (!fn && e->oneshot.ready) {
+    // A one-shot message whose peer never published leaves this rank's gradient LOCAL: such a step must not pass as a data-parallel
+    // one.  The update is awaited here and the error word turned into a failure of this call (the caller ends the job).
+    HIPC(hipStreamSynchronize(e->stream));
+    CHK(check_async_error(e));
+  }
+  return MOBROB_OK;
+}
+
+namespace {
+// exchange self-check (mobrob_ppo_exchange_selfcheck): small integers -- every partial sum is exact in float32 whatever the order
+__device__ __forceinline__ float selfcheck_value(unsigned i, int rank) {
+  const unsigned hsh = (i * 2654435761u + (unsigned)(rank + 1) * 0x9E3779B9u) >> 20;
+  return (float)(int)(hsh & 0xFFFu) - 2048.0f;
+}
+__global__ void k_selfcheck_fill(float* buf, int n, int rank) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) buf[i] = selfcheck_value((unsigned)i, rank);
+}
+__global__ void k_selfcheck_compare(const float* buf, int n, int world, int* mismatches) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float want = 0.f;
+  for (int r = 0; r < world; ++r) want += selfcheck_value((unsigned)i, r);   // rank order; exact anyway
+  if (!(buf[i] == want)) atomicAdd(mismatches, 1);
+}
+}  // namespace
+
+// A known vector through the exchange train_dp would use, compared with the rank-ordered sum -- at communicator set-up, before any
+// gradient depends on it.  which: 0 = the engine's RCCL communicator, 1 = the one-shot exchange.  Collective over the ranks.
+// *mismatches = elements of the [P + 8] message that are not bit-equal to the expected sum (0 = the exchange is sound).
+int mobrob_ppo_exchange_selfcheck(mobrob_ppo_engine_t* e, int32_t which, int32_t* mismatches) {
+  if (!e || !mismatches) return fail(MOBROB_ERR_INVALID, "exchange_selfcheck: null argument");
+  *mismatches = -1;
+  int world = 0, rank = -1;
+  if (which == 0) {
+    if (!e->comm) return fail(MOBROB_ERR_STATE, "exchange_selfcheck: no RCCL communicator");
+    NCCLC(g_rccl.CommCount(e->comm, &world));
+    NCCLC(g_rccl.CommUserRank(e->comm, &rank));
+  } else if (which == 1) {
+    if (!e->oneshot.ready) return fail(MOBROB_ERR_STATE, "exchange_selfcheck: the one-shot exchange is not open");
+    world = e->oneshot.world; rank = e->oneshot.rank;
+  } else {
+    return fail(MOBROB_ERR_INVALID, "exchange_selfcheck: which = %d", which);
+  }
+  const int n = e->P + 8;
+  int* bad = nullptr;
+  HIPC(hipMalloc((void**)&bad, sizeof(int)));
+  HIPC(hipMemsetAsync(bad, 0, sizeof(int), e->stream));
+  hipLaunchKernelGGL(k_selfcheck_fill, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->grads, n, rank);
+  int rc = MOBROB_OK;
+  if (which == 1) rc = oneshot_all_reduce(e, e->grads, (size_t)n, 0);
+  else if (g_rccl.AllReduce(e->grads, e->grads, (size_t)n, ncclFloat, ncclSum, e->comm, e->stream) != ncclSuccess) rc = fail(MOBROB_ERR_HIP, "exchange_selfcheck: ncclAllReduce failed");
+  if (rc == MOBROB_OK) {
+    hipLaunchKernelGGL(k_selfcheck_compare, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->grads, n, world, bad);
+    int h = -1;
+    hipError_t er = hipMemcpyAsync(&h, bad, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+    if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
+    if (er != hipSuccess) rc = fail(MOBROB_ERR_HIP, "exchange_selfcheck: %s", hipGetErrorString(er));
+    else *mismatches = h;
+  }
+  // the gradient vector and the eight loss accumulators behind it go back to the state the update loop expects
+  (void)hipMemsetAsync(e->grads, 0, (size_t)n * sizeof(float), e->stream);
+  (void)hipStreamSynchronize(e->stream);
+  (void)hipFree(bad);
+  if (rc != MOBROB_OK) return rc;
+  if (which == 1) CHK(check_async_error(e));
+  return MOBROB_OK;
 }
 int mobrob_ppo_allreduce_counters(mobrob_ppo_engine_t* e, int64_t* calls, int64_t* bytes, int32_t reset) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");

@@ -8,12 +8,17 @@
 //     [kMaxChunks] u64 flags     flags[c] = s once chunk c of message s is published (monotonic sequence numbers)
 //
 // One launch per message, one workgroup per 16 KB chunk c:
-//   publish   copy chunk c of the local message into the own slot; every storing wave drains its stores, workgroup barrier,
-//             lane 0: SYSTEM-scope release fence, drain, relaxed system-scope store of flags[c] = s
+//   publish   copy chunk c of the local message into the own slot with SYSTEM-scope write-through stores (sc0 sc1: the bytes
+//             leave the caches with the store); every storing wave drains its stores, workgroup barrier, lane 0: relaxed
+//             system-scope store of flags[c] = s.  (Round 3 used plain stores + a system-scope RELEASE fence per workgroup: on
+//             this part a release writes back the whole XCD's L2, 41 times per message; MOBROB_ONESHOT_FENCE=1 selects that form.)
 //   wait      lane 0 polls flags[c] of every rank with relaxed system-scope loads until all are >= s (bounded: a dead peer
-//             raises the error word instead of hanging the device), SYSTEM-scope acquire fence, drain, workgroup barrier
-//   combine   sum chunk c of all ranks IN RANK ORDER into the local message: ((x0 + x1) + x2) + ...  -- the same bits on
-//             every rank and from run to run (for two ranks also the bits any other all-reduce produces)
+//             raises the error word, and the HOST fails the step at its next synchronisation), workgroup barrier
+//   combine   sum chunk c of all ranks IN RANK ORDER into the local message, every remote byte read with system-scope
+//             loads (sc0 sc1: past this device's caches): ((x0 + x1) + x2) + ...  -- the same bits on every rank and from
+//             run to run (for two ranks also the bits any other all-reduce produces)
+// The exchange is validated at set-up (mobrob_ppo_exchange_selfcheck: a known vector through it, compared with the rank-ordered
+// sum); a run on real peers uses it only if that came out bit-equal.
 // A chunk depends only on the same chunk of the peers, so no rank waits for a whole remote message.
 //
 // Reuse of a slot: message s + 2 overwrites slot s & 1.  A rank launches message s + 2 after its launch of s + 1 has
@@ -41,10 +46,12 @@ struct OneShotArgs {
   unsigned long long seq;
   int* error;                                      // device word: set to seq's low bits + 1 when a peer never arrived
   long long timeout_ticks;                         // of wall_clock64() (100 MHz)
+  int fence_form;                                  // 1: round-3 protocol (plain stores + system-scope release / acquire fences)
 };
 
 template <typename T>
 struct alignas(16) OneShotVec { T v[16 / sizeof(T)]; };
+typedef unsigned oneshot_u4 __attribute__((ext_vector_type(4)));
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_oneshot_allreduce(OneShotArgs a) {
@@ -58,16 +65,28 @@ __global__ __launch_bounds__(256) void k_oneshot_allreduce(OneShotArgs a) {
   const size_t ntail = (b1 - tail0) / sizeof(T);
   char* loc = static_cast<char*>(a.local);
   // ---- publish ----
-  for (size_t i = threadIdx.x; i < nvec; i += 256)
-    *reinterpret_cast<V*>(a.mine + b0 + i * 16) = *reinterpret_cast<const V*>(loc + b0 + i * 16);
-  if (threadIdx.x < ntail)
-    *reinterpret_cast<T*>(a.mine + tail0 + threadIdx.x * sizeof(T)) = *reinterpret_cast<const T*>(loc + tail0 + threadIdx.x * sizeof(T));
+  if (a.fence_form) {
+    for (size_t i = threadIdx.x; i < nvec; i += 256)
+      *reinterpret_cast<V*>(a.mine + b0 + i * 16) = *reinterpret_cast<const V*>(loc + b0 + i * 16);
+    if (threadIdx.x < ntail)
+      *reinterpret_cast<T*>(a.mine + tail0 + threadIdx.x * sizeof(T)) = *reinterpret_cast<const T*>(loc + tail0 + threadIdx.x * sizeof(T));
+  } else {
+    for (size_t i = threadIdx.x; i < nvec; i += 256) {
+      const oneshot_u4 x = *reinterpret_cast<const oneshot_u4*>(loc + b0 + i * 16);
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(a.mine + b0 + i * 16), "v"(x) : "memory");
+    }
+    if (threadIdx.x < ntail)
+      __hip_atomic_store(reinterpret_cast<T*>(a.mine + tail0 + threadIdx.x * sizeof(T)), *reinterpret_cast<const T*>(loc + tail0 + threadIdx.x * sizeof(T)),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   __shared__ int ok;
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: the peers may sit on another device
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the flag must not overtake the write-back (MI355X_MICROARCH.md, compiler hazard)
+    if (a.fence_form) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: the peers may sit on another device
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the flag must not overtake the write-back (MI355X_MICROARCH.md, compiler hazard)
+    }
     __hip_atomic_store(a.my_flags + c, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // ---- wait ----
     int good = 1;
@@ -83,26 +102,42 @@ __global__ __launch_bounds__(256) void k_oneshot_allreduce(OneShotArgs a) {
       *reinterpret_cast<volatile int*>(a.error) = (int)(a.seq & 0x3fffffff) + 1;
       __threadfence_system();
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.fence_form) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     ok = good;
   }
   __syncthreads();
-  if (!ok) return;  // the message stays local; the host finds the error word at its next synchronisation
+  if (!ok) return;  // the host finds the error word at its next synchronisation and FAILS the step (engine.hip check_async_error)
   // ---- combine, rank order ----
   for (size_t i = threadIdx.x; i < nvec; i += 256) {
-    V acc = *reinterpret_cast<const V*>(a.peer[0] + b0 + i * 16);
-    for (int r = 1; r < a.world; ++r) {
-      const V x = *reinterpret_cast<const V*>(a.peer[r] + b0 + i * 16);
+    oneshot_u4 xs[kOneShotMaxRanks];
+    if (a.fence_form) {
 #pragma unroll
-      for (int k = 0; k < kPer; ++k) acc.v[k] = acc.v[k] + x.v[k];
+      for (int r = 0; r < kOneShotMaxRanks; ++r)
+        if (r < a.world) xs[r] = *reinterpret_cast<const oneshot_u4*>(a.peer[r] + b0 + i * 16);
+    } else {   // every rank's 16 bytes requested first (system scope: past this device's caches), one wait for all of them
+#pragma unroll
+      for (int r = 0; r < kOneShotMaxRanks; ++r)
+        if (r < a.world) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(xs[r]) : "v"(a.peer[r] + b0 + i * 16) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xs[0]), "+v"(xs[1]), "+v"(xs[2]), "+v"(xs[3]), "+v"(xs[4]), "+v"(xs[5]), "+v"(xs[6]), "+v"(xs[7]) :: "memory");
+    }
+    V acc = __builtin_bit_cast(V, xs[0]);
+#pragma unroll
+    for (int r = 1; r < kOneShotMaxRanks; ++r) {
+      if (r < a.world) {
+        const V x = __builtin_bit_cast(V, xs[r]);
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) acc.v[k] = acc.v[k] + x.v[k];
+      }
     }
     *reinterpret_cast<V*>(loc + b0 + i * 16) = acc;
   }
   if (threadIdx.x < ntail) {
     const size_t o = tail0 + threadIdx.x * sizeof(T);
-    T acc = *reinterpret_cast<const T*>(a.peer[0] + o);
-    for (int r = 1; r < a.world; ++r) acc = acc + *reinterpret_cast<const T*>(a.peer[r] + o);
+    T acc = __hip_atomic_load(reinterpret_cast<const T*>(a.peer[0] + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int r = 1; r < a.world; ++r) acc = acc + __hip_atomic_load(reinterpret_cast<const T*>(a.peer[r] + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     *reinterpret_cast<T*>(loc + o) = acc;
   }
 }

@@ -400,6 +400,13 @@ class PPOEngine:
     def oneshot_close(self):
         check(self.lib.mobrob_ppo_oneshot_close(self._h))
 
+    def exchange_selfcheck(self, which):
+        """A known vector through the engine's RCCL communicator (which = "rccl") or its one-shot exchange ("oneshot"), compared
+        with the rank-ordered sum (collective).  -> number of message elements that are not bit-equal to it (0 = sound)."""
+        bad = C.c_int32(-1)
+        check(self.lib.mobrob_ppo_exchange_selfcheck(self._h, {"rccl": 0, "oneshot": 1}[which], C.byref(bad)))
+        return int(bad.value)
+
     def allreduce_counters(self, reset=False):
         """(calls, payload bytes) of the all-reduces train_dp issued since the last reset."""
         c, b = C.c_int64(), C.c_int64()

@@ -144,6 +144,68 @@ class EngineBackend:
                 warnings.warn("one-shot all-reduce unavailable (%r): using the default exchange" % (getattr(self, "_oneshot_error", "another rank failed"),))
         return self._oneshot_ready
 
+    def choose_exchange(self, group=None):
+        """Decide ONCE, collectively, which exchange the C loop uses on this group -- and prove it on a known vector before a
+        gradient depends on it (the first multi-GPU run must be safe and attributable without anybody watching):
+
+          * the one-shot exchange over peer-mapped memory if it was asked for (MOBROB_ONESHOT_AR=1 on EVERY rank: the switch is
+            agreed with a MIN all-reduce, a rank that lacks it cannot strand the others) and its self-check -- a deterministic
+            vector per rank through the exchange, compared with the rank-ordered sum -- is bit-equal on every rank;
+          * else the engine's RCCL communicator, self-checked the same way ("nccl" groups);
+          * else torch.distributed's own collectives from the Python loop ("nccl" groups whose engine communicator failed),
+            or the host-staged callback (CPU groups: the two-ranks-on-one-GPU tests).
+
+        -> the name of the exchange; `self.exchange_selfcheck` holds what was measured: {"oneshot": "ok" | "<n> mismatches" |
+        "unavailable: ...", "rccl": ...} -- bench.py writes both into its line."""
+        if getattr(self, "exchange", None) is not None:
+            return self.exchange
+        import os
+        self.exchange_selfcheck = {}
+        backend = dist.get_backend(group)
+        dev = self.device if backend == "nccl" else "cpu"
+
+        def agree(flag):
+            t = torch.tensor([int(bool(flag))], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return bool(int(t.item()))
+
+        def checked(which):
+            """run the self-check on every rank; ok only if EVERY rank saw zero mismatches"""
+            try:
+                bad = self.e.exchange_selfcheck(which)
+                note = "ok" if bad == 0 else f"{bad} of {self.e.P + 8} elements differ from the rank-ordered sum"
+            except Exception as ex:  # noqa: BLE001 - e.g. a peer that never published (bounded wait inside the kernel)
+                bad, note = -1, f"failed: {ex}"
+            ok = agree(bad == 0)
+            self.exchange_selfcheck[which] = note if ok or bad != 0 else "ok here, failed on another rank"
+            return ok
+
+        world = dist.get_world_size(group)
+        want_oneshot = agree(os.environ.get("MOBROB_ONESHOT_AR", "0") == "1") and world <= 8
+        if want_oneshot:
+            if self.ensure_oneshot(group):
+                if checked("oneshot"):
+                    self.exchange = "oneshot"
+                    return self.exchange
+                dist.barrier(group=group)          # no rank frees its exchange buffer while a peer may still read it
+                self.e.oneshot_close()
+            else:
+                self.exchange_selfcheck["oneshot"] = "unavailable: %r" % (getattr(self, "_oneshot_error", "another rank failed"),)
+        if backend == "nccl":
+            if self.ensure_comm(group):
+                if checked("rccl"):
+                    self.exchange = "rccl"
+                    return self.exchange
+                import warnings
+                warnings.warn("the engine's RCCL communicator failed its self-check (%s): torch.distributed collectives from the "
+                              "Python loop instead" % self.exchange_selfcheck.get("rccl"))
+            else:
+                self.exchange_selfcheck["rccl"] = "unavailable (engine-owned communicator could not be created)"
+            self.exchange = "torch.distributed"
+        else:
+            self.exchange = "gloo-callback"
+        return self.exchange
+
     def gloo_all_reduce(self, group=None):
         """All-reduce callback for `engine.train_dp` under a CPU process group: stage through the host."""
         def reduce_in_place(ptr, count, dtype, _stream):
@@ -214,14 +276,11 @@ def train_data_parallel(backend, perms=None, group=None, force_collectives=False
     comm = world > 1 or (force_collectives and dist.is_initialized())
     stream = getattr(backend, "stream", None)
     if isinstance(backend, EngineBackend) and comm and not python_loop:
-        import os
-        if os.environ.get("MOBROB_ONESHOT_AR", "0") == "1" and world <= 8 and backend.ensure_oneshot(group):
-            backend.e.train_dp(perms)        # the C loop, sums through peer-mapped memory (csrc/oneshot_allreduce.h)
+        exchange = backend.choose_exchange(group)      # decided and self-checked once per backend (collective)
+        if exchange in ("oneshot", "rccl"):
+            backend.e.train_dp(perms)        # the C loop: sums through peer-mapped memory (csrc/oneshot_allreduce.h) or RCCL
             return backend.e.last_train_info()
-        if dist.get_backend(group) == "nccl":
-            if backend.ensure_comm(group):
-                backend.e.train_dp(perms)
-                return backend.e.last_train_info()
+        if exchange == "torch.distributed":
             with torch.cuda.stream(stream):
                 return _update_loop(backend, perms, group, comm)
         backend.e.train_dp(perms, allreduce=backend.gloo_all_reduce(group))

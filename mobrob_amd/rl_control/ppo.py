@@ -516,6 +516,12 @@ class PPO:
         return self
 
     def _log(self, iteration, stats):
+        """SB3's logger dump.  Data parallel: only rank 0 writes (stdout and event file alike), the other ranks return before
+        any device read.  The loss statistics are GLOBAL means (the C loop all-reduces their sums with the gradient);
+        `rollout/ep_*`, `train/explained_variance` and `time/fps` describe rank 0's shard of the environments (every shard
+        draws from the same distribution: an unbiased estimate of the global figure from 1/world of the data)."""
+        if self.rank != 0:
+            return
         elapsed = max((time.time_ns() - self.start_time) / 1e9, sys.float_info.epsilon)
         fps = int((self.num_timesteps - self._num_timesteps_at_start) / elapsed)
         rows = []
@@ -536,7 +542,7 @@ class PPO:
         if self._tb is not None:   # SB3 keeps these three out of the event file (logger.record(..., exclude="tensorboard"))
             skip = ("time/iterations", "time/time_elapsed", "time/total_timesteps")
             self._tb.add_scalars([(k, v) for k, v in rows if k not in skip], self.num_timesteps)
-        if self.verbose < 1 or self.rank != 0:
+        if self.verbose < 1:
             return
         rows.sort()
         w = max(len(k) for k, _ in rows)

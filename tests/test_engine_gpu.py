@@ -797,6 +797,14 @@ def test_error_paths():
         e.epoch_begin(None)  # rollout not finished
     with pytest.raises(ValueError):
         e.set_flat_params(np.zeros(3, np.float32))
+    # a caller's permutation is validated on the host before a kernel scatters through it
+    buf, lv, dones = synthetic_rollout(2, 2, 4, 2, seed=1)
+    e.load_rollout(buf, lv, dones)
+    e.compute_gae()
+    for bad, what in (([0, 1, 2, 4], "outside"), ([0, 1, -1, 2], "outside"), ([0, 1, 1, 2], "twice")):
+        with pytest.raises(Exception, match=what):
+            e.epoch_begin(np.array(bad, np.int64))
+    e.epoch_begin(np.array([3, 1, 0, 2], np.int64))
     e.close()
 
 

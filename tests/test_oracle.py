@@ -252,3 +252,34 @@ def test_relu_networks_match_torch_autograd():
     m_t, v_t = O.policy_outputs(p, obs, activation="tanh")
     m_r, v_r = O.policy_outputs(p, obs, activation="relu")
     assert np.max(np.abs(m_r - mean.detach().numpy())) < 1e-6 and np.max(np.abs(m_t - m_r)) > 1e-3
+
+
+def test_torch_baseline_matches_the_oracle():
+    """oracle/torch_baseline.py (the torch-CPU leg of bench.py's cpu_baseline: nn.Linear / Normal / autograd / clip_grad_norm_ /
+    optim.Adam in SB3's order) runs the same iteration as the NumPy oracle: same rollout on the same synthetic env source and
+    noise, same parameters after two epochs of minibatch steps (incl. a short last minibatch)."""
+    import torch
+    from oracle import torch_baseline as TB
+    torch.set_num_threads(1)
+    D, A, H, N, T = 9, 3, 32, 6, 17
+    rng = np.random.default_rng(4)
+    p = O.init_params(D, A, (H, H), (H, H), seed=1)
+    p["log_std"] = rng.normal(-0.2, 0.1, A).astype(np.float32)
+    h = O.Hyper(n_epochs=2, batch_size=40, ent_coef=0.01)
+    eps = rng.standard_normal((T, N, A)).astype(np.float32)
+    perms = [rng.permutation(T * N) for _ in range(2)]
+    env_a = O.NumpySyntheticVecEnv(N, D, A, p_term=0.05, time_limit=9, seed=3)
+    env_b = O.NumpySyntheticVecEnv(N, D, A, p_term=0.05, time_limit=9, seed=3)
+    pol = TB.TorchPolicy(p)
+    buf_t, _, _ = TB.collect_rollout(pol, env_b, env_b.reset(), np.ones(N, bool), T, h, lambda t: eps[t])
+    buf_o, _, _ = O.collect_rollout(p, env_a, env_a.reset(), np.ones(N, bool), T, h, lambda t: eps[t])
+    for k in ("obs", "rewards", "episode_starts"):
+        assert np.allclose(buf_t[k], buf_o[k], atol=1e-5), k
+    for k in ("actions", "values", "log_probs", "advantages", "returns"):
+        assert np.allclose(buf_t[k], buf_o[k], rtol=1e-4, atol=1e-4), k
+    TB.train(pol, TB.make_optimizer(pol, h), buf_o, h, perms)
+    q = {k: v.copy() for k, v in p.items()}
+    O.train(q, O.AdamState.zeros_like(q), buf_o, h, perms)
+    got = pol.state()
+    for k in q:
+        assert np.max(np.abs(got[k] - q[k])) < 2e-5, (k, float(np.max(np.abs(got[k] - q[k]))))

@@ -255,12 +255,18 @@ def _rccl_world1_worker(rank, world, port, out):
                     warnings.simplefilter("always")
                     train_data_parallel(broken, perms, force_collectives=True)
                 assert any("falling back" in str(x.message) for x in w)
+                assert broken.exchange == "torch.distributed" and "unavailable" in broken.exchange_selfcheck["rccl"]
             else:
                 train_data_parallel(be, perms, force_collectives=True, python_loop=(mode == "python_torch"))
             torch.cuda.synchronize()
             res[f"{case}/{mode}"] = e.get_flat_params()
             if mode == "c_rccl":   # ncclCommCount / ncclCommUserRank of the engine's own communicator, and the C loop's counters
                 assert e.comm_info() == (1, 0)
+                # the exchange was proven on a known vector at set-up, and says so (bench.py prints both)
+                assert be.exchange == "rccl" and be.exchange_selfcheck == {"rccl": "ok"}
+                assert e.exchange_selfcheck("rccl") == 0
+                with pytest.raises(Exception, match="one-shot exchange is not open"):
+                    e.exchange_selfcheck("oneshot")
                 nmb = e.n_minibatches
                 assert e.last_train_info() == (c["E"], False, c["E"] * nmb)
                 calls, nbytes = e.allreduce_counters(reset=True)
@@ -317,11 +323,13 @@ def _oneshot_worker(rank, world, port, case, out):
     e = PPOEngine(obs_dim=c["D"], act_dim=c["A"], n_envs=c["N"], n_steps=c["T"], batch_size=c["B"], n_epochs=c["E"],
                   pi=(H, H), vf=(H, H), ent_coef=h.ent_coef, device_id=0, rank=rank, world_size=world)
     e.load_rollout(buf, lv, dones)
-    be = EngineBackend(e)
     z = {k: np.zeros_like(v) for k, v in p.items()}
     res = {}
     for mode in ("callback", "oneshot"):
         os.environ["MOBROB_ONESHOT_AR"] = "1" if mode == "oneshot" else "0"
+        if mode == "oneshot" and rank == 1 and os.environ.get("TEST_ONE_RANK_WITHOUT_SWITCH"):
+            os.environ["MOBROB_ONESHOT_AR"] = "0"    # the switch is AGREED: one rank without it sends both to the default
+        be = EngineBackend(e)           # the exchange is chosen (and self-checked) once per backend
         ms = []
         for rep in range(3):            # repetitions: sequence numbers, slot reuse and flag monotonicity over many messages
             e.set_params(p)
@@ -337,8 +345,12 @@ def _oneshot_worker(rank, world, port, case, out):
             else:
                 assert np.array_equal(res[mode + "/flat"], e.get_flat_params()), (mode, rep)
         res[mode + "/ms"] = np.array(ms)
-        if mode == "oneshot":
+        if mode == "callback" or os.environ.get("TEST_ONE_RANK_WITHOUT_SWITCH"):
+            assert be.exchange == "gloo-callback" and be.exchange_selfcheck == {}
+        else:
             assert be._oneshot_ready is True
+            assert be.exchange == "oneshot" and be.exchange_selfcheck == {"oneshot": "ok"}
+            assert e.exchange_selfcheck("oneshot") == 0       # again, between updates: sequence numbers stay in step
             calls, _ = e.allreduce_counters()
             assert calls == 2 * 3 * c["E"] * (e.n_minibatches + 1)
     np.savez(out.format(rank=rank), **res)
@@ -346,9 +358,11 @@ def _oneshot_worker(rank, world, port, case, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["h256", "h64"])
-def test_oneshot_all_reduce_through_ipc_equals_the_callback_path(case, tmp_path):
+@pytest.mark.parametrize("case,fence", [("h256", "0"), ("h64", "0"), ("h256", "1")])
+def test_oneshot_all_reduce_through_ipc_equals_the_callback_path(case, fence, tmp_path, monkeypatch):
+    """fence "0": write-through publish / system-scope loads (the default); "1": round 3's release / acquire fences."""
     import torch.multiprocessing as mp
+    monkeypatch.setenv("MOBROB_ONESHOT_FENCE", fence)
     world = 2
     out = str(tmp_path / "os{rank}.npz")
     mp.spawn(_oneshot_worker, args=(world, _free_port(), case, out), nprocs=world, join=True)
@@ -361,9 +375,18 @@ def test_oneshot_all_reduce_through_ipc_equals_the_callback_path(case, tmp_path)
     rec = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(rec):
         import json
-        with open(os.path.join(rec, f"oneshot_vs_callback_{case}.json"), "w") as f:
-            json.dump({"case": CASES[case], "world": world, "device": "both ranks on cuda:0",
+        with open(os.path.join(rec, f"oneshot_vs_callback_{case}_fence{fence}.json"), "w") as f:
+            json.dump({"case": CASES[case], "world": world, "publish": "release fence" if fence == "1" else "write-through stores", "device": "both ranks on cuda:0",
                        "ms_per_train_callback": r[0]["callback/ms"].tolist(), "ms_per_train_oneshot": r[0]["oneshot/ms"].tolist()}, f)
+
+
+def test_oneshot_switch_on_one_rank_only_falls_back_on_both(tmp_path, monkeypatch):
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("TEST_ONE_RANK_WITHOUT_SWITCH", "1")
+    out = str(tmp_path / "sw{rank}.npz")
+    mp.spawn(_oneshot_worker, args=(2, _free_port(), "h64", out), nprocs=2, join=True)
+    r = [np.load(out.format(rank=i)) for i in range(2)]
+    assert np.array_equal(r[0]["oneshot/flat"], r[1]["oneshot/flat"]) and np.array_equal(r[0]["oneshot/flat"], r[0]["callback/flat"])
 
 
 def _oneshot_dead_peer_worker(rank, world, port, out):
@@ -383,7 +406,7 @@ def _oneshot_dead_peer_worker(rank, world, port, out):
     e.set_params(p)
     e.load_rollout(buf, lv, dones)
     be = EngineBackend(e)
-    assert be.ensure_oneshot()
+    assert be.choose_exchange() == "oneshot" and be.exchange_selfcheck == {"oneshot": "ok"}   # both ranks alive at set-up
     msg = ""
     if rank == 0:
         try:
