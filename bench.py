@@ -245,10 +245,13 @@ def blended_peak(D, H, A, x3_train):
     return 1.0 / ideal_s_per_flop / 1e12, x3_share
 
 
-def dominant_kernel_name(H, rows_per_launch, generic, x3_train=False):
+def dominant_kernel_name(H, rows_per_launch, generic, x3_train=False, chain=False):
     """Which gradient kernel the engine launches for this shape (engine.hip: fused64_minibatch_grad / fused_minibatch_grad)."""
     if generic:
         return "generic GEMM chain"
+    if H == 256 and x3_train and chain:
+        return ("k_chain_train (minibatch forward+loss+backward, 16 rows per wave chained through registers; hidden-layer products on the "
+                "bf16 pipe, split float32 operands, weights streamed through an LDS ring)")
     if H == 256:
         return ("k_fused_train<.., X3> (minibatch forward+loss+backward; hidden-layer products on the bf16 pipe, split float32 operands)"
                 if x3_train else "k_fused_train (minibatch forward+loss+backward)")
@@ -259,7 +262,7 @@ def dominant_kernel_name(H, rows_per_launch, generic, x3_train=False):
 def measured_traffic(kernel_prefix):
     """(bytes per launch | None, note): PMC-counted HBM traffic of the dominant kernel from the newest committed
     profile -- only if that profile was taken on exactly these kernel sources; otherwise None (never a stale figure)."""
-    for rnd in ("r3", "r2", "r1"):
+    for rnd in ("r4", "r3", "r2", "r1"):
         tj = os.path.join(ROOT, "profiles", rnd, "hbm_traffic_pmc.json")
         if not os.path.exists(tj):
             continue
@@ -669,7 +672,7 @@ def bench_single(args, name, steps, warmup, job, phases):
         peak, x3_share = blended_peak(D, H, A, x3_train)
         traffic, traffic_note = None, "PMC traffic is profiled for the default workload on one GPU only"
         if not args.generic and name == "doggo-4096env-2x256" and not use_dp and not phases:
-            traffic, traffic_note = measured_traffic("void mobrob::k_fused_train<64")
+            traffic, traffic_note = measured_traffic("void mobrob::k_chain_train<" if x3_train and (x3_mode & 4) else "void mobrob::k_fused_train<64")
         if comm_n > 0:      # the engine's own communicator carried the collectives: ITS size is what took part
             ranks_seen, ranks_src = comm_n, "ncclCommCount of the engine's communicator"
         elif use_dp:
@@ -701,7 +704,7 @@ def bench_single(args, name, steps, warmup, job, phases):
                                       if host is not None else "device-resident synthetic (Philox)"),
                        "parallelism": f"dp{world}", "n_ranks_seen": ranks_seen, "n_ranks_source": ranks_src,
                        "kernels": "generic" if args.generic else "fused"},
-            "roofline": {"bound": "mfma", "kernel": dominant_kernel_name(H, B, args.generic, x3_train),
+            "roofline": {"bound": "mfma", "kernel": dominant_kernel_name(H, B, args.generic, x3_train, bool(x3_mode & 4)),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "traffic_note": traffic_note,

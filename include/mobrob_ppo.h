@@ -415,7 +415,8 @@ int mobrob_ppo_mark_rollout_ready(mobrob_ppo_engine_t* e);
 
 /* Which matrix products of this engine run on the bf16 pipe with three-way split float32 operands (config.forward_x3, 256-wide tanh
  * nets): bit 0 = rollout policy forward and batched value pass, bit 1 = the hidden-layer products inside the gradient kernel (forward,
- * dh1, dW2, dW1; heads <= 16 wide, observation rows of 16 / 32 / 64 padded columns).  0: everything on v_mfma_f32.  Measurement code
+ * dh1, dW2, dW1; heads <= 16 wide, observation rows of 16 / 32 / 64 padded columns), bit 2 = that gradient kernel is the register-chained
+ * k_chain_train (csrc/kernels_chain.h; MOBROB_NO_CHAIN=1 keeps k_fused_train<.., X3>).  0: everything on v_mfma_f32.  Measurement code
  * prices the kernels against the matrix peak of the pipe each product ran on (bench.py). */
 int mobrob_ppo_x3_mode(const mobrob_ppo_engine_t* e);
 

@@ -1263,7 +1263,7 @@ int mobrob_ppo_compute_gae(mobrob_ppo_engine_t* e) {
 
 int mobrob_ppo_x3_mode(const mobrob_ppo_engine_t* e) {
   if (!e || !e->fused.enabled || e->fused.net[0].W2x == nullptr) return 0;
-  return 1 | (e->fused.train_x3 ? 2 : 0);
+  return 1 | (e->fused.train_x3 ? 2 : 0) | (e->fused.train_x3 && e->fused.train_chain ? 4 : 0);
 }
 
 int mobrob_ppo_explained_variance(mobrob_ppo_engine_t* e, double* out) {

@@ -263,7 +263,9 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int nwg = gridDim.x >> 1;
   int net, wg;
-  {  // blockIdx -> (network, tile sequence): as k_fused_train (policy / value workgroups of a tile sequence share an XCD)
+  {  // blockIdx -> (network, tile sequence): as k_fused_train (policy / value workgroups of a tile sequence share an XCD and the rows
+     // they gather).  One network per XCD (0.9 MB of weight packs next to the 2 MB of dW1 sums in each 4 MB L2) was measured: L2 misses
+     // 1.9 M -> 1.35 M and fabric reads 78 -> 48 MB per launch, in-kernel cycles -4 %, wall time +1.5 % (profiles/r4/chain_l2.txt).
     const int b = blockIdx.x, g16 = b >> 4, o = b & 15;
     const int gsz = min(16, (int)gridDim.x - 16 * g16), half = gsz >> 1;
     net = o >= half ? 1 : 0;
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const int u = CSEG * q + 4 * hh + wv;
-        dma_unit(W2bc_ + (size_t)u * 192, (CSEG * q + 4 * hh) % CSLOTS + wv, lane16, L::RING);
+        dma_unit(((MOBROB_CHAIN_SKIP & 64) ? W2c_ : W2bc_) + (size_t)u * 192, (CSEG * q + 4 * hh) % CSLOTS + wv, lane16, L::RING);
       }
     };
     {

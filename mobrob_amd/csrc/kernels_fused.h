@@ -429,15 +429,25 @@ struct Lay {
     tprev_ = t_;                                                                                   \
   }
 #define STAMP_INIT()                                                                               \
-  unsigned long long tprev_;                                                                       \
-  unsigned long long tacc_[24];                                                                    \
-  _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) tacc_[i_] = 0;                                 \
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev_)::"memory");
+  unsigned long long tprev_, tclk0_, treal0_;                                                      \
+  unsigned long long tacc_[26];                                                                    \
+  _Pragma("unroll") for (int i_ = 0; i_ < 26; ++i_) tacc_[i_] = 0;                                 \
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(treal0_)::"memory");              \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev_)::"memory");                   \
+  tclk0_ = tprev_;
+// slots 24 / 25: the wave's shader-clock cycles and 100 MHz ticks between STAMP_INIT and STAMP_FLUSH -> the in-kernel clock
+// (MI355X_MICROARCH.md, DVFS give-back item 6)
 #define STAMP_FLUSH()                                                                              \
+  {                                                                                                \
+    unsigned long long t1_, r1_;                                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_)::"memory");                    \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1_)::"memory");                \
+    tacc_[24] = t1_ - tclk0_; tacc_[25] = r1_ - treal0_;                                           \
+  }                                                                                                \
   if ((threadIdx.x & 63) == 0) {                                                                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) atomicAdd(&stamps_[i_], tacc_[i_]);          \
+    _Pragma("unroll") for (int i_ = 0; i_ < 26; ++i_) atomicAdd(&stamps_[i_], tacc_[i_]);          \
   }
-#define STAMP_PARAMS , unsigned long long (&tacc_)[24], unsigned long long &tprev_
+#define STAMP_PARAMS , unsigned long long (&tacc_)[26], unsigned long long &tprev_
 #define STAMP_ARGS , tacc_, tprev_
 #else
 #define STAMP(id)

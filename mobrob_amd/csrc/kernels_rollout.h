@@ -450,7 +450,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_value_batch(FusedNet W, const f
   }
   const float bv = W.b3[0];
 #ifdef MOBROB_STAMPS  // diagnostic build: the shared forward code stamps into a scratch array here
-  unsigned long long tacc_[24] = {0};
+  unsigned long long tacc_[26] = {0};
   unsigned long long tprev_ = 0;
 #endif
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {

@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256, 1) void k(int iters, float* out, unsigned long
   u32x4 x0, x1, x2, w0, w1, w2, n0, n1, n2;
   for (int i = 0; i < 4; ++i) { x0[i] = 0x3f803f80u + lane; x1[i] = 0x3c003c00u; x2[i] = 0x38003800u; w0[i] = 0x3f003f00u + i; w1[i] = 0x3b003b00u; w2[i] = 0x37003700u; }
   n0 = w0; n1 = w1; n2 = w2;
+  float fa = 1.0f + lane, fb = 2.0f + lane; unsigned sink = 0;
   int base = 4 * lane;
   asm volatile("" : "+v"(base));
   base = 4 * (base >> 2);
@@ -45,12 +46,21 @@ __global__ __launch_bounds__(256, 1) void k(int iters, float* out, unsigned long
         a = M16(w2, x0, a); a = M16(w1, x1, a); a = M16(w1, x0, a); a = M16(w0, x2, a); a = M16(w0, x1, a); a = M16(w0, x0, a);
       }
       if (V & 2) { w0 = n0; w1 = n1; w2 = n2; }
+      if (V & 12) {   // side work of the real loop: half a pair-split (5-6 VALU) per unit, or a whole one
+        constexpr int reps = (V & 8) ? 2 : 1;
+#pragma unroll
+        for (int r = 0; r < reps; ++r) {
+          unsigned p = __builtin_amdgcn_perm(__float_as_uint(fa), __float_as_uint(fb), 0x07060302u);
+          fa = fa - __uint_as_float(p << 16); fb = fb - __uint_as_float(p & 0xffff0000u);
+          fa = fa * 1.0001f; fb = fb + fa; sink ^= p;
+        }
+      }
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   float s = 0.f;
   for (int t = 0; t < 16; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
-  out[blockIdx.x * 256 + threadIdx.x] = s;
+  out[blockIdx.x * 256 + threadIdx.x] = s + fa + fb + (float)sink;
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 template <int V>
@@ -71,5 +81,8 @@ int main() {
   run<1>("two units interleaved (independent neighbours), operands in registers", out, cyc);
   run<2>("six dependent MFMAs + the next unit's three ds_read_b128", out, cyc);
   run<3>("two units interleaved + reads (one weight fragment feeds both: not the kernel's data flow)", out, cyc);
+  run<6>("six dependent MFMAs + reads + 6 VALU per unit", out, cyc);
+  run<10>("six dependent MFMAs + reads + 12 VALU per unit", out, cyc);
+  run<4>("six dependent MFMAs + 6 VALU per unit (no reads)", out, cyc);
   return 0;
 }

@@ -5,7 +5,7 @@ from mobrob_amd import _lib
 _lib.LIB_PATH = os.path.abspath(os.environ.get("STAMPS_LIB", "scratch/libmobrob_ppo_stamps.so"))
 from mobrob_amd.engine import PPOEngine
 from mobrob_amd.rl_control.init import orthogonal_policy_init
-D, A, H, N, T, B = 58, 12, 256, 4096, 64, 65536
+D, A, H, N, T, B = 58, 12, 256, 4096, int(os.environ.get('STAMPS_T', '1000')), 65536
 e = PPOEngine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=1, pi=(H, H), vf=(H, H), ent_coef=0.01)
 e.set_params(orthogonal_policy_init(D, A, (H, H), (H, H), 0))
 e.collect_synthetic()
@@ -21,7 +21,9 @@ names = {0: "X image + split", 1: "layer 1 (ring)", 2: "layer 2 (ring) + end bar
          11: "dW1 stores", 12: "end barrier", 13: "  dW1 prologue (4 fragments)", 14: "  dW1 slab-load wait", 15: "  dW1 loop",
          16: "  dh1 ring prologue (first DMA wait)", 17: "  dh1 loop", 18: "  fwd ring prologue (first DMA wait)"}
 v = np.array(list(out), dtype=np.float64)
-tot = v.sum()
+tot = v[:19].sum()
 for i in range(19):
-    print(f"{i:2d} {names[i]:34s} {100 * v[i] / tot:6.2f}%   {v[i] / (1024 * 8 * 4):12.0f} cycles/wave/tile")
-print("total cycles/wave/tile", tot / (1024 * 8 * 4))
+    print(f"{i:2d} {names[i]:34s} {100 * v[i] / tot:6.2f}%   {v[i] / ((N * T + B - 1) // B * 256 * 8 * 4):12.0f} cycles/wave/tile")
+launches = (N * T + B - 1) // B
+print("total cycles/wave/tile", v[:19].sum() / (launches * 256 * 8 * 4))
+print(f"in-kernel clock {v[24] / v[25] * 0.1:.3f} GHz; kernel span per wave {v[25] / (launches * 256 * 4) / 100:.1f} us ({launches} launches)")
