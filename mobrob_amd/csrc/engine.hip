@@ -1399,8 +1399,13 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
     ProfScope ps(e, MOBROB_K_ENV);
     for (int t0 = 0; t0 < T; t0 += chunk) {
       a.t0 = t0; a.t1 = std::min(T, t0 + chunk);
-      FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout_persistent<DPc>), dim3(rblocks), dim3(kRolloutThreads),
-                                               rollout_lds_bytes(Dp), e->stream, a));
+      if (a.kind == 1) {
+        FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout_persistent<DPc, 1>), dim3(rblocks), dim3(kRolloutThreads),
+                                                 rollout_lds_bytes(Dp), e->stream, a));
+      } else {
+        FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout_persistent<DPc, 2>), dim3(rblocks), dim3(kRolloutThreads),
+                                                 rollout_lds_bytes(Dp), e->stream, a));
+      }
       if (overlap && a.t1 < T) {  // observations [t0, t1) are final: value them on the side stream
         hipEvent_t ev = e->ev_chunks[t0 / chunk];
         HIPC(hipEventRecord(ev, e->stream));
@@ -1790,16 +1795,20 @@ void fill_adam_pack_args(mobrob_ppo_engine* e, AdamPackArgs& a) {
     a.fW1f[n] = on ? (float*)e->fused.net[n].W1f : nullptr;
     a.fW2f[n] = on ? (float*)e->fused.net[n].W2f : nullptr;
     a.fW3f[n] = on ? (float*)e->fused.net[n].W3f : nullptr;
-    a.fW2b[n] = on ? (float*)e->fused.net[n].W2b : nullptr;
-    a.fW3b[n] = on ? (float*)e->fused.net[n].W3b : nullptr;
+    // k_chain_train reads its own packs only: the backward packs of the other 256-wide gradient kernels (W2b, W3b, W2bx) are not
+    // refreshed per step while it is the engine's gradient kernel (set_params / load rebuild every pack: fused_repack, pack_x3_all).
+    // W3h stays: k_value_batch's 16-wide head reads it.
+    const bool ch = on && e->fused.train_chain;
+    a.fW2b[n] = on && !ch ? (float*)e->fused.net[n].W2b : nullptr;
+    a.fW3b[n] = on && !ch ? (float*)e->fused.net[n].W3b : nullptr;
     a.fW3h[n] = (on && (n == 1 || e->fused.A <= 16)) ? (float*)e->fused.net[n].W3h : nullptr;
     a.fb1s[n] = on ? (float*)e->fused.net[n].b1s : nullptr;
     a.fb2s[n] = on ? (float*)e->fused.net[n].b2s : nullptr;
     const bool x3 = on && e->fused.train_x3;  // the gradient kernel reads the x3 packs every step: k_adam_pack keeps them current
     a.xW1[n] = x3 ? reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W1x)) : nullptr;
     a.xW2[n] = x3 ? reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2x)) : nullptr;
-    a.xW2b[n] = x3 ? reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2bx)) : nullptr;
-    const bool ch = on && e->fused.train_chain;  // likewise the chain packs of k_chain_train
+    a.xW2b[n] = x3 && !ch ? reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2bx)) : nullptr;
+    // likewise the chain packs of k_chain_train
     a.cW1[n] = ch ? reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W1c)) : nullptr;
     a.cW2[n] = ch ? reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2c)) : nullptr;
     a.cW2b[n] = ch ? reinterpret_cast<unsigned short*>(const_cast<unsigned*>(e->fused.net[n].W2bc)) : nullptr;

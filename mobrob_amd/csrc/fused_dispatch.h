@@ -93,7 +93,9 @@ inline hipError_t fused_set_lds_attr(FusedState& f) {
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_act<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_act_bytes);
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_persistent<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rollout_lds_bytes(f.Dp));
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_persistent<DPc, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rollout_lds_bytes(f.Dp));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_persistent<DPc, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rollout_lds_bytes(f.Dp));
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_value_batch<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);
     });

@@ -587,6 +587,9 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
         for (int i = 0; i < 4; ++i) acc2[t][i] = c[i] * (1.0f - acc2[t][i] * acc2[t][i]);
       }
     }
+    // (Touching the dh1 weight pack's lines here, 19 k cycles ahead of its stream -- it has usually left the XCD's L2 since the last
+    //  tile -- was measured: dh1 loop 24.3 k -> 19.8 k cycles, the twelve 4-byte LDS-DMAs per wave cost 2.2 k in this phase, launch
+    //  332.7 -> 341.5 us on the same box.  Not kept; profiles/r4/chain_l2.txt.)
     STAMP(3)
     LDS_BARRIER();   // h2 image and dout image complete
     STAMP(4)

@@ -2190,11 +2190,10 @@ __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, fl
       if (a.fW2f[net]) {
         const int K = net ? a.G1 : a.H1, n = e / K, k = e - n * K;
         a.fW2f[net][pack_fwd_idx(n, k, K / 8)] = kTanhScale * pn;
-        a.fW2b[net][pack_bwd_idx(n, k, (net ? a.G2 : a.H2) / 8)] = pn;
-        if (a.xW2[net]) {
-          x3_pack_store(a.xW2[net], n, k, K / 16, kTanhScale * pn);               // forward operand B[k][n] = scale W2[n][k]
-          x3_pack_store(a.xW2b[net], k, n, (net ? a.G2 : a.H2) / 16, pn);          // backward operand B[n][k] = W2[n][k]
-        }
+        // (packs only a gradient kernel reads are null while another gradient kernel is the engine's: k_chain_train has its own)
+        if (a.fW2b[net]) a.fW2b[net][pack_bwd_idx(n, k, (net ? a.G2 : a.H2) / 8)] = pn;
+        if (a.xW2[net]) x3_pack_store(a.xW2[net], n, k, K / 16, kTanhScale * pn);                       // forward operand B[k][n] = scale W2[n][k]
+        if (a.xW2b[net]) x3_pack_store(a.xW2b[net], k, n, (net ? a.G2 : a.H2) / 16, pn);                // backward operand B[n][k] = W2[n][k]
         if (a.cW2[net]) chain_store_w2(a.cW2[net], a.cW2b[net], n, k, kTanhScale * pn, pn);
       }
     } break;
@@ -2203,7 +2202,7 @@ __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, fl
       (net ? a.vWp : a.aWp)[e] = pn;
       if (a.fW3f[net]) {
         a.fW3f[net][pack_fwd_idx(n, k, K / 8)] = pn;
-        a.fW3b[net][pack_bwd_idx(n, k, 4)] = pn;
+        if (a.fW3b[net]) a.fW3b[net][pack_bwd_idx(n, k, 4)] = pn;
         if (a.fW3h[net] && n < 16) a.fW3h[net][pack_h16_idx(n, k)] = pn;
         if (a.cW3[net] && n < 16) { a.cW3[net][chain_head_fwd_idx(n, k)] = pn; a.cW3b[net][chain_head_bwd_idx(n, k)] = pn; }
       }

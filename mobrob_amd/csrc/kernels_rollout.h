@@ -108,7 +108,9 @@ __device__ __forceinline__ void gemm_two_resident(int a_off, const RFrags<NKG>& 
   }
 }
 
-template <int DP>
+// KIND: the env source compiled in (1 synthetic, 2 goal environment; = a.kind): one variant carries one env's scalars -- with both in
+// one kernel ~200 scalar registers were parked in VGPR lanes and read back (v_readlane) inside the step loop.
+template <int DP, int KIND>
 __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(RolloutArgs a) {
   using L = LayRo<DP>;
   using LB = Lay32<DP>;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
     const int n = row0 + tid0;
     float* S = &lds[L::ST + tid0 * 16];
     if (n < N) {
-      if (a.kind == 2) {
+      if (KIND == 2) {
 #pragma unroll
         for (int j = 0; j < kGoalStateFloats; ++j) S[j] = a.gstate[(size_t)n * kGoalStateFloats + j];
       } else {
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
     int ep_len_new = 0, ep_len_fin = 0;
     GoalState g{};
     if (live && ROLL_ON(16)) {
-      if (a.kind == 1) {
+      if (KIND == 1) {
         const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, ek0, ek1);
         const bool term = u32_to_unit_open(mr.x) < a.p_term;
         const int len = reinterpret_cast<const int*>(S)[13] + 1;
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       if (ROLL_ON(128)) a.es[so] = S[12];
       S[12] = done ? 1.f : 0.f;
       if (ROLL_ON(128)) a.trunc[n] = tr ? 1 : 0;
-      if (a.kind == 1) {
+      if (KIND == 1) {
         reinterpret_cast<int*>(S)[13] = ep_len_new;
       } else {
         goal_store(S, g);
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
     }
   }
   // ---- episode statistics: one set of atomics per wave and launch (order irrelevant: diagnostics) ----
-  if (a.kind == 2) {
+  if (KIND == 2) {
     const double n = wave_sum_d(es_n), r = wave_sum_d(es_ret), l = wave_sum_d(es_len), g = wave_sum_d(es_goal);
     if ((tid0 & 63) == 0 && n > 0.0) {
       atomicAdd(&a.ep_stats[0], n); atomicAdd(&a.ep_stats[1], r); atomicAdd(&a.ep_stats[2], l); atomicAdd(&a.ep_stats[3], g);
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
     const int n = row0 + tid0;
     const float* S = &lds[L::ST + tid0 * 16];
     if (n < N) {
-      if (a.kind == 2) {
+      if (KIND == 2) {
 #pragma unroll
         for (int j = 0; j < kGoalStateFloats; ++j) a.gstate[(size_t)n * kGoalStateFloats + j] = S[j];
       } else {
