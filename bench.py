@@ -727,11 +727,12 @@ def bench_single(args, name, steps, warmup, job, phases):
             out["exchange_selfcheck"] = getattr(backend, "exchange_selfcheck", {}) or {"note": "no engine-owned exchange to check (host-staged callback)"}
         if job.same_device:
             out["rehearsal"] = {"what": f"{world} ranks time-sharing ONE GPU (MOBROB_DP_SAME_DEVICE=1): gloo process group, the C "
-                                        "loop mobrob_ppo_train_dp with the host-staged all-reduce callback; no throughput is "
-                                        "claimed",
+                                        f"loop mobrob_ppo_train_dp, sums through: {exchange}; no throughput is claimed",
                                 "env_steps_per_s_time_shared": value, "replicas_bit_identical": identical}
     if use_dp and not identical:
         raise SystemExit("bench.py: the replicas' parameters differ between ranks")
+    if use_dp:
+        backend.close()       # one-shot exchange: no rank unmaps its buffer while a peer may still read it
     eng.close()
     return out
 

@@ -206,6 +206,17 @@ class EngineBackend:
             self.exchange = "gloo-callback"
         return self.exchange
 
+    def close(self, group=None):
+        """Closing handshake of the one-shot exchange (collective; a no-op for the other exchanges): a rank that has finished
+        its last all-reduce has read every peer's slot, but a peer may still be reading ITS slot -- so every rank drains its
+        stream, all meet at a barrier, and only then are the exchange buffers unmapped and freed."""
+        if getattr(self, "exchange", None) == "oneshot" and getattr(self, "_oneshot_ready", False):
+            self.e.synchronize()
+            dist.barrier(group=group)
+            self.e.oneshot_close()
+            self._oneshot_ready = None      # a later update sets the exchange up again
+            self.exchange = None
+
     def gloo_all_reduce(self, group=None):
         """All-reduce callback for `engine.train_dp` under a CPU process group: stage through the host."""
         def reduce_in_place(ptr, count, dtype, _stream):

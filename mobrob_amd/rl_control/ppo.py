@@ -512,6 +512,8 @@ class PPO:
         if self._tb is not None:
             self._tb.close()
             self._tb = None
+        if self._backend is not None:
+            self._backend.close()     # one-shot exchange: collective closing handshake (parallel.EngineBackend.close)
         callback.on_training_end()
         return self
 

@@ -8,7 +8,7 @@ for r in rows:
     agg[name][r['Counter_Name']].append(float(r['Counter_Value']))
     dur[name].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
 for k in agg:
-    if 'fused' in k or 'slab' in k:
+    if any(t in k for t in ('fused', 'slab', 'chain', 'rollout', 'value_batch', 'adam_pack')):
         c = {n: statistics.median(v) for n, v in agg[k].items()}
         d = statistics.median(dur[k])
         print(k, "median dur us", d / 1e3)

@@ -354,6 +354,8 @@ def _oneshot_worker(rank, world, port, case, out):
             calls, _ = e.allreduce_counters()
             assert calls == 2 * 3 * c["E"] * (e.n_minibatches + 1)
     np.savez(out.format(rank=rank), **res)
+    be.close()          # closing handshake: drain, barrier, then unmap
+    assert be.exchange is None
     e.close()
     dist.destroy_process_group()
 
