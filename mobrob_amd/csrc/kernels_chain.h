@@ -126,9 +126,8 @@ __device__ __forceinline__ X3Frag ring_read(int ring_lane_f0, int slot) {  // ri
 #define CHAIN_WAIT_DMA(more) \
   if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
-// Workgroup barrier for LDS hand-offs only.  __syncthreads() is a workgroup-scope fence as well: it drains vmcnt, i.e. it waits for the
-// next tile's gathers (HBM latency) and for the slab stores at every barrier of the tile -- 2-3 k cycles each.
-#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// (LDS_BARRIER: kernels_fused.h.  __syncthreads() here would wait for the next tile's gathers (HBM latency) and for the slab stores at
+//  every barrier of the tile -- 2-3 k cycles each.)
 #if MOBROB_CHAIN_SKIP & 2
 #define CHAIN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #else
@@ -762,6 +761,20 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
       });
     }
     STAMP(9)
+    // dW1's first X fragments: the X image was complete long ago, so they are read and split in front of the barrier -- while this wave
+    // would otherwise wait for the slowest wave's dz1 epilogue
+    X3Frag B0, B1;
+    int b0o, b1o;
+    {
+      const int r = lane & 31, h = lane >> 5;
+      const int c0 = (r < DP) ? r : 0;
+      const int c1 = (32 + r < DP) ? 32 + r : c0;   // clamped columns are never read back
+      b0o = opaque4(L::XI + c0 * 64 + ((((2 * h) ^ c0) & 15) << 2));
+      b1o = opaque4(L::XI + c1 * 64 + ((((2 * h) ^ c1) & 15) << 2));
+      B0 = col_frag_split(img_frag_load(b0o));
+      B1 = B0;
+      if (DP > 32) B1 = col_frag_split(img_frag_load(b1o));
+    }
     // level 2 of the next tile's gathers: in flight under dW1 (LDS operands only) and into the next tile
     if (!(MOBROB_CHAIN_SKIP & 32)) gather_tile(nsrc, g);
     LDS_BARRIER();   // dz1 image complete (and every wave is done with the ring)
@@ -777,17 +790,12 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
       constexpr bool two = DP > 32;
       const int r = lane & 31, h = lane >> 5;
       const int ao = opaque4(L::H1 + (64 * wave + r) * 64 + ((((2 * h) ^ r) & 15) << 2));
-      const int c0 = (r < DP) ? r : 0;
-      const int c1 = (32 + r < DP) ? 32 + r : c0;   // clamped columns are never read back
-      const int b0o = opaque4(L::XI + c0 * 64 + ((((2 * h) ^ c0) & 15) << 2)), b1o = opaque4(L::XI + c1 * 64 + ((((2 * h) ^ c1) & 15) << 2));
       const int co = opaque4(L::H1 + tid * 64);
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
       // Software pipeline over the four k steps of sixteen rows: while the six MFMA statements of step ks run (four MFMAs each at
       // DP = 64), the fragments of step ks + 1 -- read from LDS at the top of the step -- are split pair by pair between them
       // (the first version split everything in front of the MFMAs: 12.5 k cycles per tile for 3 k of matrix time).
       X3Frag A0 = col_frag_split(img_frag_load(ao)), A1 = col_frag_split(img_frag_load(ao + 32 * 64));
-      X3Frag B0 = col_frag_split(img_frag_load(b0o)), B1 = B0;
-      if (two) B1 = col_frag_split(img_frag_load(b1o));
       STAMP(13)
       // the slab loads have landed (the gathers behind them, and the twelve ring DMAs of a primed next tile, may still be in flight)
       if (primed) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(gW1a), "+v"(gW1b), "+v"(gW1c), "+v"(gW1d) : "n"(NGL + 12) : "memory");

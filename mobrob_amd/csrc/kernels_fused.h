@@ -164,6 +164,10 @@ __device__ __forceinline__ unsigned opaque_u(unsigned x) {
   asm volatile("" : "+v"(x));
   return x;
 }
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() is a workgroup-scope fence as well: it drains vmcnt, i.e. it waits for
+// every global load AND STORE the wave has in flight (a store's acknowledgement comes from L2 / HBM) -- which a hand-off through LDS
+// does not need.  Global stores that only a later kernel reads need no wait inside this one.
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 __device__ __forceinline__ f32x4 ldg16(const void* base, unsigned byte_off) {
   return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
 }

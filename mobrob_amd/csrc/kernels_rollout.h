@@ -54,19 +54,22 @@ struct LayRo {
   static constexpr int ST = CA + 32 * 33;   // [32][16] row state: goal state [0..11] | prev_done [12] | ep_len [13]
   static constexpr int BL = ST + 32 * 16;   // bootstrap list: cnt[4] | row[32] | reward[32]
   static constexpr int AC = BL + 4 + 64;    // per-action constants: sd[32] | 2 sd^2 [32] | log sd [32] | b3[32]
-  static constexpr int ZN = AC + 128;       // [32][32] standard normals of the current step
-  static constexpr int TM = ZN + 32 * 32;   // [32][33] log-prob terms of the current step
-  static constexpr int EN = TM + 32 * 33;   // [32][DP] standard normals of the env phase (observation noise)
-  static constexpr int END = EN + 32 * DP;
+  static constexpr int ZN = AC + 128;       // [2][32][32] standard normals of the sampling stage, double-buffered by step parity
+  static constexpr int TM = ZN + 2 * 32 * 32;   // [32][33] log-prob terms of the current step
+  static constexpr int EN = TM + 32 * 33;   // [2][32][DP] standard normals of the env phase (observation noise), by step parity
+  static constexpr int END = EN + 2 * 32 * DP;
 };
 inline size_t rollout_lds_bytes(int Dp) {
-  return fused_lds_act_bytes(Dp) + (size_t)(32 * 33 + 32 * 16 + 68 + 128 + 32 * 32 + 32 * 33 + 32 * Dp) * sizeof(float);
+  return fused_lds_act_bytes(Dp) + (size_t)(32 * 33 + 32 * 16 + 68 + 128 + 2 * 32 * 32 + 32 * 33 + 2 * 32 * Dp) * sizeof(float);
 }
 // The workgroup is EIGHT waves: four run the policy forward / sampling / env rules of the tile (one per SIMD, as before),
-// four "noise waves" (the second wave of every SIMD) draw the step's random numbers -- Philox4x32-10 + Box-Muller for
-// the sampling normals and for the observation noise of the env phase, 600 draws per step and tile -- into LDS
-// while the matrix pipe runs the hidden-layer GEMMs of the same step.  Same counters, same values as before (and as the
-// per-step kernels); the draws used to sit in front of the GEMMs and inside the env phase: 2.9 of 15.2 us per step.
+// four "noise waves" (the second wave of every SIMD) draw the random numbers -- Philox4x32-10 + Box-Muller for
+// the sampling normals and for the observation noise of the env phase, 600 draws per step and tile -- into LDS.  Same
+// counters, same values as before (and as the per-step kernels); the draws used to sit in front of the GEMMs and inside the
+// env phase: 2.9 of 15.2 us per step.  Round 3 drew step t's numbers under the GEMMs of step t; with the x3 GEMMs that costs
+// 1.8 us per step un-hidden (the operand splits of the policy waves need the same VALU issue slots).  Round 4: the numbers of
+// step t + 1 are drawn during the sampling / env / state phases of step t, when the policy waves' VALU work is light, into
+// the other half of a double buffer (the counters depend on (row, chunk, step) only, not on the state).
 // (The second draw of a row that ends an episode -- its reset observation -- stays with the policy waves: rare.)
 // MOBROB_ROLLOUT_STATIONARY (default 0: measured SLOWER, kept as a switch): the other plan for the same kernel -- FOUR waves, one per SIMD with all 512 registers
 // of a lane, and the policy's weights STATIONARY in them for the whole launch: wave w holds the fragment packs of its 64
@@ -178,39 +181,52 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
   for (int t = a.t0; t < a.t1; ++t) {
     const int tid = opaque(tid0), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
-    if (noise_wave || kRolloutStationary) {  // the step's random numbers: by the noise waves under the GEMMs of the other
-      // four (then they only keep the barriers' count), or -- weights-stationary plan -- by the four waves themselves, first
-      const int hid = kRolloutStationary ? tid : tid - FTHREADS;
-      const uint32_t step = sbase + (uint32_t)t;
-      if (ROLL_ON(1)) {  // standard normals of the sampling stage (consumed after the head)
-        const int ngrp = (A + 3) >> 2;
-        for (int i = hid; i < R * ngrp; i += FTHREADS) {
-          const int rr_ = i / ngrp, gq = i - rr_ * ngrp;
-          float z[4];
-          box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)gq, (uint32_t)t + dbase, 0x45505331u, (uint32_t)a.seed,
-                                    (uint32_t)(a.seed >> 32)), z);
+    // the random numbers of step ts into buffer ts & 1
+    auto draw_sampling = [&](int ts, int hid) {  // standard normals of the sampling stage (consumed after the head)
+      if (!ROLL_ON(1)) return;
+      const int ngrp = (A + 3) >> 2;
+      const int zb = L::ZN + (ts & 1) * (32 * 32);
+      for (int i = hid; i < R * ngrp; i += FTHREADS) {
+        const int rr_ = i / ngrp, gq = i - rr_ * ngrp;
+        float z[4];
+        box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)gq, (uint32_t)ts + dbase, 0x45505331u, (uint32_t)a.seed,
+                                  (uint32_t)(a.seed >> 32)), z);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) lds[L::ZN + rr_ * 32 + 4 * gq + j] = z[j];
+        for (int j = 0; j < 4; ++j) lds[zb + rr_ * 32 + 4 * gq + j] = z[j];
+      }
+    };
+    auto draw_env = [&](int ts, int hid) {  // observation noise of the env phase
+      if (!ROLL_ON(16) || !ROLL_ON(256)) return;   // (256: the draw alone, for timing)
+      const uint32_t step_ = sbase + (uint32_t)ts;
+      const int eb = L::EN + (ts & 1) * (32 * DP);
+      for (int i = hid; i < R * per; i += FTHREADS) {
+        const int rr_ = i / per, c = i - rr_ * per;
+        if (row0 + rr_ < N) {
+          float z[4];
+          box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)c, step_, kStreamEnvObs, ek0, ek1), z);
+          *reinterpret_cast<f32x4*>(&lds[eb + rr_ * DP + 4 * c]) = f32x4{z[0], z[1], z[2], z[3]};
         }
       }
-      if (!kRolloutStationary) __syncthreads();  // (1) after layer 1: the env phase of the previous step has long finished reading EN
-      if (ROLL_ON(16)) {  // observation noise of the env phase
-        for (int i = hid; i < R * per; i += FTHREADS) {
-          const int rr_ = i / per, c = i - rr_ * per;
-          if (row0 + rr_ < N) {
-            float z[4];
-            box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)c, step, kStreamEnvObs, ek0, ek1), z);
-            *reinterpret_cast<f32x4*>(&lds[L::EN + rr_ * DP + 4 * c]) = f32x4{z[0], z[1], z[2], z[3]};
-          }
-        }
-      }
-      if (!kRolloutStationary) {
-        __syncthreads();  // (2) after layer 2
-        __syncthreads();  // (3) after the head
-        __syncthreads();  // (4) after the sampling stage
-        __syncthreads();  // (5) after the env phase
-        __syncthreads();  // (6) after the state update
-      }
+    };
+    if (kRolloutStationary) {  // weights-stationary plan: the four waves draw their own numbers, first
+      draw_sampling(t, tid);
+      draw_env(t, tid);
+    } else if (noise_wave) {
+      // (every barrier of the step loop is LDS-only: the step's global stores -- observations, actions, log-probs, rewards -- are read by
+      //  later kernels, and __syncthreads() made each of the three barriers behind them wait for their acknowledgement: 1.5 us per step)
+      // Step t's numbers were drawn during step t - 1 (or in front of the loop); the noise waves keep the barriers' count and
+      // draw step t + 1's numbers into the other buffer halves while the policy waves sample, step the env and update the state:
+      // the half being written was last read in step t - 1, whose phases all ended before barrier (6) of that step.
+      const int hid = tid - FTHREADS;
+      if (t == a.t0) { draw_sampling(t, hid); draw_env(t, hid); }
+      LDS_BARRIER();  // (1) after layer 1
+      LDS_BARRIER();  // (2) after layer 2
+      LDS_BARRIER();  // (3) after the head
+      if (t + 1 < a.t1) draw_sampling(t + 1, hid);
+      LDS_BARRIER();  // (4) after the sampling stage
+      if (t + 1 < a.t1) draw_env(t + 1, hid);
+      LDS_BARRIER();  // (5) after the env phase
+      LDS_BARRIER();  // (6) after the state update
     }
     if (!noise_wave) {
     {  // layer 1
@@ -229,7 +245,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         lds[o + crc(i) * FLDH + 32] = ROLL_TANH(c1[i]);
       }
     }
-    __syncthreads();
+    LDS_BARRIER();
     {  // layer 2
       f32x16 c0 = splat16(W.b2s[64 * wave + r]), c1 = splat16(W.b2s[64 * wave + 32 + r]);
       constexpr int nkg = FH / 8;
@@ -246,7 +262,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         lds[o + crc(i) * FLDH + 32] = ROLL_TANH(c1[i]);
       }
     }
-    __syncthreads();
+    LDS_BARRIER();
     {  // head: K split over the 4 waves (64 each); partial tiles side by side, summed in the sampling stage
       f32x16 acc = zero16(), acc2 = zero16();
       const int ab = 4 * opaque((LB::H2 + r * FLDH + wave * 64 + 4 * h) >> 2);
@@ -269,7 +285,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       for (int i = 0; i < 16; ++i) lds[o + crc(i) * FLDO] = acc[i] + acc2[i];
     }
     if (tid == 0) *cnt = 0;
-    __syncthreads();
+    LDS_BARRIER();
     // ---- Gaussian sample + log-prob.  Same expressions and Philox counters as k_fused_act, spread over the block:
     //      (row, action group) items draw the normals, (row, action) items form action and log-prob term, one lane
     //      per row adds the terms in action order (-> bit-identical log-probs) ----
@@ -280,7 +296,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         const int db = LB::DO + rr_ * FLDO + k;
         const float m = ((lds[db] + lds[db + R * FLDO]) + (lds[db + 2 * R * FLDO] + lds[db + 3 * R * FLDO])) + lds[L::AC + 96 + k];
         const float sd = lds[L::AC + k];
-        const float act = m + lds[L::ZN + rr_ * 32 + k] * sd;
+        const float act = m + lds[L::ZN + (t & 1) * (32 * 32) + rr_ * 32 + k] * sd;
         const float d = act - m;
         lds[L::TM + rr_ * 33 + k] = -(d * d) / lds[L::AC + 32 + k] - lds[L::AC + 64 + k] - 0.91893853320467274178f;
         const float ac = fminf(fmaxf(act, a.lo), a.hi);
@@ -289,7 +305,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         lds[L::CA + rr_ * 33 + k] = ac;
       }
     }
-    __syncthreads();
+    LDS_BARRIER();
     if (tid < R && row0 + tid < N) {
       float lp = 0.f;
       for (int k = 0; k < A; ++k) lp += lds[L::TM + tid * 33 + k];
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         done = term || tr;
         ep_len_new = done ? 0 : len;
         for (int c = sub; c < per; c += 8) {
-          f32x4 z = *reinterpret_cast<const f32x4*>(&lds[L::EN + rr * DP + 4 * c]);  // drawn by the noise waves
+          f32x4 z = *reinterpret_cast<const f32x4*>(&lds[L::EN + (t & 1) * (32 * DP) + rr * DP + 4 * c]);  // drawn by the noise waves
           f32x4 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
@@ -347,7 +363,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         for (int c = sub; c < per; c += 8) {
           float z[4];
           {
-            const f32x4 zz = *reinterpret_cast<const f32x4*>(&lds[L::EN + rr * DP + 4 * c]);  // drawn by the noise waves
+            const f32x4 zz = *reinterpret_cast<const f32x4*>(&lds[L::EN + (t & 1) * (32 * DP) + rr * DP + 4 * c]);  // drawn by the noise waves
             z[0] = zz[0]; z[1] = zz[1]; z[2] = zz[2]; z[3] = zz[3];
           }
           f32x4 ob = goal_features(g, a.goal.P, D, c, z, a.goal.noise);
@@ -365,7 +381,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         g = gn;
       }
     }
-    __syncthreads();  // every thread of a row has read the row's old state
+    LDS_BARRIER();  // every thread of a row has read the row's old state
     if (live && sub == 0) {
       const size_t so = (size_t)t * N + n;
       if (ROLL_ON(128)) a.es[so] = S[12];
@@ -388,7 +404,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         if (ROLL_ON(128)) a.rewards[so] = reward;
       }
     }
-    __syncthreads();
+    LDS_BARRIER();
     }  // (policy waves)
     // ---- time-limit bootstrap of the (rare) truncated rows: r += gamma * V(terminal_obs).  All eight waves (the value MLP
     //      of a row is a block-wide routine with its own barriers; the noise waves hold no hidden unit and add zeros) ----
