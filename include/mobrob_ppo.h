@@ -359,7 +359,10 @@ int mobrob_ppo_train_enqueue(mobrob_ppo_engine_t* e, const int64_t* perms);
  *   [all-reduce advstat_dev, 3 doubles per minibatch]
  *   minibatch_grad(mb) -> local gradient of the GLOBAL-mean loss into grad_dev (P floats)
  *   [all-reduce grad_dev (sum)]
- *   minibatch_apply -> clip_grad_norm_ + Adam.step on every rank (replicas stay identical) */
+ *   minibatch_apply -> clip_grad_norm_ + Adam.step on every rank (replicas stay identical)
+ * `perm` (also every row of `perms` of mobrob_ppo_train / _train_dp / _train_enqueue) must be a PERMUTATION of [0, T*N) in SB3's env-major
+ * flat order (index = n * T + t): it is validated on the host -- every index in range, none twice -- and MOBROB_ERR_INVALID is returned
+ * before any kernel scatters through it.  NULL: the engine draws its own (a keyed Feistel permutation on the device). */
 int mobrob_ppo_epoch_begin(mobrob_ppo_engine_t* e, const int64_t* perm /* T*N or NULL */);
 int mobrob_ppo_num_minibatches(const mobrob_ppo_engine_t* e);
 int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb);
