@@ -621,7 +621,13 @@ def test_x3_gradient_kernel_is_float32_accurate(D, A):
     idx = rng.permutation(T * N)
     _, og, aux = O.loss_and_grads(p, *O.gather_minibatch(buf, idx[:B]), h, acc=np.float64)
     lo, hi = 1.0 - h.clip_range, 1.0 + h.clip_range
-    assert not ((np.abs(aux["ratio"] - lo) < 2e-5) | (np.abs(aux["ratio"] - hi) < 2e-5)).any()  # no row on a clip boundary
+    near = (np.abs(aux["ratio"] - lo) < 2e-5) | (np.abs(aux["ratio"] - hi) < 2e-5)
+    if near.any():   # rows within float32 rounding of a clip boundary flip between two correct implementations: move them off it
+        assert int(near.sum()) <= 4, int(near.sum())       # (a 4e-5-wide band holds ~1e-4 of 8192 rows: a handful at most)
+        t, n = O.flat_to_tn(idx[:B][near], T)
+        buf["log_probs"][t, n] -= np.float32(0.01)         # the engines below load the moved buffer
+        _, og, aux = O.loss_and_grads(p, *O.gather_minibatch(buf, idx[:B]), h, acc=np.float64)
+        assert not ((np.abs(aux["ratio"] - lo) < 2e-5) | (np.abs(aux["ratio"] - hi) < 2e-5)).any()
     errs = {}
     for x3 in (True, False):
         e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=1, pi=(H, H), vf=(H, H),
