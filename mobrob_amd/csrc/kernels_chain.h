@@ -587,8 +587,9 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
       }
     }
     // (Touching the dh1 weight pack's lines here, 19 k cycles ahead of its stream -- it has usually left the XCD's L2 since the last
-    //  tile -- was measured: dh1 loop 24.3 k -> 19.8 k cycles, the twelve 4-byte LDS-DMAs per wave cost 2.2 k in this phase, launch
-    //  332.7 -> 341.5 us on the same box.  Not kept; profiles/r4/chain_l2.txt.)
+    //  tile -- was measured twice: by every workgroup for itself (dh1 loop 24.3 k -> 19.8 k cycles, 2.2 k of issue here, launch 332.7 ->
+    //  341.5 us on the same box) and by ONE of the sixteen workgroups of an XCD and network per tile iteration (total 104.0 k -> 102.0 k
+    //  cycles per tile, launch 338.2 -> 343.8 us).  Fewer cycles, longer launches, both times: not kept; profiles/r4/chain_l2.txt.)
     STAMP(3)
     LDS_BARRIER();   // h2 image and dout image complete
     STAMP(4)
