@@ -57,8 +57,8 @@ typedef struct mobrob_ppo_config {
   int32_t abi_version;        /* = MOBROB_PPO_ABI_VERSION                                        */
   int32_t obs_dim;            /* D: 14 point, 26 car, 58 doggo, 12 drone, 43 turtlebot3          */
   int32_t act_dim;            /* A:  2,        2,      12,       18,       2                     */
-  int32_t pi_hidden[2];       /* policy_kwargs.net_arch.pi  (default [64,64])                    */
-  int32_t vf_hidden[2];       /* policy_kwargs.net_arch.vf  (default [64,64])                    */
+  int32_t pi_hidden[2];       /* policy_kwargs.net_arch.pi  (default [64,64]); one hidden layer: [h, 0]; a third: pi_hidden3 below */
+  int32_t vf_hidden[2];       /* policy_kwargs.net_arch.vf  (default [64,64]); likewise with vf_hidden3                         */
   int32_t n_envs;             /* N: vectorised envs owned by THIS rank (yaml n_envs)             */
   int32_t n_steps;            /* T: rollout horizon (ppo_kwargs.n_steps, default 2048)           */
   int32_t batch_size;         /* GLOBAL minibatch size (ppo_kwargs.batch_size, default 64)       */
@@ -89,7 +89,10 @@ typedef struct mobrob_ppo_config {
                                  RESULTS (error against float64 not larger than v_mfma_f32's, not bit-equal to it) at up to
                                  16/6 of the f32 matrix rate.  0: v_mfma_f32 everywhere.  Heads, loss, GAE, clip and Adam are plain float32
                                  either way; so are the 64-wide kernel families and the generic GEMM chain. */
-  int32_t reserved[3];
+  int32_t pi_hidden3;         /* width of a THIRD policy hidden layer (0: none).  net_arch depths 1 .. 3 are accepted per network (SB3 takes any
+                                 list; the reference's YAMLs use two layers); depths other than two run the generic GEMM chain */
+  int32_t vf_hidden3;         /* likewise for the value network */
+  int32_t reserved[1];
 } mobrob_ppo_config_t;
 
 /* Fill `cfg` with SB3 2.0.0 defaults (Appendix A.1).  Replaces PPO.__init__'s default kwargs. */

@@ -33,7 +33,8 @@ class Config(C.Structure):
         ("action_low", C.c_double), ("action_high", C.c_double),
         ("normalize_advantage", C.c_int32), ("seed", C.c_uint64), ("device_id", C.c_int32),
         ("rank", C.c_int32), ("world_size", C.c_int32), ("fast_kernels", C.c_int32), ("rollout_graph", C.c_int32), ("rollout_persistent", C.c_int32),
-        ("activation", C.c_int32), ("forward_x3", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("activation", C.c_int32), ("forward_x3", C.c_int32), ("pi_hidden3", C.c_int32), ("vf_hidden3", C.c_int32),
+        ("reserved", C.c_int32 * 1),
     ]
 
 

@@ -44,6 +44,22 @@ POLICY_KEYS = ["log_std",
                "action_net.weight", "action_net.bias", "value_net.weight", "value_net.bias"]
 
 
+def policy_keys(n_hidden_pi=2, n_hidden_vf=2):
+    """SB3's registration order for `net_arch` depths other than the reference's two hidden layers (`nn.Sequential` indices 0, 2,
+    4 ...: every Linear is followed by its activation module); POLICY_KEYS == policy_keys(2, 2)."""
+    keys = ["log_std"]
+    for net, n in (("policy_net", n_hidden_pi), ("value_net", n_hidden_vf)):
+        for i in range(n):
+            keys += [f"mlp_extractor.{net}.{2 * i}.weight", f"mlp_extractor.{net}.{2 * i}.bias"]
+    return keys + ["action_net.weight", "action_net.bias", "value_net.weight", "value_net.bias"]
+
+
+def depth_of_keys(keys):
+    """(policy hidden layers, value hidden layers) of a state-dict key list."""
+    return (sum(1 for k in keys if k.startswith("mlp_extractor.policy_net.") and k.endswith(".weight")),
+            sum(1 for k in keys if k.startswith("mlp_extractor.value_net.") and k.endswith(".weight")))
+
+
 # ---------------------------------------------------------------------------------------------------
 # tiny pickle assembler (protocol 5, same opcodes as the reference blobs; payloads are bytearrays)
 # ---------------------------------------------------------------------------------------------------
@@ -267,7 +283,7 @@ def save_zip(path, *, params, optimizer, hyper, obs_dim, act_dim, net_arch=None,
         path = str(path) + ".zip"
     counters = dict(counters or {})
     keys = list(params.keys())
-    assert keys == POLICY_KEYS, "parameters must be in SB3 registration order"
+    assert keys == policy_keys(*depth_of_keys(keys)), "parameters must be in SB3 registration order"
     obs_low = np.broadcast_to(np.asarray(-np.inf if obs_low is None else obs_low, np.float32), (obs_dim,)).copy()
     obs_high = np.broadcast_to(np.asarray(np.inf if obs_high is None else obs_high, np.float32), (obs_dim,)).copy()
     act_low = np.broadcast_to(np.asarray(action_low, np.float32), (act_dim,)).copy()

@@ -89,17 +89,40 @@ struct ProfSpan {
   int id;
 };
 
-enum { T_LOGSTD = 0, T_PW1, T_PB1, T_PW2, T_PB2, T_VW1, T_VB1, T_VW2, T_VB2, T_AW, T_AB, T_VW, T_VB, T_COUNT };
+// Canonical tensors in SB3's registration order: log_std, (W, b) of every policy hidden layer, (W, b) of every value hidden layer,
+// action head, value head.  With one to three hidden layers per network that is 9 .. 17 tensors; the ids are the engine's
+// (engine_dims), the names below resolve through `e`.  Two hidden layers per network give the numbering 0 .. 12 the fused
+// kernels' argument structs were written for.
+constexpr int kMaxHidden = 3;
+constexpr int kMaxTensors = 1 + 4 * kMaxHidden + 4;   // 17
+#define T_LOGSTD 0
+#define T_PW1 (e->tPW[0])
+#define T_PB1 (e->tPB[0])
+#define T_PW2 (e->tPW[1])
+#define T_PB2 (e->tPB[1])
+#define T_VW1 (e->tVW[0])
+#define T_VB1 (e->tVB[0])
+#define T_VW2 (e->tVW[1])
+#define T_VB2 (e->tVB[1])
+#define T_AW (e->tAW)
+#define T_AB (e->tAB)
+#define T_VW (e->tVWh)
+#define T_VB (e->tVBh)
 
 }  // namespace
 
 struct mobrob_ppo_engine {
   mobrob_ppo_config_t cfg;
-  int D, Dp, A, Ap, H1, H2, G1, G2, N, T, P;
+  int D, Dp, A, Ap, H1, H2, G1, G2, N, T, P;   // H1, H2 / G1, G2: the first two hidden widths (the fused kernels' view; H2 = 0 at depth 1)
+  int Lp = 2, Lv = 2;                          // hidden layers of the policy / value network (1 .. 3)
+  int Hp[kMaxHidden] = {0}, Hv[kMaxHidden] = {0};   // their widths
+  int HL = 0, GL = 0;                          // width of the last hidden layer of each network (what the heads read)
+  int tPW[kMaxHidden] = {0}, tPB[kMaxHidden] = {0}, tVW[kMaxHidden] = {0}, tVB[kMaxHidden] = {0}, tAW = 0, tAB = 0, tVWh = 0, tVBh = 0;
+  int ntens = 13;
   int Bl;        // local minibatch rows (batch_size / world)
   int nmb;       // minibatches per epoch
   int rows_max;  // max rows any forward sees at once
-  int offs[T_COUNT + 1];  // canonical parameter offsets (SB3 order); offs[13] = P
+  int offs[kMaxTensors + 1];  // canonical parameter offsets (SB3 order); offs[ntens] = P
   hipStream_t stream = nullptr;
   bool own_stream = false;
   // parameters / optimizer
@@ -178,15 +201,15 @@ struct mobrob_ppo_engine {
   } oneshot;
   // norm records of the reduction kernels (kernels_fused.h: block_norm_records): used inside mobrob_ppo_train only
   double* norm_rec_sum = nullptr; int* norm_rec_t = nullptr; int* fold_idx_dev = nullptr;
-  int fold_start[14] = {0};
+  int fold_start[kMaxTensors + 1] = {0};
   bool use_norm_records = false;
   int rollout64_tile_max = 256;  // rollouts of up to this many 32-env tiles use k_rollout64_tile (MOBROB_ROLLOUT64_TILE_MAX)
   int pair64_min_tiles = 65;     // minibatches of at least this many tiles use k_pair64_train (MOBROB_PAIR64_MIN_TILES; 0: never)
   int split64_max_tiles = 64;  // minibatches of up to this many 32-row tiles use k_split64_train (MOBROB_SPLIT64_MAX_TILES)
   // generic-path workspace
   float *Xg = nullptr, *actg = nullptr, *lpg = nullptr, *advg = nullptr, *retg = nullptr, *oldvg = nullptr;
-  float *h1p = nullptr, *h2p = nullptr, *h1v = nullptr, *h2v = nullptr, *mu = nullptr, *vout = nullptr;
-  float *dmu = nullptr, *dv = nullptr, *dz2p = nullptr, *dz1p = nullptr, *dz2v = nullptr, *dz1v = nullptr;
+  float *hp[kMaxHidden] = {nullptr}, *hv[kMaxHidden] = {nullptr}, *mu = nullptr, *vout = nullptr;     // activations per hidden layer
+  float *dmu = nullptr, *dv = nullptr, *dzp[kMaxHidden] = {nullptr}, *dzv[kMaxHidden] = {nullptr};     // pre-activation gradients
   float *pred_obs = nullptr, *pred_act = nullptr;
   // rollout streamer (host-env path): pinned staging + a side stream for the H2D/D2H copies
   hipStream_t cstream = nullptr;
@@ -359,8 +382,8 @@ void repack(mobrob_ppo_engine* e) {
   };
   pad(Pp(e, T_PW1), e->pW1p, e->H1, e->D, e->H1, e->Dp);
   pad(Pp(e, T_VW1), e->vW1p, e->G1, e->D, e->G1, e->Dp);
-  pad(Pp(e, T_AW), e->aWp, e->A, e->H2, e->Ap, e->H2);
-  pad(Pp(e, T_VW), e->vWp, 1, e->G2, 8, e->G2);
+  pad(Pp(e, T_AW), e->aWp, e->A, e->HL, e->Ap, e->HL);
+  pad(Pp(e, T_VW), e->vWp, 1, e->GL, 8, e->GL);
   fused_repack(e->fused, e->params, e->offs, e->stream);
   pack_x3_all(e);
 }
@@ -368,15 +391,18 @@ void repack(mobrob_ppo_engine* e) {
 // forward of both networks on `rows` device rows of padded observations (ld = Dp); mu ld = Ap, v ld = 1
 void forward_generic(mobrob_ppo_engine* e, const float* X, int rows, bool want_pi, float* mu_out, bool want_v,
                      float* v_out) {
+  // layer 0 reads the zero-padded copy of its weights (observation rows are padded to Dp columns); one to three hidden layers
   if (want_pi) {
-    linear_fwd(e, X, e->Dp, e->pW1p, e->Dp, Pp(e, T_PB1), e->h1p, e->H1, rows, e->H1, e->Dp, true);
-    linear_fwd(e, e->h1p, e->H1, Pp(e, T_PW2), e->H1, Pp(e, T_PB2), e->h2p, e->H2, rows, e->H2, e->H1, true);
-    linear_fwd(e, e->h2p, e->H2, e->aWp, e->H2, Pp(e, T_AB), mu_out, e->Ap, rows, e->A, e->H2, false);
+    linear_fwd(e, X, e->Dp, e->pW1p, e->Dp, Pp(e, e->tPB[0]), e->hp[0], e->Hp[0], rows, e->Hp[0], e->Dp, true);
+    for (int l = 1; l < e->Lp; ++l)
+      linear_fwd(e, e->hp[l - 1], e->Hp[l - 1], Pp(e, e->tPW[l]), e->Hp[l - 1], Pp(e, e->tPB[l]), e->hp[l], e->Hp[l], rows, e->Hp[l], e->Hp[l - 1], true);
+    linear_fwd(e, e->hp[e->Lp - 1], e->HL, e->aWp, e->HL, Pp(e, T_AB), mu_out, e->Ap, rows, e->A, e->HL, false);
   }
   if (want_v) {
-    linear_fwd(e, X, e->Dp, e->vW1p, e->Dp, Pp(e, T_VB1), e->h1v, e->G1, rows, e->G1, e->Dp, true);
-    linear_fwd(e, e->h1v, e->G1, Pp(e, T_VW2), e->G1, Pp(e, T_VB2), e->h2v, e->G2, rows, e->G2, e->G1, true);
-    linear_fwd(e, e->h2v, e->G2, e->vWp, e->G2, Pp(e, T_VB), v_out, 1, rows, 1, e->G2, false);
+    linear_fwd(e, X, e->Dp, e->vW1p, e->Dp, Pp(e, e->tVB[0]), e->hv[0], e->Hv[0], rows, e->Hv[0], e->Dp, true);
+    for (int l = 1; l < e->Lv; ++l)
+      linear_fwd(e, e->hv[l - 1], e->Hv[l - 1], Pp(e, e->tVW[l]), e->Hv[l - 1], Pp(e, e->tVB[l]), e->hv[l], e->Hv[l], rows, e->Hv[l], e->Hv[l - 1], true);
+    linear_fwd(e, e->hv[e->Lv - 1], e->GL, e->vWp, e->GL, Pp(e, T_VB), v_out, 1, rows, 1, e->GL, false);
   }
 }
 
@@ -385,12 +411,27 @@ void forward(mobrob_ppo_engine* e, const float* X, int rows, bool want_pi, float
   forward_generic(e, X, rows, want_pi, mu_out, want_v, v_out);
 }
 
+// the value network as the per-row evaluators take it (canonical parameters; layers beyond the network's depth are null)
+ValueNetArgs value_net_args(mobrob_ppo_engine* e) {
+  ValueNetArgs vn{};
+  for (int l = 0; l < e->Lv; ++l) { vn.W[l] = Pp(e, e->tVW[l]); vn.b[l] = Pp(e, e->tVB[l]); vn.G[l] = e->Hv[l]; }
+  vn.Wv = Pp(e, T_VW); vn.bv = Pp(e, T_VB);
+  vn.relu = e->cfg.activation == MOBROB_ACT_RELU;
+  return vn;
+}
+int value_net_width_sum(const mobrob_ppo_engine* e) { return e->Hv[0] + e->Hv[1] + e->Hv[2]; }
+BootArgs boot_args(mobrob_ppo_engine* e) {
+  const ValueNetArgs vn = value_net_args(e);
+  BootArgs bt{vn.W[0], vn.b[0], vn.W[1], vn.b[1], vn.Wv, vn.bv, vn.G[0], vn.G[1], (float)e->cfg.gamma, e->term_val, vn.relu};
+  bt.W3 = vn.W[2]; bt.b3 = vn.b[2]; bt.G3 = vn.G[2];
+  return bt;
+}
+
 void value_flagged(mobrob_ppo_engine* e, const float* obs_rows, const uint8_t* flags, float* out,
                    float* bootstrap_rewards = nullptr) {
-  const size_t sm = (size_t)(e->D + e->G1 + e->G2 + 16) * sizeof(float);
-  hipLaunchKernelGGL(k_value_flagged, dim3(e->N), dim3(256), sm, e->stream, obs_rows, e->Dp, flags, Pp(e, T_VW1),
-                     Pp(e, T_VB1), Pp(e, T_VW2), Pp(e, T_VB2), Pp(e, T_VW), Pp(e, T_VB), e->D, e->G1, e->G2, out,
-                     bootstrap_rewards, (float)e->cfg.gamma, (int)(e->cfg.activation == MOBROB_ACT_RELU));
+  const size_t sm = (size_t)(e->D + value_net_width_sum(e) + 16) * sizeof(float);
+  hipLaunchKernelGGL(k_value_flagged, dim3(e->N), dim3(256), sm, e->stream, obs_rows, e->Dp, flags, value_net_args(e), e->D, out,
+                     bootstrap_rewards, (float)e->cfg.gamma);
 }
 
 // Philox key of the action-noise stream: data-parallel ranks must not share it
@@ -442,7 +483,8 @@ int upload_obs(mobrob_ppo_engine* e, const float* host, float* dev_rows, int row
 int fused_init(mobrob_ppo_engine* e) {
   FusedState& f = e->fused;
   // (every fused kernel's epilogue is tanh: ReLU networks run the generic GEMM chain)
-  f.enabled = e->cfg.fast_kernels && e->cfg.activation == MOBROB_ACT_TANH && fused_shape_ok(e->D, e->A, e->H1, e->H2, e->G1, e->G2);
+  f.enabled = e->cfg.fast_kernels && e->cfg.activation == MOBROB_ACT_TANH && e->Lp == 2 && e->Lv == 2 &&
+              fused_shape_ok(e->D, e->A, e->H1, e->H2, e->G1, e->G2);   // (other depths: generic GEMM chain)
   if (!f.enabled) return MOBROB_OK;
   f.D = e->D; f.Dp = e->Dp; f.A = e->A; f.H = e->H1;
   if ((uint64_t)(e->T + 1) * e->N * e->Dp * 4ull >= (1ull << 32) || (uint64_t)e->T * e->N * e->A * 4ull >= (1ull << 32) ||
@@ -686,9 +728,17 @@ int upload_obs_on(mobrob_ppo_engine* e, hipStream_t st, const float* host, float
 int check_cfg(const mobrob_ppo_config_t* c) {
   if (c->abi_version != MOBROB_PPO_ABI_VERSION) return fail(MOBROB_ERR_INVALID, "abi_version %d != %d", c->abi_version, MOBROB_PPO_ABI_VERSION);
   if (c->obs_dim < 1 || c->act_dim < 1) return fail(MOBROB_ERR_INVALID, "obs_dim/act_dim must be >= 1");
-  for (int i = 0; i < 2; ++i)
-    if (c->pi_hidden[i] < 8 || c->pi_hidden[i] % 8 || c->vf_hidden[i] < 8 || c->vf_hidden[i] % 8)
-      return fail(MOBROB_ERR_INVALID, "hidden widths must be positive multiples of 8 (two layers per network)");
+  {  // one to three hidden layers per network: [h1, h2, h3] with trailing zeros, every width a positive multiple of 8
+    const int pw[3] = {c->pi_hidden[0], c->pi_hidden[1], c->pi_hidden3}, vw[3] = {c->vf_hidden[0], c->vf_hidden[1], c->vf_hidden3};
+    for (const int* w : {pw, vw}) {
+      bool ended = false;
+      for (int i = 0; i < 3; ++i) {
+        if (w[i] == 0 && i > 0) { ended = true; continue; }
+        if (ended || w[i] < 8 || w[i] % 8)
+          return fail(MOBROB_ERR_INVALID, "hidden widths must be positive multiples of 8, one to three layers per network (a width of 0 ends the list)");
+      }
+    }
+  }
   if (c->n_envs < 1 || c->n_steps < 1 || c->batch_size < 1 || c->n_epochs < 1)
     return fail(MOBROB_ERR_INVALID, "n_envs, n_steps, batch_size, n_epochs must be >= 1");
   if (c->world_size < 1 || c->rank < 0 || c->rank >= c->world_size) return fail(MOBROB_ERR_INVALID, "bad rank/world_size");
@@ -763,21 +813,36 @@ namespace {
 int engine_dims(mobrob_ppo_engine* e, const mobrob_ppo_config_t* cfg) {
   e->cfg = *cfg;
   e->D = cfg->obs_dim; e->Dp = padded_obs_dim(cfg->obs_dim); e->A = cfg->act_dim; e->Ap = rup(cfg->act_dim, 8);
-  e->H1 = cfg->pi_hidden[0]; e->H2 = cfg->pi_hidden[1]; e->G1 = cfg->vf_hidden[0]; e->G2 = cfg->vf_hidden[1];
+  // net_arch: pi_hidden[0 .. 1] + pi_hidden3 (likewise vf); a width of 0 ends the list (check_cfg has validated the pattern)
+  const int pw[kMaxHidden] = {cfg->pi_hidden[0], cfg->pi_hidden[1], cfg->pi_hidden3};
+  const int vw[kMaxHidden] = {cfg->vf_hidden[0], cfg->vf_hidden[1], cfg->vf_hidden3};
+  e->Lp = e->Lv = 0;
+  for (int l = 0; l < kMaxHidden; ++l) { e->Hp[l] = e->Hv[l] = 0; }
+  for (int l = 0; l < kMaxHidden && pw[l] > 0; ++l) e->Hp[e->Lp++] = pw[l];
+  for (int l = 0; l < kMaxHidden && vw[l] > 0; ++l) e->Hv[e->Lv++] = vw[l];
+  e->HL = e->Hp[e->Lp - 1]; e->GL = e->Hv[e->Lv - 1];
+  e->H1 = e->Hp[0]; e->H2 = e->Hp[1]; e->G1 = e->Hv[0]; e->G2 = e->Hv[1];
   e->N = cfg->n_envs; e->T = cfg->n_steps;
   e->Bl = cfg->batch_size / cfg->world_size;
   const int total = e->N * e->T;
   e->nmb = cdiv(total, e->Bl);
   e->rows_max = std::max(e->N, std::min(e->Bl, total));
-  const int sizes[T_COUNT] = {e->A, e->H1 * e->D, e->H1, e->H2 * e->H1, e->H2, e->G1 * e->D, e->G1, e->G2 * e->G1,
-                              e->G2, e->A * e->H2, e->A, e->G2, 1};
+  int sizes[kMaxTensors] = {0};
+  int nt = 0;
+  sizes[nt++] = e->A;                                             // log_std
+  for (int l = 0; l < e->Lp; ++l) { e->tPW[l] = nt; sizes[nt++] = e->Hp[l] * (l ? e->Hp[l - 1] : e->D); e->tPB[l] = nt; sizes[nt++] = e->Hp[l]; }
+  for (int l = 0; l < e->Lv; ++l) { e->tVW[l] = nt; sizes[nt++] = e->Hv[l] * (l ? e->Hv[l - 1] : e->D); e->tVB[l] = nt; sizes[nt++] = e->Hv[l]; }
+  e->tAW = nt; sizes[nt++] = e->A * e->HL; e->tAB = nt; sizes[nt++] = e->A;
+  e->tVWh = nt; sizes[nt++] = e->GL; e->tVBh = nt; sizes[nt++] = 1;
+  e->ntens = nt;
   e->offs[0] = 0;
-  for (int i = 0; i < T_COUNT; ++i) e->offs[i + 1] = e->offs[i] + sizes[i];
-  e->P = e->offs[T_COUNT];
+  for (int i = 0; i < nt; ++i) e->offs[i + 1] = e->offs[i] + sizes[i];
+  for (int i = nt; i < kMaxTensors; ++i) e->offs[i + 1] = e->offs[nt];
+  e->P = e->offs[nt];
   e->stats_cap = std::max(64, 4 * e->nmb * cfg->n_epochs);
   // chunk table for the gradient-norm reduction: <= 4096 elements per block, chunks sorted by tensor
   e->chunk_table.clear();
-  for (int tt = 0; tt < T_COUNT; ++tt)
+  for (int tt = 0; tt < e->ntens; ++tt)
     for (int s0 = e->offs[tt]; s0 < e->offs[tt + 1]; s0 += 4096)
       e->chunk_table.push_back(NormChunk{tt, s0, std::min(s0 + 4096, e->offs[tt + 1]), 0});
   e->nchunks = (int)e->chunk_table.size();
@@ -790,7 +855,7 @@ int engine_alloc(mobrob_ppo_engine* e) {
   const size_t P = e->P, N = e->N, T = e->T, Dp = e->Dp, A = e->A, Bl = std::min(e->Bl, e->N * e->T), R = e->rows_max;
   CHK(dalloc(e, &e->params, P)); CHK(dalloc(e, &e->grads, P + 8)); CHK(dalloc(e, &e->m, P)); CHK(dalloc(e, &e->v, P));
   CHK(dalloc(e, &e->pW1p, (size_t)e->H1 * Dp)); CHK(dalloc(e, &e->vW1p, (size_t)e->G1 * Dp));
-  CHK(dalloc(e, &e->aWp, (size_t)e->Ap * e->H2)); CHK(dalloc(e, &e->vWp, (size_t)8 * e->G2));
+  CHK(dalloc(e, &e->aWp, (size_t)e->Ap * e->HL)); CHK(dalloc(e, &e->vWp, (size_t)8 * e->GL));
   CHK(dalloc(e, &e->obs, (T + 1) * N * Dp)); CHK(dalloc(e, &e->actions, T * N * A));
   CHK(dalloc(e, &e->rewards, T * N)); CHK(dalloc(e, &e->es, T * N)); CHK(dalloc(e, &e->values, (T + 1) * N));
   e->last_values = e->values + T * N;  // V(last_obs) sits behind the stored values: one batched pass covers both
@@ -803,11 +868,12 @@ int engine_alloc(mobrob_ppo_engine* e) {
   CHK(dalloc(e, &e->stats, (size_t)e->stats_cap * 8));
   CHK(dalloc(e, &e->Xg, Bl * Dp)); CHK(dalloc(e, &e->actg, Bl * A)); CHK(dalloc(e, &e->lpg, Bl));
   CHK(dalloc(e, &e->advg, Bl)); CHK(dalloc(e, &e->retg, Bl)); CHK(dalloc(e, &e->oldvg, Bl));
-  CHK(dalloc(e, &e->h1p, R * e->H1)); CHK(dalloc(e, &e->h2p, R * e->H2)); CHK(dalloc(e, &e->h1v, R * e->G1));
-  CHK(dalloc(e, &e->h2v, R * e->G2)); CHK(dalloc(e, &e->mu, R * e->Ap)); CHK(dalloc(e, &e->vout, R));
+  for (int l = 0; l < e->Lp; ++l) CHK(dalloc(e, &e->hp[l], R * e->Hp[l]));
+  for (int l = 0; l < e->Lv; ++l) CHK(dalloc(e, &e->hv[l], R * e->Hv[l]));
+  CHK(dalloc(e, &e->mu, R * e->Ap)); CHK(dalloc(e, &e->vout, R));
   CHK(dalloc(e, &e->dmu, Bl * e->Ap)); CHK(dalloc(e, &e->dv, Bl * 8));
-  CHK(dalloc(e, &e->dz2p, Bl * e->H2)); CHK(dalloc(e, &e->dz1p, Bl * e->H1));
-  CHK(dalloc(e, &e->dz2v, Bl * e->G2)); CHK(dalloc(e, &e->dz1v, Bl * e->G1));
+  for (int l = 0; l < e->Lp; ++l) CHK(dalloc(e, &e->dzp[l], Bl * e->Hp[l]));
+  for (int l = 0; l < e->Lv; ++l) CHK(dalloc(e, &e->dzv[l], Bl * e->Hv[l]));
   CHK(dalloc(e, &e->pred_obs, R * Dp)); CHK(dalloc(e, &e->pred_act, R * A));
   CHK(dalloc(e, &e->gstate[0], N * kGoalStateFloats)); CHK(dalloc(e, &e->gstate[1], N * kGoalStateFloats));
   CHK(dalloc(e, &e->ep_stats, kEpStatsDoubles));
@@ -1178,16 +1244,15 @@ int mobrob_ppo_store_part(mobrob_ppo_engine_t* e, int32_t part, int32_t nparts, 
   StorePullArgs a{};
   a.rew_in = rewards + r0; a.dones = dones + r0;
   a.trunc = any ? truncated + r0 : nullptr; a.term_obs = any ? terminal_obs + (size_t)r0 * e->D : nullptr;
-  a.W1 = Pp(e, T_VW1); a.b1 = Pp(e, T_VB1); a.W2 = Pp(e, T_VW2); a.b2 = Pp(e, T_VB2); a.Wv = Pp(e, T_VW); a.bv = Pp(e, T_VB);
-  a.D = e->D; a.Dp = e->Dp; a.G1 = e->G1; a.G2 = e->G2; a.n = n; a.gamma = (float)e->cfg.gamma;
-  a.relu = e->cfg.activation == MOBROB_ACT_RELU;
+  a.vn = value_net_args(e);
+  a.D = e->D; a.Dp = e->Dp; a.n = n; a.gamma = (float)e->cfg.gamma;
   a.prev_dones = e->prev_dones + r0; a.rew_out = e->rewards + o; a.es_out = e->es + o; a.term_val = e->term_val + r0;
   if (next_obs) {  // slot t+1 exists for every t < T (slot T holds the last observations)
     a.next_obs = next_obs + (size_t)r0 * e->D;
     a.obs_slot = e->obs + ((size_t)(t + 1) * e->N + r0) * e->Dp;
     e->part_obs_t[part] = t + 1;
   }
-  const size_t sm = (size_t)(e->D + e->G1 + e->G2 + 32) * sizeof(float);
+  const size_t sm = (size_t)(e->D + value_net_width_sum(e) + 32) * sizeof(float);
   hipLaunchKernelGGL(k_store_pull_part, dim3(cdiv(n, kPartRows)), dim3(256), sm, e->stream, a);
   HIPC(hipGetLastError());
   e->part_store_t[part] = t + 1;
@@ -1436,9 +1501,8 @@ int enqueue_rollout(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& 
   const uint64_t env_seed = env_seed_of(e);
   // the previous rollout's last observation is this rollout's first
   HIPC(hipMemcpyAsync(e->obs, e->obs + (size_t)e->T * slot, slot * 4, hipMemcpyDeviceToDevice, e->stream));
-  BootArgs bt{Pp(e, T_VW1), Pp(e, T_VB1), Pp(e, T_VW2), Pp(e, T_VB2), Pp(e, T_VW), Pp(e, T_VB), e->G1, e->G2,
-              (float)e->cfg.gamma, e->term_val, (int)(e->cfg.activation == MOBROB_ACT_RELU)};
-  const size_t sm = env_step_lds_bytes(Dp, e->G1, e->G2);
+  const BootArgs bt = boot_args(e);
+  const size_t sm = env_step_lds_bytes(Dp, e->Hv[0], e->Hv[1], e->Hv[2]);
   for (int t = 0; t < e->T; ++t) {
     act_slot(e, t, nullptr, true);
     {
@@ -1763,18 +1827,21 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
   hipLaunchKernelGGL(k_loss, dim3(cdiv(B, 256)), dim3(256), 0, e->stream, L);
   hipLaunchKernelGGL(k_entropy_grad, dim3(1), dim3(64), 0, e->stream, Gp(e, T_LOGSTD), e->A, (float)e->cfg.ent_coef,
                      (float)B, inv_bg);
-  // policy network backward
-  linear_bwd_weight(e, e->dmu, e->Ap, e->h2p, e->H2, Gp(e, T_AW), e->H2, e->A, e->H2, B);
-  linear_bwd_input(e, e->dmu, e->Ap, e->aWp, e->H2, e->h2p, e->H2, e->dz2p, e->H2, Gp(e, T_PB2), B, e->H2, e->Ap);
-  linear_bwd_weight(e, e->dz2p, e->H2, e->h1p, e->H1, Gp(e, T_PW2), e->H1, e->H2, e->H1, B);
-  linear_bwd_input(e, e->dz2p, e->H2, Pp(e, T_PW2), e->H1, e->h1p, e->H1, e->dz1p, e->H1, Gp(e, T_PB1), B, e->H1, e->H2);
-  linear_bwd_weight(e, e->dz1p, e->H1, e->Xg, e->Dp, Gp(e, T_PW1), e->D, e->H1, e->D, B);
-  // value network backward
-  linear_bwd_weight(e, e->dv, 8, e->h2v, e->G2, Gp(e, T_VW), e->G2, 1, e->G2, B);
-  linear_bwd_input(e, e->dv, 8, e->vWp, e->G2, e->h2v, e->G2, e->dz2v, e->G2, Gp(e, T_VB2), B, e->G2, 8);
-  linear_bwd_weight(e, e->dz2v, e->G2, e->h1v, e->G1, Gp(e, T_VW2), e->G1, e->G2, e->G1, B);
-  linear_bwd_input(e, e->dz2v, e->G2, Pp(e, T_VW2), e->G1, e->h1v, e->G1, e->dz1v, e->G1, Gp(e, T_VB1), B, e->G1, e->G2);
-  linear_bwd_weight(e, e->dz1v, e->G1, e->Xg, e->Dp, Gp(e, T_VW1), e->D, e->G1, e->D, B);
+  // backward of both networks, last hidden layer first: dW of the layer above, then dz of this layer (dtanh / dReLU + bias sums)
+  auto backward = [&](int L, const int* Hw, float* const* h, float* const* dz, const float* dhead, int ldd, const float* headWp,
+                      int head_rows, int head_pad, int t_headW, const int* tW, const int* tB, const float* W1pad_unused) {
+    (void)W1pad_unused;
+    const int HLw = Hw[L - 1];
+    linear_bwd_weight(e, dhead, ldd, h[L - 1], HLw, Gp(e, t_headW), HLw, head_rows, HLw, B);
+    linear_bwd_input(e, dhead, ldd, headWp, HLw, h[L - 1], HLw, dz[L - 1], HLw, Gp(e, tB[L - 1]), B, HLw, head_pad);
+    for (int l = L - 1; l >= 1; --l) {
+      linear_bwd_weight(e, dz[l], Hw[l], h[l - 1], Hw[l - 1], Gp(e, tW[l]), Hw[l - 1], Hw[l], Hw[l - 1], B);
+      linear_bwd_input(e, dz[l], Hw[l], Pp(e, tW[l]), Hw[l - 1], h[l - 1], Hw[l - 1], dz[l - 1], Hw[l - 1], Gp(e, tB[l - 1]), B, Hw[l - 1], Hw[l]);
+    }
+    linear_bwd_weight(e, dz[0], Hw[0], e->Xg, e->Dp, Gp(e, tW[0]), e->D, Hw[0], e->D, B);
+  };
+  backward(e->Lp, e->Hp, e->hp, e->dzp, e->dmu, e->Ap, e->aWp, e->A, e->Ap, T_AW, e->tPW, e->tPB, nullptr);
+  backward(e->Lv, e->Hv, e->hv, e->dzv, e->dv, 8, e->vWp, 1, 8, T_VW, e->tVW, e->tVB, nullptr);
   HIPC(hipGetLastError());
   e->grad_pending = true;
   return MOBROB_OK;
@@ -1787,7 +1854,8 @@ void fill_adam_pack_args(mobrob_ppo_engine* e, AdamPackArgs& a) {
   a.chunks = e->chunks_dev; a.partial = e->chunk_partial; a.nchunks = e->nchunks;
   a.max_norm = (float)e->cfg.max_grad_norm; a.beta1 = (float)e->cfg.adam_beta1; a.beta2 = (float)e->cfg.adam_beta2;
   a.eps = (float)e->cfg.adam_eps;
-  for (int i = 0; i < 14; ++i) a.offs[i] = e->offs[i];
+  for (int i = 0; i <= kMaxTensors; ++i) a.offs[i] = e->offs[i];
+  a.ntens = e->ntens; a.two_by_two = e->Lp == 2 && e->Lv == 2; a.id_pw1 = T_PW1; a.id_vw1 = T_VW1; a.id_aw = T_AW; a.id_vw = T_VW; a.HL = e->HL; a.GL = e->GL;
   a.D = e->D; a.Dp = e->Dp; a.A = e->A; a.Ap = e->Ap; a.H1 = e->H1; a.H2 = e->H2; a.G1 = e->G1; a.G2 = e->G2;
   a.pW1p = e->pW1p; a.vW1p = e->vW1p; a.aWp = e->aWp; a.vWp = e->vWp;
   for (int n = 0; n < 2; ++n) {
@@ -1851,7 +1919,7 @@ int apply_adam(mobrob_ppo_engine* e, const ApplyCtx& c) {
     st.ent_coef = (float)e->cfg.ent_coef; st.vf_coef = (float)e->cfg.vf_coef;
     st.inv_bg = 1.0f / (float)((int64_t)e->cur_count * e->cfg.world_size); st.n_act = e->A;
     a.partial = e->norm_rec_sum; a.fold_idx = e->fold_idx_dev; a.st = st;
-    for (int i = 0; i < 14; ++i) a.fold_start[i] = e->fold_start[i];
+    for (int i = 0; i <= kMaxTensors; ++i) a.fold_start[i] = e->fold_start[i];
   }
   a.stats_row = c.stats_row;
   a.loss_sums_zero = e->fused.enabled ? e->grads + e->P : nullptr;

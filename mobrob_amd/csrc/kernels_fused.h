@@ -2083,9 +2083,14 @@ struct AdamPackArgs {
   float* p; const float* g; float* m; float* v; int P;
   float* g_out;  // the same vector, writable (persistent small-batch kernel: it produces the gradient itself)
   const NormChunk* chunks; const double* partial; int nchunks;
-  const int* fold_idx; int fold_start[14];  // non-null: `partial` is a record table; tensor t folds partial[fold_idx[k]], k in [fold_start[t], fold_start[t+1])
+  const int* fold_idx; int fold_start[18];  // non-null: `partial` is a record table; tensor t folds partial[fold_idx[k]], k in [fold_start[t], fold_start[t+1])
   float max_norm, step_size, bc2_sqrt, beta1, beta2, eps;
-  int offs[14];
+  int offs[18];    // canonical offsets of the engine's ntens tensors (9 .. 17: one to three hidden layers per network), padded with P
+  int ntens;       // 9 .. 17
+  int two_by_two;  // two hidden layers in BOTH networks: tensor numbering 0 .. 12, the one the fused cases below are written for
+                   // (1 + 3 layers also make thirteen tensors)
+  int id_pw1, id_vw1, id_aw, id_vw;   // tensors with a zero-padded compute copy (first-layer weights, heads), whatever the depth
+  int HL, GL;      // width of the last hidden layer of the policy / value network (row length of the heads)
   int D, Dp, A, Ap, H1, H2, G1, G2;
   // generic-path padded copies (always maintained: cheap, and k_value_flagged/predict fallbacks use canonical)
   float* pW1p; float* vW1p; float* aWp; float* vWp;
@@ -2179,8 +2184,17 @@ __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, fl
 #endif
   int t = 0;
 #pragma unroll
-  for (int k = 1; k < 13; ++k) t += (i >= a.offs[k]) ? 1 : 0;
+  for (int k = 1; k < 17; ++k) t += (i >= a.offs[k]) ? 1 : 0;   // (offsets beyond the engine's tensors equal P)
   const int e = i - a.offs[t];
+  if (!a.two_by_two) {  // other depths than two hidden layers: the generic GEMM chain's zero-padded copies only (no fused packs exist)
+    if (t == a.id_pw1 || t == a.id_vw1) {
+      const int n = e / a.D, k = e - n * a.D;
+      (t == a.id_vw1 ? a.vW1p : a.pW1p)[n * a.Dp + k] = pn;
+    } else if (t == a.id_aw || t == a.id_vw) {
+      (t == a.id_vw ? a.vWp : a.aWp)[e] = pn;
+    }
+    return;
+  }
   switch (t) {
     case 1: case 5: {  // W1 [H][D]
       const int net = t == 5, n = e / a.D, k = e - n * a.D;
@@ -2220,7 +2234,7 @@ __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, fl
 __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
   __shared__ double part[1024];
   __shared__ int tens[256];
-  __shared__ float nts[16];
+  __shared__ float nts[20];
   __shared__ float coef_s, total_s;
   // this thread's four operands are requested first: their memory latency runs under the norm fold below
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2228,7 +2242,7 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
   if (i < a.P) { g_in = a.g[i]; m_in = a.m[i]; v_in = a.v[i]; p_in = a.p[i]; }
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.st.stats_row != nullptr) stats_row_from_sums(a.st);  // pre-update log_std
   if (a.fold_idx != nullptr) {  // norm records of the reduction kernel, listed per tensor by the host
-    const int nrec = a.fold_start[13];
+    const int nrec = a.fold_start[13];   // (records exist with the fused kernels only: two hidden layers, 13 tensors)
     if (nrec <= 128) {  // 64-wide nets (~90 records): one lane per tensor, thirteen short serial folds side by side
       for (int c = threadIdx.x; c < nrec; c += blockDim.x) part[c] = a.partial[a.fold_idx[c]];
       __syncthreads();
@@ -2268,7 +2282,7 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
     // total norm = norm of per-tensor norms (torch.norm(torch.stack(norms))).  One thread per tensor folds that
     // tensor's chunk partials in chunk order and takes the float64 square root (a software routine: thirteen of them
     // one after the other were half of this kernel), thread 0 then adds the thirteen squares in tensor order.
-    if (threadIdx.x < 13) {
+    if ((int)threadIdx.x < a.ntens) {
       double ts = 0.0;
       for (int c = 0; c < a.nchunks; ++c)
         if (tens[c] == (int)threadIdx.x) ts += part[c];
@@ -2278,7 +2292,7 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
   __syncthreads();
   if (threadIdx.x == 0) {
     float tot_sq = 0.f;
-    for (int t = 0; t < 13; ++t) tot_sq = __fmaf_rn(nts[t], nts[t], tot_sq);  // explicit: one rounding per tensor
+    for (int t = 0; t < a.ntens; ++t) tot_sq = __fmaf_rn(nts[t], nts[t], tot_sq);  // explicit: one rounding per tensor
     const float total = sqrtf(tot_sq);
     total_s = total;
     coef_s = fminf(a.max_norm / (total + 1e-6f), 1.0f);

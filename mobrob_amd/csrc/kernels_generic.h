@@ -231,46 +231,66 @@ __global__ void k_u8_to_f32(const uint8_t* __restrict__ in, float* __restrict__ 
 // Value of flagged rows only (time-limit bootstrap is rare: one block per env, exits unless flagged).
 // V(x) = Wv . tanh(W2 tanh(W1 x + b1) + b2) + bv with the canonical (unpadded) parameter vector.
 // ------------------------------------------------------------------------------------------------
-// x[D] is already in LDS; h1[G1], h2[G2], red[16] are LDS scratch.  Every thread of the block returns V(x).
+// x[D] is already in LDS; h1[G1], h2[G2], h3[G3], red[16] are LDS scratch.  Every thread of the block returns V(x).
+// One to three hidden layers (net_arch depths 1 .. 3): a layer exists iff its weight pointer is non-null (W2 == nullptr: one hidden
+// layer; W3 != nullptr: three).  The two-layer callers of the fused paths pass neither W3 nor h3.
 __device__ __forceinline__ float value_row_lds(const float* x, float* h1, float* h2, float* red,
                                                const float* __restrict__ W1, const float* __restrict__ b1,
                                                const float* __restrict__ W2, const float* __restrict__ b2,
                                                const float* __restrict__ Wv, const float* __restrict__ bv, int D, int G1,
-                                               int G2, int relu = 0) {
+                                               int G2, int relu = 0, const float* __restrict__ W3 = nullptr,
+                                               const float* __restrict__ b3 = nullptr, int G3 = 0, float* h3 = nullptr) {
   for (int j = threadIdx.x; j < G1; j += blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < D; ++k) s = fmaf(x[k], W1[(size_t)j * D + k], s);
     h1[j] = relu ? fmaxf(s + b1[j], 0.f) : tanhf(s + b1[j]);
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < G2; j += blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < G1; ++k) s = fmaf(h1[k], W2[(size_t)j * G1 + k], s);
-    h2[j] = relu ? fmaxf(s + b2[j], 0.f) : tanhf(s + b2[j]);
+  const float* last = h1;
+  int GL = G1;
+  if (W2 != nullptr) {
+    for (int j = threadIdx.x; j < G2; j += blockDim.x) {
+      float s = 0.f;
+      for (int k = 0; k < G1; ++k) s = fmaf(h1[k], W2[(size_t)j * G1 + k], s);
+      h2[j] = relu ? fmaxf(s + b2[j], 0.f) : tanhf(s + b2[j]);
+    }
+    __syncthreads();
+    last = h2; GL = G2;
+    if (W3 != nullptr) {
+      for (int j = threadIdx.x; j < G3; j += blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < G2; ++k) s = fmaf(h2[k], W3[(size_t)j * G2 + k], s);
+        h3[j] = relu ? fmaxf(s + b3[j], 0.f) : tanhf(s + b3[j]);
+      }
+      __syncthreads();
+      last = h3; GL = G3;
+    }
   }
-  __syncthreads();
   float p = 0.f;
-  for (int k = threadIdx.x; k < G2; k += blockDim.x) p += h2[k] * Wv[k];
+  for (int k = threadIdx.x; k < GL; k += blockDim.x) p += last[k] * Wv[k];
   return block_sum(p, red) + bv[0];
 }
 
+struct ValueNetArgs {  // value network, canonical (unpadded) parameters; layer l exists iff W[l] != nullptr (W[0] always)
+  const float* W[3]; const float* b[3]; const float* Wv; const float* bv;
+  int G[3];
+  int relu;
+};
 __global__ __launch_bounds__(256) void k_value_flagged(const float* __restrict__ obs, int ldo,
-                                                       const uint8_t* __restrict__ flags,
-                                                       const float* __restrict__ W1, const float* __restrict__ b1,
-                                                       const float* __restrict__ W2, const float* __restrict__ b2,
-                                                       const float* __restrict__ Wv, const float* __restrict__ bv,
-                                                       int D, int G1, int G2, float* __restrict__ out,
-                                                       float* __restrict__ rew_inout, float gamma, int relu) {
+                                                       const uint8_t* __restrict__ flags, ValueNetArgs vn, int D,
+                                                       float* __restrict__ out, float* __restrict__ rew_inout, float gamma) {
   const int row = blockIdx.x;
   if (!flags[row]) return;
-  extern __shared__ float sm[];  // x[D] | h1[G1] | h2[G2] | red[16]
+  extern __shared__ float sm[];  // x[D] | h1[G1] | h2[G2] | h3[G3] | red[16]
   float* x = sm;
   float* h1 = x + D;
-  float* h2 = h1 + G1;
-  float* red = h2 + G2;
+  float* h2 = h1 + vn.G[0];
+  float* h3 = h2 + vn.G[1];
+  float* red = h3 + vn.G[2];
   for (int i = threadIdx.x; i < D; i += blockDim.x) x[i] = obs[(size_t)row * ldo + i];
   __syncthreads();
-  const float v = value_row_lds(x, h1, h2, red, W1, b1, W2, b2, Wv, bv, D, G1, G2, relu);
+  const float v = value_row_lds(x, h1, h2, red, vn.W[0], vn.b[0], vn.W[1], vn.b[1], vn.Wv, vn.bv, D, vn.G[0], vn.G[1], vn.relu,
+                                vn.W[2], vn.b[2], vn.G[2], h3);
   if (threadIdx.x == 0) {
     out[row] = v;
     if (rew_inout != nullptr)  // rewards[idx] += gamma * V(terminal_obs)  [oracle bootstrap_reward]
@@ -290,19 +310,19 @@ __global__ __launch_bounds__(256) void k_value_flagged(const float* __restrict__
 constexpr int kPartRows = 16;
 struct StorePullArgs {
   const float* rew_in; const uint8_t* dones; const uint8_t* trunc; const float* term_obs;  // caller's pinned rows (range base)
-  const float *W1, *b1, *W2, *b2, *Wv, *bv;                                                // value network (canonical)
-  int D, Dp, G1, G2, n;
+  ValueNetArgs vn;                                                                         // value network (canonical)
+  int D, Dp, n;
   float gamma;
   float *prev_dones, *rew_out, *es_out, *term_val;
   const float* next_obs; float* obs_slot;  // null: no pull
-  int relu;                                // hidden activation of the value network
 };
 __global__ __launch_bounds__(256) void k_store_pull_part(StorePullArgs a) {
-  extern __shared__ float sm[];  // x[D] | h1[G1] | h2[G2] | red[16] | tv[16]
+  extern __shared__ float sm[];  // x[D] | h1[G1] | h2[G2] | h3[G3] | red[16] | tv[16]
   float* x = sm;
   float* h1 = x + a.D;
-  float* h2 = h1 + a.G1;
-  float* red = h2 + a.G2;
+  float* h2 = h1 + a.vn.G[0];
+  float* h3 = h2 + a.vn.G[1];
+  float* red = h3 + a.vn.G[2];
   float* tv = red + 16;
   const int i0 = blockIdx.x * kPartRows, tid = threadIdx.x;
   if (a.trunc != nullptr) {
@@ -311,7 +331,8 @@ __global__ __launch_bounds__(256) void k_store_pull_part(StorePullArgs a) {
       if (i >= a.n || !a.trunc[i]) continue;  // block-uniform
       for (int k = tid; k < a.D; k += blockDim.x) x[k] = a.term_obs[(size_t)i * a.D + k];
       __syncthreads();
-      const float v = value_row_lds(x, h1, h2, red, a.W1, a.b1, a.W2, a.b2, a.Wv, a.bv, a.D, a.G1, a.G2, a.relu);
+      const float v = value_row_lds(x, h1, h2, red, a.vn.W[0], a.vn.b[0], a.vn.W[1], a.vn.b[1], a.vn.Wv, a.vn.bv, a.D, a.vn.G[0],
+                                    a.vn.G[1], a.vn.relu, a.vn.W[2], a.vn.b[2], a.vn.G[2], h3);
       if (tid == 0) tv[r] = v;
       __syncthreads();
     }
@@ -759,14 +780,16 @@ __global__ void k_add_counters(uint32_t* ctr, uint32_t d0, uint32_t d1) {
   if (threadIdx.x == 0 && blockIdx.x == 0) { ctr[0] += d0; ctr[1] += d1; }
 }
 struct BootArgs {  // value network (canonical parameters) for the in-kernel time-limit bootstrap
-  const float *W1, *b1, *W2, *b2, *Wv, *bv;
+  const float *W1, *b1, *W2, *b2, *Wv, *bv;   // W2 == nullptr: one hidden layer (G2 = 0)
   int G1, G2;
   float gamma;
   float* term_val;  // [N] V(terminal_obs) of truncated rows (diagnostics / tests)
   int relu;         // hidden activation of the value network (0 tanh, 1 ReLU)
+  const float *W3 = nullptr, *b3 = nullptr;   // third hidden layer (generic paths only; the fused kernels are two-layer)
+  int G3 = 0;
 };
 constexpr int kBootMaxEnvs = 72;  // envs whose chunk-0 thread can live in one 256-thread block (Dp >= 16: <= 65)
-inline size_t env_step_lds_bytes(int Dp, int G1, int G2) { return (size_t)(Dp + G1 + G2 + 16 + 4 + 2 * kBootMaxEnvs) * 4; }
+inline size_t env_step_lds_bytes(int Dp, int G1, int G2, int G3 = 0) { return (size_t)(Dp + G1 + G2 + G3 + 16 + 4 + 2 * kBootMaxEnvs) * 4; }
 
 // Time-limit truncation is rare (one row in `time_limit`), so the bootstrap  r += gamma * V(terminal_obs)  [oracle
 // bootstrap_reward] runs in the same launch: the block that owns chunk 0 of a truncated env re-draws its terminal
@@ -778,11 +801,12 @@ __global__ __launch_bounds__(256) void k_env_step_store(uint64_t seed, uint32_t 
                                  const float* __restrict__ prev_dones, float* __restrict__ next_dones,
                                  uint8_t* __restrict__ trunc, float* __restrict__ rew_out, float* __restrict__ es_out,
                                  BootArgs bt) {
-  extern __shared__ float sm[];  // x[Dp] | h1[G1] | h2[G2] | red[16] | cnt[4] | env[kBootMaxEnvs] | rew[kBootMaxEnvs]
+  extern __shared__ float sm[];  // x[Dp] | h1[G1] | h2[G2] | h3[G3] | red[16] | cnt[4] | env[kBootMaxEnvs] | rew[kBootMaxEnvs]
   float* x = sm;
   float* h1 = x + Dp;
   float* h2 = h1 + bt.G1;
-  float* red = h2 + bt.G2;
+  float* h3 = h2 + bt.G2;
+  float* red = h3 + bt.G3;
   int* cnt = reinterpret_cast<int*>(red + 16);
   int* lenv = cnt + 4;
   float* lrew = reinterpret_cast<float*>(lenv + kBootMaxEnvs);
@@ -840,7 +864,7 @@ __global__ __launch_bounds__(256) void k_env_step_store(uint64_t seed, uint32_t 
       for (int j = 0; j < 4; ++j) x[4 * c + j] = (4 * c + j < D) ? z[j] : 0.f;
     }
     __syncthreads();
-    const float v = value_row_lds(x, h1, h2, red, bt.W1, bt.b1, bt.W2, bt.b2, bt.Wv, bt.bv, D, bt.G1, bt.G2, bt.relu);
+    const float v = value_row_lds(x, h1, h2, red, bt.W1, bt.b1, bt.W2, bt.b2, bt.Wv, bt.bv, D, bt.G1, bt.G2, bt.relu, bt.W3, bt.b3, bt.G3, h3);
     if (threadIdx.x == 0) {
       bt.term_val[n] = v;
       rew_out[n] = (float)((double)lrew[q] + (double)__fmul_rn(bt.gamma, v));

@@ -29,20 +29,19 @@ def _f32c(a, shape=None):
 
 
 def param_shapes(obs_dim, act_dim, pi, vf):
-    """SB3 `policy.state_dict()` key order and shapes (include/mobrob_ppo.h 'Conventions')."""
+    """SB3 `policy.state_dict()` key order and shapes (include/mobrob_ppo.h 'Conventions'); one to three hidden layers per
+    network (`nn.Sequential` indices 0, 2, 4: every Linear is followed by its activation module)."""
     s = OrderedDict()
     s["log_std"] = (act_dim,)
-    s["mlp_extractor.policy_net.0.weight"] = (pi[0], obs_dim)
-    s["mlp_extractor.policy_net.0.bias"] = (pi[0],)
-    s["mlp_extractor.policy_net.2.weight"] = (pi[1], pi[0])
-    s["mlp_extractor.policy_net.2.bias"] = (pi[1],)
-    s["mlp_extractor.value_net.0.weight"] = (vf[0], obs_dim)
-    s["mlp_extractor.value_net.0.bias"] = (vf[0],)
-    s["mlp_extractor.value_net.2.weight"] = (vf[1], vf[0])
-    s["mlp_extractor.value_net.2.bias"] = (vf[1],)
-    s["action_net.weight"] = (act_dim, pi[1])
+    for net, widths in (("policy_net", pi), ("value_net", vf)):
+        prev = obs_dim
+        for i, w in enumerate(widths):
+            s[f"mlp_extractor.{net}.{2 * i}.weight"] = (w, prev)
+            s[f"mlp_extractor.{net}.{2 * i}.bias"] = (w,)
+            prev = w
+    s["action_net.weight"] = (act_dim, pi[-1])
     s["action_net.bias"] = (act_dim,)
-    s["value_net.weight"] = (1, vf[1])
+    s["value_net.weight"] = (1, vf[-1])
     s["value_net.bias"] = (1,)
     return s
 
@@ -130,13 +129,14 @@ class PPOEngine:
                     action_low=-1.0, action_high=1.0, seed=0, device_id=0, rank=0, world_size=1, fast_kernels=True,
                     rollout_graph=True, rollout_persistent=True, activation="tanh", forward_x3=True) -> Config:
         """PPO(...) keyword arguments -> `mobrob_ppo_config_t` (SB3 defaults, Appendix A.1)."""
-        if len(pi) != 2 or len(vf) != 2:
-            raise ValueError("net_arch must have exactly two hidden layers per network (pi=[h1,h2], vf=[h1,h2])")
+        if not (1 <= len(pi) <= 3 and 1 <= len(vf) <= 3):
+            raise ValueError("net_arch: one to three hidden layers per network (pi=[h1, ...], vf=[h1, ...])")
         cfg = Config()
         _lib.load().mobrob_ppo_default_config(C.byref(cfg))
         cfg.obs_dim, cfg.act_dim = int(obs_dim), int(act_dim)
-        cfg.pi_hidden[0], cfg.pi_hidden[1] = int(pi[0]), int(pi[1])
-        cfg.vf_hidden[0], cfg.vf_hidden[1] = int(vf[0]), int(vf[1])
+        p3, v3 = (list(map(int, pi)) + [0, 0])[:3], (list(map(int, vf)) + [0, 0])[:3]   # a width of 0 ends the list
+        cfg.pi_hidden[0], cfg.pi_hidden[1], cfg.pi_hidden3 = p3
+        cfg.vf_hidden[0], cfg.vf_hidden[1], cfg.vf_hidden3 = v3
         cfg.n_envs, cfg.n_steps, cfg.batch_size, cfg.n_epochs = int(n_envs), int(n_steps), int(batch_size), int(n_epochs)
         cfg.gamma, cfg.gae_lambda, cfg.clip_range = float(gamma), float(gae_lambda), float(clip_range)
         cfg.ent_coef, cfg.vf_coef, cfg.max_grad_norm = float(ent_coef), float(vf_coef), float(max_grad_norm)
@@ -167,7 +167,8 @@ class PPOEngine:
         (mobrob_ppo_create_in_arena; the fleet packs several engines into one allocation this way)."""
         self.lib = _lib.load()
         cfg = self.make_config(obs_dim, act_dim, n_envs, n_steps, **kwargs)
-        pi, vf = tuple(cfg.pi_hidden), tuple(cfg.vf_hidden)
+        pi = tuple(w for w in (cfg.pi_hidden[0], cfg.pi_hidden[1], cfg.pi_hidden3) if w > 0)
+        vf = tuple(w for w in (cfg.vf_hidden[0], cfg.vf_hidden[1], cfg.vf_hidden3) if w > 0)
         self.cfg = cfg
         self.D, self.A, self.N, self.T = int(obs_dim), int(act_dim), int(n_envs), int(n_steps)
         self.shapes = param_shapes(self.D, self.A, pi, vf)

@@ -36,9 +36,14 @@ def policy_init(obs_dim, act_dim, pi=(64, 64), vf=(64, 64), seed=0, log_std_init
     rng = np.random.default_rng(seed)
     p = OrderedDict()
     p["log_std"] = np.full((act_dim,), log_std_init, np.float32)
-    for name, rows, cols in (("mlp_extractor.policy_net.0", pi[0], obs_dim), ("mlp_extractor.policy_net.2", pi[1], pi[0]),
-                             ("mlp_extractor.value_net.0", vf[0], obs_dim), ("mlp_extractor.value_net.2", vf[1], vf[0]),
-                             ("action_net", act_dim, pi[1]), ("value_net", 1, vf[1])):
+    layers = []
+    for net, widths in (("policy_net", pi), ("value_net", vf)):   # one to three hidden layers per network, SB3's registration order
+        prev = obs_dim
+        for i, w in enumerate(widths):
+            layers.append((f"mlp_extractor.{net}.{2 * i}", w, prev))
+            prev = w
+    layers += [("action_net", act_dim, pi[-1]), ("value_net", 1, vf[-1])]
+    for name, rows, cols in layers:
         p[name + ".weight"], p[name + ".bias"] = default_linear_init(rng, rows, cols)
     return p
 
@@ -48,16 +53,14 @@ def orthogonal_policy_init(obs_dim, act_dim, pi=(64, 64), vf=(64, 64), seed=0, l
     p = OrderedDict()
     p["log_std"] = np.full((act_dim,), log_std_init, np.float32)
     g = math.sqrt(2.0)
-    p["mlp_extractor.policy_net.0.weight"] = _orthogonal(rng, pi[0], obs_dim, g)
-    p["mlp_extractor.policy_net.0.bias"] = np.zeros(pi[0], np.float32)
-    p["mlp_extractor.policy_net.2.weight"] = _orthogonal(rng, pi[1], pi[0], g)
-    p["mlp_extractor.policy_net.2.bias"] = np.zeros(pi[1], np.float32)
-    p["mlp_extractor.value_net.0.weight"] = _orthogonal(rng, vf[0], obs_dim, g)
-    p["mlp_extractor.value_net.0.bias"] = np.zeros(vf[0], np.float32)
-    p["mlp_extractor.value_net.2.weight"] = _orthogonal(rng, vf[1], vf[0], g)
-    p["mlp_extractor.value_net.2.bias"] = np.zeros(vf[1], np.float32)
-    p["action_net.weight"] = _orthogonal(rng, act_dim, pi[1], 0.01)
+    for net, widths in (("policy_net", pi), ("value_net", vf)):   # (two hidden layers draw from the generator in the order they always did)
+        prev = obs_dim
+        for i, w in enumerate(widths):
+            p[f"mlp_extractor.{net}.{2 * i}.weight"] = _orthogonal(rng, w, prev, g)
+            p[f"mlp_extractor.{net}.{2 * i}.bias"] = np.zeros(w, np.float32)
+            prev = w
+    p["action_net.weight"] = _orthogonal(rng, act_dim, pi[-1], 0.01)
     p["action_net.bias"] = np.zeros(act_dim, np.float32)
-    p["value_net.weight"] = _orthogonal(rng, 1, vf[1], 1.0)
+    p["value_net.weight"] = _orthogonal(rng, 1, vf[-1], 1.0)
     p["value_net.bias"] = np.zeros(1, np.float32)
     return p

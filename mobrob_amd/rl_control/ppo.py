@@ -225,8 +225,8 @@ class PPO:
         unknown = set(self.policy_kwargs) - {"net_arch", "log_std_init", "ortho_init", "optimizer_kwargs", "activation_fn",
                                              "optimizer_class"}
         if unknown:
-            raise NotImplementedError(f"policy_kwargs {sorted(unknown)} are not supported (MlpPolicy, two hidden layers per "
-                                      "network)")
+            raise NotImplementedError(f"policy_kwargs {sorted(unknown)} are not supported (MlpPolicy, one to three hidden layers "
+                                      "per network)")
         self.num_timesteps = 0
         self._total_timesteps = 0
         self._num_timesteps_at_start = 0
@@ -595,8 +595,13 @@ class PPO:
         d, params = ck["data"], ck["params"]
         D = params["mlp_extractor.policy_net.0.weight"].shape[1]
         A = params["log_std"].shape[0]
-        pi = (params["mlp_extractor.policy_net.0.weight"].shape[0], params["mlp_extractor.policy_net.2.weight"].shape[0])
-        vf = (params["mlp_extractor.value_net.0.weight"].shape[0], params["mlp_extractor.value_net.2.weight"].shape[0])
+        def widths(net):   # hidden widths from the state dict itself (nn.Sequential indices 0, 2, 4: one to three hidden layers)
+            out, i = [], 0
+            while f"mlp_extractor.{net}.{2 * i}.weight" in params:
+                out.append(params[f"mlp_extractor.{net}.{2 * i}.weight"].shape[0])
+                i += 1
+            return tuple(out)
+        pi, vf = widths("policy_net"), widths("value_net")
         pk = dict(d.get("policy_kwargs") or {})
         pk.setdefault("net_arch", dict(pi=list(pi), vf=list(vf)))
         explicit_arch = "net_arch" in (d.get("policy_kwargs") or {})

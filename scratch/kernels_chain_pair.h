@@ -1,3 +1,5 @@
+// REJECTED EXPERIMENT (round 4), kept for the record, not part of the library: kernels_chain.h with the wave-pair ownership of the
+// forward pass (MOBROB_CHAIN_PAIR).  Correct (193 engine / x3 parity tests), 1.3 - 4 % slower per launch than the kernel it was meant to beat.
 // k_chain_train: the gradient kernel of the 256-wide networks designed around the bf16 matrix pipe (round 4).
 //
 // k_fused_train<.., X3> (kernels_fused.h) is the f32 kernel with its GEMM loops swapped for "x3" loops (float32 products as six
@@ -22,9 +24,6 @@
 //     dW3 run as in k_fused_train: dW2's 256 x 256 accumulators pinned in the 256 AGPRs of the four waves for the whole launch.
 //     dW1 no longer holds 64 VGPRs for the launch: it is accumulated per tile and added to the workgroup's (L2-resident) slab.
 //
-// (Measured and not kept, scratch/kernels_chain_pair.h: a wave-PAIR ownership of the forward pass -- 32 rows x half the neurons per
-//  wave, every weight fragment read from the ring feeding two B fragments, half the ring reads -- correct on the whole suite, 2 % slower:
-//  CHANGELOG.md, round 4.)
 // LDS (160 KB): h1 / dz1 image 64 KB | X image | constants | ring 12 KB + (h2 / dz2 image 64 KB: ring space while no image is live).
 // Same slab format as k_fused_train: k_slab_reduce, the norm records and k_adam_pack are unchanged.
 // Conditions: 256-wide tanh nets, heads <= 16 wide, observation rows padded to 16 / 32 / 64 columns (engine.hip fused_init).
@@ -93,8 +92,35 @@ __device__ __forceinline__ u32x4 ring_read_piece(int ring_lane_f0, int slot, int
   C_ = MFMA16B(Wr.p0[par], X_.p[1], C_);                                                     \
   C_ = MFMA16B(Wr.p0[par], X_.p[0], C_);
 
+// The same with ONE weight fragment feeding two B fragments (two accumulator tiles: the wave-pair forward): twelve MFMAs per unit,
+// alternating accumulators; the next unit's pieces are read behind the last use of the registers they go to.
+#define CHAIN_UNIT2_A(Wr, par, X0_, X1_, C0_, C1_, have_next, nslot)                          \
+  if (have_next) Wr.p0[(par) ^ 1] = ring_read_piece(ringp, nslot, 0);                          \
+  C0_ = MFMA16B(Wr.p2, X0_.p[0], C0_);                                                         \
+  C1_ = MFMA16B(Wr.p2, X1_.p[0], C1_);                                                         \
+  if (have_next) Wr.p2 = ring_read_piece(ringp, nslot, 2);                                     \
+  C0_ = MFMA16B(Wr.p1, X0_.p[1], C0_);                                                         \
+  C1_ = MFMA16B(Wr.p1, X1_.p[1], C1_);                                                         \
+  C0_ = MFMA16B(Wr.p1, X0_.p[0], C0_);                                                         \
+  C1_ = MFMA16B(Wr.p1, X1_.p[0], C1_);                                                         \
+  if (have_next) Wr.p1 = ring_read_piece(ringp, nslot, 1);   /* (in THIS half: behind the scheduling barrier that follows it the   \
+                                                                 read cannot sink to the end of the unit, two MFMAs from its use) */
+#define CHAIN_UNIT2_B(Wr, par, X0_, X1_, C0_, C1_, have_next, nslot)                          \
+  C0_ = MFMA16B(Wr.p0[par], X0_.p[2], C0_);                                                    \
+  C1_ = MFMA16B(Wr.p0[par], X1_.p[2], C1_);                                                    \
+  C0_ = MFMA16B(Wr.p0[par], X0_.p[1], C0_);                                                    \
+  C1_ = MFMA16B(Wr.p0[par], X1_.p[1], C1_);                                                    \
+  C0_ = MFMA16B(Wr.p0[par], X0_.p[0], C0_);                                                    \
+  C1_ = MFMA16B(Wr.p0[par], X1_.p[0], C1_);
+#define CHAIN_UNIT2(Wr, par, X0_, X1_, C0_, C1_, have_next, nslot) \
+  CHAIN_UNIT2_A(Wr, par, X0_, X1_, C0_, C1_, have_next, nslot)     \
+  CHAIN_UNIT2_B(Wr, par, X0_, X1_, C0_, C1_, have_next, nslot)
+
 // LDS-DMA of 1 KB: lane l's 16 bytes at sbase + voff land at LDS byte address lds_byte + 16 l.  Issued as inline asm: the
 // compiler knows nothing of it (no conservative vmcnt(0) in front of every ring read); the ring protocol below waits by hand.
+#ifndef MOBROB_CHAIN_PAIR     // 1: wave-pair ownership of the forward pass (32 rows x half the neurons per wave)
+#define MOBROB_CHAIN_PAIR 1
+#endif
 #ifndef MOBROB_CHAIN_SKIP     // timing-only ablation builds (outputs wrong by construction; never in the product library)
 #define MOBROB_CHAIN_SKIP 0
 #endif
@@ -387,6 +413,155 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
     }
 
     STAMP(0)
+#if MOBROB_CHAIN_PAIR
+    // ============================ forward, wave-PAIR ownership: 32 rows x half the neurons per wave ============================
+    // Waves 2 rg and 2 rg + 1 share the 32 batch rows of row group rg; wave (rg, nh) computes neuron tiles 8 nh .. 8 nh + 7 of both
+    // layers for ALL 32 rows: every weight fragment it reads from the ring feeds TWO B fragments (its own sixteen rows: registers
+    // as before; the partner's sixteen rows, trow ^ 16: read from the X / h1 images, which exist anyway), so a wave reads half
+    // the ring (the probe's "one weight fragment feeds both" loop: 100.3 cycles per six MFMAs against 113.8).  The stream holds
+    // the same packs in another order -- layer 1 [tile of the half][k step][half], layer 2 [k step][tile of the half][half] -- so
+    // that a wave's units sit in every other ring slot (a constant offset per wave) and every segment carries work for both
+    // halves.  After the stream h2 goes to its image in this ownership and comes back in the backward ownership (sixteen rows x
+    // all neurons per wave): everything from the head on is unchanged.
+    constexpr int NOWN = 8 * K1 + 64;                      // units a wave consumes: stream position 2 k + nh, ring slot (2 k) % 24 (+ nh)
+    const int nh = wv & 1;
+    const int orow = trow ^ 16;                            // the partner's row with this lane's position
+    const int ringp = opaque4(ringl + nh * CUNIT);
+    auto fwd_issue = [&](int q) {   // DMAs of segment q: this wave moves stream positions 8 q + wave and 8 q + 4 + wave
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int pos = CSEG * q + 4 * hh + wv, half = pos & 1, c = pos >> 1;   // (c: the unit's index among its half's units)
+        const u32x4* src;
+        if (CSEG * q < NU1) src = W1c_ + (size_t)((8 * half + c / K1) * K1 + c % K1) * 192;                       // chain_unit_w1(tile, k step)
+        else { const int c2 = c - NU1 / 2; src = W2c_ + (size_t)((c2 >> 3) * 16 + 8 * half + (c2 & 7)) * 192; }   // chain_unit_w2(tile, k step)
+        dma_unit(src, (CSEG * q + 4 * hh) % CSLOTS + wv, lane16, L::RING);
+      }
+    };
+    int hb1[4], hbx[4];    // this lane's elements of the h1 image, own rows / partner's rows: column 16 t + 4 g + i -> + 1024 t
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      hb1[i] = opaque(L::H1 + img_addr(4 * g + i, trow));
+      hbx[i] = opaque(L::H1 + img_addr(4 * g + i, orow));
+    }
+    f32x4 acc2[16];
+    f32x4 hw[8];
+    if (!primed) {
+      fwd_issue(0);
+      fwd_issue(1);
+    }
+    CHAIN_WAIT_DMA(true);
+    CHAIN_BARRIER();       // also: the X image is complete, the previous tile's last reads of the images are done everywhere
+    STAMP(18)
+    fwd_issue(2);
+    // the partner rows' layer-1 B fragments: from the X image (the own rows' came from the gather registers above)
+    X3Frag xq[K1];
+#pragma unroll
+    for (int s = 0; s < K1; ++s) {
+      float v[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) v[jj] = (32 * s + 8 * g < DP) ? lds[L::XI + img_addr(32 * s + 8 * g + jj, orow)] : 0.f;
+      xq[s] = x3_split8v(v);
+    }
+    RingW Wr;
+    Wr.p0[0] = ring_read_piece(ringp, 0, 0); Wr.p1 = ring_read_piece(ringp, 0, 1); Wr.p2 = ring_read_piece(ringp, 0, 2);
+    X3Frag Bc[2], Bn[2];   // B fragments of the current / next layer-2 k step: [0] own rows, [1] partner's rows
+    f32x4 accn[8][2];      // layer 2: this wave's eight neuron tiles x two row fragments
+    f32x4 c1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, pend[2] = {c1[0], c1[1]};
+    const int b1b = opaque4(L::B1 + 4 * g + 128 * nh), b2b = opaque4(L::B2 + 4 * g + 128 * nh);
+    const int w1o = 8192 * nh;   // image offset of this wave's first neuron tile (tile 8 nh: column 128 nh)
+    // The B fragments of layer-2 k step sn, one pair (two elements) of one fragment per unit: the two image reads go out at the top
+    // of the unit, the pair-split sits among its LAST six MFMAs (left to the scheduler, read and split ended up back to back behind
+    // the MFMAs: the LDS latency and eleven VALU instructions exposed, 394 cycles per unit instead of ~200).
+    float pa = 0.f, pb = 0.f;
+    auto issue_pair = [&](int sn, int f, int jp) {
+      const int e0 = 2 * jp, e1 = 2 * jp + 1;
+      const int* hb = f ? hbx : hb1;
+      pa = lds[hb[e0 & 3] + 1024 * (2 * sn + (e0 >> 2))];
+      pb = lds[hb[e1 & 3] + 1024 * (2 * sn + (e1 >> 2))];
+    };
+    auto split_pair = [&](int f, int jp, X3Frag (&dst)[2]) {
+      SplitMid m;
+      split_half1<true>(pa, pb, m);
+      split_half2<true>(m, jp, dst[f]);
+    };
+    auto prep_pair = [&](int sn, int f, int jp, X3Frag (&dst)[2]) {   // un-pipelined form (K1 = 1 bubble)
+      issue_pair(sn, f, jp);
+      split_pair(f, jp, dst);
+    };
+    static_for<0, NOWN>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (k == 8 * K1) { STAMP(1) }
+      if constexpr (k == NOWN - 8) {   // the head's weight fragments (16 KB from L2): two ring segments ahead of their use
+#pragma unroll
+        for (int t = 0; t < 8; ++t) hw[t] = ldg16(W.W3c, lane16 + 1024u * t);
+      }
+      if constexpr ((k + 1) % 4 == 0 && k + 1 < NOWN) {   // four of a wave's units = one ring segment of eight
+        constexpr int q = (k + 1) / 4;
+        CHAIN_WAIT_DMA(q + 1 < NSF);
+        CHAIN_BARRIER();
+        if constexpr (q + 2 < NSF) fwd_issue(q + 2);
+      }
+      constexpr int nslot = (2 * (k + 1)) % CSLOTS;
+      if constexpr (k < 8 * K1) {
+        constexpr int t8 = k / K1, ks = k % K1;
+        if constexpr (ks == 0) c1[0] = c1[1] = *reinterpret_cast<const f32x4*>(&lds[b1b + 16 * t8]);
+        constexpr int o = k - (8 * K1 - 8);            // >= 0: layer-2 k step 0 is prepared under the last eight units of layer 1
+        if constexpr (K1 >= 2 && o >= 0) { issue_pair(0, o >> 2, o & 3); __builtin_amdgcn_sched_barrier(0); }
+        CHAIN_UNIT2_A(Wr, k & 1, xp[ks], xq[ks], c1[0], c1[1], k + 1 < NOWN, nslot)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (K1 >= 2 && o >= 0) split_pair(o >> 2, o & 3, Bc);
+        CHAIN_UNIT2_B(Wr, k & 1, xp[ks], xq[ks], c1[0], c1[1], k + 1 < NOWN, nslot)
+        if constexpr (t8 > 0 && ks == 0) {   // the previous tile: tanh -> h1 image, both row fragments
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            lds[hb1[i] + w1o + 1024 * (t8 - 1)] = fast_tanh_scaled(pend[0][i]);
+            lds[hbx[i] + w1o + 1024 * (t8 - 1)] = fast_tanh_scaled(pend[1][i]);
+          }
+        }
+        if constexpr (ks == K1 - 1) { pend[0] = c1[0]; pend[1] = c1[1]; }
+        // (K1 = 2: h1 tiles 0, 1, which k step 0 reads, were finished two segments ago)
+      } else {
+        constexpr int k2 = k - 8 * K1, ks = k2 / 8, t8 = k2 % 8;
+        if constexpr (k2 == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            lds[hb1[i] + w1o + 1024 * 7] = fast_tanh_scaled(pend[0][i]);
+            lds[hbx[i] + w1o + 1024 * 7] = fast_tanh_scaled(pend[1][i]);
+          }
+          if constexpr (K1 < 2) {   // one layer-1 k step: h1 tiles 0, 1 are only now a segment old -- prepared here, not overlapped
+#pragma unroll
+            for (int o = 0; o < 8; ++o) prep_pair(0, o >> 2, o & 3, Bc);
+          }
+        }
+        if constexpr (ks == 0) accn[t8][0] = accn[t8][1] = *reinterpret_cast<const f32x4*>(&lds[b2b + 16 * t8]);
+        if constexpr (ks + 1 < 8) { issue_pair(ks + 1, t8 >> 2, t8 & 3); __builtin_amdgcn_sched_barrier(0); }   // the next k step's B fragments
+        CHAIN_UNIT2_A(Wr, k & 1, Bc[0], Bc[1], accn[t8][0], accn[t8][1], k + 1 < NOWN, nslot)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ks + 1 < 8) split_pair(t8 >> 2, t8 & 3, Bn);
+        CHAIN_UNIT2_B(Wr, k & 1, Bc[0], Bc[1], accn[t8][0], accn[t8][1], k + 1 < NOWN, nslot)
+        if constexpr (ks + 1 < 8 && t8 == 7) { Bc[0] = Bn[0]; Bc[1] = Bn[1]; }
+      }
+    });
+    // every wave is done with the ring: its space beyond the first four units becomes the h2 image
+    CHAIN_BARRIER();
+    {  // h2 = tanh in the forward ownership -> image; back in the backward ownership (sixteen rows x all tiles per wave)
+#pragma unroll
+      for (int t8 = 0; t8 < 8; ++t8)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          lds[hb1[i] + (L::H2 - L::H1) + w1o + 1024 * t8] = fast_tanh_scaled(accn[t8][0][i]);
+          lds[hbx[i] + (L::H2 - L::H1) + w1o + 1024 * t8] = fast_tanh_scaled(accn[t8][1][i]);
+        }
+      LDS_BARRIER();
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc2[t][i] = lds[hb1[i] + (L::H2 - L::H1) + 1024 * t];
+    }
+    STAMP(2)
+
+#else
     // ============================ forward: layer 1 and layer 2 as ONE stream of ring units ============================
     // unit u < NU1: layer 1, neuron tile u / K1, k step u % K1 (pack W1c, [tile][k step]: a tile is complete after K1 units, its
     // tanh goes to the h1 image under the next tile's MFMAs and its accumulator dies -- layer 1 holds four registers, not 64);
@@ -478,6 +653,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
     CHAIN_BARRIER();
     STAMP(2)
 
+#endif
     // ============================ h2 = tanh, head (float32 16x16x4), loss, dout ============================
     int hb2[4];            // the same elements of the h2 / dz2 image (derived here: four registers that need not live through the ring phases)
 #pragma unroll
@@ -492,9 +668,13 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
         hw[t & 7] = t < 8 ? ldg16(W.W3c, lane16 + 1024u * (t + 8)) : ldg16(W.W3bc, lane16 + 1024u * (t - 8));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+#if MOBROB_CHAIN_PAIR
+          const float h = acc2[t][i];     // tanh was taken, and the h2 image written, in the forward ownership
+#else
           const float h = fast_tanh_scaled(acc2[t][i]);
           acc2[t][i] = h;
           lds[hb2[i] + 1024 * t] = h;
+#endif
           if (t & 1) mean2 = MFMA16(wv[i], h, mean2);
           else mean = MFMA16(wv[i], h, mean);
         }

@@ -1,4 +1,5 @@
 """CPU: SB3-zip checkpoint reader/writer (mobrob_amd/checkpoint.py)."""
+import io
 import json
 import os
 import pickle
@@ -224,3 +225,60 @@ def test_event_file_writer_round_trip(tmp_path):
     want = bytes([0x09]) + __import__("struct").pack("<d", 1.5) + bytes([0x10, 0x03, 0x2A, 0x0A, 0x0A, 0x08, 0x0A, 0x01, 0x61, 0x15]) \
         + __import__("struct").pack("<f", 2.0)
     assert tb.encode_event(1.5, 3, [("a", 2.0)]) == want
+
+
+@pytest.mark.parametrize("pi,vf", [((64,), (64,)), ((64, 48, 32), (64, 48, 32)), ((40,), (64, 32, 16))])
+def test_zip_of_other_depths_round_trips(pi, vf, tmp_path):
+    """net_arch with one or three hidden layers per network: SB3's registration order (nn.Sequential indices 0, 2, 4) in the
+    state dict and in the optimizer's parameter numbering, torch-loadable, round trip exact (torch-CPU builds the same modules
+    and must agree on every key and shape)."""
+    import torch
+    from oracle import ppo_oracle as O
+    D, A = 14, 2
+    params = O.init_params(D, A, pi, vf, seed=1)
+    assert list(params.keys()) == ck.policy_keys(len(pi), len(vf)) == O.param_keys(len(pi), len(vf))
+    assert ck.policy_keys(2, 2) == ck.POLICY_KEYS and ck.depth_of_keys(list(params.keys())) == (len(pi), len(vf))
+    rng = np.random.default_rng(0)
+    m = OrderedDict((k, rng.standard_normal(v.shape).astype(np.float32)) for k, v in params.items())
+    v_ = OrderedDict((k, rng.random(v.shape).astype(np.float32)) for k, v in params.items())
+    hyper = dict(n_steps=32, batch_size=64, n_epochs=2, gamma=0.99, gae_lambda=0.95, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
+                 learning_rate=3e-4, clip_range=0.2, n_envs=4)
+    path = ck.save_zip(str(tmp_path / "deep"), params=params, optimizer=dict(exp_avg=m, exp_avg_sq=v_, step=12), hyper=hyper,
+                       obs_dim=D, act_dim=A, net_arch=(pi, vf))
+    c = ck.load_zip(path)
+    assert list(c["params"].keys()) == list(params.keys())
+    assert all(np.array_equal(c["params"][k], params[k]) for k in params)
+    assert all(np.array_equal(c["optimizer"]["exp_avg"][k], m[k]) for k in params) and c["optimizer"]["step"] == 12
+    assert c["data"]["policy_kwargs"] == {"net_arch": {"pi": list(pi), "vf": list(vf)}}
+    # the torch modules SB3's MlpExtractor builds for this net_arch accept the state dict key for key
+    def seq(widths):
+        mods, prev = [], D
+        for w in widths:
+            mods += [torch.nn.Linear(prev, w), torch.nn.Tanh()]
+            prev = w
+        return torch.nn.Sequential(*mods)
+    pol, val = seq(pi), seq(vf)
+    with zipfile.ZipFile(path) as z:
+        sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)
+    pol.load_state_dict({k.split("policy_net.")[1]: t for k, t in sd.items() if "policy_net" in k})
+    val.load_state_dict({k.split("value_net.")[1]: t for k, t in sd.items() if ".value_net." in k})
+
+
+def test_config_accepts_one_to_three_hidden_layers_and_nothing_else():
+    """Host-only sizing pass (mobrob_ppo_device_bytes runs check_cfg without touching a device)."""
+    from mobrob_amd.engine import PPOEngine
+    base = dict(obs_dim=14, act_dim=2, n_envs=8, n_steps=16, batch_size=32)
+    sizes = {arch: PPOEngine.device_bytes(pi=arch, vf=arch, **base) for arch in [(64,), (64, 64), (64, 64, 64)]}
+    assert all(v > 0 for v in sizes.values()) and sizes[(64,)] < sizes[(64, 64, 64)]   # (both on the generic chain; two layers: fused kernels)
+    assert PPOEngine.device_bytes(pi=(40,), vf=(64, 32, 16), **base) > 0
+    for bad in [(), (64, 64, 64, 64)]:
+        with pytest.raises(ValueError):
+            PPOEngine.device_bytes(pi=bad, vf=(64, 64), **base)
+    with pytest.raises(Exception, match="multiples of 8"):
+        PPOEngine.device_bytes(pi=(64, 30), vf=(64, 64), **base)
+    cfg = PPOEngine.make_config(pi=(64, 64), vf=(64, 64), **base)
+    cfg.pi_hidden[1], cfg.pi_hidden3 = 0, 64                      # a hole in the list
+    from mobrob_amd import _lib
+    import ctypes as C
+    n = C.c_size_t(0)
+    assert _lib.load().mobrob_ppo_device_bytes(C.byref(cfg), C.byref(n)) != 0
