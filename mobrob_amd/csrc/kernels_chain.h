@@ -395,12 +395,18 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
     // tanh goes to the h1 image under the next tile's MFMAs and its accumulator dies -- layer 1 holds four registers, not 64);
     // then layer 2, k step (u - NU1) / 16, neuron tile (u - NU1) % 16 (pack W2c), whose B fragments are this lane's own eight
     // elements of the h1 image, read back and split one k step ahead.
+    // per-wave bases of the DMAs, re-materialised per tile: the unit a wave moves is base + a compile-time constant (source and
+    // LDS destination alike), two scalar adds and one M0 write per unit instead of the multiply / shift chains of (8 q + 4 hh + wave)
+    const u32x4* w1w = opaque_sp(W1c_ + (size_t)wv * 192);
+    const u32x4* w2w = opaque_sp(W2c_ + (size_t)wv * 192);
+    const u32x4* w2bw = opaque_sp(((MOBROB_CHAIN_SKIP & 64) ? W2c_ : W2bc_) + (size_t)wv * 192);
+    const int ringw = opaque_s(L::RING + wv * CUNIT);
     auto fwd_issue = [&](int q) {   // DMAs of segment q: this wave moves units 8 q + wave and 8 q + 4 + wave
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        const int u = CSEG * q + 4 * hh + wv;
-        const u32x4* src = (CSEG * q < NU1) ? W1c_ + (size_t)u * 192 : W2c_ + (size_t)(u - NU1) * 192;
-        dma_unit(src, (CSEG * q + 4 * hh) % CSLOTS + wv, lane16, L::RING);
+        const int u0 = CSEG * q + 4 * hh;
+        const u32x4* src = (CSEG * q < NU1) ? w1w + (size_t)u0 * 192 : w2w + (size_t)(u0 - NU1) * 192;
+        dma_unit(src, u0 % CSLOTS, lane16, ringw);
       }
     };
     // this lane's elements of an image: column 16 t + 4 g + i, row trow -> hb[i] + 1024 t
@@ -704,8 +710,8 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
     auto bwd_issue = [&](int q) {
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        const int u = CSEG * q + 4 * hh + wv;
-        dma_unit(((MOBROB_CHAIN_SKIP & 64) ? W2c_ : W2bc_) + (size_t)u * 192, (CSEG * q + 4 * hh) % CSLOTS + wv, lane16, L::RING);
+        const int u0 = CSEG * q + 4 * hh;
+        dma_unit(w2bw + (size_t)u0 * 192, u0 % CSLOTS, lane16, ringw);
       }
     };
     {
