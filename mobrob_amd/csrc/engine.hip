@@ -1829,8 +1829,7 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
                      (float)B, inv_bg);
   // backward of both networks, last hidden layer first: dW of the layer above, then dz of this layer (dtanh / dReLU + bias sums)
   auto backward = [&](int L, const int* Hw, float* const* h, float* const* dz, const float* dhead, int ldd, const float* headWp,
-                      int head_rows, int head_pad, int t_headW, const int* tW, const int* tB, const float* W1pad_unused) {
-    (void)W1pad_unused;
+                      int head_rows, int head_pad, int t_headW, const int* tW, const int* tB) {
     const int HLw = Hw[L - 1];
     linear_bwd_weight(e, dhead, ldd, h[L - 1], HLw, Gp(e, t_headW), HLw, head_rows, HLw, B);
     linear_bwd_input(e, dhead, ldd, headWp, HLw, h[L - 1], HLw, dz[L - 1], HLw, Gp(e, tB[L - 1]), B, HLw, head_pad);
@@ -1840,8 +1839,8 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
     }
     linear_bwd_weight(e, dz[0], Hw[0], e->Xg, e->Dp, Gp(e, tW[0]), e->D, Hw[0], e->D, B);
   };
-  backward(e->Lp, e->Hp, e->hp, e->dzp, e->dmu, e->Ap, e->aWp, e->A, e->Ap, T_AW, e->tPW, e->tPB, nullptr);
-  backward(e->Lv, e->Hv, e->hv, e->dzv, e->dv, 8, e->vWp, 1, 8, T_VW, e->tVW, e->tVB, nullptr);
+  backward(e->Lp, e->Hp, e->hp, e->dzp, e->dmu, e->Ap, e->aWp, e->A, e->Ap, T_AW, e->tPW, e->tPB);
+  backward(e->Lv, e->Hv, e->hv, e->dzv, e->dv, 8, e->vWp, 1, 8, T_VW, e->tVW, e->tVB);
   HIPC(hipGetLastError());
   e->grad_pending = true;
   return MOBROB_OK;
