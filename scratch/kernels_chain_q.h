@@ -1,3 +1,6 @@
+// REJECTED EXPERIMENT (round 4), kept for the record, not part of the library: kernels_chain.h with the wave-pair forward on
+// v_mfma_f32_32x32x16_bf16 (MOBROB_CHAIN_Q; needs the Q-format forward packs: chain_packq_idx in the kernels_fused.h of that experiment).
+// Correct (177 engine / x3 parity tests, the cancelling adversarial case at 2.6x instead of <= 2.5x), 3.4 % slower per launch.
 // k_chain_train: the gradient kernel of the 256-wide networks designed around the bf16 matrix pipe (round 4).
 //
 // k_fused_train<.., X3> (kernels_fused.h) is the f32 kernel with its GEMM loops swapped for "x3" loops (float32 products as six
@@ -78,53 +81,38 @@ __host__ __device__ __forceinline__ int img_addr(int m, int row) { return m * 64
 // to the end, alternates between two registers by unit parity).  Every read is then issued 3 .. 6 MFMAs (48 .. 96 cycles) before
 // the MFMA that needs it: with all three pieces read in one burst late in the unit (the first version) every unit started with
 // an LDS wait.  Magnitudes: (2,0) (1,1) ~2^-16, (1,0) ~2^-8, (0,2) ~2^-16, (0,1) ~2^-8, (0,0) ~1 of the product.
-#ifndef MOBROB_CHAIN_AHEAD2
-#define MOBROB_CHAIN_AHEAD2 1
-#endif
-#if MOBROB_CHAIN_AHEAD2
-// Pieces are read TWO units ahead of their use (the LDS answers a read in 200-300 cycles while four waves and the ring's DMA writes
-// load it; a unit is ~150): piece 0 rotates through three registers, pieces 1 and 2 through two each.
-struct RingW { u32x4 p0[3], p1[2], p2[2]; };
-#else
 struct RingW { u32x4 p0[2], p1, p2; };
-#endif
 __device__ __forceinline__ u32x4 ring_read_piece(int ring_lane_f0, int slot, int pc) {
   return *reinterpret_cast<const u32x4*>(&lds[ring_lane_f0 + slot * CUNIT + 256 * pc]);
 }
 // (Scheduling barriers behind the second and third read -- the scheduler otherwise issues the three reads together behind the third
 //  MFMA, 48 cycles before the next unit needs the first -- were measured twice (after every MFMA, and behind the two reads only): layer 2 19.0 k -> 19.8 k
 //  cycles, launch +1.3 %.  The reads stay where the scheduler puts them.)
-#if MOBROB_CHAIN_AHEAD2
-// u: the unit's index in its stream (compile time); have2 / slot2: whether unit u + 2 exists, and its ring slot
-#define CHAIN_UNIT(Wr, u_, X_, C_, have2, slot2)                                             \
-  if (have2) Wr.p0[((u_) + 2) % 3] = ring_read_piece(ringl, slot2, 0);                       \
-  C_ = MFMA16B(Wr.p2[(u_) & 1], X_.p[0], C_);                                                \
-  if (have2) Wr.p2[(u_) & 1] = ring_read_piece(ringl, slot2, 2);                             \
-  C_ = MFMA16B(Wr.p1[(u_) & 1], X_.p[1], C_);                                                \
-  C_ = MFMA16B(Wr.p1[(u_) & 1], X_.p[0], C_);                                                \
-  if (have2) Wr.p1[(u_) & 1] = ring_read_piece(ringl, slot2, 1);                             \
-  C_ = MFMA16B(Wr.p0[(u_) % 3], X_.p[2], C_);                                                \
-  C_ = MFMA16B(Wr.p0[(u_) % 3], X_.p[1], C_);                                                \
-  C_ = MFMA16B(Wr.p0[(u_) % 3], X_.p[0], C_);
-#define CHAIN_RING_PRIME(Wr)                                                                                             \
-  Wr.p0[0] = ring_read_piece(ringl, 0, 0); Wr.p1[0] = ring_read_piece(ringl, 0, 1); Wr.p2[0] = ring_read_piece(ringl, 0, 2); \
-  Wr.p0[1] = ring_read_piece(ringl, 1, 0); Wr.p1[1] = ring_read_piece(ringl, 1, 1); Wr.p2[1] = ring_read_piece(ringl, 1, 2);
-#define CHAIN_AHEAD 2
-#else
-#define CHAIN_UNIT(Wr, u_, X_, C_, have_next, nslot)                                         \
-  if (have_next) Wr.p0[((u_) & 1) ^ 1] = ring_read_piece(ringl, nslot, 0);                   \
+#define CHAIN_UNIT(Wr, par, X_, C_, have_next, nslot)                                        \
+  if (have_next) Wr.p0[(par) ^ 1] = ring_read_piece(ringl, nslot, 0);                        \
   C_ = MFMA16B(Wr.p2, X_.p[0], C_);                                                          \
   if (have_next) Wr.p2 = ring_read_piece(ringl, nslot, 2);                                   \
   C_ = MFMA16B(Wr.p1, X_.p[1], C_);                                                          \
   C_ = MFMA16B(Wr.p1, X_.p[0], C_);                                                          \
   if (have_next) Wr.p1 = ring_read_piece(ringl, nslot, 1);                                   \
-  C_ = MFMA16B(Wr.p0[(u_) & 1], X_.p[2], C_);                                                \
-  C_ = MFMA16B(Wr.p0[(u_) & 1], X_.p[1], C_);                                                \
-  C_ = MFMA16B(Wr.p0[(u_) & 1], X_.p[0], C_);
-#define CHAIN_RING_PRIME(Wr) \
-  Wr.p0[0] = ring_read_piece(ringl, 0, 0); Wr.p1 = ring_read_piece(ringl, 0, 1); Wr.p2 = ring_read_piece(ringl, 0, 2);
-#define CHAIN_AHEAD 1
-#endif
+  C_ = MFMA16B(Wr.p0[par], X_.p[2], C_);                                                     \
+  C_ = MFMA16B(Wr.p0[par], X_.p[1], C_);                                                     \
+  C_ = MFMA16B(Wr.p0[par], X_.p[0], C_);
+
+// The wave-pair forward (MOBROB_CHAIN_Q): one unit = one A fragment of 32 neurons x 16 k, six v_mfma_f32_32x32x16_bf16 into one
+// 32 x 32 accumulator tile (32 neurons x the row group's 32 batch rows); `ringp` is the wave's ring base (its units sit in
+// every other slot).
+#define CHAIN_UNITQ_A(Wr, par, X_, C_, have_next, nslot)                                      \
+  if (have_next) Wr.p0[(par) ^ 1] = ring_read_piece(ringp, nslot, 0);                         \
+  C_ = MFMA32B(Wr.p2, X_.p[0], C_);                                                           \
+  if (have_next) Wr.p2 = ring_read_piece(ringp, nslot, 2);                                    \
+  C_ = MFMA32B(Wr.p1, X_.p[1], C_);                                                           \
+  C_ = MFMA32B(Wr.p1, X_.p[0], C_);                                                           \
+  if (have_next) Wr.p1 = ring_read_piece(ringp, nslot, 1);
+#define CHAIN_UNITQ_B(Wr, par, X_, C_)                                                        \
+  C_ = MFMA32B(Wr.p0[par], X_.p[2], C_);                                                      \
+  C_ = MFMA32B(Wr.p0[par], X_.p[1], C_);                                                      \
+  C_ = MFMA32B(Wr.p0[par], X_.p[0], C_);
 
 // LDS-DMA of 1 KB: lane l's 16 bytes at sbase + voff land at LDS byte address lds_byte + 16 l.  Issued as inline asm: the
 // compiler knows nothing of it (no conservative vmcnt(0) in front of every ring read); the ring protocol below waits by hand.
@@ -406,7 +394,9 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
     const bool has_next = tile + nwg < ntiles;
 
     // ---- X: float32 image for dW1 (column-major, rows contiguous) and the layer-1 B fragments (split once) ----
+#if !MOBROB_CHAIN_Q
     X3Frag xp[K1];
+#endif
 #pragma unroll
     for (int s = 0; s < K1; ++s) {
       float v[8];
@@ -416,21 +406,169 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) lds[L::XI + img_addr(32 * s + 8 * g + j, trow)] = v[j];
       }
+#if !MOBROB_CHAIN_Q
       xp[s] = x3_split8v(v);
+#endif
     }
 
+    // per-wave bases of the DMAs, re-materialised per tile: the unit a wave moves is base + a compile-time constant (source and
+    // LDS destination alike), two scalar adds and one M0 write per unit instead of the multiply / shift chains of (8 q + 4 hh + wave)
+    [[maybe_unused]] const u32x4* w1w = opaque_sp(W1c_ + (size_t)wv * 192);
+    [[maybe_unused]] const u32x4* w2w = opaque_sp(W2c_ + (size_t)wv * 192);
+    const u32x4* w2bw = opaque_sp(((MOBROB_CHAIN_SKIP & 64) ? W2c_ : W2bc_) + (size_t)wv * 192);
+    const int ringw = opaque_s(L::RING + wv * CUNIT);
     STAMP(0)
+#if MOBROB_CHAIN_Q
+    // ============================ forward, wave-PAIR ownership on 32x32x16 MFMAs ============================
+    // Waves 2 rg and 2 rg + 1 share the 32 batch rows of row group rg; wave (rg, nh) computes the 128 neurons 128 nh .. + 127 of both
+    // layers for all 32 rows as four 32 x 32 accumulator tiles (v_mfma_f32_32x32x16_bf16: weights A[32 neurons][16 k], activations
+    // B[16 k][32 rows]).  Every weight fragment read from the ring feeds six 32-cycle MFMAs (the 16x16x32 chain: six 16-cycle ones), and
+    // a 32-cycle MFMA hides about four of the wave's other instructions where a 16-cycle one hides one: the unit's three ring reads,
+    // its share of the B-fragment preparation and its waits disappear behind the matrix pipe.  B fragments come from the X / h1
+    // images for all 32 rows (natural k order: no permutation); the stream holds the forward packs as layer 1 [tile of the half][k
+    // step][half], layer 2 [k step][tile of the half][half], so a wave's units sit in every other ring slot.  h2 goes to its image in
+    // this ownership and is read back in the backward ownership (sixteen rows x all neurons per wave): everything from the head
+    // on is unchanged.
+    constexpr int KS1 = DP / 16;                           // layer-1 k steps of 16 observation columns
+    constexpr int NOWN = 4 * KS1 + 64;                     // units a wave consumes: stream position 2 k + nh, ring slot (2 k) % 24 (+ nh)
+    constexpr int NU1Q = 8 * KS1, NSFQ = (NU1Q + 128) / CSEG;
+    static_assert(NU1Q % CSEG == 0, "layer-1 units fill whole ring segments");
+    const int nh = wv & 1;
+    const int ringp = opaque4(ringl + nh * CUNIT);
+    const int qrow = 32 * (wv >> 1) + (lane & 31), qh = lane >> 5;   // this lane's batch row in the 32 x 32 tiles, its k half
+    auto fwd_issue = [&](int q) {   // DMAs of segment q: this wave moves stream positions 8 q + wave and 8 q + 4 + wave
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int pos = CSEG * q + 4 * hh + wv, half = pos & 1, c = pos >> 1;   // (c: the unit's index among its half's units)
+        const u32x4* src;
+        if (CSEG * q < NU1Q) src = W1c_ + (size_t)((4 * half + c / KS1) * KS1 + c % KS1) * 192;                     // chain_unitq_w1(tile, k step)
+        else { const int c2 = c - NU1Q / 2; src = W2c_ + (size_t)((c2 >> 2) * 8 + 4 * half + (c2 & 3)) * 192; }   // chain_unitq_w2(tile, k step)
+        dma_unit(src, (CSEG * q + 4 * hh) % CSLOTS + wv, lane16, L::RING);
+      }
+    };
+    int hb1[4];            // backward ownership: this lane's elements of an image, column 16 t + 4 g + i, row trow -> hb1[i] + 1024 t
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hb1[i] = opaque(L::H1 + img_addr(4 * g + i, trow));
+    int hq[8];             // forward ownership, B fragments: column 16 s + 8 qh + j, row qrow -> hq[j] + 1024 s
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) hq[jj] = opaque(L::H1 + img_addr(8 * qh + jj, qrow));
+    int hwq[16];           // forward ownership, accumulator elements: neuron 32 T + crc(i) + 4 qh, row qrow -> hwq[i] + 2048 T
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hwq[i] = opaque(L::H1 + img_addr(crc(i) + 4 * qh, qrow) + 8192 * nh);
+    f32x4 acc2[16];
+    f32x4 hw[8];
+    if (!primed) {
+      fwd_issue(0);
+      fwd_issue(1);
+    }
+    CHAIN_WAIT_DMA(true);
+    CHAIN_BARRIER();       // also: the X image is complete, the previous tile's last reads of the images are done everywhere
+    STAMP(18)
+    fwd_issue(2);
+    // layer-1 B fragments of the row group, from the X image
+    X3Frag xq[KS1];
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) {
+      float v[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) v[jj] = lds[hq[jj] + (L::XI - L::H1) + 1024 * s];
+      xq[s] = x3_split8v(v);
+    }
+    RingW Wr;
+    Wr.p0[0] = ring_read_piece(ringp, 0, 0); Wr.p1 = ring_read_piece(ringp, 0, 1); Wr.p2 = ring_read_piece(ringp, 0, 2);
+    X3Frag Bc, Bn;         // B fragment of the current / next layer-2 k step
+    f32x16 accq[4];        // layer 2: this wave's four 32-neuron tiles
+    f32x16 c1 = zero16(), pend = zero16();
+    const int b1q = opaque4(L::B1 + 4 * qh + 128 * nh), b2q = opaque4(L::B2 + 4 * qh + 128 * nh);   // bias of neuron 32 T + crc(i) + 4 qh
+    auto bias16 = [&](int base, int T4) {
+      f32x16 c;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&lds[base + 32 * T4 + 8 * qd]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[4 * qd + e] = b[e];
+      }
+      return c;
+    };
+    float pa = 0.f, pb = 0.f;
+    auto issue_pair = [&](int s, int jp) {   // two elements of layer-2 k step s's B fragment: read at the top of a unit ...
+      pa = lds[hq[2 * jp] + 1024 * s];
+      pb = lds[hq[2 * jp + 1] + 1024 * s];
+    };
+    auto split_pair = [&](int jp, X3Frag& dst) {   // ... split among its last three MFMAs
+      SplitMid m;
+      split_half1<true>(pa, pb, m);
+      split_half2<true>(m, jp, dst);
+    };
+    static_for<0, NOWN>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (k == 4 * KS1) { STAMP(1) }
+      if constexpr (k == NOWN - 8) {   // the head's weight fragments (16 KB from L2): two ring segments ahead of their use
+#pragma unroll
+        for (int t = 0; t < 8; ++t) hw[t] = ldg16(W.W3c, lane16 + 1024u * t);
+      }
+      if constexpr ((k + 1) % 4 == 0 && k + 1 < NOWN) {   // four of a wave's units = one ring segment of eight
+        constexpr int q = (k + 1) / 4;
+        CHAIN_WAIT_DMA(q + 1 < NSFQ);
+        CHAIN_BARRIER();
+        if constexpr (q + 2 < NSFQ) fwd_issue(q + 2);
+      }
+      constexpr int nslot = (2 * (k + 1)) % CSLOTS;
+      if constexpr (k < 4 * KS1) {
+        constexpr int T4 = k / KS1, ks = k % KS1;
+        if constexpr (ks == 0) c1 = bias16(b1q, T4);
+        constexpr int o = k - (4 * KS1 - 4);   // >= 0: layer-2 k step 0 is prepared under the last four units of layer 1 (KS1 >= 2)
+        if constexpr (KS1 >= 2 && o >= 0) { issue_pair(0, o); __builtin_amdgcn_sched_barrier(0); }
+        CHAIN_UNITQ_A(Wr, k & 1, xq[ks], c1, k + 1 < NOWN, nslot)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (KS1 >= 2 && o >= 0) split_pair(o, Bc);
+        CHAIN_UNITQ_B(Wr, k & 1, xq[ks], c1)
+        if constexpr (T4 > 0 && ks == 0) {   // the previous tile: tanh -> h1 image
+#pragma unroll
+          for (int i = 0; i < 16; ++i) lds[hwq[i] + 2048 * (T4 - 1)] = fast_tanh_scaled(pend[i]);
+        }
+        if constexpr (ks == KS1 - 1) pend = c1;
+      } else {
+        constexpr int k2 = k - 4 * KS1, ks = k2 / 4, T4 = k2 % 4;
+        if constexpr (k2 == 0) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) lds[hwq[i] + 2048 * 3] = fast_tanh_scaled(pend[i]);
+          if constexpr (KS1 < 2) {   // one layer-1 k step: h1 tiles are only now a segment old -- k step 0 prepared here, not overlapped
+#pragma unroll
+            for (int o = 0; o < 4; ++o) { issue_pair(0, o); split_pair(o, Bc); }
+          }
+        }
+        if constexpr (ks == 0) accq[T4] = bias16(b2q, T4);
+        if constexpr (ks + 1 < 16) { issue_pair(ks + 1, T4); __builtin_amdgcn_sched_barrier(0); }   // the next k step's B fragment: one pair per unit
+        CHAIN_UNITQ_A(Wr, k & 1, Bc, accq[T4], k + 1 < NOWN, nslot)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ks + 1 < 16) split_pair(T4, Bn);
+        CHAIN_UNITQ_B(Wr, k & 1, Bc, accq[T4])
+        if constexpr (ks + 1 < 16 && T4 == 3) Bc = Bn;
+      }
+    });
+    // every wave is done with the ring: its space beyond the first four units becomes the h2 image
+    CHAIN_BARRIER();
+    {  // h2 = tanh in the forward ownership -> image; back in the backward ownership (sixteen rows x all tiles per wave)
+#pragma unroll
+      for (int T4 = 0; T4 < 4; ++T4)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) lds[hwq[i] + (L::H2 - L::H1) + 2048 * T4] = fast_tanh_scaled(accq[T4][i]);
+      LDS_BARRIER();
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc2[t][i] = lds[hb1[i] + (L::H2 - L::H1) + 1024 * t];
+    }
+    STAMP(2)
+
+#else
     // ============================ forward: layer 1 and layer 2 as ONE stream of ring units ============================
     // unit u < NU1: layer 1, neuron tile u / K1, k step u % K1 (pack W1c, [tile][k step]: a tile is complete after K1 units, its
     // tanh goes to the h1 image under the next tile's MFMAs and its accumulator dies -- layer 1 holds four registers, not 64);
     // then layer 2, k step (u - NU1) / 16, neuron tile (u - NU1) % 16 (pack W2c), whose B fragments are this lane's own eight
     // elements of the h1 image, read back and split one k step ahead.
-    // per-wave bases of the DMAs, re-materialised per tile: the unit a wave moves is base + a compile-time constant (source and
-    // LDS destination alike), two scalar adds and one M0 write per unit instead of the multiply / shift chains of (8 q + 4 hh + wave)
-    const u32x4* w1w = opaque_sp(W1c_ + (size_t)wv * 192);
-    const u32x4* w2w = opaque_sp(W2c_ + (size_t)wv * 192);
-    const u32x4* w2bw = opaque_sp(((MOBROB_CHAIN_SKIP & 64) ? W2c_ : W2bc_) + (size_t)wv * 192);
-    const int ringw = opaque_s(L::RING + wv * CUNIT);
     auto fwd_issue = [&](int q) {   // DMAs of segment q: this wave moves units 8 q + wave and 8 q + 4 + wave
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
@@ -456,7 +594,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
     STAMP(18)
     fwd_issue(2);
     RingW Wr;
-    CHAIN_RING_PRIME(Wr)
+    Wr.p0[0] = ring_read_piece(ringl, 0, 0); Wr.p1 = ring_read_piece(ringl, 0, 1); Wr.p2 = ring_read_piece(ringl, 0, 2);
     X3Frag Bc, Bn;         // B fragment of the current / next layer-2 k step
     float hv[8];           // float32 elements of the B fragment being prepared
     SplitMid sm;           // a pair-split between its two halves
@@ -470,8 +608,8 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) hw[t] = ldg16(W.W3c, lane16 + 1024u * t);   // uniform base + per-lane 32-bit offset: no 64-bit pointer registers
       }
-      if constexpr ((u + CHAIN_AHEAD) % CSEG == 0 && u + CHAIN_AHEAD < NUF) {   // in front of the first READ of segment q (CHAIN_AHEAD units early)
-        constexpr int q = (u + CHAIN_AHEAD) / CSEG;
+      if constexpr ((u + 1) % CSEG == 0 && u + 1 < NUF) {
+        constexpr int q = (u + 1) / CSEG;
         CHAIN_WAIT_DMA(q + 1 < NSF);
         CHAIN_BARRIER();
         if constexpr (q + 2 < NSF) fwd_issue(q + 2);
@@ -480,7 +618,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
         constexpr int t = u / K1, ks = u % K1;
         if constexpr (ks == 0) c1 = cn;
         if constexpr (ks == K1 - 1 && t + 1 < 16) cn = *reinterpret_cast<const f32x4*>(&lds[L::B1 + 16 * (t + 1) + 4 * g]);
-        CHAIN_UNIT(Wr, u, xp[ks], c1, u + CHAIN_AHEAD < NUF, (u + CHAIN_AHEAD) % CSLOTS)
+        CHAIN_UNIT(Wr, u & 1, xp[ks], c1, u + 1 < NUF, (u + 1) % CSLOTS)
         if constexpr (t > 0 && ks == 0) {   // the previous tile: tanh -> h1 image
 #pragma unroll
           for (int i = 0; i < 4; ++i) lds[hb1[i] + 1024 * (t - 1)] = fast_tanh_scaled(pend[i]);
@@ -492,7 +630,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) lds[hb1[i] + 1024 * 15] = fast_tanh_scaled(pend[i]);
         }
-        CHAIN_UNIT(Wr, u, Bc, acc2[t], u + CHAIN_AHEAD < NUF, (u + CHAIN_AHEAD) % CSLOTS)
+        CHAIN_UNIT(Wr, u & 1, Bc, acc2[t], u + 1 < NUF, (u + 1) % CSLOTS)
       }
       // side work: the B fragment of layer-2 k step sn, prepared in the sixteen units in front of it (sn = 0: the last sixteen
       // units of layer 1, by which time tiles 0 and 1 of h1 are in the image): eight reads, then four pair-splits
@@ -517,6 +655,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
     CHAIN_BARRIER();
     STAMP(2)
 
+#endif
     // ============================ h2 = tanh, head (float32 16x16x4), loss, dout ============================
     int hb2[4];            // the same elements of the h2 / dz2 image (derived here: four registers that need not live through the ring phases)
 #pragma unroll
@@ -531,9 +670,13 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
         hw[t & 7] = t < 8 ? ldg16(W.W3c, lane16 + 1024u * (t + 8)) : ldg16(W.W3bc, lane16 + 1024u * (t - 8));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+#if MOBROB_CHAIN_Q
+          const float h = acc2[t][i];     // tanh was taken, and the h2 image written, in the forward ownership
+#else
           const float h = fast_tanh_scaled(acc2[t][i]);
           acc2[t][i] = h;
           lds[hb2[i] + 1024 * t] = h;
+#endif
           if (t & 1) mean2 = MFMA16(wv[i], h, mean2);
           else mean = MFMA16(wv[i], h, mean);
         }
@@ -760,19 +903,19 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
       CHAIN_BARRIER();
       STAMP(16)
       bwd_issue(2);
-      CHAIN_RING_PRIME(Wr)
+      Wr.p0[0] = ring_read_piece(ringl, 0, 0); Wr.p1 = ring_read_piece(ringl, 0, 1); Wr.p2 = ring_read_piece(ringl, 0, 2);
       static_for<0, NUB>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr ((u + CHAIN_AHEAD) % CSEG == 0 && u + CHAIN_AHEAD < NUB) {
-          constexpr int q = (u + CHAIN_AHEAD) / CSEG;
+        if constexpr ((u + 1) % CSEG == 0 && u + 1 < NUB) {
+          constexpr int q = (u + 1) / CSEG;
           CHAIN_WAIT_DMA(q + 1 < NSB);
           CHAIN_BARRIER();
           if constexpr (q + 2 < NSB) bwd_issue(q + 2);
         }
         constexpr int half = u / 64, ks = (u % 64) / 8, t8 = u % 8;
         if constexpr (ks == 0) acc4[t8] = f32x4{0.f, 0.f, 0.f, 0.f};
-        CHAIN_UNIT(Wr, u, Bd, acc4[t8], u + CHAIN_AHEAD < NUB, (u + CHAIN_AHEAD) % CSLOTS)
+        CHAIN_UNIT(Wr, u & 1, Bd, acc4[t8], u + 1 < NUB, (u + 1) % CSLOTS)
         constexpr int sn = (ks + 1) % 8;           // the next k step (the second pass starts over at 0)
         if constexpr (u + 1 < NUB) {               // its B fragment: pair jp in units 2 jp (first half) and 2 jp + 1 (second half) of this step
           constexpr int jp = t8 >> 1, e0 = 2 * jp, e1 = 2 * jp + 1;
@@ -976,10 +1119,17 @@ __global__ __launch_bounds__(256) void k_pack_chain(ChainPackArgs a) {
     const float w = a.W2[net][i];
     chain_store_w2(a.w2c[net], a.w2bc[net], n, k, kTanhScale * w, w);
   }
+#if MOBROB_CHAIN_Q
+  if (i < FH * a.Dp) {      // every k slot of the layer-1 pack (k steps of 16), padding included
+    const int n = i / a.Dp, k = i - n * a.Dp;
+    chain_store_w1(a.w1c[net], n, k, K1, k < a.D ? kTanhScale * a.W1[net][n * a.D + k] : 0.f, a.Dp);
+  }
+#else
   if (i < FH * 32 * K1) {   // every k slot of the layer-1 pack, padding included
     const int n = i / (32 * K1), k = i - n * (32 * K1);
-    chain_store_w1(a.w1c[net], n, k, K1, k < a.D ? kTanhScale * a.W1[net][n * a.D + k] : 0.f);
+    chain_store_w1(a.w1c[net], n, k, K1, k < a.D ? kTanhScale * a.W1[net][n * a.D + k] : 0.f, a.Dp);
   }
+#endif
   if (i < 16 * FH) {
     const int a_ = i / FH, k = i - a_ * FH;
     const float w = a_ < a.head[net] ? a.W3[net][a_ * FH + k] : 0.f;
