@@ -78,53 +78,23 @@ __host__ __device__ __forceinline__ int img_addr(int m, int row) { return m * 64
 // to the end, alternates between two registers by unit parity).  Every read is then issued 3 .. 6 MFMAs (48 .. 96 cycles) before
 // the MFMA that needs it: with all three pieces read in one burst late in the unit (the first version) every unit started with
 // an LDS wait.  Magnitudes: (2,0) (1,1) ~2^-16, (1,0) ~2^-8, (0,2) ~2^-16, (0,1) ~2^-8, (0,0) ~1 of the product.
-#ifndef MOBROB_CHAIN_AHEAD2
-#define MOBROB_CHAIN_AHEAD2 1
-#endif
-#if MOBROB_CHAIN_AHEAD2
-// Pieces are read TWO units ahead of their use (the LDS answers a read in 200-300 cycles while four waves and the ring's DMA writes
-// load it; a unit is ~150): piece 0 rotates through three registers, pieces 1 and 2 through two each.
-struct RingW { u32x4 p0[3], p1[2], p2[2]; };
-#else
 struct RingW { u32x4 p0[2], p1, p2; };
-#endif
 __device__ __forceinline__ u32x4 ring_read_piece(int ring_lane_f0, int slot, int pc) {
   return *reinterpret_cast<const u32x4*>(&lds[ring_lane_f0 + slot * CUNIT + 256 * pc]);
 }
 // (Scheduling barriers behind the second and third read -- the scheduler otherwise issues the three reads together behind the third
 //  MFMA, 48 cycles before the next unit needs the first -- were measured twice (after every MFMA, and behind the two reads only): layer 2 19.0 k -> 19.8 k
 //  cycles, launch +1.3 %.  The reads stay where the scheduler puts them.)
-#if MOBROB_CHAIN_AHEAD2
-// u: the unit's index in its stream (compile time); have2 / slot2: whether unit u + 2 exists, and its ring slot
-#define CHAIN_UNIT(Wr, u_, X_, C_, have2, slot2)                                             \
-  if (have2) Wr.p0[((u_) + 2) % 3] = ring_read_piece(ringl, slot2, 0);                       \
-  C_ = MFMA16B(Wr.p2[(u_) & 1], X_.p[0], C_);                                                \
-  if (have2) Wr.p2[(u_) & 1] = ring_read_piece(ringl, slot2, 2);                             \
-  C_ = MFMA16B(Wr.p1[(u_) & 1], X_.p[1], C_);                                                \
-  C_ = MFMA16B(Wr.p1[(u_) & 1], X_.p[0], C_);                                                \
-  if (have2) Wr.p1[(u_) & 1] = ring_read_piece(ringl, slot2, 1);                             \
-  C_ = MFMA16B(Wr.p0[(u_) % 3], X_.p[2], C_);                                                \
-  C_ = MFMA16B(Wr.p0[(u_) % 3], X_.p[1], C_);                                                \
-  C_ = MFMA16B(Wr.p0[(u_) % 3], X_.p[0], C_);
-#define CHAIN_RING_PRIME(Wr)                                                                                             \
-  Wr.p0[0] = ring_read_piece(ringl, 0, 0); Wr.p1[0] = ring_read_piece(ringl, 0, 1); Wr.p2[0] = ring_read_piece(ringl, 0, 2); \
-  Wr.p0[1] = ring_read_piece(ringl, 1, 0); Wr.p1[1] = ring_read_piece(ringl, 1, 1); Wr.p2[1] = ring_read_piece(ringl, 1, 2);
-#define CHAIN_AHEAD 2
-#else
-#define CHAIN_UNIT(Wr, u_, X_, C_, have_next, nslot)                                         \
-  if (have_next) Wr.p0[((u_) & 1) ^ 1] = ring_read_piece(ringl, nslot, 0);                   \
+#define CHAIN_UNIT(Wr, par, X_, C_, have_next, nslot)                                        \
+  if (have_next) Wr.p0[(par) ^ 1] = ring_read_piece(ringl, nslot, 0);                        \
   C_ = MFMA16B(Wr.p2, X_.p[0], C_);                                                          \
   if (have_next) Wr.p2 = ring_read_piece(ringl, nslot, 2);                                   \
   C_ = MFMA16B(Wr.p1, X_.p[1], C_);                                                          \
   C_ = MFMA16B(Wr.p1, X_.p[0], C_);                                                          \
   if (have_next) Wr.p1 = ring_read_piece(ringl, nslot, 1);                                   \
-  C_ = MFMA16B(Wr.p0[(u_) & 1], X_.p[2], C_);                                                \
-  C_ = MFMA16B(Wr.p0[(u_) & 1], X_.p[1], C_);                                                \
-  C_ = MFMA16B(Wr.p0[(u_) & 1], X_.p[0], C_);
-#define CHAIN_RING_PRIME(Wr) \
-  Wr.p0[0] = ring_read_piece(ringl, 0, 0); Wr.p1 = ring_read_piece(ringl, 0, 1); Wr.p2 = ring_read_piece(ringl, 0, 2);
-#define CHAIN_AHEAD 1
-#endif
+  C_ = MFMA16B(Wr.p0[par], X_.p[2], C_);                                                     \
+  C_ = MFMA16B(Wr.p0[par], X_.p[1], C_);                                                     \
+  C_ = MFMA16B(Wr.p0[par], X_.p[0], C_);
 
 // LDS-DMA of 1 KB: lane l's 16 bytes at sbase + voff land at LDS byte address lds_byte + 16 l.  Issued as inline asm: the
 // compiler knows nothing of it (no conservative vmcnt(0) in front of every ring read); the ring protocol below waits by hand.
@@ -456,7 +426,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
     STAMP(18)
     fwd_issue(2);
     RingW Wr;
-    CHAIN_RING_PRIME(Wr)
+    Wr.p0[0] = ring_read_piece(ringl, 0, 0); Wr.p1 = ring_read_piece(ringl, 0, 1); Wr.p2 = ring_read_piece(ringl, 0, 2);
     X3Frag Bc, Bn;         // B fragment of the current / next layer-2 k step
     float hv[8];           // float32 elements of the B fragment being prepared
     SplitMid sm;           // a pair-split between its two halves
@@ -470,8 +440,8 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) hw[t] = ldg16(W.W3c, lane16 + 1024u * t);   // uniform base + per-lane 32-bit offset: no 64-bit pointer registers
       }
-      if constexpr ((u + CHAIN_AHEAD) % CSEG == 0 && u + CHAIN_AHEAD < NUF) {   // in front of the first READ of segment q (CHAIN_AHEAD units early)
-        constexpr int q = (u + CHAIN_AHEAD) / CSEG;
+      if constexpr ((u + 1) % CSEG == 0 && u + 1 < NUF) {
+        constexpr int q = (u + 1) / CSEG;
         CHAIN_WAIT_DMA(q + 1 < NSF);
         CHAIN_BARRIER();
         if constexpr (q + 2 < NSF) fwd_issue(q + 2);
@@ -480,7 +450,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
         constexpr int t = u / K1, ks = u % K1;
         if constexpr (ks == 0) c1 = cn;
         if constexpr (ks == K1 - 1 && t + 1 < 16) cn = *reinterpret_cast<const f32x4*>(&lds[L::B1 + 16 * (t + 1) + 4 * g]);
-        CHAIN_UNIT(Wr, u, xp[ks], c1, u + CHAIN_AHEAD < NUF, (u + CHAIN_AHEAD) % CSLOTS)
+        CHAIN_UNIT(Wr, u & 1, xp[ks], c1, u + 1 < NUF, (u + 1) % CSLOTS)
         if constexpr (t > 0 && ks == 0) {   // the previous tile: tanh -> h1 image
 #pragma unroll
           for (int i = 0; i < 4; ++i) lds[hb1[i] + 1024 * (t - 1)] = fast_tanh_scaled(pend[i]);
@@ -492,7 +462,7 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) lds[hb1[i] + 1024 * 15] = fast_tanh_scaled(pend[i]);
         }
-        CHAIN_UNIT(Wr, u, Bc, acc2[t], u + CHAIN_AHEAD < NUF, (u + CHAIN_AHEAD) % CSLOTS)
+        CHAIN_UNIT(Wr, u & 1, Bc, acc2[t], u + 1 < NUF, (u + 1) % CSLOTS)
       }
       // side work: the B fragment of layer-2 k step sn, prepared in the sixteen units in front of it (sn = 0: the last sixteen
       // units of layer 1, by which time tiles 0 and 1 of h1 are in the image): eight reads, then four pair-splits
@@ -760,19 +730,19 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
       CHAIN_BARRIER();
       STAMP(16)
       bwd_issue(2);
-      CHAIN_RING_PRIME(Wr)
+      Wr.p0[0] = ring_read_piece(ringl, 0, 0); Wr.p1 = ring_read_piece(ringl, 0, 1); Wr.p2 = ring_read_piece(ringl, 0, 2);
       static_for<0, NUB>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr ((u + CHAIN_AHEAD) % CSEG == 0 && u + CHAIN_AHEAD < NUB) {
-          constexpr int q = (u + CHAIN_AHEAD) / CSEG;
+        if constexpr ((u + 1) % CSEG == 0 && u + 1 < NUB) {
+          constexpr int q = (u + 1) / CSEG;
           CHAIN_WAIT_DMA(q + 1 < NSB);
           CHAIN_BARRIER();
           if constexpr (q + 2 < NSB) bwd_issue(q + 2);
         }
         constexpr int half = u / 64, ks = (u % 64) / 8, t8 = u % 8;
         if constexpr (ks == 0) acc4[t8] = f32x4{0.f, 0.f, 0.f, 0.f};
-        CHAIN_UNIT(Wr, u, Bd, acc4[t8], u + CHAIN_AHEAD < NUB, (u + CHAIN_AHEAD) % CSLOTS)
+        CHAIN_UNIT(Wr, u & 1, Bd, acc4[t8], u + 1 < NUB, (u + 1) % CSLOTS)
         constexpr int sn = (ks + 1) % 8;           // the next k step (the second pass starts over at 0)
         if constexpr (u + 1 < NUB) {               // its B fragment: pair jp in units 2 jp (first half) and 2 jp + 1 (second half) of this step
           constexpr int jp = t8 >> 1, e0 = 2 * jp, e1 = 2 * jp + 1;
