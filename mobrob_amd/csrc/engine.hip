@@ -93,8 +93,7 @@ struct ProfSpan {
 // action head, value head.  With one to three hidden layers per network that is 9 .. 17 tensors; the ids are the engine's
 // (engine_dims), the names below resolve through `e`.  Two hidden layers per network give the numbering 0 .. 12 the fused
 // kernels' argument structs were written for.
-constexpr int kMaxHidden = 3;
-constexpr int kMaxTensors = 1 + 4 * kMaxHidden + 4;   // 17
+// (kMaxHidden = 3, kMaxTensors = 17: kernels_fused.h)
 #define T_LOGSTD 0
 #define T_PW1 (e->tPW[0])
 #define T_PB1 (e->tPB[0])

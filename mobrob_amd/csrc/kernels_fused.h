@@ -2079,13 +2079,16 @@ __global__ __launch_bounds__(256) void k_sqnorm_chunks(const float* __restrict__
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// tensors of a policy: log_std, (W, b) of one to three hidden layers per network, the two heads (engine.hip keeps the table)
+constexpr int kMaxHidden = 3;
+constexpr int kMaxTensors = 1 + 4 * kMaxHidden + 4;   // 17
 struct AdamPackArgs {
   float* p; const float* g; float* m; float* v; int P;
   float* g_out;  // the same vector, writable (persistent small-batch kernel: it produces the gradient itself)
   const NormChunk* chunks; const double* partial; int nchunks;
-  const int* fold_idx; int fold_start[18];  // non-null: `partial` is a record table; tensor t folds partial[fold_idx[k]], k in [fold_start[t], fold_start[t+1])
+  const int* fold_idx; int fold_start[kMaxTensors + 1];  // non-null: `partial` is a record table; tensor t folds partial[fold_idx[k]], k in [fold_start[t], fold_start[t+1])
   float max_norm, step_size, bc2_sqrt, beta1, beta2, eps;
-  int offs[18];    // canonical offsets of the engine's ntens tensors (9 .. 17: one to three hidden layers per network), padded with P
+  int offs[kMaxTensors + 1];    // canonical offsets of the engine's ntens tensors (9 .. 17: one to three hidden layers per network), padded with P
   int ntens;       // 9 .. 17
   int two_by_two;  // two hidden layers in BOTH networks: tensor numbering 0 .. 12, the one the fused cases below are written for
                    // (1 + 3 layers also make thirteen tensors)
@@ -2184,7 +2187,7 @@ __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, fl
 #endif
   int t = 0;
 #pragma unroll
-  for (int k = 1; k < 17; ++k) t += (i >= a.offs[k]) ? 1 : 0;   // (offsets beyond the engine's tensors equal P)
+  for (int k = 1; k < kMaxTensors; ++k) t += (i >= a.offs[k]) ? 1 : 0;   // (offsets beyond the engine's tensors equal P)
   const int e = i - a.offs[t];
   if (!a.two_by_two) {  // other depths than two hidden layers: the generic GEMM chain's zero-padded copies only (no fused packs exist)
     if (t == a.id_pw1 || t == a.id_vw1) {
@@ -2234,7 +2237,7 @@ __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, fl
 __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
   __shared__ double part[1024];
   __shared__ int tens[256];
-  __shared__ float nts[20];
+  __shared__ float nts[kMaxTensors + 3];
   __shared__ float coef_s, total_s;
   // this thread's four operands are requested first: their memory latency runs under the norm fold below
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
