@@ -98,6 +98,12 @@ __device__ __forceinline__ u32x4 ring_read_piece(int ring_lane_f0, int slot, int
 
 // LDS-DMA of 1 KB: lane l's 16 bytes at sbase + voff land at LDS byte address lds_byte + 16 l.  Issued as inline asm: the
 // compiler knows nothing of it (no conservative vmcnt(0) in front of every ring read); the ring protocol below waits by hand.
+// The six DMA instructions a wave owes a ring segment go out ONE PER UNIT behind the segment's barrier, not as a burst of six right
+// behind it (an LDS-DMA costs its wave 60 - 180 cycles of issue inside a busy phase; spread, most of that falls into MFMA shadows):
+// launch -1.9 .. -2.8 % on four of four boxes (profiles/r4/chain_l2.txt).  0: the burst form.
+#ifndef MOBROB_CHAIN_SPREAD
+#define MOBROB_CHAIN_SPREAD 1
+#endif
 #ifndef MOBROB_CHAIN_SKIP     // timing-only ablation builds (outputs wrong by construction; never in the product library)
 #define MOBROB_CHAIN_SKIP 0
 #endif
@@ -114,6 +120,13 @@ __device__ __forceinline__ void dma_unit(const u32x4* src, int slot, unsigned la
                "global_load_lds_dwordx4 %1, %2\n\t"
                "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
                "global_load_lds_dwordx4 %1, %2 offset:2048" ::"s"(dst), "v"(lane16), "s"(src) : "memory", "m0");
+}
+// one PIECE (1 KB) of a ring unit: for the spread issue (MOBROB_CHAIN_SPREAD), one DMA instruction per unit of the stream instead of six in
+// a burst behind the segment barrier
+__device__ __forceinline__ void dma_piece(const u32x4* src, int slot, int pc, unsigned lane16, int ring_f0) {
+  if (MOBROB_CHAIN_SKIP & 1) return;
+  const unsigned dst = (unsigned)(ring_f0 + slot * CUNIT + 256 * pc) * 4u;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(lane16), "s"(src + 64 * pc) : "memory", "m0");
 }
 __device__ __forceinline__ X3Frag ring_read(int ring_lane_f0, int slot) {  // ring_lane_f0 = RING + 4 lane (opaque per-lane base)
   X3Frag f;
@@ -444,7 +457,15 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
         constexpr int q = (u + 1) / CSEG;
         CHAIN_WAIT_DMA(q + 1 < NSF);
         CHAIN_BARRIER();
-        if constexpr (q + 2 < NSF) fwd_issue(q + 2);
+        if constexpr (!MOBROB_CHAIN_SPREAD && q + 2 < NSF) fwd_issue(q + 2);
+      }
+      if constexpr (MOBROB_CHAIN_SPREAD && u >= CSEG - 1) {   // piece i of segment q + 2 behind unit 8 q - 1 + i (i = 0 .. 5): after barrier q
+        constexpr int q = (u + 1) / CSEG, i = (u + 1) % CSEG;
+        if constexpr (i < 6 && q + 2 < NSF) {
+          constexpr int u0 = CSEG * (q + 2) + 4 * (i / 3);
+          const u32x4* src = (CSEG * (q + 2) < NU1) ? w1w + (size_t)u0 * 192 : w2w + (size_t)(u0 - NU1) * 192;
+          dma_piece(src, u0 % CSLOTS, i % 3, lane16, ringw);
+        }
       }
       if constexpr (u < NU1) {
         constexpr int t = u / K1, ks = u % K1;
@@ -738,7 +759,14 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
           constexpr int q = (u + 1) / CSEG;
           CHAIN_WAIT_DMA(q + 1 < NSB);
           CHAIN_BARRIER();
-          if constexpr (q + 2 < NSB) bwd_issue(q + 2);
+          if constexpr (!MOBROB_CHAIN_SPREAD && q + 2 < NSB) bwd_issue(q + 2);
+        }
+        if constexpr (MOBROB_CHAIN_SPREAD && u >= CSEG - 1) {
+          constexpr int q = (u + 1) / CSEG, i = (u + 1) % CSEG;
+          if constexpr (i < 6 && q + 2 < NSB) {
+            constexpr int u0 = CSEG * (q + 2) + 4 * (i / 3);
+            dma_piece(w2bw + (size_t)u0 * 192, u0 % CSLOTS, i % 3, lane16, ringw);
+          }
         }
         constexpr int half = u / 64, ks = (u % 64) / 8, t8 = u % 8;
         if constexpr (ks == 0) acc4[t8] = f32x4{0.f, 0.f, 0.f, 0.f};
