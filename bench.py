@@ -56,6 +56,11 @@ def f_fwd(D, H, A):
     return 2 * (2 * D * H + 2 * H * H + H * A + H)
 
 
+def executed_flops_per_sample(D, H, A):
+    """forward + backward of both networks without the layer-1 input gradient (nothing consumes d loss / d obs)"""
+    return 3.0 * f_fwd(D, H, A) - 2 * (2 * D * H)
+
+
 def init_params(D, A, H, seed):
     """Orthogonal init with SB3 gains (random-init weights of the named architecture)."""
     from mobrob_amd.rl_control.init import orthogonal_policy_init
@@ -262,7 +267,7 @@ def dominant_kernel_name(H, rows_per_launch, generic, x3_train=False, chain=Fals
 def measured_traffic(kernel_prefix):
     """(bytes per launch | None, note): PMC-counted HBM traffic of the dominant kernel from the newest committed
     profile -- only if that profile was taken on exactly these kernel sources; otherwise None (never a stale figure)."""
-    for rnd in ("r4", "r3", "r2", "r1"):
+    for rnd in ("r5", "r4", "r3", "r2", "r1"):
         tj = os.path.join(ROOT, "profiles", rnd, "hbm_traffic_pmc.json")
         if not os.path.exists(tj):
             continue
@@ -714,7 +719,11 @@ def bench_single(args, name, steps, warmup, job, phases):
                                        f"the kernel would read {achieved / PEAK_F32_MFMA_TFLOPS:.3f}" if x3_train else
                                        "every matrix product on v_mfma_f32 (peak 157.3 TFLOP/s)"),
                          "avg_launch_ms": ms / max(calls, 1), "launches": calls,
-                         "flops_per_launch": flops_per_launch},
+                         "flops_per_launch": flops_per_launch,
+                         # the flops the kernel must EXECUTE: BASELINE.md's 3 F_fwd convention counts a layer-1 dX = dz1 . W1 that PPO
+                         # never needs (2 networks x 2 D H per sample); `achieved` / `frac` keep the convention
+                         "executed_flops_per_launch": executed_flops_per_sample(D, H, A) * (float(N) * T * E * steps) / max(calls, 1),
+                         "executed_frac": (executed_flops_per_sample(D, H, A) / (3.0 * f_fwd(D, H, A))) * achieved / peak},
             "phases_bracketed": "all" if phases else ("dominant kernel + all-reduces" if use_dp else "dominant kernel only"),
             "phase_ms_per_step": {k: v[0] / steps for k, v in prof.items() if v[1] > 0},
         }
@@ -724,6 +733,8 @@ def bench_single(args, name, steps, warmup, job, phases):
                                       "advantage_statistics_message": nmb * 4 * 8}
             out["replicas_bit_identical"] = identical
             out["config"]["exchange"] = exchange
+            out["exchange"] = chosen          # "rccl" | "oneshot" | "torch.distributed" | "gloo-callback": read against DESIGN.md §5's table
+            out["allreduce_ms_per_step"] = out["phase_ms_per_step"].get("allreduce")
             out["exchange_selfcheck"] = getattr(backend, "exchange_selfcheck", {}) or {"note": "no engine-owned exchange to check (host-staged callback)"}
         if job.same_device:
             out["rehearsal"] = {"what": f"{world} ranks time-sharing ONE GPU (MOBROB_DP_SAME_DEVICE=1): gloo process group, the C "
@@ -735,6 +746,156 @@ def bench_single(args, name, steps, warmup, job, phases):
         backend.close()       # one-shot exchange: no rank unmaps its buffer while a peer may still read it
     eng.close()
     return out
+
+
+def host_path_measurements(args, job):
+    """north_star's own data path in front of the driver: host-core environments -> pinned staging -> GPU policy ->
+    actions back, at the headline shape (doggo 58 / 12, 4096 envs, 2x256).  Reference: the VecEnv loop SB3 drives through
+    /root/reference/src/mobrob/rl_control/ppo.py:30-48 over EnvWrapper.step (/root/reference/src/mobrob/envs/wrapper.py:156-201).
+
+    Three numbers per collector, per vector step of all environments, so that collector overhead is a figure, not a guess:
+      host_sim_alone   the environments stepped with fixed actions, no GPU work
+      gpu_alone        act + store on static staging buffers, no environment stepped
+      pipelined        the collector as it runs (mobrob_ppo_collect_host for the native env, PPO's part pipeline for ShmVecEnv)
+    and, for the native env, the `host_parts` sweep 1 / 2 / 4 / 8 plus the whole iteration (rollout + update) at the best setting."""
+    import copy
+    import torch
+    from mobrob_amd.engine import PPOEngine
+    from mobrob_amd.envs.native_env import NativeGoalVecEnv
+    res = {}
+    w = WORKLOADS["doggo-4096env-2x256-hostenv"]
+    D, A, H, N, T, E, B = w["D"], w["A"], w["H"], w["N"], w["T"], w["E"], w["B"]
+
+    def timed(fn, sync):
+        sync()
+        t0 = time.perf_counter()
+        fn()
+        sync()
+        return time.perf_counter() - t0
+
+    # ---- (1) native C env (csrc/host_env.c, OpenMP), pinned zero-copy staging ----
+    try:
+        eng = PPOEngine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H), ent_coef=0.01,
+                        seed=0, device_id=job.device_id)
+        eng.set_params(init_params(D, A, H, seed=0))
+        host = NativeGoalVecEnv.for_robot(w["host_env"], N, time_limit=w["tl"], seed=0)
+        hb = dict(obs=eng.pinned((N, D)), clip=eng.pinned((N, A)), rew=eng.pinned((N,)), done=eng.pinned((N,), np.uint8),
+                  trunc=eng.pinned((N,), np.uint8), term=eng.pinned((N, D)))
+        host.use_buffers(obs=hb["obs"], rewards=hb["rew"], dones=hb["done"], truncated=hb["trunc"], terminal_obs=hb["term"])
+        host.reset()
+        sync = eng.synchronize
+
+        rng = np.random.default_rng(0)
+        pool = [np.ascontiguousarray(rng.uniform(-1, 1, (N, A)), np.float32) for _ in range(16)]   # the sim legs step on varied actions
+
+        def sim_alone():
+            for t in range(T):
+                hb["clip"][:] = pool[t & 15]
+                host.step_arrays(hb["clip"])
+
+        def gpu_alone():
+            eng.rollout_begin()
+            for _ in range(T):
+                eng.act(hb["obs"], out_clipped=hb["clip"], want_all=False)
+                eng.store(hb["rew"], hb["done"], None, None)
+            eng.finish_rollout(hb["obs"], hb["done"])
+
+        def collector(parts):
+            def run():
+                eng.rollout_begin()
+                if parts > 1:
+                    pipe = eng.part_pipeline(parts, hb["obs"], hb["clip"], hb["rew"], hb["done"], hb["trunc"], hb["term"])
+                    pipe.collect(host.step_range_fn, host.handle)      # the whole loop in one native call, finish_rollout included
+                else:
+                    for _ in range(T):
+                        eng.act(hb["obs"], out_clipped=hb["clip"], want_all=False)
+                        nt = host.step_arrays(hb["clip"])[5]
+                        eng.store(hb["rew"], hb["done"], hb["trunc"] if nt else None, hb["term"] if nt else None)
+                    eng.finish_rollout(hb["obs"], hb["done"])
+            return run
+        gpu_alone()                                            # warm-up (first launches, pinned mappings)
+        t_sim = min(timed(sim_alone, sync) for _ in range(2))
+        t_gpu = min(timed(gpu_alone, sync) for _ in range(2))
+        sweep = {}
+        for parts in (1, 2, 4, 8):
+            run = collector(parts)
+            run()
+            sweep[parts] = min(timed(run, sync) for _ in range(2))
+        best = min(sweep, key=sweep.get)
+        us = lambda t: 1e6 * t / T   # noqa: E731 - microseconds per vector step of N environments
+        res["native-c-env (csrc/host_env.c), pinned zero-copy, mobrob_ppo_collect_host"] = {
+            "envs": N, "steps_per_rollout": T, "env_threads": host.threads,
+            "us_per_vector_step": {"host_sim_alone": us(t_sim), "gpu_act_store_alone": us(t_gpu),
+                                   "pipelined": {f"host_parts={k}" + (" (Python loop, whole batch per step)" if k == 1 else ""): us(v)
+                                                 for k, v in sweep.items()}},
+            "collector_overhead_us_per_step": us(sweep[best]) - max(us(t_sim), us(t_gpu)),
+            "rollout_only_env_steps_per_s": N * T / sweep[best], "best_host_parts": best,
+            "note": "overhead = pipelined wall minus the longer of its two legs: what the hand-off itself costs once sim and policy overlap",
+        }
+        host.close()
+        eng.close()
+        a2 = copy.copy(args)
+        a2.host_parts = best
+        o = bench_single(a2, "doggo-4096env-2x256-hostenv", 2, 1, job, False)
+        res["doggo-4096env-2x256-hostenv"] = {
+            "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": 2, "warmup": 1, "host_parts": best,
+            "what": "whole PPO iteration (host rollout + GAE + all epochs) with the environments on the host: the PCIe-inclusive rate, never the headline value",
+            "roofline": {k: o["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches")}}
+    except Exception as ex:  # noqa: BLE001 - a side measurement must not take the headline line down
+        res["native-c-env"] = {"error": f"{type(ex).__name__}: {ex}"}
+
+    # ---- (2) ShmVecEnv (`vec_env_type: subproc`): Python EnvWrapper instances in worker processes over a GPU-registered block ----
+    try:
+        from mobrob_amd.rl_control.ppo import PPOCtrl, BaseCallback
+        Ts = 32                                              # a bounded sample: 4096 Python envs take milliseconds per vector step
+        cfg = {"ppo_kwargs": {"policy": "MlpPolicy", "n_steps": Ts, "batch_size": B, "n_epochs": E, "gamma": 0.99, "gae_lambda": 0.95,
+                              "ent_coef": 0.01, "clip_range": 0.2, "policy_kwargs": {"net_arch": {"pi": [H, H], "vf": [H, H]}}},
+               "env_name": "doggo", "time_limit": w["tl"], "n_envs": N, "vec_env_type": "subproc", "enable_gui": False, "seed": 0}
+        ppo = PPOCtrl.from_config(cfg).ppo
+        env, e2 = ppo.env, ppo.engine
+        ppo.learn(total_timesteps=N * Ts)                   # warm-up iteration: staging registered, workers running
+        b = ppo._host_bufs
+        cb = BaseCallback()
+        cb.init_callback(ppo)
+
+        rng = np.random.default_rng(0)
+        pool = [np.ascontiguousarray(rng.uniform(-1, 1, (N, A)), np.float32) for _ in range(16)]
+        parts2 = ppo.host_parts
+        bounds = [(N * q // parts2, N * (q + 1) // parts2) for q in range(parts2)]
+
+        def shm_sim():   # the same commands the pipelined collector sends (one per row range), no GPU work between them
+            for t in range(Ts):
+                b["clip"][:] = pool[t & 15]
+                for i0, i1 in bounds:
+                    env.step_range(i0, i1, b["clip"])
+
+        def shm_gpu():
+            e2.rollout_begin()
+            for _ in range(Ts):
+                e2.act(b["obs"], out_clipped=b["clip"], want_all=False)
+                e2.store(b["rew"], b["done"], None, None)
+            e2.finish_rollout(b["obs"], b["done"])
+        t_sim = min(timed(shm_sim, e2.synchronize) for _ in range(2))
+        t_gpu = min(timed(shm_gpu, e2.synchronize) for _ in range(2))
+        t_pipe = min(timed(lambda: ppo._collect_rollouts(cb), e2.synchronize) for _ in range(2))
+        t0 = time.perf_counter()
+        ppo.learn(total_timesteps=2 * N * Ts, reset_num_timesteps=False)
+        e2.synchronize()
+        t_learn = (time.perf_counter() - t0) / 2
+        us2 = lambda t: 1e6 * t / Ts   # noqa: E731
+        res["ShmVecEnv (vec_env_type: subproc), 4096 Python EnvWrapper instances"] = {
+            "envs": N, "steps_per_rollout": Ts, "workers": getattr(env, "n_workers", None), "host_parts": ppo.host_parts,
+            "us_per_vector_step": {"host_sim_alone": us2(t_sim), "gpu_act_store_alone": us2(t_gpu), "pipelined": us2(t_pipe)},
+            "collector_overhead_us_per_step": us2(t_pipe) - max(us2(t_sim), us2(t_gpu)),
+            "rollout_only_env_steps_per_s": N * Ts / t_pipe,
+            "learn_env_steps_per_s": N * Ts / t_learn,
+            "note": "kinematic stand-in behind the EnvWrapper surface (no MuJoCo / Bullet on the box); bounded sample of 32 vector steps per rollout",
+        }
+        env.close()
+        e2.close()
+    except Exception as ex:  # noqa: BLE001
+        res["ShmVecEnv"] = {"error": f"{type(ex).__name__}: {ex}"}
+    return res
 
 
 def also_measured(args, job):
@@ -761,6 +922,8 @@ def also_measured(args, job):
             "roofline": {k: o["roofline"][k] for k in ("kernel", "achieved", "peak", "frac", "avg_launch_ms", "launches")}}
     except Exception as ex:  # noqa: BLE001
         res["doggo-4096env-2x256, forward_x3 off (all products on v_mfma_f32)"] = {"error": f"{type(ex).__name__}: {ex}"}
+    if not getattr(args, "no_host_path", False):
+        res["host_env_streaming_path"] = host_path_measurements(args, job)
     return res
 
 
@@ -780,6 +943,8 @@ def main():
     ap.add_argument("--workload", default="doggo-4096env-2x256", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the also_measured side configurations")
+    ap.add_argument("--no-host-path", action="store_true", help="also_measured: skip the host-env streaming path (native C env, ShmVecEnv)")
+    ap.add_argument("--only-host-path", action="store_true", help="print only the host-env streaming-path measurements (one JSON line)")
     ap.add_argument("--generic", action="store_true", help="force the generic (unfused) kernels")
     ap.add_argument("--f32-pipe", action="store_true",
                     help="forward_x3 off: every matrix product on v_mfma_f32 (default: the forward passes of 256-wide nets run as six "
@@ -826,6 +991,11 @@ def main():
         __graft_entry__.build()
     job.barrier()
 
+    if args.only_host_path:
+        if rank == 0:
+            emit({"host_env_streaming_path": host_path_measurements(args, job)})
+        job.finish()
+        return
     fn = bench_fleet if "segments" in w else bench_single
     out = fn(args, args.workload, args.steps, args.warmup, job, args.phases)
     if rank == 0:

@@ -296,9 +296,12 @@ int mobrob_ppo_train_dp(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_all
 int mobrob_ppo_oneshot_export(mobrob_ppo_engine_t* e, uint8_t* handle64);
 int mobrob_ppo_oneshot_open(mobrob_ppo_engine_t* e, const uint8_t* handles, int32_t rank, int32_t nranks);
 int mobrob_ppo_oneshot_close(mobrob_ppo_engine_t* e);
-/* A known vector through the exchange train_dp would use, compared with the rank-ordered sum: run at communicator set-up (collective),
- * before any gradient depends on the exchange.  which: 0 = the engine's RCCL communicator, 1 = the one-shot exchange.
- * *mismatches = elements of the [P + 8]-float message that are not bit-equal to the expected sum; 0 = sound.  The reference has one
+/* Known vectors through the exchange train_dp would use, compared with the rank-ordered sums: run at communicator set-up (collective),
+ * before any gradient depends on the exchange.  which: 0 = the engine's RCCL communicator, 1 = the one-shot exchange.  Four
+ * messages: the [P + 8]-float gradient message twice and the [n_minibatches][4]-double advantage message twice (both payload slots
+ * of the one-shot exchange, slot reuse, both element types), on a scratch buffer of the call's own; MOBROB_ERR_STATE while an
+ * epoch is open or a gradient awaits its apply.
+ * *mismatches = elements over the four messages that are not bit-equal to the expected sum; 0 = sound.  The reference has one
  * exchange path and trusts it (SubprocVecEnv pipes, /root/reference/src/mobrob/rl_control/ppo.py:30-33); here a peer-mapped
  * exchange is used on real peers only after it has passed, RCCL otherwise (mobrob_amd/parallel.py). */
 int mobrob_ppo_exchange_selfcheck(mobrob_ppo_engine_t* e, int32_t which, int32_t* mismatches);

@@ -1745,16 +1745,10 @@ int mobrob_ppo_epoch_begin(mobrob_ppo_engine_t* e, const int64_t* perm) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   if (!e->rollout_ready) return fail(MOBROB_ERR_STATE, "epoch_begin: rollout not finished (finish_rollout / collect first)");
   const int total = e->N * e->T;
-  ensure_train_records(e);
-  AdvStatArgs as{};
-  as.adv = e->adv; as.total = total; as.T = e->T; as.N = e->N; as.bl = e->Bl; as.nmb = e->nmb;
-  as.bins = e->advbins;
-  unsigned* maxw = reinterpret_cast<unsigned*>(e->advbins + (size_t)2 * e->nmb);  // two words, used alternately
-  as.absmax_bits = maxw + (e->adv_pass & 1); as.absmax_next = maxw + ((e->adv_pass + 1) & 1);
-  e->adv_pass++;
   if (perm) {
     // a caller's permutation is checked before a kernel scatters through it (k_perm_from_host writes rows[] and the
-    // minibatch-of-row table at the indices it holds): every flat index once, none out of range
+    // minibatch-of-row table at the indices it holds): every flat index once, none out of range.  FIRST, before any engine
+    // state moves (the parity of the max-|adv| words below, the training records): a rejected call leaves nothing behind.
     std::vector<uint64_t> seen(((size_t)total + 63) / 64, 0);
     for (int i = 0; i < total; ++i) {
       const int64_t v = perm[i];
@@ -1764,6 +1758,15 @@ int mobrob_ppo_epoch_begin(mobrob_ppo_engine_t* e, const int64_t* perm) {
       if (w & bit) return fail(MOBROB_ERR_INVALID, "epoch_begin: perm holds index %lld twice (not a permutation of [0, %d))", (long long)v, total);
       w |= bit;
     }
+  }
+  ensure_train_records(e);
+  AdvStatArgs as{};
+  as.adv = e->adv; as.total = total; as.T = e->T; as.N = e->N; as.bl = e->Bl; as.nmb = e->nmb;
+  as.bins = e->advbins;
+  unsigned* maxw = reinterpret_cast<unsigned*>(e->advbins + (size_t)2 * e->nmb);  // two words, used alternately
+  as.absmax_bits = maxw + (e->adv_pass & 1); as.absmax_next = maxw + ((e->adv_pass + 1) & 1);
+  e->adv_pass++;
+  if (perm) {
     HIPC(hipMemcpyAsync(e->perm_dev, perm, (size_t)total * 8, hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(k_perm_from_host, dim3(cdiv(total, 256)), dim3(256), 0, e->stream, e->perm_dev, total, e->T,
                        e->N, e->Bl, e->rows);
@@ -2281,31 +2284,43 @@ int mobrob_ppo_train_dp(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_all
   return MOBROB_OK;
 }
 
+extern "C++" {   // templates: C++ linkage inside the C-ABI block
 namespace {
-// exchange self-check (mobrob_ppo_exchange_selfcheck): small integers -- every partial sum is exact in float32 whatever the order
-__device__ __forceinline__ float selfcheck_value(unsigned i, int rank) {
-  const unsigned hsh = (i * 2654435761u + (unsigned)(rank + 1) * 0x9E3779B9u) >> 20;
-  return (float)(int)(hsh & 0xFFFu) - 2048.0f;
+// exchange self-check (mobrob_ppo_exchange_selfcheck): small integers -- every partial sum is exact in float32 (and float64) whatever
+// the order; `salt` makes every message of a check a different vector
+template <typename T>
+__device__ __forceinline__ T selfcheck_value(unsigned i, int rank, unsigned salt) {
+  const unsigned hsh = ((i + 0x51ED27u * salt) * 2654435761u + (unsigned)(rank + 1) * 0x9E3779B9u) >> 20;
+  return (T)((int)(hsh & 0xFFFu) - 2048);
 }
-__global__ void k_selfcheck_fill(float* buf, int n, int rank) {
+template <typename T>
+__global__ void k_selfcheck_fill(T* buf, int n, int rank, unsigned salt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) buf[i] = selfcheck_value((unsigned)i, rank);
+  if (i < n) buf[i] = selfcheck_value<T>((unsigned)i, rank, salt);
 }
-__global__ void k_selfcheck_compare(const float* buf, int n, int world, int* mismatches) {
+template <typename T>
+__global__ void k_selfcheck_compare(const T* buf, int n, int world, unsigned salt, int* mismatches) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float want = 0.f;
-  for (int r = 0; r < world; ++r) want += selfcheck_value((unsigned)i, r);   // rank order; exact anyway
+  T want = 0;
+  for (int r = 0; r < world; ++r) want += selfcheck_value<T>((unsigned)i, r, salt);   // rank order; exact anyway
   if (!(buf[i] == want)) atomicAdd(mismatches, 1);
 }
 }  // namespace
+}  // extern "C++"
 
-// A known vector through the exchange train_dp would use, compared with the rank-ordered sum -- at communicator set-up, before any
+// Known vectors through the exchange train_dp would use, compared with the rank-ordered sums -- at communicator set-up, before any
 // gradient depends on it.  which: 0 = the engine's RCCL communicator, 1 = the one-shot exchange.  Collective over the ranks.
-// *mismatches = elements of the [P + 8] message that are not bit-equal to the expected sum (0 = the exchange is sound).
+// The update loop sends two kinds of message -- the [P + 8] float gradient message per optimizer step and the [n_minibatches][4]
+// float64 advantage sums per epoch -- and the one-shot exchange alternates between two payload slots: the check sends TWO messages
+// of EACH kind (both slots, slot reuse, both element types).  It runs on a scratch buffer of its own, so the gradient vector and
+// the loss accumulators behind it are never touched; it is refused while an epoch is open or a gradient awaits its apply.
+// *mismatches = elements (over the four messages) that are not bit-equal to the expected sum (0 = the exchange is sound).
 int mobrob_ppo_exchange_selfcheck(mobrob_ppo_engine_t* e, int32_t which, int32_t* mismatches) {
   if (!e || !mismatches) return fail(MOBROB_ERR_INVALID, "exchange_selfcheck: null argument");
   *mismatches = -1;
+  if (e->epoch_open || e->grad_pending)
+    return fail(MOBROB_ERR_STATE, "exchange_selfcheck: an epoch is open or a gradient is pending (call it between updates)");
   int world = 0, rank = -1;
   if (which == 0) {
     if (!e->comm) return fail(MOBROB_ERR_STATE, "exchange_selfcheck: no RCCL communicator");
@@ -2317,27 +2332,38 @@ int mobrob_ppo_exchange_selfcheck(mobrob_ppo_engine_t* e, int32_t which, int32_t
   } else {
     return fail(MOBROB_ERR_INVALID, "exchange_selfcheck: which = %d", which);
   }
-  const int n = e->P + 8;
+  const int nf = e->P + 8, nd = e->nmb * 4;
+  char* scratch = nullptr;
   int* bad = nullptr;
-  HIPC(hipMalloc((void**)&bad, sizeof(int)));
-  HIPC(hipMemsetAsync(bad, 0, sizeof(int), e->stream));
-  hipLaunchKernelGGL(k_selfcheck_fill, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->grads, n, rank);
+  const size_t sbytes = std::max((size_t)nf * sizeof(float), (size_t)nd * sizeof(double));
+  HIPC(hipMalloc((void**)&scratch, sbytes + 256));
+  if (hipMalloc((void**)&bad, sizeof(int)) != hipSuccess) { (void)hipFree(scratch); return fail(MOBROB_ERR_HIP, "exchange_selfcheck: hipMalloc"); }
+  (void)hipMemsetAsync(bad, 0, sizeof(int), e->stream);
   int rc = MOBROB_OK;
-  if (which == 1) rc = oneshot_all_reduce(e, e->grads, (size_t)n, 0);
-  else if (g_rccl.AllReduce(e->grads, e->grads, (size_t)n, ncclFloat, ncclSum, e->comm, e->stream) != ncclSuccess) rc = fail(MOBROB_ERR_HIP, "exchange_selfcheck: ncclAllReduce failed");
+  for (unsigned msg = 0; msg < 4 && rc == MOBROB_OK; ++msg) {   // float, float, double, double
+    const int dtype = msg >> 1, n = dtype ? nd : nf;
+    if (dtype) hipLaunchKernelGGL(k_selfcheck_fill<double>, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, reinterpret_cast<double*>(scratch), n, rank, msg);
+    else hipLaunchKernelGGL(k_selfcheck_fill<float>, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, reinterpret_cast<float*>(scratch), n, rank, msg);
+    if (which == 1) rc = oneshot_all_reduce(e, scratch, (size_t)n, dtype);
+    else if (g_rccl.AllReduce(scratch, scratch, (size_t)n, dtype ? ncclDouble : ncclFloat, ncclSum, e->comm, e->stream) != ncclSuccess)
+      rc = fail(MOBROB_ERR_HIP, "exchange_selfcheck: ncclAllReduce failed");
+    if (rc != MOBROB_OK) break;
+    if (dtype) hipLaunchKernelGGL(k_selfcheck_compare<double>, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, reinterpret_cast<const double*>(scratch), n, world, msg, bad);
+    else hipLaunchKernelGGL(k_selfcheck_compare<float>, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, reinterpret_cast<const float*>(scratch), n, world, msg, bad);
+  }
   if (rc == MOBROB_OK) {
-    hipLaunchKernelGGL(k_selfcheck_compare, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->grads, n, world, bad);
     int h = -1;
     hipError_t er = hipMemcpyAsync(&h, bad, sizeof(int), hipMemcpyDeviceToHost, e->stream);
     if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
     if (er != hipSuccess) rc = fail(MOBROB_ERR_HIP, "exchange_selfcheck: %s", hipGetErrorString(er));
     else *mismatches = h;
   }
-  // the gradient vector and the eight loss accumulators behind it go back to the state the update loop expects
-  (void)hipMemsetAsync(e->grads, 0, (size_t)n * sizeof(float), e->stream);
   (void)hipStreamSynchronize(e->stream);
   (void)hipFree(bad);
+  (void)hipFree(scratch);
   if (rc != MOBROB_OK) return rc;
+  // a peer that never published raised the error word: reported here, and LEFT SET for the closing path only if the caller ignores
+  // this return value -- check_async_error clears it once it has been turned into a failure
   if (which == 1) CHK(check_async_error(e));
   return MOBROB_OK;
 }

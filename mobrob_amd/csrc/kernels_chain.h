@@ -270,6 +270,24 @@ __device__ __forceinline__ ColFrag img_frag_load(int a0) {
   return f;
 }
 
+// dW1's running sums go back to the slab once per tile (64 KB per workgroup) and are read again one tile later.  Cache policy of
+// that store (MOBROB_DW1_ST): 0 plain (the line stays in the XCD's L2: 32 workgroups x 64 KB = 2 MB of the 4 MB, next to 1.8 MB of
+// weight packs), 1 sc1 / 3 sc0 sc1 (write-through, line dropped from L2: the re-read comes from the Infinity Cache), 2 nt.
+#ifndef MOBROB_DW1_ST
+#define MOBROB_DW1_ST 0
+#endif
+__device__ __forceinline__ void dw1_store(float* base, unsigned byte_off, const f32x4& v) {
+#if MOBROB_DW1_ST == 1
+  asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
+#elif MOBROB_DW1_ST == 2
+  asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
+#elif MOBROB_DW1_ST == 3
+  asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
+#else
+  stg16(base, byte_off, v);
+#endif
+}
+
 template <int DP>
 __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
   using L = CLay<DP>;
@@ -840,9 +858,20 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
       // (the first version split everything in front of the MFMAs: 12.5 k cycles per tile for 3 k of matrix time).
       X3Frag A0 = col_frag_split(img_frag_load(ao)), A1 = col_frag_split(img_frag_load(ao + 32 * 64));
       STAMP(13)
-      // the slab loads have landed (the gathers behind them, and the twelve ring DMAs of a primed next tile, may still be in flight)
+      // the slab loads have landed (the gathers behind them, and the twelve ring DMAs of a primed next tile, may still be in flight).
+      // What this hand-counted wait rests on is CHECKED on every build (tests/test_chain_isa.py, from the disassembly of the shipped
+      // code object): the slab loads write the accumulator registers themselves (the quads coalesced into the 16-register tuples:
+      // nothing reads or copies a loaded register in front of this wait), exactly NGL gather loads and twelve ring DMAs -- and no
+      // other vector-memory instruction -- lie between the slab loads and it.  Collecting the quads in standalone registers and
+      // assembling the tuples behind the wait cost 64 transient registers: three spills at 64 observation columns.
+      // -DMOBROB_CHAIN_VMCNT0 (validation build): vmcnt(0) here and at the ring's segment boundaries; its gradients must be
+      // bit-equal to the default build's (tests/test_engine_gpu.py::test_chain_counted_waits_equal_full_waits).
+#ifdef MOBROB_CHAIN_VMCNT0
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(gW1a), "+v"(gW1b), "+v"(gW1c), "+v"(gW1d) : : "memory");
+#else
       if (primed) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(gW1a), "+v"(gW1b), "+v"(gW1c), "+v"(gW1d) : "n"(NGL + 12) : "memory");
       else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(gW1a), "+v"(gW1b), "+v"(gW1c), "+v"(gW1d) : "n"(NGL) : "memory");
+#endif
       STAMP(14)
 #pragma unroll 1
       for (int ks = 0; ks < CR / 16; ++ks) {
@@ -894,8 +923,8 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           const f32x4 v = {gacc[4 * qd], gacc[4 * qd + 1], gacc[4 * qd + 2], gacc[4 * qd + 3]};
-          if (!(MOBROB_CHAIN_SKIP & 8)) stg16(slab_w1, sb1 + (unsigned)(tile_idx * 4 + qd) * 1024u, v);
-          else asm volatile("" :: "v"(v));
+          if (MOBROB_CHAIN_SKIP & 8) asm volatile("" :: "v"(v));
+          else dw1_store(slab_w1, sb1 + (unsigned)(tile_idx * 4 + qd) * 1024u, v);
         }
       };
       put(gW1a, 0);

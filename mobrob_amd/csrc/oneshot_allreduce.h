@@ -53,6 +53,37 @@ template <typename T>
 struct alignas(16) OneShotVec { T v[16 / sizeof(T)]; };
 typedef unsigned oneshot_u4 __attribute__((ext_vector_type(4)));
 
+// The 16 bytes at `off` of every rank's slot, system scope (sc0 sc1: past this device's caches).  Loads AND their wait sit in ONE asm
+// statement with early-clobber outputs: the compiler sees the registers defined only behind the s_waitcnt, so it cannot copy, spill
+// or re-allocate one while its load is in flight (a load in one statement and the wait in a later one leaves exactly that window).
+// Worlds of 2, 4 and 8 ranks request everything first and wait once; other sizes wait per load (correct, one round trip each).
+__device__ __forceinline__ void oneshot_load_all(oneshot_u4 (&xs)[kOneShotMaxRanks], const OneShotArgs& a, size_t off) {
+#pragma unroll
+  for (int r = 0; r < kOneShotMaxRanks; ++r) xs[r] = oneshot_u4{0u, 0u, 0u, 0u};   // ranks beyond the world: defined, unused
+  if (a.world == 2) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(xs[0]), "=&v"(xs[1]) : "v"(a.peer[0] + off), "v"(a.peer[1] + off) : "memory");
+  } else if (a.world == 4) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(xs[0]), "=&v"(xs[1]), "=&v"(xs[2]), "=&v"(xs[3])
+                 : "v"(a.peer[0] + off), "v"(a.peer[1] + off), "v"(a.peer[2] + off), "v"(a.peer[3] + off) : "memory");
+  } else if (a.world == 8) {
+    asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %10, off sc0 sc1\n\tglobal_load_dwordx4 %3, %11, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %4, %12, off sc0 sc1\n\tglobal_load_dwordx4 %5, %13, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %6, %14, off sc0 sc1\n\tglobal_load_dwordx4 %7, %15, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(xs[0]), "=&v"(xs[1]), "=&v"(xs[2]), "=&v"(xs[3]), "=&v"(xs[4]), "=&v"(xs[5]), "=&v"(xs[6]), "=&v"(xs[7])
+                 : "v"(a.peer[0] + off), "v"(a.peer[1] + off), "v"(a.peer[2] + off), "v"(a.peer[3] + off),
+                   "v"(a.peer[4] + off), "v"(a.peer[5] + off), "v"(a.peer[6] + off), "v"(a.peer[7] + off) : "memory");
+  } else {
+#pragma unroll
+    for (int r = 0; r < kOneShotMaxRanks; ++r)
+      if (r < a.world)
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(xs[r]) : "v"(a.peer[r] + off) : "memory");
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_oneshot_allreduce(OneShotArgs a) {
   using V = OneShotVec<T>;
@@ -118,10 +149,7 @@ __global__ __launch_bounds__(256) void k_oneshot_allreduce(OneShotArgs a) {
       for (int r = 0; r < kOneShotMaxRanks; ++r)
         if (r < a.world) xs[r] = *reinterpret_cast<const oneshot_u4*>(a.peer[r] + b0 + i * 16);
     } else {   // every rank's 16 bytes requested first (system scope: past this device's caches), one wait for all of them
-#pragma unroll
-      for (int r = 0; r < kOneShotMaxRanks; ++r)
-        if (r < a.world) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(xs[r]) : "v"(a.peer[r] + b0 + i * 16) : "memory");
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xs[0]), "+v"(xs[1]), "+v"(xs[2]), "+v"(xs[3]), "+v"(xs[4]), "+v"(xs[5]), "+v"(xs[6]), "+v"(xs[7]) :: "memory");
+      oneshot_load_all(xs, a, b0 + i * 16);
     }
     V acc = __builtin_bit_cast(V, xs[0]);
 #pragma unroll

@@ -49,6 +49,14 @@ def distributed_context(init=True):
     return dist.get_world_size(), dist.get_rank(), local
 
 
+def agree_all(flag, group=None, device_id=0):
+    """True only if `flag` is true on EVERY rank of the group (one MIN all-reduce): how the learn loop agrees to go on."""
+    dev = torch.device("cuda", device_id) if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([int(bool(flag))], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
 class _DevArray:
     """__cuda_array_interface__ view of an engine-owned device buffer (zero-copy into torch)."""
 
@@ -161,6 +169,7 @@ class EngineBackend:
             return self.exchange
         import os
         self.exchange_selfcheck = {}
+        self._group = group                  # close() meets the SAME ranks at its barrier (a sub-group stays a sub-group)
         backend = dist.get_backend(group)
         dev = self.device if backend == "nccl" else "cpu"
 
@@ -173,7 +182,7 @@ class EngineBackend:
             """run the self-check on every rank; ok only if EVERY rank saw zero mismatches"""
             try:
                 bad = self.e.exchange_selfcheck(which)
-                note = "ok" if bad == 0 else f"{bad} of {self.e.P + 8} elements differ from the rank-ordered sum"
+                note = "ok" if bad == 0 else f"{bad} elements of the four check messages differ from the rank-ordered sum"
             except Exception as ex:  # noqa: BLE001 - e.g. a peer that never published (bounded wait inside the kernel)
                 bad, note = -1, f"failed: {ex}"
             ok = agree(bad == 0)
@@ -210,6 +219,8 @@ class EngineBackend:
         """Closing handshake of the one-shot exchange (collective; a no-op for the other exchanges): a rank that has finished
         its last all-reduce has read every peer's slot, but a peer may still be reading ITS slot -- so every rank drains its
         stream, all meet at a barrier, and only then are the exchange buffers unmapped and freed."""
+        if group is None:
+            group = getattr(self, "_group", None)   # the group the exchange was chosen on
         if getattr(self, "exchange", None) == "oneshot" and getattr(self, "_oneshot_ready", False):
             self.e.synchronize()
             dist.barrier(group=group)

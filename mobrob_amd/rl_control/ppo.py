@@ -496,7 +496,13 @@ class PPO:
             self._tb = EventFileWriter(next_run_dir(self.tensorboard_log, tb_log_name, continue_latest=not reset_num_timesteps))
         while self.num_timesteps < total_timesteps:
             before = self.num_timesteps
-            if not self._collect_rollouts(callback):
+            go_on = self._collect_rollouts(callback)
+            if self.world_size > 1:
+                # a callback may stop SOME ranks only (it sees its own shard): the stop flag is agreed across the ranks
+                # before anybody leaves the loop, so no rank enters train()'s collectives -- or the closing barrier -- alone
+                from ..parallel import agree_all
+                go_on = agree_all(go_on, device_id=int(self.engine.cfg.device_id))
+            if not go_on:
                 break
             iteration += 1
             self._current_progress_remaining = 1.0 - float(self.num_timesteps) / float(total_timesteps)
@@ -512,9 +518,9 @@ class PPO:
         if self._tb is not None:
             self._tb.close()
             self._tb = None
+        callback.on_training_end()   # before the collective close: a callback that raises here leaves no rank inside a barrier
         if self._backend is not None:
             self._backend.close()     # one-shot exchange: collective closing handshake (parallel.EngineBackend.close)
-        callback.on_training_end()
         return self
 
     def _log(self, iteration, stats):

@@ -12,10 +12,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 extern __shared__ __attribute__((aligned(16))) float lds[];
 #define M16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), (c), 0, 0, 0)
-template <int V>
-__global__ __launch_bounds__(256, 1) void k(int iters, float* out, unsigned long long* cyc) {
+// NT = 256: one wave per SIMD (the kernel as built); NT = 512: TWO waves per SIMD running the same unit stream (round 5: what a
+// second wave per SIMD would buy the chain phases -- per-SIMD cycles per unit = the printed per-wave figure / 2)
+template <int V, int NT = 256>
+__global__ __launch_bounds__(NT, NT / 256) void k(int iters, float* out, unsigned long long* cyc) {
   const int lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < 24 * 768; i += 256) lds[i] = 1e-3f * (float)(i & 1023);
+  for (int i = threadIdx.x; i < 24 * 768; i += NT) lds[i] = 1e-3f * (float)(i & 1023);
   __syncthreads();
   f32x4 acc[16];
   for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256, 1) void k(int iters, float* out, unsigned long
       }
       if (V & 2) { w0 = n0; w1 = n1; w2 = n2; }
       if (V & 12) {   // side work of the real loop: half a pair-split (5-6 VALU) per unit, or a whole one
-        constexpr int reps = (V & 8) ? 2 : 1;
+        constexpr int reps = ((V & 12) == 12) ? 3 : (V & 8) ? 2 : 1;
 #pragma unroll
         for (int r = 0; r < reps; ++r) {
           unsigned p = __builtin_amdgcn_perm(__float_as_uint(fa), __float_as_uint(fb), 0x07060302u);
@@ -60,23 +62,24 @@ __global__ __launch_bounds__(256, 1) void k(int iters, float* out, unsigned long
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   float s = 0.f;
   for (int t = 0; t < 16; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
-  out[blockIdx.x * 256 + threadIdx.x] = s + fa + fb + (float)sink;
+  out[blockIdx.x * NT + threadIdx.x] = s + fa + fb + (float)sink;
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
-template <int V>
+template <int V, int NT = 256>
 void run(const char* name, float* out, unsigned long long* cyc) {
   const int iters = 2000;
-  hipFuncSetAttribute((const void*)k<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 768 * 4);
-  hipLaunchKernelGGL((k<V>), dim3(256), dim3(256), 24 * 768 * 4, 0, 10, out, cyc);
+  hipFuncSetAttribute((const void*)k<V, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 768 * 4);
+  hipLaunchKernelGGL((k<V, NT>), dim3(256), dim3(NT), 24 * 768 * 4, 0, 10, out, cyc);
   hipDeviceSynchronize();
-  hipLaunchKernelGGL((k<V>), dim3(256), dim3(256), 24 * 768 * 4, 0, iters, out, cyc);
+  hipLaunchKernelGGL((k<V, NT>), dim3(256), dim3(NT), 24 * 768 * 4, 0, iters, out, cyc);
   hipDeviceSynchronize();
   unsigned long long h; hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
-  printf("%-72s %.1f cycles per unit of six MFMAs (96 = the matrix pipe's own time)\n", name, (double)h / (16.0 * iters));
+  if (NT == 256) printf("%-72s %.1f cycles per unit of six MFMAs (96 = the matrix pipe's own time)\n", name, (double)h / (16.0 * iters));
+  else printf("%-72s %.1f cycles per unit and wave = %.1f per unit on the SIMD's matrix pipe (96 = its own time)\n", name, (double)h / (16.0 * iters), (double)h / (32.0 * iters));
 }
 int main() {
   float* out; unsigned long long* cyc;
-  hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 8);
+  hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 8);
   run<0>("six dependent 16x16x32 MFMAs per unit, operands in registers", out, cyc);
   run<1>("two units interleaved (independent neighbours), operands in registers", out, cyc);
   run<2>("six dependent MFMAs + the next unit's three ds_read_b128", out, cyc);
@@ -84,5 +87,12 @@ int main() {
   run<6>("six dependent MFMAs + reads + 6 VALU per unit", out, cyc);
   run<10>("six dependent MFMAs + reads + 12 VALU per unit", out, cyc);
   run<4>("six dependent MFMAs + 6 VALU per unit (no reads)", out, cyc);
+  printf("-- two waves per SIMD (512-thread workgroups), the same streams --\n");
+  run<0, 512>("2 waves/SIMD: six dependent MFMAs per unit, operands in registers", out, cyc);
+  run<2, 512>("2 waves/SIMD: + the next unit's three ds_read_b128", out, cyc);
+  run<6, 512>("2 waves/SIMD: + reads + 6 VALU per unit", out, cyc);
+  run<10, 512>("2 waves/SIMD: + reads + 12 VALU per unit", out, cyc);
+  run<14, 512>("2 waves/SIMD: + reads + 18 VALU per unit", out, cyc);
+  run<14>("1 wave/SIMD:  + reads + 18 VALU per unit", out, cyc);
   return 0;
 }

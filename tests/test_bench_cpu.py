@@ -20,7 +20,7 @@ def _clean_env(**extra):
     return env
 
 
-@pytest.mark.parametrize("n", [1, 2, 4])
+@pytest.mark.parametrize("n", [1, 2, 4, 8])   # 8: the driver's full-node SCALE run
 def test_bench_launches_its_own_ranks(n):
     r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--steps", "2", "--warmup", "1", "--dry-run-cpu"],
                        env=_clean_env(), capture_output=True, text=True, timeout=300)
@@ -72,7 +72,7 @@ def test_traffic_figure_is_tied_to_the_kernel_sources():
     sha = bench.csrc_sha256()
     assert len(sha) == 64 and sha == bench.csrc_sha256()
     val, note = bench.measured_traffic("void mobrob::k_chain_train<")
-    newest = next(r for r in ("r4", "r3", "r2", "r1") if os.path.exists(os.path.join(ROOT, "profiles", r, "hbm_traffic_pmc.json")))
+    newest = next(r for r in ("r5", "r4", "r3", "r2", "r1") if os.path.exists(os.path.join(ROOT, "profiles", r, "hbm_traffic_pmc.json")))
     recorded = json.load(open(os.path.join(ROOT, "profiles", newest, "hbm_traffic_pmc.json"))).get("csrc_sha256")
     if recorded == sha:
         assert isinstance(val, int) and val > 0

@@ -1,4 +1,6 @@
 """GPU parity tests: HIP engine (through the C ABI) vs the CPU oracle and the golden vectors."""
+import os
+
 import numpy as np
 import pytest
 
@@ -924,6 +926,50 @@ def test_fused_gradients_are_run_to_run_deterministic():
     g2 = e.read("grads")
     assert np.array_equal(g1, g2)  # slab reduction, no float atomics
     e.close()
+
+
+_COUNTED_WAIT_SCRIPT = r"""
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from mobrob_amd.engine import PPOEngine
+out = {}
+for D, A in ((14, 2), (26, 2), (58, 12)):             # observation rows padded to 16 / 32 / 64 columns: the three instantiations
+    H, N, T = 256, 256, 128                            # 32 768 rows = 512 tiles: four per workgroup (priming, running dW1 sums)
+    e = PPOEngine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=N * T, n_epochs=1, pi=(H, H), vf=(H, H), seed=3)
+    assert e.x3_mode() == 7, e.x3_mode()               # k_chain_train
+    e.collect_synthetic()
+    hs = []
+    for rep in range(3):
+        e.epoch_begin(None)
+        e.minibatch_grad(0)
+        hs.append(hashlib.sha256(e.read("grads").tobytes()).hexdigest())
+        e.minibatch_apply()
+    out[str(D)] = hs
+    e.close()
+print(json.dumps(out))
+"""
+
+
+def test_chain_counted_waits_equal_full_waits(tmp_path):
+    """k_chain_train waits for its LDS-DMA ring and for the dW1 running sums with hand-counted `s_waitcnt vmcnt(N)` (the loads are
+    inline asm the compiler does not track).  The validation build (-DMOBROB_CHAIN_VMCNT0: vmcnt(0) at every such wait, built by
+    __graft_entry__.build() beside the product library) must produce the SAME gradient bits for all three observation widths,
+    over three optimizer steps each (the static half of the check is tests/test_chain_isa.py)."""
+    import subprocess
+    import sys
+    import json
+    import __graft_entry__ as G
+    script = tmp_path / "counted_waits.py"
+    script.write_text(_COUNTED_WAIT_SCRIPT)
+    res = {}
+    for tag, lib in (("product", G.LIB), ("vmcnt0", G.LIB_VMCNT0)):
+        assert os.path.exists(lib), lib
+        env = dict(os.environ, MOBROB_PPO_LIB=lib)
+        r = subprocess.run([sys.executable, str(script), G.ROOT], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stderr[-2000:])
+        res[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["product"] == res["vmcnt0"], res
 
 
 def test_training_records_follow_every_write_to_the_arrays_they_pack():
