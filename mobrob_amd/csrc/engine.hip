@@ -1463,7 +1463,17 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
     ProfScope ps(e, MOBROB_K_ENV);
     for (int t0 = 0; t0 < T; t0 += chunk) {
       a.t0 = t0; a.t1 = std::min(T, t0 + chunk);
-      if (a.kind == 1) {
+      // x3 engines: the eight-wave form with W2's leading pieces stationary in registers (kernels_rollout.h, S8);
+      // MOBROB_ROLLOUT_S8=0 keeps the four-wave form (A/B and the bit-equality test of the two)
+      static const bool s8_on = !kRolloutStationary && !(getenv("MOBROB_ROLLOUT_S8") && atoi(getenv("MOBROB_ROLLOUT_S8")) == 0);
+      const bool s8 = s8_on && a.pi.W2x != nullptr;
+      if (s8 && a.kind == 1) {
+        FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout_persistent<DPc, 1, true>), dim3(rblocks), dim3(kRolloutThreads),
+                                                 rollout_lds_bytes(Dp, true), e->stream, a));
+      } else if (s8) {
+        FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout_persistent<DPc, 2, true>), dim3(rblocks), dim3(kRolloutThreads),
+                                                 rollout_lds_bytes(Dp, true), e->stream, a));
+      } else if (a.kind == 1) {
         FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout_persistent<DPc, 1>), dim3(rblocks), dim3(kRolloutThreads),
                                                  rollout_lds_bytes(Dp), e->stream, a));
       } else {

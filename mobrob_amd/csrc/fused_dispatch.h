@@ -96,6 +96,12 @@ inline hipError_t fused_set_lds_attr(FusedState& f) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_persistent<DPc, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rollout_lds_bytes(f.Dp));
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_persistent<DPc, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rollout_lds_bytes(f.Dp));
+      if (!kRolloutStationary) {
+        if (e == hipSuccess)
+          e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_persistent<DPc, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rollout_lds_bytes(f.Dp, true));
+        if (e == hipSuccess)
+          e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_persistent<DPc, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rollout_lds_bytes(f.Dp, true));
+      }
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_value_batch<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);
     });

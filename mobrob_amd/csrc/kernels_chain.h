@@ -22,9 +22,9 @@
 //     dW3 run as in k_fused_train: dW2's 256 x 256 accumulators pinned in the 256 AGPRs of the four waves for the whole launch.
 //     dW1 no longer holds 64 VGPRs for the launch: it is accumulated per tile and added to the workgroup's (L2-resident) slab.
 //
-// (Measured and not kept, scratch/kernels_chain_pair.h: a wave-PAIR ownership of the forward pass -- 32 rows x half the neurons per
-//  wave, every weight fragment read from the ring feeding two B fragments, half the ring reads -- correct on the whole suite, 2 % slower:
-//  CHANGELOG.md, round 4.)
+// (Measured and not kept: a wave-PAIR ownership of the forward pass -- 32 rows x half the neurons per wave, every weight fragment
+//  read from the ring feeding two B fragments, half the ring reads -- correct on the whole suite, 2 % slower: CHANGELOG.md, round 4;
+//  the source is in git history, scratch/kernels_chain_pair.h at commit 72f49c6.)
 // LDS (160 KB): h1 / dz1 image 64 KB | X image | constants | ring 12 KB + (h2 / dz2 image 64 KB: ring space while no image is live).
 // Same slab format as k_fused_train: k_slab_reduce, the norm records and k_adam_pack are unchanged.
 // Conditions: 256-wide tanh nets, heads <= 16 wide, observation rows padded to 16 / 32 / 64 columns (engine.hip fused_init).

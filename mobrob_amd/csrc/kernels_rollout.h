@@ -17,6 +17,7 @@
 // counters are (row, chunk, base + t), so the persistent and the per-step rollouts are bit-identical
 // (tests/test_engine_gpu.py::test_persistent_rollout_equals_per_step_rollout).
 #pragma once
+#include <type_traits>
 #include "kernels_env.h"
 #include "kernels_fused.h"
 #include "kernels_fused64.h"
@@ -47,9 +48,25 @@ struct RolloutArgs {
   int* ep_len; float* prev_dones; float* gstate; double* ep_stats;
 };
 
+// LDS carve-up of the rollout tile with the h1 activations kept as three bf16 PLANES (the x3 pieces, split once by the layer-1
+// epilogue) instead of one float32 tile: k_rollout_persistent<.., S8 = true>.  Plane p, row r, column k at H1 bytes
+// (p 32 + r) * 528 + 2 k: a row stride of 264 bf16 = 132 words shifts consecutive rows by four banks, the conflict-free pattern of
+// the float32 tiles' 260-float rows for 16-byte fragment reads.
+constexpr int kPlaneLd = FH + 8;                              // bf16 elements per plane row
+constexpr int kPlaneFloats = 3 * 32 * kPlaneLd / 2;           // the three planes of a 32-row tile, in floats
 template <int DP>
+struct Lay32S {
+  static constexpr int R = 32;
+  static constexpr int LDX = DP + 4;
+  static constexpr int X = 0;
+  static constexpr int H1 = X + R * LDX;                      // planes [3][32][264] bf16 (scratch of the bootstrap afterwards)
+  static constexpr int H2 = H1 + kPlaneFloats;
+  static constexpr int DO = H2 + R * FLDH;
+  static constexpr int END = DO + 4 * R * FLDO;
+};
+template <int DP, bool S8 = false>
 struct LayRo {
-  using B = Lay32<DP>;
+  using B = std::conditional_t<S8, Lay32S<DP>, Lay32<DP>>;
   static constexpr int CA = B::END;         // [32][33] clipped actions of the current step
   static constexpr int ST = CA + 32 * 33;   // [32][16] row state: goal state [0..11] | prev_done [12] | ep_len [13]
   static constexpr int BL = ST + 32 * 16;   // bootstrap list: cnt[4] | row[32] | reward[32]
@@ -59,8 +76,9 @@ struct LayRo {
   static constexpr int EN = TM + 32 * 33;   // [2][32][DP] standard normals of the env phase (observation noise), by step parity
   static constexpr int END = EN + 2 * 32 * DP;
 };
-inline size_t rollout_lds_bytes(int Dp) {
-  return fused_lds_act_bytes(Dp) + (size_t)(32 * 33 + 32 * 16 + 68 + 128 + 2 * 32 * 32 + 32 * 33 + 2 * 32 * Dp) * sizeof(float);
+inline size_t rollout_lds_bytes(int Dp, bool s8 = false) {
+  return fused_lds_act_bytes(Dp) + (s8 ? (size_t)(kPlaneFloats - 32 * FLDH) * sizeof(float) : 0) +
+         (size_t)(32 * 33 + 32 * 16 + 68 + 128 + 2 * 32 * 32 + 32 * 33 + 2 * 32 * Dp) * sizeof(float);
 }
 // The workgroup is EIGHT waves: four run the policy forward / sampling / env rules of the tile (one per SIMD, as before),
 // four "noise waves" (the second wave of every SIMD) draw the random numbers -- Philox4x32-10 + Box-Muller for
@@ -113,10 +131,25 @@ __device__ __forceinline__ void gemm_two_resident(int a_off, const RFrags<NKG>& 
 
 // KIND: the env source compiled in (1 synthetic, 2 goal environment; = a.kind): one variant carries one env's scalars -- with both in
 // one kernel ~200 scalar registers were parked in VGPR lanes and read back (v_readlane) inside the step loop.
-template <int DP, int KIND>
+// S8 (round 5; x3 engines only): the two hidden-layer GEMMs run on ALL EIGHT waves -- wave w owns the 32 output columns 32 w .. 32 w + 31
+// of both layers -- with the two leading bf16 pieces of its W2 block STATIONARY in 128 registers for the whole launch:
+//   * What paced the four-wave form: every step streamed the three pieces of W1 and W2 (98 + 393 KB per tile) through the CU's
+//     vector memory port, 64 B/clk: 7.7 k cycles per step against 7.7 k cycles of MFMA issue on the four policy waves -- two limits
+//     of the same size that do not overlap perfectly (6.98 us measured for 3.5 us of matrix time, profiles/r4/rollout_phase_ablation.txt).
+//     Now only piece 2 of W2 (one sixth of the products' operand bytes) and W1 cross the port: 245 KB per step.
+//   * The noise waves idle through the GEMM phases anyway (they draw during sampling / env / state phases): their SIMD slots and their
+//     256 registers each carry half of the matrix work instead.
+//   * h1 is split into its three bf16 pieces ONCE, by the layer-1 epilogue that produces it, and kept as three bf16 planes (Lay32S);
+//     layer 2's A fragments are three ds_read_b128 per k step and no VALU (the four-wave form split the same 32 rows in every wave:
+//     704 VALU instructions per wave and layer).
+// Same products, same order per accumulator as gemm_x3_r32 (X3_MFMA6 over the k steps in natural order): the rollout's numbers are
+// those of the four-wave x3 form bit for bit (tests/test_engine_gpu.py::test_s8_rollout_equals_the_four_wave_x3_rollout).
+// Sampling, env rules, storage, bootstrap: unchanged, on the four policy waves.
+template <int DP, int KIND, bool S8 = false>
 __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(RolloutArgs a) {
-  using L = LayRo<DP>;
-  using LB = Lay32<DP>;
+  static_assert(!S8 || !kRolloutStationary, "S8 needs the eight-wave workgroup");
+  using L = LayRo<DP, S8>;
+  using LB = typename L::B;
   constexpr int ldx = LB::LDX, per = DP / 4, R = 32;
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -178,9 +211,84 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
     w2b = rfrags_load<32>(W.W2f + (size_t)(2 * wave + 1) * 32 * 64, l0);
     w3s = rfrags_load<8>(W.W3f + (size_t)(wave * 8) * 64, l0);
   }
+  // S8: pieces 0 and 1 of this wave's 32 columns of W2, all sixteen k steps: resident for the launch
+  u32x4 W2s[S8 ? 16 : 1][2];
+  if constexpr (S8) {
+    const u32x4* bx = W2x + (size_t)wave * (FH / 16) * 192 + (tid0 & 63);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      W2s[ks][0] = bx[(ks * 3 + 0) * 64];
+      W2s[ks][1] = bx[(ks * 3 + 1) * 64];
+    }
+  }
   for (int t = a.t0; t < a.t1; ++t) {
     const int tid = opaque(tid0), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
+    if constexpr (S8) {   // ---- hidden layers on all eight waves ----
+      {  // layer 1: A = the float32 observation tile, split in the k loop (K <= 64: four k steps); B = this wave's block of the W1 pack
+        constexpr int NKS1 = DP / 16;
+        f32x16 c0 = splat16(W.b1s[32 * wave + r]);
+        const u32x4* b1x = W1x + (size_t)wave * NKS1 * 192 + lane;
+        X3Frag P[NKS1];
+#pragma unroll
+        for (int ks = 0; ks < NKS1; ++ks)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) P[ks].p[pc] = b1x[(ks * 3 + pc) * 64];
+        const int ab = 4 * opaque((LB::X + r * ldx + 8 * h) >> 2);
+        if (ROLL_ON(2)) {
+#pragma unroll
+          for (int ks = 0; ks < NKS1; ++ks) {
+            const X3Frag U = x3_split8(*reinterpret_cast<const f32x4*>(&lds[ab + 16 * ks]), *reinterpret_cast<const f32x4*>(&lds[ab + 16 * ks + 4]));
+            X3_MFMA6(U, P[ks], c0)
+          }
+        }
+        // epilogue: tanh, then the three bf16 pieces of every value into the planes (element (row crc(i) + 4 h, column 32 wave + r))
+        unsigned short* pl = reinterpret_cast<unsigned short*>(&lds[LB::H1]) + opaque((4 * h) * kPlaneLd + 32 * wave + r);
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          unsigned p1, p2, p3;
+          x3_split2(ROLL_TANH(c0[i]), ROLL_TANH(c0[i + 1]), p1, p2, p3);
+          const int o0 = crc(i) * kPlaneLd, o1 = crc(i + 1) * kPlaneLd;
+          pl[o0] = (unsigned short)(p1 & 0xffffu);                     pl[o1] = (unsigned short)(p1 >> 16);
+          pl[32 * kPlaneLd + o0] = (unsigned short)(p2 & 0xffffu);     pl[32 * kPlaneLd + o1] = (unsigned short)(p2 >> 16);
+          pl[64 * kPlaneLd + o0] = (unsigned short)(p3 & 0xffffu);     pl[64 * kPlaneLd + o1] = (unsigned short)(p3 >> 16);
+        }
+      }
+      LDS_BARRIER();  // (1) after layer 1
+      {  // layer 2: A fragments from the planes (no VALU), B pieces 0 / 1 from registers, piece 2 streamed kP2 k steps ahead
+        constexpr int kP2 = 3;
+        f32x16 c0 = splat16(W.b2s[32 * wave + r]);
+        const u32x4* b2x = W2x + (size_t)wave * (FH / 16) * 192 + lane;
+        u32x4 P2[kP2 + 1];
+#pragma unroll
+        for (int k = 0; k < kP2; ++k) P2[k] = b2x[(k * 3 + 2) * 64];
+        // plane p, row r, columns 16 ks + 8 h .. + 7: float offset H1 + (32 p + r) * 132 + 8 ks + 4 h
+        const int ap = 4 * opaque((LB::H1 + r * (kPlaneLd / 2) + 4 * h) >> 2);
+        auto frag = [&](int ks) {
+          X3Frag f;
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) f.p[pc] = *reinterpret_cast<const u32x4*>(&lds[ap + pc * 32 * (kPlaneLd / 2) + 8 * ks]);
+          return f;
+        };
+        X3Frag U = frag(0);
+        if (ROLL_ON(4)) {
+#pragma unroll
+          for (int ks = 0; ks < FH / 16; ++ks) {
+            X3Frag Un = U;
+            if (ks + 1 < FH / 16) Un = frag(ks + 1);
+            if (ks + kP2 < FH / 16) P2[(ks + kP2) % (kP2 + 1)] = b2x[((ks + kP2) * 3 + 2) * 64];
+            X3Frag Bf;
+            Bf.p[0] = W2s[ks][0]; Bf.p[1] = W2s[ks][1]; Bf.p[2] = P2[ks % (kP2 + 1)];
+            X3_MFMA6(U, Bf, c0)
+            U = Un;
+          }
+        }
+        const int o = opaque(LB::H2 + 4 * h * FLDH + 32 * wave + r);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) lds[o + crc(i) * FLDH] = ROLL_TANH(c0[i]);
+      }
+      LDS_BARRIER();  // (2) after layer 2
+    }
     // the random numbers of step ts into buffer ts & 1
     auto draw_sampling = [&](int ts, int hid) {  // standard normals of the sampling stage (consumed after the head)
       if (!ROLL_ON(1)) return;
@@ -219,8 +327,10 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       // the half being written was last read in step t - 1, whose phases all ended before barrier (6) of that step.
       const int hid = tid - FTHREADS;
       if (t == a.t0) { draw_sampling(t, hid); draw_env(t, hid); }
-      LDS_BARRIER();  // (1) after layer 1
-      LDS_BARRIER();  // (2) after layer 2
+      if constexpr (!S8) {
+        LDS_BARRIER();  // (1) after layer 1
+        LDS_BARRIER();  // (2) after layer 2
+      }
       LDS_BARRIER();  // (3) after the head
       if (t + 1 < a.t1) draw_sampling(t + 1, hid);
       LDS_BARRIER();  // (4) after the sampling stage
@@ -229,6 +339,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       LDS_BARRIER();  // (6) after the state update
     }
     if (!noise_wave) {
+    if constexpr (!S8) {
     {  // layer 1
       f32x16 c0 = splat16(W.b1s[64 * wave + r]), c1 = splat16(W.b1s[64 * wave + 32 + r]);
       constexpr int nkg = DP / 8;
@@ -263,6 +374,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       }
     }
     LDS_BARRIER();
+    }  // (!S8)
     {  // head: K split over the 4 waves (64 each); partial tiles side by side, summed in the sampling stage
       f32x16 acc = zero16(), acc2 = zero16();
       const int ab = 4 * opaque((LB::H2 + r * FLDH + wave * 64 + 4 * h) >> 2);

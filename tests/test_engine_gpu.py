@@ -972,6 +972,57 @@ def test_chain_counted_waits_equal_full_waits(tmp_path):
     assert res["product"] == res["vmcnt0"], res
 
 
+_S8_SCRIPT = r"""
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from mobrob_amd.engine import PPOEngine
+from mobrob_amd.envs.vec_env import DeviceGoalVecEnv
+from oracle import ppo_oracle as O
+out = {}
+for name, D, A in (("point", 14, 2), ("car", 26, 2), ("turtlebot3", 43, 2), ("doggo", 58, 12)):   # padded rows of 16 / 32 / 48 / 64 columns
+    H, N, T = 256, 200, 70                         # seven 32-row tiles, the last one ragged; 70 steps = two launches (chunks)
+    for kind in ("synthetic", "goal"):
+        e = PPOEngine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=N * T, n_epochs=1, pi=(H, H), vf=(H, H), seed=5)
+        assert e.x3_mode() & 1
+        p = O.init_params(D, A, (H, H), (H, H), seed=2)
+        p["action_net.weight"] *= 20
+        e.set_params(p)
+        for it in range(2):                         # the second rollout continues the first one's episodes
+            if kind == "synthetic":
+                e.collect_synthetic(p_term=0.02, time_limit=25)
+            else:
+                DeviceGoalVecEnv.for_robot(name, N, time_limit=25).collect(e)
+            e.synchronize()
+            hs = hashlib.sha256()
+            for k in ("obs", "actions", "log_probs", "rewards", "episode_starts", "values", "advantages", "returns", "last_values"):
+                hs.update(e.read(k).tobytes())
+            out[f"{name}/{kind}/{it}"] = hs.hexdigest()
+        e.close()
+print(json.dumps(out))
+"""
+
+
+def test_s8_rollout_equals_the_four_wave_x3_rollout(tmp_path):
+    """k_rollout_persistent<.., S8> (eight GEMM waves, W2's leading pieces stationary in registers, h1 split once into bf16 planes)
+    against the four-wave x3 form (MOBROB_ROLLOUT_S8=0): the same six products in the same order per accumulator, so EVERY stored
+    array of a rollout -- observations, actions, log-probs, rewards, episode starts, values, advantages -- is the same bit for bit,
+    for all four padded observation widths, both device env sources, ragged last tile, time-limit bootstraps, two rollouts in a row."""
+    import subprocess
+    import sys
+    import json
+    import __graft_entry__ as G
+    script = tmp_path / "s8.py"
+    script.write_text(_S8_SCRIPT)
+    res = {}
+    for s8 in ("1", "0"):
+        r = subprocess.run([sys.executable, str(script), G.ROOT], env=dict(os.environ, MOBROB_ROLLOUT_S8=s8), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, (s8, r.stderr[-2000:])
+        res[s8] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(res["1"]) == 16 and res["1"] == res["0"], {k: (res["1"][k][:8], res["0"][k][:8]) for k in res["1"] if res["1"][k] != res["0"][k]}
+
+
 def test_training_records_follow_every_write_to_the_arrays_they_pack():
     """k_fused_train reads actions / old log-prob / advantage / return / old value of a row from ONE packed record
     (kernels_fused.h, k_build_train_records) built once per rollout.  The arrays stay writable through the C ABI after

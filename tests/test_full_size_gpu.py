@@ -306,8 +306,10 @@ _TEACHER = {}
 def _clip_boundary_rows(p, buf, idx, h):
     """rows of the minibatch whose ratio lies within 2e-5 of 1 +- clip at parameters `p` (policy forward only, float32)"""
     obs, actions, _, old_lp, _, _ = O.gather_minibatch(buf, idx)
-    lat_pi = O.mlp_latents(p, obs)[0]
-    mean = lat_pi @ p["action_net.weight"].T + p["action_net.bias"]
+    x = np.asarray(obs, np.float32)
+    for w, b in O._net_layers(p, "mlp_extractor.policy_net"):      # the policy network only
+        x = np.tanh(x @ w.T + b, dtype=np.float32)
+    mean = x @ p["action_net.weight"].T + p["action_net.bias"]
     ratio = np.exp(O.gaussian_log_prob(mean, p["log_std"], actions) - old_lp)
     lo, hi = 1.0 - h.clip_range, 1.0 + h.clip_range
     return (np.abs(ratio - lo) < 2e-5) | (np.abs(ratio - hi) < 2e-5)
