@@ -120,7 +120,11 @@ struct GoalOutcome {
   bool reached, term, tr, done;
 };
 // one env step: dynamics + reward + termination rules (no reset)
-__device__ __forceinline__ GoalOutcome goal_advance(GoalState& g, const GoalEnvParams& p, const float* act, int A) {
+// (GP: GoalEnvParams, or the same struct behind a kernel-argument reference -- constant address space: the persistent rollout
+//  kernels read the parameters, the 3 x 32 mix matrix with its run-time column index among them, from the kernarg segment where
+//  they use them instead of holding ~100 scalars in registers through the step loop)
+template <class GP>
+__device__ __forceinline__ GoalOutcome goal_advance(GoalState& g, const GP& p, const float* act, int A) {
   float cmd[3] = {0.f, 0.f, 0.f};
   for (int k = 0; k < A; ++k) {
     const float a = act[k];
@@ -147,7 +151,8 @@ __device__ __forceinline__ GoalOutcome goal_advance(GoalState& g, const GoalEnvP
   return o;
 }
 // EnvWrapper.reset: lazy pose reset, always a new goal
-__device__ __forceinline__ void goal_reset(GoalState& g, const GoalEnvParams& p, bool reached, uint32_t n, uint32_t step,
+template <class GP>
+__device__ __forceinline__ void goal_reset(GoalState& g, const GP& p, bool reached, uint32_t n, uint32_t step,
                                            uint32_t k0, uint32_t k1) {
   const Philox4 a = philox4x32_10(n, 0u, step, kStreamEnvReset, k0, k1);
   const Philox4 b = philox4x32_10(n, 1u, step, kStreamEnvReset, k0, k1);

@@ -129,6 +129,14 @@ __device__ __forceinline__ void gemm_two_resident(int a_off, const RFrags<NKG>& 
   }
 }
 
+// the launch's RolloutArgs as they sit in the kernarg segment (the kernels below take ONE by-value parameter: offset 0)
+typedef const __attribute__((address_space(4))) RolloutArgs* RolloutArgsK;
+__device__ __forceinline__ RolloutArgsK rollout_kernargs() {
+  RolloutArgsK p = (RolloutArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));   // opaque per use: the loads behind it are not hoisted out of the step loop
+  return p;
+}
+
 // KIND: the env source compiled in (1 synthetic, 2 goal environment; = a.kind): one variant carries one env's scalars -- with both in
 // one kernel ~200 scalar registers were parked in VGPR lanes and read back (v_readlane) inside the step loop.
 // S8 (round 5; x3 engines only): the two hidden-layer GEMMs run on ALL EIGHT waves -- wave w owns the 32 output columns 32 w .. 32 w + 31
@@ -145,6 +153,11 @@ __device__ __forceinline__ void gemm_two_resident(int a_off, const RFrags<NKG>& 
 // Same products, same order per accumulator as gemm_x3_r32 (X3_MFMA6 over the k steps in natural order): the rollout's numbers are
 // those of the four-wave x3 form bit for bit (tests/test_engine_gpu.py::test_s8_rollout_equals_the_four_wave_x3_rollout).
 // Sampling, env rules, storage, bootstrap: unchanged, on the four policy waves.
+#define ar (*ap_)
+// Philox keys inside the step loop: derived from the kernel arguments where they are used.  As loop invariants
+// their ten-round key schedules (k + r W, twenty scalars per key pair and stream) were hoisted out of the step loop and parked.
+#define EK0 ((uint32_t)ar.env_seed)
+#define EK1 ((uint32_t)(ar.env_seed >> 32))
 template <int DP, int KIND, bool S8 = false>
 __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(RolloutArgs a) {
   static_assert(!S8 || !kRolloutStationary, "S8 needs the eight-wave workgroup");
@@ -221,15 +234,35 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       W2s[ks][1] = bx[(ks * 3 + 1) * 64];
     }
   }
-  for (int t = a.t0; t < a.t1; ++t) {
+  // S8: the first kP2 streamed pieces of W2 are requested one step AHEAD, behind the layer-2 GEMM of the previous step: their L2
+  // latency runs under the head / sampling / env phases instead of in front of layer 2's second MFMA.  (The same for this wave's
+  // block of the W1 pack -- 12 DP / 16 registers held through the step -- spilled at 32 and 48 observation columns.)
+  constexpr int NKS1s = S8 ? DP / 16 : 1;
+  constexpr int kP2 = 3;
+  u32x4 P2[kP2 + 1];
+  auto s8_prefetch = [&]() {
+    const u32x4* b2x = W2x + (size_t)wave * (FH / 16) * 192 + (tid0 & 63);
+#pragma unroll
+    for (int k = 0; k < kP2; ++k) P2[k] = b2x[(k * 3 + 2) * 64];
+  };
+  // (not for the goal environment at 64 observation columns: twelve more registers through the env phase spilled there)
+  constexpr bool kP2Ahead = S8 && !(KIND == 2 && DP == 64);
+  if constexpr (kP2Ahead) s8_prefetch();
+  // Kernel arguments inside the step loop are read THROUGH the kernarg segment where they are used (`ar`: the same struct behind a
+  // constant-address-space reference, re-materialised per step so that nothing is hoisted): by value they are ~60 pointers and
+  // ~120 scalars that the compiler loads once and then has to keep through the loop -- 147 .. 220 of them parked in lanes of vector
+  // registers, read back with v_readlane on the step's critical path (__graft_entry__.build() fails above 64).
+  const int t_begin = a.t0, t_end = a.t1;
+  for (int t = t_begin; t < t_end; ++t) {
+    RolloutArgsK ap_ = rollout_kernargs();   // `ar` below: (*ap_), re-materialised behind every barrier (a phase keeps only what it uses)
     const int tid = opaque(tid0), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     if constexpr (S8) {   // ---- hidden layers on all eight waves ----
       {  // layer 1: A = the float32 observation tile, split in the k loop (K <= 64: four k steps); B = this wave's block of the W1 pack
         constexpr int NKS1 = DP / 16;
-        f32x16 c0 = splat16(W.b1s[32 * wave + r]);
+        f32x16 c0 = splat16(ar.pi.b1s[32 * wave + r]);
         const u32x4* b1x = W1x + (size_t)wave * NKS1 * 192 + lane;
-        X3Frag P[NKS1];
+        X3Frag P[NKS1s];
 #pragma unroll
         for (int ks = 0; ks < NKS1; ++ks)
 #pragma unroll
@@ -254,14 +287,11 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
           pl[64 * kPlaneLd + o0] = (unsigned short)(p3 & 0xffffu);     pl[64 * kPlaneLd + o1] = (unsigned short)(p3 >> 16);
         }
       }
-      LDS_BARRIER();  // (1) after layer 1
+      LDS_BARRIER(); ap_ = rollout_kernargs();  // (1) after layer 1
       {  // layer 2: A fragments from the planes (no VALU), B pieces 0 / 1 from registers, piece 2 streamed kP2 k steps ahead
-        constexpr int kP2 = 3;
-        f32x16 c0 = splat16(W.b2s[32 * wave + r]);
+        f32x16 c0 = splat16(ar.pi.b2s[32 * wave + r]);
         const u32x4* b2x = W2x + (size_t)wave * (FH / 16) * 192 + lane;
-        u32x4 P2[kP2 + 1];
-#pragma unroll
-        for (int k = 0; k < kP2; ++k) P2[k] = b2x[(k * 3 + 2) * 64];
+        if constexpr (!kP2Ahead) s8_prefetch();
         // plane p, row r, columns 16 ks + 8 h .. + 7: float offset H1 + (32 p + r) * 132 + 8 ks + 4 h
         const int ap = 4 * opaque((LB::H1 + r * (kPlaneLd / 2) + 4 * h) >> 2);
         auto frag = [&](int ks) {
@@ -283,11 +313,12 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
             U = Un;
           }
         }
+        if (kP2Ahead && t + 1 < t_end) s8_prefetch();   // the next step's weight fragments (the ring slots P2[0 .. kP2) are free again: 16 % 4 == 0)
         const int o = opaque(LB::H2 + 4 * h * FLDH + 32 * wave + r);
 #pragma unroll
         for (int i = 0; i < 16; ++i) lds[o + crc(i) * FLDH] = ROLL_TANH(c0[i]);
       }
-      LDS_BARRIER();  // (2) after layer 2
+      LDS_BARRIER(); ap_ = rollout_kernargs();  // (2) after layer 2
     }
     // the random numbers of step ts into buffer ts & 1
     auto draw_sampling = [&](int ts, int hid) {  // standard normals of the sampling stage (consumed after the head)
@@ -297,8 +328,8 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       for (int i = hid; i < R * ngrp; i += FTHREADS) {
         const int rr_ = i / ngrp, gq = i - rr_ * ngrp;
         float z[4];
-        box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)gq, (uint32_t)ts + dbase, 0x45505331u, (uint32_t)a.seed,
-                                  (uint32_t)(a.seed >> 32)), z);
+        box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)gq, (uint32_t)ts + dbase, 0x45505331u, (uint32_t)ar.seed,
+                                  (uint32_t)(ar.seed >> 32)), z);
 #pragma unroll
         for (int j = 0; j < 4; ++j) lds[zb + rr_ * 32 + 4 * gq + j] = z[j];
       }
@@ -311,7 +342,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         const int rr_ = i / per, c = i - rr_ * per;
         if (row0 + rr_ < N) {
           float z[4];
-          box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)c, step_, kStreamEnvObs, ek0, ek1), z);
+          box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)c, step_, kStreamEnvObs, EK0, EK1), z);
           *reinterpret_cast<f32x4*>(&lds[eb + rr_ * DP + 4 * c]) = f32x4{z[0], z[1], z[2], z[3]};
         }
       }
@@ -326,27 +357,27 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       // draw step t + 1's numbers into the other buffer halves while the policy waves sample, step the env and update the state:
       // the half being written was last read in step t - 1, whose phases all ended before barrier (6) of that step.
       const int hid = tid - FTHREADS;
-      if (t == a.t0) { draw_sampling(t, hid); draw_env(t, hid); }
+      if (t == t_begin) { draw_sampling(t, hid); draw_env(t, hid); }
       if constexpr (!S8) {
-        LDS_BARRIER();  // (1) after layer 1
-        LDS_BARRIER();  // (2) after layer 2
+        LDS_BARRIER(); ap_ = rollout_kernargs();  // (1) after layer 1
+        LDS_BARRIER(); ap_ = rollout_kernargs();  // (2) after layer 2
       }
-      LDS_BARRIER();  // (3) after the head
-      if (t + 1 < a.t1) draw_sampling(t + 1, hid);
-      LDS_BARRIER();  // (4) after the sampling stage
-      if (t + 1 < a.t1) draw_env(t + 1, hid);
-      LDS_BARRIER();  // (5) after the env phase
-      LDS_BARRIER();  // (6) after the state update
+      LDS_BARRIER(); ap_ = rollout_kernargs();  // (3) after the head
+      if (t + 1 < t_end) draw_sampling(t + 1, hid);
+      LDS_BARRIER(); ap_ = rollout_kernargs();  // (4) after the sampling stage
+      if (t + 1 < t_end) draw_env(t + 1, hid);
+      LDS_BARRIER(); ap_ = rollout_kernargs();  // (5) after the env phase
+      LDS_BARRIER(); ap_ = rollout_kernargs();  // (6) after the state update
     }
     if (!noise_wave) {
     if constexpr (!S8) {
     {  // layer 1
-      f32x16 c0 = splat16(W.b1s[64 * wave + r]), c1 = splat16(W.b1s[64 * wave + 32 + r]);
+      f32x16 c0 = splat16(ar.pi.b1s[64 * wave + r]), c1 = splat16(ar.pi.b1s[64 * wave + 32 + r]);
       constexpr int nkg = DP / 8;
       if (ROLL_ON(2)) {
         if (kRolloutStationary) gemm_two_resident<ldx, NKG1>(LB::X, w1a, w1b, c0, c1, lane);
         else if (x3) gemm_x3_r32<ldx, DP / 16>(LB::X, W1x + (size_t)(2 * wave) * (DP / 16) * 192, W1x + (size_t)(2 * wave + 1) * (DP / 16) * 192, c0, c1, lane);
-        else gemm_lds_packed_r32<ldx>(LB::X, W.W1f + (size_t)(2 * wave) * nkg * 64, W.W1f + (size_t)(2 * wave + 1) * nkg * 64, nkg,
+        else gemm_lds_packed_r32<ldx>(LB::X, ar.pi.W1f + (size_t)(2 * wave) * nkg * 64, ar.pi.W1f + (size_t)(2 * wave + 1) * nkg * 64, nkg,
                                       c0, c1, lane);
       }
       const int o = opaque(LB::H1 + 4 * h * FLDH + 64 * wave + r);
@@ -356,15 +387,15 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         lds[o + crc(i) * FLDH + 32] = ROLL_TANH(c1[i]);
       }
     }
-    LDS_BARRIER();
+    LDS_BARRIER(); ap_ = rollout_kernargs();
     {  // layer 2
-      f32x16 c0 = splat16(W.b2s[64 * wave + r]), c1 = splat16(W.b2s[64 * wave + 32 + r]);
+      f32x16 c0 = splat16(ar.pi.b2s[64 * wave + r]), c1 = splat16(ar.pi.b2s[64 * wave + 32 + r]);
       constexpr int nkg = FH / 8;
       if (ROLL_ON(4)) {
         if (kRolloutStationary) gemm_two_resident<FLDH, 32>(LB::H1, w2a, w2b, c0, c1, lane);
         else if (x3) gemm_x3_r32<FLDH, FH / 16>(LB::H1, W2x + (size_t)(2 * wave) * (FH / 16) * 192, W2x + (size_t)(2 * wave + 1) * (FH / 16) * 192, c0, c1, lane);
-        else gemm_lds_packed_r32_deep<FLDH>(LB::H1, W.W2f + (size_t)(2 * wave) * nkg * 64,
-                                            W.W2f + (size_t)(2 * wave + 1) * nkg * 64, nkg, c0, c1, lane);
+        else gemm_lds_packed_r32_deep<FLDH>(LB::H1, ar.pi.W2f + (size_t)(2 * wave) * nkg * 64,
+                                            ar.pi.W2f + (size_t)(2 * wave + 1) * nkg * 64, nkg, c0, c1, lane);
       }
       const int o = opaque(LB::H2 + 4 * h * FLDH + 64 * wave + r);
 #pragma unroll
@@ -373,17 +404,24 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         lds[o + crc(i) * FLDH + 32] = ROLL_TANH(c1[i]);
       }
     }
-    LDS_BARRIER();
+    LDS_BARRIER(); ap_ = rollout_kernargs();
     }  // (!S8)
     {  // head: K split over the 4 waves (64 each); partial tiles side by side, summed in the sampling stage
       f32x16 acc = zero16(), acc2 = zero16();
       const int ab = 4 * opaque((LB::H2 + r * FLDH + wave * 64 + 4 * h) >> 2);
-      const f32x4* bp = W.W3f + (size_t)(wave * 8) * 64;
+      const f32x4* bp = ar.pi.W3f + (size_t)(wave * 8) * 64;
       const unsigned bo = opaque_u((unsigned)lane * 16u);
+      // fragments requested four at a time (they used to be fetched pair by pair inside the loop: four L2 round trips in a row;
+      // all eight at once spilled the goal-env variant at 64 observation columns)
+      f32x4 hb[4];
 #pragma unroll
       for (int kg = 0; kg < (ROLL_ON(64) ? 8 : 0); kg += 2) {
-        const f32x4 b0 = kRolloutStationary ? w3s.f[kg] : ldg16(bp, bo + kg * 1024u);
-        const f32x4 b1 = kRolloutStationary ? w3s.f[kg + 1] : ldg16(bp, bo + (kg + 1) * 1024u);
+        if ((kg & 3) == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) hb[q] = kRolloutStationary ? w3s.f[kg + q] : ldg16(bp, bo + (kg + q) * 1024u);
+        }
+        const f32x4 b0 = hb[kg & 3];
+        const f32x4 b1 = hb[(kg & 3) + 1];
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8]);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8 + 8]);
 #pragma unroll
@@ -397,7 +435,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       for (int i = 0; i < 16; ++i) lds[o + crc(i) * FLDO] = acc[i] + acc2[i];
     }
     if (tid == 0) *cnt = 0;
-    LDS_BARRIER();
+    LDS_BARRIER(); ap_ = rollout_kernargs();
     // ---- Gaussian sample + log-prob.  Same expressions and Philox counters as k_fused_act, spread over the block:
     //      (row, action group) items draw the normals, (row, action) items form action and log-prob term, one lane
     //      per row adds the terms in action order (-> bit-identical log-probs) ----
@@ -411,17 +449,17 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         const float act = m + lds[L::ZN + (t & 1) * (32 * 32) + rr_ * 32 + k] * sd;
         const float d = act - m;
         lds[L::TM + rr_ * 33 + k] = -(d * d) / lds[L::AC + 32 + k] - lds[L::AC + 64 + k] - 0.91893853320467274178f;
-        const float ac = fminf(fmaxf(act, a.lo), a.hi);
-        if (ROLL_ON(128)) a.actions[((size_t)t * N + row) * A + k] = act;
-        if (ROLL_ON(128)) a.clip_act[(size_t)row * A + k] = ac;
+        const float ac = fminf(fmaxf(act, ar.lo), ar.hi);
+        if (ROLL_ON(128)) ar.actions[((size_t)t * N + row) * A + k] = act;
+        if (ROLL_ON(128)) ar.clip_act[(size_t)row * A + k] = ac;
         lds[L::CA + rr_ * 33 + k] = ac;
       }
     }
-    LDS_BARRIER();
+    LDS_BARRIER(); ap_ = rollout_kernargs();
     if (tid < R && row0 + tid < N) {
       float lp = 0.f;
       for (int k = 0; k < A; ++k) lp += lds[L::TM + tid * 33 + k];
-      if (ROLL_ON(128)) a.logp[(size_t)t * N + row0 + tid] = lp;
+      if (ROLL_ON(128)) ar.logp[(size_t)t * N + row0 + tid] = lp;
     }
     // ---- env.step(clipped actions) + auto-reset: 8 threads per row, observation chunks sub and sub + 8 ----
     const int rr = tid >> 3, sub = tid & 7;
@@ -438,10 +476,10 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
     GoalState g{};
     if (live && ROLL_ON(16)) {
       if (KIND == 1) {
-        const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, ek0, ek1);
-        const bool term = u32_to_unit_open(mr.x) < a.p_term;
+        const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, EK0, EK1);
+        const bool term = u32_to_unit_open(mr.x) < ar.p_term;
         const int len = reinterpret_cast<const int*>(S)[13] + 1;
-        tr = (len >= a.time_limit) && !term;
+        tr = (len >= ar.time_limit) && !term;
         done = term || tr;
         ep_len_new = done ? 0 : len;
         for (int c = sub; c < per; c += 8) {
@@ -450,14 +488,14 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
           if (tr) {
-            reinterpret_cast<f32x4*>(a.term_obs)[(size_t)n * per + c] = o;
+            reinterpret_cast<f32x4*>(ar.term_obs)[(size_t)n * per + c] = o;
             *reinterpret_cast<f32x4*>(&trow[4 * c]) = o;
             float zt[4];
-            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), zt);
+            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, EK0, EK1), zt);
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? zt[j] : 0.f;
           }
-          if (ROLL_ON(128)) reinterpret_cast<f32x4*>(a.obs)[onext + c] = o;
+          if (ROLL_ON(128)) reinterpret_cast<f32x4*>(ar.obs)[onext + c] = o;
           *reinterpret_cast<f32x4*>(&xrow[4 * c]) = o;
         }
         if (sub == 0) {
@@ -467,45 +505,45 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         }
       } else {
         g = goal_load(S);
-        const GoalOutcome o = goal_advance(g, a.goal, &lds[L::CA + rr * 33], A);
+        const GoalOutcome o = goal_advance(g, ar.goal, &lds[L::CA + rr * 33], A);
         tr = o.tr; done = o.done; reached = o.reached; reward = o.reward;
         ep_ret = g.ep_ret; ep_len_fin = g.ep_len;
         GoalState gn = g;
-        if (done) goal_reset(gn, a.goal, o.reached, (uint32_t)n, step, ek0, ek1);
+        if (done) goal_reset(gn, ar.goal, o.reached, (uint32_t)n, step, EK0, EK1);
         for (int c = sub; c < per; c += 8) {
           float z[4];
           {
             const f32x4 zz = *reinterpret_cast<const f32x4*>(&lds[L::EN + (t & 1) * (32 * DP) + rr * DP + 4 * c]);  // drawn by the noise waves
             z[0] = zz[0]; z[1] = zz[1]; z[2] = zz[2]; z[3] = zz[3];
           }
-          f32x4 ob = goal_features(g, a.goal.P, D, c, z, a.goal.noise);
+          f32x4 ob = goal_features(g, ar.goal.P, D, c, z, ar.goal.noise);
           if (done) {
             if (tr) {
-              reinterpret_cast<f32x4*>(a.term_obs)[(size_t)n * per + c] = ob;
+              reinterpret_cast<f32x4*>(ar.term_obs)[(size_t)n * per + c] = ob;
               *reinterpret_cast<f32x4*>(&trow[4 * c]) = ob;
             }
-            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
-            ob = goal_features(gn, a.goal.P, D, c, z, a.goal.noise);
+            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, EK0, EK1), z);
+            ob = goal_features(gn, ar.goal.P, D, c, z, ar.goal.noise);
           }
-          if (ROLL_ON(128)) reinterpret_cast<f32x4*>(a.obs)[onext + c] = ob;
+          if (ROLL_ON(128)) reinterpret_cast<f32x4*>(ar.obs)[onext + c] = ob;
           *reinterpret_cast<f32x4*>(&xrow[4 * c]) = ob;
         }
         g = gn;
       }
     }
-    LDS_BARRIER();  // every thread of a row has read the row's old state
+    LDS_BARRIER(); ap_ = rollout_kernargs();  // every thread of a row has read the row's old state
     if (live && sub == 0) {
       const size_t so = (size_t)t * N + n;
-      if (ROLL_ON(128)) a.es[so] = S[12];
+      if (ROLL_ON(128)) ar.es[so] = S[12];
       S[12] = done ? 1.f : 0.f;
-      if (ROLL_ON(128)) a.trunc[n] = tr ? 1 : 0;
+      if (ROLL_ON(128)) ar.trunc[n] = tr ? 1 : 0;
       if (KIND == 1) {
         reinterpret_cast<int*>(S)[13] = ep_len_new;
       } else {
         goal_store(S, g);
         if (done) {  // Monitor statistics: accumulated per thread, flushed once per launch (see the kernel end)
           es_n += 1.0; es_ret += (double)ep_ret; es_len += (double)ep_len_fin; es_goal += reached ? 1.0 : 0.0;
-          ep_ring_push(a.ep_stats, ep_ret, (float)ep_len_fin);
+          ep_ring_push(ar.ep_stats, ep_ret, (float)ep_len_fin);
         }
       }
       if (tr) {  // reward is written after the bootstrap below
@@ -513,10 +551,10 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         lrow[q] = rr;
         lrew[q] = reward;
       } else {
-        if (ROLL_ON(128)) a.rewards[so] = reward;
+        if (ROLL_ON(128)) ar.rewards[so] = reward;
       }
     }
-    LDS_BARRIER();
+    LDS_BARRIER(); ap_ = rollout_kernargs();
     }  // (policy waves)
     // ---- time-limit bootstrap of the (rare) truncated rows: r += gamma * V(terminal_obs).  All eight waves (the value MLP
     //      of a row is a block-wide routine with its own barriers; the noise waves hold no hidden unit and add zeros) ----
@@ -524,11 +562,11 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
     for (int q = 0; q < m; ++q) {
       const int br = lrow[q];
       float* sc = &lds[LB::H1];  // h1 is dead after the layer-2 GEMM: scratch h1[G1] | h2[G2] | red[16]
-      const float v = value_row_lds(&lds[LB::H2 + br * DP], sc, sc + a.bt.G1, sc + a.bt.G1 + a.bt.G2, a.bt.W1, a.bt.b1,
-                                    a.bt.W2, a.bt.b2, a.bt.Wv, a.bt.bv, D, a.bt.G1, a.bt.G2);
+      const float v = value_row_lds(&lds[LB::H2 + br * DP], sc, sc + ar.bt.G1, sc + ar.bt.G1 + ar.bt.G2, ar.bt.W1, ar.bt.b1,
+                                    ar.bt.W2, ar.bt.b2, ar.bt.Wv, ar.bt.bv, D, ar.bt.G1, ar.bt.G2);
       if (tid == 0) {
-        a.bt.term_val[row0 + br] = v;
-        a.rewards[(size_t)t * N + row0 + br] = (float)((double)lrew[q] + (double)__fmul_rn(a.bt.gamma, v));
+        ar.bt.term_val[row0 + br] = v;
+        ar.rewards[(size_t)t * N + row0 + br] = (float)((double)lrew[q] + (double)__fmul_rn(ar.bt.gamma, v));
       }
       __syncthreads();
     }
@@ -555,6 +593,10 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
     }
   }
 }
+
+#undef ar
+#undef EK0
+#undef EK1
 
 // ------------------------------------------------------------------------------------------------
 // Batched value forward: v[row] = V(X[row]) for `rows` contiguous observations.  Persistent 256-thread blocks loop
@@ -652,7 +694,8 @@ inline size_t rollout64_lds_bytes(int Dp) {
 
 // V(x) for one row by one wave (x[D], h1[G1], h2[G2] in the wave's LDS).  Same per-unit fma chains as value_row_lds;
 // for G2 <= 64 the final wave_sum equals its block_sum (the other waves contribute exact zeros).
-__device__ __forceinline__ float value_row_wave(const float* x, float* h1, float* h2, const BootArgs& bt, int D, int lane) {
+template <class BT>   // BootArgs, or the same struct behind a kernel-argument reference (constant address space)
+__device__ __forceinline__ float value_row_wave(const float* x, float* h1, float* h2, const BT& bt, int D, int lane) {
   for (int j = lane; j < bt.G1; j += 64) {
     float s = 0.f;
     for (int k = 0; k < D; ++k) s = fmaf(x[k], bt.W1[(size_t)j * D + k], s);
@@ -668,6 +711,9 @@ __device__ __forceinline__ float value_row_wave(const float* x, float* h1, float
   return wave_sum(p) + bt.bv[0];
 }
 
+#define ar (*ap_)
+#define EK0 ((uint32_t)ar.env_seed)
+#define EK1 ((uint32_t)(ar.env_seed >> 32))
 template <int DP>
 __global__ __launch_bounds__(LayRo64<DP>::NWV * 64, 1) void k_rollout64_persistent(RolloutArgs a) {
   using L = LayRo64<DP>;
@@ -727,15 +773,17 @@ __global__ __launch_bounds__(LayRo64<DP>::NWV * 64, 1) void k_rollout64_persiste
   const uint32_t ek0 = (uint32_t)a.env_seed, ek1 = (uint32_t)(a.env_seed >> 32);
 
   double es_n = 0.0, es_ret = 0.0, es_len = 0.0, es_goal = 0.0;  // finished episodes of this thread's row
-  for (int t = a.t0; t < a.t1; ++t) {
+  const int t_begin = a.t0, t_end = a.t1;   // (kernel arguments and Philox keys inside the step loop: see k_rollout_persistent)
+  for (int t = t_begin; t < t_end; ++t) {
+    RolloutArgsK ap_ = rollout_kernargs();
     const int lane = opaque(lane0);
     {  // standard normals of this step
       const int ngrp = (A + 3) >> 2;
       for (int i = lane; i < R * ngrp; i += 64) {
         const int rr_ = i / ngrp, gq = i - rr_ * ngrp;
         float z[4];
-        box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)gq, (uint32_t)t + dbase, 0x45505331u, (uint32_t)a.seed,
-                                  (uint32_t)(a.seed >> 32)), z);
+        box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)gq, (uint32_t)t + dbase, 0x45505331u, (uint32_t)ar.seed,
+                                  (uint32_t)(ar.seed >> 32)), z);
 #pragma unroll
         for (int j = 0; j < 4; ++j) lds[wb + L::ZN + rr_ * 32 + 4 * gq + j] = z[j];
       }
@@ -751,16 +799,16 @@ __global__ __launch_bounds__(LayRo64<DP>::NWV * 64, 1) void k_rollout64_persiste
         const float act = m + lds[wb + L::ZN + rr_ * 32 + k] * sd;
         const float d = act - m;
         lds[wb + L::TM + rr_ * 33 + k] = -(d * d) / lds[L::AC + 32 + k] - lds[L::AC + 64 + k] - 0.91893853320467274178f;
-        const float ac = fminf(fmaxf(act, a.lo), a.hi);
-        a.actions[((size_t)t * N + row) * A + k] = act;
-        a.clip_act[(size_t)row * A + k] = ac;
+        const float ac = fminf(fmaxf(act, ar.lo), ar.hi);
+        ar.actions[((size_t)t * N + row) * A + k] = act;
+        ar.clip_act[(size_t)row * A + k] = ac;
         lds[wb + L::CA + rr_ * 33 + k] = ac;
       }
     }
     if (lane < R && row0 + lane < N) {
       float lp = 0.f;
       for (int k = 0; k < A; ++k) lp += lds[wb + L::TM + lane * 33 + k];
-      a.logp[(size_t)t * N + row0 + lane] = lp;
+      ar.logp[(size_t)t * N + row0 + lane] = lp;
     }
     // ---- env.step + auto-reset: 2 lanes per row, observation chunks sub, sub + 2, ... ----
     const int rr = lane >> 1, sub = lane & 1;
@@ -776,27 +824,27 @@ __global__ __launch_bounds__(LayRo64<DP>::NWV * 64, 1) void k_rollout64_persiste
     int ep_len_new = 0, ep_len_fin = 0;
     GoalState g{};
     if (live) {
-      if (a.kind == 1) {
-        const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, ek0, ek1);
-        const bool term = u32_to_unit_open(mr.x) < a.p_term;
+      if (ar.kind == 1) {
+        const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, EK0, EK1);
+        const bool term = u32_to_unit_open(mr.x) < ar.p_term;
         const int len = reinterpret_cast<const int*>(S)[13] + 1;
-        tr = (len >= a.time_limit) && !term;
+        tr = (len >= ar.time_limit) && !term;
         done = term || tr;
         ep_len_new = done ? 0 : len;
         for (int c = sub; c < per; c += 2) {
           float z[4];
-          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, ek0, ek1), z);
+          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, EK0, EK1), z);
           f32x4 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
           if (tr) {
-            reinterpret_cast<f32x4*>(a.term_obs)[(size_t)n * per + c] = o;
+            reinterpret_cast<f32x4*>(ar.term_obs)[(size_t)n * per + c] = o;
             *reinterpret_cast<f32x4*>(&trow[4 * c]) = o;
-            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
+            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, EK0, EK1), z);
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
           }
-          reinterpret_cast<f32x4*>(a.obs)[onext + c] = o;
+          reinterpret_cast<f32x4*>(ar.obs)[onext + c] = o;
           *reinterpret_cast<f32x4*>(&xrow[4 * c]) = o;
         }
         if (sub == 0) {
@@ -806,24 +854,24 @@ __global__ __launch_bounds__(LayRo64<DP>::NWV * 64, 1) void k_rollout64_persiste
         }
       } else {
         g = goal_load(S);
-        const GoalOutcome o = goal_advance(g, a.goal, &lds[wb + L::CA + rr * 33], A);
+        const GoalOutcome o = goal_advance(g, ar.goal, &lds[wb + L::CA + rr * 33], A);
         tr = o.tr; done = o.done; reached = o.reached; reward = o.reward;
         ep_ret = g.ep_ret; ep_len_fin = g.ep_len;
         GoalState gn = g;
-        if (done) goal_reset(gn, a.goal, o.reached, (uint32_t)n, step, ek0, ek1);
+        if (done) goal_reset(gn, ar.goal, o.reached, (uint32_t)n, step, EK0, EK1);
         for (int c = sub; c < per; c += 2) {
           float z[4];
-          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, ek0, ek1), z);
-          f32x4 ob = goal_features(g, a.goal.P, D, c, z, a.goal.noise);
+          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, EK0, EK1), z);
+          f32x4 ob = goal_features(g, ar.goal.P, D, c, z, ar.goal.noise);
           if (done) {
             if (tr) {
-              reinterpret_cast<f32x4*>(a.term_obs)[(size_t)n * per + c] = ob;
+              reinterpret_cast<f32x4*>(ar.term_obs)[(size_t)n * per + c] = ob;
               *reinterpret_cast<f32x4*>(&trow[4 * c]) = ob;
             }
-            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
-            ob = goal_features(gn, a.goal.P, D, c, z, a.goal.noise);
+            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, EK0, EK1), z);
+            ob = goal_features(gn, ar.goal.P, D, c, z, ar.goal.noise);
           }
-          reinterpret_cast<f32x4*>(a.obs)[onext + c] = ob;
+          reinterpret_cast<f32x4*>(ar.obs)[onext + c] = ob;
           *reinterpret_cast<f32x4*>(&xrow[4 * c]) = ob;
         }
         g = gn;
@@ -833,19 +881,19 @@ __global__ __launch_bounds__(LayRo64<DP>::NWV * 64, 1) void k_rollout64_persiste
     const bool boot = live && sub == 0 && tr;
     if (live && sub == 0) {
       const size_t so = (size_t)t * N + n;
-      a.es[so] = S[12];
+      ar.es[so] = S[12];
       S[12] = done ? 1.f : 0.f;
-      a.trunc[n] = tr ? 1 : 0;
-      if (a.kind == 1) {
+      ar.trunc[n] = tr ? 1 : 0;
+      if (ar.kind == 1) {
         reinterpret_cast<int*>(S)[13] = ep_len_new;
       } else {
         goal_store(S, g);
         if (done) {  // Monitor statistics: accumulated per thread, flushed once per launch (see the kernel end)
           es_n += 1.0; es_ret += (double)ep_ret; es_len += (double)ep_len_fin; es_goal += reached ? 1.0 : 0.0;
-          ep_ring_push(a.ep_stats, ep_ret, (float)ep_len_fin);
+          ep_ring_push(ar.ep_stats, ep_ret, (float)ep_len_fin);
         }
       }
-      if (!tr) a.rewards[so] = reward;
+      if (!tr) ar.rewards[so] = reward;
     }
     // ---- time-limit bootstrap of the (rare) truncated rows: the wave evaluates the value MLP row by row ----
     unsigned long long pending = __ballot(boot);
@@ -855,10 +903,10 @@ __global__ __launch_bounds__(LayRo64<DP>::NWV * 64, 1) void k_rollout64_persiste
       const int br = src >> 1;
       const float rw = __shfl(reward, src, 64);
       float* sc = &lds[wb + LB::H1];  // h1 is dead: scratch h1[G1] | h2[G2]
-      const float v = value_row_wave(&lds[wb + LB::H2 + br * GLDH], sc, sc + a.bt.G1, a.bt, D, lane);
+      const float v = value_row_wave(&lds[wb + LB::H2 + br * GLDH], sc, sc + ar.bt.G1, ar.bt, D, lane);
       if (lane == 0) {
-        a.bt.term_val[row0 + br] = v;
-        a.rewards[(size_t)t * N + row0 + br] = (float)((double)rw + (double)__fmul_rn(a.bt.gamma, v));
+        ar.bt.term_val[row0 + br] = v;
+        ar.rewards[(size_t)t * N + row0 + br] = (float)((double)rw + (double)__fmul_rn(ar.bt.gamma, v));
       }
     }
   }
@@ -884,6 +932,9 @@ __global__ __launch_bounds__(LayRo64<DP>::NWV * 64, 1) void k_rollout64_persiste
     }
   }
 }
+#undef ar
+#undef EK0
+#undef EK1
 
 // weight fragments of one 32-column block held in registers, and a single-chain 32-row GEMM over them (the k order of
 // gemm_lds_packed_r32 / gemm_lds_lds_r32; see kernels_split64.h, which has the same pair for the training tile)
@@ -945,6 +996,9 @@ inline size_t rollout64_tile_lds_bytes(int Dp) {
   return (size_t)(32 * (Dp + 4) + 2 * 32 * GLDH + 2 * 32 * FLDO + 32 * 33 + 32 * 16 + 68 + 128 + 32 * 32 + 32 * 33) * sizeof(float);
 }
 
+#define ar (*ap_)
+#define EK0 ((uint32_t)ar.env_seed)
+#define EK1 ((uint32_t)(ar.env_seed >> 32))
 template <int DP>
 __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
   using L = LayRoT<DP>;
@@ -1007,7 +1061,9 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
   const uint32_t ek0 = (uint32_t)a.env_seed, ek1 = (uint32_t)(a.env_seed >> 32);
 
   double es_n = 0.0, es_ret = 0.0, es_len = 0.0, es_goal = 0.0;  // finished episodes of this thread's row
-  for (int t = a.t0; t < a.t1; ++t) {
+  const int t_begin = a.t0, t_end = a.t1;   // (kernel arguments and Philox keys inside the step loop: see k_rollout_persistent)
+  for (int t = t_begin; t < t_end; ++t) {
+    RolloutArgsK ap_ = rollout_kernargs();
     const int tid = opaque(tid0), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     if (wave < 2) {  // layer 1: column block `wave`
@@ -1021,13 +1077,13 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
       for (int i = tid - 128; i < R * ngrp; i += 128) {
         const int rr_ = i / ngrp, gq = i - rr_ * ngrp;
         float z[4];
-        box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)gq, (uint32_t)t + dbase, 0x45505331u, (uint32_t)a.seed,
-                                  (uint32_t)(a.seed >> 32)), z);
+        box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)gq, (uint32_t)t + dbase, 0x45505331u, (uint32_t)ar.seed,
+                                  (uint32_t)(ar.seed >> 32)), z);
 #pragma unroll
         for (int j = 0; j < 4; ++j) lds[L::ZN + rr_ * 32 + 4 * gq + j] = z[j];
       }
     }
-    __syncthreads();
+    __syncthreads(); ap_ = rollout_kernargs();
     if (wave < 2) {  // layer 2
       f32x16 c = splat16(bias2);
       gemm_one_ro<GLDH, 8>(L::H1, f2, c, lane);
@@ -1035,7 +1091,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) lds[o + crc(i) * GLDH] = fast_tanh_scaled(c[i]);
     }
-    __syncthreads();
+    __syncthreads(); ap_ = rollout_kernargs();
     if (wave < 2) {  // head: wave 0 the even k-groups (tile64_forward's `acc`), wave 1 the odd ones (`acc2`)
       f32x16 acc = zero16();
       const int ab = 4 * opaque((L::H2 + r * GLDH + 4 * h) >> 2);
@@ -1049,7 +1105,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) lds[o + crc(i) * FLDO] = acc[i];
     }
-    __syncthreads();
+    __syncthreads(); ap_ = rollout_kernargs();
     // ---- Gaussian sample + log-prob (expressions and Philox counters of k_fused64_act), then env.step(clipped actions) +
     //      auto-reset: the SAME 8 threads serve a row in both (actions sub, sub + 8, ...; observation chunks sub, sub + 8):
     //      they sit in one wave, so the row's clipped actions and log-prob terms are ordered by the wave's DS queue and no
@@ -1062,9 +1118,9 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
         const float act = m + lds[L::ZN + rr * 32 + k] * sd;
         const float d = act - m;
         lds[L::TM + rr * 33 + k] = -(d * d) / lds[L::AC + 32 + k] - lds[L::AC + 64 + k] - 0.91893853320467274178f;
-        const float ac = fminf(fmaxf(act, a.lo), a.hi);
-        a.actions[((size_t)t * N + row0 + rr) * A + k] = act;
-        a.clip_act[(size_t)(row0 + rr) * A + k] = ac;
+        const float ac = fminf(fmaxf(act, ar.lo), ar.hi);
+        ar.actions[((size_t)t * N + row0 + rr) * A + k] = act;
+        ar.clip_act[(size_t)(row0 + rr) * A + k] = ac;
         lds[L::CA + rr * 33 + k] = ac;
       }
     }
@@ -1072,7 +1128,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
     if (sub == 0 && row0 + rr < N) {
       float lp = 0.f;
       for (int k = 0; k < A; ++k) lp += lds[L::TM + rr * 33 + k];
-      a.logp[(size_t)t * N + row0 + rr] = lp;
+      ar.logp[(size_t)t * N + row0 + rr] = lp;
     }
     const int n = row0 + rr;
     const bool live = n < N;
@@ -1086,27 +1142,27 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
     int ep_len_new = 0, ep_len_fin = 0;
     GoalState g{};
     if (live) {
-      if (a.kind == 1) {
-        const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, ek0, ek1);
-        const bool term = u32_to_unit_open(mr.x) < a.p_term;
+      if (ar.kind == 1) {
+        const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, EK0, EK1);
+        const bool term = u32_to_unit_open(mr.x) < ar.p_term;
         const int len = reinterpret_cast<const int*>(S)[13] + 1;
-        tr = (len >= a.time_limit) && !term;
+        tr = (len >= ar.time_limit) && !term;
         done = term || tr;
         ep_len_new = done ? 0 : len;
         for (int c = sub; c < per; c += 8) {
           float z[4];
-          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, ek0, ek1), z);
+          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, EK0, EK1), z);
           f32x4 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
           if (tr) {
-            reinterpret_cast<f32x4*>(a.term_obs)[(size_t)n * per + c] = o;
+            reinterpret_cast<f32x4*>(ar.term_obs)[(size_t)n * per + c] = o;
             *reinterpret_cast<f32x4*>(&trow[4 * c]) = o;
-            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
+            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, EK0, EK1), z);
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
           }
-          reinterpret_cast<f32x4*>(a.obs)[onext + c] = o;
+          reinterpret_cast<f32x4*>(ar.obs)[onext + c] = o;
           *reinterpret_cast<f32x4*>(&xrow[4 * c]) = o;
         }
         if (sub == 0) {
@@ -1116,24 +1172,24 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
         }
       } else {
         g = goal_load(S);
-        const GoalOutcome o = goal_advance(g, a.goal, &lds[L::CA + rr * 33], A);
+        const GoalOutcome o = goal_advance(g, ar.goal, &lds[L::CA + rr * 33], A);
         tr = o.tr; done = o.done; reached = o.reached; reward = o.reward;
         ep_ret = g.ep_ret; ep_len_fin = g.ep_len;
         GoalState gn = g;
-        if (done) goal_reset(gn, a.goal, o.reached, (uint32_t)n, step, ek0, ek1);
+        if (done) goal_reset(gn, ar.goal, o.reached, (uint32_t)n, step, EK0, EK1);
         for (int c = sub; c < per; c += 8) {
           float z[4];
-          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, ek0, ek1), z);
-          f32x4 ob = goal_features(g, a.goal.P, D, c, z, a.goal.noise);
+          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, EK0, EK1), z);
+          f32x4 ob = goal_features(g, ar.goal.P, D, c, z, ar.goal.noise);
           if (done) {
             if (tr) {
-              reinterpret_cast<f32x4*>(a.term_obs)[(size_t)n * per + c] = ob;
+              reinterpret_cast<f32x4*>(ar.term_obs)[(size_t)n * per + c] = ob;
               *reinterpret_cast<f32x4*>(&trow[4 * c]) = ob;
             }
-            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, ek0, ek1), z);
-            ob = goal_features(gn, a.goal.P, D, c, z, a.goal.noise);
+            box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvTerm, EK0, EK1), z);
+            ob = goal_features(gn, ar.goal.P, D, c, z, ar.goal.noise);
           }
-          reinterpret_cast<f32x4*>(a.obs)[onext + c] = ob;
+          reinterpret_cast<f32x4*>(ar.obs)[onext + c] = ob;
           *reinterpret_cast<f32x4*>(&xrow[4 * c]) = ob;
         }
         g = gn;
@@ -1142,16 +1198,16 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
     // the 8 threads of a row sit in ONE wave and have consumed the row's old state (program order): commit
     if (live && sub == 0) {
       const size_t so = (size_t)t * N + n;
-      a.es[so] = S[12];
+      ar.es[so] = S[12];
       S[12] = done ? 1.f : 0.f;
-      a.trunc[n] = tr ? 1 : 0;
-      if (a.kind == 1) {
+      ar.trunc[n] = tr ? 1 : 0;
+      if (ar.kind == 1) {
         reinterpret_cast<int*>(S)[13] = ep_len_new;
       } else {
         goal_store(S, g);
         if (done) {  // Monitor statistics: accumulated per thread, flushed once per launch (see the kernel end)
           es_n += 1.0; es_ret += (double)ep_ret; es_len += (double)ep_len_fin; es_goal += reached ? 1.0 : 0.0;
-          ep_ring_push(a.ep_stats, ep_ret, (float)ep_len_fin);
+          ep_ring_push(ar.ep_stats, ep_ret, (float)ep_len_fin);
         }
       }
       if (tr) {  // reward is written after the bootstrap below
@@ -1159,10 +1215,10 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
         lrow[q] = rr;
         lrew[q] = reward;
       } else {
-        a.rewards[so] = reward;
+        ar.rewards[so] = reward;
       }
     }
-    __syncthreads();  // next observation tile, row state and the bootstrap list are complete
+    __syncthreads(); ap_ = rollout_kernargs();  // next observation tile, row state and the bootstrap list are complete
     // ---- time-limit bootstrap of the (rare) truncated rows: wave 0 evaluates the value MLP row by row ----
     const int m = *cnt;
     if (m > 0) {  // block-uniform
@@ -1170,14 +1226,14 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
         for (int q = 0; q < m; ++q) {
           const int br = lrow[q];
           float* sc = &lds[L::H1];  // h1 is dead: scratch h1[G1] | h2[G2]
-          const float v = value_row_wave(&lds[L::H2 + br * GLDH], sc, sc + a.bt.G1, a.bt, D, lane);
+          const float v = value_row_wave(&lds[L::H2 + br * GLDH], sc, sc + ar.bt.G1, ar.bt, D, lane);
           if (lane == 0) {
-            a.bt.term_val[row0 + br] = v;
-            a.rewards[(size_t)t * N + row0 + br] = (float)((double)lrew[q] + (double)__fmul_rn(a.bt.gamma, v));
+            ar.bt.term_val[row0 + br] = v;
+            ar.rewards[(size_t)t * N + row0 + br] = (float)((double)lrew[q] + (double)__fmul_rn(ar.bt.gamma, v));
           }
         }
       }
-      __syncthreads();
+      __syncthreads(); ap_ = rollout_kernargs();
       if (tid == 0) *cnt = 0;  // read again only after the next step's barriers
     }
   }
@@ -1203,5 +1259,8 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
     }
   }
 }
+#undef ar
+#undef EK0
+#undef EK1
 
 }  // namespace mobrob
