@@ -617,6 +617,8 @@ def bench_single(args, name, steps, warmup, job, phases):
         hb = dict(obs=eng.pinned((N, D)), clip=eng.pinned((N, A)), rew=eng.pinned((N,)), done=eng.pinned((N,), np.uint8),
                   trunc=eng.pinned((N,), np.uint8), term=eng.pinned((N, D)))
         host.use_buffers(obs=hb["obs"], rewards=hb["rew"], dones=hb["done"], truncated=hb["trunc"], terminal_obs=hb["term"])
+        if getattr(args, "host_env_threads", 0):
+            host.set_threads(args.host_env_threads)
         host.reset()
         pipe = (eng.part_pipeline(args.host_parts, hb["obs"], hb["clip"], hb["rew"], hb["done"], hb["trunc"], hb["term"])
                 if args.host_parts > 1 else None)
@@ -835,24 +837,40 @@ def host_path_measurements(args, job):
                         eng.store(hb["rew"], hb["done"], hb["trunc"] if nt else None, hb["term"] if nt else None)
                     eng.finish_rollout(hb["obs"], hb["done"])
             return run
+        # Every leg is timed INSIDE a PPO iteration -- leg, then the five-epoch update -- as (iteration - update alone): a rollout of
+        # small launches does not keep the GPU's clocks up by itself, and a leg timed on a GPU that has just idled through the
+        # CPU-only legs read 40 % longer than the same loop does between two updates (the only place it ever runs).
         gpu_alone()                                            # warm-up (first launches, pinned mappings)
-        t_sim = min(timed(sim_alone, sync) for _ in range(2))
-        t_gpu = min(timed(gpu_alone, sync) for _ in range(2))
-        sweep = {}
-        for parts in (1, 2, 4, 8):
-            run = collector(parts)
+        eng.train(None)
+        reps = 2
+
+        def in_iteration(leg):
+            def run():
+                for _ in range(reps):
+                    leg()
+                    if leg is sim_alone:                       # the simulator leg leaves no rollout to train on: the last one stays
+                        eng.mark_rollout_ready()
+                    eng.train(None)
             run()
-            sweep[parts] = min(timed(run, sync) for _ in range(2))
+            return timed(run, sync) / reps
+        t_upd = in_iteration(lambda: None)
+        t_sim = in_iteration(sim_alone) - t_upd
+        t_gpu = in_iteration(gpu_alone) - t_upd
+        sweep = {}
+        for parts in (2, 4, 8, 1):
+            sweep[parts] = in_iteration(collector(parts)) - t_upd
         best = min(sweep, key=sweep.get)
         us = lambda t: 1e6 * t / T   # noqa: E731 - microseconds per vector step of N environments
         res["native-c-env (csrc/host_env.c), pinned zero-copy, mobrob_ppo_collect_host"] = {
             "envs": N, "steps_per_rollout": T, "env_threads": host.threads,
             "us_per_vector_step": {"host_sim_alone": us(t_sim), "gpu_act_store_alone": us(t_gpu),
                                    "pipelined": {f"host_parts={k}" + (" (Python loop, whole batch per step)" if k == 1 else ""): us(v)
-                                                 for k, v in sweep.items()}},
+                                                 for k, v in sorted(sweep.items())}},
             "collector_overhead_us_per_step": us(sweep[best]) - max(us(t_sim), us(t_gpu)),
             "rollout_only_env_steps_per_s": N * T / sweep[best], "best_host_parts": best,
-            "note": "overhead = pipelined wall minus the longer of its two legs: what the hand-off itself costs once sim and policy overlap",
+            "update_ms": 1e3 * t_upd,
+            "note": ("every leg = (leg + update) - update alone, inside PPO iterations (GPU clocks as in the real loop); overhead = pipelined "
+                     "wall minus the longer of its two legs: what the hand-off itself costs once sim and policy overlap"),
         }
         host.close()
         eng.close()
@@ -979,6 +997,7 @@ def main():
                          "at the headline shape)")
     ap.add_argument("--host-python-loop", action="store_true",
                     help="host-env workloads: drive the pipelined rollout from Python instead of mobrob_ppo_collect_host")
+    ap.add_argument("--host-env-threads", type=int, default=0, help="host-env workloads: OpenMP team of the native env (0: its default)")
     ap.add_argument("--host-parts", type=int, default=2,
                     help="host-env workloads: row ranges of the pipelined rollout (1 = whole batch per step)")
     ap.add_argument("--dry-run-cpu", action="store_true",

@@ -6,6 +6,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1272,6 +1274,75 @@ int mobrob_ppo_collect_host(mobrob_ppo_engine_t* e, mobrob_env_step_range_fn ste
   CHK(mobrob_ppo_rollout_begin(e));
   for (int p = 0; p < nparts; ++p) CHK(mobrob_ppo_act_part(e, p, nparts, obs, actions_clipped));
   const bool timing = getenv("MOBROB_COLLECT_TIMING") != nullptr;
+  // Two host threads (round 5, OPT-IN: MOBROB_COLLECT_THREADS=1).  The single-thread loop below spends, per vector step of 4096 envs at
+  // two parts (MOBROB_COLLECT_TIMING=1, profiles/r5/host_path_timing.txt): 55 us stepping the simulator, 12 us in HIP calls (two
+  // launches and an event record per part), 16 - 21 us waiting for the policy's actions.  With a DRIVER thread that owns the stream
+  // -- it turns "part p stepped" into store_part + act_part and "act of part p finished" (hipEventQuery, no blocking wait) into
+  // "part p ready" -- the calling thread only steps the environment.  Same kernels, same per-part order on the one stream: the rollout
+  // is the single-thread loop's bit for bit.  MEASURED (whole iteration, same box, alternating): 198.2 / 198.9 ms single thread,
+  // 200.0 - 203.4 ms with the driver thread (16, 15 or 14 env threads): what bounds a part's cycle is sim -> launch latency -> two small
+  // kernels -> sim, and the spinning driver takes a core from the simulator's team.  Kept for hosts with cores to spare; off by default.
+  const bool threaded = nparts >= 2 && !timing && getenv("MOBROB_COLLECT_THREADS") && atoi(getenv("MOBROB_COLLECT_THREADS")) != 0;
+  if (threaded) {
+    struct Shared {
+      std::atomic<int> ready[MOBROB_MAX_PARTS];     // acts of part p the GPU has finished (actions of step ready - 1 are in host memory)
+      std::atomic<int> simdone[MOBROB_MAX_PARTS];   // steps of part p the simulator has finished
+      std::atomic<int> ntrunc[MOBROB_MAX_PARTS];    // truncated rows of the part's newest step
+      std::atomic<int> err{0};
+    } sh;
+    for (int p = 0; p < MOBROB_MAX_PARTS; ++p) { sh.ready[p] = 0; sh.simdone[p] = 0; sh.ntrunc[p] = 0; }
+    std::string driver_msg;
+    int driver_rc = MOBROB_OK;
+    const int T = e->T;
+    std::thread driver([&] {
+      if (hipSetDevice(e->cfg.device_id) != hipSuccess) { driver_rc = MOBROB_ERR_HIP; driver_msg = "collect_host driver: hipSetDevice failed"; sh.err = 1; return; }
+      int acted[MOBROB_MAX_PARTS], synced[MOBROB_MAX_PARTS], stored[MOBROB_MAX_PARTS];
+      for (int p = 0; p < nparts; ++p) { acted[p] = 1; synced[p] = 0; stored[p] = 0; }
+      for (;;) {
+        bool all_done = true, progress = false;
+        for (int p = 0; p < nparts && !sh.err.load(std::memory_order_relaxed); ++p) {
+          if (synced[p] < acted[p]) {                       // the part's newest act: finished?
+            const hipError_t q = hipEventQuery(e->ev_part[p]);
+            if (q == hipSuccess) {
+              synced[p] = acted[p];
+              sh.ready[p].store(synced[p], std::memory_order_release);
+              progress = true;
+            } else if (q != hipErrorNotReady) {
+              driver_rc = MOBROB_ERR_HIP; driver_msg = std::string("collect_host driver: ") + hipGetErrorString(q); sh.err = 1;
+            }
+          }
+          if (stored[p] < T && sh.simdone[p].load(std::memory_order_acquire) > stored[p]) {   // the part was stepped: store, act again
+            const int nt = sh.ntrunc[p].load(std::memory_order_relaxed);
+            int rc = mobrob_ppo_store_part(e, p, nparts, rewards, dones, nt ? truncated : nullptr, nt ? terminal_obs : nullptr, obs);
+            ++stored[p];
+            if (rc == MOBROB_OK && stored[p] < T) { rc = mobrob_ppo_act_part(e, p, nparts, obs, actions_clipped); ++acted[p]; }
+            if (rc != MOBROB_OK) { driver_rc = rc; driver_msg = g_err; sh.err = 1; }
+            progress = true;
+          }
+          if (stored[p] < T) all_done = false;
+        }
+        if (all_done || sh.err.load(std::memory_order_relaxed)) break;
+        if (!progress) __builtin_ia32_pause();
+      }
+    });
+    int sim_rc = MOBROB_OK;
+    for (int t = 0; t < T && !sh.err.load(std::memory_order_relaxed); ++t) {
+      for (int p = 0; p < nparts; ++p) {
+        int r0, n;
+        if (part_range(e, p, nparts, &r0, &n) != MOBROB_OK) { sim_rc = MOBROB_ERR_INVALID; sh.err = 1; break; }
+        while (sh.ready[p].load(std::memory_order_acquire) < t + 1 && !sh.err.load(std::memory_order_relaxed)) __builtin_ia32_pause();
+        if (sh.err.load(std::memory_order_relaxed)) break;
+        const int32_t ntrunc = step_range(env, r0, r0 + n, actions_clipped, obs, rewards, dones, truncated, terminal_obs);
+        if (ntrunc < 0) { sim_rc = MOBROB_ERR_STATE; sh.err = 1; break; }
+        sh.ntrunc[p].store(ntrunc, std::memory_order_relaxed);
+        sh.simdone[p].store(t + 1, std::memory_order_release);
+      }
+    }
+    driver.join();
+    if (driver_rc != MOBROB_OK) return fail(driver_rc, "%s", driver_msg.c_str());
+    if (sim_rc != MOBROB_OK) return fail(sim_rc, "collect_host: the environment's step_range failed");
+    return mobrob_ppo_finish_rollout(e, obs, dones);
+  }
   double tw = 0, te = 0, tq = 0;
   auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
   for (int t = 0; t < e->T; ++t) {

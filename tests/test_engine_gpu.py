@@ -347,7 +347,7 @@ def test_pipelined_part_rollout_equals_whole_batch_rollout(robot, hidden, N, par
     p = O.init_params(D, A, (hidden, hidden), (hidden, hidden), seed=4)
     keys = ("obs", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns", "last_values")
     out = {}
-    for mode in ("whole", "parts", "native"):
+    for mode in ("whole", "parts", "native", "native-threads"):
         e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=64, n_epochs=1, seed=9,
                         pi=(hidden, hidden), vf=(hidden, hidden))
         e.set_params(p)
@@ -363,9 +363,14 @@ def test_pipelined_part_rollout_equals_whole_batch_rollout(robot, hidden, N, par
                     e.act(b["obs"], out_clipped=b["clip"], want_all=False)
                     nt = env.step_arrays(b["clip"])[5]
                     e.store(b["rew"], b["done"], b["trunc"] if nt else None, b["term"] if nt else None)
-            elif mode == "native":  # the same pipeline as one C call (mobrob_ppo_collect_host), finish_rollout included
-                e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"]).collect(
-                    env.step_range_fn, env.handle)
+            elif mode.startswith("native"):  # the same pipeline as one C call (mobrob_ppo_collect_host), finish_rollout included;
+                # "-threads": the opt-in two-thread collector (a driver thread owns the stream, the caller steps the env)
+                os.environ["MOBROB_COLLECT_THREADS"] = "1" if mode.endswith("threads") else "0"
+                try:
+                    e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"]).collect(
+                        env.step_range_fn, env.handle)
+                finally:
+                    os.environ.pop("MOBROB_COLLECT_THREADS", None)
                 continue
             else:
                 pipe = e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"])
@@ -396,7 +401,7 @@ def test_pipelined_part_rollout_equals_whole_batch_rollout(robot, hidden, N, par
         env.close()
         e.close()
     assert out["whole"]["stats"]["episodes"] > N  # truncations and goals happened
-    for mode in ("parts", "native"):
+    for mode in ("parts", "native", "native-threads"):
         for k in keys:
             assert np.array_equal(out["whole"][k], out[mode][k]), (mode, k)
         sw, sp = out["whole"]["stats"], out[mode]["stats"]
