@@ -19,8 +19,10 @@ Appendix A) and is pinned by
 
 PARITY STATUS: the reference ships no tests for this path -> "parity
 unpinned by reference tests"; it is pinned only by the artefacts and torch-op goldens above.
-(The only reference-HELD outputs are the `observation_space` / `action_space` blobs inside the
-zips; they pin the checkpoint writer, tests/golden/reference_spaces.json, not this arithmetic.)
+(Reference-HELD outputs exist for two things, neither of them this arithmetic: the `observation_space` /
+`action_space` blobs inside the zips pin the checkpoint writer, tests/golden/reference_spaces.json; the counters
+the five checkpoints were saved with -- num_timesteps, _n_updates, Adam's step, _current_progress_remaining -- pin the
+learn loop's bookkeeping, `learn_loop_counters` below, tests/golden/reference_counters.json.)
 
 `loss_and_grads(..., acc=np.float64)` accumulates every contraction in float64 (products of
 float32 are exact there): the mode the full-size parity tests use, so that the checker's own
@@ -530,6 +532,39 @@ def train(p, st, buf, h: Hyper, perms):
             if out[-1].get("early_stop"):
                 return out
     return out
+
+
+# --------------------------------------------------------------------------------------
+# learn-loop bookkeeping [SB3 common/on_policy_algorithm.py OnPolicyAlgorithm.learn / collect_rollouts, ppo/ppo.py PPO.train,
+# common/callbacks.py CheckpointCallback], reached through /root/reference/src/mobrob/rl_control/ppo.py:73-74 from
+# /root/reference/examples/train.py:36-46.  Pinned by REFERENCE-HELD outputs: the counters the five reference checkpoints were
+# saved with (tests/golden/reference_counters.json, tests/test_oracle.py::test_learn_loop_counters_equal_the_reference_checkpoints).
+# --------------------------------------------------------------------------------------
+def learn_loop_counters(total_timesteps, n_steps, n_envs, batch_size, n_epochs, checkpoint_at_timestep=None):
+    """The counters SB3 leaves behind after `learn(total_timesteps)` -- or, with `checkpoint_at_timestep`, the ones a
+    CheckpointCallback that fires at that `num_timesteps` (inside collect_rollouts, `train.py:37`: save_freq // n_envs vector
+    steps) writes into its zip.
+        while num_timesteps < total:   collect n_steps vector steps (num_timesteps += n_envs each; callbacks fire per step)
+                                       _current_progress_remaining = 1 - num_timesteps / total
+                                       train(): n_epochs x ceil(n_steps n_envs / batch_size) Adam steps, _n_updates += n_epochs
+    -> dict(num_timesteps, _n_updates, adam_step, _current_progress_remaining, iterations)"""
+    per_rollout = n_steps * n_envs
+    n_minibatches = -(-per_rollout // batch_size)
+    num_timesteps = n_updates = adam_step = iterations = 0
+    progress = 1.0
+    while num_timesteps < total_timesteps:
+        if checkpoint_at_timestep is not None and num_timesteps < checkpoint_at_timestep <= num_timesteps + per_rollout:
+            # saved from on_step during this rollout's collection: the rollout is not trained on yet, and
+            # _current_progress_remaining is still the previous iteration's
+            return dict(num_timesteps=checkpoint_at_timestep, _n_updates=n_updates, adam_step=adam_step,
+                        _current_progress_remaining=progress, iterations=iterations)
+        num_timesteps += per_rollout
+        iterations += 1
+        progress = 1.0 - float(num_timesteps) / float(total_timesteps)
+        adam_step += n_epochs * n_minibatches
+        n_updates += n_epochs
+    return dict(num_timesteps=num_timesteps, _n_updates=n_updates, adam_step=adam_step, _current_progress_remaining=progress,
+                iterations=iterations)
 
 
 # --------------------------------------------------------------------------------------

@@ -53,6 +53,38 @@ def test_ppoctrl_from_config_learn_save_load_predict(tmp_path):
     assert a3.shape == (2,) and np.array_equal(a3, a1[0])
 
 
+@pytest.mark.parametrize("total,ckpt", [(1000, None), (900, None), (1200, 800)])
+def test_learn_loop_counters_follow_the_reference_pinned_bookkeeping(tmp_path, total, ckpt):
+    """`PPO.learn`'s counters against `oracle.learn_loop_counters`, the restatement that reproduces the counters of all five
+    reference checkpoints (tests/test_oracle.py, tests/golden/reference_counters.json): a budget the rollouts divide, one they
+    overshoot (as the reference's drone run did: num_timesteps > total, negative progress), and a CheckpointCallback firing in
+    the middle of a rollout's collection (as in the reference's doggo zip: the rollout being collected is counted in
+    num_timesteps, not yet trained on, and `_current_progress_remaining` is still the previous iteration's)."""
+    import zipfile
+    import json
+    from mobrob_amd.rl_control.ppo import CheckpointCallback, PPOCtrl
+    n_envs, n_steps, n_epochs, batch = 4, 50, 3, 64           # 200 timesteps per rollout, four minibatches (the last one short)
+    cfg = _config("point", n_envs=n_envs, time_limit=20, ppo_kwargs=dict(n_steps=n_steps, n_epochs=n_epochs, batch_size=batch, verbose=0))
+    ctrl = PPOCtrl.from_config(cfg)
+    cb = CheckpointCallback(save_freq=ckpt // n_envs, save_path=str(tmp_path), name_prefix="t") if ckpt else None
+    ctrl.learn(total_timesteps=total, callback=cb, progress_bar=False)
+    want = O.learn_loop_counters(total, n_steps, n_envs, batch, n_epochs)
+    ppo = ctrl.ppo
+    _, _, adam_step = ppo.engine.get_optimizer_state()
+    assert (ppo.num_timesteps, ppo._n_updates, adam_step) == (want["num_timesteps"], want["_n_updates"], want["adam_step"])
+    assert abs(ppo._current_progress_remaining - want["_current_progress_remaining"]) < 1e-12
+    if ckpt:
+        at = O.learn_loop_counters(total, n_steps, n_envs, batch, n_epochs, checkpoint_at_timestep=ckpt)
+        z = zipfile.ZipFile(str(tmp_path / f"t_{ckpt}_steps.zip"))
+        d = json.loads(z.read("data"))
+        assert (d["num_timesteps"], d["_n_updates"]) == (at["num_timesteps"], at["_n_updates"]), (d["num_timesteps"], d["_n_updates"], at)
+        assert abs(d["_current_progress_remaining"] - at["_current_progress_remaining"]) < 1e-12
+        import io
+        import torch
+        opt = torch.load(io.BytesIO(z.read("policy.optimizer.pth")), map_location="cpu", weights_only=True)
+        assert {int(v["step"]) for v in opt["state"].values()} == {at["adam_step"]}
+
+
 def test_unknown_vec_env_type_raises_value_error():
     from mobrob_amd.rl_control.ppo import PPOCtrl
     with pytest.raises(ValueError, match="Unknown vec_env_type"):

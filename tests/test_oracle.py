@@ -283,3 +283,22 @@ def test_torch_baseline_matches_the_oracle():
     got = pol.state()
     for k in q:
         assert np.max(np.abs(got[k] - q[k])) < 2e-5, (k, float(np.max(np.abs(got[k] - q[k]))))
+
+
+def test_learn_loop_counters_equal_the_reference_checkpoints():
+    """The counters SB3's learn loop left in the five reference zips (reference-HELD outputs: tests/golden/reference_counters.json,
+    made by tests/golden/make_counter_fixture.py) against the oracle's restatement of the loop's bookkeeping: what a timestep
+    is, when the loop stops (drone overshoots its 1 000 000 by a whole rollout, progress -0.008), that `_n_updates` counts epochs
+    and Adam counts minibatches, and what a CheckpointCallback sees mid-collection (doggo: saved at 30 M of 50 M, after 1874
+    trained rollouts, `_current_progress_remaining` = 1 - 1874 * 16000 / 5e7)."""
+    import json
+    import os
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_counters.json")))
+    assert set(ref) == {"point", "car", "doggo", "drone", "turtlebot3"}
+    for env, r in ref.items():
+        finished = r["num_timesteps"] >= r["_total_timesteps"]
+        got = O.learn_loop_counters(r["_total_timesteps"], r["n_steps"], r["n_envs"], r["batch_size"], r["n_epochs"],
+                                    checkpoint_at_timestep=None if finished else r["num_timesteps"])
+        for k in ("num_timesteps", "_n_updates", "adam_step"):
+            assert got[k] == r[k], (env, k, got[k], r[k])
+        assert abs(got["_current_progress_remaining"] - r["_current_progress_remaining"]) < 1e-12, (env, got, r)
