@@ -926,7 +926,10 @@ def host_path_measurements(args, job):
         res["ShmVecEnv (vec_env_type: subproc), 4096 Python EnvWrapper instances"] = {
             "envs": N, "steps_per_rollout": Ts, "workers": getattr(env, "n_workers", None), "host_parts": ppo.host_parts,
             "us_per_vector_step": {"host_sim_alone": us2(t_sim), "gpu_act_store_alone": us2(t_gpu), "pipelined": us2(t_pipe)},
-            "collector_overhead_us_per_step": us2(t_pipe) - max(us2(t_sim), us2(t_gpu)),
+            # (the simulator-alone leg -- the same per-range commands, uniform random actions, nothing between them -- has read
+            #  LONGER than the pipelined rollout on every box: the Python environments' step time depends on what they are doing
+            #  and the workers' wake-ups on the command cadence; an "overhead" is quoted only when the legs bracket the pipeline)
+            "collector_overhead_us_per_step": (us2(t_pipe) - max(us2(t_sim), us2(t_gpu))) if t_pipe >= max(t_sim, t_gpu) else None,
             "rollout_only_env_steps_per_s": N * Ts / t_pipe,
             "learn_env_steps_per_s": N * Ts / t_learn,
             "note": "kinematic stand-in behind the EnvWrapper surface (no MuJoCo / Bullet on the box); bounded sample of 32 vector steps per rollout",
