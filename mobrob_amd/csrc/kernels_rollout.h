@@ -97,6 +97,9 @@ inline size_t rollout_lds_bytes(int Dp, bool s8 = false) {
 // wave slot of every SIMD and therefore exclude this plan.  A/B on one box: 15.49 ms per 1000-step rollout of
 // 4096 envs against 14.69 ms with streamed fragments + noise waves (15.07 ms in round 2) -- the weight stream was never
 // what paced the step; 352 resident registers cost v_accvgpr_read copies in front of the MFMAs instead.
+#ifndef MOBROB_S8_STAGGER
+#define MOBROB_S8_STAGGER 2
+#endif
 #ifndef MOBROB_ROLLOUT_STATIONARY
 #define MOBROB_ROLLOUT_STATIONARY 0
 #endif
@@ -301,6 +304,10 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
           return f;
         };
         X3Frag U = frag(0);
+        // The two waves of a SIMD run the same k loop: left alone they reach their LDS read bursts and their MFMAs together.  The
+        // second-dispatched half starts the loop 128 cycles late (MI355X_MICROARCH.md, two waves per SIMD, item 9): rollout 10.37 ->
+        // 10.15 ms on one box, two alternations (s_sleep 4: the same; static priority for that half instead: 10.68).  Timing only.
+        if (MOBROB_S8_STAGGER > 0 && wave >= 4) __builtin_amdgcn_s_sleep(MOBROB_S8_STAGGER);
         if (ROLL_ON(4)) {
 #pragma unroll
           for (int ks = 0; ks < FH / 16; ++ks) {
