@@ -28,6 +28,9 @@ __global__ __launch_bounds__(NT, NT / 256) void k(int iters, float* out, unsigne
   int base = 4 * lane;
   asm volatile("" : "+v"(base));
   base = 4 * (base >> 2);
+#ifdef PROBE_STAGGER   // the four (eight) waves of the workgroup enter the loop PROBE_STAGGER x wave cycles apart (are they slower in lockstep?)
+  for (int k = 0; k < (int)(threadIdx.x >> 6) * (PROBE_STAGGER / 4); ++k) asm volatile("s_nop 0");
+#endif
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
