@@ -1294,7 +1294,7 @@ int mobrob_ppo_collect_host(mobrob_ppo_engine_t* e, mobrob_env_step_range_fn ste
     std::string driver_msg;
     int driver_rc = MOBROB_OK;
     const int T = e->T;
-    std::thread driver([&] {
+    auto driver_body = [&] {
       if (hipSetDevice(e->cfg.device_id) != hipSuccess) { driver_rc = MOBROB_ERR_HIP; driver_msg = "collect_host driver: hipSetDevice failed"; sh.err = 1; return; }
       int acted[MOBROB_MAX_PARTS], synced[MOBROB_MAX_PARTS], stored[MOBROB_MAX_PARTS];
       for (int p = 0; p < nparts; ++p) { acted[p] = 1; synced[p] = 0; stored[p] = 0; }
@@ -1324,7 +1324,14 @@ int mobrob_ppo_collect_host(mobrob_ppo_engine_t* e, mobrob_env_step_range_fn ste
         if (all_done || sh.err.load(std::memory_order_relaxed)) break;
         if (!progress) __builtin_ia32_pause();
       }
-    });
+    };
+    std::thread driver;
+    try {
+      driver = std::thread(driver_body);
+    } catch (...) {   // no thread to be had: nothing has been stepped yet, so the single-thread loop below takes over from here
+      driver = std::thread();
+    }
+    if (driver.joinable()) {
     int sim_rc = MOBROB_OK;
     for (int t = 0; t < T && !sh.err.load(std::memory_order_relaxed); ++t) {
       for (int p = 0; p < nparts; ++p) {
@@ -1342,6 +1349,7 @@ int mobrob_ppo_collect_host(mobrob_ppo_engine_t* e, mobrob_env_step_range_fn ste
     if (driver_rc != MOBROB_OK) return fail(driver_rc, "%s", driver_msg.c_str());
     if (sim_rc != MOBROB_OK) return fail(sim_rc, "collect_host: the environment's step_range failed");
     return mobrob_ppo_finish_rollout(e, obs, dones);
+    }
   }
   double tw = 0, te = 0, tq = 0;
   auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
