@@ -62,7 +62,9 @@ struct Lay32S {
   static constexpr int H1 = X + R * LDX;                      // planes [3][32][264] bf16 (scratch of the bootstrap afterwards)
   static constexpr int H2 = H1 + kPlaneFloats;
   static constexpr int DO = H2 + R * FLDH;
-  static constexpr int END = DO + 4 * R * FLDO;
+  static constexpr int XP = DO + 4 * R * FLDO;                 // the observation tile as three bf16 planes [3][32][DP + 8] (MOBROB_S8_XPLANES)
+  static constexpr int XLD = DP + 8;                           // bf16 elements per plane row: 36 words at DP = 64, conflict-free b128 fragment reads
+  static constexpr int END = XP + 3 * R * XLD / 2;
 };
 template <int DP, bool S8 = false>
 struct LayRo {
@@ -77,7 +79,7 @@ struct LayRo {
   static constexpr int END = EN + 2 * 32 * DP;
 };
 inline size_t rollout_lds_bytes(int Dp, bool s8 = false) {
-  return fused_lds_act_bytes(Dp) + (s8 ? (size_t)(kPlaneFloats - 32 * FLDH) * sizeof(float) : 0) +
+  return fused_lds_act_bytes(Dp) + (s8 ? (size_t)(kPlaneFloats - 32 * FLDH + 3 * 32 * (Dp + 8) / 2) * sizeof(float) : 0) +
          (size_t)(32 * 33 + 32 * 16 + 68 + 128 + 2 * 32 * 32 + 32 * 33 + 2 * 32 * Dp) * sizeof(float);
 }
 // The workgroup is EIGHT waves: four run the policy forward / sampling / env rules of the tile (one per SIMD, as before),
@@ -138,6 +140,25 @@ __device__ __forceinline__ RolloutArgsK rollout_kernargs() {
   RolloutArgsK p = (RolloutArgsK)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(p));   // opaque per use: the loads behind it are not hoisted out of the step loop
   return p;
+}
+
+#ifndef MOBROB_S8_W1_FIRST
+#define MOBROB_S8_W1_FIRST 1
+#endif
+#ifndef MOBROB_S8_XPLANES   // S8: the observation tile is kept as bf16 planes too (split once by whoever writes it) and layer 1 reads fragments, no VALU
+#define MOBROB_S8_XPLANES 1
+#endif
+// four consecutive columns 4 c .. 4 c + 3 of row rr -> the three planes (each piece: four bf16 = one 8-byte store)
+template <class LS>
+__device__ __forceinline__ void xplanes_store4(int rr, int c, const f32x4& o) {
+  unsigned a1, a2, a3, b1, b2, b3;
+  x3_split2(o[0], o[1], a1, a2, a3);
+  x3_split2(o[2], o[3], b1, b2, b3);
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const int f0 = LS::XP + (rr * LS::XLD + 4 * c) / 2;            // float offset of the first plane's quad (XLD and 4 c are even)
+  *reinterpret_cast<u32x2*>(&lds[f0]) = u32x2{a1, b1};
+  *reinterpret_cast<u32x2*>(&lds[f0 + 32 * LS::XLD / 2]) = u32x2{a2, b2};
+  *reinterpret_cast<u32x2*>(&lds[f0 + 64 * LS::XLD / 2]) = u32x2{a3, b3};
 }
 
 // KIND: the env source compiled in (1 synthetic, 2 goal environment; = a.kind): one variant carries one env's scalars -- with both in
@@ -209,6 +230,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
     if (row0 + rr < N)
       v = ldg16(a.obs, (unsigned)((size_t)a.t0 * N + row0 + rr) * (unsigned)(DP * 4) + (unsigned)(c * 16));
     *reinterpret_cast<f32x4*>(&lds[LB::X + rr * ldx + 4 * c]) = v;
+    if constexpr (S8 && MOBROB_S8_XPLANES) xplanes_store4<LB>(rr, c, v);
   }
   __syncthreads();
   const uint32_t dbase = a.draw_base ? *a.draw_base : 0u, sbase = a.step_base ? *a.step_base : 0u;
@@ -243,10 +265,19 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
   constexpr int NKS1s = S8 ? DP / 16 : 1;
   constexpr int kP2 = 3;
   u32x4 P2[kP2 + 1];
+  // ... and (synthetic source only: the goal env's phases have no registers to spare) the three pieces of W1's FIRST k step, so that
+  // layer 1's first six MFMAs do not wait for the weight fragments requested at its start
+  constexpr bool kW1First = S8 && KIND == 1 && MOBROB_S8_W1_FIRST;
+  X3Frag P10;
   auto s8_prefetch = [&]() {
     const u32x4* b2x = W2x + (size_t)wave * (FH / 16) * 192 + (tid0 & 63);
 #pragma unroll
     for (int k = 0; k < kP2; ++k) P2[k] = b2x[(k * 3 + 2) * 64];
+    if constexpr (kW1First) {
+      const u32x4* b1x = W1x + (size_t)wave * NKS1s * 192 + (tid0 & 63);
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) P10.p[pc] = b1x[pc * 64];
+    }
   };
   // (not for the goal environment at 64 observation columns: twelve more registers through the env phase spilled there)
   constexpr bool kP2Ahead = S8 && !(KIND == 2 && DP == 64);
@@ -267,14 +298,22 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         const u32x4* b1x = W1x + (size_t)wave * NKS1 * 192 + lane;
         X3Frag P[NKS1s];
 #pragma unroll
-        for (int ks = 0; ks < NKS1; ++ks)
+        for (int ks = kW1First ? 1 : 0; ks < NKS1; ++ks)
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc) P[ks].p[pc] = b1x[(ks * 3 + pc) * 64];
+        if constexpr (kW1First) P[0] = P10;
         const int ab = 4 * opaque((LB::X + r * ldx + 8 * h) >> 2);
         if (ROLL_ON(2)) {
 #pragma unroll
           for (int ks = 0; ks < NKS1; ++ks) {
-            const X3Frag U = x3_split8(*reinterpret_cast<const f32x4*>(&lds[ab + 16 * ks]), *reinterpret_cast<const f32x4*>(&lds[ab + 16 * ks + 4]));
+            X3Frag U;
+            if constexpr (MOBROB_S8_XPLANES) {   // row r, columns 16 ks + 8 h .. + 7 of plane pc: float offset XP + (32 pc + r) XLD / 2 + 8 ks + 4 h
+              const int axp = 4 * opaque((LB::XP + r * (LB::XLD / 2) + 4 * h) >> 2);
+#pragma unroll
+              for (int pc = 0; pc < 3; ++pc) U.p[pc] = *reinterpret_cast<const u32x4*>(&lds[axp + pc * 32 * (LB::XLD / 2) + 8 * ks]);
+            } else {
+              U = x3_split8(*reinterpret_cast<const f32x4*>(&lds[ab + 16 * ks]), *reinterpret_cast<const f32x4*>(&lds[ab + 16 * ks + 4]));
+            }
             X3_MFMA6(U, P[ks], c0)
           }
         }
@@ -503,7 +542,8 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
             for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? zt[j] : 0.f;
           }
           if (ROLL_ON(128)) reinterpret_cast<f32x4*>(ar.obs)[onext + c] = o;
-          *reinterpret_cast<f32x4*>(&xrow[4 * c]) = o;
+          if constexpr (S8 && MOBROB_S8_XPLANES) xplanes_store4<LB>(rr, c, o);
+          else *reinterpret_cast<f32x4*>(&xrow[4 * c]) = o;
         }
         if (sub == 0) {
           float zz[4];
@@ -533,7 +573,8 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
             ob = goal_features(gn, ar.goal.P, D, c, z, ar.goal.noise);
           }
           if (ROLL_ON(128)) reinterpret_cast<f32x4*>(ar.obs)[onext + c] = ob;
-          *reinterpret_cast<f32x4*>(&xrow[4 * c]) = ob;
+          if constexpr (S8 && MOBROB_S8_XPLANES) xplanes_store4<LB>(rr, c, ob);
+          else *reinterpret_cast<f32x4*>(&xrow[4 * c]) = ob;
         }
         g = gn;
       }
