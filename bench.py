@@ -50,6 +50,11 @@ WORKLOADS = {
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 16 * PEAK_F32_MFMA_TFLOPS  # same table: the f32 matrix rate is "1/16 of BF16 MFMA" (~2.5 PF dense)
 X3_PRODUCTS = 6  # bf16 x bf16 MFMAs issued per float32 multiply-add of a product computed from three-way split operands
+# What the two matrix pipes SUSTAIN on this part under its 1400 W package cap (profiles/r5/mfma_power_probe.txt: a stream of nothing
+# but MFMAs on every SIMD for seconds, random operands): v_mfma_f32_16x16x32_bf16 at full issue rate holds 1.88 - 1.97 GHz, not 2.4;
+# v_mfma_f32 is not power limited.  Never the `peak` of the roofline object (that is the guide's figure) -- reported beside it.
+SUSTAINED_BF16_MFMA_TFLOPS = 1950.7
+SUSTAINED_F32_MFMA_TFLOPS = 155.0
 
 
 def f_fwd(D, H, A):
@@ -248,6 +253,56 @@ def blended_peak(D, H, A, x3_train):
     x3_share = (hidden_fwd + dh1 + dw2 + dw1) / (3.0 * f_fwd(D, H, A))
     ideal_s_per_flop = x3_share * X3_PRODUCTS / (PEAK_BF16_MFMA_TFLOPS * 1e12) + (1.0 - x3_share) / (PEAK_F32_MFMA_TFLOPS * 1e12)
     return 1.0 / ideal_s_per_flop / 1e12, x3_share
+
+
+def power_capped_peak(x3_share):
+    """The blended peak with the SUSTAINED rates of the two pipes in place of the nominal ones (see SUSTAINED_*_TFLOPS)."""
+    return 1.0 / (x3_share * X3_PRODUCTS / SUSTAINED_BF16_MFMA_TFLOPS + (1.0 - x3_share) / SUSTAINED_F32_MFMA_TFLOPS)
+
+
+def sample_power_and_clock(run, min_samples=4):
+    """Package power and shader clock (rocm-smi) while run() keeps the GPU busy: is the dominant kernel power limited?  rocm-smi
+    runs in a child process with a clean environment; the samples of the busy part (>= 90 % of the highest power seen) are kept."""
+    import re
+    import shutil
+    import signal
+    import statistics
+    import subprocess
+    import tempfile
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return {"error": "rocm-smi not found"}
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD",) and not k.startswith(("ROCP", "ROCPROF"))}
+    try:
+        cap = subprocess.run([smi, "--showmaxpower"], capture_output=True, text=True, timeout=20, env=env).stdout
+        m = re.search(r"Power \(W\):\s*([0-9.]+)", cap)
+        cap_w = float(m.group(1)) if m else None
+        with tempfile.TemporaryFile("w+") as log:
+            child = subprocess.Popen(["bash", "-c", f"while :; do {smi} --showclocks --showpower; sleep 0.25; done"], stdout=log,
+                                     stderr=subprocess.DEVNULL, env=env, start_new_session=True)
+            try:
+                run()
+            finally:
+                os.killpg(child.pid, signal.SIGTERM)   # the process group this function started, nothing else
+                child.wait()
+            log.seek(0)
+            text = log.read()
+    except Exception as ex:  # noqa: BLE001 -- a diagnostic leg never fails the bench
+        return {"error": f"{type(ex).__name__}: {ex}"}
+    samples, clk = [], None      # one rocm-smi call prints its clock lines first, then the power line
+    for m in re.finditer(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)|Power \(W\):\s*([0-9.]+)", text):
+        if m.group(1):
+            clk = int(m.group(1))
+        elif clk is not None:
+            samples.append((float(m.group(2)), clk))
+            clk = None
+    if len(samples) < min_samples:
+        return {"error": f"only {len(samples)} rocm-smi samples", "package_cap_w": cap_w}
+    top = max(p for p, _ in samples)
+    busy = [(p, c) for p, c in samples if p >= 0.9 * top]
+    return {"package_cap_w": cap_w, "samples": len(samples), "busy_samples": len(busy),
+            "package_power_w": statistics.median(p for p, _ in busy), "shader_clock_mhz": statistics.median(c for _, c in busy),
+            "how": "rocm-smi --showclocks --showpower every ~0.6 s during extra iterations AFTER the timed region; medians of the busy samples"}
 
 
 def dominant_kernel_name(H, rows_per_launch, generic, x3_train=False, chain=False):
@@ -764,6 +819,22 @@ def bench_single(args, name, steps, warmup, job, phases):
             out["rehearsal"] = {"what": f"{world} ranks time-sharing ONE GPU (MOBROB_DP_SAME_DEVICE=1): gloo process group, the C "
                                         f"loop mobrob_ppo_train_dp, sums through: {exchange}; no throughput is claimed",
                                 "env_steps_per_s_time_shared": value, "replicas_bit_identical": identical}
+    if out is not None and getattr(args, "power_leg", False) and not use_dp and host is None and name == "doggo-4096env-2x256":
+        # Is the dominant kernel power limited?  ~3 s of further iterations (outside the timed region) with rocm-smi sampled beside
+        # them, and the blended peak recomputed from what the two matrix pipes sustain under the package cap (a committed probe).
+        def busy():
+            for _ in range(max(8, int(3.0 * steps / max(dt, 1e-3)))):
+                iteration()
+            fence()
+        pw = sample_power_and_clock(busy)
+        if x3_train:
+            capped = power_capped_peak(x3_share)
+            pw.update({"power_capped_peak": capped, "frac_of_power_capped_peak": achieved / capped,
+                       "power_capped_peak_note": (f"the blended peak with the rates the pipes SUSTAIN under the package cap in place of the nominal ones: "
+                                                  f"bf16 MFMA {SUSTAINED_BF16_MFMA_TFLOPS} TFLOP/s (full issue rate, random operands, 1.88 - 1.97 GHz at ~1320 W), "
+                                                  f"f32 MFMA {SUSTAINED_F32_MFMA_TFLOPS} (not power limited); profiles/r5/mfma_power_probe.txt, "
+                                                  f"scratch/mfma_power_probe.hip -- a measured property of the part, not the roofline's `peak`")})
+        out["roofline"]["power"] = pw
     if use_dp and not identical:
         raise SystemExit("bench.py: the replicas' parameters differ between ranks")
     if use_dp:
@@ -962,7 +1033,7 @@ def also_measured(args, job):
         o = bench_single(a32, "doggo-4096env-2x256", 3, 1, job, False)
         res["doggo-4096env-2x256, forward_x3 off (all products on v_mfma_f32)"] = {
             "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": 3, "warmup": 1,
-            "roofline": {k: o["roofline"][k] for k in ("kernel", "achieved", "peak", "frac", "avg_launch_ms", "launches")}}
+            "roofline": {k: o["roofline"].get(k) for k in ("kernel", "achieved", "peak", "frac", "avg_launch_ms", "launches", "power")}}
     except Exception as ex:  # noqa: BLE001
         res["doggo-4096env-2x256, forward_x3 off (all products on v_mfma_f32)"] = {"error": f"{type(ex).__name__}: {ex}"}
     if not getattr(args, "no_host_path", False):
@@ -986,6 +1057,7 @@ def main():
     ap.add_argument("--workload", default="doggo-4096env-2x256", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the also_measured side configurations")
+    ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock samples (roofline.power; ~4 s after the timed region)")
     ap.add_argument("--no-host-path", action="store_true", help="also_measured: skip the host-env streaming path (native C env, ShmVecEnv)")
     ap.add_argument("--only-host-path", action="store_true", help="print only the host-env streaming-path measurements (one JSON line)")
     ap.add_argument("--generic", action="store_true", help="force the generic (unfused) kernels")
@@ -1041,6 +1113,7 @@ def main():
         job.finish()
         return
     fn = bench_fleet if "segments" in w else bench_single
+    args.power_leg = world == 1 and not args.no_power and not args.phases and not args.generic
     out = fn(args, args.workload, args.steps, args.warmup, job, args.phases)
     if rank == 0:
         if world == 1 and not job.use_dp and args.workload == "doggo-4096env-2x256" and not args.no_also and not args.generic:
