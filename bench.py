@@ -895,12 +895,18 @@ def host_path_measurements(args, job):
                 eng.store(hb["rew"], hb["done"], None, None)
             eng.finish_rollout(hb["obs"], hb["done"])
 
-        def collector(parts):
+        def collector(parts, served=True):
             def run():
                 eng.rollout_begin()
                 if parts > 1:
                     pipe = eng.part_pipeline(parts, hb["obs"], hb["clip"], hb["rew"], hb["done"], hb["trunc"], hb["term"])
-                    pipe.collect(host.step_range_fn, host.handle)      # the whole loop in one native call, finish_rollout included
+                    # served: the persistent rollout kernel serves the host env (flags in pinned memory, no launch / event per step;
+                    # the default on 256-wide x3 engines); else the launch-per-step collector (act_part / store_part per row range)
+                    os.environ["MOBROB_COLLECT_SERVER"] = "1" if served else "0"
+                    try:
+                        pipe.collect(host.step_range_fn, host.handle)  # the whole loop in one native call, finish_rollout included
+                    finally:
+                        os.environ.pop("MOBROB_COLLECT_SERVER", None)
                 else:
                     for _ in range(T):
                         eng.act(hb["obs"], out_clipped=hb["clip"], want_all=False)
@@ -927,16 +933,24 @@ def host_path_measurements(args, job):
         t_upd = in_iteration(lambda: None)
         t_sim = in_iteration(sim_alone) - t_upd
         t_gpu = in_iteration(gpu_alone) - t_upd
-        sweep = {}
+        sweep, sweep_launch = {}, {}
         for parts in (2, 4, 8, 1):
             sweep[parts] = in_iteration(collector(parts)) - t_upd
+        for parts in (2, 4):
+            sweep_launch[parts] = in_iteration(collector(parts, served=False)) - t_upd
         best = min(sweep, key=sweep.get)
         us = lambda t: 1e6 * t / T   # noqa: E731 - microseconds per vector step of N environments
         res["native-c-env (csrc/host_env.c), pinned zero-copy, mobrob_ppo_collect_host"] = {
             "envs": N, "steps_per_rollout": T, "env_threads": host.threads,
             "us_per_vector_step": {"host_sim_alone": us(t_sim), "gpu_act_store_alone": us(t_gpu),
                                    "pipelined": {f"host_parts={k}" + (" (Python loop, whole batch per step)" if k == 1 else ""): us(v)
-                                                 for k, v in sorted(sweep.items())}},
+                                                 for k, v in sorted(sweep.items())},
+                                   "pipelined_launch_per_step_collector": {f"host_parts={k}": us(v) for k, v in sorted(sweep_launch.items())}},
+            "collector": ("host_parts >= 2: the persistent rollout kernel SERVES the host environment -- its env phase is the host's: a workgroup "
+                          "writes its rows' clipped actions into the pinned buffer, raises a flag word in pinned memory and polls the host's word "
+                          "for its row range (the range's first workgroup polls host memory and relays through a device word); no launch, no event, "
+                          "no HIP call inside the step loop (csrc/kernels_rollout.h KIND 3, engine.hip collect_host_served); "
+                          "pipelined_launch_per_step_collector = the round-4 form (two launches and an event per range and step), MOBROB_COLLECT_SERVER=0"),
             "collector_overhead_us_per_step": us(sweep[best]) - max(us(t_sim), us(t_gpu)),
             "rollout_only_env_steps_per_s": N * T / sweep[best], "best_host_parts": best,
             "update_ms": 1e3 * t_upd,

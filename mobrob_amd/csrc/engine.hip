@@ -165,6 +165,10 @@ struct mobrob_ppo_engine {
   const void* pinned_seen[8] = {nullptr};  // pointers validated by is_pinned_cached since rollout_begin
   unsigned pinned_seen_n = 0;
   uint32_t draw_ro0 = 0;  // draw_counter at rollout_begin: part p at its step t draws with draw_ro0 + t
+  // host-env rollout SERVED by the persistent rollout kernel (collect_host_served): flags in pinned memory, abort word on the device
+  unsigned* srv_flags = nullptr;   // [srv_blocks] workgroup flags | [MOBROB_MAX_PARTS][16] host words | [16] error word
+  int srv_blocks = 0;
+  int* srv_abort = nullptr;
   uint32_t env_step_counter = 0;
   int t = 0;
   bool rollout_ready = false;
@@ -985,6 +989,8 @@ void mobrob_ppo_destroy(mobrob_ppo_engine_t* e) {
   }
   for (hipEvent_t ev : e->ev_part)
     if (ev) (void)hipEventDestroy(ev);
+  if (e->srv_flags) (void)hipHostFree(e->srv_flags);
+  if (e->srv_abort) (void)hipFree(e->srv_abort);
   if (e->ro_exec) (void)hipGraphExecDestroy(e->ro_exec);
   if (e->ro_graph) (void)hipGraphDestroy(e->ro_graph);
   if (e->vstream) {
@@ -1263,6 +1269,12 @@ int mobrob_ppo_store_part(mobrob_ppo_engine_t* e, int32_t part, int32_t nparts, 
   return MOBROB_OK;
 }
 
+namespace {
+// defined behind the device-rollout code it shares (enqueue of the persistent kernel's chunks and the overlapped value passes)
+int collect_host_served(mobrob_ppo_engine* e, mobrob_env_step_range_fn step_range, void* env, int nparts, float* obs,
+                        float* actions_clipped, float* rewards, uint8_t* dones, uint8_t* truncated, float* terminal_obs, bool* served);
+}  // namespace
+
 // The whole pipelined rollout in one call: rollout_begin, n_steps x nparts x (wait_part, env step of the range,
 // store_part + act_part), finish_rollout -- the collector loop of SB3's collect_rollouts as native code, driving a
 // native vectorised environment through one function pointer.
@@ -1272,6 +1284,11 @@ int mobrob_ppo_collect_host(mobrob_ppo_engine_t* e, mobrob_env_step_range_fn ste
   if (!e || !step_range || !obs || !actions_clipped || !rewards || !dones || !truncated || !terminal_obs)
     return fail(MOBROB_ERR_INVALID, "collect_host: null argument");
   CHK(mobrob_ppo_rollout_begin(e));
+  {  // 256-wide x3 engines: the persistent rollout kernel serves the host environment (no launch, no event per step)
+    bool served = false;
+    const int rc = collect_host_served(e, step_range, env, nparts, obs, actions_clipped, rewards, dones, truncated, terminal_obs, &served);
+    if (served || rc != MOBROB_OK) return rc;
+  }
   for (int p = 0; p < nparts; ++p) CHK(mobrob_ppo_act_part(e, p, nparts, obs, actions_clipped));
   const bool timing = getenv("MOBROB_COLLECT_TIMING") != nullptr;
   // Two host threads (round 5, OPT-IN: MOBROB_COLLECT_THREADS=1).  The single-thread loop below spends, per vector step of 4096 envs at
@@ -1686,6 +1703,182 @@ int collect_device(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& s
   e->t = e->T;
   e->rollout_ready = true; e->train_rec_valid = false;
   return MOBROB_OK;
+}
+
+// Host environments SERVED by the persistent rollout kernel (round 5; kernels_rollout.h, KIND 3).  The launch-per-step collector above
+// pays, per row range and step, two kernel launches, an event, the event's completion latency and the weight stream of a fresh
+// k_fused_act -- 74 - 76 us of GPU-side time per vector step of 4096 envs against 10 us for the same arithmetic inside the device
+// rollout.  Here the device rollout's own kernel runs the policy (weights stationary, S8) and its env phase is the host's: a
+// workgroup writes its rows' clipped actions into the caller's pinned buffer, raises its flag word in pinned memory and polls the
+// host's word for its row range; the host waits for the flags of a range, steps it, raises its word.  No HIP call inside the step
+// loop.  Same Philox counters, same forward / sampling / storage / bootstrap code as the device rollout; against the launch-per-step
+// collector the buffers agree to float32 rounding (its k_fused_act runs the policy on the f32 pipe, the rollout kernel on the bf16
+// pipe with split operands: the same relation the device rollout has to its per-step form), what the kernel only moves -- clipped
+// actions to the host, rewards / observations from it -- is exact (tests/test_engine_gpu.py::test_served_host_rollout_...).
+// Conditions (else *served stays false and the caller runs the launch-per-step loop): 256-wide x3 engine with the eight-wave rollout
+// kernel, whole 32-row tiles per row range, every workgroup resident at once (tiles <= CUs: a waiting workgroup never yields its CU),
+// pinned buffers.  MOBROB_COLLECT_SERVER=0 switches it off; MOBROB_SERVER_TIMEOUT_S (default 60) bounds every wait on either side.
+int collect_host_served(mobrob_ppo_engine* e, mobrob_env_step_range_fn step_range, void* env, int nparts, float* obs,
+                        float* actions_clipped, float* rewards, uint8_t* dones, uint8_t* truncated, float* terminal_obs, bool* served) {
+  *served = false;
+  const int mode = getenv("MOBROB_COLLECT_SERVER") ? atoi(getenv("MOBROB_COLLECT_SERVER")) : 1;   // 0 off, 1 when possible, 2 required (tests); read per rollout
+  static const bool s8_on = !kRolloutStationary && !(getenv("MOBROB_ROLLOUT_S8") && atoi(getenv("MOBROB_ROLLOUT_S8")) == 0);
+  const int N = e->N, T = e->T, Dp = e->Dp;
+  const int rblocks = cdiv(N, 32);
+  if (mode == 0) return MOBROB_OK;
+  const char* why = nullptr;
+  int cus = 0;
+  if (!s8_on || !rollout_persistent_ok(e) || e->fused.H != FH || e->fused.net[0].W2x == nullptr) why = "not a 256-wide x3 engine with the eight-wave rollout kernel";
+  else if (getenv("MOBROB_COLLECT_TIMING") || (getenv("MOBROB_COLLECT_THREADS") && atoi(getenv("MOBROB_COLLECT_THREADS")) != 0)) why = "an instrumented / threaded collector was asked for";
+  else if (nparts < 1 || nparts > MOBROB_MAX_PARTS || N % nparts != 0 || (N / nparts) % 32 != 0) why = "row ranges are not whole 32-row tiles";
+  else if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device_id) != hipSuccess || rblocks > cus) why = "more tiles than compute units";
+  else if (!is_pinned(obs) || !is_pinned(actions_clipped) || !is_pinned(rewards) || !is_pinned(dones) || !is_pinned(truncated) || !is_pinned(terminal_obs)) why = "pageable buffers";
+  if (why) return mode == 2 ? fail(MOBROB_ERR_STATE, "collect_host: MOBROB_COLLECT_SERVER=2 but %s", why) : MOBROB_OK;
+  CHK(rollout_side_stream_init(e));
+  CHK(streamer_init(e));
+  constexpr int kHostWords = 16 * MOBROB_MAX_PARTS;
+  constexpr int kStampWords = 64 * 8 * 2;   // -DMOBROB_SERVE_STAMPS builds: 64 steps x 8 stamps (long long) of workgroup 0
+  const int fb = (rblocks + 15) / 16 * 16;
+  if (!e->srv_flags || e->srv_blocks < fb) {
+    if (e->srv_flags) (void)hipHostFree(e->srv_flags);
+    e->srv_flags = nullptr;
+    HIPC(hipHostMalloc((void**)&e->srv_flags, (size_t)(fb + kHostWords + 16 + kStampWords) * sizeof(unsigned), hipHostMallocCoherent | hipHostMallocMapped));
+    e->srv_blocks = fb;
+  }
+  if (!e->srv_abort) HIPC(hipMalloc((void**)&e->srv_abort, 256));   // abort word | one 8-byte relay word per row range
+  unsigned* gpu_flag = e->srv_flags;
+  unsigned* host_flag = e->srv_flags + e->srv_blocks;
+  int* err_word = reinterpret_cast<int*>(host_flag + kHostWords);
+  memset(e->srv_flags, 0, (size_t)(e->srv_blocks + kHostWords + 16 + kStampWords) * sizeof(unsigned));
+  HIPC(hipMemsetAsync(e->srv_abort, 0, 256, e->stream));
+  const double timeout_s = getenv("MOBROB_SERVER_TIMEOUT_S") ? atof(getenv("MOBROB_SERVER_TIMEOUT_S")) : 60.0;
+
+  // slot 0 <- the environments' current observations (the kernel reads its first tile from the slot, like the device rollout)
+  hipLaunchKernelGGL(k_pull_rows, dim3(cdiv(N * Dp, 256)), dim3(256), 0, e->stream, obs, e->obs, N, e->D, Dp);
+  if (!e->fused.train_x3) pack_x3_all(e);
+  RolloutArgs a{};
+  a.pi = e->fused.net[0];
+  a.log_std = Pp(e, T_LOGSTD); a.seed = eps_seed(e); a.draw_base = nullptr; a.draw0 = e->draw_ro0;
+  a.lo = (float)e->cfg.action_low; a.hi = (float)e->cfg.action_high;
+  a.kind = 3; a.env_seed = 0; a.step_base = nullptr;
+  a.bt = BootArgs{Pp(e, T_VW1), Pp(e, T_VB1), Pp(e, T_VW2), Pp(e, T_VB2), Pp(e, T_VW), Pp(e, T_VB), e->G1, e->G2,
+                  (float)e->cfg.gamma, e->term_val, 0};
+  a.N = N; a.D = e->D; a.A = e->A;
+  a.obs = e->obs; a.actions = e->actions; a.logp = e->logp; a.rewards = e->rewards; a.es = e->es;
+  a.term_obs = e->term_obs; a.trunc = e->trunc_dev; a.clip_act = actions_clipped;   // (the caller's pinned buffer)
+  a.ep_len = e->ep_len; a.prev_dones = e->prev_dones; a.gstate = e->gstate[0]; a.ep_stats = e->ep_stats;
+  a.h_obs = obs; a.h_rew = rewards; a.h_done = dones; a.h_trunc = truncated; a.h_term = terminal_obs;
+  a.h_gpu_flag = gpu_flag; a.h_host_flag = host_flag; a.h_error = err_word; a.abort_dev = e->srv_abort;
+  a.rows_per_part = N / nparts; a.timeout_ticks = (long long)(timeout_s * 1e8);
+
+  // chunks of the step loop on the compute stream, V(obs) of a finished chunk on the side stream (as enqueue_rollout_persistent)
+  const bool overlap = rblocks <= 192;
+  const int chunk = overlap ? std::max(16, cdiv(T, 20)) : T;
+  const int vgrid_max = overlap ? std::max(32, 256 - rblocks) : 256;
+  auto value_pass = [&](hipStream_t st, int r0, int r1, int grid_max) {
+    FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_value_batch<DPc>), dim3(std::min(grid_max, cdiv(r1 - r0, FR))), dim3(FTHREADS),
+                                             e->fused.lds_bytes, st, e->fused.net[1], e->obs + (size_t)r0 * Dp, r1 - r0, e->values + r0));
+  };
+  {
+    ProfScope ps(e, MOBROB_K_ENV);
+    for (int t0 = 0; t0 < T; t0 += chunk) {
+      a.t0 = t0; a.t1 = std::min(T, t0 + chunk);
+      FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout_persistent<DPc, 3, true>), dim3(rblocks), dim3(kRolloutThreads),
+                                               rollout_lds_bytes(Dp, true), e->stream, a));
+      if (overlap && a.t1 < T) {
+        hipEvent_t ev = e->ev_chunks[t0 / chunk];
+        HIPC(hipEventRecord(ev, e->stream));
+        HIPC(hipStreamWaitEvent(e->vstream, ev, 0));
+        value_pass(e->vstream, t0 * N, a.t1 * N, vgrid_max);
+      }
+    }
+  }
+  {
+    ProfScope ps(e, MOBROB_K_ACT);   // V of the last chunk (V(last_obs) is finish_rollout's)
+    const int done_rows = overlap ? ((T - 1) / chunk) * chunk * N : 0;
+    value_pass(e->stream, done_rows, T * N, 256);
+    if (overlap && done_rows > 0) {
+      HIPC(hipEventRecord(e->ev_vdone, e->vstream));
+      HIPC(hipStreamWaitEvent(e->stream, e->ev_vdone, 0));
+    }
+  }
+  HIPC(hipGetLastError());
+
+  // ---- the host's side of the step loop: wait for the flags of a row range, step it, raise the range's word ----
+  auto give_up = [&](void) {
+    for (int p = 0; p < nparts; ++p) __atomic_store_n(reinterpret_cast<unsigned long long*>(&host_flag[16 * p]), 0xFFFFFFFFull, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipStreamSynchronize(e->vstream);
+  };
+  auto now_s = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+  const int bpp = (N / nparts) / 32;   // workgroups per row range
+  const bool timing = getenv("MOBROB_SERVER_TIMING") != nullptr;   // per-step split of the host thread's time (stderr)
+  double tw = 0, te = 0;
+  for (int t = 0; t < T; ++t) {
+    for (int p = 0; p < nparts; ++p) {
+      const unsigned want = (unsigned)(t + 1);
+      double t_wait = -1.0;
+      const double c0 = timing ? now_s() : 0;
+      for (int b = p * bpp; b < (p + 1) * bpp; ++b) {
+        unsigned spins = 0;
+        while (__atomic_load_n(&gpu_flag[b], __ATOMIC_ACQUIRE) < want) {
+          __builtin_ia32_pause();
+          if ((++spins & 0xFFFFu) == 0) {   // every ~65 k polls: the device gave up, or nothing moved for the whole timeout
+            if (__atomic_load_n(err_word, __ATOMIC_ACQUIRE) != 0) {
+              give_up();
+              return fail(MOBROB_ERR_STATE, "collect_host: the rollout kernel gave up waiting for the host at step %d", *err_word - 1);
+            }
+            const double tn = now_s();
+            if (t_wait < 0) t_wait = tn;
+            if (tn - t_wait > timeout_s) {
+              give_up();
+              return fail(MOBROB_ERR_HIP, "collect_host: no actions from the device for %.0f s (step %d, row range %d)", timeout_s, t, p);
+            }
+          }
+        }
+      }
+      const int r0 = p * (N / nparts);
+      const double c1 = timing ? now_s() : 0;
+      const int32_t ntrunc = step_range(env, r0, r0 + N / nparts, actions_clipped, obs, rewards, dones, truncated, terminal_obs);
+      if (ntrunc < 0) {
+        give_up();
+        return fail(MOBROB_ERR_STATE, "collect_host: the environment's step_range returned %d", ntrunc);
+      }
+      __atomic_store_n(reinterpret_cast<unsigned long long*>(&host_flag[16 * p]), ((unsigned long long)(unsigned)ntrunc << 32) | want, __ATOMIC_RELEASE);
+      if (timing) { tw += c1 - c0; te += now_s() - c1; }
+    }
+  }
+#ifdef MOBROB_SERVE_STAMPS
+  if (timing) {
+    (void)hipStreamSynchronize(e->stream);
+    const long long* st = reinterpret_cast<const long long*>(err_word + 16);
+    double d[8] = {0};
+    int n = 0;
+    for (int t = 8; t + 1 < 64 && t + 1 < T; ++t, ++n) {
+      d[0] += st[8 * t + 1] - st[8 * t + 0];        // publish -> host word seen
+      d[1] += st[8 * t + 2] - st[8 * t + 1];        // barrier (4b)
+      d[2] += st[8 * t + 3] - st[8 * t + 2];        // pull (this wave)
+      d[3] += st[8 * t + 4] - st[8 * t + 3];        // barrier (4c)
+      d[4] += st[8 * t + 5] - st[8 * t + 4];        // env phase + state update
+      d[5] += st[8 * (t + 1) + 6] - st[8 * t + 5];  // layers, head, sampling (next step)
+      d[6] += st[8 * (t + 1) + 7] - st[8 * (t + 1) + 6];  // drain of the action stores
+      d[7] += st[8 * (t + 1) + 0] - st[8 * (t + 1) + 7];  // barrier (4)
+    }
+    fprintf(stderr, "[served stamps, workgroup 0, us] wait for host %.2f | (4b) %.2f | pull %.2f | (4c) %.2f | env+state %.2f | policy %.2f | drain %.2f | (4) %.2f\n",
+            d[0] / n / 100, d[1] / n / 100, d[2] / n / 100, d[3] / n / 100, d[4] / n / 100, d[5] / n / 100, d[6] / n / 100, d[7] / n / 100);
+  }
+#endif
+  if (timing)
+    fprintf(stderr, "[collect_host served] per step: waiting for the device %.1f us, env %.1f us (%d row ranges)\n", 1e6 * tw / T, 1e6 * te / T, nparts);
+  e->t = T;
+  e->nparts = nparts;
+  for (int p = 0; p < nparts; ++p) { e->part_act_t[p] = e->part_store_t[p] = T; e->part_obs_t[p] = T; }
+  if (e->draw_counter < e->draw_ro0 + (uint32_t)T) e->draw_counter = e->draw_ro0 + (uint32_t)T;
+  *served = true;
+  const int rc = mobrob_ppo_finish_rollout(e, obs, dones);   // last observations / dones, V(last_obs), GAE; synchronises the stream
+  if (rc == MOBROB_OK && __atomic_load_n(err_word, __ATOMIC_ACQUIRE) != 0)
+    return fail(MOBROB_ERR_STATE, "collect_host: the rollout kernel gave up waiting for the host at step %d", *err_word - 1);
+  return rc;
 }
 }  // namespace
 

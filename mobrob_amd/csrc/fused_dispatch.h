@@ -101,6 +101,8 @@ inline hipError_t fused_set_lds_attr(FusedState& f) {
           e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_persistent<DPc, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rollout_lds_bytes(f.Dp, true));
         if (e == hipSuccess)
           e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_persistent<DPc, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rollout_lds_bytes(f.Dp, true));
+        if (e == hipSuccess)
+          e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_persistent<DPc, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rollout_lds_bytes(f.Dp, true));
       }
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_value_batch<DPc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_bytes);

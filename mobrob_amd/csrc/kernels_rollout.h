@@ -46,6 +46,17 @@ struct RolloutArgs {
   float* term_obs; uint8_t* trunc; float* clip_act;        // latest-step buffers
   // carried state (in/out)
   int* ep_len; float* prev_dones; float* gstate; double* ep_stats;
+  uint32_t draw0;                    // Philox draw index of step 0 when draw_base is null (host-side counter)
+  // kind 3 -- HOST environments served by this launch (k_rollout_persistent<.., 3, true>, round 5): the env phase of a step is the
+  // host's: the workgroup hands its rows' clipped actions over in pinned memory, waits for the host to step them, pulls the result.
+  const float* h_obs; const float* h_rew; const uint8_t* h_done; const uint8_t* h_trunc; const float* h_term;  // [N][D] | [N] ... (pinned)
+  unsigned* h_gpu_flag;              // [workgroups] pinned: t + 1 once the clipped actions of step t of the workgroup's rows are in host memory
+  const unsigned* h_host_flag;       // [parts][16] pinned: the first 8 bytes = (truncated rows in the part's newest step) << 32 | steps of the
+                                     //                      part the host has finished (low word 0xFFFFFFFF: give up); one 8-byte store
+  // abort_dev (below) is followed by one 8-byte relay word per part: the part's first workgroup re-publishes the host's word there
+  int* h_error;                      // pinned: set when a workgroup waited longer than timeout_ticks
+  int* abort_dev;                    // device word: a launch that gave up tells the launches queued behind it
+  int rows_per_part; long long timeout_ticks;   // of wall_clock64() (100 MHz)
 };
 
 // LDS carve-up of the rollout tile with the h1 activations kept as three bf16 PLANES (the x3 pieces, split once by the layer-1
@@ -177,6 +188,11 @@ __device__ __forceinline__ void xplanes_store4(int rr, int c, const f32x4& o) {
 // Same products, same order per accumulator as gemm_x3_r32 (X3_MFMA6 over the k steps in natural order): the rollout's numbers are
 // those of the four-wave x3 form bit for bit (tests/test_engine_gpu.py::test_s8_rollout_equals_the_four_wave_x3_rollout).
 // Sampling, env rules, storage, bootstrap: unchanged, on the four policy waves.
+#ifdef MOBROB_SERVE_STAMPS   // diagnostic build: workgroup 0 records wall_clock64() (100 MHz) at six points of its first 64 served steps
+#define SERVE_STAMP(k) if (KIND == 3 && blockIdx.x == 0 && t < 64) { if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 1) reinterpret_cast<long long*>(ar.h_error + 16)[8 * t + (k)] = wall_clock64(); }
+#else
+#define SERVE_STAMP(k)
+#endif
 #define ar (*ap_)
 // Philox keys inside the step loop: derived from the kernel arguments where they are used.  As loop invariants
 // their ten-round key schedules (k + r W, twenty scalars per key pair and stream) were hoisted out of the step loop and parked.
@@ -185,6 +201,10 @@ __device__ __forceinline__ void xplanes_store4(int rr, int c, const f32x4& o) {
 template <int DP, int KIND, bool S8 = false>
 __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(RolloutArgs a) {
   static_assert(!S8 || !kRolloutStationary, "S8 needs the eight-wave workgroup");
+  static_assert(KIND != 3 || S8, "the host-env form exists for the eight-wave kernel only");
+  if constexpr (KIND == 3) {   // a launch in front of this one gave up on the host: do nothing (uniform)
+    if (__hip_atomic_load(a.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+  }
   using L = LayRo<DP, S8>;
   using LB = typename L::B;
   constexpr int ldx = LB::LDX, per = DP / 4, R = 32;
@@ -210,7 +230,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       if (KIND == 2) {
 #pragma unroll
         for (int j = 0; j < kGoalStateFloats; ++j) S[j] = a.gstate[(size_t)n * kGoalStateFloats + j];
-      } else {
+      } else if (KIND == 1) {
         reinterpret_cast<int*>(S)[13] = a.ep_len[n];
       }
       S[12] = a.prev_dones[n];
@@ -233,7 +253,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
     if constexpr (S8 && MOBROB_S8_XPLANES) xplanes_store4<LB>(rr, c, v);
   }
   __syncthreads();
-  const uint32_t dbase = a.draw_base ? *a.draw_base : 0u, sbase = a.step_base ? *a.step_base : 0u;
+  const uint32_t dbase = a.draw_base ? *a.draw_base : a.draw0, sbase = a.step_base ? *a.step_base : 0u;
   const uint32_t ek0 = (uint32_t)a.env_seed, ek1 = (uint32_t)(a.env_seed >> 32);
 
   double es_n = 0.0, es_ret = 0.0, es_len = 0.0, es_goal = 0.0;  // finished episodes of this thread's row
@@ -393,6 +413,40 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         }
       }
     };
+    // KIND 3: what the host wrote for this tile's 32 rows -> LDS, by all eight waves with whole-wave contiguous 16-byte loads (the
+    // tile's rows are one contiguous, 16-byte aligned range of the [N][D] host array: 32 D floats; per-row gathers of single floats
+    // from uncached host memory cost a PCIe read each and made the step 25x slower).  Staging: the env-noise buffers this kind never
+    // draws into -- observations at EN, terminal observations (only when the host reports a truncated row in the range) behind them;
+    // rewards / done / truncated flags in the log-prob term buffer, free between barrier (4b) and the next sampling stage.
+    auto host_pull = [&](int th) {
+      if constexpr (KIND == 3) {
+        const int nrow = min(R, N - row0);
+        const int nq = nrow * D / 4, rem0 = 4 * nq, nfl = nrow * D;      // whole float4s, then a tail of single floats (nrow < 32 only)
+        const f32x4* so = reinterpret_cast<const f32x4*>(ar.h_obs + (size_t)row0 * D);
+        for (int i = th; i < nq; i += kRolloutThreads) {
+          f32x4 v;
+          asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(so + i) : "memory");
+          *reinterpret_cast<f32x4*>(&lds[L::EN + 4 * i]) = v;
+        }
+        for (int i = rem0 + th; i < nfl; i += kRolloutThreads)
+          lds[L::EN + i] = __hip_atomic_load(ar.h_obs + (size_t)row0 * D + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (cnt[2] != 0) {
+          const f32x4* st = reinterpret_cast<const f32x4*>(ar.h_term + (size_t)row0 * D);
+          for (int i = th; i < nq; i += kRolloutThreads) {
+            f32x4 v;
+            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(st + i) : "memory");
+            *reinterpret_cast<f32x4*>(&lds[L::EN + 32 * DP + 4 * i]) = v;
+          }
+          for (int i = rem0 + th; i < nfl; i += kRolloutThreads)
+            lds[L::EN + 32 * DP + i] = __hip_atomic_load(ar.h_term + (size_t)row0 * D + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (th < nrow) {
+          lds[L::TM + th] = __hip_atomic_load(ar.h_rew + row0 + th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          reinterpret_cast<int*>(&lds[L::TM])[32 + th] = __hip_atomic_load(ar.h_done + row0 + th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          reinterpret_cast<int*>(&lds[L::TM])[64 + th] = cnt[2] != 0 ? (int)__hip_atomic_load(ar.h_trunc + row0 + th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
+        }
+      }
+    };
     if (kRolloutStationary) {  // weights-stationary plan: the four waves draw their own numbers, first
       draw_sampling(t, tid);
       draw_env(t, tid);
@@ -403,7 +457,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       // draw step t + 1's numbers into the other buffer halves while the policy waves sample, step the env and update the state:
       // the half being written was last read in step t - 1, whose phases all ended before barrier (6) of that step.
       const int hid = tid - FTHREADS;
-      if (t == t_begin) { draw_sampling(t, hid); draw_env(t, hid); }
+      if (t == t_begin) { draw_sampling(t, hid); if constexpr (KIND != 3) draw_env(t, hid); }
       if constexpr (!S8) {
         LDS_BARRIER(); ap_ = rollout_kernargs();  // (1) after layer 1
         LDS_BARRIER(); ap_ = rollout_kernargs();  // (2) after layer 2
@@ -411,7 +465,14 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       LDS_BARRIER(); ap_ = rollout_kernargs();  // (3) after the head
       if (t + 1 < t_end) draw_sampling(t + 1, hid);
       LDS_BARRIER(); ap_ = rollout_kernargs();  // (4) after the sampling stage
-      if (t + 1 < t_end) draw_env(t + 1, hid);
+      if constexpr (KIND == 3) {
+        LDS_BARRIER(); ap_ = rollout_kernargs();  // (4b) the host has stepped the rows (or the wait was given up)
+        if (cnt[1]) break;
+        host_pull(tid);
+        LDS_BARRIER(); ap_ = rollout_kernargs();  // (4c) the host's tile is in LDS
+      } else {
+        if (t + 1 < t_end) draw_env(t + 1, hid);
+      }
       LDS_BARRIER(); ap_ = rollout_kernargs();  // (5) after the env phase
       LDS_BARRIER(); ap_ = rollout_kernargs();  // (6) after the state update
     }
@@ -497,15 +558,63 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         lds[L::TM + rr_ * 33 + k] = -(d * d) / lds[L::AC + 32 + k] - lds[L::AC + 64 + k] - 0.91893853320467274178f;
         const float ac = fminf(fmaxf(act, ar.lo), ar.hi);
         if (ROLL_ON(128)) ar.actions[((size_t)t * N + row) * A + k] = act;
-        if (ROLL_ON(128)) ar.clip_act[(size_t)row * A + k] = ac;
+        if constexpr (KIND == 3) __hip_atomic_store(&ar.clip_act[(size_t)row * A + k], ac, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // pinned host memory, past the caches
+        else if (ROLL_ON(128)) ar.clip_act[(size_t)row * A + k] = ac;
         lds[L::CA + rr_ * 33 + k] = ac;
       }
     }
+    SERVE_STAMP(6)
+    if constexpr (KIND == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its actions have left for host memory
+    SERVE_STAMP(7)
     LDS_BARRIER(); ap_ = rollout_kernargs();
+    if constexpr (KIND == 3) {
+      // Hand-over: one lane tells the host "the actions of step t of these 32 rows are in your memory" and then waits until the host
+      // has stepped the row range (part) these rows belong to.  Relaxed system-scope accesses past the caches (sc0 sc1), ordered by the
+      // drained stores above and by the barriers around this block; bounded: a host that never answers raises the error word and this
+      // launch (and, through abort_dev, the launches queued behind it) gives up -- the HOST then fails the rollout.
+      SERVE_STAMP(0)   // actions drained, barrier passed
+      if (tid == 64) {
+        __hip_atomic_store(ar.h_gpu_flag + blockIdx.x, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // The host's word of the row range: (truncated rows of the newest step) << 32 | steps finished -- ONE 8-byte load per poll.
+        // Only the range's FIRST workgroup polls host memory (a PCIe round trip per poll); it relays what it saw through a device
+        // word the other workgroups of the range poll (64 pollers per range on the PCIe link made every round trip ~4 us).
+        const int part = row0 / ar.rows_per_part;
+        const bool relay = row0 == part * ar.rows_per_part;
+        const unsigned long long* hf = reinterpret_cast<const unsigned long long*>(ar.h_host_flag + 16 * part);
+        unsigned long long* df = reinterpret_cast<unsigned long long*>(ar.abort_dev) + 1 + part;
+        const long long w0 = wall_clock64();
+        unsigned long long v;
+        for (;;) {
+          v = relay ? __hip_atomic_load(hf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(df, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned)v >= (unsigned)(t + 1)) break;
+          if (wall_clock64() - w0 > ar.timeout_ticks) {
+            v = 0xFFFFFFFFull;
+            __hip_atomic_store(ar.h_error, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+          }
+          if (relay) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(2);
+        }
+        if (relay) __hip_atomic_store(df, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool dead = (unsigned)v == 0xFFFFFFFFu;
+        if (dead) __hip_atomic_store(ar.abort_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SERVE_STAMP(1)   // the host's word arrived
+        cnt[1] = dead ? 1 : 0;
+        cnt[2] = dead ? 0 : (int)(v >> 32);
+      }
+    }
     if (tid < R && row0 + tid < N) {
       float lp = 0.f;
       for (int k = 0; k < A; ++k) lp += lds[L::TM + tid * 33 + k];
       if (ROLL_ON(128)) ar.logp[(size_t)t * N + row0 + tid] = lp;
+    }
+    if constexpr (KIND == 3) {
+      LDS_BARRIER(); ap_ = rollout_kernargs();  // (4b)
+      if (cnt[1]) break;
+      SERVE_STAMP(2)
+      host_pull(tid);
+      SERVE_STAMP(3)   // this wave's share of the tile is in LDS
+      LDS_BARRIER(); ap_ = rollout_kernargs();  // (4c)
+      SERVE_STAMP(4)
     }
     // ---- env.step(clipped actions) + auto-reset: 8 threads per row, observation chunks sub and sub + 8 ----
     const int rr = tid >> 3, sub = tid & 7;
@@ -520,7 +629,33 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
     float reward = 0.f, ep_ret = 0.f;
     int ep_len_new = 0, ep_len_fin = 0;
     GoalState g{};
-    if (live && ROLL_ON(16)) {
+    if constexpr (KIND == 3) {
+      if (live) {   // what the host wrote for this row (staged in LDS by host_pull): reward, done, truncated, next observation, terminal one
+        done = reinterpret_cast<const int*>(&lds[L::TM])[32 + rr] != 0;
+        tr = reinterpret_cast<const int*>(&lds[L::TM])[64 + rr] != 0;
+        if (sub == 0) reward = lds[L::TM + rr];
+        auto staged_chunk = [&](int base, int c) {   // columns 4 c .. 4 c + 3 of the tile's row rr ([32][D] floats at `base`)
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int col = 4 * c + j;
+            o[j] = col < D ? lds[base + rr * D + (col < D ? col : 0)] : 0.f;
+          }
+          return o;
+        };
+        for (int c = sub; c < per; c += 8) {
+          const f32x4 o = staged_chunk(L::EN, c);
+          if (tr) {
+            const f32x4 to = staged_chunk(L::EN + 32 * DP, c);
+            reinterpret_cast<f32x4*>(ar.term_obs)[(size_t)n * per + c] = to;
+            *reinterpret_cast<f32x4*>(&trow[4 * c]) = to;
+          }
+          reinterpret_cast<f32x4*>(ar.obs)[onext + c] = o;
+          if constexpr (S8 && MOBROB_S8_XPLANES) xplanes_store4<LB>(rr, c, o);
+          else *reinterpret_cast<f32x4*>(&xrow[4 * c]) = o;
+        }
+      }
+    } else if (live && ROLL_ON(16)) {
       if (KIND == 1) {
         const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, EK0, EK1);
         const bool term = u32_to_unit_open(mr.x) < ar.p_term;
@@ -587,7 +722,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       if (ROLL_ON(128)) ar.trunc[n] = tr ? 1 : 0;
       if (KIND == 1) {
         reinterpret_cast<int*>(S)[13] = ep_len_new;
-      } else {
+      } else if (KIND == 2) {
         goal_store(S, g);
         if (done) {  // Monitor statistics: accumulated per thread, flushed once per launch (see the kernel end)
           es_n += 1.0; es_ret += (double)ep_ret; es_len += (double)ep_len_fin; es_goal += reached ? 1.0 : 0.0;
@@ -603,6 +738,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       }
     }
     LDS_BARRIER(); ap_ = rollout_kernargs();
+    SERVE_STAMP(5)   // step over: state updated
     }  // (policy waves)
     // ---- time-limit bootstrap of the (rare) truncated rows: r += gamma * V(terminal_obs).  All eight waves (the value MLP
     //      of a row is a block-wide routine with its own barriers; the noise waves hold no hidden unit and add zeros) ----
@@ -634,7 +770,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       if (KIND == 2) {
 #pragma unroll
         for (int j = 0; j < kGoalStateFloats; ++j) a.gstate[(size_t)n * kGoalStateFloats + j] = S[j];
-      } else {
+      } else if (KIND == 1) {
         a.ep_len[n] = reinterpret_cast<const int*>(S)[13];
       }
       a.prev_dones[n] = S[12];
@@ -817,7 +953,7 @@ __global__ __launch_bounds__(LayRo64<DP>::NWV * 64, 1) void k_rollout64_persiste
       v = ldg16(a.obs, (unsigned)((size_t)a.t0 * N + row0 + rr) * (unsigned)(DP * 4) + (unsigned)(c * 16));
     *reinterpret_cast<f32x4*>(&lds[wb + LB::X + rr * ldx + 4 * c]) = v;
   }
-  const uint32_t dbase = a.draw_base ? *a.draw_base : 0u, sbase = a.step_base ? *a.step_base : 0u;
+  const uint32_t dbase = a.draw_base ? *a.draw_base : a.draw0, sbase = a.step_base ? *a.step_base : 0u;
   const uint32_t ek0 = (uint32_t)a.env_seed, ek1 = (uint32_t)(a.env_seed >> 32);
 
   double es_n = 0.0, es_ret = 0.0, es_len = 0.0, es_goal = 0.0;  // finished episodes of this thread's row
@@ -1105,7 +1241,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
   }
   if (tid0 == 0) *cnt = 0;
   __syncthreads();
-  const uint32_t dbase = a.draw_base ? *a.draw_base : 0u, sbase = a.step_base ? *a.step_base : 0u;
+  const uint32_t dbase = a.draw_base ? *a.draw_base : a.draw0, sbase = a.step_base ? *a.step_base : 0u;
   const uint32_t ek0 = (uint32_t)a.env_seed, ek1 = (uint32_t)(a.env_seed >> 32);
 
   double es_n = 0.0, es_ret = 0.0, es_len = 0.0, es_goal = 0.0;  // finished episodes of this thread's row

@@ -408,6 +408,103 @@ def test_pipelined_part_rollout_equals_whole_batch_rollout(robot, hidden, N, par
         assert (sw["episodes"], sw["goals"]) == (sp["episodes"], sp["goals"]) and abs(sw["ep_rew_mean"] - sp["ep_rew_mean"]) < 1e-9
 
 
+@pytest.mark.parametrize("robot,N,parts", [("doggo", 192, 2), ("doggo", 64, 1), ("point", 128, 4), ("car", 96, 3),
+                                           ("turtlebot3", 64, 2), ("drone", 128, 2)])
+def test_served_host_rollout_equals_the_launch_per_step_rollout(robot, N, parts):
+    """mobrob_ppo_collect_host on a 256-wide x3 engine: the persistent rollout kernel serves the host environment (flags in pinned
+    memory, no launch and no event inside the step loop; kernels_rollout.h KIND 3) against the launch-per-step collector
+    (MOBROB_COLLECT_SERVER=0: act_part / store_part per row range and step).  Same Philox counters, same sampling / storage /
+    time-limit bootstrap code; the policy forward is the rollout kernel's split-bf16 one where the launch-per-step path runs
+    k_fused_act on the f32 pipe, so the two agree to float32 rounding (as the device rollout and its per-step form do:
+    test_persistent_rollout_equals_per_step_rollout), not in bits -- and the quantities the kernel only moves are exact: the
+    clipped actions handed to the host, the rewards / observations taken from it.  Short episodes: truncations in every rollout.
+    Four padded observation widths, one to four row ranges, two rollouts each (noise counter and episode-start flags carry over).
+    MOBROB_COLLECT_SERVER=2 makes the engine refuse to fall back, so the served path is what ran."""
+    from mobrob_amd.envs.native_env import NativeGoalVecEnv
+    from mobrob_amd.envs.wrapper import ROBOT_DIMS
+    D, A, _ = ROBOT_DIMS[robot]
+    T = 37
+    p = O.init_params(D, A, (256, 256), (256, 256), seed=6)
+    keys = ("obs", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns", "last_values")
+    out = {}
+    for mode in ("0", "2"):
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=64, n_epochs=1, seed=11, pi=(256, 256), vf=(256, 256))
+        e.set_params(p)
+        env = NativeGoalVecEnv.for_robot(robot, N, time_limit=5, seed=7)
+        b = dict(obs=e.pinned((N, D)), clip=e.pinned((N, A)), rew=e.pinned((N,)), done=e.pinned((N,), np.uint8),
+                 trunc=e.pinned((N,), np.uint8), term=e.pinned((N, D)))
+        env.use_buffers(obs=b["obs"], rewards=b["rew"], dones=b["done"], truncated=b["trunc"], terminal_obs=b["term"])
+        env.reset()
+        os.environ["MOBROB_COLLECT_SERVER"] = mode
+        os.environ["MOBROB_SERVER_TIMEOUT_S"] = "5"
+        try:
+            res = []
+            for _ in range(2):
+                e.rollout_begin()
+                e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"]).collect(env.step_range_fn, env.handle)
+                r = {k: e.read(k) for k in keys}
+                # what the kernel only moves is exact: the host saw clip(actions) of the last step; the last observations and the
+                # rewards of rows that were not truncated in the last step are the host's
+                assert np.array_equal(b["clip"], np.clip(r["actions"][-1], -1, 1))
+                assert np.array_equal(r["obs"][T], b["obs"])
+                keep = b["trunc"] == 0
+                assert np.array_equal(r["rewards"][-1][keep], b["rew"][keep])
+                res.append(r)
+        finally:
+            os.environ.pop("MOBROB_COLLECT_SERVER", None)
+            os.environ.pop("MOBROB_SERVER_TIMEOUT_S", None)
+        out[mode] = res
+        out[mode + "stats"] = env.episode_stats()
+        env.close()
+        e.close()
+    assert out["0stats"]["episodes"] > N
+    assert out["0stats"]["episodes"] == out["2stats"]["episodes"] and out["0stats"]["goals"] == out["2stats"]["goals"]
+    tol = dict(obs=2e-5, actions=2e-5, rewards=2e-5, values=1e-4, log_probs=2e-4, advantages=1e-3, returns=1e-3, last_values=1e-4)
+    for r in range(2):
+        assert np.array_equal(out["0"][r]["episode_starts"], out["2"][r]["episode_starts"])
+        for k, bound in tol.items():
+            assert np.max(np.abs(out["0"][r][k] - out["2"][r][k])) < bound, (r, k)
+
+
+def test_served_host_rollout_gives_up_when_the_environment_fails():
+    """A step_range that reports an error in the middle of a served rollout: the host tells the waiting workgroups to stop, the
+    queued launches return at once, the call fails -- and the engine serves the next rollout normally."""
+    import ctypes
+    from mobrob_amd.envs.native_env import NativeGoalVecEnv
+    D, A, N, T = 58, 12, 64, 40
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=64, n_epochs=1, seed=1, pi=(256, 256), vf=(256, 256))
+    e.set_params(O.init_params(D, A, (256, 256), (256, 256), seed=2))
+    env = NativeGoalVecEnv.for_robot("doggo", N, time_limit=50, seed=1)
+    b = dict(obs=e.pinned((N, D)), clip=e.pinned((N, A)), rew=e.pinned((N,)), done=e.pinned((N,), np.uint8),
+             trunc=e.pinned((N,), np.uint8), term=e.pinned((N, D)))
+    env.use_buffers(obs=b["obs"], rewards=b["rew"], dones=b["done"], truncated=b["trunc"], terminal_obs=b["term"])
+    env.reset()
+    calls = [0]
+    FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+    inner = ctypes.cast(ctypes.c_void_p(env.step_range_fn), FN)
+
+    def failing(h, i0, i1, a, o, r, d, tr, to):
+        calls[0] += 1
+        return -7 if calls[0] == 25 else inner(h, i0, i1, a, o, r, d, tr, to)
+    cb = FN(failing)
+    os.environ["MOBROB_COLLECT_SERVER"] = "2"
+    os.environ["MOBROB_SERVER_TIMEOUT_S"] = "5"
+    try:
+        pipe = e.part_pipeline(2, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"])
+        e.rollout_begin()
+        with pytest.raises(Exception, match="step_range returned -7"):
+            pipe.collect(ctypes.cast(cb, ctypes.c_void_p).value, env.handle)
+        e.rollout_begin()
+        pipe.collect(env.step_range_fn, env.handle)     # and the next rollout is served
+        assert np.isfinite(e.read("advantages")).all()
+    finally:
+        os.environ.pop("MOBROB_COLLECT_SERVER", None)
+        os.environ.pop("MOBROB_SERVER_TIMEOUT_S", None)
+    env.close()
+    e.close()
+
+
 def test_part_rollout_protocol_and_counter_continuity():
     """One part == the whole batch; a rollout cannot be finished while a part lags; and a whole-batch rollout after a
     pipelined one continues the same noise sequence as after a whole-batch one."""
