@@ -153,6 +153,9 @@ __device__ __forceinline__ RolloutArgsK rollout_kernargs() {
   return p;
 }
 
+#ifndef MOBROB_ROLLOUT_BARRIER5
+#define MOBROB_ROLLOUT_BARRIER5 0
+#endif
 #ifndef MOBROB_S8_W1_FIRST
 #define MOBROB_S8_W1_FIRST 1
 #endif
@@ -473,7 +476,9 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
       } else {
         if (t + 1 < t_end) draw_env(t + 1, hid);
       }
+#if MOBROB_ROLLOUT_BARRIER5
       LDS_BARRIER(); ap_ = rollout_kernargs();  // (5) after the env phase
+#endif
       LDS_BARRIER(); ap_ = rollout_kernargs();  // (6) after the state update
     }
     if (!noise_wave) {
@@ -714,7 +719,13 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
         g = gn;
       }
     }
-    LDS_BARRIER(); ap_ = rollout_kernargs();  // every thread of a row has read the row's old state
+    // The eight threads of a row (tid >> 3) sit in ONE wave: their reads of the row's old state above are issued before lane sub == 0's
+    // writes below and a wave's LDS operations execute in order -- the workgroup barrier that used to stand here ("every thread of a
+    // row has read the row's old state") ordered nothing else (MOBROB_ROLLOUT_BARRIER5=1 brings it back; bit-identical either way).
+#if MOBROB_ROLLOUT_BARRIER5
+    LDS_BARRIER();
+#endif
+    ap_ = rollout_kernargs();
     if (live && sub == 0) {
       const size_t so = (size_t)t * N + n;
       if (ROLL_ON(128)) ar.es[so] = S[12];
