@@ -5,13 +5,13 @@ O=$R/gpurun_out/r5f
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p_kt /tmp/p_f /tmp/p_w /tmp/p_sq
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_kt -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also > $O/fused_bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_kt -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also --no-power > $O/fused_bench_under_rocprof.json 2>/dev/null
 cp $(find /tmp/p_kt -name "*kernel_stats.csv" | head -1) $O/fused_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_f -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-also > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_w -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-also > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_f -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-also --no-power > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_w -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-also --no-power > /dev/null 2>&1
 python3 $R/profiles/tools/pmc_traffic.py /tmp/p_f /tmp/p_w > $O/hbm_traffic_pmc.json
 mkdir -p $R/profiles/r5; cp $O/hbm_traffic_pmc.json $R/profiles/r5/hbm_traffic_pmc.json   # the bench lines below report this run's traffic figure (same sources)
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/p_sq -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-also > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/p_sq -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-also --no-power > /dev/null 2>&1
 python3 $R/profiles/tools/pmc_sq_summary.py /tmp/p_sq > $O/sq_counters_summary.txt 2>&1
 cd $R
 python3 bench.py --steps 20 --warmup 5 > $O/bench_final.json 2>$O/bench_final.err
