@@ -505,6 +505,56 @@ def test_served_host_rollout_gives_up_when_the_environment_fails():
     e.close()
 
 
+def test_served_host_rollout_is_bounded_when_the_host_stalls_and_refuses_shapes_it_cannot_serve():
+    """The waits of the served collector are bounded on BOTH sides: an environment that stalls longer than MOBROB_SERVER_TIMEOUT_S
+    makes the waiting workgroups give up (error word in pinned memory, abort word for the queued launches) and the call fails
+    instead of hanging the device; the next rollout is served again.  And MOBROB_COLLECT_SERVER=2 names the reason when a shape
+    cannot be served (row ranges that are not whole 32-row tiles) instead of silently taking the launch-per-step path."""
+    import ctypes
+    import time as _time
+    from mobrob_amd.envs.native_env import NativeGoalVecEnv
+    D, A, N, T = 58, 12, 64, 12
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=64, n_epochs=1, seed=1, pi=(256, 256), vf=(256, 256))
+    e.set_params(O.init_params(D, A, (256, 256), (256, 256), seed=2))
+    env = NativeGoalVecEnv.for_robot("doggo", N, time_limit=50, seed=1)
+    b = dict(obs=e.pinned((N, D)), clip=e.pinned((N, A)), rew=e.pinned((N,)), done=e.pinned((N,), np.uint8),
+             trunc=e.pinned((N,), np.uint8), term=e.pinned((N, D)))
+    env.use_buffers(obs=b["obs"], rewards=b["rew"], dones=b["done"], truncated=b["trunc"], terminal_obs=b["term"])
+    env.reset()
+    calls = [0]
+    FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+    inner = ctypes.cast(ctypes.c_void_p(env.step_range_fn), FN)
+
+    def stalling(h, i0, i1, a, o, r, d, tr, to):
+        calls[0] += 1
+        if calls[0] == 5:
+            _time.sleep(1.5)
+        return inner(h, i0, i1, a, o, r, d, tr, to)
+    cb = FN(stalling)
+    os.environ["MOBROB_COLLECT_SERVER"] = "2"
+    os.environ["MOBROB_SERVER_TIMEOUT_S"] = "0.3"
+    try:
+        pipe = e.part_pipeline(2, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"])
+        e.rollout_begin()
+        t0 = _time.time()
+        with pytest.raises(Exception, match="gave up waiting for the host"):
+            pipe.collect(ctypes.cast(cb, ctypes.c_void_p).value, env.handle)
+        assert _time.time() - t0 < 20
+        os.environ["MOBROB_SERVER_TIMEOUT_S"] = "5"
+        e.rollout_begin()
+        pipe.collect(env.step_range_fn, env.handle)
+        assert np.isfinite(e.read("advantages")).all()
+        e.rollout_begin()
+        with pytest.raises(Exception, match="not whole 32-row tiles"):
+            e.part_pipeline(4, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"]).collect(env.step_range_fn, env.handle)
+    finally:
+        os.environ.pop("MOBROB_COLLECT_SERVER", None)
+        os.environ.pop("MOBROB_SERVER_TIMEOUT_S", None)
+    env.close()
+    e.close()
+
+
 def test_part_rollout_protocol_and_counter_continuity():
     """One part == the whole batch; a rollout cannot be finished while a part lags; and a whole-batch rollout after a
     pipelined one continues the same noise sequence as after a whole-batch one."""
