@@ -834,6 +834,12 @@ def bench_single(args, name, steps, warmup, job, phases):
                                                   f"bf16 MFMA {SUSTAINED_BF16_MFMA_TFLOPS} TFLOP/s (full issue rate, random operands, 1.88 - 1.97 GHz at ~1320 W), "
                                                   f"f32 MFMA {SUSTAINED_F32_MFMA_TFLOPS} (not power limited); profiles/r5/mfma_power_probe.txt, "
                                                   f"scratch/mfma_power_probe.hip -- a measured property of the part, not the roofline's `peak`")})
+        if pw.get("package_power_w"):
+            # launch time x package power: at the cap the launch time IS (dynamic energy) / (cap - static power) -- the ablation of
+            # profiles/r5/chain_energy_ablation.txt splits the 0.33 J of k_chain_train into MFMAs 61 %, on-CU skeleton 25 %, ring DMA 10 %,
+            # dW1 running sums 6 %; the clocked-but-idle chip draws ~390 W
+            pw["joules_per_launch"] = pw["package_power_w"] * (ms / max(calls, 1)) * 1e-3
+            pw["dynamic_joules_per_launch_above_390W"] = (pw["package_power_w"] - 390.0) * (ms / max(calls, 1)) * 1e-3
         out["roofline"]["power"] = pw
     if use_dp and not identical:
         raise SystemExit("bench.py: the replicas' parameters differ between ranks")
