@@ -260,6 +260,20 @@ def power_capped_peak(x3_share):
     return 1.0 / (x3_share * X3_PRODUCTS / SUSTAINED_BF16_MFMA_TFLOPS + (1.0 - x3_share) / SUSTAINED_F32_MFMA_TFLOPS)
 
 
+def parse_smi_samples(text):
+    """[(package power in W, shader clock in MHz)] from the concatenated output of `rocm-smi --showclocks --showpower` calls: one call
+    prints its clock lines first, then the power line; a power line without a clock line in front of it is dropped."""
+    import re
+    samples, clk = [], None
+    for m in re.finditer(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)|Power \(W\):\s*([0-9.]+)", text):
+        if m.group(1):
+            clk = int(m.group(1))
+        elif clk is not None:
+            samples.append((float(m.group(2)), clk))
+            clk = None
+    return samples
+
+
 def sample_power_and_clock(run, min_samples=4):
     """Package power and shader clock (rocm-smi) while run() keeps the GPU busy: is the dominant kernel power limited?  rocm-smi
     runs in a child process with a clean environment; the samples of the busy part (>= 90 % of the highest power seen) are kept."""
@@ -289,13 +303,7 @@ def sample_power_and_clock(run, min_samples=4):
             text = log.read()
     except Exception as ex:  # noqa: BLE001 -- a diagnostic leg never fails the bench
         return {"error": f"{type(ex).__name__}: {ex}"}
-    samples, clk = [], None      # one rocm-smi call prints its clock lines first, then the power line
-    for m in re.finditer(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)|Power \(W\):\s*([0-9.]+)", text):
-        if m.group(1):
-            clk = int(m.group(1))
-        elif clk is not None:
-            samples.append((float(m.group(2)), clk))
-            clk = None
+    samples = parse_smi_samples(text)
     if len(samples) < min_samples:
         return {"error": f"only {len(samples)} rocm-smi samples", "package_cap_w": cap_w}
     top = max(p for p, _ in samples)

@@ -89,3 +89,20 @@ def test_blended_matrix_peak_of_the_x3_gradient_kernel():
     assert abs(share - 905216.0 / 984576.0) < 1e-12 and abs(share - 0.919) < 1e-3
     ideal = share * 6 / (16 * 157.3) + (1 - share) / 157.3
     assert abs(peak - 1.0 / ideal) < 1e-9 and 369.0 < peak < 370.5
+
+
+def test_rocm_smi_samples_are_paired_clock_then_power():
+    """bench.parse_smi_samples: the text of repeated `rocm-smi --showclocks --showpower` calls -> (power, shader clock) pairs; the
+    cap line of --showmaxpower and a power line that no clock line precedes are not samples."""
+    import bench
+    one = ("GPU[0]\t\t: fclk clock level: 0: (1250Mhz)\nGPU[0]\t\t: mclk clock level: 0: (2000Mhz)\nGPU[0]\t\t: sclk clock level: 1: (%dMhz)\n"
+           "=== Power Consumption ===\nGPU[0]\t\t: Current Socket Graphics Package Power (W): %s\n")
+    text = "GPU[0]\t\t: Current Socket Graphics Package Power (W): 999.0\n" + one % (2255, "1297.0") + one % (2253, "1288.0") + one % (114, "244.0")
+    assert bench.parse_smi_samples(text) == [(1297.0, 2255), (1288.0, 2253), (244.0, 114)]
+    assert bench.parse_smi_samples("") == []
+    # the blended peak with the sustained pipe rates: below the nominal blend, above the f32 pipe alone
+    D, H, A = 58, 256, 12
+    peak, share = bench.blended_peak(D, H, A, True)
+    capped = bench.power_capped_peak(share)
+    assert bench.SUSTAINED_F32_MFMA_TFLOPS < capped < peak and 0.9 < share < 0.93
+
