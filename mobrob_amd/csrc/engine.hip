@@ -1733,6 +1733,18 @@ int collect_host_served(mobrob_ppo_engine* e, mobrob_env_step_range_fn step_rang
   else if (nparts < 1 || nparts > MOBROB_MAX_PARTS || N % nparts != 0 || (N / nparts) % 32 != 0) why = "row ranges are not whole 32-row tiles";
   else if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device_id) != hipSuccess || rblocks > cus) why = "more tiles than compute units";
   else if (!is_pinned(obs) || !is_pinned(actions_clipped) || !is_pinned(rewards) || !is_pinned(dones) || !is_pinned(truncated) || !is_pinned(terminal_obs)) why = "pageable buffers";
+  // Every workgroup of a served rollout must be resident at once, and it keeps its compute unit until the host has stepped all n_steps:
+  // engines of ONE process that collect at the same time (a fleet's threads) share the device's compute units through this counter --
+  // the one that does not fit takes the launch-per-step path instead of queueing behind a kernel that waits for a host.
+  static std::atomic<int> cus_serving{0};
+  struct Lease {
+    std::atomic<int>& c; int n; bool held;
+    ~Lease() { if (held) c.fetch_sub(n); }
+  } lease{cus_serving, rblocks, false};
+  if (!why) {
+    if (cus_serving.fetch_add(rblocks) + rblocks > cus) { cus_serving.fetch_sub(rblocks); why = "the device's compute units are serving another engine's rollout"; }
+    else lease.held = true;
+  }
   if (why) return mode == 2 ? fail(MOBROB_ERR_STATE, "collect_host: MOBROB_COLLECT_SERVER=2 but %s", why) : MOBROB_OK;
   CHK(rollout_side_stream_init(e));
   CHK(streamer_init(e));

@@ -1191,6 +1191,17 @@ inline size_t rollout64_tile_lds_bytes(int Dp) {
   return (size_t)(32 * (Dp + 4) + 2 * 32 * GLDH + 2 * 32 * FLDO + 32 * 33 + 32 * 16 + 68 + 128 + 32 * 32 + 32 * 33) * sizeof(float);
 }
 
+// Step-loop barriers of the tile kernel: LDS hand-offs only (as in k_rollout_persistent: the step's global stores are read by later
+// kernels; __syncthreads() also waits for their acknowledgements at every barrier).  Worth 1 % of config 2's rollout (7.90 -> 7.80 ms),
+// nothing at 16 envs; bit-identical.  MOBROB_R64_SYNCTHREADS=1: the old form.
+#ifndef MOBROB_R64_SYNCTHREADS
+#define MOBROB_R64_SYNCTHREADS 0
+#endif
+#if MOBROB_R64_SYNCTHREADS
+#define R64_BARRIER() __syncthreads()
+#else
+#define R64_BARRIER() LDS_BARRIER()
+#endif
 #define ar (*ap_)
 #define EK0 ((uint32_t)ar.env_seed)
 #define EK1 ((uint32_t)(ar.env_seed >> 32))
@@ -1278,7 +1289,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
         for (int j = 0; j < 4; ++j) lds[L::ZN + rr_ * 32 + 4 * gq + j] = z[j];
       }
     }
-    __syncthreads(); ap_ = rollout_kernargs();
+    R64_BARRIER(); ap_ = rollout_kernargs();
     if (wave < 2) {  // layer 2
       f32x16 c = splat16(bias2);
       gemm_one_ro<GLDH, 8>(L::H1, f2, c, lane);
@@ -1286,7 +1297,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) lds[o + crc(i) * GLDH] = fast_tanh_scaled(c[i]);
     }
-    __syncthreads(); ap_ = rollout_kernargs();
+    R64_BARRIER(); ap_ = rollout_kernargs();
     if (wave < 2) {  // head: wave 0 the even k-groups (tile64_forward's `acc`), wave 1 the odd ones (`acc2`)
       f32x16 acc = zero16();
       const int ab = 4 * opaque((L::H2 + r * GLDH + 4 * h) >> 2);
@@ -1300,7 +1311,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) lds[o + crc(i) * FLDO] = acc[i];
     }
-    __syncthreads(); ap_ = rollout_kernargs();
+    R64_BARRIER(); ap_ = rollout_kernargs();
     // ---- Gaussian sample + log-prob (expressions and Philox counters of k_fused64_act), then env.step(clipped actions) +
     //      auto-reset: the SAME 8 threads serve a row in both (actions sub, sub + 8, ...; observation chunks sub, sub + 8):
     //      they sit in one wave, so the row's clipped actions and log-prob terms are ordered by the wave's DS queue and no
@@ -1413,7 +1424,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
         ar.rewards[so] = reward;
       }
     }
-    __syncthreads(); ap_ = rollout_kernargs();  // next observation tile, row state and the bootstrap list are complete
+    R64_BARRIER(); ap_ = rollout_kernargs();  // next observation tile, row state and the bootstrap list are complete
     // ---- time-limit bootstrap of the (rare) truncated rows: wave 0 evaluates the value MLP row by row ----
     const int m = *cnt;
     if (m > 0) {  // block-uniform

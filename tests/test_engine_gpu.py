@@ -555,6 +555,74 @@ def test_served_host_rollout_is_bounded_when_the_host_stalls_and_refuses_shapes_
     e.close()
 
 
+def test_served_rollouts_of_two_engines_share_the_compute_units_through_a_lease():
+    """Every workgroup of a served rollout stays resident until the host has stepped all n_steps, so two engines of one process
+    that collect at the same time must fit the device's compute units TOGETHER: the second one (160 + 160 tiles > 256 CUs) is told
+    so in required mode (and takes the launch-per-step path otherwise) instead of queueing behind a kernel that waits for a host."""
+    import ctypes
+    import threading
+    import time as _time
+    from mobrob_amd.envs.native_env import NativeGoalVecEnv
+    D, A, N, T = 14, 2, 32 * 160, 6
+    p = O.init_params(D, A, (256, 256), (256, 256), seed=3)
+    FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+    rigs = []
+    for k in range(2):
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=1024, n_epochs=1, seed=k, pi=(256, 256), vf=(256, 256))
+        e.set_params(p)
+        env = NativeGoalVecEnv.for_robot("point", N, time_limit=50, seed=k)
+        b = dict(obs=e.pinned((N, D)), clip=e.pinned((N, A)), rew=e.pinned((N,)), done=e.pinned((N,), np.uint8),
+                 trunc=e.pinned((N,), np.uint8), term=e.pinned((N, D)))
+        env.use_buffers(obs=b["obs"], rewards=b["rew"], dones=b["done"], truncated=b["trunc"], terminal_obs=b["term"])
+        env.reset()
+        rigs.append((e, env, b))
+    inner = ctypes.cast(ctypes.c_void_p(rigs[0][1].step_range_fn), FN)
+    first = [True]
+
+    def slow_first_step(h, i0, i1, a, o, r, d, tr, to):
+        if first[0]:
+            first[0] = False
+            _time.sleep(0.6)          # engine 0's kernel is resident and waiting for this while engine 1 asks for its lease
+        return inner(h, i0, i1, a, o, r, d, tr, to)
+    cb = FN(slow_first_step)
+    res = {}
+
+    def run(k, fn):
+        e, env, b = rigs[k]
+        try:
+            e.rollout_begin()
+            e.part_pipeline(1 if k == 0 else 2, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"]).collect(fn, env.handle)
+            res[k] = "ok"
+        except Exception as ex:  # noqa: BLE001
+            res[k] = str(ex)
+    os.environ["MOBROB_COLLECT_SERVER"] = "2"
+    os.environ["MOBROB_SERVER_TIMEOUT_S"] = "10"
+    try:
+        t0 = threading.Thread(target=run, args=(0, ctypes.cast(cb, ctypes.c_void_p).value))
+        t0.start()
+        _time.sleep(0.2)
+        run(1, rigs[1][1].step_range_fn)
+        t0.join()
+        assert res[0] == "ok", res
+        assert "serving another engine" in res[1], res
+        os.environ["MOBROB_COLLECT_SERVER"] = "1"      # not required: the same situation falls back and completes
+        first[0] = True
+        t0 = threading.Thread(target=run, args=(0, ctypes.cast(cb, ctypes.c_void_p).value))
+        t0.start()
+        _time.sleep(0.2)
+        run(1, rigs[1][1].step_range_fn)
+        t0.join()
+        assert res[0] == "ok" and res[1] == "ok", res
+        assert np.isfinite(rigs[1][0].read("advantages")).all() and np.isfinite(rigs[0][0].read("advantages")).all()
+    finally:
+        os.environ.pop("MOBROB_COLLECT_SERVER", None)
+        os.environ.pop("MOBROB_SERVER_TIMEOUT_S", None)
+    for e, env, _ in rigs:
+        env.close()
+        e.close()
+
+
 def test_part_rollout_protocol_and_counter_continuity():
     """One part == the whole batch; a rollout cannot be finished while a part lags; and a whole-batch rollout after a
     pipelined one continues the same noise sequence as after a whole-batch one."""
