@@ -965,11 +965,15 @@ def host_path_measurements(args, job):
                           "for its row range (the range's first workgroup polls host memory and relays through a device word); no launch, no event, "
                           "no HIP call inside the step loop (csrc/kernels_rollout.h KIND 3, engine.hip collect_host_served); "
                           "pipelined_launch_per_step_collector = the round-4 form (two launches and an event per range and step), MOBROB_COLLECT_SERVER=0"),
-            "collector_overhead_us_per_step": us(sweep[best]) - max(us(t_sim), us(t_gpu)),
+            # served collector: the device's work hides under the simulator's -> overhead over the simulator alone; launch-per-step
+            # collector: over the longer of ITS two legs (gpu_act_store_alone is that collector's GPU leg: act + store launches per step)
+            "collector_overhead_us_per_step": {
+                "served (pipelined - host_sim_alone)": us(sweep[best]) - us(t_sim),
+                "launch_per_step (pipelined - longer leg)": us(min(sweep_launch.values())) - max(us(t_sim), us(t_gpu))},
             "rollout_only_env_steps_per_s": N * T / sweep[best], "best_host_parts": best,
             "update_ms": 1e3 * t_upd,
-            "note": ("every leg = (leg + update) - update alone, inside PPO iterations (GPU clocks as in the real loop); overhead = pipelined "
-                     "wall minus the longer of its two legs: what the hand-off itself costs once sim and policy overlap"),
+            "note": ("every leg = (leg + update) - update alone, inside PPO iterations (GPU clocks as in the real loop); overhead = what the "
+                     "hand-off itself costs once simulator and policy overlap"),
         }
         host.close()
         eng.close()
