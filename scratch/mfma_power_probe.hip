@@ -23,6 +23,7 @@ __device__ __forceinline__ unsigned rnd_bf16x2(unsigned s) {
 }
 
 // MODE 0: bf16 16x16x32, random operands (eight different A / B register sets in turn)   1: the same, all operands zero
+// MODE 5 / 6: 16x16x32 with the same A and B registers in every MFMA / A fixed and B changing (does switching operands cost power?)
 // MODE 4: bf16 32x32x16, random operands (two accumulators in turn)
 // MODE 2: f32 16x16x4, random operands                                                   3: bf16 at HALF issue rate (an s_sleep-free gap: 4 v_nop-class VALU between MFMAs)
 template <int MODE, int NT>
@@ -50,6 +51,8 @@ __global__ __launch_bounds__(NT) void k(int iters, float* out, unsigned long lon
       }
       f32x4& c = acc[u & 3];
       if (MODE == 2) c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[(u >> 2) & 3], fb[u & 3], c, 0, 0, 0);
+      else if (MODE == 5) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), c, 0, 0, 0);   // the SAME operand registers every time
+      else if (MODE == 6) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[u & 3]), c, 0, 0, 0);   // A fixed, B changes every MFMA
       else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[(u >> 2) & 3]), __builtin_bit_cast(bf16x8, b[u & 3]), c, 0, 0, 0);
       if (MODE == 3) asm volatile("s_nop 7\n\ts_nop 7");
     }
@@ -97,6 +100,8 @@ int main(int argc, char** argv) {
   run<0, 512>("bf16 16x16x32, random operands, 2 waves / SIMD", seconds, out, cyc);
   run<1, 256>("bf16 16x16x32, all operands zero, 1 wave / SIMD", seconds, out, cyc);
   run<3, 256>("bf16 16x16x32, random operands, ~half issue rate (s_nop gaps)", seconds, out, cyc);
+  run<5, 512>("bf16 16x16x32, random operands, the SAME A and B registers every MFMA, 2 waves / SIMD", seconds, out, cyc);
+  run<6, 512>("bf16 16x16x32, random operands, A fixed, B changes every MFMA, 2 waves / SIMD", seconds, out, cyc);
   run<4, 256>("bf16 32x32x16, random operands, 1 wave / SIMD (per 2 x 16x16x32 of work)", seconds, out, cyc);
   run<4, 512>("bf16 32x32x16, random operands, 2 waves / SIMD", seconds, out, cyc);
   run<2, 256>("f32 16x16x4, random operands, 1 wave / SIMD", seconds, out, cyc);
