@@ -687,6 +687,29 @@ bool is_pinned(const void* p) {
   }
   return at.type == hipMemoryTypeHost;
 }
+// What the SERVED host collector (collect_host_served) may be handed: the rollout kernel's hand-over is built on system-scope
+// write-through stores, relaxed flag words and one acquire per step, which is sound for COHERENT (fine-grained) host memory --
+// hipHostMalloc(Coherent) and hipHostRegister blocks while HIP_HOST_COHERENT is not 0.  A non-coherent allocation is refused by
+// name, and BOTH ends of the range the kernel reads / writes must lie in device-visible host memory (the first byte alone says
+// nothing about an [N][D] array).
+const char* served_buffer_problem(const void* p, size_t bytes) {
+  if (!p || bytes == 0) return "a null or empty buffer";
+  const char* hc = getenv("HIP_HOST_COHERENT");
+  const bool default_noncoherent = hc != nullptr && atoi(hc) == 0;
+  const char* ends[2] = {static_cast<const char*>(p), static_cast<const char*>(p) + bytes - 1};
+  for (const char* q : ends) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, q) != hipSuccess) {
+      (void)hipGetLastError();
+      return q == ends[0] ? "pageable buffers" : "a buffer whose end lies outside the pinned block";
+    }
+    if (at.type != hipMemoryTypeHost) return "buffers that are not pinned host memory";
+    if (at.allocationFlags & hipHostMallocNonCoherent) return "a non-coherent host allocation (hipHostMallocNonCoherent)";
+    if (default_noncoherent && !(at.allocationFlags & hipHostMallocCoherent))
+      return "host memory that is non-coherent by default (HIP_HOST_COHERENT=0) and was not allocated hipHostMallocCoherent";
+  }
+  return nullptr;
+}
 // The per-step calls of the pipelined host path see the same few buffers for a whole rollout: a pointer that was
 // found pinned is remembered until the next rollout_begin (the driver query costs about a microsecond each time).
 bool is_pinned_cached(mobrob_ppo_engine* e, const void* p) {
@@ -778,7 +801,11 @@ void mobrob_ppo_default_config(mobrob_ppo_config_t* c) {
 
 void* mobrob_ppo_host_alloc(size_t bytes) {
   void* p = nullptr;
-  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  // coherent (fine-grained) whatever HIP_HOST_COHERENT says: the zero-copy and served collectors hand data over through it
+  if (hipHostMalloc(&p, bytes, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  }
   return p;
 }
 void mobrob_ppo_host_free(void* p) { if (p) (void)hipHostFree(p); }
@@ -1732,17 +1759,30 @@ int collect_host_served(mobrob_ppo_engine* e, mobrob_env_step_range_fn step_rang
   else if (getenv("MOBROB_COLLECT_TIMING") || (getenv("MOBROB_COLLECT_THREADS") && atoi(getenv("MOBROB_COLLECT_THREADS")) != 0)) why = "an instrumented / threaded collector was asked for";
   else if (nparts < 1 || nparts > MOBROB_MAX_PARTS || N % nparts != 0 || (N / nparts) % 32 != 0) why = "row ranges are not whole 32-row tiles";
   else if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device_id) != hipSuccess || rblocks > cus) why = "more tiles than compute units";
-  else if (!is_pinned(obs) || !is_pinned(actions_clipped) || !is_pinned(rewards) || !is_pinned(dones) || !is_pinned(truncated) || !is_pinned(terminal_obs)) why = "pageable buffers";
+  // Other tenants of the device that this process cannot count: ranks rehearsing data parallelism on ONE device, a CU mask.  Every
+  // workgroup of a served rollout must be resident at once (a waiting workgroup never yields its CU), so with them the launch-per-step
+  // collector -- which always works -- is the one that runs.  (A tenant nobody announced is caught by the residency check below.)
+  else if (getenv("MOBROB_DP_SAME_DEVICE") && atoi(getenv("MOBROB_DP_SAME_DEVICE")) != 0 && e->cfg.world_size > 1) why = "several data-parallel ranks share this device (MOBROB_DP_SAME_DEVICE)";
+  else if (getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK")) why = "a compute-unit mask is set (HSA_CU_MASK / ROC_GLOBAL_CU_MASK)";
+  else {
+    const size_t N_ = (size_t)N;
+    const struct { const void* p; size_t bytes; } bufs[6] = {{obs, N_ * e->D * 4}, {actions_clipped, N_ * e->A * 4}, {rewards, N_ * 4},
+                                                              {dones, N_}, {truncated, N_}, {terminal_obs, N_ * e->D * 4}};
+    for (const auto& b : bufs)
+      if (!why) why = served_buffer_problem(b.p, b.bytes);
+  }
   // Every workgroup of a served rollout must be resident at once, and it keeps its compute unit until the host has stepped all n_steps:
-  // engines of ONE process that collect at the same time (a fleet's threads) share the device's compute units through this counter --
-  // the one that does not fit takes the launch-per-step path instead of queueing behind a kernel that waits for a host.
-  static std::atomic<int> cus_serving{0};
+  // engines of ONE process that collect at the same time (a fleet's threads) share a DEVICE's compute units through that device's
+  // counter -- the one that does not fit takes the launch-per-step path instead of queueing behind a kernel that waits for a host.
+  constexpr int kLeaseDevices = 64;
+  static std::atomic<int> cus_serving[kLeaseDevices];   // zero-initialised (static storage)
+  std::atomic<int>& dev_lease = cus_serving[(unsigned)e->cfg.device_id % kLeaseDevices];
   struct Lease {
     std::atomic<int>& c; int n; bool held;
     ~Lease() { if (held) c.fetch_sub(n); }
-  } lease{cus_serving, rblocks, false};
+  } lease{dev_lease, rblocks, false};
   if (!why) {
-    if (cus_serving.fetch_add(rblocks) + rblocks > cus) { cus_serving.fetch_sub(rblocks); why = "the device's compute units are serving another engine's rollout"; }
+    if (dev_lease.fetch_add(rblocks) + rblocks > cus) { dev_lease.fetch_sub(rblocks); why = "the device's compute units are serving another engine's rollout"; }
     else lease.held = true;
   }
   if (why) return mode == 2 ? fail(MOBROB_ERR_STATE, "collect_host: MOBROB_COLLECT_SERVER=2 but %s", why) : MOBROB_OK;
@@ -1783,6 +1823,21 @@ int collect_host_served(mobrob_ppo_engine* e, mobrob_env_step_range_fn step_rang
   a.h_gpu_flag = gpu_flag; a.h_host_flag = host_flag; a.h_error = err_word; a.abort_dev = e->srv_abort;
   a.rows_per_part = N / nparts; a.timeout_ticks = (long long)(timeout_s * 1e8);
 
+  // From the first KIND-3 launch on, EVERY way out of this function that is not the normal one tells the (possibly resident, possibly
+  // waiting) workgroups to stop first: they would otherwise spin for the whole timeout and the next synchronising call with them.
+  auto give_up = [&](void) {
+    for (int p = 0; p < nparts; ++p) __atomic_store_n(reinterpret_cast<unsigned long long*>(&host_flag[16 * p]), 0xFFFFFFFFull, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipStreamSynchronize(e->vstream);
+  };
+#define SRV_HIPC(expr)                                                                                          \
+  do {                                                                                                          \
+    hipError_t _e = (expr);                                                                                     \
+    if (_e != hipSuccess) {                                                                                     \
+      give_up();                                                                                                \
+      return fail(MOBROB_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);   \
+    }                                                                                                           \
+  } while (0)
   // chunks of the step loop on the compute stream, V(obs) of a finished chunk on the side stream (as enqueue_rollout_persistent)
   const bool overlap = rblocks <= 192;
   const int chunk = overlap ? std::max(16, cdiv(T, 20)) : T;
@@ -1799,8 +1854,8 @@ int collect_host_served(mobrob_ppo_engine* e, mobrob_env_step_range_fn step_rang
                                                rollout_lds_bytes(Dp, true), e->stream, a));
       if (overlap && a.t1 < T) {
         hipEvent_t ev = e->ev_chunks[t0 / chunk];
-        HIPC(hipEventRecord(ev, e->stream));
-        HIPC(hipStreamWaitEvent(e->vstream, ev, 0));
+        SRV_HIPC(hipEventRecord(ev, e->stream));
+        SRV_HIPC(hipStreamWaitEvent(e->vstream, ev, 0));
         value_pass(e->vstream, t0 * N, a.t1 * N, vgrid_max);
       }
     }
@@ -1810,20 +1865,38 @@ int collect_host_served(mobrob_ppo_engine* e, mobrob_env_step_range_fn step_rang
     const int done_rows = overlap ? ((T - 1) / chunk) * chunk * N : 0;
     value_pass(e->stream, done_rows, T * N, 256);
     if (overlap && done_rows > 0) {
-      HIPC(hipEventRecord(e->ev_vdone, e->vstream));
-      HIPC(hipStreamWaitEvent(e->stream, e->ev_vdone, 0));
+      SRV_HIPC(hipEventRecord(e->ev_vdone, e->vstream));
+      SRV_HIPC(hipStreamWaitEvent(e->stream, e->ev_vdone, 0));
     }
   }
-  HIPC(hipGetLastError());
+  SRV_HIPC(hipGetLastError());
+#undef SRV_HIPC
 
   // ---- the host's side of the step loop: wait for the flags of a row range, step it, raise the range's word ----
-  auto give_up = [&](void) {
-    for (int p = 0; p < nparts; ++p) __atomic_store_n(reinterpret_cast<unsigned long long*>(&host_flag[16 * p]), 0xFFFFFFFFull, __ATOMIC_RELEASE);
-    (void)hipStreamSynchronize(e->stream);
-    (void)hipStreamSynchronize(e->vstream);
-  };
   auto now_s = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
   const int bpp = (N / nparts) / 32;   // workgroups per row range
+  {
+    // Residency check, before the environment is touched: the clipped actions of step 0 of EVERY workgroup within a short bound
+    // (MOBROB_SERVER_RESIDENCY_S, default 2 s; a resident workgroup needs ~25 us).  A workgroup that is not resident -- another
+    // process on the device, a CU mask nobody announced -- would leave the resident ones waiting for the host while the host waits
+    // for it: instead of stalling for the whole timeout and failing the rollout, the launches are told to stop and the caller runs
+    // the launch-per-step collector from the untouched rollout state (nothing has been stepped, no counter has moved).
+    const double bound = getenv("MOBROB_SERVER_RESIDENCY_S") ? atof(getenv("MOBROB_SERVER_RESIDENCY_S")) : 2.0;
+    const double r0 = now_s();
+    bool all_resident = false;
+    for (unsigned spins = 0;; ++spins) {
+      int b = 0;
+      while (b < rblocks && __atomic_load_n(&gpu_flag[b], __ATOMIC_ACQUIRE) >= 1u) ++b;
+      if (b == rblocks) { all_resident = true; break; }
+      __builtin_ia32_pause();
+      if ((spins & 0x3FFu) == 0x3FFu && (__atomic_load_n(err_word, __ATOMIC_ACQUIRE) != 0 || now_s() - r0 > bound)) break;
+    }
+    if (!all_resident) {
+      give_up();
+      if (mode == 2) return fail(MOBROB_ERR_STATE, "collect_host: MOBROB_COLLECT_SERVER=2 but not every workgroup of the rollout kernel became resident within %.1f s (another tenant on the device?)", bound);
+      return MOBROB_OK;   // *served is false: the caller's launch-per-step loop takes over
+    }
+  }
   const bool timing = getenv("MOBROB_SERVER_TIMING") != nullptr;   // per-step split of the host thread's time (stderr)
   double tw = 0, te = 0;
   for (int t = 0; t < T; ++t) {

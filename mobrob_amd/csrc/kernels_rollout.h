@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
   // Kernel arguments inside the step loop are read THROUGH the kernarg segment where they are used (`ar`: the same struct behind a
   // constant-address-space reference, re-materialised per step so that nothing is hoisted): by value they are ~60 pointers and
   // ~120 scalars that the compiler loads once and then has to keep through the loop -- 147 .. 220 of them parked in lanes of vector
-  // registers, read back with v_readlane on the step's critical path (__graft_entry__.build() fails above 64).
+  // registers, read back with v_readlane on the step's critical path (__graft_entry__.build() fails above SGPR_PARK_LIMIT = 84).
   const int t_begin = a.t0, t_end = a.t1;
   for (int t = t_begin; t < t_end; ++t) {
     RolloutArgsK ap_ = rollout_kernargs();   // `ar` below: (*ap_), re-materialised behind every barrier (a phase keeps only what it uses)
@@ -600,6 +600,12 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void k_rollout_persistent(Rollo
           if (relay) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(2);
         }
         if (relay) __hip_atomic_store(df, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ONE system-scope acquire between the word's arrival and host_pull (buffer_inv sc0 sc1: this CU's L1 and the XCD L2's
+        // non-coherent lines), completed (vmcnt) before barrier (4b) lets the other waves load: what the host wrote before it
+        // raised its word is what every load behind the barrier sees, whatever the caching policy of the block.  (The polls
+        // themselves stay relaxed: an acquire per poll is an invalidate per PCIe round trip.)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const bool dead = (unsigned)v == 0xFFFFFFFFu;
         if (dead) __hip_atomic_store(ar.abort_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         SERVE_STAMP(1)   // the host's word arrived

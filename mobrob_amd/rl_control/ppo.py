@@ -501,7 +501,7 @@ class PPO:
                 # a callback may stop SOME ranks only (it sees its own shard): the stop flag is agreed across the ranks
                 # before anybody leaves the loop, so no rank enters train()'s collectives -- or the closing barrier -- alone
                 from ..parallel import agree_all
-                go_on = agree_all(go_on, device_id=int(self.engine.cfg.device_id))
+                go_on = agree_all(go_on, group=getattr(self._backend, "_group", None), device_id=int(self.engine.cfg.device_id))
             if not go_on:
                 break
             iteration += 1
@@ -518,9 +518,13 @@ class PPO:
         if self._tb is not None:
             self._tb.close()
             self._tb = None
-        callback.on_training_end()   # before the collective close: a callback that raises here leaves no rank inside a barrier
-        if self._backend is not None:
-            self._backend.close()     # one-shot exchange: collective closing handshake (parallel.EngineBackend.close)
+        try:
+            callback.on_training_end()
+        finally:
+            # EVERY rank reaches the collective closing handshake (parallel.EngineBackend.close: drain, barrier, unmap the one-shot
+            # exchange), also the rank whose callback raised: its peers would otherwise wait in the barrier for it
+            if self._backend is not None:
+                self._backend.close()
         return self
 
     def _log(self, iteration, stats):

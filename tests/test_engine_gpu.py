@@ -466,6 +466,109 @@ def test_served_host_rollout_equals_the_launch_per_step_rollout(robot, N, parts)
             assert np.max(np.abs(out["0"][r][k] - out["2"][r][k])) < bound, (r, k)
 
 
+class _RecordingStepRange:
+    """A mobrob_env_step_range_fn that forwards to a native environment's and keeps a copy of what the host handed over per step and
+    row range (rewards, done / truncated flags, terminal and next observations): what an oracle check of a host-env rollout needs."""
+
+    def __init__(self, env, b, T, N, D):
+        import ctypes
+        self.FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+        self.inner = ctypes.cast(ctypes.c_void_p(env.step_range_fn), self.FN)
+        self.b, self.T, self.N, self.D = b, T, N, D
+        self.cb = self.FN(self._call)
+        self.address = ctypes.cast(self.cb, ctypes.c_void_p).value
+        self.begin()
+
+    def begin(self):
+        T, N, D = self.T, self.N, self.D
+        self.rew, self.done, self.trunc = np.zeros((T, N), np.float32), np.zeros((T, N), bool), np.zeros((T, N), bool)
+        self.term, self.nxt = np.zeros((T, N, D), np.float32), np.zeros((T, N, D), np.float32)
+        self.clip = np.zeros((T, N, self.b["clip"].shape[1]), np.float32)
+        self.steps = {}
+        self.obs0 = self.b["obs"].copy()
+
+    def _call(self, h, i0, i1, a, o, r, d, tr, to):
+        t = self.steps.get(i0, 0)
+        self.clip[t, i0:i1] = self.b["clip"][i0:i1]          # the clipped actions the host is about to step with
+        rc = self.inner(h, i0, i1, a, o, r, d, tr, to)
+        self.rew[t, i0:i1], self.done[t, i0:i1] = self.b["rew"][i0:i1], self.b["done"][i0:i1] != 0
+        self.trunc[t, i0:i1] = (self.b["trunc"][i0:i1] != 0) if rc > 0 else False
+        self.term[t, i0:i1], self.nxt[t, i0:i1] = self.b["term"][i0:i1], self.b["obs"][i0:i1]
+        self.steps[i0] = t + 1
+        return rc
+
+
+def _check_host_rollout_against_oracle(e, p, rec, first_starts, gamma=0.99, lam=0.95):
+    """A host-env rollout held to the ORACLE at north_star's 1e-4: values / log-probs of the stored observations and actions
+    (O.policy_outputs, O.gaussian_log_prob), what the kernel only moves exactly (observations, rewards, episode starts, clipped
+    actions), the time-limit bootstrap of truncated rows (O.bootstrap_reward on V(terminal observation)), and GAE on the stored
+    arrays bit for bit (O.gae).  Returns the episode-start flags the NEXT rollout must begin with."""
+    T, N, D = rec.T, rec.N, rec.D
+    r = {k: e.read(k) for k in ("obs", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns",
+                                 "last_values", "last_dones")}
+    assert np.array_equal(r["obs"][0], rec.obs0) and np.array_equal(r["obs"][1:T + 1], rec.nxt)
+    assert np.array_equal(rec.clip, np.clip(r["actions"], -1, 1))
+    starts = np.concatenate([first_starts[None].astype(np.float32), rec.done[:-1].astype(np.float32)])
+    assert np.array_equal(r["episode_starts"], starts)
+    mean, val = O.policy_outputs(p, r["obs"][:T].reshape(T * N, D))
+    assert np.max(np.abs(r["values"].reshape(-1) - val)) < 1e-4 * max(1.0, float(np.max(np.abs(val))))
+    lp = O.gaussian_log_prob(mean, p["log_std"], r["actions"].reshape(T * N, -1))
+    assert np.max(np.abs(r["log_probs"].reshape(-1) - lp)) < 1e-4 * max(1.0, float(np.max(np.abs(lp))))
+    _, lastv = O.policy_outputs(p, r["obs"][T])
+    assert np.max(np.abs(r["last_values"] - lastv)) < 1e-4 * max(1.0, float(np.max(np.abs(lastv))))
+    keep = ~rec.trunc
+    assert np.array_equal(r["rewards"][keep], rec.rew[keep])
+    if rec.trunc.any():
+        tt, nn = np.nonzero(rec.trunc)
+        _, tv = O.policy_outputs(p, rec.term[tt, nn])
+        want = np.array([O.bootstrap_reward(rec.rew[t, n], gamma, v) for t, n, v in zip(tt, nn, tv)], np.float32)
+        assert np.max(np.abs(r["rewards"][tt, nn] - want)) < 1e-4 * max(1.0, float(np.max(np.abs(want))))
+    assert np.array_equal(r["last_dones"] > 0, rec.done[-1])
+    adv, ret = O.gae(r["rewards"], r["values"], r["episode_starts"], r["last_values"], rec.done[-1], gamma, lam)
+    assert np.array_equal(r["advantages"], adv) and np.array_equal(r["returns"], ret)
+    return rec.done[-1].copy()
+
+
+@pytest.mark.parametrize("robot,H,N,parts", [("doggo", 256, 192, 2), ("point", 256, 128, 4), ("car", 256, 96, 3), ("drone", 256, 64, 1)])
+def test_served_host_rollout_matches_the_oracle(robot, H, N, parts):
+    """The SERVED host collector (the rollout kernel hands actions over and pulls the host's step through pinned flag words:
+    kernels_rollout.h KIND 3; MOBROB_COLLECT_SERVER=2 refuses to fall back) against the oracle, not against another HIP path:
+    SB3's collect_rollouts [reached through /root/reference/src/mobrob/rl_control/ppo.py:73-74] on the VecEnv contract of
+    /root/reference/src/mobrob/envs/wrapper.py:156-201.  Two rollouts (episode starts and the noise counter carry over), short
+    episodes (truncations with a bootstrap in every rollout)."""
+    from mobrob_amd.envs.native_env import NativeGoalVecEnv
+    from mobrob_amd.envs.wrapper import ROBOT_DIMS
+    D, A, _ = ROBOT_DIMS[robot]
+    T = 29
+    p = O.init_params(D, A, (H, H), (H, H), seed=8)
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=64, n_epochs=1, seed=5, pi=(H, H), vf=(H, H))
+    e.set_params(p)
+    env = NativeGoalVecEnv.for_robot(robot, N, time_limit=5, seed=2)
+    b = dict(obs=e.pinned((N, D)), clip=e.pinned((N, A)), rew=e.pinned((N,)), done=e.pinned((N,), np.uint8),
+             trunc=e.pinned((N,), np.uint8), term=e.pinned((N, D)))
+    env.use_buffers(obs=b["obs"], rewards=b["rew"], dones=b["done"], truncated=b["trunc"], terminal_obs=b["term"])
+    env.reset()
+    rec = _RecordingStepRange(env, b, T, N, D)
+    os.environ["MOBROB_COLLECT_SERVER"] = "2"
+    os.environ["MOBROB_SERVER_TIMEOUT_S"] = "5"
+    try:
+        starts = np.ones(N, bool)
+        saw_trunc = False
+        for _ in range(2):
+            rec.begin()
+            e.rollout_begin()
+            e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"]).collect(rec.address, env.handle)
+            saw_trunc |= bool(rec.trunc.any())
+            starts = _check_host_rollout_against_oracle(e, p, rec, starts)
+        assert saw_trunc
+    finally:
+        os.environ.pop("MOBROB_COLLECT_SERVER", None)
+        os.environ.pop("MOBROB_SERVER_TIMEOUT_S", None)
+    env.close()
+    e.close()
+
+
 def test_served_host_rollout_gives_up_when_the_environment_fails():
     """A step_range that reports an error in the middle of a served rollout: the host tells the waiting workgroups to stop, the
     queued launches return at once, the call fails -- and the engine serves the next rollout normally."""
