@@ -43,6 +43,8 @@ WORKLOADS = {
     # PCIe-inclusive rate of DESIGN.md -- never the headline `value`, which keeps its inputs resident in HBM
     "doggo-4096env-2x256-hostenv": dict(D=58, A=12, H=256, N=4096, T=1000, E=5, B=65536, p_term=1 / 107.0, tl=1000,
                                         host_env="doggo"),
+    # BASELINE configs[1] with the environments on the HOST: the 2x64 networks every reference YAML trains, served by k_rollout64_tile<.., 3>
+    "point-1024env-2x64-hostenv": dict(D=14, A=2, H=64, N=1024, T=2048, E=10, B=65536, p_term=1 / 119.0, tl=1000, host_env="point"),
     # BASELINE configs[4]: mixed fleet, ragged obs/act dims packed into one rollout arena (mobrob_amd/fleet.py)
     "fleet-car-drone-turtlebot3-2x64": dict(segments=["car", "drone", "turtlebot3"], H=64, N=1024, T=2048, E=10,
                                             B=65536, tl=1000),
@@ -857,23 +859,16 @@ def bench_single(args, name, steps, warmup, job, phases):
     return out
 
 
-def host_path_measurements(args, job):
-    """north_star's own data path in front of the driver (VERDICT r4 #4): host-core environments -> pinned staging -> GPU policy ->
-    actions back, at the headline shape (doggo 58 / 12, 4096 envs, 2x256).  Reference: the VecEnv loop SB3 drives through
-    /root/reference/src/mobrob/rl_control/ppo.py:30-48 over EnvWrapper.step (/root/reference/src/mobrob/envs/wrapper.py:156-201).
-
-    Three numbers per collector, per vector step of all environments, so that collector overhead is a figure, not a guess:
-      host_sim_alone   the environments stepped with fixed actions, no GPU work
-      gpu_alone        act + store on static staging buffers, no environment stepped
-      pipelined        the collector as it runs (mobrob_ppo_collect_host for the native env, PPO's part pipeline for ShmVecEnv)
-    and, for the native env, the `host_parts` sweep 1 / 2 / 4 / 8 plus the whole iteration (rollout + update) at the best setting."""
+def native_env_legs(args, job, wname, parts_sweep=(2, 4, 8, 1), launch_sweep=(2, 4)):
+    """Three numbers per vector step for the native C env behind mobrob_ppo_collect_host at workload `wname` (simulator alone / GPU act +
+    store alone / pipelined, served and launch-per-step collectors), and the whole PPO iteration at the best row-range count."""
     import copy
-    import torch
     from mobrob_amd.engine import PPOEngine
     from mobrob_amd.envs.native_env import NativeGoalVecEnv
     res = {}
-    w = WORKLOADS["doggo-4096env-2x256-hostenv"]
+    w = WORKLOADS[wname]
     D, A, H, N, T, E, B = w["D"], w["A"], w["H"], w["N"], w["T"], w["E"], w["B"]
+    tag = "" if wname.startswith("doggo-4096env-2x256") else f" [{wname}]"
 
     def timed(fn, sync):
         sync()
@@ -882,7 +877,6 @@ def host_path_measurements(args, job):
         sync()
         return time.perf_counter() - t0
 
-    # ---- (1) native C env (csrc/host_env.c, OpenMP), pinned zero-copy staging ----
     try:
         eng = PPOEngine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H), ent_coef=0.01,
                         seed=0, device_id=job.device_id)
@@ -915,7 +909,7 @@ def host_path_measurements(args, job):
                 if parts > 1:
                     pipe = eng.part_pipeline(parts, hb["obs"], hb["clip"], hb["rew"], hb["done"], hb["trunc"], hb["term"])
                     # served: the persistent rollout kernel serves the host env (flags in pinned memory, no launch / event per step;
-                    # the default on 256-wide x3 engines); else the launch-per-step collector (act_part / store_part per row range)
+                    # the default on fused engines: 256-wide x3 and 64-wide); else the launch-per-step collector (act_part / store_part per row range)
                     os.environ["MOBROB_COLLECT_SERVER"] = "1" if served else "0"
                     try:
                         pipe.collect(host.step_range_fn, host.handle)  # the whole loop in one native call, finish_rollout included
@@ -948,13 +942,13 @@ def host_path_measurements(args, job):
         t_sim = in_iteration(sim_alone) - t_upd
         t_gpu = in_iteration(gpu_alone) - t_upd
         sweep, sweep_launch = {}, {}
-        for parts in (2, 4, 8, 1):
+        for parts in parts_sweep:
             sweep[parts] = in_iteration(collector(parts)) - t_upd
-        for parts in (2, 4):
+        for parts in launch_sweep:
             sweep_launch[parts] = in_iteration(collector(parts, served=False)) - t_upd
         best = min(sweep, key=sweep.get)
         us = lambda t: 1e6 * t / T   # noqa: E731 - microseconds per vector step of N environments
-        res["native-c-env (csrc/host_env.c), pinned zero-copy, mobrob_ppo_collect_host"] = {
+        res["native-c-env (csrc/host_env.c), pinned zero-copy, mobrob_ppo_collect_host" + tag] = {
             "envs": N, "steps_per_rollout": T, "env_threads": host.threads,
             "us_per_vector_step": {"host_sim_alone": us(t_sim), "gpu_act_store_alone": us(t_gpu),
                                    "pipelined": {f"host_parts={k}" + (" (Python loop, whole batch per step)" if k == 1 else ""): us(v)
@@ -979,14 +973,42 @@ def host_path_measurements(args, job):
         eng.close()
         a2 = copy.copy(args)
         a2.host_parts = best
-        o = bench_single(a2, "doggo-4096env-2x256-hostenv", 2, 1, job, False)
-        res["doggo-4096env-2x256-hostenv"] = {
+        o = bench_single(a2, wname, 2, 1, job, False)
+        res[wname] = {
             "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": 2, "warmup": 1, "host_parts": best,
             "what": "whole PPO iteration (host rollout + GAE + all epochs) with the environments on the host: the PCIe-inclusive rate, never the headline value",
             "roofline": {k: o["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches")}}
     except Exception as ex:  # noqa: BLE001 - a side measurement must not take the headline line down
-        res["native-c-env"] = {"error": f"{type(ex).__name__}: {ex}"}
+        res["native-c-env" + tag] = {"error": f"{type(ex).__name__}: {ex}"}
 
+    return res
+
+
+def host_path_measurements(args, job):
+    """north_star's own data path in front of the driver (VERDICT r4 #4): host-core environments -> pinned staging -> GPU policy ->
+    actions back, at the headline shape (doggo 58 / 12, 4096 envs, 2x256).  Reference: the VecEnv loop SB3 drives through
+    /root/reference/src/mobrob/rl_control/ppo.py:30-48 over EnvWrapper.step (/root/reference/src/mobrob/envs/wrapper.py:156-201).
+
+    Three numbers per collector, per vector step of all environments, so that collector overhead is a figure, not a guess:
+      host_sim_alone   the environments stepped with fixed actions, no GPU work
+      gpu_alone        act + store on static staging buffers, no environment stepped
+      pipelined        the collector as it runs (mobrob_ppo_collect_host for the native env, PPO's part pipeline for ShmVecEnv)
+    and, for the native env, the `host_parts` sweep 1 / 2 / 4 / 8 plus the whole iteration (rollout + update) at the best setting."""
+    import torch
+    res = {}
+    w = WORKLOADS["doggo-4096env-2x256-hostenv"]
+    D, A, H, N, T, E, B = w["D"], w["A"], w["H"], w["N"], w["T"], w["E"], w["B"]
+
+    def timed(fn, sync):
+        sync()
+        t0 = time.perf_counter()
+        fn()
+        sync()
+        return time.perf_counter() - t0
+
+    # ---- (1) native C env (csrc/host_env.c, OpenMP), pinned zero-copy staging: the headline shape, then BASELINE configs[1]'s ----
+    res.update(native_env_legs(args, job, "doggo-4096env-2x256-hostenv"))
+    res.update(native_env_legs(args, job, "point-1024env-2x64-hostenv", parts_sweep=(2, 4, 1), launch_sweep=(2,)))
     # ---- (2) ShmVecEnv (`vec_env_type: subproc`): Python EnvWrapper instances in worker processes over a GPU-registered block ----
     try:
         from mobrob_amd.rl_control.ppo import PPOCtrl, BaseCallback

@@ -1311,7 +1311,7 @@ int mobrob_ppo_collect_host(mobrob_ppo_engine_t* e, mobrob_env_step_range_fn ste
   if (!e || !step_range || !obs || !actions_clipped || !rewards || !dones || !truncated || !terminal_obs)
     return fail(MOBROB_ERR_INVALID, "collect_host: null argument");
   CHK(mobrob_ppo_rollout_begin(e));
-  {  // 256-wide x3 engines: the persistent rollout kernel serves the host environment (no launch, no event per step)
+  {  // fused engines (256-wide x3, 64-wide): the persistent rollout kernel serves the host environment (no launch, no event per step)
     bool served = false;
     const int rc = collect_host_served(e, step_range, env, nparts, obs, actions_clipped, rewards, dones, truncated, terminal_obs, &served);
     if (served || rc != MOBROB_OK) return rc;
@@ -1743,8 +1743,9 @@ int collect_device(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& s
 // pipe with split operands: the same relation the device rollout has to its per-step form), what the kernel only moves -- clipped
 // actions to the host, rewards / observations from it -- is exact (tests/test_engine_gpu.py::test_served_host_rollout_...).
 // Conditions (else *served stays false and the caller runs the launch-per-step loop): 256-wide x3 engine with the eight-wave rollout
-// kernel, whole 32-row tiles per row range, every workgroup resident at once (tiles <= CUs: a waiting workgroup never yields its CU),
-// pinned buffers.  MOBROB_COLLECT_SERVER=0 switches it off; MOBROB_SERVER_TIMEOUT_S (default 60) bounds every wait on either side.
+// kernel, or (round 6) a 64-wide engine within the tile kernel's range (k_rollout64_tile<.., 3>: the shape of every reference config);
+// whole 32-row tiles per row range, every workgroup resident at once (tiles <= CUs: a waiting workgroup never yields its CU),
+// coherent pinned buffers (served_buffer_problem), no announced co-tenant of the device.  MOBROB_COLLECT_SERVER=0 switches it off; MOBROB_SERVER_TIMEOUT_S (default 60) bounds every wait on either side.
 int collect_host_served(mobrob_ppo_engine* e, mobrob_env_step_range_fn step_range, void* env, int nparts, float* obs,
                         float* actions_clipped, float* rewards, uint8_t* dones, uint8_t* truncated, float* terminal_obs, bool* served) {
   *served = false;
@@ -1755,7 +1756,10 @@ int collect_host_served(mobrob_ppo_engine* e, mobrob_env_step_range_fn step_rang
   if (mode == 0) return MOBROB_OK;
   const char* why = nullptr;
   int cus = 0;
-  if (!s8_on || !rollout_persistent_ok(e) || e->fused.H != FH || e->fused.net[0].W2x == nullptr) why = "not a 256-wide x3 engine with the eight-wave rollout kernel";
+  const bool wide = e->fused.enabled && e->fused.H == FH;   // 256-wide: k_rollout_persistent<.., 3, S8>; 64-wide: k_rollout64_tile<.., 3>
+  if (!rollout_persistent_ok(e)) why = "the fused persistent rollout kernels are off for this engine";
+  else if (wide && (!s8_on || e->fused.net[0].W2x == nullptr)) why = "not a 256-wide x3 engine with the eight-wave rollout kernel";
+  else if (!wide && (e->fused.H != GH || rblocks > e->rollout64_tile_max)) why = "not a 64-wide engine within the tile kernel's range";
   else if (getenv("MOBROB_COLLECT_TIMING") || (getenv("MOBROB_COLLECT_THREADS") && atoi(getenv("MOBROB_COLLECT_THREADS")) != 0)) why = "an instrumented / threaded collector was asked for";
   else if (nparts < 1 || nparts > MOBROB_MAX_PARTS || N % nparts != 0 || (N / nparts) % 32 != 0) why = "row ranges are not whole 32-row tiles";
   else if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device_id) != hipSuccess || rblocks > cus) why = "more tiles than compute units";
@@ -1807,7 +1811,7 @@ int collect_host_served(mobrob_ppo_engine* e, mobrob_env_step_range_fn step_rang
 
   // slot 0 <- the environments' current observations (the kernel reads its first tile from the slot, like the device rollout)
   hipLaunchKernelGGL(k_pull_rows, dim3(cdiv(N * Dp, 256)), dim3(256), 0, e->stream, obs, e->obs, N, e->D, Dp);
-  if (!e->fused.train_x3) pack_x3_all(e);
+  if (wide && !e->fused.train_x3) pack_x3_all(e);
   RolloutArgs a{};
   a.pi = e->fused.net[0];
   a.log_std = Pp(e, T_LOGSTD); a.seed = eps_seed(e); a.draw_base = nullptr; a.draw0 = e->draw_ro0;
@@ -1839,19 +1843,30 @@ int collect_host_served(mobrob_ppo_engine* e, mobrob_env_step_range_fn step_rang
     }                                                                                                           \
   } while (0)
   // chunks of the step loop on the compute stream, V(obs) of a finished chunk on the side stream (as enqueue_rollout_persistent)
-  const bool overlap = rblocks <= 192;
+  const bool overlap = wide ? rblocks <= 192 : (rblocks <= 192 && (size_t)T * N >= ((size_t)1 << 18));   // (the device rollouts' rules)
   const int chunk = overlap ? std::max(16, cdiv(T, 20)) : T;
   const int vgrid_max = overlap ? std::max(32, 256 - rblocks) : 256;
   auto value_pass = [&](hipStream_t st, int r0, int r1, int grid_max) {
-    FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_value_batch<DPc>), dim3(std::min(grid_max, cdiv(r1 - r0, FR))), dim3(FTHREADS),
-                                             e->fused.lds_bytes, st, e->fused.net[1], e->obs + (size_t)r0 * Dp, r1 - r0, e->values + r0));
+    if (wide) {
+      FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_value_batch<DPc>), dim3(std::min(grid_max, cdiv(r1 - r0, FR))), dim3(FTHREADS),
+                                               e->fused.lds_bytes, st, e->fused.net[1], e->obs + (size_t)r0 * Dp, r1 - r0, e->values + r0));
+    } else {
+      fused_forward(e->fused, e->obs + (size_t)r0 * Dp, r1 - r0, false, nullptr, e->Ap, true, e->values + r0, st);
+    }
   };
+  if (!wide)   // the served tile kernel's dynamic LDS exceeds 64 KB at 64 observation columns (per device and cheap: set per rollout)
+    FUSED_DISPATCH_DP(Dp, HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout64_tile<DPc, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)rollout64_tile_lds_bytes(Dp, true))));
   {
     ProfScope ps(e, MOBROB_K_ENV);
     for (int t0 = 0; t0 < T; t0 += chunk) {
       a.t0 = t0; a.t1 = std::min(T, t0 + chunk);
-      FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout_persistent<DPc, 3, true>), dim3(rblocks), dim3(kRolloutThreads),
-                                               rollout_lds_bytes(Dp, true), e->stream, a));
+      if (wide) {
+        FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout_persistent<DPc, 3, true>), dim3(rblocks), dim3(kRolloutThreads),
+                                                 rollout_lds_bytes(Dp, true), e->stream, a));
+      } else {
+        FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_rollout64_tile<DPc, 3>), dim3(rblocks), dim3(256), rollout64_tile_lds_bytes(Dp, true), e->stream, a));
+      }
       if (overlap && a.t1 < T) {
         hipEvent_t ev = e->ev_chunks[t0 / chunk];
         SRV_HIPC(hipEventRecord(ev, e->stream));

@@ -1192,9 +1192,10 @@ struct LayRoT {
   static constexpr int ZN = AC + 128;         // [32][32] standard normals
   static constexpr int TM = ZN + 32 * 32;     // [32][33] log-prob terms
   static constexpr int END = TM + 32 * 33;
+  static constexpr int EN = END;              // KIND 3 only: [2][32][DP] what the host wrote for the tile (observations | terminal observations)
 };
-inline size_t rollout64_tile_lds_bytes(int Dp) {
-  return (size_t)(32 * (Dp + 4) + 2 * 32 * GLDH + 2 * 32 * FLDO + 32 * 33 + 32 * 16 + 68 + 128 + 32 * 32 + 32 * 33) * sizeof(float);
+inline size_t rollout64_tile_lds_bytes(int Dp, bool served = false) {
+  return (size_t)(32 * (Dp + 4) + 2 * 32 * GLDH + 2 * 32 * FLDO + 32 * 33 + 32 * 16 + 68 + 128 + 32 * 32 + 32 * 33 + (served ? 2 * 32 * Dp : 0)) * sizeof(float);
 }
 
 // Step-loop barriers of the tile kernel: LDS hand-offs only (as in k_rollout_persistent: the step's global stores are read by later
@@ -1211,8 +1212,16 @@ inline size_t rollout64_tile_lds_bytes(int Dp) {
 #define ar (*ap_)
 #define EK0 ((uint32_t)ar.env_seed)
 #define EK1 ((uint32_t)(ar.env_seed >> 32))
-template <int DP>
+// KIND 0: the device env sources (a.kind 1 / 2, a runtime switch as before).  KIND 3 (round 6): HOST environments served by this launch,
+// the hand-over of k_rollout_persistent<.., 3, true> for the 64-wide networks every reference config trains
+// (/root/reference/data/configs/*-ppo.yaml:20-23): the tile's clipped actions go to the caller's pinned buffer with system-scope
+// stores, one lane raises the workgroup's flag word and waits for the host's word of the row range, all four waves pull what the host
+// wrote for the 32 rows into LDS, and the step goes on as on the device (storage, time-limit bootstrap, next observation tile).
+template <int DP, int KIND = 0>
 __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
+  if constexpr (KIND == 3) {   // a launch in front of this one gave up on the host: do nothing (uniform)
+    if (__hip_atomic_load(a.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+  }
   using L = LayRoT<DP>;
   constexpr int ldx = L::LDX, per = DP / 4, R = 32, NKG1 = DP / 8;
   const int tid0 = threadIdx.x;
@@ -1242,11 +1251,13 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
     const int n = row0 + tid0;
     float* S = &lds[L::ST + tid0 * 16];
     if (n < N) {
-      if (a.kind == 2) {
+      if constexpr (KIND != 3) {
+        if (a.kind == 2) {
 #pragma unroll
-        for (int j = 0; j < kGoalStateFloats; ++j) S[j] = a.gstate[(size_t)n * kGoalStateFloats + j];
-      } else {
-        reinterpret_cast<int*>(S)[13] = a.ep_len[n];
+          for (int j = 0; j < kGoalStateFloats; ++j) S[j] = a.gstate[(size_t)n * kGoalStateFloats + j];
+        } else {
+          reinterpret_cast<int*>(S)[13] = a.ep_len[n];
+        }
       }
       S[12] = a.prev_dones[n];
     }
@@ -1267,7 +1278,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
       v = ldg16(a.obs, (unsigned)((size_t)a.t0 * N + row0 + rr) * (unsigned)(DP * 4) + (unsigned)(c * 16));
     *reinterpret_cast<f32x4*>(&lds[L::X + rr * ldx + 4 * c]) = v;
   }
-  if (tid0 == 0) *cnt = 0;
+  if (tid0 == 0) { cnt[0] = 0; cnt[1] = 0; cnt[2] = 0; }
   __syncthreads();
   const uint32_t dbase = a.draw_base ? *a.draw_base : a.draw0, sbase = a.step_base ? *a.step_base : 0u;
   const uint32_t ek0 = (uint32_t)a.env_seed, ek1 = (uint32_t)(a.env_seed >> 32);
@@ -1332,7 +1343,8 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
         lds[L::TM + rr * 33 + k] = -(d * d) / lds[L::AC + 32 + k] - lds[L::AC + 64 + k] - 0.91893853320467274178f;
         const float ac = fminf(fmaxf(act, ar.lo), ar.hi);
         ar.actions[((size_t)t * N + row0 + rr) * A + k] = act;
-        ar.clip_act[(size_t)(row0 + rr) * A + k] = ac;
+        if constexpr (KIND == 3) __hip_atomic_store(&ar.clip_act[(size_t)(row0 + rr) * A + k], ac, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // pinned host memory, past the caches
+        else ar.clip_act[(size_t)(row0 + rr) * A + k] = ac;
         lds[L::CA + rr * 33 + k] = ac;
       }
     }
@@ -1341,6 +1353,71 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
       float lp = 0.f;
       for (int k = 0; k < A; ++k) lp += lds[L::TM + rr * 33 + k];
       ar.logp[(size_t)t * N + row0 + rr] = lp;
+    }
+    if constexpr (KIND == 3) {
+      // Hand-over (the protocol of k_rollout_persistent<.., 3, true>): every storing wave drains its stores -- the actions have left for
+      // host memory --, a barrier, then ONE lane tells the host "step t of these 32 rows" and waits for the host's word of the row range
+      // ((truncated rows) << 32 | steps finished; 0xFFFFFFFF: give up).  Only the range's FIRST workgroup polls host memory and relays
+      // what it saw through a device word; bounded; one system-scope acquire between the word's arrival and the pull.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      R64_BARRIER(); ap_ = rollout_kernargs();
+      if (tid == 0) {
+        __hip_atomic_store(ar.h_gpu_flag + blockIdx.x, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const int part = row0 / ar.rows_per_part;
+        const bool relay = row0 == part * ar.rows_per_part;
+        const unsigned long long* hf = reinterpret_cast<const unsigned long long*>(ar.h_host_flag + 16 * part);
+        unsigned long long* df = reinterpret_cast<unsigned long long*>(ar.abort_dev) + 1 + part;
+        const long long w0 = wall_clock64();
+        unsigned long long v;
+        for (;;) {
+          v = relay ? __hip_atomic_load(hf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(df, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned)v >= (unsigned)(t + 1)) break;
+          if (wall_clock64() - w0 > ar.timeout_ticks) {
+            v = 0xFFFFFFFFull;
+            __hip_atomic_store(ar.h_error, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+          }
+          if (relay) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(2);
+        }
+        if (relay) __hip_atomic_store(df, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool dead = (unsigned)v == 0xFFFFFFFFu;
+        if (dead) __hip_atomic_store(ar.abort_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cnt[1] = dead ? 1 : 0;
+        cnt[2] = dead ? 0 : (int)(v >> 32);
+      }
+      R64_BARRIER(); ap_ = rollout_kernargs();  // (4b) the host has stepped the rows (or the wait was given up)
+      if (cnt[1]) break;
+      {  // what the host wrote for this tile's 32 rows -> LDS: one contiguous, 16-byte aligned range of the [N][D] arrays, whole-wave
+         // 16-byte loads past the caches; rewards / done / truncated flags into the log-prob term buffer (free until the next sampling)
+        const int nrow = min(R, N - row0);
+        const int nq = nrow * D / 4, rem0 = 4 * nq, nfl = nrow * D;
+        const f32x4* so = reinterpret_cast<const f32x4*>(ar.h_obs + (size_t)row0 * D);
+        for (int i = tid; i < nq; i += 256) {
+          f32x4 v;
+          asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(so + i) : "memory");
+          *reinterpret_cast<f32x4*>(&lds[L::EN + 4 * i]) = v;
+        }
+        for (int i = rem0 + tid; i < nfl; i += 256)
+          lds[L::EN + i] = __hip_atomic_load(ar.h_obs + (size_t)row0 * D + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (cnt[2] != 0) {
+          const f32x4* st = reinterpret_cast<const f32x4*>(ar.h_term + (size_t)row0 * D);
+          for (int i = tid; i < nq; i += 256) {
+            f32x4 v;
+            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(st + i) : "memory");
+            *reinterpret_cast<f32x4*>(&lds[L::EN + 32 * DP + 4 * i]) = v;
+          }
+          for (int i = rem0 + tid; i < nfl; i += 256)
+            lds[L::EN + 32 * DP + i] = __hip_atomic_load(ar.h_term + (size_t)row0 * D + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (tid < nrow) {
+          lds[L::TM + tid] = __hip_atomic_load(ar.h_rew + row0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          reinterpret_cast<int*>(&lds[L::TM])[32 + tid] = __hip_atomic_load(ar.h_done + row0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          reinterpret_cast<int*>(&lds[L::TM])[64 + tid] = cnt[2] != 0 ? (int)__hip_atomic_load(ar.h_trunc + row0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
+        }
+      }
+      R64_BARRIER(); ap_ = rollout_kernargs();  // (4c) the host's tile is in LDS
     }
     const int n = row0 + rr;
     const bool live = n < N;
@@ -1353,7 +1430,32 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
     float reward = 0.f, ep_ret = 0.f;
     int ep_len_new = 0, ep_len_fin = 0;
     GoalState g{};
-    if (live) {
+    if constexpr (KIND == 3) {
+      if (live) {   // what the host wrote for this row (staged above): reward, done, truncated, next observation, terminal one
+        done = reinterpret_cast<const int*>(&lds[L::TM])[32 + rr] != 0;
+        tr = reinterpret_cast<const int*>(&lds[L::TM])[64 + rr] != 0;
+        if (sub == 0) reward = lds[L::TM + rr];
+        auto staged_chunk = [&](int base, int c) {   // columns 4 c .. 4 c + 3 of the tile's row rr ([32][D] floats at `base`)
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int col = 4 * c + j;
+            o[j] = col < D ? lds[base + rr * D + (col < D ? col : 0)] : 0.f;
+          }
+          return o;
+        };
+        for (int c = sub; c < per; c += 8) {
+          const f32x4 o = staged_chunk(L::EN, c);
+          if (tr) {
+            const f32x4 to = staged_chunk(L::EN + 32 * DP, c);
+            reinterpret_cast<f32x4*>(ar.term_obs)[(size_t)n * per + c] = to;
+            *reinterpret_cast<f32x4*>(&trow[4 * c]) = to;
+          }
+          reinterpret_cast<f32x4*>(ar.obs)[onext + c] = o;
+          *reinterpret_cast<f32x4*>(&xrow[4 * c]) = o;
+        }
+      }
+    } else if (live) {
       if (ar.kind == 1) {
         const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, EK0, EK1);
         const bool term = u32_to_unit_open(mr.x) < ar.p_term;
@@ -1413,6 +1515,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
       ar.es[so] = S[12];
       S[12] = done ? 1.f : 0.f;
       ar.trunc[n] = tr ? 1 : 0;
+      if constexpr (KIND != 3) {
       if (ar.kind == 1) {
         reinterpret_cast<int*>(S)[13] = ep_len_new;
       } else {
@@ -1421,6 +1524,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
           es_n += 1.0; es_ret += (double)ep_ret; es_len += (double)ep_len_fin; es_goal += reached ? 1.0 : 0.0;
           ep_ring_push(ar.ep_stats, ep_ret, (float)ep_len_fin);
         }
+      }
       }
       if (tr) {  // reward is written after the bootstrap below
         const int q = atomicAdd(cnt, 1);
@@ -1450,7 +1554,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
     }
   }
   // ---- episode statistics: one set of atomics per wave and launch (order irrelevant: diagnostics) ----
-  if (a.kind == 2) {
+  if (KIND != 3 && a.kind == 2) {
     const double n = wave_sum_d(es_n), r = wave_sum_d(es_ret), l = wave_sum_d(es_len), g = wave_sum_d(es_goal);
     if ((tid0 & 63) == 0 && n > 0.0) {
       atomicAdd(&a.ep_stats[0], n); atomicAdd(&a.ep_stats[1], r); atomicAdd(&a.ep_stats[2], l); atomicAdd(&a.ep_stats[3], g);
@@ -1461,11 +1565,13 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
     const int n = row0 + tid0;
     const float* S = &lds[L::ST + tid0 * 16];
     if (n < N) {
-      if (a.kind == 2) {
+      if constexpr (KIND != 3) {
+        if (a.kind == 2) {
 #pragma unroll
-        for (int j = 0; j < kGoalStateFloats; ++j) a.gstate[(size_t)n * kGoalStateFloats + j] = S[j];
-      } else {
-        a.ep_len[n] = reinterpret_cast<const int*>(S)[13];
+          for (int j = 0; j < kGoalStateFloats; ++j) a.gstate[(size_t)n * kGoalStateFloats + j] = S[j];
+        } else {
+          a.ep_len[n] = reinterpret_cast<const int*>(S)[13];
+        }
       }
       a.prev_dones[n] = S[12];
     }

@@ -408,9 +408,10 @@ def test_pipelined_part_rollout_equals_whole_batch_rollout(robot, hidden, N, par
         assert (sw["episodes"], sw["goals"]) == (sp["episodes"], sp["goals"]) and abs(sw["ep_rew_mean"] - sp["ep_rew_mean"]) < 1e-9
 
 
+@pytest.mark.parametrize("H", [256, 64])
 @pytest.mark.parametrize("robot,N,parts", [("doggo", 192, 2), ("doggo", 64, 1), ("point", 128, 4), ("car", 96, 3),
                                            ("turtlebot3", 64, 2), ("drone", 128, 2)])
-def test_served_host_rollout_equals_the_launch_per_step_rollout(robot, N, parts):
+def test_served_host_rollout_equals_the_launch_per_step_rollout(robot, N, parts, H):
     """mobrob_ppo_collect_host on a 256-wide x3 engine: the persistent rollout kernel serves the host environment (flags in pinned
     memory, no launch and no event inside the step loop; kernels_rollout.h KIND 3) against the launch-per-step collector
     (MOBROB_COLLECT_SERVER=0: act_part / store_part per row range and step).  Same Philox counters, same sampling / storage /
@@ -419,16 +420,18 @@ def test_served_host_rollout_equals_the_launch_per_step_rollout(robot, N, parts)
     test_persistent_rollout_equals_per_step_rollout), not in bits -- and the quantities the kernel only moves are exact: the
     clipped actions handed to the host, the rewards / observations taken from it.  Short episodes: truncations in every rollout.
     Four padded observation widths, one to four row ranges, two rollouts each (noise counter and episode-start flags carry over).
-    MOBROB_COLLECT_SERVER=2 makes the engine refuse to fall back, so the served path is what ran."""
+    MOBROB_COLLECT_SERVER=2 makes the engine refuse to fall back, so the served path is what ran.
+    H = 64 (round 6: k_rollout64_tile<.., 3>, the networks of every reference YAML): the tile kernel's forward is the one-wave
+    kernel's MFMA sequence per accumulator, so there the two collectors agree BIT FOR BIT."""
     from mobrob_amd.envs.native_env import NativeGoalVecEnv
     from mobrob_amd.envs.wrapper import ROBOT_DIMS
     D, A, _ = ROBOT_DIMS[robot]
     T = 37
-    p = O.init_params(D, A, (256, 256), (256, 256), seed=6)
+    p = O.init_params(D, A, (H, H), (H, H), seed=6)
     keys = ("obs", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns", "last_values")
     out = {}
     for mode in ("0", "2"):
-        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=64, n_epochs=1, seed=11, pi=(256, 256), vf=(256, 256))
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=64, n_epochs=1, seed=11, pi=(H, H), vf=(H, H))
         e.set_params(p)
         env = NativeGoalVecEnv.for_robot(robot, N, time_limit=5, seed=7)
         b = dict(obs=e.pinned((N, D)), clip=e.pinned((N, A)), rew=e.pinned((N,)), done=e.pinned((N,), np.uint8),
@@ -463,7 +466,10 @@ def test_served_host_rollout_equals_the_launch_per_step_rollout(robot, N, parts)
     for r in range(2):
         assert np.array_equal(out["0"][r]["episode_starts"], out["2"][r]["episode_starts"])
         for k, bound in tol.items():
-            assert np.max(np.abs(out["0"][r][k] - out["2"][r][k])) < bound, (r, k)
+            if H == 64:
+                assert np.array_equal(out["0"][r][k], out["2"][r][k]), (r, k)
+            else:
+                assert np.max(np.abs(out["0"][r][k] - out["2"][r][k])) < bound, (r, k)
 
 
 class _RecordingStepRange:
@@ -530,7 +536,9 @@ def _check_host_rollout_against_oracle(e, p, rec, first_starts, gamma=0.99, lam=
     return rec.done[-1].copy()
 
 
-@pytest.mark.parametrize("robot,H,N,parts", [("doggo", 256, 192, 2), ("point", 256, 128, 4), ("car", 256, 96, 3), ("drone", 256, 64, 1)])
+@pytest.mark.parametrize("robot,H,N,parts", [("doggo", 256, 192, 2), ("point", 256, 128, 4), ("car", 256, 96, 3), ("drone", 256, 64, 1),
+                                             ("doggo", 64, 192, 2), ("point", 64, 1024, 2), ("car", 64, 96, 3), ("turtlebot3", 64, 64, 1),
+                                             ("drone", 64, 128, 4)])
 def test_served_host_rollout_matches_the_oracle(robot, H, N, parts):
     """The SERVED host collector (the rollout kernel hands actions over and pulls the host's step through pinned flag words:
     kernels_rollout.h KIND 3; MOBROB_COLLECT_SERVER=2 refuses to fall back) against the oracle, not against another HIP path:
@@ -566,6 +574,57 @@ def test_served_host_rollout_matches_the_oracle(robot, H, N, parts):
         os.environ.pop("MOBROB_COLLECT_SERVER", None)
         os.environ.pop("MOBROB_SERVER_TIMEOUT_S", None)
     env.close()
+    e.close()
+
+
+@pytest.mark.parametrize("H", [64, 256])
+def test_served_host_rollout_from_a_registered_block_matches_the_oracle(H):
+    """The served collector on caller-owned memory pinned in place (mobrob_ppo_host_register = hipHostRegister: what ShmVecEnv's shared
+    block is) instead of mobrob_ppo_host_alloc buffers: accepted (registered blocks are coherent unless HIP_HOST_COHERENT=0, which
+    collect_host_served refuses by name) and held to the oracle like the allocated ones -- the hand-over's acquire is what makes the
+    pull see the host's writes whatever the block's caching policy."""
+    import mmap
+    from mobrob_amd.envs.native_env import NativeGoalVecEnv
+    from mobrob_amd.envs.wrapper import ROBOT_DIMS
+    robot, N, parts, T = "doggo", 128, 2, 21
+    D, A, _ = ROBOT_DIMS[robot]
+    p = O.init_params(D, A, (H, H), (H, H), seed=3)
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=64, n_epochs=1, seed=4, pi=(H, H), vf=(H, H))
+    e.set_params(p)
+    sizes = dict(obs=N * D * 4, clip=N * A * 4, rew=N * 4, done=N, trunc=N, term=N * D * 4)
+    offs, total = {}, 0
+    for k, n in sizes.items():
+        offs[k] = total
+        total += (n + 255) // 256 * 256
+    block = mmap.mmap(-1, (total + 4095) // 4096 * 4096)          # page-aligned anonymous memory
+    base = np.frombuffer(block, np.uint8)
+    e.register_host(base.ctypes.data, len(block))
+    view = lambda k, shape, dt: base[offs[k]:offs[k] + sizes[k]].view(dt).reshape(shape)   # noqa: E731
+    b = dict(obs=view("obs", (N, D), np.float32), clip=view("clip", (N, A), np.float32), rew=view("rew", (N,), np.float32),
+             done=view("done", (N,), np.uint8), trunc=view("trunc", (N,), np.uint8), term=view("term", (N, D), np.float32))
+    env = NativeGoalVecEnv.for_robot(robot, N, time_limit=5, seed=9)
+    env.use_buffers(obs=b["obs"], rewards=b["rew"], dones=b["done"], truncated=b["trunc"], terminal_obs=b["term"])
+    env.reset()
+    rec = _RecordingStepRange(env, b, T, N, D)
+    os.environ["MOBROB_COLLECT_SERVER"] = "2"
+    os.environ["MOBROB_SERVER_TIMEOUT_S"] = "5"
+    try:
+        starts = np.ones(N, bool)
+        for _ in range(2):
+            rec.begin()
+            e.rollout_begin()
+            e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"]).collect(rec.address, env.handle)
+            starts = _check_host_rollout_against_oracle(e, p, rec, starts)
+        # a buffer whose END lies outside the pinned block is refused by name (the first byte alone says nothing about [N][D])
+        tail = np.zeros((N, D), np.float32)
+        e.rollout_begin()
+        with pytest.raises(Exception, match="pageable|pinned"):
+            e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], tail).collect(rec.address, env.handle)
+    finally:
+        os.environ.pop("MOBROB_COLLECT_SERVER", None)
+        os.environ.pop("MOBROB_SERVER_TIMEOUT_S", None)
+    env.close()
+    e.unregister_host(base.ctypes.data)
     e.close()
 
 
