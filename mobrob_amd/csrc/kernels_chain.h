@@ -707,14 +707,15 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
         for (int jb = 0; jb < 8; ++jb) {
           X3Frag Bn2;
           __builtin_amdgcn_sched_barrier(0);
+          constexpr bool kSplitB = !(MOBROB_CHAIN_SKIP & 128);   // (128, timing only: the h1 fragments are not split -- what split-once planes could save at most)
           if (jb < 6) {
             const ColFrag raw2 = img_frag_load_at(b0x, b1x, 32 * 64 * (jb + 2));
-            dw2_block<true>(gW2[jb], gW2[8 + jb], A0, A1, B, raw, Bn2);
-            B = Bn2;
+            dw2_block<kSplitB>(gW2[jb], gW2[8 + jb], A0, A1, B, raw, Bn2);
+            if (kSplitB) B = Bn2;
             raw = raw2;
           } else if (jb == 6) {
-            dw2_block<true>(gW2[jb], gW2[8 + jb], A0, A1, B, raw, Bn2);   // splits the last h1 fragment of this step
-            B = Bn2;
+            dw2_block<kSplitB>(gW2[jb], gW2[8 + jb], A0, A1, B, raw, Bn2);   // splits the last h1 fragment of this step
+            if (kSplitB) B = Bn2;
           } else {
             dw2_block2(gW2[jb], gW2[8 + jb], A0, A1, B, rA0, nA0, rA1, nA1);   // splits the next step's two dz2 fragments
           }
