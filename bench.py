@@ -45,6 +45,8 @@ WORKLOADS = {
                                         host_env="doggo"),
     # BASELINE configs[1] with the environments on the HOST: the 2x64 networks every reference YAML trains, served by k_rollout64_tile<.., 3>
     "point-1024env-2x64-hostenv": dict(D=14, A=2, H=64, N=1024, T=2048, E=10, B=65536, p_term=1 / 119.0, tl=1000, host_env="point"),
+    # data/configs/doggo-ppo.yaml as it stands (16 envs, batch 100, 2x64) with the environments on the HOST: one row range, half a tile
+    "doggo-ref-16env-2x64-hostenv": dict(D=58, A=12, H=64, N=16, T=1000, E=5, B=100, p_term=1 / 107.0, tl=1000, host_env="doggo", cpu_threads=1),
     # BASELINE configs[4]: mixed fleet, ragged obs/act dims packed into one rollout arena (mobrob_amd/fleet.py)
     "fleet-car-drone-turtlebot3-2x64": dict(segments=["car", "drone", "turtlebot3"], H=64, N=1024, T=2048, E=10,
                                             B=65536, tl=1000),
@@ -685,12 +687,11 @@ def bench_single(args, name, steps, warmup, job, phases):
         if getattr(args, "host_env_threads", 0):
             host.set_threads(args.host_env_threads)
         host.reset()
-        pipe = (eng.part_pipeline(args.host_parts, hb["obs"], hb["clip"], hb["rew"], hb["done"], hb["trunc"], hb["term"])
-                if args.host_parts > 1 else None)
+        pipe = eng.part_pipeline(max(1, args.host_parts), hb["obs"], hb["clip"], hb["rew"], hb["done"], hb["trunc"], hb["term"])
 
     def host_rollout():
         eng.rollout_begin()
-        if args.host_parts > 1 and not args.host_python_loop:  # the whole pipelined collector loop in one native call
+        if not args.host_python_loop:  # the whole collector loop in one native call (one row range included: served, no Python frame per step)
             pipe.collect(host.step_range_fn, host.handle)
             return
         if args.host_parts > 1:  # same pipeline driven from Python (what a Python-stepped env would use)
@@ -903,10 +904,10 @@ def native_env_legs(args, job, wname, parts_sweep=(2, 4, 8, 1), launch_sweep=(2,
                 eng.store(hb["rew"], hb["done"], None, None)
             eng.finish_rollout(hb["obs"], hb["done"])
 
-        def collector(parts, served=True):
+        def collector(parts, served=True, c_loop=False):
             def run():
                 eng.rollout_begin()
-                if parts > 1:
+                if parts > 1 or c_loop:
                     pipe = eng.part_pipeline(parts, hb["obs"], hb["clip"], hb["rew"], hb["done"], hb["trunc"], hb["term"])
                     # served: the persistent rollout kernel serves the host env (flags in pinned memory, no launch / event per step;
                     # the default on fused engines: 256-wide x3 and 64-wide); else the launch-per-step collector (act_part / store_part per row range)
@@ -944,15 +945,20 @@ def native_env_legs(args, job, wname, parts_sweep=(2, 4, 8, 1), launch_sweep=(2,
         sweep, sweep_launch = {}, {}
         for parts in parts_sweep:
             sweep[parts] = in_iteration(collector(parts)) - t_upd
+        t_one_c = in_iteration(collector(1, c_loop=True)) - t_upd          # ONE row range through mobrob_ppo_collect_host (served where the engine can)
         for parts in launch_sweep:
             sweep_launch[parts] = in_iteration(collector(parts, served=False)) - t_upd
         best = min(sweep, key=sweep.get)
+        best_t = sweep[best]
+        if t_one_c < best_t:
+            best, best_t = 1, t_one_c          # (bench_single's host_parts=1 is this C loop, not the Python loop)
         us = lambda t: 1e6 * t / T   # noqa: E731 - microseconds per vector step of N environments
         res["native-c-env (csrc/host_env.c), pinned zero-copy, mobrob_ppo_collect_host" + tag] = {
             "envs": N, "steps_per_rollout": T, "env_threads": host.threads,
             "us_per_vector_step": {"host_sim_alone": us(t_sim), "gpu_act_store_alone": us(t_gpu),
                                    "pipelined": {f"host_parts={k}" + (" (Python loop, whole batch per step)" if k == 1 else ""): us(v)
                                                  for k, v in sorted(sweep.items())},
+                                   "one_range_c_loop (mobrob_ppo_collect_host, host_parts=1: served, nothing overlaps)": us(t_one_c),
                                    "pipelined_launch_per_step_collector": {f"host_parts={k}": us(v) for k, v in sorted(sweep_launch.items())}},
             "collector": ("host_parts >= 2: the persistent rollout kernel SERVES the host environment -- its env phase is the host's: a workgroup "
                           "writes its rows' clipped actions into the pinned buffer, raises a flag word in pinned memory and polls the host's word "
@@ -962,9 +968,9 @@ def native_env_legs(args, job, wname, parts_sweep=(2, 4, 8, 1), launch_sweep=(2,
             # served collector: the device's work hides under the simulator's -> overhead over the simulator alone; launch-per-step
             # collector: over the longer of ITS two legs (gpu_act_store_alone is that collector's GPU leg: act + store launches per step)
             "collector_overhead_us_per_step": {
-                "served (pipelined - host_sim_alone)": us(sweep[best]) - us(t_sim),
-                "launch_per_step (pipelined - longer leg)": us(min(sweep_launch.values())) - max(us(t_sim), us(t_gpu))},
-            "rollout_only_env_steps_per_s": N * T / sweep[best], "best_host_parts": best,
+                "served (pipelined - host_sim_alone)": us(best_t) - us(t_sim),
+                "launch_per_step (pipelined - longer leg)": (us(min(sweep_launch.values())) - max(us(t_sim), us(t_gpu))) if sweep_launch else None},
+            "rollout_only_env_steps_per_s": N * T / best_t, "best_host_parts": best,
             "update_ms": 1e3 * t_upd,
             "note": ("every leg = (leg + update) - update alone, inside PPO iterations (GPU clocks as in the real loop); overhead = what the "
                      "hand-off itself costs once simulator and policy overlap"),
@@ -1009,6 +1015,7 @@ def host_path_measurements(args, job):
     # ---- (1) native C env (csrc/host_env.c, OpenMP), pinned zero-copy staging: the headline shape, then BASELINE configs[1]'s ----
     res.update(native_env_legs(args, job, "doggo-4096env-2x256-hostenv"))
     res.update(native_env_legs(args, job, "point-1024env-2x64-hostenv", parts_sweep=(2, 4, 1), launch_sweep=(2,)))
+    res.update(native_env_legs(args, job, "doggo-ref-16env-2x64-hostenv", parts_sweep=(1,), launch_sweep=()))
     # ---- (2) ShmVecEnv (`vec_env_type: subproc`): Python EnvWrapper instances in worker processes over a GPU-registered block ----
     try:
         from mobrob_amd.rl_control.ppo import PPOCtrl, BaseCallback

@@ -51,9 +51,6 @@ inline void poison_lds(hipStream_t st) {
 #include "kernels_rollout.h"
 #include "robot_ctrl.h"
 #include "oneshot_allreduce.h"
-#ifdef MOBROB_VALUE8  // experiment, see scratch/value8.py
-#include "../../scratch/kernels_fused8.h"
-#endif
 
 using namespace mobrob;
 
@@ -1570,17 +1567,9 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
   const int chunk = overlap ? std::max(16, cdiv(T, 20)) : T;
   const int vgrid_max = overlap ? std::max(32, 256 - rblocks) : 256;
   auto value_pass = [&](hipStream_t st, int r0, int r1, int grid_max) {  // rows [r0, r1) of obs -> values
-#ifdef MOBROB_VALUE8  // experiment: two waves per SIMD (kernels_fused8.h)
-    FUSED_DISPATCH_DP(Dp, (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_value_batch8<DPc>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->fused.lds_bytes));
-    FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_value_batch8<DPc>), dim3(std::min(grid_max, cdiv(r1 - r0, FR))),
-                                             dim3(FTHREADS8), e->fused.lds_bytes, st, e->fused.net[1],
-                                             e->obs + (size_t)r0 * Dp, r1 - r0, e->values + r0));
-#else
     FUSED_DISPATCH_DP(Dp, hipLaunchKernelGGL((k_value_batch<DPc>), dim3(std::min(grid_max, cdiv(r1 - r0, FR))),
                                              dim3(FTHREADS), e->fused.lds_bytes, st, e->fused.net[1],
                                              e->obs + (size_t)r0 * Dp, r1 - r0, e->values + r0));
-#endif
   };
   {
     ProfScope ps(e, MOBROB_K_ENV);
@@ -1761,7 +1750,8 @@ int collect_host_served(mobrob_ppo_engine* e, mobrob_env_step_range_fn step_rang
   else if (wide && (!s8_on || e->fused.net[0].W2x == nullptr)) why = "not a 256-wide x3 engine with the eight-wave rollout kernel";
   else if (!wide && (e->fused.H != GH || rblocks > e->rollout64_tile_max)) why = "not a 64-wide engine within the tile kernel's range";
   else if (getenv("MOBROB_COLLECT_TIMING") || (getenv("MOBROB_COLLECT_THREADS") && atoi(getenv("MOBROB_COLLECT_THREADS")) != 0)) why = "an instrumented / threaded collector was asked for";
-  else if (nparts < 1 || nparts > MOBROB_MAX_PARTS || N % nparts != 0 || (N / nparts) % 32 != 0) why = "row ranges are not whole 32-row tiles";
+  // a 32-row tile must not straddle two row ranges; ONE range takes any number of environments (the reference YAMLs: 2 - 16, half a tile)
+  else if (nparts < 1 || nparts > MOBROB_MAX_PARTS || (nparts > 1 && (N % nparts != 0 || (N / nparts) % 32 != 0))) why = "row ranges are not whole 32-row tiles";
   else if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device_id) != hipSuccess || rblocks > cus) why = "more tiles than compute units";
   // Other tenants of the device that this process cannot count: ranks rehearsing data parallelism on ONE device, a CU mask.  Every
   // workgroup of a served rollout must be resident at once (a waiting workgroup never yields its CU), so with them the launch-per-step
@@ -1889,7 +1879,7 @@ int collect_host_served(mobrob_ppo_engine* e, mobrob_env_step_range_fn step_rang
 
   // ---- the host's side of the step loop: wait for the flags of a row range, step it, raise the range's word ----
   auto now_s = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
-  const int bpp = (N / nparts) / 32;   // workgroups per row range
+  const int bpp = nparts == 1 ? rblocks : (N / nparts) / 32;   // workgroups per row range
   {
     // Residency check, before the environment is touched: the clipped actions of step 0 of EVERY workgroup within a short bound
     // (MOBROB_SERVER_RESIDENCY_S, default 2 s; a resident workgroup needs ~25 us).  A workgroup that is not resident -- another

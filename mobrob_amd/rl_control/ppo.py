@@ -384,8 +384,10 @@ class PPO:
         parts = self.host_parts if hasattr(env, "step_range") and N >= 64 else 1
         finished = False
         e.rollout_begin()
-        if parts > 1 and type(callback) is BaseCallback and hasattr(env, "step_range_fn"):
-            # nothing to call per step and a natively stepped env: the whole collector loop runs in C
+        if type(callback) is BaseCallback and hasattr(env, "step_range_fn"):
+            # nothing to call per step and a natively stepped env: the whole collector loop runs in C (mobrob_ppo_collect_host),
+            # served by the persistent rollout kernel where the engine can -- also ONE range of a handful of environments (the
+            # reference YAMLs' 2 - 16): no launch, no synchronisation and no Python frame per step
             pipe = e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"])
             pipe.collect(env.step_range_fn, env.handle)  # includes finish_rollout
             finished = True

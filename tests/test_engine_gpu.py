@@ -538,7 +538,9 @@ def _check_host_rollout_against_oracle(e, p, rec, first_starts, gamma=0.99, lam=
 
 @pytest.mark.parametrize("robot,H,N,parts", [("doggo", 256, 192, 2), ("point", 256, 128, 4), ("car", 256, 96, 3), ("drone", 256, 64, 1),
                                              ("doggo", 64, 192, 2), ("point", 64, 1024, 2), ("car", 64, 96, 3), ("turtlebot3", 64, 64, 1),
-                                             ("drone", 64, 128, 4)])
+                                             ("drone", 64, 128, 4),
+                                             # ONE row range takes any number of environments: the reference YAMLs' 2 - 16 (half a tile)
+                                             ("doggo", 64, 16, 1), ("point", 64, 2, 1), ("doggo", 256, 100, 1), ("car", 256, 7, 1)])
 def test_served_host_rollout_matches_the_oracle(robot, H, N, parts):
     """The SERVED host collector (the rollout kernel hands actions over and pulls the host's step through pinned flag words:
     kernels_rollout.h KIND 3; MOBROB_COLLECT_SERVER=2 refuses to fall back) against the oracle, not against another HIP path:
