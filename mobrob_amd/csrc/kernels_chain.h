@@ -964,7 +964,8 @@ __global__ __launch_bounds__(FTHREADS, 1) void k_chain_train(FusedTrainArgs a) {
       f32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = gW2[t][4 * qd + e];
-      stg16(w2base, s2 + (unsigned)(t * 4 + qd) * 1024u, v);
+      if (MOBROB_CHAIN_SKIP & 256) asm volatile("" :: "v"(v));   // (256, timing only: no dW2 slab stores -- what hiding them could gain at most)
+      else stg16(w2base, s2 + (unsigned)(t * 4 + qd) * 1024u, v);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
