@@ -334,7 +334,7 @@ def dominant_kernel_name(H, rows_per_launch, generic, x3_train=False, chain=Fals
 def measured_traffic(kernel_prefix):
     """(bytes per launch | None, note): PMC-counted HBM traffic of the dominant kernel from the newest committed
     profile -- only if that profile was taken on exactly these kernel sources; otherwise None (never a stale figure)."""
-    for rnd in ("r5", "r4", "r3", "r2", "r1"):
+    for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):
         tj = os.path.join(ROOT, "profiles", rnd, "hbm_traffic_pmc.json")
         if not os.path.exists(tj):
             continue

@@ -194,14 +194,19 @@ int mobrob_ppo_store_part(mobrob_ppo_engine_t* e, int32_t part, int32_t nparts, 
  * error).  csrc/host_env.c's mobrob_hostenv_step_range has exactly this signature.  `obs` must hold the current
  * observations (VecEnv.reset() or the previous rollout's last step) on entry and holds the last ones on return.
  *
- * 256-wide engines with the split-bf16 forward (the default), row ranges of whole 32-row tiles (n_envs % (32 nparts) == 0), at most
- * one tile per compute unit and pinned buffers: the step loop contains NO launch, event or other HIP call -- the persistent rollout
- * kernel of the device environments serves the host one (csrc/kernels_rollout.h KIND 3).  A workgroup writes its rows' clipped
- * actions into `actions_clipped`, raises a flag word in pinned memory and polls the host's word for its row range; this function
+ * SERVED form (the default where it applies): the step loop contains NO launch, event or other HIP call -- the persistent rollout kernel
+ * of the device environments serves the host one (csrc/kernels_rollout.h KIND 3: k_rollout_persistent<.., 3, S8> for 256-wide engines
+ * with the split-bf16 forward, k_rollout64_tile<.., 3> for the 64-wide networks of the reference YAMLs).  A workgroup writes its rows'
+ * clipped actions into `actions_clipped`, raises a flag word in pinned memory and polls the host's word for its row range; this function
  * waits for the flags of a range, calls step_range on it and raises the range's word; V(obs) comes from the batched value pass.
- * Numbers agree with the launch-per-step form to float32 rounding (policy forward on the other matrix pipe); every wait on either
- * side is bounded (MOBROB_SERVER_TIMEOUT_S, default 60: the call fails, the queued launches return at once).
- * MOBROB_COLLECT_SERVER=0 keeps the launch-per-step form, =2 fails instead of falling back to it. */
+ * Conditions: a fused engine of one of the two widths; row ranges of whole 32-row tiles (n_envs % (32 nparts) == 0) or ONE range of any
+ * size (nparts == 1: the reference's 2 - 16 environments); at most one tile per compute unit; all six buffers in COHERENT pinned host
+ * memory over their whole length (mobrob_ppo_host_alloc, or mobrob_ppo_host_register while HIP_HOST_COHERENT is not 0; a non-coherent
+ * allocation is refused by name); no announced co-tenant of the device (MOBROB_DP_SAME_DEVICE ranks, a CU mask); every workgroup
+ * resident within MOBROB_SERVER_RESIDENCY_S (default 2 s) -- otherwise, and with MOBROB_COLLECT_SERVER=0, the launch-per-step form runs
+ * (=2: fail instead, naming the reason).  256-wide: numbers agree with the launch-per-step form to float32 rounding (policy forward on
+ * the other matrix pipe); 64-wide: bit for bit.  Every wait on either side is bounded (MOBROB_SERVER_TIMEOUT_S, default 60: the call
+ * fails, the queued launches return at once). */
 typedef int32_t (*mobrob_env_step_range_fn)(void* env, int32_t i0, int32_t i1, const float* actions, float* obs,
                                             float* rewards, uint8_t* dones, uint8_t* truncated, float* terminal_obs);
 int mobrob_ppo_collect_host(mobrob_ppo_engine_t* e, mobrob_env_step_range_fn step_range, void* env, int32_t nparts,

@@ -1192,10 +1192,12 @@ struct LayRoT {
   static constexpr int ZN = AC + 128;         // [32][32] standard normals
   static constexpr int TM = ZN + 32 * 32;     // [32][33] log-prob terms
   static constexpr int END = TM + 32 * 33;
-  static constexpr int EN = END;              // KIND 3 only: [2][32][DP] what the host wrote for the tile (observations | terminal observations)
+  static constexpr int EN = END;              // KIND 0: [32][DP] standard normals of this step's env phase (observation noise), drawn by the noise waves;
+                                              // KIND 3: [2][32][DP] what the host wrote for the tile (observations | terminal observations)
+  static constexpr int MR = EN + 32 * DP;     // KIND 0, synthetic source: [32][2] per-row draws (termination word | reward normal)
 };
 inline size_t rollout64_tile_lds_bytes(int Dp, bool served = false) {
-  return (size_t)(32 * (Dp + 4) + 2 * 32 * GLDH + 2 * 32 * FLDO + 32 * 33 + 32 * 16 + 68 + 128 + 32 * 32 + 32 * 33 + (served ? 2 * 32 * Dp : 0)) * sizeof(float);
+  return (size_t)(32 * (Dp + 4) + 2 * 32 * GLDH + 2 * 32 * FLDO + 32 * 33 + 32 * 16 + 68 + 128 + 32 * 32 + 32 * 33 + (served ? 2 * 32 * Dp : 32 * Dp + 64)) * sizeof(float);
 }
 
 // Step-loop barriers of the tile kernel: LDS hand-offs only (as in k_rollout_persistent: the step's global stores are read by later
@@ -1313,8 +1315,31 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
       const int o = opaque(L::H2 + 4 * h * GLDH + 32 * wave + r);
 #pragma unroll
       for (int i = 0; i < 16; ++i) lds[o + crc(i) * GLDH] = fast_tanh_scaled(c[i]);
+    } else if constexpr (KIND == 0) {
+      // Round 6: the env phase's observation noise -- one Philox4x32-10 + Box-Muller per (row, 4-column chunk), 100+ VALU instructions
+      // that every thread of the env phase used to run in front of its stores -- is drawn HERE, by the two waves that idle through
+      // layer 2 and the head.  Same counters (row, chunk, step), same functions: the same bits (the second draw of a row that ends an
+      // episode, its reset observation, stays with the env phase: rare).
+      const uint32_t step_ = sbase + (uint32_t)t;
+      for (int i = tid - 128; i < R * per; i += 128) {
+        const int rr_ = i / per, c = i - rr_ * per;
+        if (row0 + rr_ < N) {
+          float z[4];
+          box_muller4(philox4x32_10((uint32_t)(row0 + rr_), (uint32_t)c, step_, kStreamEnvObs, EK0, EK1), z);
+          *reinterpret_cast<f32x4*>(&lds[L::EN + rr_ * DP + 4 * c]) = f32x4{z[0], z[1], z[2], z[3]};
+        }
+      }
     }
     R64_BARRIER(); ap_ = rollout_kernargs();
+    if constexpr (KIND == 0) {
+      if (wave >= 2 && ar.kind == 1 && tid - 128 < R && row0 + (tid - 128) < N) {  // synthetic source: the row's termination word and reward normal
+        const Philox4 mr = philox4x32_10((uint32_t)(row0 + tid - 128), 0u, sbase + (uint32_t)t, kStreamEnvMisc, EK0, EK1);
+        float zz[4];
+        box_muller4(Philox4{mr.y, mr.z, mr.w, mr.x ^ 0x9E3779B9u}, zz);
+        reinterpret_cast<uint32_t*>(&lds[L::MR])[2 * (tid - 128)] = mr.x;
+        lds[L::MR + 2 * (tid - 128) + 1] = zz[0];
+      }
+    }
     if (wave < 2) {  // head: wave 0 the even k-groups (tile64_forward's `acc`), wave 1 the odd ones (`acc2`)
       f32x16 acc = zero16();
       const int ab = 4 * opaque((L::H2 + r * GLDH + 4 * h) >> 2);
@@ -1457,15 +1482,17 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
       }
     } else if (live) {
       if (ar.kind == 1) {
-        const Philox4 mr = philox4x32_10((uint32_t)n, 0u, step, kStreamEnvMisc, EK0, EK1);
-        const bool term = u32_to_unit_open(mr.x) < ar.p_term;
+        const bool term = u32_to_unit_open(reinterpret_cast<const uint32_t*>(&lds[L::MR])[2 * rr]) < ar.p_term;   // drawn by the noise waves
         const int len = reinterpret_cast<const int*>(S)[13] + 1;
         tr = (len >= ar.time_limit) && !term;
         done = term || tr;
         ep_len_new = done ? 0 : len;
         for (int c = sub; c < per; c += 8) {
           float z[4];
-          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, EK0, EK1), z);
+          {
+            const f32x4 zq = *reinterpret_cast<const f32x4*>(&lds[L::EN + rr * DP + 4 * c]);   // drawn by the noise waves
+            z[0] = zq[0]; z[1] = zq[1]; z[2] = zq[2]; z[3] = zq[3];
+          }
           f32x4 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = (4 * c + j < D) ? z[j] : 0.f;
@@ -1479,11 +1506,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
           reinterpret_cast<f32x4*>(ar.obs)[onext + c] = o;
           *reinterpret_cast<f32x4*>(&xrow[4 * c]) = o;
         }
-        if (sub == 0) {
-          float zz[4];
-          box_muller4(Philox4{mr.y, mr.z, mr.w, mr.x ^ 0x9E3779B9u}, zz);
-          reward = 0.03f + 0.1f * zz[0] + (term ? 5.0f : 0.f);
-        }
+        if (sub == 0) reward = 0.03f + 0.1f * lds[L::MR + 2 * rr + 1] + (term ? 5.0f : 0.f);
       } else {
         g = goal_load(S);
         const GoalOutcome o = goal_advance(g, ar.goal, &lds[L::CA + rr * 33], A);
@@ -1493,7 +1516,10 @@ __global__ __launch_bounds__(256, 1) void k_rollout64_tile(RolloutArgs a) {
         if (done) goal_reset(gn, ar.goal, o.reached, (uint32_t)n, step, EK0, EK1);
         for (int c = sub; c < per; c += 8) {
           float z[4];
-          box_muller4(philox4x32_10((uint32_t)n, (uint32_t)c, step, kStreamEnvObs, EK0, EK1), z);
+          {
+            const f32x4 zq = *reinterpret_cast<const f32x4*>(&lds[L::EN + rr * DP + 4 * c]);   // drawn by the noise waves
+            z[0] = zq[0]; z[1] = zq[1]; z[2] = zq[2]; z[3] = zq[3];
+          }
           f32x4 ob = goal_features(g, ar.goal.P, D, c, z, ar.goal.noise);
           if (done) {
             if (tr) {

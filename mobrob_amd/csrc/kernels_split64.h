@@ -8,7 +8,8 @@
 //
 //   phase      waves 0 / 1                                   waves 2 / 3
 //   L1, L2     one 32-column block of the layer each           idle
-//   head+loss  wave 0: head GEMM (both chains) and loss stage  idle
+//   head       wave 0 / 1: one of the head GEMM's two accumulation chains each (even / odd k-groups)   idle
+//   loss       wave 0: adds the two partial tiles (the block kernel's `acc + acc2`) and runs the loss stage       idle
 //   dh2 | dW3  dz2 block 0 / 1 (own buffer, h2 stays intact)   dW3 tile 0 / 1
 //   dh1 | dW2  dz1 block 0 / 1                                 dW2 tiles (a, b) / (c, d)
 //   dW1        tile a / b                                      tile c / d (observations wider than 32), bias sums
@@ -33,13 +34,14 @@ struct LayS64 {
   static constexpr int H2 = H1 + GR * GLDH;
   static constexpr int Z1 = H2 + GR * GLDH;   // dz1 / dz2 in buffers of their own: dW2 / dW3 still read h1 / h2
   static constexpr int Z2 = Z1 + GR * GLDH;
-  static constexpr int DO = Z2 + GR * GLDH;
-  static constexpr int GACC = DO + GR * FLDO;  // [2][32] head-bias / log_std gradient sums
+  static constexpr int DO = Z2 + GR * GLDH;    // head partial of wave 0 (even k-groups); after the loss stage: dL/d(head)
+  static constexpr int DO2 = DO + GR * FLDO;   // head partial of wave 1 (odd k-groups)
+  static constexpr int GACC = DO2 + GR * FLDO; // [2][32] head-bias / log_std gradient sums
   static constexpr int CST = GACC + 64;        // [3][32] per-action constants
   static constexpr int END = CST + 96;
 };
 inline size_t split64_lds_bytes(int Dp) {
-  return (size_t)(GR * (Dp + 4) + 4 * GR * GLDH + GR * FLDO + 64 + 96) * sizeof(float);
+  return (size_t)(GR * (Dp + 4) + 4 * GR * GLDH + 2 * GR * FLDO + 64 + 96) * sizeof(float);
 }
 
 template <int NKG>
@@ -84,11 +86,13 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
 
   // ---- weight fragments of the forward phases (waves 0 / 1: column block `wave`) ----
   Frags<NKG1> f1;
-  Frags<8> f2, fh;
+  Frags<8> f2;
+  Frags<4> fh;  // head k-groups wave, wave + 2, wave + 4, wave + 6: the chain `acc` (wave 0) / `acc2` (wave 1) of tile64_train's head GEMM
   if (wave < 2) {
     f1 = load_frags<NKG1>(W.W1f + (size_t)wave * NKG1 * 64, lane);
     f2 = load_frags<8>(W.W2f + (size_t)wave * 8 * 64, lane);
-    if (wave == 0) fh = load_frags<8>(W.W3f, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fh.f[j] = ldg16(W.W3f, (unsigned)lane * 16u + (unsigned)(2 * j + wave) * 1024u);
   }
   // ---- observation rows of the tile -> LDS ----
 #pragma unroll
@@ -172,30 +176,31 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
   }
   __syncthreads();
 
-  // ---- head + loss: wave 0 ----
+  // ---- head: the two accumulation chains of tile64_train's head GEMM on waves 0 / 1 (round 6; one wave ran both: 64 dependent-issue
+  //      MFMAs = 1.7 us of a 12 us launch).  Each chain sees its own MFMA sequence; the loss stage adds the partial tiles as `acc + acc2`
+  //      did: the same bits. ----
+  if (wave < 2) {
+    f32x16 acc = zero16();
+    const int ab = 4 * opaque((L::H2 + r * GLDH + 4 * h) >> 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(&lds[ab + (2 * j + wave) * 8]);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) acc = MFMA32(av[s_], fh.f[j][s_], acc);
+    }
+    const int o = opaque((wave == 0 ? L::DO : L::DO2) + 4 * h * FLDO + r);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lds[o + crc(i) * FLDO] = acc[i];
+  }
+  __syncthreads();
+  // ---- loss: wave 0 ----
   float s_pl = 0.f, s_vl = 0.f, s_kl = 0.f, s_cf = 0.f;
   if (wave == 0) {
-    {
-      f32x16 acc = zero16(), acc2 = zero16();  // two chains: even / odd k-groups, summed at the end
-      const int ab = 4 * opaque((L::H2 + r * GLDH + 4 * h) >> 2);
-#pragma unroll
-      for (int kg = 0; kg < 8; kg += 2) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8]);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[ab + kg * 8 + 8]);
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) {
-          acc = MFMA32(a0[s_], fh.f[kg][s_], acc);
-          acc2 = MFMA32(a1[s_], fh.f[kg + 1][s_], acc2);
-        }
-      }
-      const int o = opaque(L::DO + 4 * h * FLDO + r);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) lds[o + crc(i) * FLDO] = acc[i] + acc2[i];
-    }
     // loss: two lanes per row (q = action parity); dL/d(head) -> head tile, zero padded   (tile64_train's stage)
     const int rr = r, q = h;
     const bool live = llive;
     const int db = opaque(L::DO + rr * FLDO + q);
+    const int d2 = opaque(L::DO2 + rr * FLDO + q);
     const int cb = opaque(L::CST + q);
     const int gb = opaque(L::GACC + q);
     const int A = a.A;
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const float on = (2 * j + q < A && live) ? 1.f : 0.f;
-        const float d = on * (l_act[j] - (lds[db + 2 * j] + c_bb[j]));
+        const float d = on * (l_act[j] - ((lds[db + 2 * j] + lds[d2 + 2 * j]) + c_bb[j]));
         lp += on * (-(d * d) * (0.5f * c_iv[j]) - c_lc[j]);
         dk[j] = d;
       }
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
       float dv = 0.f;
       if (live && q == 0) {
         float sq, gv_;
-        value_loss_terms(lds[db] + lds[cb + 64], l_old, l_adv, a.clip_vf, sq, gv_);
+        value_loss_terms((lds[db] + lds[d2]) + lds[cb + 64], l_old, l_adv, a.clip_vf, sq, gv_);
         s_vl += sq;
         dv = a.vf_coef * gv_ * a.inv_bg;
       }
