@@ -1889,7 +1889,7 @@ int collect_host_served(mobrob_ppo_engine* e, mobrob_env_step_range_fn step_rang
     const double bound = getenv("MOBROB_SERVER_RESIDENCY_S") ? atof(getenv("MOBROB_SERVER_RESIDENCY_S")) : 2.0;
     const double r0 = now_s();
     bool all_resident = false;
-    for (unsigned spins = 0;; ++spins) {
+    for (unsigned spins = 0; bound > 0.0; ++spins) {   // (a bound <= 0 always misses: how the tests reach the fallback below)
       int b = 0;
       while (b < rblocks && __atomic_load_n(&gpu_flag[b], __ATOMIC_ACQUIRE) >= 1u) ++b;
       if (b == rblocks) { all_resident = true; break; }

@@ -617,6 +617,15 @@ def test_served_host_rollout_from_a_registered_block_matches_the_oracle(H):
             e.rollout_begin()
             e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"]).collect(rec.address, env.handle)
             starts = _check_host_rollout_against_oracle(e, p, rec, starts)
+        # while HIP_HOST_COHERENT=0 a registered block (no hipHostMallocCoherent flag) counts as non-coherent: refused by name; buffers from
+        # mobrob_ppo_host_alloc carry the flag and stay eligible
+        os.environ["HIP_HOST_COHERENT"] = "0"
+        try:
+            e.rollout_begin()
+            with pytest.raises(Exception, match="non-coherent"):
+                e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"]).collect(rec.address, env.handle)
+        finally:
+            os.environ.pop("HIP_HOST_COHERENT", None)
         # a buffer whose END lies outside the pinned block is refused by name (the first byte alone says nothing about [N][D])
         tail = np.zeros((N, D), np.float32)
         e.rollout_begin()
@@ -628,6 +637,54 @@ def test_served_host_rollout_from_a_registered_block_matches_the_oracle(H):
     env.close()
     e.unregister_host(base.ctypes.data)
     e.close()
+
+
+@pytest.mark.parametrize("H", [64, 256])
+def test_served_collector_falls_back_when_a_workgroup_is_not_resident(H):
+    """The residency check in front of the first environment step (a workgroup of the serving kernel that is not resident -- another
+    tenant on the device -- would leave the others waiting for the host while the host waits for it): on a miss the launches are told
+    to stop and the launch-per-step collector runs from the untouched rollout state.  MOBROB_SERVER_RESIDENCY_S=0 makes the check
+    miss; the rollout must then equal the MOBROB_COLLECT_SERVER=0 rollout bit for bit (the same kernels ran), twice in a row, and
+    MOBROB_COLLECT_SERVER=2 must name the reason instead."""
+    from mobrob_amd.envs.native_env import NativeGoalVecEnv
+    from mobrob_amd.envs.wrapper import ROBOT_DIMS
+    robot, N, parts, T = "car", 128, 2, 19
+    D, A, _ = ROBOT_DIMS[robot]
+    p = O.init_params(D, A, (H, H), (H, H), seed=1)
+    keys = ("obs", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns", "last_values")
+    out = {}
+    for mode, res_s in (("0", None), ("1", "0")):
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=64, n_epochs=1, seed=3, pi=(H, H), vf=(H, H))
+        e.set_params(p)
+        env = NativeGoalVecEnv.for_robot(robot, N, time_limit=5, seed=4)
+        b = dict(obs=e.pinned((N, D)), clip=e.pinned((N, A)), rew=e.pinned((N,)), done=e.pinned((N,), np.uint8),
+                 trunc=e.pinned((N,), np.uint8), term=e.pinned((N, D)))
+        env.use_buffers(obs=b["obs"], rewards=b["rew"], dones=b["done"], truncated=b["trunc"], terminal_obs=b["term"])
+        env.reset()
+        os.environ["MOBROB_COLLECT_SERVER"] = mode
+        os.environ["MOBROB_SERVER_TIMEOUT_S"] = "5"
+        if res_s is not None:
+            os.environ["MOBROB_SERVER_RESIDENCY_S"] = res_s
+        try:
+            res = []
+            for _ in range(2):
+                e.rollout_begin()
+                e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"]).collect(env.step_range_fn, env.handle)
+                res.append({k: e.read(k) for k in keys})
+            if res_s is not None:
+                os.environ["MOBROB_COLLECT_SERVER"] = "2"
+                e.rollout_begin()
+                with pytest.raises(Exception, match="not every workgroup"):
+                    e.part_pipeline(parts, b["obs"], b["clip"], b["rew"], b["done"], b["trunc"], b["term"]).collect(env.step_range_fn, env.handle)
+        finally:
+            for k in ("MOBROB_COLLECT_SERVER", "MOBROB_SERVER_TIMEOUT_S", "MOBROB_SERVER_RESIDENCY_S"):
+                os.environ.pop(k, None)
+        out[mode] = res
+        env.close()
+        e.close()
+    for r in range(2):
+        for k in keys:
+            assert np.array_equal(out["0"][r][k], out["1"][r][k]), (r, k)
 
 
 def test_served_host_rollout_gives_up_when_the_environment_fails():
