@@ -188,6 +188,31 @@ def test_ppo_learns_with_the_native_host_env_through_pinned_staging():
     assert ppo.num_timesteps == 24 * 128 * 512
 
 
+def test_the_reference_doggo_yaml_on_native_host_envs_is_served_by_the_rollout_kernel(monkeypatch):
+    """data/configs/doggo-ppo.yaml as the reference ships it (16 environments, n_steps 1000, batch 100, 2x64) with the environments on
+    the host (`vec_env_type: native`): PPO.learn runs the whole collector loop in C as ONE row range of half a tile, served by
+    k_rollout64_tile<.., 3> -- MOBROB_COLLECT_SERVER=2 makes any fallback an error -- and the loop's counters are the reference's
+    (/root/reference/data/configs/doggo-ppo.yaml:3-23 through /root/reference/src/mobrob/rl_control/ppo.py:61-74)."""
+    import yaml
+    from mobrob_amd.rl_control.ppo import PPOCtrl
+    from mobrob_amd.utils import DATA_DIR
+    with open(f"{DATA_DIR}/configs/doggo-ppo.yaml") as f:
+        cfg = yaml.safe_load(f)
+    cfg["vec_env_type"] = "native"
+    monkeypatch.setenv("MOBROB_COLLECT_SERVER", "2")
+    monkeypatch.setenv("MOBROB_SERVER_TIMEOUT_S", "10")
+    ctrl = PPOCtrl.from_config(cfg)
+    ppo = ctrl.ppo
+    n_envs, n_steps = cfg["n_envs"], cfg["ppo_kwargs"]["n_steps"]
+    assert n_envs < 32                                    # half a tile: the shape this test is about
+    ppo.learn(total_timesteps=2 * n_envs * n_steps)
+    assert ppo.num_timesteps == 2 * n_envs * n_steps and ppo._n_updates == 2 * cfg["ppo_kwargs"]["n_epochs"]
+    st = ppo.device_episode_stats
+    assert st["episodes"] > 0 and np.isfinite(st["ep_rew_mean"])
+    assert all(np.isfinite(v).all() for v in ppo.engine.get_params().values())
+    ppo.engine.close()
+
+
 def test_ep_info_buffer_holds_real_monitor_records_and_the_zip_keeps_the_robot_bounds(tmp_path):
     """Device goal env and native host env: `ep_info_buffer` gets the (return, length) of individual finished episodes
     (it used to get the rollout mean repeated), consistent with the aggregated counters; a saved drone model carries
