@@ -317,10 +317,13 @@ def sample_power_and_clock(run, min_samples=4):
             "how": "rocm-smi --showclocks --showpower every ~0.6 s during extra iterations AFTER the timed region; medians of the busy samples"}
 
 
-def dominant_kernel_name(H, rows_per_launch, generic, x3_train=False, chain=False):
+def dominant_kernel_name(H, rows_per_launch, generic, x3_train=False, chain=False, epoch_kernel=False):
     """Which gradient kernel the engine launches for this shape (engine.hip: fused64_minibatch_grad / fused_minibatch_grad)."""
     if generic:
         return "generic GEMM chain"
+    if epoch_kernel:
+        return ("k_epoch64 (ONE co-operative launch per epoch: per minibatch the k_split64_train gradient, the fixed-order slab reduction and "
+                "clip + Adam + packs as phases behind grid barriers; `avg_launch_ms` is a whole epoch, `achieved` prices all three phases)")
     if H == 256 and x3_train and chain:
         return ("k_chain_train (minibatch forward+loss+backward, 16 rows per wave chained through registers; hidden-layer products on the "
                 "bf16 pipe, split float32 operands, weights streamed through an LDS ring)")
@@ -799,7 +802,7 @@ def bench_single(args, name, steps, warmup, job, phases):
                                       if host is not None else "device-resident synthetic (Philox)"),
                        "parallelism": f"dp{world}", "n_ranks_seen": ranks_seen, "n_ranks_source": ranks_src,
                        "kernels": "generic" if args.generic else "fused"},
-            "roofline": {"bound": "mfma", "kernel": dominant_kernel_name(H, B, args.generic, x3_train, bool(x3_mode & 4)),
+            "roofline": {"bound": "mfma", "kernel": dominant_kernel_name(H, B, args.generic, x3_train, bool(x3_mode & 4), bool(eng.update_mode() & 1)),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "traffic_note": traffic_note,

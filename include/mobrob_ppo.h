@@ -357,7 +357,11 @@ int mobrob_ctrl_drone_pid(mobrob_ppo_engine_t* e, int32_t n, int32_t dev_ptrs, c
  *   ENT_COEF / VF_COEF          loss coefficients */
 enum {
   MOBROB_HYPER_LEARNING_RATE = 0, MOBROB_HYPER_CLIP_RANGE = 1, MOBROB_HYPER_CLIP_RANGE_VF = 2, MOBROB_HYPER_TARGET_KL = 3,
-  MOBROB_HYPER_ENT_COEF = 4, MOBROB_HYPER_VF_COEF = 5
+  MOBROB_HYPER_ENT_COEF = 4, MOBROB_HYPER_VF_COEF = 5,
+  MOBROB_HYPER_EPOCH_KERNEL = 6   /* not an SB3 keyword: 0 keeps three launches per optimizer step where mobrob_ppo_train would run an
+                                     epoch as one co-operative launch (csrc/kernels_epoch64.h; the env MOBROB_EPOCH_KERNEL=0 does the
+                                     same for every engine of the process).  Engines that update CONCURRENTLY on one device (a fleet's
+                                     segments) set 0: co-resident spinning launches must fit the device together. */
 };
 int mobrob_ppo_set_hyper(mobrob_ppo_engine_t* e, int32_t which, double value);
 /* Of the latest mobrob_ppo_train / train_enqueue: epochs started (SB3's `_n_updates` increment), whether target_kl
@@ -442,6 +446,11 @@ int mobrob_ppo_mark_rollout_ready(mobrob_ppo_engine_t* e);
  * k_chain_train (csrc/kernels_chain.h; MOBROB_NO_CHAIN=1 keeps k_fused_train<.., X3>).  0: everything on v_mfma_f32.  Measurement code
  * prices the kernels against the matrix peak of the pipe each product ran on (bench.py). */
 int mobrob_ppo_x3_mode(const mobrob_ppo_engine_t* e);
+/* How the latest mobrob_ppo_train / train_enqueue ran SB3's PPO.train (/root/reference/src/mobrob/rl_control/ppo.py:73-74): bit 0 = every
+ * epoch as ONE co-operative launch (k_epoch64: gradient -> grid barrier -> fixed-order slab reduction -> grid barrier -> clip + Adam + packs
+ * -> grid barrier, per minibatch; single rank, 64-wide networks, minibatches of at most 64 tiles, no target_kl), 0 = three launches per
+ * optimizer step.  Same bits either way. */
+int mobrob_ppo_update_mode(const mobrob_ppo_engine_t* e);
 
 /* train/explained_variance as SB3's PPO.train logs it (stable_baselines3 2.0.0 ppo.py: explained_variance(rollout_buffer.values.flatten(),
  * rollout_buffer.returns.flatten()) = 1 - Var[returns - values] / Var[returns], NaN when the returns do not vary), over the rollout

@@ -18,7 +18,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 BUF = dict(obs=0, actions=1, rewards=2, episode_starts=3, values=4, log_probs=5, advantages=6, returns=7,
            params=8, grads=9, advstat=10, last_values=11, last_dones=12, clipped_actions=13, episode_start_state=14,
            terminal_obs=15, terminal_values=16, truncated=17, env_state=18, grad_exchange=19)
-HYPER = dict(learning_rate=0, clip_range=1, clip_range_vf=2, target_kl=3, ent_coef=4, vf_coef=5)
+HYPER = dict(learning_rate=0, clip_range=1, clip_range_vf=2, target_kl=3, ent_coef=4, vf_coef=5, epoch_kernel=6)
 KERNEL_IDS = dict(act=0, gae=1, train_grad=2, apply=3, env=4, grad_reduce=5, allreduce=6)
 
 
@@ -126,6 +126,7 @@ SYMBOLS = {
     "mobrob_ppo_compute_gae": (C.c_int, [_P]),
     "mobrob_ppo_explained_variance": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "mobrob_ppo_x3_mode": (C.c_int, [_P]),
+    "mobrob_ppo_update_mode": (C.c_int, [_P]),
     "mobrob_ppo_feistel_permutation": (C.c_int, [_P, C.c_int64, C.c_uint64, _I64]),
     "mobrob_ppo_profile_enable": (C.c_int, [_P, C.c_int32]),
     "mobrob_ppo_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), _I64]),

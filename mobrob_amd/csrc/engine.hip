@@ -49,6 +49,7 @@ inline void poison_lds(hipStream_t st) {
 #include "fused_dispatch.h"
 #include "kernels_env.h"
 #include "kernels_rollout.h"
+#include "kernels_epoch64.h"
 #include "robot_ctrl.h"
 #include "oneshot_allreduce.h"
 
@@ -205,6 +206,15 @@ struct mobrob_ppo_engine {
   double* norm_rec_sum = nullptr; int* norm_rec_t = nullptr; int* fold_idx_dev = nullptr;
   int fold_start[kMaxTensors + 1] = {0};
   bool use_norm_records = false;
+  // one co-operative launch per epoch for small minibatches of 64-wide nets (kernels_epoch64.h)
+  bool epoch_kernel_on = true;        // MOBROB_EPOCH_KERNEL=0 / mobrob_ppo_set_hyper(MOBROB_HYPER_EPOCH_KERNEL, 0): the three launches per step
+  unsigned* epoch_bar = nullptr;      // [0] arrival counter, [1] abort word
+  float* epoch_consts = nullptr;      // [nmb][2] per-step Adam constants of the epoch being launched
+  int* epoch_idx = nullptr;           // [nmb] statistics rows of the epoch being launched
+  char* epoch_stage = nullptr;        // pinned staging of the two (12 bytes per step), one slot per epoch of a train() call
+  int* epoch_err_host = nullptr;      // pinned: raised by a launch that gave up at a barrier
+  hipEvent_t epoch_ev = nullptr;      // behind the last staging copy of a train() call: the staging may be rewritten after it
+  int last_update_mode = 0;           // bit 0: the latest train() ran its epochs as k_epoch64 launches
   int rollout64_tile_max = 256;  // rollouts of up to this many 32-env tiles use k_rollout64_tile (MOBROB_ROLLOUT64_TILE_MAX)
   int pair64_min_tiles = 65;     // minibatches of at least this many tiles use k_pair64_train (MOBROB_PAIR64_MIN_TILES; 0: never)
   int split64_max_tiles = 64;  // minibatches of up to this many 32-row tiles use k_split64_train (MOBROB_SPLIT64_MAX_TILES)
@@ -526,6 +536,9 @@ int fused_init(mobrob_ppo_engine* e) {
     CHK(dalloc(e, &f.slabs, (size_t)std::max(f.max_grid, 2 * f.pair_nseq_max) * f.slab_floats));
     f.lds_bytes = fused64_train_lds_bytes(e->Dp);
     f.lds_act_bytes = fused64_lds_bytes(e->Dp);
+    CHK(dalloc(e, &e->epoch_bar, 64));
+    CHK(dalloc(e, &e->epoch_consts, (size_t)2 * e->nmb));
+    CHK(dalloc(e, &e->epoch_idx, (size_t)e->nmb));
   } else {
     f.slab_floats = slab_size(e->Dp);
     CHK(dalloc(e, &f.slabs, (size_t)f.max_grid * f.slab_floats));
@@ -933,6 +946,7 @@ int engine_create(const mobrob_ppo_config_t* cfg, void* arena, size_t arena_byte
   if (const char* v = getenv("MOBROB_ROLLOUT64_TILE_MAX")) e->rollout64_tile_max = atoi(v);  // 0: one-wave kernel only
   if (const char* v = getenv("MOBROB_PAIR64_MIN_TILES")) e->pair64_min_tiles = atoi(v);  // 0: block kernel for large minibatches
   if (const char* v = getenv("MOBROB_SPLIT64_MAX_TILES")) e->split64_max_tiles = atoi(v);  // 0: block kernel only (A/B, tests)
+  if (const char* v = getenv("MOBROB_EPOCH_KERNEL")) e->epoch_kernel_on = atoi(v) != 0;     // 0: three launches per optimizer step, always
   CHK(engine_dims(e, cfg));
   HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   e->own_stream = true;
@@ -1015,6 +1029,9 @@ void mobrob_ppo_destroy(mobrob_ppo_engine_t* e) {
     if (ev) (void)hipEventDestroy(ev);
   if (e->srv_flags) (void)hipHostFree(e->srv_flags);
   if (e->srv_abort) (void)hipFree(e->srv_abort);
+  if (e->epoch_stage) (void)hipHostFree(e->epoch_stage);
+  if (e->epoch_err_host) (void)hipHostFree(e->epoch_err_host);
+  if (e->epoch_ev) (void)hipEventDestroy(e->epoch_ev);
   if (e->ro_exec) (void)hipGraphExecDestroy(e->ro_exec);
   if (e->ro_graph) (void)hipGraphDestroy(e->ro_graph);
   if (e->vstream) {
@@ -1449,6 +1466,8 @@ int mobrob_ppo_x3_mode(const mobrob_ppo_engine_t* e) {
   if (!e || !e->fused.enabled || e->fused.net[0].W2x == nullptr) return 0;
   return 1 | (e->fused.train_x3 ? 2 : 0) | (e->fused.train_x3 && e->fused.train_chain ? 4 : 0);
 }
+
+int mobrob_ppo_update_mode(const mobrob_ppo_engine_t* e) { return e ? e->last_update_mode : 0; }
 
 int mobrob_ppo_explained_variance(mobrob_ppo_engine_t* e, double* out) {
   if (!e || !out) return fail(MOBROB_ERR_INVALID, "explained_variance: null argument");
@@ -2359,6 +2378,7 @@ int mobrob_ppo_set_hyper(mobrob_ppo_engine_t* e, int32_t which, double value) {
     case MOBROB_HYPER_TARGET_KL: e->target_kl = value > 0.0 ? value : -1.0; break;
     case MOBROB_HYPER_ENT_COEF: e->cfg.ent_coef = value; break;
     case MOBROB_HYPER_VF_COEF: e->cfg.vf_coef = value; break;
+    case MOBROB_HYPER_EPOCH_KERNEL: e->epoch_kernel_on = value != 0.0; break;
     default: return fail(MOBROB_ERR_INVALID, "unknown hyper-parameter id %d", which);
   }
   return MOBROB_OK;
@@ -2451,6 +2471,11 @@ int oneshot_all_reduce(mobrob_ppo_engine* e, void* buf, size_t count, int dtype)
 }
 // raised by a one-shot all-reduce whose peer never published (dead rank): reported at the next synchronising call
 int check_async_error(mobrob_ppo_engine* e) {
+  if (e->epoch_err_host && *(volatile int*)e->epoch_err_host != 0) {
+    *(volatile int*)e->epoch_err_host = 0;
+    return fail(MOBROB_ERR_STATE, "the co-operative epoch kernel gave up at a grid barrier (a workgroup never arrived: another tenant on the "
+                                  "device?); the update of this train() is incomplete -- MOBROB_EPOCH_KERNEL=0 runs the three launches per step");
+  }
   if (e->oneshot.error && *(volatile int*)e->oneshot.error != 0) {
     const int v = *(volatile int*)e->oneshot.error;
     *(volatile int*)e->oneshot.error = 0;
@@ -2475,6 +2500,113 @@ int dp_all_reduce(mobrob_ppo_engine* e, void* buf, size_t count, int dtype, mobr
 }  // namespace
 
 namespace {
+// ---- one co-operative launch per epoch (kernels_epoch64.h) ----
+// Eligible: single rank, 64-wide fused engine, every minibatch of the epoch small enough for the split-tile gradient kernel
+// (fused64_minibatch_grad's `split`), norm records in use (no target_kl: its stop needs a host read per step), only the dominant
+// kernel bracketed when profiling, grid <= compute units.  *grid_out: workgroups of the launch.
+bool epoch_kernel_eligible(mobrob_ppo_engine* e, bool dp, int* grid_out) {
+  static_assert(kEpochRedBlocks * 256 >= 10 * 1024 + 200 && (kEpochRedBlocks - 1) * 256 < 10 * 1024 + 200, "kEpochRedBlocks = ceil(s64_size() / 256)");
+  const FusedState& f = e->fused;
+  if (dp || e->cfg.world_size != 1 || !e->epoch_kernel_on || !f.enabled || f.H != GH || e->epoch_bar == nullptr) return false;
+  if (e->target_kl > 0.0 || !e->use_norm_records || kEpochRedBlocks != cdiv(s64_size(), 256)) return false;
+  if (e->prof_on && (e->prof_mask & ((1u << MOBROB_K_GRAD_REDUCE) | (1u << MOBROB_K_APPLY))) != 0) return false;   // --phases: the per-step launches are what gets bracketed
+  const int total = e->N * e->T;
+  const int ntiles = cdiv(std::min(e->Bl, total), GR);
+  const int grid = 2 * std::min(f.max_grid / 2, cdiv(ntiles, g_train_waves(e->Dp)));
+  const bool split = ntiles <= e->split64_max_tiles && 2 * ntiles <= f.max_grid && ntiles <= (grid / 2) * g_train_waves(e->Dp);
+  if (!split) return false;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device_id) != hipSuccess) return false;
+  const int G = std::max(2 * ntiles, 2 * kEpochRedBlocks);
+  if (G > cus) return false;
+  *grid_out = G;
+  return true;
+}
+constexpr size_t kEpochLdsBytes = 84 * 1024;   // more than half of a CU's 160 KB: one workgroup per CU (the residency the hand-offs were validated in)
+
+int launch_epoch_kernel(mobrob_ppo_engine* e, int ep, int G) {
+  FusedState& f = e->fused;
+  const int total = e->N * e->T, nmb = e->nmb;
+  // per-step constants of this epoch: Adam's bias corrections in float64 exactly as apply_adam forms them, and the statistics rows the
+  // steps log into (apply_norms' ring)
+  const size_t slot_bytes = (size_t)nmb * 12;
+  if (!e->epoch_stage) {
+    HIPC(hipHostMalloc((void**)&e->epoch_stage, slot_bytes * (size_t)std::max(1, e->cfg.n_epochs), hipHostMallocDefault));
+    HIPC(hipHostMalloc((void**)&e->epoch_err_host, sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
+    *e->epoch_err_host = 0;
+    HIPC(hipEventCreateWithFlags(&e->epoch_ev, hipEventDisableTiming));
+  }
+  if (ep == 0) HIPC(hipEventSynchronize(e->epoch_ev));   // the previous train()'s staging copies are done (never recorded: returns at once)
+  char* slot = e->epoch_stage + slot_bytes * (size_t)(ep % std::max(1, e->cfg.n_epochs));
+  float* consts = reinterpret_cast<float*>(slot);
+  int* idx = reinterpret_cast<int*>(slot + (size_t)nmb * 8);
+  const double b1 = e->cfg.adam_beta1, b2 = e->cfg.adam_beta2;
+  for (int mb = 0; mb < nmb; ++mb) {
+    e->adam_step++;
+    consts[2 * mb] = (float)(e->cfg.learning_rate / (1.0 - std::pow(b1, (double)e->adam_step)));
+    consts[2 * mb + 1] = (float)std::sqrt(1.0 - std::pow(b2, (double)e->adam_step));
+    if (e->stats_n >= e->stats_cap) e->stats_n = 0;
+    idx[mb] = e->stats_n++;
+  }
+  HIPC(hipMemcpyAsync(e->epoch_consts, consts, (size_t)nmb * 8, hipMemcpyHostToDevice, e->stream));
+  HIPC(hipMemcpyAsync(e->epoch_idx, idx, (size_t)nmb * 4, hipMemcpyHostToDevice, e->stream));
+  HIPC(hipEventRecord(e->epoch_ev, e->stream));
+  HIPC(hipMemsetAsync(e->epoch_bar, 0, 64 * sizeof(unsigned), e->stream));
+
+  Epoch64Args ea{};
+  {  // gradient phase (fused64_minibatch_grad)
+    Fused64TrainArgs& a = ea.tr;
+    a.net[0] = f.net[0]; a.net[1] = f.net[1];
+    a.obs = e->obs; a.actions = e->actions; a.A = e->A; a.old_logp = e->logp; a.adv = e->adv; a.ret = e->ret;
+    a.log_std = e->params + e->offs[T_LOGSTD];
+    a.normalize = e->cfg.normalize_advantage;
+    a.clip = (float)e->cfg.clip_range; a.vf_coef = (float)e->cfg.vf_coef; a.ent_coef = (float)e->cfg.ent_coef;
+    a.clip_vf = (float)e->clip_vf; a.old_values = e->values;
+    a.slabs = f.slabs; a.sums = e->grads + e->P; a.stamps = f.stamps;
+    a.wpack[0] = reinterpret_cast<const float*>(f.net[0].W1f);
+    a.wpack[1] = reinterpret_cast<const float*>(f.net[1].W1f);
+  }
+  {  // reduction phase
+    Slab64ReduceArgs& r = ea.rd;
+    r.slabs = f.slabs; r.group = g_train_waves(e->Dp); r.grads = e->grads; r.P = e->P;
+    for (int i = 0; i < 14; ++i) r.offs[i] = e->offs[i];
+    r.D = e->D; r.A = e->A; r.ent_coef = (float)e->cfg.ent_coef;
+    r.sums = e->grads + e->P;
+    r.rec_sum = e->norm_rec_sum; r.rec_t = e->norm_rec_t;
+  }
+  {  // clip + Adam + packs (apply_adam with the norm records)
+    AdamPackArgs& a = ea.ad;
+    fill_adam_pack_args(e, a);
+    StatsArgs st{};
+    st.loss_sums = e->grads + e->P; st.log_std = Pp(e, T_LOGSTD);
+    st.ent_coef = (float)e->cfg.ent_coef; st.vf_coef = (float)e->cfg.vf_coef; st.n_act = e->A;
+    a.partial = e->norm_rec_sum; a.fold_idx = e->fold_idx_dev; a.st = st;
+    for (int i = 0; i <= kMaxTensors; ++i) a.fold_start[i] = e->fold_start[i];
+    a.loss_sums_zero = e->grads + e->P;
+  }
+  ea.rows = e->rows; ea.advstat = e->advstat;
+  ea.total = total; ea.bl = e->Bl; ea.nmb = nmb; ea.world = e->cfg.world_size;
+  ea.step_consts = e->epoch_consts; ea.stats_idx = e->epoch_idx; ea.stats = e->stats;
+  ea.barrier = e->epoch_bar; ea.error_host = e->epoch_err_host;
+  const double timeout_s = getenv("MOBROB_EPOCH_TIMEOUT_S") ? atof(getenv("MOBROB_EPOCH_TIMEOUT_S")) : 10.0;
+  ea.timeout_ticks = (long long)(timeout_s * 1e8);
+  void* kargs[1] = {&ea};
+  {
+    ProfScope ps(e, MOBROB_K_TRAIN_GRAD);   // the whole epoch: gradient, reduction and Adam phases are one launch
+    hipError_t le = hipSuccess;
+    FUSED_DISPATCH_DP(e->Dp, FUSED64_DISPATCH_NJ(e->A, {
+      const void* fn = reinterpret_cast<const void*>(k_epoch64<DPc, NJc>);
+      le = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEpochLdsBytes);
+      if (le == hipSuccess) le = hipLaunchCooperativeKernel(fn, dim3(G), dim3(256), kargs, (unsigned)kEpochLdsBytes, e->stream);
+    }));
+    if (le != hipSuccess) return fail(MOBROB_ERR_HIP, "k_epoch64 launch (%d workgroups): %s", G, hipGetErrorString(le));
+  }
+  e->cur_count = std::min(e->Bl, total - (nmb - 1) * e->Bl);
+  e->grad_pending = false;
+  e->last_steps_applied += nmb;
+  return MOBROB_OK;
+}
+
 // PPO.train() [SB3 ppo/ppo.py], single rank (dp == false) or data parallel (dp == true: the advantage statistics are
 // all-reduced once per epoch, the gradient TOGETHER WITH the eight loss sums behind it once per optimizer step, so the
 // logged statistics and the target_kl decision are those of the union minibatch on every rank alike).
@@ -2493,12 +2625,19 @@ int train_loop(mobrob_ppo_engine* e, const int64_t* perms, bool dp, mobrob_allre
     RecordsOn(mobrob_ppo_engine* e_, bool dp_) : e(e_) { e->use_norm_records = !dp_ && e->fused.enabled && e->target_kl <= 0.0 && getenv("MOBROB_NO_NORM_RECORDS") == nullptr; }
     ~RecordsOn() { e->use_norm_records = false; }
   } records_on(e, dp);
+  int epoch_grid = 0;
+  const bool epoch_kernel = epoch_kernel_eligible(e, dp, &epoch_grid);
+  e->last_update_mode = epoch_kernel ? 1 : 0;
   for (int ep = 0; ep < e->cfg.n_epochs; ++ep) {
     CHK(mobrob_ppo_epoch_begin(e, perms ? perms + (size_t)ep * total : nullptr));
     // per-minibatch (sum, sum of squares, count) of the advantages: global statistics for the normalisation
     if (dp) CHK(dp_all_reduce(e, e->advstat, (size_t)e->nmb * 4, 1, fn, ctx));
     e->last_epochs_started = ep + 1;
     if (ep == e->cfg.n_epochs - 1 || kl) e->stats_n = 0;  // the rows kept are those of the last epoch that ran
+    if (epoch_kernel) {   // all optimizer steps of the epoch in ONE co-operative launch (kernels_epoch64.h): same arithmetic, same bits
+      CHK(launch_epoch_kernel(e, ep, epoch_grid));
+      continue;
+    }
     for (int mb = 0; mb < e->nmb && !e->last_stopped_early; ++mb) {
       CHK(mobrob_ppo_minibatch_grad(e, mb));
       // THE exchange step, one per optimizer step: [P] gradient + [8] loss sums (policy, value, approx_kl, clip
@@ -2914,7 +3053,7 @@ int mobrob_ppo_profile_read(mobrob_ppo_engine_t* e, double* ms, int64_t* calls) 
   return MOBROB_OK;
 }
 
-#if defined(MOBROB_STAMPS) || defined(MOBROB_PAIR_STAMPS)
+#if defined(MOBROB_STAMPS) || defined(MOBROB_PAIR_STAMPS) || defined(MOBROB_EPOCH_STAMPS)
 // diagnostic build only (not part of include/mobrob_ppo.h)
 int mobrob_dbg_read_stamps(mobrob_ppo_engine_t* e, unsigned long long* out32, int reset) {
   HIPC(hipStreamSynchronize(e->stream));

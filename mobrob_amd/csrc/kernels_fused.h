@@ -174,6 +174,39 @@ __device__ __forceinline__ f32x4 ldg16(const void* base, unsigned byte_off) {
 __device__ __forceinline__ void stg16(void* base, unsigned byte_off, const f32x4& v) {
   *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
+// Agent-scope ("sc1": past the vector L1, write-through) accesses -- what a hand-off between workgroups INSIDE one launch is built
+// from (k_epoch64, kernels_epoch64.h).  COH = false is the plain access every other kernel uses: a kernel boundary orders those.
+// All of them are relaxed atomics of 4 or 8 bytes (compiler-tracked waits, no inline asm); a 16-byte access is two 8-byte ones
+// (MI355X_MICROARCH.md, inter-workgroup visibility: stores and loads of the handed-off bytes all sc1, 4- / 8- / 16-byte forms).
+template <bool COH, class T>
+__device__ __forceinline__ T ldc(const T* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COH, class T>
+__device__ __forceinline__ void stc(T* p, T v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ f32x4 ldg16c(const void* base, unsigned byte_off) {
+  if constexpr (!COH) return ldg16(base, byte_off);
+  else {
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(base) + byte_off);
+    const unsigned long long a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return f32x4{__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32))};
+  }
+}
+template <bool COH>
+__device__ __forceinline__ void stg16c(void* base, unsigned byte_off, const f32x4& v) {
+  if constexpr (!COH) stg16(base, byte_off, v);
+  else {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(base) + byte_off);
+    __hip_atomic_store(p, (unsigned long long)__float_as_uint(v[0]) | ((unsigned long long)__float_as_uint(v[1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, (unsigned long long)__float_as_uint(v[2]) | ((unsigned long long)__float_as_uint(v[3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 // C layout: element i of a 32x32 accumulator sits at row crc(i) + 4*h, column r of the tile
 __host__ __device__ __forceinline__ constexpr int crc(int i) { return (i & 3) + 8 * (i >> 2); }
 
@@ -1641,13 +1674,15 @@ struct SlabReduceArgs {
 // order (norm_fold_table), and k_adam_pack folds them like it folds chunk partials.
 // ------------------------------------------------------------------------------------------------
 constexpr int kNormRec = 4;
-__host__ __device__ inline int tensor_of_canonical(const int* offs, int P, int dst) {
+template <class PI>   // const int*, or the same behind a kernel-argument reference (constant address space)
+__host__ __device__ inline int tensor_of_canonical(PI offs, int P, int dst) {
   if (dst < 0 || dst >= P) return -1;
   int t = 0;
   for (int k = 1; k < 13; ++k) t += (dst >= offs[k]) ? 1 : 0;
   return t;
 }
 // records of one wave in lane order: first occurrence of a tensor opens a record (<= kNormRec distinct tensors)
+template <bool COH = false>
 __device__ __forceinline__ void block_norm_records(int t, float val, double* rec_sum, int* rec_t) {
   __shared__ double sc[4 * kNormRec];
   __shared__ int sct[4 * kNormRec];
@@ -1674,12 +1709,12 @@ __device__ __forceinline__ void block_norm_records(int t, float val, double* rec
       const int tt = sct[k];
       if (tt < 0) continue;
       if (tt == cur) { acc += sc[k]; continue; }
-      if (cur >= 0 && n < kNormRec) { rec_sum[n] = acc; rec_t[n] = cur; ++n; }
+      if (cur >= 0 && n < kNormRec) { stc<COH>(rec_sum + n, acc); stc<COH>(rec_t + n, cur); ++n; }
       cur = tt;
       acc = sc[k];
     }
-    if (cur >= 0 && n < kNormRec) { rec_sum[n] = acc; rec_t[n] = cur; ++n; }
-    for (; n < kNormRec; ++n) rec_t[n] = -1;
+    if (cur >= 0 && n < kNormRec) { stc<COH>(rec_sum + n, acc); stc<COH>(rec_t + n, cur); ++n; }
+    for (; n < kNormRec; ++n) stc<COH>(rec_t + n, -1);
   }
 }
 
@@ -1773,7 +1808,7 @@ __global__ __launch_bounds__(256) void k_slab_reduce(SlabReduceArgs s) {
 #pragma unroll
       for (int k = 0; k < d; ++k) ac[k] += ac[k + d];
     acc = ac[0];
-    if (dst < s.offs[1]) acc += s.ent_coef * (-s.b_local) * s.inv_bg;  // entropy bonus gradient on log_std
+    if (dst < s.offs[1]) acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(s.ent_coef, -s.b_local), s.inv_bg));  // entropy bonus gradient on log_std
     s.grads[dst] = acc;
   }
   if (s.rec_sum != nullptr) {
@@ -2049,16 +2084,34 @@ struct StatsArgs {
   float* stats_row; const float* loss_sums; const float* log_std; float ent_coef, vf_coef, inv_bg; int n_act;
 };
 // logged loss statistics of one optimizer step from the loss sums behind the gradient vector
-__device__ __forceinline__ void stats_row_from_sums(const StatsArgs& st) {
-  const float pl = -st.loss_sums[0] * st.inv_bg;
-  const float vl = st.loss_sums[1] * st.inv_bg;
+// sum over the actions of 0.5 + log sqrt(2 pi) + log sd [SB3 DiagGaussianDistribution.entropy], in action order.  COH: log_std was written
+// by other workgroups of the same launch (k_epoch64).  The loads go out eight at a time (as relaxed atomics they are not hoisted out of a
+// load - use - load - use loop: twelve dependent round trips on one lane).
+template <bool COH = false, class PF = const float*>
+__device__ __forceinline__ float entropy_of_log_std(PF log_std, int n_act) {
   float ent = 0.f;
-  for (int k = 0; k < st.n_act; ++k) ent += (0.5f + 0.91893853320467274178f) + logf(expf(st.log_std[k]));
-  const float el = -(ent * st.loss_sums[4]) * st.inv_bg;
+  for (int k0 = 0; k0 < n_act; k0 += 8) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = ldc<COH>(log_std + (k0 + u < n_act ? k0 + u : 0));
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + u < n_act) ent += (0.5f + 0.91893853320467274178f) + logf(expf(x[u]));
+  }
+  return ent;
+}
+// the logged statistics of a step from its loss sums and the entropy term of the PRE-update log_std (`ent`, entropy_of_log_std)
+template <bool COH = false>
+__device__ __forceinline__ void stats_row_from_sums(const StatsArgs& st, float ent) {
+  const float s0 = ldc<COH>(st.loss_sums + 0), s1 = ldc<COH>(st.loss_sums + 1), s2 = ldc<COH>(st.loss_sums + 2), s3 = ldc<COH>(st.loss_sums + 3),
+              s4 = ldc<COH>(st.loss_sums + 4);
+  const float pl = -s0 * st.inv_bg;
+  const float vl = s1 * st.inv_bg;
+  const float el = -(ent * s4) * st.inv_bg;
   st.stats_row[0] = pl; st.stats_row[1] = vl; st.stats_row[2] = el;
-  st.stats_row[3] = pl + st.ent_coef * el + st.vf_coef * vl;
-  st.stats_row[4] = st.loss_sums[2] * st.inv_bg;
-  st.stats_row[5] = st.loss_sums[3] * st.inv_bg;
+  st.stats_row[3] = __fmaf_rn(st.vf_coef, vl, __fmaf_rn(st.ent_coef, el, pl));   // (explicit: the same bits from every kernel this is compiled into)
+  st.stats_row[4] = s2 * st.inv_bg;
+  st.stats_row[5] = s3 * st.inv_bg;
   st.stats_row[7] = 0.f;
 }
 // thread `tid` of 256: its share of the sum of squares of one chunk (float64).  Shared by k_sqnorm_chunks and the
@@ -2074,7 +2127,7 @@ __device__ __forceinline__ double chunk_sumsq_thread(const float* __restrict__ g
 __global__ __launch_bounds__(256) void k_sqnorm_chunks(const float* __restrict__ g, const NormChunk* __restrict__ chunks,
                                                        double* __restrict__ partial, StatsArgs st) {
   __shared__ double sc[16];
-  if (blockIdx.x == 0 && threadIdx.x == 0 && st.stats_row != nullptr) stats_row_from_sums(st);  // pre-update log_std
+  if (blockIdx.x == 0 && threadIdx.x == 0 && st.stats_row != nullptr) stats_row_from_sums(st, entropy_of_log_std(st.log_std, st.n_act));  // pre-update log_std
   const double tot = block_sum_d(chunk_sumsq_thread(g, chunks[blockIdx.x], threadIdx.x), sc);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
@@ -2168,27 +2221,37 @@ __host__ __device__ __forceinline__ int chain_head_bwd_idx(int a_, int k) { retu
 
 // clip + Adam of canonical parameter i and its scatter into the padded copies / fragment packs [torch 2.0.1
 // single-tensor Adam; oracle adam_step].  Shared by k_adam_pack and the persistent small-batch kernel.
-__device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, float graw, float m0, float v0, float p0, float coef);
-__device__ __forceinline__ void adam_pack_element(const AdamPackArgs& a, int i, float coef) {
-  adam_pack_apply(a, i, a.g[i], a.m[i], a.v[i], a.p[i], coef);
-}
-// the same with the four operands already in registers (callers that batch their loads)
-__device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, float graw, float m0, float v0, float p0, float coef) {
-  const float g = graw * coef;
-  const float m = m0 * a.beta1 + (1.0f - a.beta1) * g;
-  const float v = v0 * a.beta2 + (1.0f - a.beta2) * (g * g);
-  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-  const float pn = p0 - a.step_size * (m / denom);
-  a.m[i] = m;
-  a.v[i] = v;
-  a.p[i] = pn;
-#ifdef ADAM_NO_PACK  // timing-only ablation: what the scattered pack stores cost
-  return;
-#endif
+// the four operands already in registers (the caller batches its loads).  COH: parameters, moments and the 64-wide families' packs are
+// read by other workgroups of the same launch (k_epoch64): stored at agent scope.  (The x3 / chain packs exist for 256-wide engines
+// only, which never run that kernel: plain stores.)
+// (step_size / bc2_sqrt: the per-step constants, passed beside `a`: k_epoch64 changes them per step and a modified local copy of the
+//  argument struct, with its runtime-indexed arrays, would live in scratch memory)
+template <bool COH = false, class TA = AdamPackArgs>   // TA: AdamPackArgs, or the same struct behind a kernel-argument reference (constant address space)
+__device__ __forceinline__ void adam_pack_apply(const TA& a, int i, float graw, float m0, float v0, float p0, float coef, float step_size, float bc2_sqrt) {
+  // Explicit roundings (no fp-contract): this function is compiled into several kernels (k_adam_pack, k_epoch64) that must produce the
+  // SAME bits, and which of `m0 b1 + (1 - b1) g`'s two products the compiler fuses into an fma is its choice per instantiation.
+  // The forms are torch's: exp_avg.mul_(b1).add_(g, alpha = 1 - b1); exp_avg_sq.mul_(b2).addcmul_(g, g, value = 1 - b2);
+  // denom = exp_avg_sq.sqrt() / sqrt(bc2) + eps; param.addcdiv_(exp_avg, denom, value = -step_size).
+  const float g = __fmul_rn(graw, coef);
+  const float m = __fmaf_rn(g, 1.0f - a.beta1, __fmul_rn(m0, a.beta1));
+  const float v = __fmaf_rn(__fmul_rn(g, g), 1.0f - a.beta2, __fmul_rn(v0, a.beta2));
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), a.eps);
+  const float pn = __fmaf_rn(-step_size, __fdiv_rn(m, denom), p0);
   int t = 0;
 #pragma unroll
   for (int k = 1; k < kMaxTensors; ++k) t += (i >= a.offs[k]) ? 1 : 0;   // (offsets beyond the engine's tensors equal P)
   const int e = i - a.offs[t];
+  // Store policy inside a co-operative launch (COH): agent-scope (write-through, one fabric write per 4-byte store: what the barrier
+  // behind this phase waits for) ONLY for what another workgroup reads before the launch ends -- the packs, and the canonical
+  // log_std / head biases the gradient phase reads directly.  The moments and every other parameter are read back by THIS thread
+  // only (past the vector L1: the line is in this XCD's L2), the zero-padded copies by later kernels: plain stores.
+  a.m[i] = m;
+  a.v[i] = v;
+  if (COH && a.two_by_two && (t == 0 || t == 10 || t == 12)) stc<true>(a.p + i, pn);
+  else a.p[i] = pn;
+#ifdef ADAM_NO_PACK  // timing-only ablation: what the scattered pack stores cost
+  return;
+#endif
   if (!a.two_by_two) {  // other depths than two hidden layers: the generic GEMM chain's zero-padded copies only (no fused packs exist)
     if (t == a.id_pw1 || t == a.id_vw1) {
       const int n = e / a.D, k = e - n * a.D;
@@ -2202,7 +2265,7 @@ __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, fl
     case 1: case 5: {  // W1 [H][D]
       const int net = t == 5, n = e / a.D, k = e - n * a.D;
       (net ? a.vW1p : a.pW1p)[n * a.Dp + k] = pn;
-      if (a.fW1f[net]) a.fW1f[net][pack_fwd_idx(n, k, a.Dp / 8)] = kTanhScale * pn;
+      if (a.fW1f[net]) stc<COH>(a.fW1f[net] + pack_fwd_idx(n, k, a.Dp / 8), kTanhScale * pn);
       if (a.xW1[net]) x3_pack_store(a.xW1[net], n, k, a.Dp / 16, kTanhScale * pn);
       if (a.cW1[net]) chain_store_w1(a.cW1[net], n, k, (a.Dp + 31) / 32, kTanhScale * pn);
     } break;
@@ -2210,9 +2273,9 @@ __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, fl
       const int net = t == 7;
       if (a.fW2f[net]) {
         const int K = net ? a.G1 : a.H1, n = e / K, k = e - n * K;
-        a.fW2f[net][pack_fwd_idx(n, k, K / 8)] = kTanhScale * pn;
+        stc<COH>(a.fW2f[net] + pack_fwd_idx(n, k, K / 8), kTanhScale * pn);
         // (packs only a gradient kernel reads are null while another gradient kernel is the engine's: k_chain_train has its own)
-        if (a.fW2b[net]) a.fW2b[net][pack_bwd_idx(n, k, (net ? a.G2 : a.H2) / 8)] = pn;
+        if (a.fW2b[net]) stc<COH>(a.fW2b[net] + pack_bwd_idx(n, k, (net ? a.G2 : a.H2) / 8), pn);
         if (a.xW2[net]) x3_pack_store(a.xW2[net], n, k, K / 16, kTanhScale * pn);                       // forward operand B[k][n] = scale W2[n][k]
         if (a.xW2b[net]) x3_pack_store(a.xW2b[net], k, n, (net ? a.G2 : a.H2) / 16, pn);                // backward operand B[n][k] = W2[n][k]
         if (a.cW2[net]) chain_store_w2(a.cW2[net], a.cW2b[net], n, k, kTanhScale * pn, pn);
@@ -2222,32 +2285,43 @@ __device__ __forceinline__ void adam_pack_apply(const AdamPackArgs& a, int i, fl
       const int net = t == 11, K = net ? a.G2 : a.H2, n = e / K, k = e - n * K;
       (net ? a.vWp : a.aWp)[e] = pn;
       if (a.fW3f[net]) {
-        a.fW3f[net][pack_fwd_idx(n, k, K / 8)] = pn;
-        if (a.fW3b[net]) a.fW3b[net][pack_bwd_idx(n, k, 4)] = pn;
-        if (a.fW3h[net] && n < 16) a.fW3h[net][pack_h16_idx(n, k)] = pn;
+        stc<COH>(a.fW3f[net] + pack_fwd_idx(n, k, K / 8), pn);
+        if (a.fW3b[net]) stc<COH>(a.fW3b[net] + pack_bwd_idx(n, k, 4), pn);
+        if (a.fW3h[net] && n < 16) stc<COH>(a.fW3h[net] + pack_h16_idx(n, k), pn);
         if (a.cW3[net] && n < 16) { a.cW3[net][chain_head_fwd_idx(n, k)] = pn; a.cW3b[net][chain_head_bwd_idx(n, k)] = pn; }
       }
     } break;
-    case 2: case 6: if (a.fb1s[t == 6]) a.fb1s[t == 6][e] = kTanhScale * pn; break;  // hidden biases (scaled copies)
-    case 4: case 8: if (a.fb2s[t == 8]) a.fb2s[t == 8][e] = kTanhScale * pn; break;
+    case 2: case 6: if (a.fb1s[t == 6]) stc<COH>(a.fb1s[t == 6] + e, kTanhScale * pn); break;  // hidden biases (scaled copies)
+    case 4: case 8: if (a.fb2s[t == 8]) stc<COH>(a.fb2s[t == 8] + e, kTanhScale * pn); break;
     default: break;
   }
 }
 
-__global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
+// One 256-parameter block of clip + Adam + packs: block bx.  COH: gradient, norm records and loss sums come from other workgroups of
+// the same launch, parameters / moments / packs go to them (k_epoch64): agent-scope accesses.
+// (step_size / bc2_sqrt / stats_row / inv_bg: the per-step fields of `a` and `a.st`, passed beside it)
+// The block's work with the element each thread updates CHOSEN BY THE CALLER: `i` = its canonical parameter (-1: none) and the four
+// operands already requested (k_adam_pack: parameter bx 256 + thread, loaded here below; k_epoch64: the parameter whose gradient the
+// thread has just reduced, still in its registers).  `lin` = bx 256 + thread: who does the block-0 duties (statistics, zeroing).
+template <bool COH, class TA>
+// `ent_pre` (used by the thread with lin == 0 only): entropy_of_log_std of the log_std this step's gradient was taken at -- the caller
+// reads it BEFORE any thread of the launch can have updated log_std.
+__device__ __forceinline__ void adam_pack_block_at(const TA& a, int lin, int i, float g_in, float m_in, float v_in, float p_in, float step_size,
+                                                   float bc2_sqrt, float* stats_row, float inv_bg, float ent_pre) {
   __shared__ double part[1024];
   __shared__ int tens[256];
   __shared__ float nts[kMaxTensors + 3];
   __shared__ float coef_s, total_s;
-  // this thread's four operands are requested first: their memory latency runs under the norm fold below
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  float g_in = 0.f, m_in = 0.f, v_in = 0.f, p_in = 0.f;
-  if (i < a.P) { g_in = a.g[i]; m_in = a.m[i]; v_in = a.v[i]; p_in = a.p[i]; }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && a.st.stats_row != nullptr) stats_row_from_sums(a.st);  // pre-update log_std
+  if (lin == 0 && a.st.loss_sums != nullptr) {  // this kernel also writes the step's loss statistics (pre-update log_std)
+    StatsArgs st;
+    st.stats_row = stats_row; st.loss_sums = a.st.loss_sums; st.log_std = a.st.log_std;
+    st.ent_coef = a.st.ent_coef; st.vf_coef = a.st.vf_coef; st.inv_bg = inv_bg; st.n_act = a.st.n_act;
+    stats_row_from_sums<COH>(st, ent_pre);
+  }
   if (a.fold_idx != nullptr) {  // norm records of the reduction kernel, listed per tensor by the host
     const int nrec = a.fold_start[13];   // (records exist with the fused kernels only: two hidden layers, 13 tensors)
     if (nrec <= 128) {  // 64-wide nets (~90 records): one lane per tensor, thirteen short serial folds side by side
-      for (int c = threadIdx.x; c < nrec; c += blockDim.x) part[c] = a.partial[a.fold_idx[c]];
+      for (int c = threadIdx.x; c < nrec; c += blockDim.x) part[c] = ldc<COH>(a.partial + a.fold_idx[c]);
       __syncthreads();
       if (threadIdx.x < 13) {
         double ts = 0.0;
@@ -2263,7 +2337,7 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
       const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
       const bool staged = nrec <= 1024;
       if (staged) {
-        for (int c = threadIdx.x; c < nrec; c += blockDim.x) part[c] = a.partial[a.fold_idx[c]];
+        for (int c = threadIdx.x; c < nrec; c += blockDim.x) part[c] = ldc<COH>(a.partial + a.fold_idx[c]);
         __syncthreads();
       }
       for (int t = wv; t < 13; t += 4) {
@@ -2271,14 +2345,14 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
         if (staged)
           for (int c = a.fold_start[t] + lane; c < a.fold_start[t + 1]; c += 64) ts += part[c];
         else
-          for (int c = a.fold_start[t] + lane; c < a.fold_start[t + 1]; c += 64) ts += a.partial[a.fold_idx[c]];
+          for (int c = a.fold_start[t] + lane; c < a.fold_start[t + 1]; c += 64) ts += ldc<COH>(a.partial + a.fold_idx[c]);
         ts = wave_sum_d(ts);
         if (lane == 0) nts[t] = (float)sqrt(ts);
       }
     }
   } else {
     for (int c = threadIdx.x; c < a.nchunks; c += blockDim.x) {  // one parallel round trip; the serial fold below is LDS only
-      part[c] = a.partial[c];
+      part[c] = ldc<COH>(a.partial + c);
       tens[c] = a.chunks[c].tensor;
     }
     __syncthreads();
@@ -2302,10 +2376,23 @@ __global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
   }
   __syncthreads();
   const float coef = coef_s;
-  if (i == 0 && a.stats_row != nullptr) a.stats_row[6] = total_s;
-  if (i < 8 && a.loss_sums_zero != nullptr) a.loss_sums_zero[i] = 0.f;  // consumed by k_sqnorm_chunks; ready for the next step
-  if (i >= a.P) return;
-  adam_pack_apply(a, i, g_in, m_in, v_in, p_in, coef);
+  if (lin == 0 && stats_row != nullptr) stats_row[6] = total_s;
+  if (lin < 8 && a.loss_sums_zero != nullptr) stc<COH>(a.loss_sums_zero + lin, 0.f);  // consumed by k_sqnorm_chunks; ready for the next step
+  if (i < 0 || i >= a.P) return;
+  adam_pack_apply<COH>(a, i, g_in, m_in, v_in, p_in, coef, step_size, bc2_sqrt);
+}
+template <bool COH, class TA>
+__device__ __forceinline__ void adam_pack_block(const TA& a, int bx, float step_size, float bc2_sqrt, float* stats_row, float inv_bg) {
+  // this thread's four operands are requested first: their memory latency runs under the norm fold
+  const int i = bx * 256 + (int)threadIdx.x;
+  float g_in = 0.f, m_in = 0.f, v_in = 0.f, p_in = 0.f;
+  if (i < a.P) { g_in = ldc<COH>(a.g + i); m_in = ldc<COH>(a.m + i); v_in = ldc<COH>(a.v + i); p_in = ldc<COH>(a.p + i); }
+  // (block 0 updates log_std itself, behind the barriers of the norm fold: its thread 0 reads the pre-update values here)
+  const float ent = (i == 0 && a.st.loss_sums != nullptr) ? entropy_of_log_std<COH>(a.st.log_std, a.st.n_act) : 0.f;
+  adam_pack_block_at<COH>(a, i, i, g_in, m_in, v_in, p_in, step_size, bc2_sqrt, stats_row, inv_bg, ent);
+}
+__global__ __launch_bounds__(256) void k_adam_pack(AdamPackArgs a) {
+  adam_pack_block<false>(a, blockIdx.x, a.step_size, a.bc2_sqrt, a.stats_row, a.st.inv_bg);
 }
 
 // ------------------------------------------------------------------------------------------------

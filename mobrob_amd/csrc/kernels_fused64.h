@@ -642,7 +642,8 @@ struct Slab64ReduceArgs {
   float* sums;
   double* rec_sum; int* rec_t;  // optional norm records (block_norm_records, kernels_fused.h)
 };
-__host__ __device__ __forceinline__ int slab64_to_canonical(const Slab64ReduceArgs& s, int net, int p) {
+template <class TS>
+__host__ __device__ __forceinline__ int slab64_to_canonical(const TS& s, int net, int p) {
   const int T_W1 = net == 0 ? 1 : 5, T_B1 = net == 0 ? 2 : 6, T_W2 = net == 0 ? 3 : 7, T_B2 = net == 0 ? 4 : 8;
   const int T_W3 = net == 0 ? 9 : 11, T_B3 = net == 0 ? 10 : 12;
   const int head = net == 0 ? s.A : 1;
@@ -680,24 +681,27 @@ __host__ __device__ __forceinline__ int slab64_to_canonical(const Slab64ReduceAr
   const bool mine = net == 0 ? (k == 0 || k == 2 || k == 3) : k == 1;
   return mine ? s.P + k : -1;
 }
-__global__ __launch_bounds__(256) void k_slab64_reduce(Slab64ReduceArgs s) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const int net = blockIdx.y;
-  if (p == 0 && net == 0) s.sums[4] = s.b_local;
+// One 256-position block of the reduction: block bx of gx along the slab, network `net`.  COH: the slabs were written and the results
+// are read by OTHER workgroups of the same launch (k_epoch64): every access of handed-off bytes at agent scope.
+// (nblocks_ / b_local_ / inv_bg_: the per-minibatch fields of `s`, passed beside it: see split64_tile)
+template <bool COH, class TS>   // TS: Slab64ReduceArgs, or the same struct behind a kernel-argument reference (constant address space)
+__device__ __forceinline__ void slab64_reduce_block(const TS& s, int bx, int net, int gx, int nblocks_, float b_local_, float inv_bg_, int& dst_o, float& acc_o) {
+  const int p = bx * 256 + (int)threadIdx.x;
+  if (p == 0 && net == 0) stc<COH>(s.sums + 4, b_local_);
   const int dst = p < s64_size() ? slab64_to_canonical(s, net, p) : -1;
   float acc = 0.f;
   if (dst >= 0) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // blocks of this network: net, net+2, ...
     const float* src = s.slabs + (size_t)net * s64_size() + p;
     const size_t stride = 2 * (size_t)s64_size();
-    const int nslabs = (s.nblocks - net + 1) / 2;
+    const int nslabs = (nblocks_ - net + 1) / 2;
     if (s.group <= 1) {
       const int n = nslabs;
       int w = 0;
       for (; w + 16 <= n; w += 16) {  // sixteen loads in flight; the adds keep the four-accumulator order below
         float x[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) x[u] = src[(size_t)(w + u) * stride];
+        for (int u = 0; u < 16; ++u) x[u] = ldc<COH>(src + (size_t)(w + u) * stride);
 #pragma unroll
         for (int u = 0; u < 16; u += 4) {
           a0 += x[u];
@@ -707,19 +711,19 @@ __global__ __launch_bounds__(256) void k_slab64_reduce(Slab64ReduceArgs s) {
         }
       }
       for (; w + 4 <= n; w += 4) {
-        a0 += src[(size_t)w * stride];
-        a1 += src[(size_t)(w + 1) * stride];
-        a2 += src[(size_t)(w + 2) * stride];
-        a3 += src[(size_t)(w + 3) * stride];
+        a0 += ldc<COH>(src + (size_t)w * stride);
+        a1 += ldc<COH>(src + (size_t)(w + 1) * stride);
+        a2 += ldc<COH>(src + (size_t)(w + 2) * stride);
+        a3 += ldc<COH>(src + (size_t)(w + 3) * stride);
       }
-      for (; w < n; ++w) a0 += src[(size_t)w * stride];
+      for (; w < n; ++w) a0 += ldc<COH>(src + (size_t)w * stride);
     } else {
       const int G = s.group, n = (nslabs + G - 1) / G;
       auto fold = [&](int gi) {  // tiles gi*G .. gi*G + G-1 in order (an idle wave of the block kernel added 0.f)
         const int t0 = gi * G;
         float x[4];                // G <= 4 (g_train_waves); all loads of a fold are independent
 #pragma unroll
-        for (int u = 0; u < 4; ++u) x[u] = (u < G && t0 + u < nslabs) ? src[(size_t)(t0 + u) * stride] : 0.f;
+        for (int u = 0; u < 4; ++u) x[u] = (u < G && t0 + u < nslabs) ? ldc<COH>(src + (size_t)(t0 + u) * stride) : 0.f;
         return ((x[0] + x[1]) + x[2]) + x[3];
       };
       int w = 0;
@@ -732,13 +736,21 @@ __global__ __launch_bounds__(256) void k_slab64_reduce(Slab64ReduceArgs s) {
       for (; w < n; ++w) a0 += fold(w);
     }
     acc = (a0 + a1) + (a2 + a3);
-    if (dst < s.offs[1]) acc += s.ent_coef * (-s.b_local) * s.inv_bg;
-    s.grads[dst] = acc;
+    if (dst < s.offs[1]) acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(s.ent_coef, -b_local_), inv_bg_));   // (explicit: no fma contraction, the same bits from every kernel)
+    // (inside a co-operative launch the gradient itself goes on in this thread's registers: only the loss sums behind it are read by
+    //  another workgroup -- the statistics row)
+    if (dst < s.P) s.grads[dst] = acc;
+    else stc<COH>(s.grads + dst, acc);
   }
+  dst_o = dst; acc_o = acc;   // (what this thread reduced: k_epoch64 goes on with it in registers)
   if (s.rec_sum != nullptr) {
-    const size_t b = ((size_t)net * gridDim.x + blockIdx.x) * kNormRec;
-    block_norm_records(tensor_of_canonical(s.offs, s.P, dst), acc, s.rec_sum + b, s.rec_t + b);
+    const size_t b = ((size_t)net * gx + bx) * kNormRec;
+    block_norm_records<COH>(tensor_of_canonical(s.offs, s.P, dst), acc, s.rec_sum + b, s.rec_t + b);
   }
+}
+__global__ __launch_bounds__(256) void k_slab64_reduce(Slab64ReduceArgs s) {
+  int dst; float acc;
+  slab64_reduce_block<false>(s, blockIdx.x, blockIdx.y, gridDim.x, s.nblocks, s.b_local, s.inv_bg, dst, acc);
 }
 
 // The same reduction for MANY slabs per network (k_pair64_train: up to 256 per network).  82 workgroups cover the slab, so
@@ -798,7 +810,7 @@ __global__ __launch_bounds__(1024) void k_slab64_reduce_wide(Slab64ReduceArgs s)
   if (dst >= 0) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc += part[q][tp];
-    if (dst < s.offs[1]) acc += s.ent_coef * (-s.b_local) * s.inv_bg;
+    if (dst < s.offs[1]) acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(s.ent_coef, -s.b_local), s.inv_bg));
     s.grads[dst] = acc;
   }
   if (s.rec_sum != nullptr) {

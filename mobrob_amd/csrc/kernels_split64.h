@@ -44,12 +44,12 @@ inline size_t split64_lds_bytes(int Dp) {
   return (size_t)(GR * (Dp + 4) + 4 * GR * GLDH + 2 * GR * FLDO + 64 + 96) * sizeof(float);
 }
 
-template <int NKG>
+template <int NKG, bool COH = false>
 __device__ __forceinline__ Frags<NKG> load_frags(const f32x4* __restrict__ Bp, int lane, int nkg = NKG) {
   Frags<NKG> w;
   const unsigned bo = opaque_u((unsigned)lane * 16u);
 #pragma unroll
-  for (int kg = 0; kg < NKG; ++kg) w.f[kg] = kg < nkg ? ldg16(Bp, bo + (unsigned)kg * 1024u) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kg = 0; kg < NKG; ++kg) w.f[kg] = kg < nkg ? ldg16c<COH>(Bp, bo + (unsigned)kg * 1024u) : f32x4{0.f, 0.f, 0.f, 0.f};
   return w;
 }
 // c += A[32 x 8*nkg] (LDS, row stride LDA) . B (one 32-column block, fragments in registers): ONE accumulation chain,
@@ -71,28 +71,35 @@ __device__ __forceinline__ void gemm_one(int a_off, const Frags<NKG>& w, f32x16&
 // slab of tile (blockIdx.x >> 1) of network (blockIdx.x & 1): layout of k_fused64_train's block slab
 // NJ: action pairs the loss stage is unrolled over (2 NJ >= A).  The head tile's columns beyond A are exact +0 from the
 // zero-padded head pack -- the very values tile64_train writes there -- so the shorter loops change no bit.
-template <int DP, int NJ>
-__global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
+// The body as a device function of the block index `vb` (= blockIdx.x of k_split64_train; k_epoch64 runs it per minibatch inside one
+// launch).  COH: the weight packs / parameters were written and the slab is read by OTHER workgroups of the same launch: those accesses
+// at agent scope (kernels_fused.h ldc / stc / ldg16c / stg16c); the rollout arrays are constant during an update: plain loads.
+// (rows_ / count_ / advstat_ / inv_bg_: the per-minibatch fields of `a`, passed beside it -- k_epoch64 changes them per step, and a
+//  modified local COPY of the argument struct, with its runtime-indexed net[2], would live in scratch memory)
+template <int DP, int NJ, bool COH, class TA>   // TA: Fused64TrainArgs, or the same struct behind a kernel-argument reference (constant address space)
+__device__ __forceinline__ void split64_tile(const TA& a, int vb, const int* __restrict__ rows_, int count_, const double* advstat_, float inv_bg_) {
   using L = LayS64<DP>;
   constexpr int ldx = L::LDX, per = DP / 4, NKG1 = DP / 8;
   constexpr bool two = DP > 32;
   const int tid0 = threadIdx.x;
   const int lane = tid0 & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-  const int net = blockIdx.x & 1, tile = blockIdx.x >> 1;
-  const int row0 = tile * GR, cnt = a.count;
-  const FusedNet W = a.net[net];
-  float* slab = a.slabs + (size_t)blockIdx.x * s64_size();
+  const int net = vb & 1, tile = vb >> 1;
+  const int row0 = tile * GR, cnt = count_;
+  // (the fields of a.net[net] this kernel uses, copied one by one: `a` may sit in the constant address space)
+  const struct { const f32x4 *W1f, *W2f, *W3f, *W2b, *W3b; const float *b1s, *b2s, *b3; int head; } W = {
+      a.net[net].W1f, a.net[net].W2f, a.net[net].W3f, a.net[net].W2b, a.net[net].W3b, a.net[net].b1s, a.net[net].b2s, a.net[net].b3, a.net[net].head};
+  float* slab = a.slabs + (size_t)vb * s64_size();
 
   // ---- weight fragments of the forward phases (waves 0 / 1: column block `wave`) ----
   Frags<NKG1> f1;
   Frags<8> f2;
   Frags<4> fh;  // head k-groups wave, wave + 2, wave + 4, wave + 6: the chain `acc` (wave 0) / `acc2` (wave 1) of tile64_train's head GEMM
   if (wave < 2) {
-    f1 = load_frags<NKG1>(W.W1f + (size_t)wave * NKG1 * 64, lane);
-    f2 = load_frags<8>(W.W2f + (size_t)wave * 8 * 64, lane);
+    f1 = load_frags<NKG1, COH>(W.W1f + (size_t)wave * NKG1 * 64, lane);
+    f2 = load_frags<8, COH>(W.W2f + (size_t)wave * 8 * 64, lane);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fh.f[j] = ldg16(W.W3f, (unsigned)lane * 16u + (unsigned)(2 * j + wave) * 1024u);
+    for (int j = 0; j < 4; ++j) fh.f[j] = ldg16c<COH>(W.W3f, (unsigned)lane * 16u + (unsigned)(2 * j + wave) * 1024u);
   }
   // ---- observation rows of the tile -> LDS ----
 #pragma unroll
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
     if (i < GR * per) {
       const int rr = i / per, c = i - rr * per;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row0 + rr < cnt) v = ldg16(a.obs, (unsigned)a.rows[row0 + rr] * (unsigned)(DP * 4) + (unsigned)(c * 16));
+      if (row0 + rr < cnt) v = ldg16(a.obs, (unsigned)rows_[row0 + rr] * (unsigned)(DP * 4) + (unsigned)(c * 16));
       *reinterpret_cast<f32x4*>(&lds[L::X + rr * ldx + 4 * c]) = v;
     }
   }
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
   float adv_mean = 0.f, adv_sd = 1.f;
   bool adv_on = false;
   if (wave == 0) {
-    const unsigned src = llive ? (unsigned)a.rows[row0 + r] : 0u;
+    const unsigned src = llive ? (unsigned)rows_[row0 + r] : 0u;
     if (net == 0) {
       const float* arow = a.actions + (size_t)src * a.A + h;
 #pragma unroll
@@ -125,10 +132,10 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
         if (a.clip_vf >= 0.f) l_adv = a.old_values[src];
       }
     }
-    const double n = a.advstat[2];
+    const double n = advstat_[2];
     adv_on = n > 1.0;
-    const double m = a.advstat[0] / (n > 0 ? n : 1.0);
-    double var = adv_on ? (a.advstat[1] - n * m * m) / (n - 1.0) : 0.0;
+    const double m = advstat_[0] / (n > 0 ? n : 1.0);
+    double var = adv_on ? (advstat_[1] - n * m * m) / (n - 1.0) : 0.0;
     if (var < 0.0) var = 0.0;
     adv_mean = (float)m;
     adv_sd = (float)sqrt(var);
@@ -140,11 +147,11 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
     const int k = tid0 - 64;
     float iv = 0.f, lc = 0.f, bb = 0.f;
     if (net == 0 && k < a.A) {
-      const float sd = expf(a.log_std[k]);
+      const float sd = expf(ldc<COH>(a.log_std + k));
       iv = 1.0f / (sd * sd);
       lc = logf(sd) + 0.91893853320467274178f;
     }
-    if (k < W.head) bb = W.b3[k];
+    if (k < W.head) bb = ldc<COH>(W.b3 + k);
     lds[L::CST + k] = iv;
     lds[L::CST + 32 + k] = lc;
     lds[L::CST + 64 + k] = bb;
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
 
   // ---- layer 1, layer 2: waves 0 / 1 take one column block each ----
   if (wave < 2) {
-    f32x16 c = splat16(W.b1s[32 * wave + r]);
+    f32x16 c = splat16(ldc<COH>(W.b1s + 32 * wave + r));
     gemm_one<ldx, NKG1>(L::X, f1, c, lane);
     const int o = opaque(L::H1 + 4 * h * GLDH + 32 * wave + r);
 #pragma unroll
@@ -166,9 +173,9 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
   Frags<8> b2;
   const int nkh = W.head <= 16 ? 2 : 4;  // k-groups of 8 head columns; those beyond `head` are zero
   if (wave < 2) {
-    b3 = load_frags<4>(W.W3b + (size_t)wave * 4 * 64, lane, nkh);
-    b2 = load_frags<8>(W.W2b + (size_t)wave * 8 * 64, lane);
-    f32x16 c = splat16(W.b2s[32 * wave + r]);
+    b3 = load_frags<4, COH>(W.W3b + (size_t)wave * 4 * 64, lane, nkh);
+    b2 = load_frags<8, COH>(W.W2b + (size_t)wave * 8 * 64, lane);
+    f32x16 c = splat16(ldc<COH>(W.b2s + 32 * wave + r));
     gemm_one<GLDH, 8>(L::H1, f2, c, lane);
     const int o = opaque(L::H2 + 4 * h * GLDH + 32 * wave + r);
 #pragma unroll
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
         }
         const float in_range = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
         const float w1 = (s1 < s2) ? 1.f : ((s1 > s2) ? 0.f : 0.5f);
-        g_logp = -(w1 * adv + (1.0f - w1) * adv * in_range) * a.inv_bg * ratio;
+        g_logp = -(w1 * adv + (1.0f - w1) * adv * in_range) * inv_bg_ * ratio;
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {  // k = 2j + q
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
         float sq, gv_;
         value_loss_terms((lds[db] + lds[d2]) + lds[cb + 64], l_old, l_adv, a.clip_vf, sq, gv_);
         s_vl += sq;
-        dv = a.vf_coef * gv_ * a.inv_bg;
+        dv = a.vf_coef * gv_ * inv_bg_;
       }
       lds[db] = dv;  // column q of the row: dv (q = 0) or 0; the columns beyond are +0 already
       const float t = wave_sum(dv);
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
     const unsigned lb = (unsigned)lane * 16u;  // put(s64_w3(), wave - 2, gA)
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd)
-      stg16(slab + s64_w3(), (unsigned)(((wave - 2) * 4 + qd) * 64) * 16u + lb, f32x4{gA[4 * qd], gA[4 * qd + 1], gA[4 * qd + 2], gA[4 * qd + 3]});
+      stg16c<COH>(slab + s64_w3(), (unsigned)(((wave - 2) * 4 + qd) * 64) * 16u + lb, f32x4{gA[4 * qd], gA[4 * qd + 1], gA[4 * qd + 2], gA[4 * qd + 3]});
   }
   __syncthreads();
 
@@ -323,8 +330,8 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
     const int ta = wave - 2, tb = wave;
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
-      stg16(slab + s64_w2(), (unsigned)((ta * 4 + qd) * 64) * 16u + lb, f32x4{gA[4 * qd], gA[4 * qd + 1], gA[4 * qd + 2], gA[4 * qd + 3]});
-      stg16(slab + s64_w2(), (unsigned)((tb * 4 + qd) * 64) * 16u + lb, f32x4{gB[4 * qd], gB[4 * qd + 1], gB[4 * qd + 2], gB[4 * qd + 3]});
+      stg16c<COH>(slab + s64_w2(), (unsigned)((ta * 4 + qd) * 64) * 16u + lb, f32x4{gA[4 * qd], gA[4 * qd + 1], gA[4 * qd + 2], gA[4 * qd + 3]});
+      stg16c<COH>(slab + s64_w2(), (unsigned)((tb * 4 + qd) * 64) * 16u + lb, f32x4{gB[4 * qd], gB[4 * qd + 1], gB[4 * qd + 2], gB[4 * qd + 3]});
     }
   }
   __syncthreads();
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
       const unsigned lb = (unsigned)lane * 16u;
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd)
-        stg16(slab + s64_w1(), (unsigned)((t * 4 + qd) * 64) * 16u + lb, f32x4{gw[4 * qd], gw[4 * qd + 1], gw[4 * qd + 2], gw[4 * qd + 3]});
+        stg16c<COH>(slab + s64_w1(), (unsigned)((t * 4 + qd) * 64) * 16u + lb, f32x4{gw[4 * qd], gw[4 * qd + 1], gw[4 * qd + 2], gw[4 * qd + 3]});
     }
     if (wave >= 2) {  // column sums of dz2 (wave 2) / dz1 (wave 3): lane c <-> column c
       const int o = opaque((wave == 2 ? L::Z2 : L::Z1) + lane);
@@ -354,17 +361,19 @@ __global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) {
         s0 += lds[o + rr * GLDH];
         s1 += lds[o + (rr + 1) * GLDH];
       }
-      slab[(wave == 2 ? s64_b2() : s64_b1()) + lane] = s0 + s1;
+      stc<COH>(slab + (wave == 2 ? s64_b2() : s64_b1()) + lane, s0 + s1);
     }
   }
   if (wave == 0) {
     const float t0 = wave_sum(s_pl), t1 = wave_sum(s_vl), t2 = wave_sum(s_kl), t3 = wave_sum(s_cf);
-    if (lane < 4) slab[s64_st() + lane] = lane == 0 ? t0 : (lane == 1 ? t1 : (lane == 2 ? t2 : t3));
+    if (lane < 4) stc<COH>(slab + s64_st() + lane, lane == 0 ? t0 : (lane == 1 ? t1 : (lane == 2 ? t2 : t3)));
     if (lane < 32) {
-      slab[s64_b3() + lane] = lds[L::GACC + lane];
-      slab[s64_ls() + lane] = lds[L::GACC + 32 + lane];
+      stc<COH>(slab + s64_b3() + lane, lds[L::GACC + lane]);
+      stc<COH>(slab + s64_ls() + lane, lds[L::GACC + 32 + lane]);
     }
   }
 }
+template <int DP, int NJ>
+__global__ __launch_bounds__(256, 1) void k_split64_train(Fused64TrainArgs a) { split64_tile<DP, NJ, false>(a, (int)blockIdx.x, a.rows, a.count, a.advstat, a.inv_bg); }
 
 }  // namespace mobrob

@@ -341,6 +341,10 @@ class PPOEngine:
         """Bit 0: rollout / value forward on the bf16 pipe with split float32 operands; bit 1: the gradient kernel's forward too."""
         return int(self.lib.mobrob_ppo_x3_mode(self._h))
 
+    def update_mode(self):
+        """Bit 0: the latest train() ran every epoch as one co-operative launch (k_epoch64) instead of three launches per step."""
+        return int(self.lib.mobrob_ppo_update_mode(self._h))
+
     def explained_variance(self):
         """1 - Var[returns - values] / Var[returns] over the rollout in the buffer (SB3's train/explained_variance)."""
         out = C.c_double()

@@ -82,6 +82,9 @@ class MixedFleet:
         try:
             for (name, kw), nb in zip(specs, sizes):
                 eng = PPOEngine(arena=(self._arena + off, nb), **kw)
+                # the segments update CONCURRENTLY on per-segment streams: co-operative epoch launches (spinning workgroups that must all
+                # be resident) of three engines at once are not what one device's residency check covers -> three launches per step
+                eng.set_hyper(epoch_kernel=0)
                 self.segments.append(FleetSegment(name, kw["obs_dim"], kw["act_dim"], kw["n_envs"], off, nb, eng))
                 off += nb
         except Exception:

@@ -1576,6 +1576,84 @@ def test_split_tile_kernel_is_bit_identical_to_the_block_kernel(cfg, monkeypatch
     assert np.max(np.abs(pa - ref)) < 1e-4, float(np.max(np.abs(pa - ref)))
 
 
+@pytest.mark.parametrize("cfg", [dict(D=58, A=12, T=100, N=16, B=100, E=3),     # data/configs/doggo-ppo.yaml: four tiles per minibatch, 16 minibatches
+                                 dict(D=14, A=2, T=200, N=2, B=96, E=2),        # point-ppo.yaml's envs; a short last minibatch (16 rows)
+                                 dict(D=26, A=2, T=64, N=4, B=100, E=2),        # car: DP = 32; 256 rows = 100 + 100 + 56
+                                 dict(D=12, A=18, T=50, N=16, B=100, E=2),      # drone: 18 actions (NJ = 10)
+                                 dict(D=43, A=2, T=40, N=16, B=100, E=2),       # turtlebot3: DP = 48
+                                 dict(D=58, A=12, T=128, N=32, B=2048, E=2)])   # 64 tiles per minibatch: 128 gradient workgroups
+def test_epoch_kernel_is_bit_identical_to_the_three_launch_update(cfg):
+    """k_epoch64 (csrc/kernels_epoch64.h: every epoch of PPO.train as ONE co-operative launch -- gradient -> grid barrier -> fixed-order slab
+    reduction -> grid barrier -> clip + Adam + packs -> grid barrier, per minibatch) against the three launches per optimizer step it
+    replaces (`epoch_kernel = 0`): the same device functions in the same order, so parameters, both Adam moments, the step counter and
+    every logged statistic must be the same BITS after two train() calls; and both equal the oracle to 1e-4
+    [SB3 PPO.train through /root/reference/src/mobrob/rl_control/ppo.py:73-74; shapes /root/reference/data/configs/*-ppo.yaml:12-23]."""
+    D, A, T, N, B, E = (cfg[k] for k in "DATNBE")
+    H = 64
+    rng = np.random.default_rng(17)
+    p0 = O.init_params(D, A, (H, H), (H, H), seed=5)
+    p0["log_std"] = rng.normal(-0.2, 0.2, A).astype(np.float32)
+    p0["action_net.weight"] *= 20
+    buf, lv, dones = _consistent_rollout(p0, T, N, D, A, seed=8)
+    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=E, batch_size=B, learning_rate=3e-4)
+    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, h.gamma, h.gae_lambda)
+    perms = np.stack([[rng.permutation(T * N) for _ in range(E)] for _ in range(2)])
+    m0 = {k: rng.normal(0, 1e-3, v.shape).astype(np.float32) for k, v in p0.items()}
+    v0 = {k: (1e-6 * (0.5 + rng.random(v.shape))).astype(np.float32) for k, v in p0.items()}
+    out = {}
+    for epoch in (True, False):
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H),
+                        ent_coef=h.ent_coef, learning_rate=h.learning_rate)
+        if not epoch:
+            e.set_hyper(epoch_kernel=0)
+        e.set_params(p0)
+        e.set_optimizer_state(m0, v0, 37)
+        e.load_rollout(buf, lv, dones)
+        stats = [e.train(perms[0]), e.train(perms[1])]
+        assert e.update_mode() == (1 if epoch else 0)
+        out[epoch] = (e.get_flat_params(), e.get_optimizer_state(), stats, e.read("grads"))
+        e.close()
+    (pa, (ma, va, sa), sta, ga), (pb, (mb_, vb, sb), stb, gb) = out[True], out[False]
+    assert sa == sb == 37 + 2 * E * -(-(T * N) // B)
+    assert np.array_equal(pa, pb), float(np.max(np.abs(pa - pb)))
+    for k in ma:
+        assert np.array_equal(ma[k], mb_[k]) and np.array_equal(va[k], vb[k]), k
+    assert sta == stb, (sta, stb)
+    assert np.array_equal(ga, gb)
+    p = {k: v.copy() for k, v in p0.items()}
+    st = O.AdamState(type(p0)((k, v.copy()) for k, v in m0.items()), type(p0)((k, v.copy()) for k, v in v0.items()), 37)
+    O.train(p, st, buf, h, perms[0])
+    O.train(p, st, buf, h, perms[1])
+    ref = O.flatten_params(p)
+    assert np.max(np.abs(pa - ref)) < 1e-4, float(np.max(np.abs(pa - ref)))
+
+
+def test_epoch_kernel_gives_up_at_a_barrier_instead_of_hanging(monkeypatch):
+    """Every wait of k_epoch64's grid barrier is bounded: with MOBROB_EPOCH_TIMEOUT_S so small that no barrier can be passed in time the
+    launch raises its abort word, every workgroup leaves, and the update FAILS at the host's next synchronisation (the parameters of an
+    aborted update are not trustworthy) instead of spinning; with the switch off the same engine then trains normally."""
+    D, A, T, N, B, E, H = 14, 2, 64, 4, 64, 2, 64
+    p0 = O.init_params(D, A, (H, H), (H, H), seed=2)
+    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H))
+    e.set_params(p0)
+    e.collect_synthetic()
+    monkeypatch.setenv("MOBROB_EPOCH_TIMEOUT_S", "1e-9")
+    with pytest.raises(Exception, match="gave up at a grid barrier"):
+        e.train(None)
+    monkeypatch.delenv("MOBROB_EPOCH_TIMEOUT_S")
+    e.set_hyper(epoch_kernel=0)
+    e.set_params(p0)
+    e.set_optimizer_state({k: np.zeros_like(v) for k, v in p0.items()}, {k: np.zeros_like(v) for k, v in p0.items()}, 0)
+    e.collect_synthetic()
+    st = e.train(None)
+    assert e.update_mode() == 0 and np.isfinite(st["loss"]) and all(np.isfinite(v).all() for v in e.get_params().values())
+    e.set_hyper(epoch_kernel=1)
+    e.collect_synthetic()
+    st = e.train(None)
+    assert e.update_mode() == 1 and np.isfinite(st["loss"])
+    e.close()
+
+
 @pytest.mark.parametrize("kind", ["synthetic", "goal"])
 @pytest.mark.parametrize("D,A,N,T", [(58, 12, 16, 60),     # data/configs/doggo-ppo.yaml: half a tile
                                      (14, 2, 2, 80),       # point-ppo.yaml: two envs
