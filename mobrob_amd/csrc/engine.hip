@@ -536,7 +536,7 @@ int fused_init(mobrob_ppo_engine* e) {
     CHK(dalloc(e, &f.slabs, (size_t)std::max(f.max_grid, 2 * f.pair_nseq_max) * f.slab_floats));
     f.lds_bytes = fused64_train_lds_bytes(e->Dp);
     f.lds_act_bytes = fused64_lds_bytes(e->Dp);
-    CHK(dalloc(e, &e->epoch_bar, 64));
+    CHK(dalloc(e, &e->epoch_bar, 1024));
     CHK(dalloc(e, &e->epoch_consts, (size_t)2 * e->nmb));
     CHK(dalloc(e, &e->epoch_idx, (size_t)e->nmb));
   } else {
@@ -2551,7 +2551,7 @@ int launch_epoch_kernel(mobrob_ppo_engine* e, int ep, int G) {
   HIPC(hipMemcpyAsync(e->epoch_consts, consts, (size_t)nmb * 8, hipMemcpyHostToDevice, e->stream));
   HIPC(hipMemcpyAsync(e->epoch_idx, idx, (size_t)nmb * 4, hipMemcpyHostToDevice, e->stream));
   HIPC(hipEventRecord(e->epoch_ev, e->stream));
-  HIPC(hipMemsetAsync(e->epoch_bar, 0, 64 * sizeof(unsigned), e->stream));
+  HIPC(hipMemsetAsync(e->epoch_bar, 0, 1024 * sizeof(unsigned), e->stream));
 
   Epoch64Args ea{};
   {  // gradient phase (fused64_minibatch_grad)

@@ -2306,8 +2306,10 @@ __device__ __forceinline__ void adam_pack_apply(const TA& a, int i, float graw, 
 template <bool COH, class TA>
 // `ent_pre` (used by the thread with lin == 0 only): entropy_of_log_std of the log_std this step's gradient was taken at -- the caller
 // reads it BEFORE any thread of the launch can have updated log_std.
+// `fidx_pre` (>= 0: a.fold_idx[threadIdx.x], fetched by the caller ahead of time; else fetched here): the index of the norm record this
+// thread stages when the record table has at most 128 entries -- one dependent round trip less behind a grid barrier.
 __device__ __forceinline__ void adam_pack_block_at(const TA& a, int lin, int i, float g_in, float m_in, float v_in, float p_in, float step_size,
-                                                   float bc2_sqrt, float* stats_row, float inv_bg, float ent_pre) {
+                                                   float bc2_sqrt, float* stats_row, float inv_bg, float ent_pre, int fidx_pre = -1) {
   __shared__ double part[1024];
   __shared__ int tens[256];
   __shared__ float nts[kMaxTensors + 3];
@@ -2321,7 +2323,7 @@ __device__ __forceinline__ void adam_pack_block_at(const TA& a, int lin, int i, 
   if (a.fold_idx != nullptr) {  // norm records of the reduction kernel, listed per tensor by the host
     const int nrec = a.fold_start[13];   // (records exist with the fused kernels only: two hidden layers, 13 tensors)
     if (nrec <= 128) {  // 64-wide nets (~90 records): one lane per tensor, thirteen short serial folds side by side
-      for (int c = threadIdx.x; c < nrec; c += blockDim.x) part[c] = ldc<COH>(a.partial + a.fold_idx[c]);
+      if ((int)threadIdx.x < nrec) part[threadIdx.x] = ldc<COH>(a.partial + (fidx_pre >= 0 ? fidx_pre : a.fold_idx[threadIdx.x]));   // (nrec <= 128 < blockDim)
       __syncthreads();
       if (threadIdx.x < 13) {
         double ts = 0.0;

@@ -21,10 +21,12 @@ e.train(None)
 e.lib.mobrob_dbg_read_stamps(e._h, out, 1)
 assert e.update_mode() == 1
 v = np.array(list(out)[:7], dtype=np.float64)
+w = np.array(list(out)[8:14], dtype=np.float64)
 steps = v[6]
 names = ["A gradient (k_split64_train's body)", "barrier 1 (slabs -> reduction)", "B slab reduction + norm records", "barrier 2 (gradient, records -> Adam)",
          "C clip + Adam + packs", "barrier 3 (weights -> next gradient)"]
 print(f"k_epoch64, doggo reference YAML shape ({N} envs x {T} steps, batch {B}, 2x{H}, {E} epochs): workgroup 0, microseconds per optimizer step over {int(steps)} steps")
+print(f"  {'phase':44s} {'wg 0':>10s} {'wg 81 (statistics duties)':>28s}")
 for k in range(6):
-    print(f"  {names[k]:44s} {v[k] / steps / 100:7.2f} us")
-print(f"  {'sum':44s} {v[:6].sum() / steps / 100:7.2f} us")
+    print(f"  {names[k]:44s} {v[k] / steps / 100:7.2f} us {w[k] / steps / 100:25.2f} us")
+print(f"  {'sum':44s} {v[:6].sum() / steps / 100:7.2f} us {w[:6].sum() / steps / 100:25.2f} us")
