@@ -449,7 +449,10 @@ int mobrob_ppo_x3_mode(const mobrob_ppo_engine_t* e);
 /* How the latest mobrob_ppo_train / train_enqueue ran SB3's PPO.train (/root/reference/src/mobrob/rl_control/ppo.py:73-74): bit 0 = every
  * epoch as ONE co-operative launch (k_epoch64: gradient -> grid barrier -> fixed-order slab reduction -> grid barrier -> clip + Adam + packs
  * -> grid barrier, per minibatch; single rank, 64-wide networks, minibatches of at most 64 tiles, no target_kl), 0 = three launches per
- * optimizer step.  Same bits either way. */
+ * optimizer step.  Same bits either way.  Every wait of the co-operative form is bounded (MOBROB_EPOCH_TIMEOUT_S, default 10): if a launch
+ * gives up (workgroups not resident together), mobrob_ppo_train restores the snapshot it took of parameters and moments and re-runs the
+ * update as three launches per step -- the call succeeds, the engine keeps that form, this query returns 0 from then on;
+ * mobrob_ppo_train_enqueue (no snapshot) fails at the next synchronising call instead. */
 int mobrob_ppo_update_mode(const mobrob_ppo_engine_t* e);
 
 /* train/explained_variance as SB3's PPO.train logs it (stable_baselines3 2.0.0 ppo.py: explained_variance(rollout_buffer.values.flatten(),

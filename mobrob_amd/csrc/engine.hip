@@ -215,6 +215,7 @@ struct mobrob_ppo_engine {
   int* epoch_err_host = nullptr;      // pinned: raised by a launch that gave up at a barrier
   hipEvent_t epoch_ev = nullptr;      // behind the last staging copy of a train() call: the staging may be rewritten after it
   int last_update_mode = 0;           // bit 0: the latest train() ran its epochs as k_epoch64 launches
+  float* epoch_snap = nullptr;        // [3][P] parameters and both moments as they were before a mobrob_ppo_train that uses k_epoch64 (restored if it aborts)
   int rollout64_tile_max = 256;  // rollouts of up to this many 32-env tiles use k_rollout64_tile (MOBROB_ROLLOUT64_TILE_MAX)
   int pair64_min_tiles = 65;     // minibatches of at least this many tiles use k_pair64_train (MOBROB_PAIR64_MIN_TILES; 0: never)
   int split64_max_tiles = 64;  // minibatches of up to this many 32-row tiles use k_split64_train (MOBROB_SPLIT64_MAX_TILES)
@@ -537,6 +538,7 @@ int fused_init(mobrob_ppo_engine* e) {
     f.lds_bytes = fused64_train_lds_bytes(e->Dp);
     f.lds_act_bytes = fused64_lds_bytes(e->Dp);
     CHK(dalloc(e, &e->epoch_bar, 1024));
+    CHK(dalloc(e, &e->epoch_snap, (size_t)3 * e->P));
     CHK(dalloc(e, &e->epoch_consts, (size_t)2 * e->nmb));
     CHK(dalloc(e, &e->epoch_idx, (size_t)e->nmb));
   } else {
@@ -2887,7 +2889,49 @@ int mobrob_ppo_allreduce_counters(mobrob_ppo_engine_t* e, int64_t* calls, int64_
 }
 
 int mobrob_ppo_train(mobrob_ppo_engine_t* e, const int64_t* perms, mobrob_ppo_train_stats_t* st) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  // An update that will run its epochs as co-operative launches (k_epoch64) is taken from a SNAPSHOT of the optimizer's state: should a
+  // launch give up at a grid barrier (a workgroup that never became resident: more spinning tenants on the device than it has room for),
+  // the state is restored and the whole update runs again as three launches per step -- the same bits, never a failed or half-applied
+  // train().  The engine then keeps the three launches (mobrob_ppo_update_mode reports it).  (mobrob_ppo_train_enqueue has no such
+  // retry: it returns before the outcome is known; there the abort fails the next synchronising call.)
+  int grid_unused = 0;
+  struct RecordsProbe {   // eligibility as train_loop will see it (it switches use_norm_records on for the loop's duration)
+    mobrob_ppo_engine* e; bool old;
+    explicit RecordsProbe(mobrob_ppo_engine* e_) : e(e_), old(e_->use_norm_records) { e->use_norm_records = e->fused.enabled && e->target_kl <= 0.0 && getenv("MOBROB_NO_NORM_RECORDS") == nullptr; }
+    ~RecordsProbe() { e->use_norm_records = old; }
+  };
+  bool snap = false;
+  {
+    RecordsProbe rp(e);
+    snap = e->cfg.world_size == 1 && e->epoch_snap != nullptr && epoch_kernel_eligible(e, false, &grid_unused);
+  }
+  const int64_t adam_step0 = e->adam_step;
+  const uint64_t perm_counter0 = e->perm_counter;
+  if (snap) {
+    const size_t pb = (size_t)e->P * sizeof(float);
+    HIPC(hipMemcpyAsync(e->epoch_snap, e->params, pb, hipMemcpyDeviceToDevice, e->stream));
+    HIPC(hipMemcpyAsync(e->epoch_snap + e->P, e->m, pb, hipMemcpyDeviceToDevice, e->stream));
+    HIPC(hipMemcpyAsync(e->epoch_snap + 2 * (size_t)e->P, e->v, pb, hipMemcpyDeviceToDevice, e->stream));
+  }
   CHK(mobrob_ppo_train_enqueue(e, perms));
+  if (snap && (e->last_update_mode & 1)) {
+    HIPC(hipStreamSynchronize(e->stream));
+    if (e->epoch_err_host && *(volatile int*)e->epoch_err_host != 0) {
+      *(volatile int*)e->epoch_err_host = 0;
+      fprintf(stderr, "[mobrob_ppo] the co-operative epoch kernel gave up at a grid barrier (workgroups not resident together: other spinning tenants "
+                      "on the device?); the update is re-run as three launches per optimizer step and this engine keeps that form\n");
+      const size_t pb = (size_t)e->P * sizeof(float);
+      HIPC(hipMemcpyAsync(e->params, e->epoch_snap, pb, hipMemcpyDeviceToDevice, e->stream));
+      HIPC(hipMemcpyAsync(e->m, e->epoch_snap + e->P, pb, hipMemcpyDeviceToDevice, e->stream));
+      HIPC(hipMemcpyAsync(e->v, e->epoch_snap + 2 * (size_t)e->P, pb, hipMemcpyDeviceToDevice, e->stream));
+      HIPC(hipMemsetAsync(e->grads + e->P, 0, 8 * sizeof(float), e->stream));
+      repack(e);   // every weight pack from the restored parameters
+      e->adam_step = adam_step0; e->perm_counter = perm_counter0;   // (the same permutations again; the parity of the max-|adv| words simply goes on)
+      e->epoch_kernel_on = false;
+      CHK(mobrob_ppo_train_enqueue(e, perms));
+    }
+  }
   if (st) {
     std::vector<float> rows((size_t)e->nmb * 8);
     const int n = mobrob_ppo_fetch_step_stats(e, rows.data(), e->nmb);

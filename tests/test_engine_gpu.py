@@ -1630,30 +1630,47 @@ def test_epoch_kernel_is_bit_identical_to_the_three_launch_update(cfg):
     assert np.max(np.abs(pa - ref)) < 1e-4, float(np.max(np.abs(pa - ref)))
 
 
-def test_epoch_kernel_gives_up_at_a_barrier_instead_of_hanging(monkeypatch):
-    """Every wait of k_epoch64's grid barrier is bounded: with MOBROB_EPOCH_TIMEOUT_S so small that no barrier can be passed in time the
-    launch raises its abort word, every workgroup leaves, and the update FAILS at the host's next synchronisation (the parameters of an
-    aborted update are not trustworthy) instead of spinning; with the switch off the same engine then trains normally."""
+def test_epoch_kernel_gives_up_at_a_barrier_and_the_update_is_rerun_as_three_launches(monkeypatch, capfd):
+    """Every wait of k_epoch64's grid barrier is bounded.  With MOBROB_EPOCH_TIMEOUT_S so small that no barrier can be passed in time the
+    launch raises its abort word and every workgroup leaves -- and mobrob_ppo_train, which took a snapshot of the optimizer's state,
+    restores it and runs the SAME update as three launches per step: the call succeeds, the result is the three-launch engine's bit
+    for bit, the engine keeps that form afterwards.  The asynchronous form (train_enqueue) has no retry: there the abort fails the
+    next synchronising call instead of passing a half-applied update on."""
     D, A, T, N, B, E, H = 14, 2, 64, 4, 64, 2, 64
     p0 = O.init_params(D, A, (H, H), (H, H), seed=2)
-    e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H))
-    e.set_params(p0)
-    e.collect_synthetic()
-    monkeypatch.setenv("MOBROB_EPOCH_TIMEOUT_S", "1e-9")
-    with pytest.raises(Exception, match="gave up at a grid barrier"):
-        e.train(None)
-    monkeypatch.delenv("MOBROB_EPOCH_TIMEOUT_S")
-    e.set_hyper(epoch_kernel=0)
-    e.set_params(p0)
-    e.set_optimizer_state({k: np.zeros_like(v) for k, v in p0.items()}, {k: np.zeros_like(v) for k, v in p0.items()}, 0)
-    e.collect_synthetic()
-    st = e.train(None)
-    assert e.update_mode() == 0 and np.isfinite(st["loss"]) and all(np.isfinite(v).all() for v in e.get_params().values())
-    e.set_hyper(epoch_kernel=1)
-    e.collect_synthetic()
-    st = e.train(None)
-    assert e.update_mode() == 1 and np.isfinite(st["loss"])
-    e.close()
+    zeros = {k: np.zeros_like(v) for k, v in p0.items()}
+    out = {}
+    for mode in ("abort", "three"):
+        e = make_engine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, batch_size=B, n_epochs=E, pi=(H, H), vf=(H, H), seed=9)
+        e.set_params(p0)
+        e.set_optimizer_state(zeros, zeros, 0)
+        if mode == "three":
+            e.set_hyper(epoch_kernel=0)
+        else:
+            monkeypatch.setenv("MOBROB_EPOCH_TIMEOUT_S", "1e-9")
+        e.collect_synthetic()
+        st1 = e.train(None)
+        monkeypatch.delenv("MOBROB_EPOCH_TIMEOUT_S", raising=False)
+        assert e.update_mode() == 0                       # (after the abort the engine keeps the three launches)
+        e.collect_synthetic()
+        st2 = e.train(None)
+        m, v, step = e.get_optimizer_state()
+        out[mode] = (e.get_flat_params(), m, v, step, st1, st2)
+        if mode == "abort":
+            assert "re-run as three launches" in capfd.readouterr().err
+            # the asynchronous form: no snapshot, the abort surfaces at the next synchronising call
+            e.set_hyper(epoch_kernel=1)
+            monkeypatch.setenv("MOBROB_EPOCH_TIMEOUT_S", "1e-9")
+            e.collect_synthetic()
+            e.train_enqueue()
+            with pytest.raises(Exception, match="gave up at a grid barrier"):
+                e.synchronize()
+            monkeypatch.delenv("MOBROB_EPOCH_TIMEOUT_S")
+        e.close()
+    (pa, ma, va, sa, a1, a2), (pb, mb, vb, sb, b1, b2) = out["abort"], out["three"]
+    assert sa == sb and np.array_equal(pa, pb) and a1 == b1 and a2 == b2
+    for k in ma:
+        assert np.array_equal(ma[k], mb[k]) and np.array_equal(va[k], vb[k]), k
 
 
 @pytest.mark.parametrize("kind", ["synthetic", "goal"])
