@@ -334,10 +334,17 @@ def dominant_kernel_name(H, rows_per_launch, generic, x3_train=False, chain=Fals
     return ("k_split64_train (one workgroup per 32-row tile)" if tiles <= 64 else "k_pair64_train (two waves per tile, two per SIMD)") + ": minibatch forward+loss+backward"
 
 
+def profile_rounds():
+    """profiles/rN directories, newest round first"""
+    pd = os.path.join(ROOT, "profiles")
+    names = [d for d in os.listdir(pd) if d[:1] == "r" and d[1:].isdigit()] if os.path.isdir(pd) else []
+    return sorted(names, key=lambda d: -int(d[1:]))
+
+
 def measured_traffic(kernel_prefix):
     """(bytes per launch | None, note): PMC-counted HBM traffic of the dominant kernel from the newest committed
     profile -- only if that profile was taken on exactly these kernel sources; otherwise None (never a stale figure)."""
-    for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):
+    for rnd in profile_rounds():
         tj = os.path.join(ROOT, "profiles", rnd, "hbm_traffic_pmc.json")
         if not os.path.exists(tj):
             continue

@@ -72,7 +72,7 @@ def test_traffic_figure_is_tied_to_the_kernel_sources():
     sha = bench.csrc_sha256()
     assert len(sha) == 64 and sha == bench.csrc_sha256()
     val, note = bench.measured_traffic("void mobrob::k_chain_train<")
-    newest = next(r for r in ("r5", "r4", "r3", "r2", "r1") if os.path.exists(os.path.join(ROOT, "profiles", r, "hbm_traffic_pmc.json")))
+    newest = next(r for r in bench.profile_rounds() if os.path.exists(os.path.join(ROOT, "profiles", r, "hbm_traffic_pmc.json")))
     recorded = json.load(open(os.path.join(ROOT, "profiles", newest, "hbm_traffic_pmc.json"))).get("csrc_sha256")
     if recorded == sha:
         assert isinstance(val, int) and val > 0
