@@ -37,9 +37,14 @@ extern "C" {
 #endif
 
 /* 2: config slot `persistent_train` became `activation`, `forward_x3` added, MOBROB_K_COUNT 6 -> 7 (profile_read arrays),
- *    MOBROB_BUF_COUNT / reserved[] resized -- a binding built against 1 must not load this library */
-#define MOBROB_PPO_ABI_VERSION 2
-enum { MOBROB_ACT_TANH = 0, MOBROB_ACT_RELU = 1 };
+ *    MOBROB_BUF_COUNT / reserved[] resized -- a binding built against 1 must not load this library
+ * 3: pi_hidden_ext / vf_hidden_ext (net_arch depths 4 .. 8) appended to the config, activation codes 2 .. 8 */
+#define MOBROB_PPO_ABI_VERSION 3
+/* policy_kwargs.activation_fn (SB3 ActorCriticPolicy; the reference splats ppo_kwargs into PPO verbatim, ppo.py:58): the torch.nn
+ * modules whose derivative is a function of their output, with torch's default arguments (ELU alpha 1, LeakyReLU slope 0.01,
+ * Softplus beta 1 / threshold 20, Hardtanh [-1, 1]) */
+enum { MOBROB_ACT_TANH = 0, MOBROB_ACT_RELU = 1, MOBROB_ACT_ELU = 2, MOBROB_ACT_LEAKY_RELU = 3, MOBROB_ACT_SIGMOID = 4,
+       MOBROB_ACT_SOFTPLUS = 5, MOBROB_ACT_SOFTSIGN = 6, MOBROB_ACT_HARDTANH = 7, MOBROB_ACT_RELU6 = 8, MOBROB_ACT_COUNT = 9 };
 
 enum {
   MOBROB_OK = 0,
@@ -82,17 +87,19 @@ typedef struct mobrob_ppo_config {
                                  captured hipGraph; the persistent rollout needs no graph          */
   int32_t rollout_persistent; /* 1: run the device-resident rollout as one persistent kernel (fused widths) */
   int32_t activation;         /* hidden activation of both networks: MOBROB_ACT_TANH (0; SB3's default for MlpPolicy, every
-                                 reference YAML) or MOBROB_ACT_RELU (policy_kwargs activation_fn=nn.ReLU; generic GEMM chain) */
+                                 reference YAML) or another MOBROB_ACT_* (policy_kwargs activation_fn; generic GEMM chain) */
   int32_t forward_x3;         /* 1 (default): the hidden-layer matrix products of 256-wide tanh nets -- rollout policy forward, batched value
                                  pass, and inside the gradient kernel the forward, dh1, dW2, dW1 -- run on the bf16 matrix pipe with every
                                  float32 operand split into three bf16 pieces and six piece products kept, float32 accumulation: float32
                                  RESULTS (error against float64 not larger than v_mfma_f32's, not bit-equal to it) at up to
                                  16/6 of the f32 matrix rate.  0: v_mfma_f32 everywhere.  Heads, loss, GAE, clip and Adam are plain float32
                                  either way; so are the 64-wide kernel families and the generic GEMM chain. */
-  int32_t pi_hidden3;         /* width of a THIRD policy hidden layer (0: none).  net_arch depths 1 .. 3 are accepted per network (SB3 takes any
+  int32_t pi_hidden3;         /* width of a THIRD policy hidden layer (0: none).  net_arch depths 1 .. 8 are accepted per network (SB3 takes any
                                  list; the reference's YAMLs use two layers); depths other than two run the generic GEMM chain */
   int32_t vf_hidden3;         /* likewise for the value network */
   int32_t reserved[1];
+  int32_t pi_hidden_ext[5];   /* widths of policy hidden layers 4 .. 8 (a width of 0 ends the list) */
+  int32_t vf_hidden_ext[5];   /* likewise for the value network */
 } mobrob_ppo_config_t;
 
 /* Fill `cfg` with SB3 2.0.0 defaults (Appendix A.1).  Replaces PPO.__init__'s default kwargs. */

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MOBROB_PPO_LIB: another build of the same library (A/B timing of a compile-time switch, stamp / ablation builds)
 LIB_PATH = os.environ.get("MOBROB_PPO_LIB") or os.path.join(_HERE, "libmobrob_ppo.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
@@ -34,7 +34,7 @@ class Config(C.Structure):
         ("normalize_advantage", C.c_int32), ("seed", C.c_uint64), ("device_id", C.c_int32),
         ("rank", C.c_int32), ("world_size", C.c_int32), ("fast_kernels", C.c_int32), ("rollout_graph", C.c_int32), ("rollout_persistent", C.c_int32),
         ("activation", C.c_int32), ("forward_x3", C.c_int32), ("pi_hidden3", C.c_int32), ("vf_hidden3", C.c_int32),
-        ("reserved", C.c_int32 * 1),
+        ("reserved", C.c_int32 * 1), ("pi_hidden_ext", C.c_int32 * 5), ("vf_hidden_ext", C.c_int32 * 5),
     ]
 
 

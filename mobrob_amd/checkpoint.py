@@ -176,7 +176,8 @@ _ALLOWED_GLOBALS = {
     ("numpy.random.bit_generator", "SeedSequence"), ("numpy.random._mt19937", "MT19937"),
     ("collections", "deque"), ("collections", "OrderedDict"),
     # `policy_kwargs` holding an activation class is cloudpickled as a whole by SB3: the class travels by reference
-    ("torch.nn.modules.activation", "Tanh"), ("torch.nn.modules.activation", "ReLU"),
+    *(("torch.nn.modules.activation", cls) for cls in ("Tanh", "ReLU", "ELU", "LeakyReLU", "Sigmoid", "Softplus", "Softsign",
+                                                        "Hardtanh", "ReLU6")),
 }
 
 
@@ -297,7 +298,8 @@ def save_zip(path, *, params, optimizer, hyper, obs_dim, act_dim, net_arch=None,
     policy_kwargs.update(extra_policy_kwargs or {})  # JSON-able ones the user passed: log_std_init, ortho_init, optimizer_kwargs
     act = policy_kwargs.get("activation_fn")
     if act is not None:  # SB3 pickles a policy_kwargs dict that holds a class as ONE blob (the class by reference) + readable keys
-        cls = getattr(torch.nn, {"relu": "ReLU", "tanh": "Tanh"}[str(act).lower()])
+        from .engine import ACTIVATIONS, activation_name
+        cls = getattr(torch.nn, ACTIVATIONS[activation_name(act)][1])
         real = dict(policy_kwargs, activation_fn=cls)
         readable = {k: (str(cls) if k == "activation_fn" else v) for k, v in policy_kwargs.items()}
         policy_kwargs = _blob("<class 'dict'>", pickle.dumps(real, protocol=4), **readable)

@@ -6,6 +6,9 @@
 
 namespace mobrob {
 
+constexpr int kMaxHidden = 8;   // hidden layers per network the generic chain accepts (the fused kernel families are two-layer)
+
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -90,10 +90,10 @@ struct ProfSpan {
 };
 
 // Canonical tensors in SB3's registration order: log_std, (W, b) of every policy hidden layer, (W, b) of every value hidden layer,
-// action head, value head.  With one to three hidden layers per network that is 9 .. 17 tensors; the ids are the engine's
+// action head, value head.  With one to eight hidden layers per network that is 9 .. 37 tensors; the ids are the engine's
 // (engine_dims), the names below resolve through `e`.  Two hidden layers per network give the numbering 0 .. 12 the fused
 // kernels' argument structs were written for.
-// (kMaxHidden = 3, kMaxTensors = 17: kernels_fused.h)
+// (kMaxHidden = 8: device_utils.h; kMaxTensors = 37: kernels_fused.h)
 #define T_LOGSTD 0
 #define T_PW1 (e->tPW[0])
 #define T_PB1 (e->tPB[0])
@@ -113,7 +113,7 @@ struct ProfSpan {
 struct mobrob_ppo_engine {
   mobrob_ppo_config_t cfg;
   int D, Dp, A, Ap, H1, H2, G1, G2, N, T, P;   // H1, H2 / G1, G2: the first two hidden widths (the fused kernels' view; H2 = 0 at depth 1)
-  int Lp = 2, Lv = 2;                          // hidden layers of the policy / value network (1 .. 3)
+  int Lp = 2, Lv = 2;                          // hidden layers of the policy / value network (1 .. kMaxHidden)
   int Hp[kMaxHidden] = {0}, Hv[kMaxHidden] = {0};   // their widths
   int HL = 0, GL = 0;                          // width of the last hidden layer of each network (what the heads read)
   int tPW[kMaxHidden] = {0}, tPB[kMaxHidden] = {0}, tVW[kMaxHidden] = {0}, tVB[kMaxHidden] = {0}, tAW = 0, tAB = 0, tVWh = 0, tVBh = 0;
@@ -329,7 +329,7 @@ void linear_fwd(mobrob_ppo_engine* e, const float* X, int ldx, const float* W, i
                 int ldy, int M, int Nn, int K, bool tanh_) {
   GemmArgs g{};
   g.A = X; g.B = W; g.C = Y; g.M = M; g.N = Nn; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldy; g.bias = bias;
-  g.relu = e->cfg.activation == MOBROB_ACT_RELU;
+  g.act = e->cfg.activation;
   if (tanh_) launch_gemm<MODE_NT, EPI_BIAS_TANH>(e, g);
   else launch_gemm<MODE_NT, EPI_BIAS>(e, g);
 }
@@ -338,7 +338,7 @@ void linear_bwd_input(mobrob_ppo_engine* e, const float* dY, int ldd, const floa
                       float* dZ, int ldz, float* bias_grad, int M, int Nn, int K) {
   GemmArgs g{};
   g.A = dY; g.B = W; g.C = dZ; g.M = M; g.N = Nn; g.K = K; g.lda = ldd; g.ldb = ldw; g.ldc = ldz;
-  g.Hact = H; g.ldh = ldh; g.colsum = bias_grad; g.relu = e->cfg.activation == MOBROB_ACT_RELU;
+  g.Hact = H; g.ldh = ldh; g.colsum = bias_grad; g.act = e->cfg.activation;
   launch_gemm<MODE_NN, EPI_DTANH_COLSUM>(e, g);
 }
 // dW[M x Nn] += dY[rows x M]^T . X[rows x Nn]
@@ -424,21 +424,20 @@ void forward(mobrob_ppo_engine* e, const float* X, int rows, bool want_pi, float
   forward_generic(e, X, rows, want_pi, mu_out, want_v, v_out);
 }
 
+int value_net_width_sum(const mobrob_ppo_engine* e) {
+  int s = 0;
+  for (int l = 0; l < e->Lv; ++l) s += e->Hv[l];
+  return s;
+}
 // the value network as the per-row evaluators take it (canonical parameters; layers beyond the network's depth are null)
 ValueNetArgs value_net_args(mobrob_ppo_engine* e) {
   ValueNetArgs vn{};
   for (int l = 0; l < e->Lv; ++l) { vn.W[l] = Pp(e, e->tVW[l]); vn.b[l] = Pp(e, e->tVB[l]); vn.G[l] = e->Hv[l]; }
   vn.Wv = Pp(e, T_VW); vn.bv = Pp(e, T_VB);
-  vn.relu = e->cfg.activation == MOBROB_ACT_RELU;
+  vn.L = e->Lv; vn.act = e->cfg.activation; vn.width_sum = value_net_width_sum(e);
   return vn;
 }
-int value_net_width_sum(const mobrob_ppo_engine* e) { return e->Hv[0] + e->Hv[1] + e->Hv[2]; }
-BootArgs boot_args(mobrob_ppo_engine* e) {
-  const ValueNetArgs vn = value_net_args(e);
-  BootArgs bt{vn.W[0], vn.b[0], vn.W[1], vn.b[1], vn.Wv, vn.bv, vn.G[0], vn.G[1], (float)e->cfg.gamma, e->term_val, vn.relu};
-  bt.W3 = vn.W[2]; bt.b3 = vn.b[2]; bt.G3 = vn.G[2];
-  return bt;
-}
+BootNetArgs boot_args(mobrob_ppo_engine* e) { return BootNetArgs{value_net_args(e), (float)e->cfg.gamma, e->term_val}; }
 
 void value_flagged(mobrob_ppo_engine* e, const float* obs_rows, const uint8_t* flags, float* out,
                    float* bootstrap_rewards = nullptr) {
@@ -765,17 +764,30 @@ int upload_obs_on(mobrob_ppo_engine* e, hipStream_t st, const float* host, float
   return MOBROB_OK;
 }
 
+// net_arch as the config carries it: pi_hidden[0 .. 1], pi_hidden3, pi_hidden_ext[0 .. 4] (likewise vf); a width of 0 ends the list
+void cfg_widths(const mobrob_ppo_config_t* c, int* pw, int* vw) {
+  pw[0] = c->pi_hidden[0]; pw[1] = c->pi_hidden[1]; pw[2] = c->pi_hidden3;
+  vw[0] = c->vf_hidden[0]; vw[1] = c->vf_hidden[1]; vw[2] = c->vf_hidden3;
+  for (int i = 3; i < kMaxHidden; ++i) { pw[i] = c->pi_hidden_ext[i - 3]; vw[i] = c->vf_hidden_ext[i - 3]; }
+}
+
+static_assert(ACT_TANH == MOBROB_ACT_TANH && ACT_RELU == MOBROB_ACT_RELU && ACT_ELU == MOBROB_ACT_ELU && ACT_LEAKY_RELU == MOBROB_ACT_LEAKY_RELU &&
+              ACT_SIGMOID == MOBROB_ACT_SIGMOID && ACT_SOFTPLUS == MOBROB_ACT_SOFTPLUS && ACT_SOFTSIGN == MOBROB_ACT_SOFTSIGN &&
+              ACT_HARDTANH == MOBROB_ACT_HARDTANH && ACT_RELU6 == MOBROB_ACT_RELU6 && ACT_COUNT == MOBROB_ACT_COUNT,
+              "kernels_generic.h activation codes are the header's");
+
 int check_cfg(const mobrob_ppo_config_t* c) {
   if (c->abi_version != MOBROB_PPO_ABI_VERSION) return fail(MOBROB_ERR_INVALID, "abi_version %d != %d", c->abi_version, MOBROB_PPO_ABI_VERSION);
   if (c->obs_dim < 1 || c->act_dim < 1) return fail(MOBROB_ERR_INVALID, "obs_dim/act_dim must be >= 1");
-  {  // one to three hidden layers per network: [h1, h2, h3] with trailing zeros, every width a positive multiple of 8
-    const int pw[3] = {c->pi_hidden[0], c->pi_hidden[1], c->pi_hidden3}, vw[3] = {c->vf_hidden[0], c->vf_hidden[1], c->vf_hidden3};
+  {  // one to eight hidden layers per network: [h1, h2, ...] with trailing zeros, every width a positive multiple of 8
+    int pw[kMaxHidden], vw[kMaxHidden];
+    cfg_widths(c, pw, vw);
     for (const int* w : {pw, vw}) {
       bool ended = false;
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < kMaxHidden; ++i) {
         if (w[i] == 0 && i > 0) { ended = true; continue; }
         if (ended || w[i] < 8 || w[i] % 8)
-          return fail(MOBROB_ERR_INVALID, "hidden widths must be positive multiples of 8, one to three layers per network (a width of 0 ends the list)");
+          return fail(MOBROB_ERR_INVALID, "hidden widths must be positive multiples of 8, one to %d layers per network (a width of 0 ends the list)", kMaxHidden);
       }
     }
   }
@@ -784,7 +796,7 @@ int check_cfg(const mobrob_ppo_config_t* c) {
   if (c->world_size < 1 || c->rank < 0 || c->rank >= c->world_size) return fail(MOBROB_ERR_INVALID, "bad rank/world_size");
   if (c->batch_size % c->world_size) return fail(MOBROB_ERR_INVALID, "batch_size must be divisible by world_size");
   if ((int64_t)c->n_envs * c->n_steps > (int64_t)1 << 30) return fail(MOBROB_ERR_INVALID, "rollout too large");
-  if (c->activation != MOBROB_ACT_TANH && c->activation != MOBROB_ACT_RELU) return fail(MOBROB_ERR_INVALID, "activation must be MOBROB_ACT_TANH or MOBROB_ACT_RELU");
+  if (c->activation < 0 || c->activation >= MOBROB_ACT_COUNT) return fail(MOBROB_ERR_INVALID, "activation must be one of MOBROB_ACT_* (0 .. %d)", MOBROB_ACT_COUNT - 1);
   return MOBROB_OK;
 }
 
@@ -857,9 +869,8 @@ namespace {
 int engine_dims(mobrob_ppo_engine* e, const mobrob_ppo_config_t* cfg) {
   e->cfg = *cfg;
   e->D = cfg->obs_dim; e->Dp = padded_obs_dim(cfg->obs_dim); e->A = cfg->act_dim; e->Ap = rup(cfg->act_dim, 8);
-  // net_arch: pi_hidden[0 .. 1] + pi_hidden3 (likewise vf); a width of 0 ends the list (check_cfg has validated the pattern)
-  const int pw[kMaxHidden] = {cfg->pi_hidden[0], cfg->pi_hidden[1], cfg->pi_hidden3};
-  const int vw[kMaxHidden] = {cfg->vf_hidden[0], cfg->vf_hidden[1], cfg->vf_hidden3};
+  int pw[kMaxHidden], vw[kMaxHidden];   // (check_cfg has validated the pattern)
+  cfg_widths(cfg, pw, vw);
   e->Lp = e->Lv = 0;
   for (int l = 0; l < kMaxHidden; ++l) { e->Hp[l] = e->Hv[l] = 0; }
   for (int l = 0; l < kMaxHidden && pw[l] > 0; ++l) e->Hp[e->Lp++] = pw[l];
@@ -1531,7 +1542,7 @@ int enqueue_rollout_persistent(mobrob_ppo_engine* e, const mobrob_ppo_engine::Ro
   a.kind = sp.kind; a.env_seed = env_seed_of(e); a.step_base = e->ctr_dev + 1;
   a.p_term = sp.p_term; a.time_limit = sp.time_limit; a.goal = sp.goal;
   a.bt = BootArgs{Pp(e, T_VW1), Pp(e, T_VB1), Pp(e, T_VW2), Pp(e, T_VB2), Pp(e, T_VW), Pp(e, T_VB), e->G1, e->G2,
-                  (float)e->cfg.gamma, e->term_val, 0};  // (fused path: tanh networks only)
+                  (float)e->cfg.gamma, e->term_val};  // (fused path: two tanh layers)
   a.N = N; a.D = e->D; a.A = e->A;
   a.obs = e->obs; a.actions = e->actions; a.logp = e->logp; a.rewards = e->rewards; a.es = e->es;
   a.term_obs = e->term_obs; a.trunc = e->trunc_dev; a.clip_act = e->clip_act;
@@ -1643,8 +1654,8 @@ int enqueue_rollout(mobrob_ppo_engine* e, const mobrob_ppo_engine::RolloutSpec& 
   const uint64_t env_seed = env_seed_of(e);
   // the previous rollout's last observation is this rollout's first
   HIPC(hipMemcpyAsync(e->obs, e->obs + (size_t)e->T * slot, slot * 4, hipMemcpyDeviceToDevice, e->stream));
-  const BootArgs bt = boot_args(e);
-  const size_t sm = env_step_lds_bytes(Dp, e->Hv[0], e->Hv[1], e->Hv[2]);
+  const BootNetArgs bt = boot_args(e);
+  const size_t sm = env_step_lds_bytes(Dp, value_net_width_sum(e));
   for (int t = 0; t < e->T; ++t) {
     act_slot(e, t, nullptr, true);
     {
@@ -1829,7 +1840,7 @@ int collect_host_served(mobrob_ppo_engine* e, mobrob_env_step_range_fn step_rang
   a.lo = (float)e->cfg.action_low; a.hi = (float)e->cfg.action_high;
   a.kind = 3; a.env_seed = 0; a.step_base = nullptr;
   a.bt = BootArgs{Pp(e, T_VW1), Pp(e, T_VB1), Pp(e, T_VW2), Pp(e, T_VB2), Pp(e, T_VW), Pp(e, T_VB), e->G1, e->G2,
-                  (float)e->cfg.gamma, e->term_val, 0};
+                  (float)e->cfg.gamma, e->term_val};
   a.N = N; a.D = e->D; a.A = e->A;
   a.obs = e->obs; a.actions = e->actions; a.logp = e->logp; a.rewards = e->rewards; a.es = e->es;
   a.term_obs = e->term_obs; a.trunc = e->trunc_dev; a.clip_act = actions_clipped;   // (the caller's pinned buffer)

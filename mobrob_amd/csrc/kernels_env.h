@@ -188,13 +188,11 @@ __global__ __launch_bounds__(256) void k_goal_env_reset(uint64_t seed, int N, in
 }
 
 // env.step(clipped actions) + VecEnv auto-reset + rollout_buffer.add scalars + time-limit bootstrap, one launch
-__global__ __launch_bounds__(256) void k_goal_env_step_store(GoalEnvArgs a, BootArgs bt) {
-  extern __shared__ float sm[];  // x[Dp] | h1[G1] | h2[G2] | h3[G3] | red[16] | cnt[4] | env[kBootMaxEnvs] | rew[kBootMaxEnvs]
+__global__ __launch_bounds__(256) void k_goal_env_step_store(GoalEnvArgs a, BootNetArgs bt) {
+  extern __shared__ float sm[];  // x[Dp] | activations[width_sum] | red[16] | cnt[4] | env[kBootMaxEnvs] | rew[kBootMaxEnvs]
   float* x = sm;
-  float* h1 = x + a.Dp;
-  float* h2 = h1 + bt.G1;
-  float* h3 = h2 + bt.G2;
-  float* red = h3 + bt.G3;
+  float* hbuf = x + a.Dp;
+  float* red = hbuf + bt.vn.width_sum;
   int* cnt = reinterpret_cast<int*>(red + 16);
   int* lenv = cnt + 4;
   float* lrew = reinterpret_cast<float*>(lenv + kBootMaxEnvs);
@@ -256,7 +254,7 @@ __global__ __launch_bounds__(256) void k_goal_env_step_store(GoalEnvArgs a, Boot
       for (int j = 0; j < 4; ++j) x[4 * c + j] = ob[j];
     }
     __syncthreads();
-    const float v = value_row_lds(x, h1, h2, red, bt.W1, bt.b1, bt.W2, bt.b2, bt.Wv, bt.bv, a.D, bt.G1, bt.G2, bt.relu, bt.W3, bt.b3, bt.G3, h3);
+    const float v = value_net_row(x, hbuf, red, bt.vn, a.D);
     if (threadIdx.x == 0) {
       bt.term_val[n] = v;
       a.rew_out[n] = (float)((double)lrew[q] + (double)__fmul_rn(bt.gamma, v));

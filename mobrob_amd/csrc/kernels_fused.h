@@ -2132,17 +2132,18 @@ __global__ __launch_bounds__(256) void k_sqnorm_chunks(const float* __restrict__
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
-// tensors of a policy: log_std, (W, b) of one to three hidden layers per network, the two heads (engine.hip keeps the table)
-constexpr int kMaxHidden = 3;
-constexpr int kMaxTensors = 1 + 4 * kMaxHidden + 4;   // 17
+// tensors of a policy: log_std, (W, b) of one to kMaxHidden (device_utils.h) hidden layers per network, the two heads (engine.hip
+// keeps the table).  kFusedTensors: what at most three layers per network make -- the range the per-element search below unrolls.
+constexpr int kMaxTensors = 1 + 4 * kMaxHidden + 4;   // 37
+constexpr int kFusedTensors = 17;
 struct AdamPackArgs {
   float* p; const float* g; float* m; float* v; int P;
   float* g_out;  // the same vector, writable (persistent small-batch kernel: it produces the gradient itself)
   const NormChunk* chunks; const double* partial; int nchunks;
   const int* fold_idx; int fold_start[kMaxTensors + 1];  // non-null: `partial` is a record table; tensor t folds partial[fold_idx[k]], k in [fold_start[t], fold_start[t+1])
   float max_norm, step_size, bc2_sqrt, beta1, beta2, eps;
-  int offs[kMaxTensors + 1];    // canonical offsets of the engine's ntens tensors (9 .. 17: one to three hidden layers per network), padded with P
-  int ntens;       // 9 .. 17
+  int offs[kMaxTensors + 1];    // canonical offsets of the engine's ntens tensors (9 .. 37: one to eight hidden layers per network), padded with P
+  int ntens;       // 9 .. 37
   int two_by_two;  // two hidden layers in BOTH networks: tensor numbering 0 .. 12, the one the fused cases below are written for
                    // (1 + 3 layers also make thirteen tensors)
   int id_pw1, id_vw1, id_aw, id_vw;   // tensors with a zero-padded compute copy (first-layer weights, heads), whatever the depth
@@ -2239,7 +2240,9 @@ __device__ __forceinline__ void adam_pack_apply(const TA& a, int i, float graw, 
   const float pn = __fmaf_rn(-step_size, __fdiv_rn(m, denom), p0);
   int t = 0;
 #pragma unroll
-  for (int k = 1; k < kMaxTensors; ++k) t += (i >= a.offs[k]) ? 1 : 0;   // (offsets beyond the engine's tensors equal P)
+  for (int k = 1; k < kFusedTensors; ++k) t += (i >= a.offs[k]) ? 1 : 0;   // (offsets beyond the engine's tensors equal P)
+  if (a.ntens > kFusedTensors)   // deeper generic networks only (uniform branch)
+    for (int k = kFusedTensors; k < a.ntens; ++k) t += (i >= a.offs[k]) ? 1 : 0;
   const int e = i - a.offs[t];
   // Store policy inside a co-operative launch (COH): agent-scope (write-through, one fabric write per 4-byte store: what the barrier
   // behind this phase waits for) ONLY for what another workgroup reads before the launch ends -- the packs, and the canonical

@@ -8,6 +8,47 @@
 namespace mobrob {
 
 // ------------------------------------------------------------------------------------------------
+// Hidden activations of the generic chain (`policy_kwargs.activation_fn`, SB3 MlpExtractor; the codes are MOBROB_ACT_* of
+// include/mobrob_ppo.h).  Every one of them has a derivative that is a function of its OUTPUT h = f(z), so the backward
+// epilogue needs the stored activations only (no pre-activations are kept):
+//   tanh       1 - h^2                        relu        [h > 0]   (torch threshold_backward: 0 at z = 0)
+//   elu        h > 0 ? 1 : h + 1              leaky_relu  h > 0 ? 1 : 0.01   (torch: slope where z <= 0)
+//   sigmoid    h (1 - h)                      softplus    1 - exp(-h)        (= sigmoid(z); torch beta 1, linear above 20)
+//   softsign   (1 - |h|)^2                    hardtanh    [-1 < h < 1]
+//   relu6      [0 < h < 6]
+// (SiLU / GELU / Mish are not monotonic: their derivative is not a function of h; refused by name at the API.)
+// ------------------------------------------------------------------------------------------------
+enum { ACT_TANH = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_LEAKY_RELU = 3, ACT_SIGMOID = 4, ACT_SOFTPLUS = 5, ACT_SOFTSIGN = 6,
+       ACT_HARDTANH = 7, ACT_RELU6 = 8, ACT_COUNT = 9 };
+__device__ __forceinline__ float act_fwd(int act, float z) {
+  switch (act) {
+    case ACT_TANH: return tanhf(z);
+    case ACT_RELU: return fmaxf(z, 0.f);
+    case ACT_ELU: return z > 0.f ? z : expm1f(z);
+    case ACT_LEAKY_RELU: return z > 0.f ? z : 0.01f * z;
+    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-z));
+    case ACT_SOFTPLUS: return z > 20.f ? z : log1pf(expf(z));
+    case ACT_SOFTSIGN: return z / (1.0f + fabsf(z));
+    case ACT_HARDTANH: return fminf(fmaxf(z, -1.f), 1.f);
+    default: return fminf(fmaxf(z, 0.f), 6.f);   // ACT_RELU6
+  }
+}
+// g * f'(z) from h = f(z)
+__device__ __forceinline__ float act_bwd(int act, float h, float g) {
+  switch (act) {
+    case ACT_TANH: return g * (1.0f - h * h);
+    case ACT_RELU: return h > 0.f ? g : 0.f;
+    case ACT_ELU: return h > 0.f ? g : g * (h + 1.0f);
+    case ACT_LEAKY_RELU: return h > 0.f ? g : 0.01f * g;
+    case ACT_SIGMOID: return g * (h * (1.0f - h));
+    case ACT_SOFTPLUS: return g * (1.0f - expf(-h));
+    case ACT_SOFTSIGN: { const float u = 1.0f - fabsf(h); return g * (u * u); }
+    case ACT_HARDTANH: return (h > -1.f && h < 1.f) ? g : 0.f;
+    default: return (h > 0.f && h < 6.f) ? g : 0.f;   // ACT_RELU6
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // MFMA GEMM, one 32x32 output tile per wave, 4 waves per block stacked along M.
 //   MODE_NT: C[m][n] = sum_k A[m][k] * B[n][k]      (forward:  X . W^T)        K % 8 == 0
 //   MODE_NN: C[m][n] = sum_k A[m][k] * B[k][n]      (backward: dY . W)         K % 8 == 0
@@ -30,7 +71,7 @@ struct GemmArgs {
   const float* Hact;    // EPI_DTANH_COLSUM: activation h (same shape as C), ld = ldh
   int ldh;
   float* colsum;        // EPI_DTANH_COLSUM: [N] += column sums of the stored tile (bias gradient)
-  int relu;             // hidden activation: 0 tanh (SB3's default for MlpPolicy), 1 ReLU (policy_kwargs activation_fn=nn.ReLU)
+  int act;              // hidden activation (ACT_*): tanh is SB3's default for MlpPolicy; the others come from policy_kwargs activation_fn
   int kchunk;           // MODE_TN: batch rows per blockIdx.z
 };
 
@@ -104,10 +145,10 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
       if (EPI == EPI_BIAS) {
         g.C[(size_t)row * g.ldc + col] = v + bias;
       } else if (EPI == EPI_BIAS_TANH) {
-        g.C[(size_t)row * g.ldc + col] = g.relu ? fmaxf(v + bias, 0.f) : tanhf(v + bias);
+        g.C[(size_t)row * g.ldc + col] = act_fwd(g.act, v + bias);
       } else if (EPI == EPI_DTANH_COLSUM) {
         const float hv = g.Hact[(size_t)row * g.ldh + col];
-        v = g.relu ? (hv > 0.f ? v : 0.f) : v * (1.0f - hv * hv);  // relu'(z) = [z > 0] = [h > 0] (torch: 0 at z = 0)
+        v = act_bwd(g.act, hv, v);
         g.C[(size_t)row * g.ldc + col] = v;
         csum += v;
       } else {
@@ -231,66 +272,77 @@ __global__ void k_u8_to_f32(const uint8_t* __restrict__ in, float* __restrict__ 
 // Value of flagged rows only (time-limit bootstrap is rare: one block per env, exits unless flagged).
 // V(x) = Wv . tanh(W2 tanh(W1 x + b1) + b2) + bv with the canonical (unpadded) parameter vector.
 // ------------------------------------------------------------------------------------------------
-// x[D] is already in LDS; h1[G1], h2[G2], h3[G3], red[16] are LDS scratch.  Every thread of the block returns V(x).
-// One to three hidden layers (net_arch depths 1 .. 3): a layer exists iff its weight pointer is non-null (W2 == nullptr: one hidden
-// layer; W3 != nullptr: three).  The two-layer callers of the fused paths pass neither W3 nor h3.
+// x[D] is already in LDS; h1[G1], h2[G2], red[16] are LDS scratch.  Every thread of the block returns V(x).
+// Two tanh layers: the form the fused rollout kernels call (their networks are 2 x 64 / 2 x 256 tanh by construction).
 __device__ __forceinline__ float value_row_lds(const float* x, float* h1, float* h2, float* red,
                                                const float* __restrict__ W1, const float* __restrict__ b1,
                                                const float* __restrict__ W2, const float* __restrict__ b2,
                                                const float* __restrict__ Wv, const float* __restrict__ bv, int D, int G1,
-                                               int G2, int relu = 0, const float* __restrict__ W3 = nullptr,
-                                               const float* __restrict__ b3 = nullptr, int G3 = 0, float* h3 = nullptr) {
+                                               int G2) {
   for (int j = threadIdx.x; j < G1; j += blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < D; ++k) s = fmaf(x[k], W1[(size_t)j * D + k], s);
-    h1[j] = relu ? fmaxf(s + b1[j], 0.f) : tanhf(s + b1[j]);
+    h1[j] = tanhf(s + b1[j]);
   }
   __syncthreads();
-  const float* last = h1;
-  int GL = G1;
-  if (W2 != nullptr) {
-    for (int j = threadIdx.x; j < G2; j += blockDim.x) {
-      float s = 0.f;
-      for (int k = 0; k < G1; ++k) s = fmaf(h1[k], W2[(size_t)j * G1 + k], s);
-      h2[j] = relu ? fmaxf(s + b2[j], 0.f) : tanhf(s + b2[j]);
-    }
-    __syncthreads();
-    last = h2; GL = G2;
-    if (W3 != nullptr) {
-      for (int j = threadIdx.x; j < G3; j += blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < G2; ++k) s = fmaf(h2[k], W3[(size_t)j * G2 + k], s);
-        h3[j] = relu ? fmaxf(s + b3[j], 0.f) : tanhf(s + b3[j]);
-      }
-      __syncthreads();
-      last = h3; GL = G3;
-    }
+  for (int j = threadIdx.x; j < G2; j += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < G1; ++k) s = fmaf(h1[k], W2[(size_t)j * G1 + k], s);
+    h2[j] = tanhf(s + b2[j]);
   }
+  __syncthreads();
   float p = 0.f;
-  for (int k = threadIdx.x; k < GL; k += blockDim.x) p += last[k] * Wv[k];
+  for (int k = threadIdx.x; k < G2; k += blockDim.x) p += h2[k] * Wv[k];
   return block_sum(p, red) + bv[0];
 }
 
-struct ValueNetArgs {  // value network, canonical (unpadded) parameters; layer l exists iff W[l] != nullptr (W[0] always)
-  const float* W[3]; const float* b[3]; const float* Wv; const float* bv;
-  int G[3];
-  int relu;
+// The value network as the per-row evaluators of the generic paths take it: canonical (unpadded) parameters, `L` hidden layers
+// (1 .. kMaxHidden) of widths G[l], activation `act` (ACT_*).
+struct ValueNetArgs {
+  const float* W[kMaxHidden]; const float* b[kMaxHidden]; const float* Wv; const float* bv;
+  int G[kMaxHidden];
+  int L, act;
+  int width_sum;   // G[0] + ... + G[L - 1]: floats of LDS scratch value_net_row needs for the activations
 };
+// x[D] in LDS; hbuf[width_sum], red[16] LDS scratch.  Every thread of the block returns V(x).  Same per-unit fma chains as the
+// two-layer form above.  (The layer loop is unrolled with static indices: a runtime-indexed by-value argument struct would be
+// copied to scratch memory.)
+__device__ __forceinline__ float value_net_row(const float* x, float* hbuf, float* red, const ValueNetArgs& vn, int D) {
+  const float* in = x;
+  int K = D;
+  float* out = hbuf;
+#pragma unroll
+  for (int l = 0; l < kMaxHidden; ++l) {
+    if (l < vn.L) {
+      const float* __restrict__ W = vn.W[l];
+      const float* __restrict__ bb = vn.b[l];
+      const int G = vn.G[l];
+      for (int j = threadIdx.x; j < G; j += blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s = fmaf(in[k], W[(size_t)j * K + k], s);
+        out[j] = act_fwd(vn.act, s + bb[j]);
+      }
+      __syncthreads();
+      in = out; K = G; out += G;
+    }
+  }
+  float p = 0.f;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) p += in[k] * vn.Wv[k];
+  return block_sum(p, red) + vn.bv[0];
+}
+
 __global__ __launch_bounds__(256) void k_value_flagged(const float* __restrict__ obs, int ldo,
                                                        const uint8_t* __restrict__ flags, ValueNetArgs vn, int D,
                                                        float* __restrict__ out, float* __restrict__ rew_inout, float gamma) {
   const int row = blockIdx.x;
   if (!flags[row]) return;
-  extern __shared__ float sm[];  // x[D] | h1[G1] | h2[G2] | h3[G3] | red[16]
+  extern __shared__ float sm[];  // x[D] | activations[width_sum] | red[16]
   float* x = sm;
-  float* h1 = x + D;
-  float* h2 = h1 + vn.G[0];
-  float* h3 = h2 + vn.G[1];
-  float* red = h3 + vn.G[2];
+  float* hbuf = x + D;
+  float* red = hbuf + vn.width_sum;
   for (int i = threadIdx.x; i < D; i += blockDim.x) x[i] = obs[(size_t)row * ldo + i];
   __syncthreads();
-  const float v = value_row_lds(x, h1, h2, red, vn.W[0], vn.b[0], vn.W[1], vn.b[1], vn.Wv, vn.bv, D, vn.G[0], vn.G[1], vn.relu,
-                                vn.W[2], vn.b[2], vn.G[2], h3);
+  const float v = value_net_row(x, hbuf, red, vn, D);
   if (threadIdx.x == 0) {
     out[row] = v;
     if (rew_inout != nullptr)  // rewards[idx] += gamma * V(terminal_obs)  [oracle bootstrap_reward]
@@ -317,12 +369,10 @@ struct StorePullArgs {
   const float* next_obs; float* obs_slot;  // null: no pull
 };
 __global__ __launch_bounds__(256) void k_store_pull_part(StorePullArgs a) {
-  extern __shared__ float sm[];  // x[D] | h1[G1] | h2[G2] | h3[G3] | red[16] | tv[16]
+  extern __shared__ float sm[];  // x[D] | activations[width_sum] | red[16] | tv[16]
   float* x = sm;
-  float* h1 = x + a.D;
-  float* h2 = h1 + a.vn.G[0];
-  float* h3 = h2 + a.vn.G[1];
-  float* red = h3 + a.vn.G[2];
+  float* hbuf = x + a.D;
+  float* red = hbuf + a.vn.width_sum;
   float* tv = red + 16;
   const int i0 = blockIdx.x * kPartRows, tid = threadIdx.x;
   if (a.trunc != nullptr) {
@@ -331,8 +381,7 @@ __global__ __launch_bounds__(256) void k_store_pull_part(StorePullArgs a) {
       if (i >= a.n || !a.trunc[i]) continue;  // block-uniform
       for (int k = tid; k < a.D; k += blockDim.x) x[k] = a.term_obs[(size_t)i * a.D + k];
       __syncthreads();
-      const float v = value_row_lds(x, h1, h2, red, a.vn.W[0], a.vn.b[0], a.vn.W[1], a.vn.b[1], a.vn.Wv, a.vn.bv, a.D, a.vn.G[0],
-                                    a.vn.G[1], a.vn.relu, a.vn.W[2], a.vn.b[2], a.vn.G[2], h3);
+      const float v = value_net_row(x, hbuf, red, a.vn, a.D);
       if (tid == 0) tv[r] = v;
       __syncthreads();
     }
@@ -779,17 +828,19 @@ __global__ void k_entropy_grad(float* g_log_std, int A, float ent_coef, float b_
 __global__ void k_add_counters(uint32_t* ctr, uint32_t d0, uint32_t d1) {
   if (threadIdx.x == 0 && blockIdx.x == 0) { ctr[0] += d0; ctr[1] += d1; }
 }
-struct BootArgs {  // value network (canonical parameters) for the in-kernel time-limit bootstrap
-  const float *W1, *b1, *W2, *b2, *Wv, *bv;   // W2 == nullptr: one hidden layer (G2 = 0)
+struct BootArgs {  // value network (canonical parameters, two tanh layers) for the in-kernel time-limit bootstrap of the fused rollout kernels
+  const float *W1, *b1, *W2, *b2, *Wv, *bv;
   int G1, G2;
   float gamma;
   float* term_val;  // [N] V(terminal_obs) of truncated rows (diagnostics / tests)
-  int relu;         // hidden activation of the value network (0 tanh, 1 ReLU)
-  const float *W3 = nullptr, *b3 = nullptr;   // third hidden layer (generic paths only; the fused kernels are two-layer)
-  int G3 = 0;
+};
+struct BootNetArgs {  // the same for the per-step kernels of the generic path: any depth, any activation
+  ValueNetArgs vn;
+  float gamma;
+  float* term_val;
 };
 constexpr int kBootMaxEnvs = 72;  // envs whose chunk-0 thread can live in one 256-thread block (Dp >= 16: <= 65)
-inline size_t env_step_lds_bytes(int Dp, int G1, int G2, int G3 = 0) { return (size_t)(Dp + G1 + G2 + G3 + 16 + 4 + 2 * kBootMaxEnvs) * 4; }
+inline size_t env_step_lds_bytes(int Dp, int width_sum) { return (size_t)(Dp + width_sum + 16 + 4 + 2 * kBootMaxEnvs) * 4; }
 
 // Time-limit truncation is rare (one row in `time_limit`), so the bootstrap  r += gamma * V(terminal_obs)  [oracle
 // bootstrap_reward] runs in the same launch: the block that owns chunk 0 of a truncated env re-draws its terminal
@@ -800,13 +851,11 @@ __global__ __launch_bounds__(256) void k_env_step_store(uint64_t seed, uint32_t 
                                  float* __restrict__ obs_next, float* __restrict__ term_obs,
                                  const float* __restrict__ prev_dones, float* __restrict__ next_dones,
                                  uint8_t* __restrict__ trunc, float* __restrict__ rew_out, float* __restrict__ es_out,
-                                 BootArgs bt) {
-  extern __shared__ float sm[];  // x[Dp] | h1[G1] | h2[G2] | h3[G3] | red[16] | cnt[4] | env[kBootMaxEnvs] | rew[kBootMaxEnvs]
+                                 BootNetArgs bt) {
+  extern __shared__ float sm[];  // x[Dp] | activations[width_sum] | red[16] | cnt[4] | env[kBootMaxEnvs] | rew[kBootMaxEnvs]
   float* x = sm;
-  float* h1 = x + Dp;
-  float* h2 = h1 + bt.G1;
-  float* h3 = h2 + bt.G2;
-  float* red = h3 + bt.G3;
+  float* hbuf = x + Dp;
+  float* red = hbuf + bt.vn.width_sum;
   int* cnt = reinterpret_cast<int*>(red + 16);
   int* lenv = cnt + 4;
   float* lrew = reinterpret_cast<float*>(lenv + kBootMaxEnvs);
@@ -864,7 +913,7 @@ __global__ __launch_bounds__(256) void k_env_step_store(uint64_t seed, uint32_t 
       for (int j = 0; j < 4; ++j) x[4 * c + j] = (4 * c + j < D) ? z[j] : 0.f;
     }
     __syncthreads();
-    const float v = value_row_lds(x, h1, h2, red, bt.W1, bt.b1, bt.W2, bt.b2, bt.Wv, bt.bv, D, bt.G1, bt.G2, bt.relu, bt.W3, bt.b3, bt.G3, h3);
+    const float v = value_net_row(x, hbuf, red, bt.vn, D);
     if (threadIdx.x == 0) {
       bt.term_val[n] = v;
       rew_out[n] = (float)((double)lrew[q] + (double)__fmul_rn(bt.gamma, v));

@@ -28,9 +28,33 @@ def _f32c(a, shape=None):
     return a
 
 
+MAX_HIDDEN = 8   # kMaxHidden (csrc/device_utils.h): hidden layers per network
+
+# policy_kwargs `activation_fn`: lower-cased torch.nn class name -> (MOBROB_ACT_* code, torch.nn class name).  The modules whose
+# derivative is a function of their output, with torch's default arguments; tanh / ReLU as in the reference's SB3 defaults.
+ACTIVATIONS = OrderedDict([("tanh", (0, "Tanh")), ("relu", (1, "ReLU")), ("elu", (2, "ELU")), ("leakyrelu", (3, "LeakyReLU")),
+                           ("sigmoid", (4, "Sigmoid")), ("softplus", (5, "Softplus")), ("softsign", (6, "Softsign")),
+                           ("hardtanh", (7, "Hardtanh")), ("relu6", (8, "ReLU6"))])
+
+
+def activation_name(act) -> str:
+    """`activation_fn` as a torch.nn class, its name or None (SB3's default, Tanh) -> key of ACTIVATIONS; anything else raises
+    NotImplementedError by name."""
+    if act is None:
+        return "tanh"
+    name = getattr(act, "__name__", None) or str(act)
+    if name.startswith("<class "):   # the readable side of a checkpoint blob: "<class 'torch.nn.modules.activation.ELU'>"
+        name = name.split("'")[1]
+    name = name.rsplit(".", 1)[-1].replace("_", "").lower()
+    if name not in ACTIVATIONS:
+        raise NotImplementedError(f"activation_fn {act!r}: implemented are {', '.join(v[1] for v in ACTIVATIONS.values())} "
+                                  "(modules whose derivative is a function of their output, torch's default arguments)")
+    return name
+
+
 def param_shapes(obs_dim, act_dim, pi, vf):
-    """SB3 `policy.state_dict()` key order and shapes (include/mobrob_ppo.h 'Conventions'); one to three hidden layers per
-    network (`nn.Sequential` indices 0, 2, 4: every Linear is followed by its activation module)."""
+    """SB3 `policy.state_dict()` key order and shapes (include/mobrob_ppo.h 'Conventions'); one to eight hidden layers per
+    network (`nn.Sequential` indices 0, 2, 4 ...: every Linear is followed by its activation module)."""
     s = OrderedDict()
     s["log_std"] = (act_dim,)
     for net, widths in (("policy_net", pi), ("value_net", vf)):
@@ -129,14 +153,16 @@ class PPOEngine:
                     action_low=-1.0, action_high=1.0, seed=0, device_id=0, rank=0, world_size=1, fast_kernels=True,
                     rollout_graph=True, rollout_persistent=True, activation="tanh", forward_x3=True) -> Config:
         """PPO(...) keyword arguments -> `mobrob_ppo_config_t` (SB3 defaults, Appendix A.1)."""
-        if not (1 <= len(pi) <= 3 and 1 <= len(vf) <= 3):
-            raise ValueError("net_arch: one to three hidden layers per network (pi=[h1, ...], vf=[h1, ...])")
+        if not (1 <= len(pi) <= MAX_HIDDEN and 1 <= len(vf) <= MAX_HIDDEN):
+            raise ValueError(f"net_arch: one to {MAX_HIDDEN} hidden layers per network (pi=[h1, ...], vf=[h1, ...])")
         cfg = Config()
         _lib.load().mobrob_ppo_default_config(C.byref(cfg))
         cfg.obs_dim, cfg.act_dim = int(obs_dim), int(act_dim)
-        p3, v3 = (list(map(int, pi)) + [0, 0])[:3], (list(map(int, vf)) + [0, 0])[:3]   # a width of 0 ends the list
-        cfg.pi_hidden[0], cfg.pi_hidden[1], cfg.pi_hidden3 = p3
-        cfg.vf_hidden[0], cfg.vf_hidden[1], cfg.vf_hidden3 = v3
+        pw, vw = (list(map(int, pi)) + [0] * MAX_HIDDEN)[:MAX_HIDDEN], (list(map(int, vf)) + [0] * MAX_HIDDEN)[:MAX_HIDDEN]   # 0 ends the list
+        cfg.pi_hidden[0], cfg.pi_hidden[1], cfg.pi_hidden3 = pw[:3]
+        cfg.vf_hidden[0], cfg.vf_hidden[1], cfg.vf_hidden3 = vw[:3]
+        for i in range(3, MAX_HIDDEN):
+            cfg.pi_hidden_ext[i - 3], cfg.vf_hidden_ext[i - 3] = pw[i], vw[i]
         cfg.n_envs, cfg.n_steps, cfg.batch_size, cfg.n_epochs = int(n_envs), int(n_steps), int(batch_size), int(n_epochs)
         cfg.gamma, cfg.gae_lambda, cfg.clip_range = float(gamma), float(gae_lambda), float(clip_range)
         cfg.ent_coef, cfg.vf_coef, cfg.max_grad_norm = float(ent_coef), float(vf_coef), float(max_grad_norm)
@@ -148,9 +174,7 @@ class PPOEngine:
         cfg.fast_kernels = int(bool(fast_kernels))
         cfg.rollout_graph = int(bool(rollout_graph))
         cfg.rollout_persistent = int(bool(rollout_persistent))
-        if str(activation).lower() not in ("tanh", "relu"):
-            raise ValueError(f"activation {activation!r}: 'tanh' or 'relu'")
-        cfg.activation = 1 if str(activation).lower() == "relu" else 0
+        cfg.activation = ACTIVATIONS[activation_name(activation)][0]
         cfg.forward_x3 = int(bool(forward_x3))
         return cfg
 
@@ -167,8 +191,8 @@ class PPOEngine:
         (mobrob_ppo_create_in_arena; the fleet packs several engines into one allocation this way)."""
         self.lib = _lib.load()
         cfg = self.make_config(obs_dim, act_dim, n_envs, n_steps, **kwargs)
-        pi = tuple(w for w in (cfg.pi_hidden[0], cfg.pi_hidden[1], cfg.pi_hidden3) if w > 0)
-        vf = tuple(w for w in (cfg.vf_hidden[0], cfg.vf_hidden[1], cfg.vf_hidden3) if w > 0)
+        pi = tuple(w for w in (cfg.pi_hidden[0], cfg.pi_hidden[1], cfg.pi_hidden3, *cfg.pi_hidden_ext) if w > 0)
+        vf = tuple(w for w in (cfg.vf_hidden[0], cfg.vf_hidden[1], cfg.vf_hidden3, *cfg.vf_hidden_ext) if w > 0)
         self.cfg = cfg
         self.D, self.A, self.N, self.T = int(obs_dim), int(act_dim), int(n_envs), int(n_steps)
         self.shapes = param_shapes(self.D, self.A, pi, vf)

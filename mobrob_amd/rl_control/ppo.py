@@ -21,7 +21,7 @@ from collections import OrderedDict, deque
 import numpy as np
 
 from ..checkpoint import load_zip, save_zip
-from ..engine import PPOEngine
+from ..engine import MAX_HIDDEN, PPOEngine, activation_name
 from ..envs.vec_env import DeviceGoalVecEnv, DeviceSyntheticVecEnv, HostVecEnv, SyntheticVecEnv, make_vec_env
 from ..envs.native_env import NativeGoalVecEnv
 from ..envs.shm_vec_env import ShmVecEnv
@@ -205,8 +205,10 @@ class PPO:
         #   log_std_init     initial value of the state-independent log standard deviation (default 0.0)
         #   ortho_init       True (default): orthogonal weights with SB3's gains; False: torch's nn.Linear default
         #   optimizer_kwargs Adam's `eps` / `betas` (SB3 passes eps=1e-5 itself); `optimizer_class` must stay Adam
-        #   activation_fn    nn.Tanh (default) or nn.ReLU, as a class or by name; ReLU networks run the generic GEMM chain
-        #                    (the fused kernels' epilogues are tanh)
+        #   activation_fn    nn.Tanh (default), nn.ReLU, nn.ELU, nn.LeakyReLU, nn.Sigmoid, nn.Softplus, nn.Softsign, nn.Hardtanh,
+        #                    nn.ReLU6, as a class or by name; all but tanh run the generic GEMM chain (the fused kernels'
+        #                    epilogues are tanh)
+        #   share_features_extractor  accepted: MlpPolicy's extractor is nn.Flatten (no parameters), shared or not is the same network
         self.log_std_init = float(self.policy_kwargs.get("log_std_init", 0.0))
         self.ortho_init = bool(self.policy_kwargs.get("ortho_init", True))
         opt_kw = dict(self.policy_kwargs.get("optimizer_kwargs") or {})
@@ -215,18 +217,17 @@ class PPO:
         if opt_kw.pop("weight_decay", 0.0) or opt_kw.pop("amsgrad", False) or opt_kw:
             raise NotImplementedError("optimizer_kwargs other than `eps` and `betas` are not supported (Adam without weight "
                                       "decay or amsgrad, SB3's default optimiser)")
-        act = self.policy_kwargs.get("activation_fn")
-        self.activation = "tanh" if act is None else getattr(act, "__name__", str(act)).lower()
-        if self.activation not in ("tanh", "relu"):
-            raise NotImplementedError(f"activation_fn {act!r}: Tanh (SB3's default for MlpPolicy) and ReLU are implemented")
+        self.activation = activation_name(self.policy_kwargs.get("activation_fn"))   # NotImplementedError by name for the others
         oc = self.policy_kwargs.get("optimizer_class")
         if oc is not None and getattr(oc, "__name__", str(oc)) != "Adam":
             raise NotImplementedError(f"optimizer_class {oc!r}: only Adam is implemented")
+        # MlpPolicy's features extractor is nn.Flatten (no parameters): sharing it or not is the same network; `normalize_images`
+        # concerns image spaces only -- both are accepted and travel with the checkpoint
         unknown = set(self.policy_kwargs) - {"net_arch", "log_std_init", "ortho_init", "optimizer_kwargs", "activation_fn",
-                                             "optimizer_class"}
+                                             "optimizer_class", "share_features_extractor", "normalize_images"}
         if unknown:
-            raise NotImplementedError(f"policy_kwargs {sorted(unknown)} are not supported (MlpPolicy, one to three hidden layers "
-                                      "per network)")
+            raise NotImplementedError(f"policy_kwargs {sorted(unknown)} are not supported (MlpPolicy, one to {MAX_HIDDEN} hidden "
+                                      "layers per network)")
         self.num_timesteps = 0
         self._total_timesteps = 0
         self._num_timesteps_at_start = 0
@@ -597,7 +598,8 @@ class PPO:
                  obs_low=None if self.obs_bounds is None else self.obs_bounds[0],
                  obs_high=None if self.obs_bounds is None else self.obs_bounds[1],
                  extra_policy_kwargs={k: (list(v) if isinstance(v, tuple) else v) for k, v in self.policy_kwargs.items()
-                                      if k in ("log_std_init", "ortho_init", "optimizer_kwargs")}
+                                      if k in ("log_std_init", "ortho_init", "optimizer_kwargs", "share_features_extractor",
+                                               "normalize_images")}
                  | ({"activation_fn": self.activation} if self.activation != "tanh" else {}))
 
     @classmethod
@@ -607,7 +609,7 @@ class PPO:
         d, params = ck["data"], ck["params"]
         D = params["mlp_extractor.policy_net.0.weight"].shape[1]
         A = params["log_std"].shape[0]
-        def widths(net):   # hidden widths from the state dict itself (nn.Sequential indices 0, 2, 4: one to three hidden layers)
+        def widths(net):   # hidden widths from the state dict itself (nn.Sequential indices 0, 2, 4 ...)
             out, i = [], 0
             while f"mlp_extractor.{net}.{2 * i}.weight" in params:
                 out.append(params[f"mlp_extractor.{net}.{2 * i}.weight"].shape[0])

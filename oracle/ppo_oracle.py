@@ -158,11 +158,65 @@ def _linear(x, w, b, acc=None):
     return (_mm(x, w.T, acc) + b).astype(F32)
 
 
+ACTIVATIONS = ("tanh", "relu", "elu", "leakyrelu", "sigmoid", "softplus", "softsign", "hardtanh", "relu6")
+
+
 def _activate(z, activation):
-    """`activation_fn` of SB3's MlpExtractor: nn.Tanh (default) or nn.ReLU [torch: relu(z) = max(z, 0)]."""
+    """`activation_fn` of SB3's MlpExtractor (policy_kwargs; stable_baselines3/common/torch_layers.py `create_mlp` puts one module
+    behind every Linear): nn.Tanh (default) or one of the torch.nn modules below with their default arguments
+    [torch/nn/modules/activation.py: ReLU max(z, 0); ELU alpha 1: z > 0 ? z : exp(z) - 1; LeakyReLU negative_slope 0.01;
+    Sigmoid; Softplus beta 1, threshold 20: z > 20 ? z : log(1 + exp(z)); Softsign z / (1 + |z|); Hardtanh clamp(z, -1, 1);
+    ReLU6 clamp(z, 0, 6)]."""
+    z = np.asarray(z, F32)
+    one = F32(1.0)
+    if activation == "tanh":
+        return np.tanh(z).astype(F32)
     if activation == "relu":
         return np.maximum(z, F32(0.0)).astype(F32)
-    return np.tanh(z).astype(F32)
+    if activation == "elu":
+        return np.where(z > 0, z, np.expm1(np.minimum(z, F32(0.0)))).astype(F32)
+    if activation == "leakyrelu":
+        return np.where(z > 0, z, F32(0.01) * z).astype(F32)
+    if activation == "sigmoid":
+        return (one / (one + np.exp(-z))).astype(F32)
+    if activation == "softplus":
+        return np.where(z > F32(20.0), z, np.log1p(np.exp(np.minimum(z, F32(20.0))))).astype(F32)
+    if activation == "softsign":
+        return (z / (one + np.abs(z))).astype(F32)
+    if activation == "hardtanh":
+        return np.clip(z, F32(-1.0), F32(1.0)).astype(F32)
+    if activation == "relu6":
+        return np.clip(z, F32(0.0), F32(6.0)).astype(F32)
+    raise ValueError(f"activation {activation!r}")
+
+
+def _activation_grad(h, g, activation):
+    """g * f'(z) with f'(z) written through the OUTPUT h = f(z) (all nine are monotonic) -- what torch's backward formulas give:
+    tanh_backward g (1 - h^2); threshold_backward g [z > 0]; elu_backward g (z > 0 ? 1 : exp(z) = h + 1); leaky_relu_backward
+    g (z > 0 ? 1 : 0.01); sigmoid_backward g h (1 - h); softplus_backward g sigmoid(z) = g (1 - exp(-h)); softsign: autograd of
+    z / (1 + |z|) = g / (1 + |z|)^2 = g (1 - |h|)^2; hardtanh_backward g [-1 < z < 1]; relu6 = hardtanh(0, 6): g [0 < z < 6]."""
+    h, g = np.asarray(h, F32), np.asarray(g, F32)
+    one = F32(1.0)
+    if activation == "tanh":
+        return (g * (one - h * h)).astype(F32)
+    if activation == "relu":
+        return (g * (h > 0)).astype(F32)
+    if activation == "elu":
+        return np.where(h > 0, g, g * (h + one)).astype(F32)
+    if activation == "leakyrelu":
+        return np.where(h > 0, g, F32(0.01) * g).astype(F32)
+    if activation == "sigmoid":
+        return (g * (h * (one - h))).astype(F32)
+    if activation == "softplus":
+        return (g * (one - np.exp(-h))).astype(F32)
+    if activation == "softsign":
+        u = one - np.abs(h)
+        return (g * (u * u)).astype(F32)
+    if activation == "hardtanh":
+        return (g * ((h > -1) & (h < 1))).astype(F32)
+    if activation == "relu6":
+        return (g * ((h > 0) & (h < 6))).astype(F32)
+    raise ValueError(f"activation {activation!r}")
 
 
 def mlp_latents(p, obs, acc=None, activation="tanh"):
@@ -202,11 +256,11 @@ def gaussian_entropy(log_std, n):
     return np.full((n,), ent.sum(dtype=F32), F32)
 
 
-def act(p, obs, eps, low=-1.0, high=1.0):
+def act(p, obs, eps, low=-1.0, high=1.0, activation="tanh"):
     """One rollout-time policy call [SB3 OnPolicyAlgorithm.collect_rollouts -> policy.forward].
     eps ~ N(0, I) is an INPUT (torch's CPU normal_ stream cannot be reproduced elsewhere).
     Returns raw actions (stored in the buffer), clipped actions (sent to the env), values, log-probs."""
-    mean, value = policy_outputs(p, obs)
+    mean, value = policy_outputs(p, obs, activation=activation)
     std = np.exp(p["log_std"].astype(F32)).astype(F32)
     actions = (mean + np.asarray(eps, F32) * std).astype(F32)  # Normal.rsample
     logp = gaussian_log_prob(mean, p["log_std"], actions)
@@ -214,12 +268,12 @@ def act(p, obs, eps, low=-1.0, high=1.0):
     return actions, clipped, value, logp
 
 
-def predict(p, obs, deterministic=True, eps=None, low=-1.0, high=1.0):
+def predict(p, obs, deterministic=True, eps=None, low=-1.0, high=1.0, activation="tanh"):
     """[SB3 BasePolicy.predict] deterministic -> mean; result clipped to the Box (Appendix A.10)."""
     obs = np.asarray(obs)
     single = obs.ndim == 1
     x = obs[None] if single else obs
-    mean, _ = policy_outputs(p, x)
+    mean, _ = policy_outputs(p, x, activation=activation)
     if deterministic:
         a = mean
     else:
@@ -228,8 +282,8 @@ def predict(p, obs, deterministic=True, eps=None, low=-1.0, high=1.0):
     return a[0] if single else a
 
 
-def predict_values(p, obs):
-    return policy_outputs(p, obs)[1]
+def predict_values(p, obs, activation="tanh"):
+    return policy_outputs(p, obs, activation=activation)[1]
 
 
 # --------------------------------------------------------------------------------------
@@ -343,7 +397,7 @@ class Hyper:
     batch_size: int = 64
     clip_range_vf: float | None = None   # SB3 default None: no value-function clipping
     target_kl: float | None = None       # SB3 default None: no early stop
-    activation: str = "tanh"             # policy_kwargs activation_fn: "tanh" (SB3's MlpPolicy default) or "relu"
+    activation: str = "tanh"             # policy_kwargs activation_fn: "tanh" (SB3's MlpPolicy default) or another of ACTIVATIONS
 
 
 def normalize_advantages(adv, acc=None):
@@ -437,10 +491,7 @@ def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, return
         layers = _net_layers(p, prefix)
         for li in reversed(range(len(layers))):
             w, _ = layers[li]
-            if h.activation == "relu":   # torch's threshold_backward: the gradient passes where the input was > 0
-                g_z = (g_h * (acts[li + 1] > 0)).astype(F32)
-            else:
-                g_z = (g_h * (F32(1.0) - acts[li + 1] * acts[li + 1])).astype(F32)
+            g_z = _activation_grad(acts[li + 1], g_h, h.activation)
             grads[f"{prefix}.{2 * li}.weight"] = _mm(g_z.T, acts[li], acc)
             grads[f"{prefix}.{2 * li}.bias"] = _colsum(g_z, acc)
             g_h = _mm(g_z, w, acc)
@@ -621,11 +672,11 @@ def collect_rollout(p, env, last_obs, last_episode_starts, T, h: Hyper, eps_sour
                episode_starts=np.zeros((T, N), F32), values=np.zeros((T, N), F32), log_probs=np.zeros((T, N), F32))
     dones = np.zeros(N, bool)
     for t in range(T):
-        actions, clipped, values, logp = act(p, last_obs, eps_source(t))
+        actions, clipped, values, logp = act(p, last_obs, eps_source(t), activation=h.activation)
         new_obs, rewards, dones, trunc, terminal_obs = env.step(clipped)
         rewards = rewards.astype(F32).copy()
         if trunc.any():
-            tv = predict_values(p, terminal_obs[trunc])
+            tv = predict_values(p, terminal_obs[trunc], activation=h.activation)
             rewards[trunc] = np.array([bootstrap_reward(r, h.gamma, v) for r, v in zip(rewards[trunc], tv)], F32)
         buf["obs"][t] = last_obs
         buf["actions"][t] = actions
@@ -634,7 +685,7 @@ def collect_rollout(p, env, last_obs, last_episode_starts, T, h: Hyper, eps_sour
         buf["values"][t] = values
         buf["log_probs"][t] = logp
         last_obs, last_episode_starts = new_obs, dones
-    last_values = predict_values(p, last_obs)
+    last_values = predict_values(p, last_obs, activation=h.activation)
     adv, ret = gae(buf["rewards"], buf["values"], buf["episode_starts"], last_values, dones, h.gamma, h.gae_lambda)
     buf["advantages"], buf["returns"] = adv, ret
     return buf, last_obs, last_episode_starts

@@ -1,0 +1,217 @@
+"""`policy_kwargs` beyond the reference YAMLs' two tanh layers -- the other `activation_fn` modules and `net_arch` depths up to
+eight (SB3 accepts any; the reference splats `ppo_kwargs` into PPO verbatim, /root/reference/src/mobrob/rl_control/ppo.py:58) --
+through the generic GEMM chain, against (i) torch's own modules / autograd / clip_grad_norm_ / optim.Adam
+(tests/golden/arch_cases.npz, made by tests/golden/make_arch_fixture.py) and (ii) the oracle, on every stage of the path:
+act, one optimizer step, the rollout's time-limit bootstrap (per-row value evaluator), a whole train(), PPO(...) + the SB3 zip."""
+import numpy as np
+import pytest
+
+from oracle import ppo_oracle as O
+from tests.util import ARCH_CASES, arch_case, scaled_err, synthetic_rollout
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(D, A, N, T, pi, vf, **kw):
+    from mobrob_amd.engine import PPOEngine
+    return PPOEngine(obs_dim=D, act_dim=A, n_envs=N, n_steps=T, pi=pi, vf=vf, **kw)
+
+
+@pytest.mark.parametrize("name", ARCH_CASES)
+def test_act_and_one_step_match_torch_golden(name):
+    c, act, pi, vf, p, h = arch_case(name)
+    obs, eps = c["fwd/obs"], c["fwd/eps"]
+    N, D, A = obs.shape[0], obs.shape[1], eps.shape[1]
+    e = _engine(D, A, N, 4, pi, vf, batch_size=N, n_epochs=1, activation=act)
+    assert list(e.shapes.keys()) == O.param_keys(len(pi), len(vf))
+    assert e.x3_mode() == 0 or (act == "tanh" and len(pi) == 2 and len(vf) == 2)
+    e.set_params(p)
+    a_raw, a_clip, val, lp = e.act(obs, eps)
+    o_raw, _, o_val, o_lp = O.act(p, obs, eps, activation=act)
+    assert scaled_err(a_raw, c["fwd/actions"]) < 1e-4 and scaled_err(a_raw, o_raw) < 1e-4
+    assert scaled_err(val, c["fwd/value"]) < 1e-4 and scaled_err(val, o_val) < 1e-4
+    assert np.allclose(lp, c["fwd/log_prob"], rtol=1e-4, atol=1e-4) and np.allclose(lp, o_lp, rtol=1e-4, atol=1e-4)
+    assert np.array_equal(a_clip, np.clip(a_raw, -1, 1))
+    assert np.allclose(e.predict(obs, deterministic=True), np.clip(c["fwd/mean"], -1, 1), atol=1e-4)
+    e.close()
+    # one optimizer step on the golden minibatch (injected as a T = B, N = 1 rollout, identity permutation)
+    mb_obs, mb_act = c["mb/obs"], c["mb/actions"]
+    B = mb_obs.shape[0]
+    e = _engine(D, A, 1, B, pi, vf, batch_size=B, n_epochs=1, activation=act, clip_range=h.clip_range, ent_coef=h.ent_coef,
+                vf_coef=h.vf_coef, max_grad_norm=h.max_grad_norm, learning_rate=h.learning_rate, adam_eps=h.adam_eps)
+    e.set_params(p)
+    buf = dict(obs=mb_obs[:, None], actions=mb_act[:, None], rewards=np.zeros((B, 1), np.float32),
+               episode_starts=np.zeros((B, 1), np.float32), values=c["mb/old_values"][:, None],
+               log_probs=c["mb/old_log_prob"][:, None], advantages=c["mb/advantages"][:, None], returns=c["mb/returns"][:, None])
+    e.load_rollout(buf, np.zeros(1, np.float32), np.zeros(1, bool))
+    e.epoch_begin(np.arange(B))
+    e.minibatch_grad(0)
+    grads = e.unflatten(e.read("grads"))
+    for k, v in grads.items():
+        ref = c["step/grad/" + k]
+        assert np.max(np.abs(v - ref)) < 1e-4 * max(1.0, float(np.max(np.abs(ref)))), (k, float(np.max(np.abs(v - ref))))
+    e.minibatch_apply()
+    stats = e.fetch_step_stats()[-1]
+    for i, k in enumerate(["policy_loss", "value_loss", "entropy_loss", "loss", "approx_kl", "clip_fraction", "grad_norm"]):
+        ref = float(c["step/" + k])
+        assert abs(stats[i] - ref) < 1e-4 * max(1.0, abs(ref)), (k, stats[i], ref)
+    newp = e.get_params()
+    m, v, step = e.get_optimizer_state()
+    assert step == 1
+    for k in newp:
+        assert np.max(np.abs(newp[k] - c["step/p/" + k])) < 1e-6 + 1e-5 * float(np.max(np.abs(c["step/p/" + k]))), k
+        assert np.allclose(m[k], c["step/m/" + k], rtol=1e-3, atol=1e-6) and np.allclose(v[k], c["step/v/" + k], rtol=1e-3, atol=1e-8), k
+    e.close()
+
+
+TRAIN_CASES = [("elu", (64, 48), (32, 64)), ("leakyrelu", (32, 32, 32), (64,)), ("sigmoid", (64, 64), (64, 64)),
+               ("softplus", (48,), (48, 24)), ("softsign", (64, 64), (64, 64)), ("hardtanh", (32, 64), (64, 32)),
+               ("relu6", (64, 64), (64, 64)), ("tanh", (32, 32, 24, 24), (32, 24, 32, 24)), ("relu", (24,) * 6, (32, 16, 32, 16, 8)),
+               ("elu", (16,) * 8, (16,) * 8)]
+
+
+@pytest.mark.parametrize("act,pi,vf", TRAIN_CASES)
+def test_train_matches_oracle(act, pi, vf):
+    """PPO.train over two epochs with supplied permutations (short last minibatch): every gradient tensor of the first minibatch,
+    the logged statistics and the parameters after all optimizer steps."""
+    D, A, T, N, B, E = 14, 2, 30, 7, 64, 2
+    rng = np.random.default_rng(11)
+    p = O.init_params(D, A, pi, vf, seed=2)
+    p["log_std"] = rng.normal(-0.3, 0.2, A).astype(np.float32)
+    p["action_net.weight"] *= 30
+    buf, lv, dones = synthetic_rollout(T, N, D, A, seed=5)
+    if act == "relu6":
+        buf["obs"] *= 4
+    mean, val = O.policy_outputs(p, buf["obs"].reshape(T * N, D), activation=act)
+    acts = (mean + rng.standard_normal((T * N, A)).astype(np.float32) * np.exp(p["log_std"])).astype(np.float32)
+    buf["actions"] = acts.reshape(T, N, A)
+    buf["log_probs"] = (O.gaussian_log_prob(mean, p["log_std"], acts) + rng.normal(0, 0.1, T * N)).astype(np.float32).reshape(T, N)
+    buf["values"] = (val + rng.normal(0, 0.1, T * N)).astype(np.float32).reshape(T, N)
+    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=E, batch_size=B, learning_rate=3e-4, activation=act)
+    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, h.gamma, h.gae_lambda)
+    perms = np.stack([rng.permutation(T * N) for _ in range(E)])
+    e = _engine(D, A, N, T, pi, vf, batch_size=B, n_epochs=E, gamma=h.gamma, gae_lambda=h.gae_lambda, ent_coef=h.ent_coef,
+                learning_rate=h.learning_rate, activation=act)
+    e.set_params(p)
+    e.load_rollout(buf, lv, dones)
+    e.compute_gae()
+    assert np.array_equal(e.read("advantages"), buf["advantages"])
+    e.epoch_begin(perms[0])
+    e.minibatch_grad(0)
+    got = e.unflatten(e.read("grads"))
+    _, og, _ = O.loss_and_grads(p, *O.gather_minibatch(buf, perms[0][:B]), h)
+    for k in og:
+        assert scaled_err(got[k], og[k]) < 1e-4, (k, scaled_err(got[k], og[k]))
+    stats = e.train(perms)
+    ostats = O.train(p, O.AdamState.zeros_like(p), buf, h, perms)
+    nmb = -(-T * N // B)
+    assert stats["n_minibatches"] == E * nmb == len(ostats)
+    last = ostats[-nmb:]
+    for k in ["policy_loss", "value_loss", "loss", "approx_kl", "clip_fraction", "grad_norm"]:
+        ref = float(np.mean([float(s[k]) for s in last]))
+        assert abs(stats[k] - ref) < 2e-4 * max(1.0, abs(ref)), (k, stats[k], ref)
+    newp = e.get_params()
+    for k in p:
+        assert np.max(np.abs(newp[k] - p[k])) < 1e-4, (k, float(np.max(np.abs(newp[k] - p[k]))))
+    e.close()
+
+
+@pytest.mark.parametrize("act,pi,vf", [("elu", (32,), (32, 24, 16, 24)), ("softplus", (32, 32), (24,) * 5), ("tanh", (16,) * 4, (16,) * 8)])
+def test_host_rollout_with_bootstrap_matches_oracle(act, pi, vf):
+    """act / store / finish_rollout == oracle collect_rollout on the same env stream; truncated rows' rewards take
+    gamma * V(terminal_obs) from the per-row value evaluator (value_net_row: any depth, any activation)."""
+    D, A, N, T = 14, 2, 6, 12
+    p = O.init_params(D, A, pi, vf, seed=4)
+    p["value_net.bias"] = np.array([3.0], np.float32)
+    rng = np.random.default_rng(0)
+    eps = rng.standard_normal((T, N, A)).astype(np.float32)
+    h = O.Hyper(gamma=0.99, gae_lambda=0.9, activation=act)
+    env_a = O.NumpySyntheticVecEnv(N, D, A, p_term=0.1, time_limit=5, seed=3)
+    obuf, _, _ = O.collect_rollout({k: v.copy() for k, v in p.items()}, env_a, env_a.reset(), np.ones(N, bool), T, h, lambda t: eps[t])
+    e = _engine(D, A, N, T, pi, vf, batch_size=8, n_epochs=1, gamma=h.gamma, gae_lambda=h.gae_lambda, activation=act)
+    e.set_params(p)
+    env_b = O.NumpySyntheticVecEnv(N, D, A, p_term=0.1, time_limit=5, seed=3)
+    obs = env_b.reset()
+    e.rollout_begin()
+    saw_trunc = False
+    for t in range(T):
+        _, a_clip, _, _ = e.act(obs, eps[t])
+        obs, rew, done, trunc, term_obs = env_b.step(a_clip)
+        saw_trunc |= bool(trunc.any())
+        e.store(rew, done, trunc, term_obs)
+    e.finish_rollout(obs, done)
+    assert saw_trunc
+    for k in ["actions", "rewards", "values", "log_probs", "advantages", "returns"]:
+        assert scaled_err(e.read(k), obuf[k]) < 1e-4, k
+    e.close()
+
+
+@pytest.mark.parametrize("act,pi,vf", [("leakyrelu", (32, 24, 16, 8), (32, 24, 16, 8)), ("sigmoid", (32,), (32, 32))])
+@pytest.mark.parametrize("kind", ["synthetic", "goal"])
+def test_device_rollout_bootstrap(act, pi, vf, kind):
+    """Device env sources (per-step kernels of the generic path): truncated rows' rewards carry gamma * V(terminal_obs)."""
+    D, A, N, T, TL = 26, 2, 96, 20, 10
+    p = O.init_params(D, A, pi, vf, seed=2)
+    p["value_net.bias"] = np.array([7.0], np.float32)
+    e = _engine(D, A, N, T, pi, vf, batch_size=480, n_epochs=1, seed=9, activation=act)
+    e.set_params(p)
+    if kind == "synthetic":
+        e.collect_synthetic(p_term=0.0, time_limit=TL)
+    else:
+        e.collect_goal_env(pos_dim=2, mix=np.eye(2, A, dtype=np.float32), time_limit=TL, terminate_on_goal=False)
+    e.synchronize()
+    tr = e.read("truncated").astype(bool)
+    assert tr.any()
+    tobs = e.read("terminal_obs")[:, :D]
+    _, v = O.policy_outputs(p, tobs, activation=act)
+    assert scaled_err(e.read("terminal_values")[tr], v[tr]) < 1e-4
+    obs, acts = e.read("obs")[:T].reshape(T * N, -1)[:, :D], e.read("actions").reshape(T * N, A)
+    mean, val = O.policy_outputs(p, obs, activation=act)
+    assert scaled_err(e.read("values").reshape(-1), val) < 1e-4
+    assert np.allclose(e.read("log_probs").reshape(-1), O.gaussian_log_prob(mean, p["log_std"], acts), rtol=1e-4, atol=1e-3)
+    e.close()
+
+
+@pytest.mark.parametrize("kwargs", [dict(net_arch=[32, 32, 32, 32], activation_fn="ELU"),
+                                    dict(net_arch=dict(pi=[32], vf=[32, 24, 16, 8, 8]), activation_fn="LeakyReLU", share_features_extractor=False),
+                                    dict(net_arch=[64, 64], activation_fn="Softsign", normalize_images=True)])
+def test_ppo_learns_saves_and_loads(kwargs, tmp_path):
+    """PPO(...) with these policy_kwargs (activation classes are given by torch.nn class where torch is importable): learns on the
+    device goal env, writes an SB3-layout zip (state-dict keys in nn.Sequential numbering, policy_kwargs as SB3's one-blob form with
+    the class by reference), loads back bit-identical with the same activation."""
+    import torch
+    from mobrob_amd import checkpoint as ck
+    from mobrob_amd.rl_control.ppo import PPOCtrl, PPO
+    pk = dict(kwargs, activation_fn=getattr(torch.nn, kwargs["activation_fn"]))
+    cfg = {"ppo_kwargs": {"policy": "MlpPolicy", "n_steps": 32, "batch_size": 256, "n_epochs": 2, "policy_kwargs": pk},
+           "env_name": "point", "time_limit": 50, "n_envs": 64, "vec_env_type": "device_goal", "enable_gui": False, "seed": 0}
+    ctrl = PPOCtrl.from_config(cfg)
+    ctrl.ppo.learn(total_timesteps=3 * 32 * 64)
+    path = str(tmp_path / "m.zip")
+    ctrl.ppo.save(path)
+    z = ck.load_zip(path)
+    arch = kwargs["net_arch"]
+    pi = arch["pi"] if isinstance(arch, dict) else arch
+    vf = arch["vf"] if isinstance(arch, dict) else arch
+    assert list(z["params"].keys()) == ck.policy_keys(len(pi), len(vf)) == O.param_keys(len(pi), len(vf))
+    assert z["data"]["policy_kwargs"]["activation_fn"] == kwargs["activation_fn"]
+    for k in ("share_features_extractor", "normalize_images"):
+        if k in kwargs:
+            assert z["data"]["policy_kwargs"][k] == kwargs[k]
+    back = PPO.load(path)
+    assert back.activation == ctrl.ppo.activation == kwargs["activation_fn"].lower() and back.engine.cfg.activation == ctrl.ppo.engine.cfg.activation
+    a, b = ctrl.ppo.engine.get_flat_params(), back.engine.get_flat_params()
+    assert np.array_equal(a, b) and np.isfinite(a).all()
+    assert back.net_arch == (tuple(pi), tuple(vf))
+    obs = np.random.default_rng(0).standard_normal((5, ctrl.ppo.obs_dim)).astype(np.float32)
+    assert np.array_equal(ctrl.ppo.predict(obs, deterministic=True)[0], back.predict(obs, deterministic=True)[0])
+    m, _ = O.policy_outputs(back.engine.get_params(), obs, activation=back.activation)
+    assert np.allclose(back.predict(obs, deterministic=True)[0], np.clip(m, -1, 1), atol=1e-4)
+
+
+def test_unsupported_policy_kwargs_are_refused_by_name():
+    from mobrob_amd.rl_control.ppo import PPO
+    for pk, word in [(dict(activation_fn="SiLU"), "SiLU"), (dict(activation_fn="GELU"), "GELU"), (dict(net_arch=[8] * 9), "hidden"),
+                     (dict(features_extractor_class="NatureCNN"), "features_extractor_class")]:
+        with pytest.raises((NotImplementedError, ValueError), match=word):
+            PPO("MlpPolicy", None, policy_kwargs=pk, _dims=(4, 6, 2))

@@ -34,11 +34,28 @@ def test_config_struct_layout_matches_header():
     lib = _lib.load()
     cfg = _lib.Config()
     lib.mobrob_ppo_default_config(ctypes.byref(cfg))
-    assert (cfg.abi_version, cfg.n_steps, cfg.batch_size, cfg.n_epochs) == (2, 2048, 64, 10)
+    assert (cfg.abi_version, cfg.n_steps, cfg.batch_size, cfg.n_epochs) == (_lib.ABI_VERSION, 2048, 64, 10)
     assert (cfg.gamma, cfg.gae_lambda, cfg.clip_range, cfg.vf_coef, cfg.max_grad_norm) == (0.99, 0.95, 0.2, 0.5, 0.5)
     assert (cfg.learning_rate, cfg.adam_eps, cfg.action_low, cfg.action_high) == (3e-4, 1e-5, -1.0, 1.0)
     assert (cfg.world_size, cfg.fast_kernels, cfg.normalize_advantage) == (1, 1, 1)
     assert list(cfg.pi_hidden) == [64, 64]
+    assert cfg.pi_hidden3 == 0 and list(cfg.pi_hidden_ext) == [0] * 5 and list(cfg.vf_hidden_ext) == [0] * 5
+
+
+def test_config_struct_size_and_offsets_are_the_c_compiler_s(tmp_path):
+    """sizeof / offsetof of mobrob_ppo_config_t as gcc lays the header out == the ctypes mirror (every field, by name)."""
+    import subprocess
+    from mobrob_amd import _lib
+    names = [n for n, _ in _lib.Config._fields_]
+    prog = ('#include <stdio.h>\n#include <stddef.h>\n#include "mobrob_ppo.h"\nint main(void) {\n'
+            '  printf("%zu\\n", sizeof(mobrob_ppo_config_t));\n'
+            + "".join(f'  printf("%zu\\n", offsetof(mobrob_ppo_config_t, {n}));\n' for n in names) + "  return 0;\n}\n")
+    src, exe = tmp_path / "layout.c", tmp_path / "layout"
+    src.write_text(prog)
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(_lib.Config)
+    assert out[1:] == [getattr(_lib.Config, n).offset for n in names]
 
 
 def test_no_device_fails_loudly():

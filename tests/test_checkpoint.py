@@ -264,14 +264,14 @@ def test_zip_of_other_depths_round_trips(pi, vf, tmp_path):
     val.load_state_dict({k.split("value_net.")[1]: t for k, t in sd.items() if ".value_net." in k})
 
 
-def test_config_accepts_one_to_three_hidden_layers_and_nothing_else():
+def test_config_accepts_one_to_eight_hidden_layers_and_nothing_else():
     """Host-only sizing pass (mobrob_ppo_device_bytes runs check_cfg without touching a device)."""
     from mobrob_amd.engine import PPOEngine
     base = dict(obs_dim=14, act_dim=2, n_envs=8, n_steps=16, batch_size=32)
-    sizes = {arch: PPOEngine.device_bytes(pi=arch, vf=arch, **base) for arch in [(64,), (64, 64), (64, 64, 64)]}
-    assert all(v > 0 for v in sizes.values()) and sizes[(64,)] < sizes[(64, 64, 64)]   # (both on the generic chain; two layers: fused kernels)
-    assert PPOEngine.device_bytes(pi=(40,), vf=(64, 32, 16), **base) > 0
-    for bad in [(), (64, 64, 64, 64)]:
+    sizes = {arch: PPOEngine.device_bytes(pi=arch, vf=arch, **base) for arch in [(64,), (64, 64), (64, 64, 64), (64,) * 5, (64,) * 8]}
+    assert all(v > 0 for v in sizes.values()) and sizes[(64,)] < sizes[(64, 64, 64)] < sizes[(64,) * 5] < sizes[(64,) * 8]   # (generic chain; two layers: fused kernels)
+    assert PPOEngine.device_bytes(pi=(40,), vf=(64, 32, 16, 8, 24), **base) > 0
+    for bad in [(), (64,) * 9]:
         with pytest.raises(ValueError):
             PPOEngine.device_bytes(pi=bad, vf=(64, 64), **base)
     with pytest.raises(Exception, match="multiples of 8"):
@@ -282,3 +282,10 @@ def test_config_accepts_one_to_three_hidden_layers_and_nothing_else():
     import ctypes as C
     n = C.c_size_t(0)
     assert _lib.load().mobrob_ppo_device_bytes(C.byref(cfg), C.byref(n)) != 0
+    cfg = PPOEngine.make_config(pi=(64, 64, 64), vf=(64, 64), **base)
+    cfg.pi_hidden_ext[1] = 64                                      # a hole behind the third layer
+    assert _lib.load().mobrob_ppo_device_bytes(C.byref(cfg), C.byref(n)) != 0
+    for act in ("tanh", "ReLU", "elu", "leaky_relu", "Sigmoid", "softplus", "softsign", "hardtanh", "relu6"):
+        assert PPOEngine.device_bytes(pi=(64, 64), vf=(64, 64), activation=act, **base) > 0
+    with pytest.raises(NotImplementedError, match="SiLU|silu"):
+        PPOEngine.make_config(pi=(64, 64), vf=(64, 64), activation="SiLU", **base)

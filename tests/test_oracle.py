@@ -302,3 +302,35 @@ def test_learn_loop_counters_equal_the_reference_checkpoints():
         for k in ("num_timesteps", "_n_updates", "adam_step"):
             assert got[k] == r[k], (env, k, got[k], r[k])
         assert abs(got["_current_progress_remaining"] - r["_current_progress_remaining"]) < 1e-12, (env, got, r)
+
+
+def test_arch_fixture_lists_its_cases():
+    from tests.util import ARCH_CASES, arch_cases
+    assert arch_cases() == ARCH_CASES
+
+
+@pytest.mark.parametrize("name", __import__("tests.util", fromlist=["ARCH_CASES"]).ARCH_CASES)
+def test_other_activations_and_depths_match_torch_golden(name):
+    """`policy_kwargs` beyond the YAMLs' two tanh layers (activation_fn, net_arch depths 1 .. 8; the reference splats ppo_kwargs
+    into PPO, ppo.py:58): the oracle's forward, hand-written backward, clip and Adam against torch's own modules / autograd /
+    clip_grad_norm_ / optim.Adam (tests/golden/make_arch_fixture.py)."""
+    from tests.util import arch_case
+    c, act, pi, vf, p, h = arch_case(name)
+    mean, value = O.policy_outputs(p, c["fwd/obs"], activation=act)
+    assert scaled_err(mean, c["fwd/mean"]) < 1e-5 and scaled_err(value, c["fwd/value"]) < 1e-5
+    actions, _, _, logp = O.act(p, c["fwd/obs"], c["fwd/eps"], activation=act)
+    assert scaled_err(actions, c["fwd/actions"]) < 1e-5 and np.allclose(logp, c["fwd/log_prob"], rtol=1e-5, atol=1e-4)
+    mb = (c["mb/obs"], c["mb/actions"], c["mb/old_values"], c["mb/old_log_prob"], c["mb/advantages"], c["mb/returns"])
+    stats, grads, _ = O.loss_and_grads(p, *mb, h)
+    for k in ["loss", "policy_loss", "value_loss", "entropy_loss", "approx_kl", "clip_fraction"]:
+        assert abs(float(stats[k]) - float(c["step/" + k])) < 1e-5 * max(1.0, abs(float(c["step/" + k]))), k
+    for k, v in grads.items():
+        ref = c["step/grad/" + k]
+        assert v.shape == ref.shape and np.max(np.abs(v - ref)) < 1e-5 * max(1.0, float(np.max(np.abs(ref)))), k
+    clipped, total = O.clip_grad_norm(grads, h.max_grad_norm)
+    assert abs(float(total) - float(c["step/grad_norm"])) < 1e-5 * float(c["step/grad_norm"])
+    st = O.AdamState.zeros_like(p)
+    newp = O.adam_step({k: v.copy() for k, v in p.items()}, clipped, st, h.learning_rate, h.beta1, h.beta2, h.adam_eps)
+    for k in p:
+        assert np.max(np.abs(newp[k] - c["step/p/" + k])) < 1e-6, k
+        assert np.allclose(st.exp_avg[k], c["step/m/" + k], rtol=1e-4, atol=1e-8) and np.allclose(st.exp_avg_sq[k], c["step/v/" + k], rtol=1e-4, atol=1e-11), k

@@ -61,3 +61,33 @@ def synthetic_rollout(T, N, D, A, seed=0, p_done=0.02):
     last_values = rng.standard_normal(N).astype(f)
     dones = rng.random(N) < 0.3
     return buf, last_values, dones
+
+
+# ---- tests/golden/arch_cases.npz (make_arch_fixture.py): other activations and depths through torch's own modules ----
+_ARCH = None
+
+
+def arch_cases():
+    """-> list of case names"""
+    global _ARCH
+    if _ARCH is None:
+        _ARCH = np.load(os.path.join(GOLDEN, "arch_cases.npz"))
+    return [str(c) for c in _ARCH["cases"]]
+
+
+ARCH_CASES = ["act_tanh", "act_relu", "act_elu", "act_leakyrelu", "act_sigmoid", "act_softplus", "act_softsign", "act_hardtanh",
+              "act_relu6", "depth4_tanh", "depth5_3_elu", "depth8_relu", "depth1_6_tanh"]
+
+
+def arch_case(name):
+    """-> (case dict of arrays without the name prefix, activation, pi widths, vf widths, params, Hyper)"""
+    arch_cases()
+    pre = name + "/"
+    c = {k[len(pre):]: _ARCH[k] for k in _ARCH.files if k.startswith(pre)}
+    act, pi, vf = str(c["activation"]), tuple(int(w) for w in c["pi"]), tuple(int(w) for w in c["vf"])
+    keys = O.param_keys(len(pi), len(vf))
+    p = OrderedDict((k, c["p/" + k].astype(np.float32).copy()) for k in keys)
+    lr, clip, ent, vfc, mgn, eps = (float(x) for x in _ARCH["hyper"])
+    h = O.Hyper(clip_range=clip, ent_coef=ent, vf_coef=vfc, max_grad_norm=mgn, learning_rate=lr, adam_eps=eps, activation=act,
+                batch_size=100, n_epochs=1)
+    return c, act, pi, vf, p, h
