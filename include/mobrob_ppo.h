@@ -38,7 +38,7 @@ extern "C" {
 
 /* 2: config slot `persistent_train` became `activation`, `forward_x3` added, MOBROB_K_COUNT 6 -> 7 (profile_read arrays),
  *    MOBROB_BUF_COUNT / reserved[] resized -- a binding built against 1 must not load this library
- * 3: pi_hidden_ext / vf_hidden_ext (net_arch depths 4 .. 8) appended to the config, activation codes 2 .. 8 */
+ * 3: pi_hidden_ext / vf_hidden_ext (net_arch depths 4 .. 8), use_sde, sde_sample_freq appended to the config, activation codes 2 .. 8 */
 #define MOBROB_PPO_ABI_VERSION 3
 /* policy_kwargs.activation_fn (SB3 ActorCriticPolicy; the reference splats ppo_kwargs into PPO verbatim, ppo.py:58): the torch.nn
  * modules whose derivative is a function of their output, with torch's default arguments (ELU alpha 1, LeakyReLU slope 0.01,
@@ -100,6 +100,11 @@ typedef struct mobrob_ppo_config {
   int32_t reserved[1];
   int32_t pi_hidden_ext[5];   /* widths of policy hidden layers 4 .. 8 (a width of 0 ends the list) */
   int32_t vf_hidden_ext[5];   /* likewise for the value network */
+  int32_t use_sde;            /* PPO(use_sde=True): generalised state-dependent exploration (SB3 StateDependentNoiseDistribution with its
+                                 defaults: full_std, no expln, no squashing, learn_features=False).  log_std becomes a [HL][A] matrix (HL =
+                                 width of the last policy hidden layer); generic GEMM chain.  Default 0 */
+  int32_t sde_sample_freq;    /* PPO(sde_sample_freq): new exploration matrices every this many rollout steps (-1: only at the start of a
+                                 rollout, SB3's default) */
 } mobrob_ppo_config_t;
 
 /* Fill `cfg` with SB3 2.0.0 defaults (Appendix A.1).  Replaces PPO.__init__'s default kwargs. */
@@ -411,6 +416,16 @@ int mobrob_ppo_fetch_step_stats(mobrob_ppo_engine_t* e, float* out, int32_t max_
 int mobrob_ppo_predict(mobrob_ppo_engine_t* e, const float* obs, int32_t n, int32_t deterministic,
                        const float* eps /* n*A or NULL */, float* actions_clipped, float* values);
 
+/* ---- gSDE (use_sde = 1) ------------------------------------------------------------------------
+ * policy.reset_noise(n_envs) (SB3 ActorCriticPolicy.reset_noise -> sample_weights): new exploration matrices for every environment
+ * and the single matrix predict() uses for batches of another size, from the CURRENT log_std.  The rollout collectors call it
+ * themselves at the start of a rollout and every sde_sample_freq steps (OnPolicyAlgorithm.collect_rollouts). */
+int mobrob_ppo_sde_reset_noise(mobrob_ppo_engine_t* e);
+/* The exploration matrices as an INPUT (tests, the oracle; like `eps` of mobrob_ppo_act): z = standard normals [n_envs][HL][A] ->
+ * matrices z * exp(log_std), kept until the next call -- the collectors stop resampling on their own.  z = NULL: back to the
+ * engine's own draws. */
+int mobrob_ppo_sde_set_noise(mobrob_ppo_engine_t* e, const float* z);
+
 /* ---- device buffers (tests, DP collectives, profiling) --------------------------------------- */
 enum {
   MOBROB_BUF_OBS = 0,        /* f32 [T+1][N][Dp]  (Dp = D rounded up to 8; slot T = last_obs)     */
@@ -434,7 +449,8 @@ enum {
   MOBROB_BUF_ENV_STATE = 18,       /* f32 [N][12] goal-env state: pos[3] vel[3] goal[3] return length pad         */
   MOBROB_BUF_GRAD_EXCHANGE = 19,   /* f32 [P + 8]: the gradient followed by the eight loss sums of the minibatch (policy, value,
                                       approx_kl, clip fraction, row count, ...) -- what a data-parallel step sums across ranks */
-  MOBROB_BUF_COUNT = 20
+  MOBROB_BUF_SDE_NOISE = 20,       /* f32 [N][HL][A] the environments' gSDE exploration matrices (use_sde engines only)          */
+  MOBROB_BUF_COUNT = 21
 };
 /* Device pointer and size of a buffer.  Asking for the POINTER of ACTIONS / VALUES / LOG_PROBS / ADVANTAGES / RETURNS tells the
  * engine that the caller may write those arrays behind its back: the packed per-row training records the 256-wide gradient

@@ -17,7 +17,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
 BUF = dict(obs=0, actions=1, rewards=2, episode_starts=3, values=4, log_probs=5, advantages=6, returns=7,
            params=8, grads=9, advstat=10, last_values=11, last_dones=12, clipped_actions=13, episode_start_state=14,
-           terminal_obs=15, terminal_values=16, truncated=17, env_state=18, grad_exchange=19)
+           terminal_obs=15, terminal_values=16, truncated=17, env_state=18, grad_exchange=19, sde_noise=20)
 HYPER = dict(learning_rate=0, clip_range=1, clip_range_vf=2, target_kl=3, ent_coef=4, vf_coef=5, epoch_kernel=6)
 KERNEL_IDS = dict(act=0, gae=1, train_grad=2, apply=3, env=4, grad_reduce=5, allreduce=6)
 
@@ -35,6 +35,7 @@ class Config(C.Structure):
         ("rank", C.c_int32), ("world_size", C.c_int32), ("fast_kernels", C.c_int32), ("rollout_graph", C.c_int32), ("rollout_persistent", C.c_int32),
         ("activation", C.c_int32), ("forward_x3", C.c_int32), ("pi_hidden3", C.c_int32), ("vf_hidden3", C.c_int32),
         ("reserved", C.c_int32 * 1), ("pi_hidden_ext", C.c_int32 * 5), ("vf_hidden_ext", C.c_int32 * 5),
+        ("use_sde", C.c_int32), ("sde_sample_freq", C.c_int32),
     ]
 
 
@@ -119,6 +120,8 @@ SYMBOLS = {
     "mobrob_ppo_minibatch_apply_checked": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "mobrob_ppo_fetch_step_stats": (C.c_int, [_P, _F, C.c_int32]),
     "mobrob_ppo_predict": (C.c_int, [_P, _F, C.c_int32, C.c_int32, _F, _F, _F]),
+    "mobrob_ppo_sde_reset_noise": (C.c_int, [_P]),
+    "mobrob_ppo_sde_set_noise": (C.c_int, [_P, _F]),
     "mobrob_ppo_buffer_info": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "mobrob_ppo_read_buffer": (C.c_int, [_P, C.c_int32, _P, C.c_size_t]),
     "mobrob_ppo_write_buffer": (C.c_int, [_P, C.c_int32, _P, C.c_size_t]),

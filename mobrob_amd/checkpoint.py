@@ -320,8 +320,8 @@ def save_zip(path, *, params, optimizer, hyper, obs_dim, act_dim, net_arch=None,
     data["_last_episode_starts"] = _blob("<class 'numpy.ndarray'>", pickle_ndarray(np.asarray(last_episode_starts, bool)))
     data["_last_original_obs"] = None
     data["_episode_num"] = int(counters.get("_episode_num", 0))
-    data["use_sde"] = False
-    data["sde_sample_freq"] = -1
+    data["use_sde"] = bool(hyper.get("use_sde", False))
+    data["sde_sample_freq"] = int(hyper.get("sde_sample_freq", -1))
     data["_current_progress_remaining"] = float(counters.get("_current_progress_remaining", 1.0))
     data["_stats_window_size"] = 100
     buf = collections.deque(ep_info_buffer or [], maxlen=100)

@@ -224,6 +224,10 @@ struct mobrob_ppo_engine {
   float *hp[kMaxHidden] = {nullptr}, *hv[kMaxHidden] = {nullptr}, *mu = nullptr, *vout = nullptr;     // activations per hidden layer
   float *dmu = nullptr, *dv = nullptr, *dzp[kMaxHidden] = {nullptr}, *dzv[kMaxHidden] = {nullptr};     // pre-activation gradients
   float *pred_obs = nullptr, *pred_act = nullptr;
+  // gSDE (use_sde; generic chain only): per-env exploration matrices [N][HL][A], the single matrix [HL][A], staging for supplied noise,
+  // the log_std-gradient GEMM's operands of a minibatch
+  bool sde = false, sde_hold = false;   // hold: the caller supplies the noise (mobrob_ppo_sde_set_noise); no automatic resampling
+  float *sde_E = nullptr, *sde_E1 = nullptr, *sde_lat2 = nullptr, *sde_gsig = nullptr;
   // rollout streamer (host-env path): pinned staging + a side stream for the H2D/D2H copies
   hipStream_t cstream = nullptr;
   hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_store = nullptr;
@@ -456,6 +460,13 @@ void run_gae(mobrob_ppo_engine* e) {
                      e->last_dones, (float)e->cfg.gamma, gl, e->T, e->N, e->adv, e->ret);
 }
 
+// gSDE: new exploration matrices for env rows [r0, r0 + n) (and, with `single`, the one matrix predict() uses for foreign batches)
+void sde_resample(mobrob_ppo_engine* e, int r0, int n, uint32_t draw, const uint32_t* draw_base, bool single) {
+  const int HLA = e->HL * e->A, per = cdiv(HLA, 4);
+  hipLaunchKernelGGL(k_sde_resample, dim3(cdiv((n + (single ? 1 : 0)) * per, 256)), dim3(256), 0, e->stream, Pp(e, T_LOGSTD), HLA, r0, n,
+                     eps_seed(e) ^ 0x5DE5DE5DE5DE5DEull, draw, draw_base, e->sde_E, single ? e->sde_E1 : (float*)nullptr);
+}
+
 // policy forward + sample for rows [r0, r0 + n) of rollout slot t (observations already in the slot).
 // draw = Philox draw index of the step (the whole-step callers pass the running counter and advance it).
 void act_rows(mobrob_ppo_engine* e, int t, int r0, int n, const float* eps_dev_or_null, uint32_t draw,
@@ -476,6 +487,16 @@ void act_rows(mobrob_ppo_engine* e, int t, int r0, int n, const float* eps_dev_o
     return;
   }
   forward(e, X, n, true, e->mu, true, e->values + row);
+  if (e->sde) {
+    // collect_rollouts: reset_noise(n_envs) at the start of a rollout and every sde_sample_freq steps (SB3 on_policy_algorithm.py);
+    // the rows' matrices at this step's draw index (a function of (env, draw), whichever launch draws them)
+    const int freq = e->cfg.sde_sample_freq;
+    if (!e->sde_hold && (t == 0 || (freq > 0 && t % freq == 0))) sde_resample(e, r0, n, draw, draw_base, r0 == 0);
+    hipLaunchKernelGGL(k_sample_sde, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, e->hp[e->Lp - 1], e->HL, Pp(e, T_LOGSTD),
+                       e->sde_E, r0, 0, n, e->HL, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high,
+                       e->actions + row * e->A, clip_out, e->logp + row);
+    return;
+  }
   hipLaunchKernelGGL(k_sample, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, Pp(e, T_LOGSTD),
                      eps_dev_or_null, n, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high, eps_seed(e),
                      draw, draw_base, e->actions + row * e->A, clip_out, e->logp + row, r0);
@@ -495,7 +516,7 @@ int upload_obs(mobrob_ppo_engine* e, const float* host, float* dev_rows, int row
 int fused_init(mobrob_ppo_engine* e) {
   FusedState& f = e->fused;
   // (every fused kernel's epilogue is tanh: ReLU networks run the generic GEMM chain)
-  f.enabled = e->cfg.fast_kernels && e->cfg.activation == MOBROB_ACT_TANH && e->Lp == 2 && e->Lv == 2 &&
+  f.enabled = e->cfg.fast_kernels && e->cfg.activation == MOBROB_ACT_TANH && e->Lp == 2 && e->Lv == 2 && !e->sde &&
               fused_shape_ok(e->D, e->A, e->H1, e->H2, e->G1, e->G2);   // (other depths: generic GEMM chain)
   if (!f.enabled) return MOBROB_OK;
   f.D = e->D; f.Dp = e->Dp; f.A = e->A; f.H = e->H1;
@@ -796,6 +817,7 @@ int check_cfg(const mobrob_ppo_config_t* c) {
   if (c->world_size < 1 || c->rank < 0 || c->rank >= c->world_size) return fail(MOBROB_ERR_INVALID, "bad rank/world_size");
   if (c->batch_size % c->world_size) return fail(MOBROB_ERR_INVALID, "batch_size must be divisible by world_size");
   if ((int64_t)c->n_envs * c->n_steps > (int64_t)1 << 30) return fail(MOBROB_ERR_INVALID, "rollout too large");
+  if (c->use_sde != 0 && c->use_sde != 1) return fail(MOBROB_ERR_INVALID, "use_sde must be 0 or 1");
   if (c->activation < 0 || c->activation >= MOBROB_ACT_COUNT) return fail(MOBROB_ERR_INVALID, "activation must be one of MOBROB_ACT_* (0 .. %d)", MOBROB_ACT_COUNT - 1);
   return MOBROB_OK;
 }
@@ -821,6 +843,7 @@ void mobrob_ppo_default_config(mobrob_ppo_config_t* c) {
   c->rollout_graph = 1;
   c->rollout_persistent = 1;
   c->forward_x3 = 1;
+  c->use_sde = 0; c->sde_sample_freq = -1;
 }
 
 void* mobrob_ppo_host_alloc(size_t bytes) {
@@ -884,7 +907,8 @@ int engine_dims(mobrob_ppo_engine* e, const mobrob_ppo_config_t* cfg) {
   e->rows_max = std::max(e->N, std::min(e->Bl, total));
   int sizes[kMaxTensors] = {0};
   int nt = 0;
-  sizes[nt++] = e->A;                                             // log_std
+  e->sde = cfg->use_sde != 0;
+  sizes[nt++] = e->sde ? e->HL * e->A : e->A;                     // log_std ([A]; gSDE: [HL][A])
   for (int l = 0; l < e->Lp; ++l) { e->tPW[l] = nt; sizes[nt++] = e->Hp[l] * (l ? e->Hp[l - 1] : e->D); e->tPB[l] = nt; sizes[nt++] = e->Hp[l]; }
   for (int l = 0; l < e->Lv; ++l) { e->tVW[l] = nt; sizes[nt++] = e->Hv[l] * (l ? e->Hv[l - 1] : e->D); e->tVB[l] = nt; sizes[nt++] = e->Hv[l]; }
   e->tAW = nt; sizes[nt++] = e->A * e->HL; e->tAB = nt; sizes[nt++] = e->A;
@@ -930,6 +954,10 @@ int engine_alloc(mobrob_ppo_engine* e) {
   for (int l = 0; l < e->Lp; ++l) CHK(dalloc(e, &e->dzp[l], Bl * e->Hp[l]));
   for (int l = 0; l < e->Lv; ++l) CHK(dalloc(e, &e->dzv[l], Bl * e->Hv[l]));
   CHK(dalloc(e, &e->pred_obs, R * Dp)); CHK(dalloc(e, &e->pred_act, R * A));
+  if (e->sde) {
+    CHK(dalloc(e, &e->sde_E, N * (size_t)e->HL * A)); CHK(dalloc(e, &e->sde_E1, (size_t)e->HL * A));
+    CHK(dalloc(e, &e->sde_lat2, Bl * e->HL)); CHK(dalloc(e, &e->sde_gsig, Bl * e->Ap));
+  }
   CHK(dalloc(e, &e->gstate[0], N * kGoalStateFloats)); CHK(dalloc(e, &e->gstate[1], N * kGoalStateFloats));
   CHK(dalloc(e, &e->ep_stats, kEpStatsDoubles));
   CHK(dalloc(e, &e->chunks_dev, e->chunk_table.size()));
@@ -983,6 +1011,7 @@ int engine_create(const mobrob_ppo_config_t* cfg, void* arena, size_t arena_byte
   HIPC(hipMemcpyAsync(e->prev_dones, ones.data(), (size_t)e->N * 4, hipMemcpyHostToDevice, e->stream));
   HIPC(hipStreamSynchronize(e->stream));
   repack(e);
+  if (e->sde) sde_resample(e, 0, e->N, e->draw_counter++, nullptr, true);   // proba_distribution_net samples the first weights at _build
   HIPC(hipStreamSynchronize(e->stream));
   return MOBROB_OK;
 }
@@ -2227,12 +2256,21 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
   L.clip_vf = (float)e->clip_vf; L.old_v = e->oldvg;
   L.ent_coef = (float)e->cfg.ent_coef; L.inv_bg = inv_bg; L.dmu = e->dmu; L.lddmu = e->Ap; L.dv = e->dv; L.lddv = 8;
   L.sums = sums; L.g_log_std = Gp(e, T_LOGSTD); L.g_b_action = Gp(e, T_AB); L.g_b_value = Gp(e, T_VB);
+  if (e->sde) {
+    L.lat = e->hp[e->Lp - 1]; L.HL = e->HL; L.gsig = e->sde_gsig; L.ldg = e->Ap; L.lat2 = e->sde_lat2;
+    HIPC(hipMemsetAsync(e->sde_gsig, 0, (size_t)B * e->Ap * 4, e->stream));
+  }
   // padding columns of dmu/dv must be zero (K padding of the NN GEMM)
   HIPC(hipMemsetAsync(e->dmu, 0, (size_t)B * e->Ap * 4, e->stream));
   HIPC(hipMemsetAsync(e->dv, 0, (size_t)B * 8 * 4, e->stream));
   hipLaunchKernelGGL(k_loss, dim3(cdiv(B, 256)), dim3(256), 0, e->stream, L);
-  hipLaunchKernelGGL(k_entropy_grad, dim3(1), dim3(64), 0, e->stream, Gp(e, T_LOGSTD), e->A, (float)e->cfg.ent_coef,
-                     (float)B, inv_bg);
+  if (e->sde) {   // g_log_std [HL][A] = 2 exp(log_std)^2 * ((latent^2)^T . gsig): the entropy term is inside gsig
+    linear_bwd_weight(e, e->sde_lat2, e->HL, e->sde_gsig, e->Ap, Gp(e, T_LOGSTD), e->A, e->HL, e->A, B);
+    hipLaunchKernelGGL(k_sde_scale_grad, dim3(cdiv(e->HL * e->A, 256)), dim3(256), 0, e->stream, Gp(e, T_LOGSTD), Pp(e, T_LOGSTD), e->HL * e->A);
+  } else {
+    hipLaunchKernelGGL(k_entropy_grad, dim3(1), dim3(64), 0, e->stream, Gp(e, T_LOGSTD), e->A, (float)e->cfg.ent_coef,
+                       (float)B, inv_bg);
+  }
   // backward of both networks, last hidden layer first: dW of the layer above, then dz of this layer (dtanh / dReLU + bias sums)
   auto backward = [&](int L, const int* Hw, float* const* h, float* const* dz, const float* dhead, int ldd, const float* headWp,
                       int head_rows, int head_pad, int t_headW, const int* tW, const int* tB) {
@@ -2301,7 +2339,7 @@ int apply_norms(mobrob_ppo_engine* e, ApplyCtx& c) {
   StatsArgs st{};
   st.stats_row = c.stats_row; st.loss_sums = e->grads + e->P; st.log_std = Pp(e, T_LOGSTD);
   st.ent_coef = (float)e->cfg.ent_coef; st.vf_coef = (float)e->cfg.vf_coef;
-  st.inv_bg = 1.0f / (float)((int64_t)e->cur_count * e->cfg.world_size); st.n_act = e->A;
+  st.inv_bg = 1.0f / (float)((int64_t)e->cur_count * e->cfg.world_size); st.n_act = e->A; st.sde = e->sde;
   c.records = e->use_norm_records && e->fused.enabled;  // the reduction kernel of this step left the norm records
   if (!c.records)
     hipLaunchKernelGGL(k_sqnorm_chunks, dim3(e->nchunks), dim3(256), 0, e->stream, e->grads, e->chunks_dev,
@@ -2376,6 +2414,30 @@ int mobrob_ppo_minibatch_apply_checked(mobrob_ppo_engine_t* e, int32_t* stopped)
   if (!e || !stopped) return fail(MOBROB_ERR_INVALID, "minibatch_apply_checked: null argument");
   if (!e->grad_pending) return fail(MOBROB_ERR_STATE, "minibatch_apply without a pending gradient");
   return apply_checked(e, stopped);
+}
+
+int mobrob_ppo_sde_reset_noise(mobrob_ppo_engine_t* e) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  if (!e->sde) return fail(MOBROB_ERR_STATE, "sde_reset_noise: the engine was not created with use_sde");
+  sde_resample(e, 0, e->N, e->draw_counter++, nullptr, true);
+  HIPC(hipGetLastError());
+  return MOBROB_OK;
+}
+
+int mobrob_ppo_sde_set_noise(mobrob_ppo_engine_t* e, const float* z) {
+  if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
+  if (!e->sde) return fail(MOBROB_ERR_STATE, "sde_set_noise: the engine was not created with use_sde");
+  e->sde_hold = z != nullptr;
+  if (!z) return MOBROB_OK;
+  const size_t HLA = (size_t)e->HL * e->A, n = (size_t)e->N * HLA;
+  if (n > (size_t)1 << 30) return fail(MOBROB_ERR_INVALID, "sde_set_noise: too many matrix elements");
+  // staged through the matrices' own storage: z is uploaded into it and scaled in place
+  HIPC(hipMemcpyAsync(e->sde_E, z, n * 4, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_sde_from_z, dim3(cdiv((int)n, 256)), dim3(256), 0, e->stream, e->sde_E, Pp(e, T_LOGSTD), (int)HLA, (int)n, e->sde_E);
+  hipLaunchKernelGGL(k_copy_f32, dim3(cdiv((int)HLA, 256)), dim3(256), 0, e->stream, e->sde_E, e->sde_E1, (int)HLA);   // exploration_mat := env 0's
+  HIPC(hipGetLastError());
+  HIPC(hipStreamSynchronize(e->stream));   // z may be pageable host memory
+  return MOBROB_OK;
 }
 
 int mobrob_ppo_set_hyper(mobrob_ppo_engine_t* e, int32_t which, double value) {
@@ -2977,6 +3039,16 @@ int mobrob_ppo_predict(mobrob_ppo_engine_t* e, const float* obs, int32_t n, int3
         hipLaunchKernelGGL(k_clip_mean, dim3(cdiv(c * e->A, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, c, e->A,
                            (float)e->cfg.action_low, (float)e->cfg.action_high, scratch);
       } else {
+        if (e->sde) {   // get_noise: the environments' own matrices for a batch of n_envs rows, else the single exploration_mat
+          const bool own = n == e->N;
+          hipLaunchKernelGGL(k_sample_sde, dim3(cdiv(c, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, e->hp[e->Lp - 1], e->HL, Pp(e, T_LOGSTD),
+                             own ? e->sde_E : e->sde_E1, s, own ? 0 : 1, c, e->HL, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high,
+                             (float*)nullptr, scratch, (float*)nullptr);
+          HIPC(hipMemcpyAsync(actions + (size_t)s * e->A, scratch, (size_t)c * e->A * 4, hipMemcpyDeviceToHost, e->stream));
+          if (values) HIPC(hipMemcpyAsync(values + s, e->vout, (size_t)c * 4, hipMemcpyDeviceToHost, e->stream));
+          HIPC(hipStreamSynchronize(e->stream));
+          continue;
+        }
         const float* epsd = nullptr;
         if (eps) {
           HIPC(hipMemcpyAsync(e->eps_dev, eps + (size_t)s * e->A, (size_t)c * e->A * 4, hipMemcpyHostToDevice, e->stream));
@@ -3027,6 +3099,9 @@ static int buffer_lookup(mobrob_ppo_engine* e, int32_t which, void** ptr, size_t
     case MOBROB_BUF_TRUNCATED: p = e->trunc_dev; b = N; break;
     case MOBROB_BUF_ENV_STATE: p = e->gstate[0]; b = N * kGoalStateFloats * 4; break;
     case MOBROB_BUF_GRAD_EXCHANGE: p = e->grads; b = (size_t)(e->P + 8) * 4; break;
+    case MOBROB_BUF_SDE_NOISE:
+      if (!e->sde) return fail(MOBROB_ERR_STATE, "the engine was not created with use_sde");
+      p = e->sde_E; b = N * (size_t)e->HL * e->A * 4; break;
     default: return fail(MOBROB_ERR_INVALID, "unknown buffer id %d", which);
   }
   if (ptr) *ptr = p;

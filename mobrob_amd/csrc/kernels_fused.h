@@ -2082,6 +2082,7 @@ struct NormChunk { int tensor, start, end, pad; };
 
 struct StatsArgs {
   float* stats_row; const float* loss_sums; const float* log_std; float ent_coef, vf_coef, inv_bg; int n_act;
+  int sde;   // gSDE (generic chain only): the entropy is state dependent, its sum over the minibatch is loss_sums[5]
 };
 // logged loss statistics of one optimizer step from the loss sums behind the gradient vector
 // sum over the actions of 0.5 + log sqrt(2 pi) + log sd [SB3 DiagGaussianDistribution.entropy], in action order.  COH: log_std was written
@@ -2107,7 +2108,7 @@ __device__ __forceinline__ void stats_row_from_sums(const StatsArgs& st, float e
               s4 = ldc<COH>(st.loss_sums + 4);
   const float pl = -s0 * st.inv_bg;
   const float vl = s1 * st.inv_bg;
-  const float el = -(ent * s4) * st.inv_bg;
+  const float el = st.sde ? -ldc<COH>(st.loss_sums + 5) * st.inv_bg : -(ent * s4) * st.inv_bg;
   st.stats_row[0] = pl; st.stats_row[1] = vl; st.stats_row[2] = el;
   st.stats_row[3] = __fmaf_rn(st.vf_coef, vl, __fmaf_rn(st.ent_coef, el, pl));   // (explicit: the same bits from every kernel this is compiled into)
   st.stats_row[4] = s2 * st.inv_bg;
@@ -2320,7 +2321,7 @@ __device__ __forceinline__ void adam_pack_block_at(const TA& a, int lin, int i, 
   if (lin == 0 && a.st.loss_sums != nullptr) {  // this kernel also writes the step's loss statistics (pre-update log_std)
     StatsArgs st;
     st.stats_row = stats_row; st.loss_sums = a.st.loss_sums; st.log_std = a.st.log_std;
-    st.ent_coef = a.st.ent_coef; st.vf_coef = a.st.vf_coef; st.inv_bg = inv_bg; st.n_act = a.st.n_act;
+    st.ent_coef = a.st.ent_coef; st.vf_coef = a.st.vf_coef; st.inv_bg = inv_bg; st.n_act = a.st.n_act; st.sde = a.st.sde;
     stats_row_from_sums<COH>(st, ent_pre);
   }
   if (a.fold_idx != nullptr) {  // norm records of the reduction kernel, listed per tensor by the host

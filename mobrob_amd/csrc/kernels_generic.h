@@ -222,6 +222,68 @@ __global__ void k_sample(const float* __restrict__ mu, int ldmu, const float* __
   if (logp_out) logp_out[row] = lp;
 }
 
+// ------------------------------------------------------------------------------------------------
+// gSDE -- generalised state-dependent exploration (`use_sde=True`; SB3 StateDependentNoiseDistribution with its defaults
+// full_std, no expln, no squashing, learn_features=False).  log_std is a [HL][A] matrix (HL = width of the policy's last hidden
+// layer, the "latent_sde"); per environment an exploration matrix theta_n ~ N(0, exp(log_std)^2) is drawn at reset_noise and kept
+// for sde_sample_freq steps:
+//   action = mu + latent . theta_n                     [get_noise: bmm(latent_sde, exploration_matrices)]
+//   variance = latent^2 . exp(log_std)^2 ; sigma = sqrt(variance + 1e-6)      [proba_distribution]
+//   log_prob = sum_a Normal(mu, sigma).log_prob(action) ; entropy = sum_a 0.5 + log sqrt(2 pi) + log sigma
+// The latent is DETACHED in the variance (learn_features=False): log_std is the only parameter the variance reaches.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kStreamSde = 0x53444531u;   // 'SDE1'
+constexpr float kSdeEpsilon = 1e-6f;
+// theta rows [row0, row0 + nrows) of E [N][HL * A] (+ the single matrix E1 by block row `nrows`): one thread per four elements.
+// The matrix of env n at draw index d is a function of (n, d), not of the launch that draws it.
+__global__ void k_sde_resample(const float* __restrict__ log_std, int HLA, int row0, int nrows, uint64_t seed, uint32_t draw_rel,
+                               const uint32_t* __restrict__ draw_base, float* __restrict__ E, float* __restrict__ E1) {
+  const int per = (HLA + 3) / 4;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (nrows + (E1 != nullptr ? 1 : 0)) * per) return;
+  const int r = i / per, c = i - r * per;
+  const bool single = r >= nrows;
+  const uint32_t draw = draw_rel + (draw_base ? *draw_base : 0u);
+  float z[4];
+  box_muller4(philox4x32_10(single ? 0xFFFFFFFFu : (uint32_t)(row0 + r), (uint32_t)c, draw, kStreamSde, (uint32_t)seed, (uint32_t)(seed >> 32)), z);
+  float* out = single ? E1 : E + (size_t)(row0 + r) * HLA;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (4 * c + j < HLA) out[4 * c + j] = z[j] * expf(log_std[4 * c + j]);
+}
+// the same from caller-supplied standard normals z [rows][HL * A] (tests / the oracle's noise as an INPUT, like `eps`)
+__global__ void k_sde_from_z(const float* __restrict__ z, const float* __restrict__ log_std, int HLA, int n, float* __restrict__ E) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) E[i] = z[i] * expf(log_std[i % HLA]);
+}
+// rollout-time sampling epilogue under gSDE: one thread per env row.  E: the rows' matrices ([row][HL][A], erow0 = matrix row of
+// row 0) or, with single != 0, ONE matrix for every row (SB3 get_noise when the batch is not the exploration batch).
+__global__ void k_sample_sde(const float* __restrict__ mu, int ldmu, const float* __restrict__ lat, int ldl, const float* __restrict__ log_std,
+                             const float* __restrict__ E, int erow0, int single, int n, int HL, int A, float lo, float hi,
+                             float* __restrict__ act_raw, float* __restrict__ act_clip, float* __restrict__ logp_out) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const float* l = lat + (size_t)row * ldl;
+  const float* Er = single ? E : E + (size_t)(erow0 + row) * HL * A;
+  float lp = 0.f;
+  for (int a = 0; a < A; ++a) {
+    float noise = 0.f, var = 0.f;
+    for (int k = 0; k < HL; ++k) {
+      const float lk = l[k], sd = expf(log_std[k * A + a]);
+      noise = fmaf(lk, Er[k * A + a], noise);
+      var = fmaf(lk * lk, sd * sd, var);
+    }
+    const float sigma = sqrtf(var + kSdeEpsilon);
+    const float m = mu[(size_t)row * ldmu + a];
+    const float act = m + noise;
+    const float d = act - m;
+    lp += -(d * d) / (2.0f * (sigma * sigma)) - logf(sigma) - kLogSqrt2Pi;
+    if (act_raw) act_raw[(size_t)row * A + a] = act;
+    if (act_clip) act_clip[(size_t)row * A + a] = fminf(fmaxf(act, lo), hi);
+  }
+  if (logp_out) logp_out[row] = lp;
+}
+
 // deterministic predict: clip(mu)
 __global__ void k_clip_mean(const float* __restrict__ mu, int ldmu, int n, int A, float lo, float hi,
                             float* __restrict__ out) {
@@ -737,6 +799,10 @@ struct LossArgs {
   float* dv; int lddv;        // [B][8]
   float* sums;                // [8]
   float* g_log_std; float* g_b_action; float* g_b_value;
+  // gSDE (lat != nullptr): the policy's last hidden activations of the minibatch [B][HL] (ld = HL), log_std is [HL][A];
+  // gsig [B][ldg] <- dLoss / d sigma^2 per (row, action), lat2 [B][HL] <- latent^2 (the operands of the log_std gradient GEMM)
+  const float* lat; int HL;
+  float* gsig; int ldg; float* lat2;
 };
 
 __device__ __forceinline__ void adv_mean_std(const double* st, float* mean, float* sd, bool* on) {
@@ -749,11 +815,21 @@ __device__ __forceinline__ void adv_mean_std(const double* st, float* mean, floa
   *sd = (float)sqrt(var);
 }
 
+// sigma of action a of one row under gSDE: sqrt(sum_k latent_k^2 exp(log_std[k][a])^2 + 1e-6)
+__device__ __forceinline__ float sde_sigma(const float* __restrict__ l, const float* __restrict__ log_std, int HL, int A, int a) {
+  float var = 0.f;
+  for (int k = 0; k < HL; ++k) {
+    const float lk = l[k], sd = expf(log_std[k * A + a]);
+    var = fmaf(lk * lk, sd * sd, var);
+  }
+  return sqrtf(var + kSdeEpsilon);
+}
+
 __global__ __launch_bounds__(256) void k_loss(LossArgs L) {
   __shared__ float red[16];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < L.B;
-  float s_pl = 0.f, s_vl = 0.f, s_kl = 0.f, s_cf = 0.f, g_logp = 0.f, dvv = 0.f;
+  float s_pl = 0.f, s_vl = 0.f, s_kl = 0.f, s_cf = 0.f, g_logp = 0.f, dvv = 0.f, s_ent = 0.f;
   if (live) {
     float a = L.adv[i];
     float mean, sd; bool on;
@@ -761,9 +837,10 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs L) {
     if (L.normalize && on) a = (a - mean) / (sd + 1e-8f);
     float lp = 0.f;
     for (int k = 0; k < L.A; ++k) {
-      const float sdv = expf(L.log_std[k]);
+      const float sdv = L.lat != nullptr ? sde_sigma(L.lat + (size_t)i * L.HL, L.log_std, L.HL, L.A, k) : expf(L.log_std[k]);
       const float d = L.actions[(size_t)i * L.A + k] - L.mu[(size_t)i * L.ldmu + k];
       lp += -(d * d) / (2.0f * (sdv * sdv)) - logf(sdv) - kLogSqrt2Pi;
+      s_ent += (0.5f + kLogSqrt2Pi) + logf(sdv);
     }
     const float log_ratio = lp - L.old_logp[i];
     const float ratio = expf(log_ratio);
@@ -785,19 +862,27 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs L) {
   for (int k = 0; k < L.A; ++k) {
     float gm = 0.f, gls = 0.f;
     if (live) {
-      const float sdv = expf(L.log_std[k]);
+      const float sdv = L.lat != nullptr ? sde_sigma(L.lat + (size_t)i * L.HL, L.log_std, L.HL, L.A, k) : expf(L.log_std[k]);
       const float var = sdv * sdv;
       const float d = L.actions[(size_t)i * L.A + k] - L.mu[(size_t)i * L.ldmu + k];
       gm = g_logp * d / var;
       gls = g_logp * (d * d / var - 1.0f);
       L.dmu[(size_t)i * L.lddmu + k] = gm;
+      if (L.lat != nullptr)   // d logp / d sigma^2 = (d^2 / sigma^2 - 1) / (2 sigma^2); d(-mean entropy) / d sigma^2 = -1 / (2 sigma^2 B)
+        L.gsig[(size_t)i * L.ldg + k] = (gls - L.ent_coef * L.inv_bg) / (2.0f * var);
     }
     const float t1 = block_sum(gm, red);
     const float t2 = block_sum(gls, red);
     if (threadIdx.x == 0) {
       atomicAdd(&L.g_b_action[k], t1);
-      atomicAdd(&L.g_log_std[k], t2);
+      if (L.lat == nullptr) atomicAdd(&L.g_log_std[k], t2);   // (gSDE: log_std's gradient is a GEMM over gsig, see k_sde_scale_grad)
     }
+  }
+  if (L.lat != nullptr) {
+    if (live)
+      for (int k = 0; k < L.HL; ++k) { const float lk = L.lat[(size_t)i * L.HL + k]; L.lat2[(size_t)i * L.HL + k] = lk * lk; }
+    const float r5 = block_sum(s_ent, red);
+    if (threadIdx.x == 0) atomicAdd(&L.sums[5], r5);   // state-dependent entropy: summed per row (stats_row_from_sums, sde)
   }
   const float r0 = block_sum(s_pl, red), r1 = block_sum(s_vl, red), r2 = block_sum(s_kl, red);
   const float r3 = block_sum(s_cf, red), r4 = block_sum(dvv, red);
@@ -809,6 +894,14 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs L) {
     atomicAdd(&L.sums[4], (float)min(L.B - (int)(blockIdx.x * blockDim.x), (int)blockDim.x));
     atomicAdd(L.g_b_value, r4);
   }
+}
+
+// gSDE: g_log_std[k][a] = (latent^2)^T . gsig, as the GEMM left it, times d sigma^2 / d log_std[k][a] / latent_k^2 = 2 exp(log_std[k][a])^2
+__global__ void k_sde_scale_grad(float* __restrict__ g_log_std, const float* __restrict__ log_std, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float sd = expf(log_std[i]);
+  g_log_std[i] *= 2.0f * (sd * sd);
 }
 
 // entropy term of the loss on log_std: d(-mean(entropy))/dlog_std_a = -(B_local/B_global) * ent_coef

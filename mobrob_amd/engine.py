@@ -52,11 +52,11 @@ def activation_name(act) -> str:
     return name
 
 
-def param_shapes(obs_dim, act_dim, pi, vf):
+def param_shapes(obs_dim, act_dim, pi, vf, use_sde=False):
     """SB3 `policy.state_dict()` key order and shapes (include/mobrob_ppo.h 'Conventions'); one to eight hidden layers per
     network (`nn.Sequential` indices 0, 2, 4 ...: every Linear is followed by its activation module)."""
     s = OrderedDict()
-    s["log_std"] = (act_dim,)
+    s["log_std"] = (pi[-1], act_dim) if use_sde else (act_dim,)   # gSDE: one row per unit of the policy's last hidden layer
     for net, widths in (("policy_net", pi), ("value_net", vf)):
         prev = obs_dim
         for i, w in enumerate(widths):
@@ -151,7 +151,8 @@ class PPOEngine:
                     gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
                     learning_rate=3e-4, adam_betas=(0.9, 0.999), adam_eps=1e-5, normalize_advantage=True,
                     action_low=-1.0, action_high=1.0, seed=0, device_id=0, rank=0, world_size=1, fast_kernels=True,
-                    rollout_graph=True, rollout_persistent=True, activation="tanh", forward_x3=True) -> Config:
+                    rollout_graph=True, rollout_persistent=True, activation="tanh", forward_x3=True, use_sde=False,
+                    sde_sample_freq=-1) -> Config:
         """PPO(...) keyword arguments -> `mobrob_ppo_config_t` (SB3 defaults, Appendix A.1)."""
         if not (1 <= len(pi) <= MAX_HIDDEN and 1 <= len(vf) <= MAX_HIDDEN):
             raise ValueError(f"net_arch: one to {MAX_HIDDEN} hidden layers per network (pi=[h1, ...], vf=[h1, ...])")
@@ -176,6 +177,7 @@ class PPOEngine:
         cfg.rollout_persistent = int(bool(rollout_persistent))
         cfg.activation = ACTIVATIONS[activation_name(activation)][0]
         cfg.forward_x3 = int(bool(forward_x3))
+        cfg.use_sde, cfg.sde_sample_freq = int(bool(use_sde)), int(sde_sample_freq)
         return cfg
 
     @staticmethod
@@ -195,7 +197,8 @@ class PPOEngine:
         vf = tuple(w for w in (cfg.vf_hidden[0], cfg.vf_hidden[1], cfg.vf_hidden3, *cfg.vf_hidden_ext) if w > 0)
         self.cfg = cfg
         self.D, self.A, self.N, self.T = int(obs_dim), int(act_dim), int(n_envs), int(n_steps)
-        self.shapes = param_shapes(self.D, self.A, pi, vf)
+        self.shapes = param_shapes(self.D, self.A, pi, vf, bool(cfg.use_sde))
+        self.use_sde, self.HL = bool(cfg.use_sde), int(pi[-1])
         self._h = C.c_void_p()
         if arena is None:
             check(self.lib.mobrob_ppo_create(C.byref(cfg), C.byref(self._h)))
@@ -262,6 +265,19 @@ class PPOEngine:
         check(self.lib.mobrob_ppo_set_optimizer_state(self._h, _fp(m), _fp(v), self.P, int(step)))
 
     # ---- rollout ------------------------------------------------------------------------------
+    # ---- gSDE ---------------------------------------------------------------------------------
+    def sde_reset_noise(self):
+        """policy.reset_noise(n_envs): new exploration matrices from the current log_std."""
+        check(self.lib.mobrob_ppo_sde_reset_noise(self._h))
+
+    def sde_set_noise(self, z):
+        """Exploration matrices as an input: z ~ N(0, 1) of shape [n_envs, HL, A] (None: the engine's own draws again)."""
+        if z is None:
+            check(self.lib.mobrob_ppo_sde_set_noise(self._h, None))
+            return
+        z = _f32c(z, (self.N, self.HL, self.A))
+        check(self.lib.mobrob_ppo_sde_set_noise(self._h, _fp(z)))
+
     def rollout_begin(self):
         check(self.lib.mobrob_ppo_rollout_begin(self._h))
 
@@ -557,7 +573,8 @@ class PPOEngine:
                 "grads": ((self.P,), F32), "advstat": ((self.n_minibatches, 4), np.float64),
                 "last_values": ((N,), F32), "last_dones": ((N,), F32), "clipped_actions": ((N, self.A), F32), "episode_start_state": ((N,), F32),
                 "terminal_obs": ((N, 16 * ((self.D + 15) // 16) if self.D <= 64 else 8 * ((self.D + 7) // 8)), F32), "terminal_values": ((N,), F32),
-                "truncated": ((N,), np.uint8), "env_state": ((N, 12), F32), "grad_exchange": ((self.P + 8,), F32)}[name]
+                "truncated": ((N,), np.uint8), "env_state": ((N, 12), F32), "grad_exchange": ((self.P + 8,), F32),
+                "sde_noise": ((N, getattr(self, "HL", 0), self.A), F32)}[name]
 
     def read(self, name):
         shape, dt = self._buf_shape(name)

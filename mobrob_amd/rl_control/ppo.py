@@ -172,9 +172,6 @@ class PPO:
                  _init_setup_model=True, _dims=None, _engine_kwargs=None):
         if policy not in ("MlpPolicy",) and getattr(policy, "__name__", "") != "ActorCriticPolicy":
             raise ValueError(f"Policy {policy} unknown")
-        if use_sde:
-            raise NotImplementedError("use_sde (generalised state-dependent exploration) is not implemented by the HIP "
-                                      "engine; no reference config uses it")
         self.policy_class = "MlpPolicy"
         self.env = env
         # learning_rate / clip_range / clip_range_vf may be floats or SB3 schedules: callables of progress_remaining
@@ -192,7 +189,9 @@ class PPO:
                               else (None if clip_range_vf is None else float(clip_range_vf)))
         self.normalize_advantage = bool(normalize_advantage)
         self.ent_coef, self.vf_coef, self.max_grad_norm = float(ent_coef), float(vf_coef), float(max_grad_norm)
-        self.use_sde, self.sde_sample_freq = False, -1
+        # generalised state-dependent exploration (SB3 StateDependentNoiseDistribution with its defaults): log_std is a
+        # [last policy width, act_dim] matrix, the exploration matrices are redrawn every sde_sample_freq rollout steps
+        self.use_sde, self.sde_sample_freq = bool(use_sde), int(sde_sample_freq)
         self.target_kl = None if target_kl is None else float(target_kl)
         self.tensorboard_log, self.verbose, self.seed, self.device = tensorboard_log, int(verbose), seed, device
         self.policy_kwargs = dict(policy_kwargs or {})
@@ -224,7 +223,12 @@ class PPO:
         # MlpPolicy's features extractor is nn.Flatten (no parameters): sharing it or not is the same network; `normalize_images`
         # concerns image spaces only -- both are accepted and travel with the checkpoint
         unknown = set(self.policy_kwargs) - {"net_arch", "log_std_init", "ortho_init", "optimizer_kwargs", "activation_fn",
-                                             "optimizer_class", "share_features_extractor", "normalize_images"}
+                                             "optimizer_class", "share_features_extractor", "normalize_images", "full_std",
+                                             "use_expln", "squash_output"}
+        # gSDE options of ActorCriticPolicy: only SB3's defaults are implemented (they only matter with use_sde)
+        for k, dflt in (("full_std", True), ("use_expln", False), ("squash_output", False)):
+            if k in self.policy_kwargs and bool(self.policy_kwargs[k]) != dflt:
+                raise NotImplementedError(f"policy_kwargs {k}={self.policy_kwargs[k]!r}: only SB3's default ({dflt}) is implemented")
         if unknown:
             raise NotImplementedError(f"policy_kwargs {sorted(unknown)} are not supported (MlpPolicy, one to {MAX_HIDDEN} hidden "
                                       "layers per network)")
@@ -268,7 +272,8 @@ class PPO:
                   gamma=self.gamma, gae_lambda=self.gae_lambda, clip_range=self.clip_range, ent_coef=self.ent_coef,
                   vf_coef=self.vf_coef, max_grad_norm=self.max_grad_norm, learning_rate=self.learning_rate,
                   normalize_advantage=self.normalize_advantage, seed=0 if self.seed is None else int(self.seed),
-                  adam_betas=self.adam_betas, adam_eps=self.adam_eps, activation=self.activation)
+                  adam_betas=self.adam_betas, adam_eps=self.adam_eps, activation=self.activation, use_sde=self.use_sde,
+                  sde_sample_freq=self.sde_sample_freq)
         # data parallel: under torchrun / an initialised process group every rank owns its n_envs
         # environments and rollout shard; batch_size stays SB3's GLOBAL minibatch and must divide by the world size
         from ..parallel import distributed_context
@@ -281,7 +286,7 @@ class PPO:
         self._backend = None
         self.engine.set_params(policy_init(self.obs_dim, self.act_dim, self.net_arch[0], self.net_arch[1],
                                            seed=0 if self.seed is None else int(self.seed),
-                                           log_std_init=self.log_std_init, ortho_init=self.ortho_init))
+                                           log_std_init=self.log_std_init, ortho_init=self.ortho_init, use_sde=self.use_sde))
         self.policy = ActorCriticPolicyHandle(self)
 
     def get_env(self):
@@ -572,7 +577,7 @@ class PPO:
                     gae_lambda=self.gae_lambda, ent_coef=self.ent_coef, vf_coef=self.vf_coef,
                     max_grad_norm=self.max_grad_norm, learning_rate=self.learning_rate, clip_range=self.clip_range,
                     normalize_advantage=self.normalize_advantage, n_envs=self.n_envs, clip_range_vf=self.clip_range_vf,
-                    target_kl=self.target_kl)
+                    target_kl=self.target_kl, use_sde=self.use_sde, sde_sample_freq=self.sde_sample_freq)
 
     def save(self, path):
         """SB3-layout zip (checkpoint.py); appends .zip like SB3 when the suffix is missing.  Data-parallel replicas
@@ -599,7 +604,7 @@ class PPO:
                  obs_high=None if self.obs_bounds is None else self.obs_bounds[1],
                  extra_policy_kwargs={k: (list(v) if isinstance(v, tuple) else v) for k, v in self.policy_kwargs.items()
                                       if k in ("log_std_init", "ortho_init", "optimizer_kwargs", "share_features_extractor",
-                                               "normalize_images")}
+                                               "normalize_images", "full_std", "use_expln", "squash_output")}
                  | ({"activation_fn": self.activation} if self.activation != "tanh" else {}))
 
     @classmethod
@@ -608,7 +613,7 @@ class PPO:
         ck = load_zip(path)
         d, params = ck["data"], ck["params"]
         D = params["mlp_extractor.policy_net.0.weight"].shape[1]
-        A = params["log_std"].shape[0]
+        A = params["action_net.weight"].shape[0]   # (log_std is [HL, A] with use_sde)
         def widths(net):   # hidden widths from the state dict itself (nn.Sequential indices 0, 2, 4 ...)
             out, i = [], 0
             while f"mlp_extractor.{net}.{2 * i}.weight" in params:
@@ -628,7 +633,8 @@ class PPO:
                     n_epochs=int(d.get("n_epochs", 10)), gamma=float(d.get("gamma", 0.99)),
                     gae_lambda=float(d.get("gae_lambda", 0.95)), clip_range=float(clip) if isinstance(clip, (int, float)) else 0.2,
                     clip_range_vf=d.get("clip_range_vf") if isinstance(d.get("clip_range_vf"), (int, float)) else None,
-                    target_kl=d.get("target_kl"),
+                    target_kl=d.get("target_kl"), use_sde=bool(d.get("use_sde", False)),
+                    sde_sample_freq=int(d.get("sde_sample_freq", -1)),
                     normalize_advantage=bool(d.get("normalize_advantage", True)), ent_coef=float(d.get("ent_coef", 0.0)),
                     vf_coef=float(d.get("vf_coef", 0.5)), max_grad_norm=float(d.get("max_grad_norm", 0.5)),
                     tensorboard_log=d.get("tensorboard_log"), policy_kwargs=pk, verbose=int(d.get("verbose", 0)),

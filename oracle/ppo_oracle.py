@@ -256,6 +256,53 @@ def gaussian_entropy(log_std, n):
     return np.full((n,), ent.sum(dtype=F32), F32)
 
 
+# --------------------------------------------------------------------------------------
+# gSDE  [SB3 common/distributions.py StateDependentNoiseDistribution with its defaults: full_std=True, use_expln=False,
+#        squash_output=False, learn_features=False, epsilon=1e-6; reached through ActorCriticPolicy(use_sde=True)]
+# --------------------------------------------------------------------------------------
+SDE_EPSILON = 1e-6
+
+
+def sde_sigma(latent, log_std, acc=None):
+    """proba_distribution: variance = mm(latent_sde ** 2, get_std(log_std) ** 2); Normal(mean, sqrt(variance + epsilon)).
+    latent [B, HL] (the policy's last hidden activations, detached), log_std [HL, A] -> sigma [B, A]."""
+    std = np.exp(np.asarray(log_std, F32)).astype(F32)
+    latent = np.asarray(latent, F32)
+    variance = _mm((latent * latent).astype(F32), (std * std).astype(F32), acc)
+    return np.sqrt(variance + F32(SDE_EPSILON)).astype(F32)
+
+
+def normal_log_prob(mean, sigma, actions):
+    """torch.distributions.Normal.log_prob summed over the action dimension, sigma per (row, action)."""
+    var = (sigma * sigma).astype(F32)
+    lp = (-((np.asarray(actions, F32) - mean) ** 2) / (F32(2.0) * var) - np.log(sigma) - F32(math.log(math.sqrt(2 * math.pi)))).astype(F32)
+    return lp.sum(axis=1, dtype=F32)
+
+
+def sde_exploration_matrices(log_std, z):
+    """sample_weights: weights_dist = Normal(0, std); exploration_matrices = rsample((n_envs,)) = z * std.  The standard normals z
+    [n_envs, HL, A] are an INPUT (torch's stream cannot be reproduced elsewhere)."""
+    return (np.asarray(z, F32) * np.exp(np.asarray(log_std, F32))).astype(F32)
+
+
+def act_sde(p, obs, theta, low=-1.0, high=1.0, activation="tanh"):
+    """One rollout-time policy call under gSDE: actions = mean + bmm(latent, theta) [get_noise], log-probs under
+    Normal(mean, sigma(latent)).  theta [n_envs, HL, A] = the environments' exploration matrices (one shared [HL, A] matrix is
+    broadcast: SB3's `exploration_mat` for foreign batch sizes)."""
+    acts_pi, acts_vf = mlp_latents(p, obs, activation=activation)
+    latent = acts_pi[-1]
+    mean = _linear(latent, p["action_net.weight"], p["action_net.bias"])
+    value = _linear(acts_vf[-1], p["value_net.weight"], p["value_net.bias"])[:, 0]
+    theta = np.asarray(theta, F32)
+    if theta.ndim == 2:
+        noise = _mm(latent, theta)
+    else:
+        noise = np.stack([_mm(latent[i:i + 1], theta[i])[0] for i in range(latent.shape[0])]).astype(F32)
+    actions = (mean + noise).astype(F32)
+    logp = normal_log_prob(mean, sde_sigma(latent, p["log_std"]), actions)
+    return actions, np.clip(actions, F32(low), F32(high)), value, logp
+
+
 def act(p, obs, eps, low=-1.0, high=1.0, activation="tanh"):
     """One rollout-time policy call [SB3 OnPolicyAlgorithm.collect_rollouts -> policy.forward].
     eps ~ N(0, I) is an INPUT (torch's CPU normal_ stream cannot be reproduced elsewhere).
@@ -398,6 +445,8 @@ class Hyper:
     clip_range_vf: float | None = None   # SB3 default None: no value-function clipping
     target_kl: float | None = None       # SB3 default None: no early stop
     activation: str = "tanh"             # policy_kwargs activation_fn: "tanh" (SB3's MlpPolicy default) or another of ACTIVATIONS
+    use_sde: bool = False                # PPO(use_sde=True): generalised state-dependent exploration, log_std is [HL, A]
+    sde_sample_freq: int = -1            # PPO(sde_sample_freq): steps between reset_noise calls inside a rollout (-1: never)
 
 
 def normalize_advantages(adv, acc=None):
@@ -435,9 +484,15 @@ def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, return
     values = _linear(acts_vf[-1], p["value_net.weight"], p["value_net.bias"], acc)[:, 0]
     log_std = p["log_std"].astype(F32)
     std = np.exp(log_std).astype(F32)
-    var = (std * std).astype(F32)
-    log_prob = gaussian_log_prob(mean, log_std, actions)
-    entropy = gaussian_entropy(log_std, B)
+    if h.use_sde:   # sigma per (row, action) from the detached latent; entropy = sum_a 0.5 + log sqrt(2 pi) + log sigma
+        sigma = sde_sigma(acts_pi[-1], log_std, acc)
+        var = (sigma * sigma).astype(F32)
+        log_prob = normal_log_prob(mean, sigma, actions)
+        entropy = (F32(0.5) + F32(0.5 * math.log(2 * math.pi)) + np.log(sigma)).astype(F32).sum(axis=1, dtype=F32)
+    else:
+        var = (std * std).astype(F32)
+        log_prob = gaussian_log_prob(mean, log_std, actions)
+        entropy = gaussian_entropy(log_std, B)
 
     adv = np.asarray(advantages, F32)
     if h.normalize_advantage and (denom if denom is not None else B) > 1:
@@ -476,9 +531,16 @@ def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, return
     g_logp = (d_ratio * ratio).astype(F32)  # dL/dlog_prob_i
     d = (actions - mean).astype(F32)
     g_mean = (g_logp[:, None] * d / var).astype(F32)  # [B, A]
-    g_log_std = _colsum((g_logp[:, None] * (d * d / var - F32(1.0))).astype(F32), acc)
-    # entropy: d(-mean(entropy))/dlog_std_a = -(B_local / B_global)
-    g_log_std = (g_log_std + F32(h.ent_coef) * F32(-float(B)) / Bg).astype(F32)
+    if h.use_sde:
+        # d logp / d sigma^2 = (d^2 / sigma^2 - 1) / (2 sigma^2); d(-mean entropy) / d sigma^2 = -1 / (2 sigma^2 Bg);
+        # sigma^2[r, a] = sum_k latent[r, k]^2 exp(2 log_std[k, a]) + eps  ->  d sigma^2 / d log_std[k, a] = 2 latent^2 std^2
+        g_var = ((g_logp[:, None] * (d * d / var - F32(1.0)) - F32(h.ent_coef) / Bg) / (F32(2.0) * var)).astype(F32)
+        lat = acts_pi[-1]
+        g_log_std = (_mm((lat * lat).astype(F32).T, g_var, acc) * (F32(2.0) * std * std)).astype(F32)
+    else:
+        g_log_std = _colsum((g_logp[:, None] * (d * d / var - F32(1.0))).astype(F32), acc)
+        # entropy: d(-mean(entropy))/dlog_std_a = -(B_local / B_global)
+        g_log_std = (g_log_std + F32(h.ent_coef) * F32(-float(B)) / Bg).astype(F32)
     g_value = (F32(h.vf_coef) * F32(2.0) * (values_pred - ret) * vf_pass / Bg).astype(F32)  # [B]
 
     grads = OrderedDict((k, None) for k in p.keys())
@@ -665,14 +727,22 @@ class NumpySyntheticVecEnv:
 
 
 def collect_rollout(p, env, last_obs, last_episode_starts, T, h: Hyper, eps_source):
-    """OnPolicyAlgorithm.collect_rollouts restated.  eps_source(t) -> [N,A]."""
+    """OnPolicyAlgorithm.collect_rollouts restated.  eps_source(t) -> [N,A].
+    With h.use_sde, eps_source(t) -> z [N, HL, A]: the standard normals of the reset_noise call SB3 makes at t = 0 and, with
+    sde_sample_freq > 0, at every t % sde_sample_freq == 0 (asked for only then)."""
     N, D = last_obs.shape
-    A = p["log_std"].shape[0]
+    A = p["action_net.bias"].shape[0]   # (log_std is [HL, A] under gSDE)
     buf = dict(obs=np.zeros((T, N, D), F32), actions=np.zeros((T, N, A), F32), rewards=np.zeros((T, N), F32),
                episode_starts=np.zeros((T, N), F32), values=np.zeros((T, N), F32), log_probs=np.zeros((T, N), F32))
     dones = np.zeros(N, bool)
+    theta = None
     for t in range(T):
-        actions, clipped, values, logp = act(p, last_obs, eps_source(t), activation=h.activation)
+        if h.use_sde:
+            if t == 0 or (h.sde_sample_freq > 0 and t % h.sde_sample_freq == 0):
+                theta = sde_exploration_matrices(p["log_std"], eps_source(t))
+            actions, clipped, values, logp = act_sde(p, last_obs, theta, activation=h.activation)
+        else:
+            actions, clipped, values, logp = act(p, last_obs, eps_source(t), activation=h.activation)
         new_obs, rewards, dones, trunc, terminal_obs = env.step(clipped)
         rewards = rewards.astype(F32).copy()
         if trunc.any():

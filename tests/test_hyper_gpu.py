@@ -137,7 +137,7 @@ def test_schedules_and_kwargs_through_ppo(tmp_path):
     with pytest.raises(ValueError):
         PPO("MlpPolicy", env, clip_range_vf=-1.0)
     with pytest.raises(NotImplementedError):
-        PPO("MlpPolicy", env, use_sde=True)
+        PPO("MlpPolicy", env, use_sde=True, policy_kwargs=dict(use_expln=True))   # (use_sde itself: tests/test_sde_gpu.py)
 
 
 def test_policy_kwargs_beyond_net_arch(tmp_path):

@@ -334,3 +334,51 @@ def test_other_activations_and_depths_match_torch_golden(name):
     for k in p:
         assert np.max(np.abs(newp[k] - c["step/p/" + k])) < 1e-6, k
         assert np.allclose(st.exp_avg[k], c["step/m/" + k], rtol=1e-4, atol=1e-8) and np.allclose(st.exp_avg_sq[k], c["step/v/" + k], rtol=1e-4, atol=1e-11), k
+
+
+@pytest.mark.parametrize("name", __import__("tests.util", fromlist=["SDE_CASES"]).SDE_CASES)
+def test_gsde_matches_torch_golden(name):
+    """PPO(use_sde=True): the oracle's StateDependentNoiseDistribution restatement (sample, log-prob, entropy, the log_std matrix's
+    gradient through the variance) against torch's own ops (tests/golden/make_sde_fixture.py)."""
+    from tests.util import sde_case
+    c, act, pi, vf, p, h = sde_case(name)
+    assert p["log_std"].shape == (pi[-1], c["fwd/eps"].shape[1] if "fwd/eps" in c else c["fwd/actions"].shape[1])
+    theta = O.sde_exploration_matrices(p["log_std"], c["fwd/z"])
+    actions, clipped, value, logp = O.act_sde(p, c["fwd/obs"], theta, activation=act)
+    assert scaled_err(actions, c["fwd/actions"]) < 1e-5 and scaled_err(value, c["fwd/value"]) < 1e-5
+    assert np.allclose(logp, c["fwd/log_prob"], rtol=1e-5, atol=1e-4) and np.array_equal(clipped, np.clip(actions, -1, 1))
+    single, _, _, _ = O.act_sde(p, c["fwd/obs"], theta[0], activation=act)
+    assert scaled_err(single, c["fwd/single"]) < 1e-5
+    mb = (c["mb/obs"], c["mb/actions"], c["mb/old_values"], c["mb/old_log_prob"], c["mb/advantages"], c["mb/returns"])
+    stats, grads, aux = O.loss_and_grads(p, *mb, h)
+    for k in ["loss", "policy_loss", "value_loss", "entropy_loss", "approx_kl", "clip_fraction"]:
+        assert abs(float(stats[k]) - float(c["step/" + k])) < 1e-5 * max(1.0, abs(float(c["step/" + k]))), k
+    for k, v in grads.items():
+        ref = c["step/grad/" + k]
+        assert v.shape == ref.shape and np.max(np.abs(v - ref)) < 1e-5 * max(1.0, float(np.max(np.abs(ref)))), k
+    assert float(np.max(np.abs(c["step/grad/log_std"]))) > 1e-4      # (the comparison above is not vacuous for the matrix)
+    clipped_g, total = O.clip_grad_norm(grads, h.max_grad_norm)
+    assert abs(float(total) - float(c["step/grad_norm"])) < 1e-5 * float(c["step/grad_norm"])
+    newp = O.adam_step({k: v.copy() for k, v in p.items()}, clipped_g, O.AdamState.zeros_like(p), h.learning_rate, h.beta1, h.beta2, h.adam_eps)
+    for k in p:
+        assert np.max(np.abs(newp[k] - c["step/p/" + k])) < 1e-6, k
+
+
+def test_gsde_rollout_keeps_one_matrix_per_environment_between_reset_points():
+    """collect_rollout under use_sde: the noise of an environment is ONE linear map of its latent between reset_noise points (t = 0 and
+    every sde_sample_freq steps), and the stored log-probs are the state-dependent distribution's at the stored actions."""
+    D, A, N, T, pi, vf, freq = 10, 2, 4, 12, (16, 8), (16,), 6
+    p = O.init_params(D, A, pi, vf, seed=4)
+    p["log_std"] = np.full((pi[-1], A), -1.0, np.float32)
+    zs = np.random.default_rng(0).standard_normal((T, N, pi[-1], A)).astype(np.float32)
+    asked = []
+    h = O.Hyper(use_sde=True, sde_sample_freq=freq)
+    env = O.NumpySyntheticVecEnv(N, D, A, p_term=0.05, time_limit=7, seed=3)
+    buf, _, _ = O.collect_rollout(p, env, env.reset(), np.ones(N, bool), T, h, lambda t: (asked.append(t), zs[t])[1])
+    assert asked == [0, 6]
+    for t in range(T):
+        lat = O.mlp_latents(p, buf["obs"][t])[0][-1]
+        mean = O.policy_outputs(p, buf["obs"][t])[0]
+        theta = O.sde_exploration_matrices(p["log_std"], zs[0 if t < 6 else 6])
+        assert np.allclose(buf["actions"][t], mean + np.einsum("nk,nka->na", lat, theta), atol=1e-5)
+        assert np.allclose(buf["log_probs"][t], O.normal_log_prob(mean, O.sde_sigma(lat, p["log_std"]), buf["actions"][t]), atol=1e-5)

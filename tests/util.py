@@ -91,3 +91,24 @@ def arch_case(name):
     h = O.Hyper(clip_range=clip, ent_coef=ent, vf_coef=vfc, max_grad_norm=mgn, learning_rate=lr, adam_eps=eps, activation=act,
                 batch_size=100, n_epochs=1)
     return c, act, pi, vf, p, h
+
+
+# ---- tests/golden/sde_cases.npz (make_sde_fixture.py): PPO(use_sde=True) through torch's own ops ----
+SDE_CASES = ["sde_tanh_2x2", "sde_relu_1_3", "sde_elu_4"]
+_SDE = None
+
+
+def sde_case(name):
+    """-> (case dict, activation, pi, vf, params, Hyper(use_sde=True))"""
+    global _SDE
+    if _SDE is None:
+        _SDE = np.load(os.path.join(GOLDEN, "sde_cases.npz"))
+    assert [str(c) for c in _SDE["cases"]] == SDE_CASES
+    pre = name + "/"
+    c = {k[len(pre):]: _SDE[k] for k in _SDE.files if k.startswith(pre)}
+    act, pi, vf = str(c["activation"]), tuple(int(w) for w in c["pi"]), tuple(int(w) for w in c["vf"])
+    p = OrderedDict((k, c["p/" + k].astype(np.float32).copy()) for k in O.param_keys(len(pi), len(vf)))
+    lr, clip, ent, vfc, mgn, eps = (float(x) for x in _SDE["hyper"])
+    h = O.Hyper(clip_range=clip, ent_coef=ent, vf_coef=vfc, max_grad_norm=mgn, learning_rate=lr, adam_eps=eps, activation=act,
+                batch_size=100, n_epochs=1, use_sde=True)
+    return c, act, pi, vf, p, h
