@@ -322,10 +322,21 @@ void prof_resolve(mobrob_ppo_engine* e) {
 }
 
 // ---- GEMM launchers --------------------------------------------------------------------------------
+template <int MODE, int EPI, int TM, int TN>
+void launch_gemm_tiles(mobrob_ppo_engine* e, const GemmArgs& g, int ksplit) {
+  dim3 grid(cdiv(cdiv(g.M, 32 * TM), 4), cdiv(g.N, 32 * TN), ksplit);
+  hipLaunchKernelGGL((k_gemm<MODE, EPI, TM, TN>), grid, dim3(256), 0, e->stream, g);
+}
+// tiles per wave by shape: 2x2 wherever both extents leave room for it, 2x1 for narrow outputs (heads), 1x1 for tiny ones.
+// MOBROB_GEMM_TILES=1 keeps one tile per wave (A/B).
 template <int MODE, int EPI>
 void launch_gemm(mobrob_ppo_engine* e, const GemmArgs& g, int ksplit = 1) {
-  dim3 grid(cdiv(cdiv(g.M, 32), 4), cdiv(g.N, 32), ksplit);
-  hipLaunchKernelGGL((k_gemm<MODE, EPI>), grid, dim3(256), 0, e->stream, g);
+  static const bool one_tile = getenv("MOBROB_GEMM_TILES") != nullptr && atoi(getenv("MOBROB_GEMM_TILES")) == 1;
+  // fat wave tiles only while they still leave ~8 waves per CU: a rollout step (4096 rows) is 1024 one-tile waves, 256 as 2x2
+  const long w22 = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * ksplit, w21 = (long)cdiv(g.M, 64) * cdiv(g.N, 32) * ksplit;
+  if (one_tile || g.M <= 32 || w21 < 2048) launch_gemm_tiles<MODE, EPI, 1, 1>(e, g, ksplit);
+  else if (g.N <= 32 || w22 < 2048) launch_gemm_tiles<MODE, EPI, 2, 1>(e, g, ksplit);
+  else launch_gemm_tiles<MODE, EPI, 2, 2>(e, g, ksplit);
 }
 
 // Y[M x Nn] = act(X[M x K] . W[Nn x K]^T + bias)
@@ -350,8 +361,10 @@ void linear_bwd_weight(mobrob_ppo_engine* e, const float* dY, int ldd, const flo
                        int M, int Nn, int rows) {
   GemmArgs g{};
   g.A = dY; g.B = X; g.C = dW; g.M = M; g.N = Nn; g.K = rows; g.lda = ldd; g.ldb = ldx; g.ldc = ldw;
-  const int tiles = cdiv(M, 32) * cdiv(Nn, 32);
-  int ksplit = std::max(1, std::min(cdiv(rows, 64), cdiv(4096, tiles)));
+  // waves of one pass over the output (launch_gemm's tiling: 64-row / 64-column wave tiles where the extents allow); the batch rows
+  // are split until ~2048 waves are in flight (8 per CU) -- every split adds M x Nn float atomics, so not further
+  const int wtiles = cdiv(M, M <= 32 ? 32 : 64) * cdiv(Nn, (M <= 32 || Nn <= 32) ? 32 : 64);
+  int ksplit = std::max(1, std::min(cdiv(rows, 64), cdiv(2048, wtiles)));   // (launch_gemm then finds w22 / w21 >= 2048 wherever the rows allow)
   g.kchunk = rup(cdiv(rows, ksplit), 8);
   ksplit = cdiv(rows, g.kchunk);
   launch_gemm<MODE_TN, EPI_ATOMIC>(e, g, ksplit);

@@ -49,7 +49,7 @@ __device__ __forceinline__ float act_bwd(int act, float h, float g) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// MFMA GEMM, one 32x32 output tile per wave, 4 waves per block stacked along M.
+// MFMA GEMM, TM x TN output tiles of 32x32 per wave, 4 waves per block stacked along M.
 //   MODE_NT: C[m][n] = sum_k A[m][k] * B[n][k]      (forward:  X . W^T)        K % 8 == 0
 //   MODE_NN: C[m][n] = sum_k A[m][k] * B[k][n]      (backward: dY . W)         K % 8 == 0
 //   MODE_TN: C[i][j] = sum_k A[k][i] * B[k][j]      (weight grad: dY^T . X), K = batch rows, split over
@@ -75,90 +75,133 @@ struct GemmArgs {
   int kchunk;           // MODE_TN: batch rows per blockIdx.z
 };
 
-template <int MODE, int EPI>
+// TM x TN: 32x32 tiles per wave (1x1, 2x1 or 2x2).  A wave that owns 2x2 tiles feeds sixteen MFMAs from four operand fetches where
+// four one-tile waves need eight for the same sixteen: the one-tile form ran at 22 - 34 % of the f32 matrix rate on L1 / L2
+// operand traffic (12.8 flop per byte fetched by a block; 25.6 with 2x2), see CHANGELOG round 6.
+template <int MODE, int EPI, int TM, int TN>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int tm = blockIdx.x * 4 + wv, tn = blockIdx.y;
-  const int m0 = tm * 32, n0 = tn * 32;
+  const int m0 = (blockIdx.x * 4 + wv) * (32 * TM), n0 = blockIdx.y * (32 * TN);
   if (m0 >= g.M) return;  // whole-wave exit (no block-level sync in this kernel)
-  f32x16 acc;
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   if (MODE == MODE_NT) {
-    const int am = min(m0 + r, g.M - 1), bn = min(n0 + r, g.N - 1);
-    const float* ap = g.A + (size_t)am * g.lda + 4 * h;
-    const float* bp = g.B + (size_t)bn * g.ldb + 4 * h;
+    const float* ap[TM];
+    const float* bp[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ap[i] = g.A + (size_t)min(m0 + 32 * i + r, g.M - 1) * g.lda + 4 * h;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bp[j] = g.B + (size_t)min(n0 + 32 * j + r, g.N - 1) * g.ldb + 4 * h;
 #pragma unroll 2
     for (int kk = 0; kk < g.K; kk += 8) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(bp + kk);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(ap[i] + kk);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(bp[j] + kk);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     }
   } else if (MODE == MODE_NN) {
-    const int am = min(m0 + r, g.M - 1), bn = min(n0 + r, g.N - 1);
-    const float* ap = g.A + (size_t)am * g.lda + 4 * h;
-    const float* bp = g.B + (size_t)(4 * h) * g.ldb + bn;
+    const float* ap[TM];
+    const float* bp[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ap[i] = g.A + (size_t)min(m0 + 32 * i + r, g.M - 1) * g.lda + 4 * h;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bp[j] = g.B + (size_t)(4 * h) * g.ldb + min(n0 + 32 * j + r, g.N - 1);
 #pragma unroll 2
     for (int kk = 0; kk < g.K; kk += 8) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk);
-      const float* bk = bp + (size_t)kk * g.ldb;
-      const float b0 = bk[0], b1 = bk[g.ldb], b2 = bk[2 * (size_t)g.ldb], b3 = bk[3 * (size_t)g.ldb];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b2, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b3, acc, 0, 0, 0);
+      f32x4 a[TM];
+      float b[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(ap[i] + kk);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float* bk = bp[j] + (size_t)kk * g.ldb;
+        b[j][0] = bk[0]; b[j][1] = bk[g.ldb]; b[j][2] = bk[2 * (size_t)g.ldb]; b[j][3] = bk[3 * (size_t)g.ldb];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     }
   } else {  // MODE_TN
-    const int ai = min(m0 + r, g.M - 1), bj = min(n0 + r, g.N - 1);
+    int ai[TM], bj[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ai[i] = min(m0 + 32 * i + r, g.M - 1);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bj[j] = min(n0 + 32 * j + r, g.N - 1);
     const int k0 = blockIdx.z * g.kchunk, k1 = min(k0 + g.kchunk, g.K);
     for (int kk = k0; kk < k1; kk += 8) {
-      float a[4], b[4];
+      float a[TM][4], b[TN][4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int k = kk + 2 * s + h;
         const bool ok = k < k1;
         const int kc = ok ? k : k0;
-        const float av = g.A[(size_t)kc * g.lda + ai];
-        a[s] = ok ? av : 0.f;
-        b[s] = g.B[(size_t)kc * g.ldb + bj];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float av = g.A[(size_t)kc * g.lda + ai[i]];
+          a[i][s] = ok ? av : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j][s] = g.B[(size_t)kc * g.ldb + bj[j]];
       }
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     }
   }
 
-  const int col = n0 + r;
-  const bool col_ok = col < g.N;
-  float csum = 0.f;
-  float bias = 0.f;
-  if ((EPI == EPI_BIAS || EPI == EPI_BIAS_TANH) && g.bias != nullptr && col_ok) bias = g.bias[col];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-    if (row < g.M && col_ok) {
-      float v = acc[i];
-      if (EPI == EPI_BIAS) {
-        g.C[(size_t)row * g.ldc + col] = v + bias;
-      } else if (EPI == EPI_BIAS_TANH) {
-        g.C[(size_t)row * g.ldc + col] = act_fwd(g.act, v + bias);
-      } else if (EPI == EPI_DTANH_COLSUM) {
-        const float hv = g.Hact[(size_t)row * g.ldh + col];
-        v = act_bwd(g.act, hv, v);
-        g.C[(size_t)row * g.ldc + col] = v;
-        csum += v;
-      } else {
-        atomicAdd(&g.C[(size_t)row * g.ldc + col], v);
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + 32 * j + r;
+    const bool col_ok = col < g.N;
+    float csum = 0.f;
+    float bias = 0.f;
+    if ((EPI == EPI_BIAS || EPI == EPI_BIAS_TANH) && g.bias != nullptr && col_ok) bias = g.bias[col];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < g.M && col_ok) {
+          float v = acc[i][j][e];
+          if (EPI == EPI_BIAS) {
+            g.C[(size_t)row * g.ldc + col] = v + bias;
+          } else if (EPI == EPI_BIAS_TANH) {
+            g.C[(size_t)row * g.ldc + col] = act_fwd(g.act, v + bias);
+          } else if (EPI == EPI_DTANH_COLSUM) {
+            const float hv = g.Hact[(size_t)row * g.ldh + col];
+            v = act_bwd(g.act, hv, v);
+            g.C[(size_t)row * g.ldc + col] = v;
+            csum += v;
+          } else {
+            atomicAdd(&g.C[(size_t)row * g.ldc + col], v);
+          }
+        }
       }
     }
-  }
-  if (EPI == EPI_DTANH_COLSUM && g.colsum != nullptr) {
-    csum += __shfl_xor(csum, 32, 64);
-    if (h == 0 && col_ok) atomicAdd(&g.colsum[col], csum);
+    if (EPI == EPI_DTANH_COLSUM && g.colsum != nullptr) {
+      csum += __shfl_xor(csum, 32, 64);
+      if (h == 0 && col_ok) atomicAdd(&g.colsum[col], csum);
+    }
   }
 }
 
