@@ -38,13 +38,14 @@ extern "C" {
 
 /* 2: config slot `persistent_train` became `activation`, `forward_x3` added, MOBROB_K_COUNT 6 -> 7 (profile_read arrays),
  *    MOBROB_BUF_COUNT / reserved[] resized -- a binding built against 1 must not load this library
- * 3: pi_hidden_ext / vf_hidden_ext (net_arch depths 4 .. 8), use_sde, sde_sample_freq appended to the config, activation codes 2 .. 8 */
+ * 3: pi_hidden_ext / vf_hidden_ext (net_arch depths 4 .. 8), use_sde, sde_sample_freq appended to the config, activation codes 2 .. 11 */
 #define MOBROB_PPO_ABI_VERSION 3
-/* policy_kwargs.activation_fn (SB3 ActorCriticPolicy; the reference splats ppo_kwargs into PPO verbatim, ppo.py:58): the torch.nn
- * modules whose derivative is a function of their output, with torch's default arguments (ELU alpha 1, LeakyReLU slope 0.01,
- * Softplus beta 1 / threshold 20, Hardtanh [-1, 1]) */
+/* policy_kwargs.activation_fn (SB3 ActorCriticPolicy; the reference splats ppo_kwargs into PPO verbatim, ppo.py:58): the
+ * parameter-free element-wise torch.nn modules with torch's default arguments (ELU alpha 1, LeakyReLU slope 0.01, Softplus beta 1 /
+ * threshold 20, Hardtanh [-1, 1], GELU approximate='none') */
 enum { MOBROB_ACT_TANH = 0, MOBROB_ACT_RELU = 1, MOBROB_ACT_ELU = 2, MOBROB_ACT_LEAKY_RELU = 3, MOBROB_ACT_SIGMOID = 4,
-       MOBROB_ACT_SOFTPLUS = 5, MOBROB_ACT_SOFTSIGN = 6, MOBROB_ACT_HARDTANH = 7, MOBROB_ACT_RELU6 = 8, MOBROB_ACT_COUNT = 9 };
+       MOBROB_ACT_SOFTPLUS = 5, MOBROB_ACT_SOFTSIGN = 6, MOBROB_ACT_HARDTANH = 7, MOBROB_ACT_RELU6 = 8, MOBROB_ACT_SILU = 9,
+       MOBROB_ACT_GELU = 10, MOBROB_ACT_MISH = 11, MOBROB_ACT_COUNT = 12 };
 
 enum {
   MOBROB_OK = 0,

@@ -177,7 +177,7 @@ _ALLOWED_GLOBALS = {
     ("collections", "deque"), ("collections", "OrderedDict"),
     # `policy_kwargs` holding an activation class is cloudpickled as a whole by SB3: the class travels by reference
     *(("torch.nn.modules.activation", cls) for cls in ("Tanh", "ReLU", "ELU", "LeakyReLU", "Sigmoid", "Softplus", "Softsign",
-                                                        "Hardtanh", "ReLU6")),
+                                                        "Hardtanh", "ReLU6", "SiLU", "GELU", "Mish")),
 }
 
 

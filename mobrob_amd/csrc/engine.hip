@@ -341,10 +341,11 @@ void launch_gemm(mobrob_ppo_engine* e, const GemmArgs& g, int ksplit = 1) {
 
 // Y[M x Nn] = act(X[M x K] . W[Nn x K]^T + bias)
 void linear_fwd(mobrob_ppo_engine* e, const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y,
-                int ldy, int M, int Nn, int K, bool tanh_) {
+                int ldy, int M, int Nn, int K, bool tanh_, float* Z = nullptr) {
   GemmArgs g{};
   g.A = X; g.B = W; g.C = Y; g.M = M; g.N = Nn; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldy; g.bias = bias;
   g.act = e->cfg.activation;
+  g.Z = (tanh_ && act_needs_z(g.act)) ? Z : nullptr; g.ldz = ldy;   // pre-activations for SiLU / GELU / Mish backward (same shape as Y)
   if (tanh_) launch_gemm<MODE_NT, EPI_BIAS_TANH>(e, g);
   else launch_gemm<MODE_NT, EPI_BIAS>(e, g);
 }
@@ -420,18 +421,22 @@ void repack(mobrob_ppo_engine* e) {
 
 // forward of both networks on `rows` device rows of padded observations (ld = Dp); mu ld = Ap, v ld = 1
 void forward_generic(mobrob_ppo_engine* e, const float* X, int rows, bool want_pi, float* mu_out, bool want_v,
-                     float* v_out) {
-  // layer 0 reads the zero-padded copy of its weights (observation rows are padded to Dp columns); one to three hidden layers
+                     float* v_out, bool keep_z = false) {
+  // layer 0 reads the zero-padded copy of its weights (observation rows are padded to Dp columns); one to eight hidden layers.
+  // keep_z (the training forward of a minibatch, rows <= Bl): layer l's pre-activations are left in its dz buffer for the backward
+  // epilogue of the activations that need them (act_needs_z)
   if (want_pi) {
-    linear_fwd(e, X, e->Dp, e->pW1p, e->Dp, Pp(e, e->tPB[0]), e->hp[0], e->Hp[0], rows, e->Hp[0], e->Dp, true);
+    linear_fwd(e, X, e->Dp, e->pW1p, e->Dp, Pp(e, e->tPB[0]), e->hp[0], e->Hp[0], rows, e->Hp[0], e->Dp, true, keep_z ? e->dzp[0] : nullptr);
     for (int l = 1; l < e->Lp; ++l)
-      linear_fwd(e, e->hp[l - 1], e->Hp[l - 1], Pp(e, e->tPW[l]), e->Hp[l - 1], Pp(e, e->tPB[l]), e->hp[l], e->Hp[l], rows, e->Hp[l], e->Hp[l - 1], true);
+      linear_fwd(e, e->hp[l - 1], e->Hp[l - 1], Pp(e, e->tPW[l]), e->Hp[l - 1], Pp(e, e->tPB[l]), e->hp[l], e->Hp[l], rows, e->Hp[l], e->Hp[l - 1], true,
+                 keep_z ? e->dzp[l] : nullptr);
     linear_fwd(e, e->hp[e->Lp - 1], e->HL, e->aWp, e->HL, Pp(e, T_AB), mu_out, e->Ap, rows, e->A, e->HL, false);
   }
   if (want_v) {
-    linear_fwd(e, X, e->Dp, e->vW1p, e->Dp, Pp(e, e->tVB[0]), e->hv[0], e->Hv[0], rows, e->Hv[0], e->Dp, true);
+    linear_fwd(e, X, e->Dp, e->vW1p, e->Dp, Pp(e, e->tVB[0]), e->hv[0], e->Hv[0], rows, e->Hv[0], e->Dp, true, keep_z ? e->dzv[0] : nullptr);
     for (int l = 1; l < e->Lv; ++l)
-      linear_fwd(e, e->hv[l - 1], e->Hv[l - 1], Pp(e, e->tVW[l]), e->Hv[l - 1], Pp(e, e->tVB[l]), e->hv[l], e->Hv[l], rows, e->Hv[l], e->Hv[l - 1], true);
+      linear_fwd(e, e->hv[l - 1], e->Hv[l - 1], Pp(e, e->tVW[l]), e->Hv[l - 1], Pp(e, e->tVB[l]), e->hv[l], e->Hv[l], rows, e->Hv[l], e->Hv[l - 1], true,
+                 keep_z ? e->dzv[l] : nullptr);
     linear_fwd(e, e->hv[e->Lv - 1], e->GL, e->vWp, e->GL, Pp(e, T_VB), v_out, 1, rows, 1, e->GL, false);
   }
 }
@@ -807,7 +812,8 @@ void cfg_widths(const mobrob_ppo_config_t* c, int* pw, int* vw) {
 
 static_assert(ACT_TANH == MOBROB_ACT_TANH && ACT_RELU == MOBROB_ACT_RELU && ACT_ELU == MOBROB_ACT_ELU && ACT_LEAKY_RELU == MOBROB_ACT_LEAKY_RELU &&
               ACT_SIGMOID == MOBROB_ACT_SIGMOID && ACT_SOFTPLUS == MOBROB_ACT_SOFTPLUS && ACT_SOFTSIGN == MOBROB_ACT_SOFTSIGN &&
-              ACT_HARDTANH == MOBROB_ACT_HARDTANH && ACT_RELU6 == MOBROB_ACT_RELU6 && ACT_COUNT == MOBROB_ACT_COUNT,
+              ACT_HARDTANH == MOBROB_ACT_HARDTANH && ACT_RELU6 == MOBROB_ACT_RELU6 && ACT_SILU == MOBROB_ACT_SILU &&
+              ACT_GELU == MOBROB_ACT_GELU && ACT_MISH == MOBROB_ACT_MISH && ACT_COUNT == MOBROB_ACT_COUNT,
               "kernels_generic.h activation codes are the header's");
 
 int check_cfg(const mobrob_ppo_config_t* c) {
@@ -2261,7 +2267,7 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
   hipLaunchKernelGGL(k_gather, dim3(cdiv(B * per, 256)), dim3(256), 0, e->stream, e->rows + start, B, e->obs, e->Dp,
                      e->actions, e->A, e->logp, e->adv, e->ret, e->Xg, e->actg, e->lpg, e->advg, e->retg, e->values,
                      e->clip_vf >= 0.0 ? e->oldvg : (float*)nullptr);
-  forward_generic(e, e->Xg, B, true, e->mu, true, e->vout);
+  forward_generic(e, e->Xg, B, true, e->mu, true, e->vout, true);
   LossArgs L{};
   L.mu = e->mu; L.ldmu = e->Ap; L.v = e->vout; L.actions = e->actg; L.old_logp = e->lpg; L.adv = e->advg;
   L.ret = e->retg; L.log_std = Pp(e, T_LOGSTD); L.advstat = e->advstat + 4 * (size_t)mb; L.B = B; L.A = e->A;

@@ -16,10 +16,14 @@ namespace mobrob {
 //   sigmoid    h (1 - h)                      softplus    1 - exp(-h)        (= sigmoid(z); torch beta 1, linear above 20)
 //   softsign   (1 - |h|)^2                    hardtanh    [-1 < h < 1]
 //   relu6      [0 < h < 6]
-// (SiLU / GELU / Mish are not monotonic: their derivative is not a function of h; refused by name at the API.)
+// SiLU / GELU / Mish are not monotonic: their derivative needs the PRE-activation z.  The training forward leaves z in the layer's
+// dz buffer (GemmArgs.Z; the backward epilogue of that layer reads the element it is about to overwrite):
+//   silu  s (1 + z (1 - s)), s = sigmoid(z)      gelu  Phi(z) + z phi(z)  (torch's default, exact erf form)
+//   mish  t + z s (1 - t^2), t = tanh(softplus(z))
 // ------------------------------------------------------------------------------------------------
 enum { ACT_TANH = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_LEAKY_RELU = 3, ACT_SIGMOID = 4, ACT_SOFTPLUS = 5, ACT_SOFTSIGN = 6,
-       ACT_HARDTANH = 7, ACT_RELU6 = 8, ACT_COUNT = 9 };
+       ACT_HARDTANH = 7, ACT_RELU6 = 8, ACT_SILU = 9, ACT_GELU = 10, ACT_MISH = 11, ACT_COUNT = 12 };
+__host__ __device__ __forceinline__ bool act_needs_z(int act) { return act >= ACT_SILU; }
 __device__ __forceinline__ float act_fwd(int act, float z) {
   switch (act) {
     case ACT_TANH: return tanhf(z);
@@ -30,7 +34,21 @@ __device__ __forceinline__ float act_fwd(int act, float z) {
     case ACT_SOFTPLUS: return z > 20.f ? z : log1pf(expf(z));
     case ACT_SOFTSIGN: return z / (1.0f + fabsf(z));
     case ACT_HARDTANH: return fminf(fmaxf(z, -1.f), 1.f);
-    default: return fminf(fmaxf(z, 0.f), 6.f);   // ACT_RELU6
+    case ACT_RELU6: return fminf(fmaxf(z, 0.f), 6.f);
+    case ACT_SILU: return z / (1.0f + expf(-z));
+    case ACT_GELU: return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f));
+    default: return z * tanhf(z > 20.f ? z : log1pf(expf(z)));   // ACT_MISH
+  }
+}
+// g * f'(z) for the activations whose derivative is not a function of their output
+__device__ __forceinline__ float act_bwd_z(int act, float z, float g) {
+  switch (act) {
+    case ACT_SILU: { const float s_ = 1.0f / (1.0f + expf(-z)); return g * (s_ * (1.0f + z * (1.0f - s_))); }
+    case ACT_GELU: return g * (0.5f * (1.0f + erff(z * 0.70710678118654752440f)) + z * expf(-0.5f * z * z) * 0.39894228040143267794f);
+    default: {   // ACT_MISH
+      const float t = tanhf(z > 20.f ? z : log1pf(expf(z))), s_ = 1.0f / (1.0f + expf(-z));
+      return g * (t + z * s_ * (1.0f - t * t));
+    }
   }
 }
 // g * f'(z) from h = f(z)
@@ -72,6 +90,7 @@ struct GemmArgs {
   int ldh;
   float* colsum;        // EPI_DTANH_COLSUM: [N] += column sums of the stored tile (bias gradient)
   int act;              // hidden activation (ACT_*): tanh is SB3's default for MlpPolicy; the others come from policy_kwargs activation_fn
+  float* Z; int ldz;    // EPI_BIAS_TANH, act_needs_z: where the pre-activations go (null: not kept).  EPI_DTANH_COLSUM reads them from C
   int kchunk;           // MODE_TN: batch rows per blockIdx.z
 };
 
@@ -187,9 +206,14 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
             g.C[(size_t)row * g.ldc + col] = v + bias;
           } else if (EPI == EPI_BIAS_TANH) {
             g.C[(size_t)row * g.ldc + col] = act_fwd(g.act, v + bias);
+            if (g.Z != nullptr) g.Z[(size_t)row * g.ldz + col] = v + bias;
           } else if (EPI == EPI_DTANH_COLSUM) {
-            const float hv = g.Hact[(size_t)row * g.ldh + col];
-            v = act_bwd(g.act, hv, v);
+            if (act_needs_z(g.act)) {
+              v = act_bwd_z(g.act, g.C[(size_t)row * g.ldc + col], v);   // C = the layer's dz buffer: it still holds z (training forward)
+            } else {
+              const float hv = g.Hact[(size_t)row * g.ldh + col];
+              v = act_bwd(g.act, hv, v);
+            }
             g.C[(size_t)row * g.ldc + col] = v;
             csum += v;
           } else {

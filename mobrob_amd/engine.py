@@ -30,11 +30,12 @@ def _f32c(a, shape=None):
 
 MAX_HIDDEN = 8   # kMaxHidden (csrc/device_utils.h): hidden layers per network
 
-# policy_kwargs `activation_fn`: lower-cased torch.nn class name -> (MOBROB_ACT_* code, torch.nn class name).  The modules whose
-# derivative is a function of their output, with torch's default arguments; tanh / ReLU as in the reference's SB3 defaults.
+# policy_kwargs `activation_fn`: lower-cased torch.nn class name -> (MOBROB_ACT_* code, torch.nn class name).  The parameter-free
+# element-wise modules with torch's default arguments; tanh is SB3's default for MlpPolicy (every reference YAML).
 ACTIVATIONS = OrderedDict([("tanh", (0, "Tanh")), ("relu", (1, "ReLU")), ("elu", (2, "ELU")), ("leakyrelu", (3, "LeakyReLU")),
                            ("sigmoid", (4, "Sigmoid")), ("softplus", (5, "Softplus")), ("softsign", (6, "Softsign")),
-                           ("hardtanh", (7, "Hardtanh")), ("relu6", (8, "ReLU6"))])
+                           ("hardtanh", (7, "Hardtanh")), ("relu6", (8, "ReLU6")), ("silu", (9, "SiLU")), ("gelu", (10, "GELU")),
+                           ("mish", (11, "Mish"))])
 
 
 def activation_name(act) -> str:
@@ -48,7 +49,7 @@ def activation_name(act) -> str:
     name = name.rsplit(".", 1)[-1].replace("_", "").lower()
     if name not in ACTIVATIONS:
         raise NotImplementedError(f"activation_fn {act!r}: implemented are {', '.join(v[1] for v in ACTIVATIONS.values())} "
-                                  "(modules whose derivative is a function of their output, torch's default arguments)")
+                                  "(parameter-free element-wise modules, torch's default arguments)")
     return name
 
 

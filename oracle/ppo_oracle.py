@@ -158,7 +158,13 @@ def _linear(x, w, b, acc=None):
     return (_mm(x, w.T, acc) + b).astype(F32)
 
 
-ACTIVATIONS = ("tanh", "relu", "elu", "leakyrelu", "sigmoid", "softplus", "softsign", "hardtanh", "relu6")
+ACTIVATIONS = ("tanh", "relu", "elu", "leakyrelu", "sigmoid", "softplus", "softsign", "hardtanh", "relu6", "silu", "gelu", "mish")
+NEEDS_PRE_ACTIVATION = ("silu", "gelu", "mish")   # not monotonic: the derivative is a function of z, not of f(z)
+
+
+def _erf(x):
+    """erf in float64 (Abramowitz-Stegun 7.1.26 is too coarse for 1e-5 parity: math.erf element-wise)."""
+    return np.vectorize(math.erf, otypes=[np.float64])(np.asarray(x, np.float64))
 
 
 def _activate(z, activation):
@@ -166,7 +172,7 @@ def _activate(z, activation):
     behind every Linear): nn.Tanh (default) or one of the torch.nn modules below with their default arguments
     [torch/nn/modules/activation.py: ReLU max(z, 0); ELU alpha 1: z > 0 ? z : exp(z) - 1; LeakyReLU negative_slope 0.01;
     Sigmoid; Softplus beta 1, threshold 20: z > 20 ? z : log(1 + exp(z)); Softsign z / (1 + |z|); Hardtanh clamp(z, -1, 1);
-    ReLU6 clamp(z, 0, 6)]."""
+    ReLU6 clamp(z, 0, 6); SiLU z sigmoid(z); GELU approximate='none': z Phi(z) = 0.5 z (1 + erf(z / sqrt 2)); Mish z tanh(softplus(z))]."""
     z = np.asarray(z, F32)
     one = F32(1.0)
     if activation == "tanh":
@@ -187,6 +193,32 @@ def _activate(z, activation):
         return np.clip(z, F32(-1.0), F32(1.0)).astype(F32)
     if activation == "relu6":
         return np.clip(z, F32(0.0), F32(6.0)).astype(F32)
+    if activation == "silu":
+        return (z / (one + np.exp(-z))).astype(F32)
+    if activation == "gelu":
+        return (0.5 * z.astype(np.float64) * (1.0 + _erf(z / math.sqrt(2.0)))).astype(F32)
+    if activation == "mish":
+        sp = np.where(z > F32(20.0), z, np.log1p(np.exp(np.minimum(z, F32(20.0))))).astype(F32)
+        return (z * np.tanh(sp)).astype(F32)
+    raise ValueError(f"activation {activation!r}")
+
+
+def _activation_grad_pre(z, g, activation):
+    """g * f'(z) for the non-monotonic activations, from the pre-activation z [torch's silu_backward / gelu_backward / mish_backward]:
+    silu s (1 + z (1 - s)); gelu Phi(z) + z phi(z); mish t + z s (1 - t^2) with t = tanh(softplus(z)), s = sigmoid(z)."""
+    z, g = np.asarray(z, F32), np.asarray(g, F32)
+    one = F32(1.0)
+    sg = (one / (one + np.exp(-z))).astype(F32)
+    if activation == "silu":
+        return (g * (sg * (one + z * (one - sg)))).astype(F32)
+    if activation == "gelu":
+        z64 = z.astype(np.float64)
+        d = 0.5 * (1.0 + _erf(z64 / math.sqrt(2.0))) + z64 * np.exp(-0.5 * z64 * z64) / math.sqrt(2.0 * math.pi)
+        return (g * d.astype(F32)).astype(F32)
+    if activation == "mish":
+        sp = np.where(z > F32(20.0), z, np.log1p(np.exp(np.minimum(z, F32(20.0))))).astype(F32)
+        t = np.tanh(sp).astype(F32)
+        return (g * (t + z * sg * (one - t * t))).astype(F32)
     raise ValueError(f"activation {activation!r}")
 
 
@@ -219,14 +251,19 @@ def _activation_grad(h, g, activation):
     raise ValueError(f"activation {activation!r}")
 
 
-def mlp_latents(p, obs, acc=None, activation="tanh"):
-    """Returns (per-layer activations of the policy net, of the value net); index 0 is the input."""
+def mlp_latents(p, obs, acc=None, activation="tanh", pre=None):
+    """Returns (per-layer activations of the policy net, of the value net); index 0 is the input.
+    pre: optional dict that receives the PRE-activations per network prefix (lists, index l = layer l's z) -- what the backward of
+    the non-monotonic activations needs."""
     x = np.asarray(obs).astype(F32)  # FlattenExtractor + obs.float()
     acts_pi, acts_vf = [x], [x]
-    for w, b in _net_layers(p, "mlp_extractor.policy_net"):
-        acts_pi.append(_activate(_linear(acts_pi[-1], w, b, acc), activation))
-    for w, b in _net_layers(p, "mlp_extractor.value_net"):
-        acts_vf.append(_activate(_linear(acts_vf[-1], w, b, acc), activation))
+    for prefix, acts in (("mlp_extractor.policy_net", acts_pi), ("mlp_extractor.value_net", acts_vf)):
+        zs = []
+        for w, b in _net_layers(p, prefix):
+            zs.append(_linear(acts[-1], w, b, acc))
+            acts.append(_activate(zs[-1], activation))
+        if pre is not None:
+            pre[prefix] = zs
     return acts_pi, acts_vf
 
 
@@ -479,7 +516,8 @@ def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, return
     actions = np.asarray(actions, F32)
     B = obs.shape[0]
     Bg = F32(B if denom is None else denom)
-    acts_pi, acts_vf = mlp_latents(p, obs, acc, activation=h.activation)
+    pre_z = {}
+    acts_pi, acts_vf = mlp_latents(p, obs, acc, activation=h.activation, pre=pre_z)
     mean = _linear(acts_pi[-1], p["action_net.weight"], p["action_net.bias"], acc)
     values = _linear(acts_vf[-1], p["value_net.weight"], p["value_net.bias"], acc)[:, 0]
     log_std = p["log_std"].astype(F32)
@@ -553,7 +591,10 @@ def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, return
         layers = _net_layers(p, prefix)
         for li in reversed(range(len(layers))):
             w, _ = layers[li]
-            g_z = _activation_grad(acts[li + 1], g_h, h.activation)
+            if h.activation in NEEDS_PRE_ACTIVATION:
+                g_z = _activation_grad_pre(pre_z[prefix][li], g_h, h.activation)
+            else:
+                g_z = _activation_grad(acts[li + 1], g_h, h.activation)
             grads[f"{prefix}.{2 * li}.weight"] = _mm(g_z.T, acts[li], acc)
             grads[f"{prefix}.{2 * li}.bias"] = _colsum(g_z, acc)
             g_h = _mm(g_z, w, acc)

@@ -28,7 +28,10 @@ CASES = [(f"act_{a}", a, (32, 24), (24, 32, 16)) for a in ACTS] + [
     ("depth5_3_elu", "elu", (24, 24, 16, 16, 8), (32, 16, 8)),
     ("depth8_relu", "relu", (24, 16, 16, 16, 16, 16, 16, 8), (16,) * 8),
     ("depth1_6_tanh", "tanh", (40,), (16, 24, 16, 8, 16, 8)),
+    # appended later (the cases above keep their seeds): activations whose derivative needs the pre-activation
+    ("act_silu", "silu", (32, 24), (24, 32, 16)), ("act_gelu", "gelu", (32, 24), (24, 32, 16)), ("act_mish", "mish", (32, 24), (24, 32, 16)),
 ]
+ACTS.update(silu=torch.nn.SiLU, gelu=torch.nn.GELU, mish=torch.nn.Mish)
 D, A, N, B = 14, 3, 40, 100
 
 

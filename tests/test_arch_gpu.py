@@ -67,7 +67,7 @@ def test_act_and_one_step_match_torch_golden(name):
 TRAIN_CASES = [("elu", (64, 48), (32, 64)), ("leakyrelu", (32, 32, 32), (64,)), ("sigmoid", (64, 64), (64, 64)),
                ("softplus", (48,), (48, 24)), ("softsign", (64, 64), (64, 64)), ("hardtanh", (32, 64), (64, 32)),
                ("relu6", (64, 64), (64, 64)), ("tanh", (32, 32, 24, 24), (32, 24, 32, 24)), ("relu", (24,) * 6, (32, 16, 32, 16, 8)),
-               ("elu", (16,) * 8, (16,) * 8)]
+               ("elu", (16,) * 8, (16,) * 8), ("silu", (64, 48), (32, 64)), ("gelu", (32, 32, 32), (64,)), ("mish", (64, 64), (64, 64))]
 
 
 @pytest.mark.parametrize("act,pi,vf", TRAIN_CASES)
@@ -116,7 +116,8 @@ def test_train_matches_oracle(act, pi, vf):
     e.close()
 
 
-@pytest.mark.parametrize("act,pi,vf", [("elu", (32,), (32, 24, 16, 24)), ("softplus", (32, 32), (24,) * 5), ("tanh", (16,) * 4, (16,) * 8)])
+@pytest.mark.parametrize("act,pi,vf", [("elu", (32,), (32, 24, 16, 24)), ("softplus", (32, 32), (24,) * 5), ("tanh", (16,) * 4, (16,) * 8),
+                                       ("gelu", (32, 32), (32, 16, 8))])
 def test_host_rollout_with_bootstrap_matches_oracle(act, pi, vf):
     """act / store / finish_rollout == oracle collect_rollout on the same env stream; truncated rows' rewards take
     gamma * V(terminal_obs) from the per-row value evaluator (value_net_row: any depth, any activation)."""
@@ -174,7 +175,8 @@ def test_device_rollout_bootstrap(act, pi, vf, kind):
 
 @pytest.mark.parametrize("kwargs", [dict(net_arch=[32, 32, 32, 32], activation_fn="ELU"),
                                     dict(net_arch=dict(pi=[32], vf=[32, 24, 16, 8, 8]), activation_fn="LeakyReLU", share_features_extractor=False),
-                                    dict(net_arch=[64, 64], activation_fn="Softsign", normalize_images=True)])
+                                    dict(net_arch=[64, 64], activation_fn="Softsign", normalize_images=True),
+                                    dict(net_arch=[32, 32], activation_fn="SiLU")])
 def test_ppo_learns_saves_and_loads(kwargs, tmp_path):
     """PPO(...) with these policy_kwargs (activation classes are given by torch.nn class where torch is importable): learns on the
     device goal env, writes an SB3-layout zip (state-dict keys in nn.Sequential numbering, policy_kwargs as SB3's one-blob form with
@@ -211,7 +213,7 @@ def test_ppo_learns_saves_and_loads(kwargs, tmp_path):
 
 def test_unsupported_policy_kwargs_are_refused_by_name():
     from mobrob_amd.rl_control.ppo import PPO
-    for pk, word in [(dict(activation_fn="SiLU"), "SiLU"), (dict(activation_fn="GELU"), "GELU"), (dict(net_arch=[8] * 9), "hidden"),
+    for pk, word in [(dict(activation_fn="PReLU"), "PReLU"), (dict(activation_fn="Softmax"), "Softmax"), (dict(net_arch=[8] * 9), "hidden"),
                      (dict(features_extractor_class="NatureCNN"), "features_extractor_class")]:
         with pytest.raises((NotImplementedError, ValueError), match=word):
             PPO("MlpPolicy", None, policy_kwargs=pk, _dims=(4, 6, 2))

@@ -287,5 +287,7 @@ def test_config_accepts_one_to_eight_hidden_layers_and_nothing_else():
     assert _lib.load().mobrob_ppo_device_bytes(C.byref(cfg), C.byref(n)) != 0
     for act in ("tanh", "ReLU", "elu", "leaky_relu", "Sigmoid", "softplus", "softsign", "hardtanh", "relu6"):
         assert PPOEngine.device_bytes(pi=(64, 64), vf=(64, 64), activation=act, **base) > 0
-    with pytest.raises(NotImplementedError, match="SiLU|silu"):
-        PPOEngine.make_config(pi=(64, 64), vf=(64, 64), activation="SiLU", **base)
+    for act in ("SiLU", "gelu", "Mish"):
+        assert PPOEngine.device_bytes(pi=(64, 64), vf=(64, 64), activation=act, **base) > 0
+    with pytest.raises(NotImplementedError, match="PReLU"):
+        PPOEngine.make_config(pi=(64, 64), vf=(64, 64), activation="PReLU", **base)   # (has a parameter of its own)

@@ -173,7 +173,7 @@ def test_policy_kwargs_beyond_net_arch(tmp_path):
     again = PPO.load(path)
     assert again.log_std_init == -0.5 and again.ortho_init is False and again.adam_eps == 1e-3 and again.adam_betas == (0.8, 0.95)
     assert all(np.array_equal(again.engine.get_params()[k], got[k]) for k in got)
-    for bad in (dict(activation_fn="GELU"), dict(optimizer_kwargs=dict(weight_decay=0.1)), dict(optimizer_class="SGD"),
+    for bad in (dict(activation_fn="PReLU"), dict(optimizer_kwargs=dict(weight_decay=0.1)), dict(optimizer_class="SGD"),
                 dict(features_extractor_class="NatureCNN"), dict(use_expln=True)):
         with pytest.raises(NotImplementedError):
             PPO("MlpPolicy", env, policy_kwargs=bad)

@@ -76,7 +76,7 @@ def arch_cases():
 
 
 ARCH_CASES = ["act_tanh", "act_relu", "act_elu", "act_leakyrelu", "act_sigmoid", "act_softplus", "act_softsign", "act_hardtanh",
-              "act_relu6", "depth4_tanh", "depth5_3_elu", "depth8_relu", "depth1_6_tanh"]
+              "act_relu6", "depth4_tanh", "depth5_3_elu", "depth8_relu", "depth1_6_tanh", "act_silu", "act_gelu", "act_mish"]
 
 
 def arch_case(name):
