@@ -1107,6 +1107,17 @@ def also_measured(args, job):
             "roofline": {k: o["roofline"].get(k) for k in ("kernel", "achieved", "peak", "frac", "avg_launch_ms", "launches", "power")}}
     except Exception as ex:  # noqa: BLE001
         res["doggo-4096env-2x256, forward_x3 off (all products on v_mfma_f32)"] = {"error": f"{type(ex).__name__}: {ex}"}
+    # the headline workload through the GENERIC GEMM chain (what every net_arch / activation_fn / use_sde outside the fused families
+    # runs on): one step is ~0.6 s
+    key = "doggo-4096env-2x256, generic GEMM chain (fast_kernels off)"
+    try:
+        import copy
+        ag = copy.copy(args)
+        ag.generic = True
+        o = bench_single(ag, "doggo-4096env-2x256", 1, 1, job, False)
+        res[key] = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": 1, "warmup": 1}
+    except Exception as ex:  # noqa: BLE001
+        res[key] = {"error": f"{type(ex).__name__}: {ex}"}
     if not getattr(args, "no_host_path", False):
         res["host_env_streaming_path"] = host_path_measurements(args, job)
     return res

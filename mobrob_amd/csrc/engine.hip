@@ -226,6 +226,7 @@ struct mobrob_ppo_engine {
   float *pred_obs = nullptr, *pred_act = nullptr;
   // gSDE (use_sde; generic chain only): per-env exploration matrices [N][HL][A], the single matrix [HL][A], staging for supplied noise,
   // the log_std-gradient GEMM's operands of a minibatch
+  int gemm_tiles = 0;   // MOBROB_GEMM_TILES: 0 = by shape (launch_gemm)
   bool sde = false, sde_hold = false;   // hold: the caller supplies the noise (mobrob_ppo_sde_set_noise); no automatic resampling
   float *sde_E = nullptr, *sde_E1 = nullptr, *sde_lat2 = nullptr, *sde_gsig = nullptr;
   // rollout streamer (host-env path): pinned staging + a side stream for the H2D/D2H copies
@@ -328,13 +329,16 @@ void launch_gemm_tiles(mobrob_ppo_engine* e, const GemmArgs& g, int ksplit) {
   hipLaunchKernelGGL((k_gemm<MODE, EPI, TM, TN>), grid, dim3(256), 0, e->stream, g);
 }
 // tiles per wave by shape: 2x2 wherever both extents leave room for it, 2x1 for narrow outputs (heads), 1x1 for tiny ones.
-// MOBROB_GEMM_TILES=1 keeps one tile per wave (A/B).
+// MOBROB_GEMM_TILES (read when the engine is created): 1 keeps one tile per wave (A/B); 21 / 22 force 2x1 / 2x2 wherever the output
+// has more than one tile in that direction, whatever the wave count (the parity tests drive small shapes through every form).
 template <int MODE, int EPI>
 void launch_gemm(mobrob_ppo_engine* e, const GemmArgs& g, int ksplit = 1) {
-  static const bool one_tile = getenv("MOBROB_GEMM_TILES") != nullptr && atoi(getenv("MOBROB_GEMM_TILES")) == 1;
+  const int f = e->gemm_tiles;
+  if (f == 22 && g.M > 32 && g.N > 32) return launch_gemm_tiles<MODE, EPI, 2, 2>(e, g, ksplit);
+  if ((f == 21 || f == 22) && g.M > 32) return launch_gemm_tiles<MODE, EPI, 2, 1>(e, g, ksplit);
   // fat wave tiles only while they still leave ~8 waves per CU: a rollout step (4096 rows) is 1024 one-tile waves, 256 as 2x2
   const long w22 = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * ksplit, w21 = (long)cdiv(g.M, 64) * cdiv(g.N, 32) * ksplit;
-  if (one_tile || g.M <= 32 || w21 < 2048) launch_gemm_tiles<MODE, EPI, 1, 1>(e, g, ksplit);
+  if (f != 0 || g.M <= 32 || w21 < 2048) launch_gemm_tiles<MODE, EPI, 1, 1>(e, g, ksplit);
   else if (g.N <= 32 || w22 < 2048) launch_gemm_tiles<MODE, EPI, 2, 1>(e, g, ksplit);
   else launch_gemm_tiles<MODE, EPI, 2, 2>(e, g, ksplit);
 }
@@ -1007,6 +1011,7 @@ int engine_create(const mobrob_ppo_config_t* cfg, void* arena, size_t arena_byte
   if (const char* v = getenv("MOBROB_PAIR64_MIN_TILES")) e->pair64_min_tiles = atoi(v);  // 0: block kernel for large minibatches
   if (const char* v = getenv("MOBROB_SPLIT64_MAX_TILES")) e->split64_max_tiles = atoi(v);  // 0: block kernel only (A/B, tests)
   if (const char* v = getenv("MOBROB_EPOCH_KERNEL")) e->epoch_kernel_on = atoi(v) != 0;     // 0: three launches per optimizer step, always
+  if (const char* v = getenv("MOBROB_GEMM_TILES")) e->gemm_tiles = atoi(v);                 // generic chain: tiles per wave (launch_gemm)
   CHK(engine_dims(e, cfg));
   HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   e->own_stream = true;
@@ -2446,6 +2451,12 @@ int mobrob_ppo_sde_reset_noise(mobrob_ppo_engine_t* e) {
 int mobrob_ppo_sde_set_noise(mobrob_ppo_engine_t* e, const float* z) {
   if (!e) return fail(MOBROB_ERR_INVALID, "null engine");
   if (!e->sde) return fail(MOBROB_ERR_STATE, "sde_set_noise: the engine was not created with use_sde");
+  if (e->sde_hold != (z != nullptr) && e->ro_exec) {
+    // a captured device rollout has the resampling launches (or their absence) baked in: capture again under the new mode
+    HIPC(hipStreamSynchronize(e->stream));
+    (void)hipGraphExecDestroy(e->ro_exec); e->ro_exec = nullptr;
+    if (e->ro_graph) { (void)hipGraphDestroy(e->ro_graph); e->ro_graph = nullptr; }
+  }
   e->sde_hold = z != nullptr;
   if (!z) return MOBROB_OK;
   const size_t HLA = (size_t)e->HL * e->A, n = (size_t)e->N * HLA;

@@ -217,3 +217,96 @@ def test_unsupported_policy_kwargs_are_refused_by_name():
                      (dict(features_extractor_class="NatureCNN"), "features_extractor_class")]:
         with pytest.raises((NotImplementedError, ValueError), match=word):
             PPO("MlpPolicy", None, policy_kwargs=pk, _dims=(4, 6, 2))
+
+
+def _rollout_for(p, act, D, A, T, N, rng, sde):
+    buf, lv, dones = synthetic_rollout(T, N, D, A, seed=5)
+    flat = buf["obs"].reshape(T * N, D)
+    mean, val = O.policy_outputs(p, flat, activation=act)
+    if sde:
+        sigma = O.sde_sigma(O.mlp_latents(p, flat, activation=act)[0][-1], p["log_std"])
+        acts = (mean + rng.standard_normal((T * N, A)).astype(np.float32) * sigma).astype(np.float32)
+        lp = O.normal_log_prob(mean, sigma, acts)
+    else:
+        acts = (mean + rng.standard_normal((T * N, A)).astype(np.float32) * np.exp(p["log_std"])).astype(np.float32)
+        lp = O.gaussian_log_prob(mean, p["log_std"], acts)
+    buf["actions"] = acts.reshape(T, N, A)
+    buf["log_probs"] = (lp + rng.normal(0, 0.1, T * N)).astype(np.float32).reshape(T, N)
+    buf["values"] = (val + rng.normal(0, 0.1, T * N)).astype(np.float32).reshape(T, N)
+    return buf, lv, dones
+
+
+@pytest.mark.parametrize("tiles", ["1", "21", "22"])
+@pytest.mark.parametrize("act,pi,vf,sde", [("tanh", (72, 40), (136,), False), ("elu", (40, 104, 72), (64, 64), False),
+                                           ("gelu", (96,), (40, 72), False), ("relu", (96,), (40, 72), True)])
+def test_every_gemm_tiling_matches_the_oracle(tiles, act, pi, vf, sde, monkeypatch):
+    """The generic chain's GEMM picks 1x1, 2x1 or 2x2 tiles of 32x32 per wave by launch size (engine.hip launch_gemm), which small
+    test shapes never reach: MOBROB_GEMM_TILES forces each form through shapes that are no multiple of its tile (rows 190 and 20,
+    widths 40 / 72 / 104 / 136, 27 observation columns, 5 actions) -- first minibatch's gradients, statistics and parameters after
+    two epochs against the oracle; the three forms agree with each other to rounding."""
+    monkeypatch.setenv("MOBROB_GEMM_TILES", tiles)
+    D, A, T, N, B, E = 27, 5, 30, 7, 190, 2
+    rng = np.random.default_rng(11)
+    p = O.init_params(D, A, pi, vf, seed=2)
+    p["log_std"] = (rng.normal(-1.5, 0.3, (pi[-1], A)) if sde else rng.normal(-0.3, 0.2, A)).astype(np.float32)
+    p["action_net.weight"] *= 30
+    buf, lv, dones = _rollout_for(p, act, D, A, T, N, rng, sde)
+    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=E, batch_size=B, learning_rate=3e-4, activation=act, use_sde=sde)
+    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, h.gamma, h.gae_lambda)
+    perms = np.stack([rng.permutation(T * N) for _ in range(E)])
+    e = _engine(D, A, N, T, pi, vf, batch_size=B, n_epochs=E, gamma=h.gamma, gae_lambda=h.gae_lambda, ent_coef=h.ent_coef,
+                learning_rate=h.learning_rate, activation=act, use_sde=sde)
+    e.set_params(p)
+    e.load_rollout(buf, lv, dones)
+    e.compute_gae()
+    e.epoch_begin(perms[0])
+    e.minibatch_grad(0)
+    got = e.unflatten(e.read("grads"))
+    _, og, _ = O.loss_and_grads(p, *O.gather_minibatch(buf, perms[0][:B]), h)
+    for k in og:
+        assert scaled_err(got[k], og[k]) < 1e-4, (k, scaled_err(got[k], og[k]))
+    stats = e.train(perms)
+    ostats = O.train(p, O.AdamState.zeros_like(p), buf, h, perms)
+    nmb = -(-T * N // B)
+    for k in ["policy_loss", "value_loss", "entropy_loss", "loss", "approx_kl", "clip_fraction", "grad_norm"]:
+        ref = float(np.mean([float(s[k]) for s in ostats[-nmb:]]))
+        assert abs(stats[k] - ref) < 2e-4 * max(1.0, abs(ref)), (k, stats[k], ref)
+    newp = e.get_params()
+    for k in p:
+        assert np.max(np.abs(newp[k] - p[k])) < 1e-4, (k, float(np.max(np.abs(newp[k] - p[k]))))
+    # rollout-time forward (NT launches over N rows) and the value pass through the same forced tiling
+    obs = rng.standard_normal((N, D)).astype(np.float32)
+    assert np.allclose(e.predict(obs, deterministic=True), np.clip(O.policy_outputs(p, obs, activation=act)[0], -1, 1), atol=1e-4)
+    e.close()
+
+
+@pytest.mark.parametrize("act,sde", [("tanh", False), ("silu", False), ("tanh", True)])
+def test_full_size_minibatch_on_the_generic_chain(act, sde):
+    """65 536 rows through the launch-size tile selection as shipped (2x2 tiles for the hidden layers, 2x1 for the heads, batch
+    split with float atomics for the weight gradients) at widths no fused family covers: every gradient tensor of one minibatch
+    against the float64-accumulating oracle."""
+    D, A, T, N, pi, vf = 26, 3, 64, 1024, (128, 128), (128, 96)
+    B = T * N
+    rng = np.random.default_rng(3)
+    p = O.init_params(D, A, pi, vf, seed=7)
+    p["log_std"] = (rng.normal(-1.5, 0.3, (pi[-1], A)) if sde else rng.normal(-0.3, 0.2, A)).astype(np.float32)
+    p["action_net.weight"] *= 30
+    buf, lv, dones = _rollout_for(p, act, D, A, T, N, rng, sde)
+    h = O.Hyper(ent_coef=0.01, n_epochs=1, batch_size=B, activation=act, use_sde=sde)
+    buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, h.gamma, h.gae_lambda)
+    e = _engine(D, A, N, T, pi, vf, batch_size=B, n_epochs=1, ent_coef=h.ent_coef, activation=act, use_sde=sde)
+    assert e.x3_mode() == 0
+    e.set_params(p)
+    e.load_rollout(buf, lv, dones)
+    perm = rng.permutation(B)
+    e.epoch_begin(perm)
+    e.minibatch_grad(0)
+    got = e.unflatten(e.read("grads"))
+    ostats, og, _ = O.loss_and_grads(p, *O.gather_minibatch(buf, perm), h, acc=np.float64)
+    for k in og:
+        assert scaled_err(got[k], og[k]) < 1e-4, (k, scaled_err(got[k], og[k]))
+    e.minibatch_apply()
+    stats = e.fetch_step_stats()[-1]
+    for i, k in enumerate(["policy_loss", "value_loss", "entropy_loss", "loss", "approx_kl", "clip_fraction"]):
+        assert abs(stats[i] - float(ostats[k])) < 1e-4 * max(1.0, abs(float(ostats[k]))), (k, stats[i], float(ostats[k]))
+    e.close()

@@ -177,7 +177,7 @@ def test_own_draws_follow_the_schedule(freq, kind):
             noise = np.einsum("nk,nka->na", lat[t], thetas[t])
             assert scaled_err(acts_all[t], mean[t] + noise) < 1e-4, t
         zz = thetas[0] / std
-        assert abs(float(zz.mean())) < 0.05 and abs(float(zz.std()) - 1.0) < 0.05
+        assert abs(float(zz.mean())) < 0.12 and abs(float(zz.std()) - 1.0) < 0.1      # 1024 draws: four standard errors
         zf = zz.reshape(N, -1)                                             # environments draw independently
         assert len(np.unique(zf.round(6), axis=0)) == N and abs(float(np.mean(np.sum(zf[:-1] * zf[1:], axis=1)) / zf.shape[1])) < 0.15
     else:
@@ -225,3 +225,31 @@ def test_ppo_with_sde_learns_saves_and_loads(tmp_path):
     for bad in (dict(use_expln=True), dict(full_std=False), dict(squash_output=True)):
         with pytest.raises(NotImplementedError):
             PPO("MlpPolicy", None, use_sde=True, policy_kwargs=bad, _dims=(4, 6, 2))
+
+
+def test_supplied_noise_holds_through_a_device_rollout_captured_before_it():
+    """A device rollout is replayed from a captured graph with the resampling launches baked in; supplying the matrices afterwards
+    must take effect (the graph is captured again): every step of the next rollout uses exactly the supplied theta, and releasing
+    the hold brings the engine's own draws back."""
+    D, A, N, T, pi, vf = 14, 2, 32, 8, (32, 8), (32,)
+    p = O.init_params(D, A, pi, vf, seed=1)
+    p["log_std"] = np.full((pi[-1], A), -1.0, np.float32)
+    e = _engine(D, A, N, T, pi, vf, batch_size=N * T, n_epochs=1, sde_sample_freq=2, seed=5)
+    e.set_params(p)
+    e.collect_synthetic(p_term=0.02, time_limit=9)          # captures the graph, own draws every 2 steps
+    e.synchronize()
+    z = np.random.default_rng(3).standard_normal((N, pi[-1], A)).astype(np.float32)
+    theta = O.sde_exploration_matrices(p["log_std"], z)
+    e.sde_set_noise(z)
+    e.collect_synthetic(p_term=0.02, time_limit=9)
+    e.synchronize()
+    obs_all, acts_all = e.read("obs")[:T], e.read("actions")
+    for t in range(T):
+        lat, mean = O.mlp_latents(p, obs_all[t])[0][-1], O.policy_outputs(p, obs_all[t])[0]
+        assert scaled_err(acts_all[t], mean + np.einsum("nk,nka->na", lat, theta)) < 1e-4, t
+    assert np.array_equal(e.read("sde_noise"), theta.astype(np.float32)) or scaled_err(e.read("sde_noise"), theta) < 1e-6
+    e.sde_set_noise(None)
+    e.collect_synthetic(p_term=0.02, time_limit=9)
+    e.synchronize()
+    assert scaled_err(e.read("sde_noise"), theta) > 0.1
+    e.close()
