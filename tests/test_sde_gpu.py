@@ -197,21 +197,28 @@ def test_own_draws_follow_the_schedule(freq, kind):
     e.close()
 
 
-def test_ppo_with_sde_learns_saves_and_loads(tmp_path):
+@pytest.mark.parametrize("vec_env_type", ["device_goal", "native", "dummy"])
+def test_ppo_with_sde_learns_saves_and_loads(vec_env_type, tmp_path):
+    """PPO(use_sde=True) through PPOCtrl on the device env, the native C host env (pipelined row ranges: each range redraws its own
+    environments' matrices) and Python envs stepped in process."""
     from mobrob_amd import checkpoint as ck
     from mobrob_amd.rl_control.ppo import PPOCtrl, PPO
     cfg = {"ppo_kwargs": {"policy": "MlpPolicy", "n_steps": 32, "batch_size": 256, "n_epochs": 2, "use_sde": True, "sde_sample_freq": 4,
                           "policy_kwargs": {"net_arch": [32, 32], "log_std_init": -2.0}},
-           "env_name": "point", "time_limit": 50, "n_envs": 64, "vec_env_type": "device_goal", "enable_gui": False, "seed": 0}
+           "env_name": "point", "time_limit": 50, "n_envs": 64 if vec_env_type != "dummy" else 8, "vec_env_type": vec_env_type,
+           "enable_gui": False, "seed": 0}
     ctrl = PPOCtrl.from_config(cfg)
     ppo = ctrl.ppo
     assert ppo.use_sde and ppo.sde_sample_freq == 4 and ppo.engine.get_params()["log_std"].shape == (32, ppo.act_dim)
     assert np.all(ppo.engine.get_params()["log_std"] == -2.0)
     before = ppo.engine.get_flat_params()
-    ppo.learn(total_timesteps=3 * 32 * 64)
+    ppo.learn(total_timesteps=3 * 32 * ppo.n_envs)
     after = ppo.engine.get_flat_params()
     assert np.isfinite(after).all() and not np.array_equal(before, after)
     assert not np.array_equal(ppo.engine.get_params()["log_std"], np.full((32, ppo.act_dim), -2.0, np.float32))   # the matrix is trained
+    # the rollout the last update was computed on: stored log-probs are the state-dependent distribution's at the stored actions
+    # (under the parameters BEFORE that update, so only finiteness and the clipped actions' range are checked here)
+    assert np.isfinite(ppo.engine.read("log_probs")).all() and np.isfinite(ppo.engine.read("actions")).all()
     path = str(tmp_path / "sde.zip")
     ppo.save(path)
     z = ck.load_zip(path)
