@@ -102,10 +102,12 @@ typedef struct mobrob_ppo_config {
   int32_t pi_hidden_ext[5];   /* widths of policy hidden layers 4 .. 8 (a width of 0 ends the list) */
   int32_t vf_hidden_ext[5];   /* likewise for the value network */
   int32_t use_sde;            /* PPO(use_sde=True): generalised state-dependent exploration (SB3 StateDependentNoiseDistribution with its
-                                 defaults: full_std, no expln, no squashing, learn_features=False).  log_std becomes a [HL][A] matrix (HL =
+                                 defaults; full_std / use_expln below; no squashing, learn_features=False).  log_std becomes a [HL][A] matrix (HL =
                                  width of the last policy hidden layer); generic GEMM chain.  Default 0 */
   int32_t sde_sample_freq;    /* PPO(sde_sample_freq): new exploration matrices every this many rollout steps (-1: only at the start of a
                                  rollout, SB3's default) */
+  int32_t sde_full_std;       /* policy_kwargs full_std (default 1): 0 = one standard deviation per latent unit, log_std is [HL][1] */
+  int32_t sde_use_expln;      /* policy_kwargs use_expln (default 0): std = exp(ls) for ls <= 0, log1p(ls + 1e-6) + 1 above       */
 } mobrob_ppo_config_t;
 
 /* Fill `cfg` with SB3 2.0.0 defaults (Appendix A.1).  Replaces PPO.__init__'s default kwargs. */

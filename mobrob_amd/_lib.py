@@ -35,7 +35,7 @@ class Config(C.Structure):
         ("rank", C.c_int32), ("world_size", C.c_int32), ("fast_kernels", C.c_int32), ("rollout_graph", C.c_int32), ("rollout_persistent", C.c_int32),
         ("activation", C.c_int32), ("forward_x3", C.c_int32), ("pi_hidden3", C.c_int32), ("vf_hidden3", C.c_int32),
         ("reserved", C.c_int32 * 1), ("pi_hidden_ext", C.c_int32 * 5), ("vf_hidden_ext", C.c_int32 * 5),
-        ("use_sde", C.c_int32), ("sde_sample_freq", C.c_int32),
+        ("use_sde", C.c_int32), ("sde_sample_freq", C.c_int32), ("sde_full_std", C.c_int32), ("sde_use_expln", C.c_int32),
     ]
 
 

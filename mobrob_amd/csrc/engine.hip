@@ -228,7 +228,8 @@ struct mobrob_ppo_engine {
   // the log_std-gradient GEMM's operands of a minibatch
   int gemm_tiles = 0;   // MOBROB_GEMM_TILES: 0 = by shape (launch_gemm)
   bool sde = false, sde_hold = false;   // hold: the caller supplies the noise (mobrob_ppo_sde_set_noise); no automatic resampling
-  float *sde_E = nullptr, *sde_E1 = nullptr, *sde_lat2 = nullptr, *sde_gsig = nullptr;
+  float *sde_E = nullptr, *sde_E1 = nullptr, *sde_lat2 = nullptr, *sde_gsig = nullptr, *sde_graw = nullptr;
+  SdeMode sde_mode{1, 0};   // policy_kwargs full_std / use_expln
   // rollout streamer (host-env path): pinned staging + a side stream for the H2D/D2H copies
   hipStream_t cstream = nullptr;
   hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_store = nullptr;
@@ -485,7 +486,7 @@ void run_gae(mobrob_ppo_engine* e) {
 // gSDE: new exploration matrices for env rows [r0, r0 + n) (and, with `single`, the one matrix predict() uses for foreign batches)
 void sde_resample(mobrob_ppo_engine* e, int r0, int n, uint32_t draw, const uint32_t* draw_base, bool single) {
   const int HLA = e->HL * e->A, per = cdiv(HLA, 4);
-  hipLaunchKernelGGL(k_sde_resample, dim3(cdiv((n + (single ? 1 : 0)) * per, 256)), dim3(256), 0, e->stream, Pp(e, T_LOGSTD), HLA, r0, n,
+  hipLaunchKernelGGL(k_sde_resample, dim3(cdiv((n + (single ? 1 : 0)) * per, 256)), dim3(256), 0, e->stream, Pp(e, T_LOGSTD), HLA, e->A, e->sde_mode, r0, n,
                      eps_seed(e) ^ 0x5DE5DE5DE5DE5DEull, draw, draw_base, e->sde_E, single ? e->sde_E1 : (float*)nullptr);
 }
 
@@ -515,7 +516,7 @@ void act_rows(mobrob_ppo_engine* e, int t, int r0, int n, const float* eps_dev_o
     const int freq = e->cfg.sde_sample_freq;
     if (!e->sde_hold && (t == 0 || (freq > 0 && t % freq == 0))) sde_resample(e, r0, n, draw, draw_base, r0 == 0);
     hipLaunchKernelGGL(k_sample_sde, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, e->hp[e->Lp - 1], e->HL, Pp(e, T_LOGSTD),
-                       e->sde_E, r0, 0, n, e->HL, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high,
+                       e->sde_E, r0, 0, n, e->HL, e->A, e->sde_mode, (float)e->cfg.action_low, (float)e->cfg.action_high,
                        e->actions + row * e->A, clip_out, e->logp + row);
     return;
   }
@@ -841,6 +842,8 @@ int check_cfg(const mobrob_ppo_config_t* c) {
   if (c->batch_size % c->world_size) return fail(MOBROB_ERR_INVALID, "batch_size must be divisible by world_size");
   if ((int64_t)c->n_envs * c->n_steps > (int64_t)1 << 30) return fail(MOBROB_ERR_INVALID, "rollout too large");
   if (c->use_sde != 0 && c->use_sde != 1) return fail(MOBROB_ERR_INVALID, "use_sde must be 0 or 1");
+  if ((c->sde_full_std != 0 && c->sde_full_std != 1) || (c->sde_use_expln != 0 && c->sde_use_expln != 1))
+    return fail(MOBROB_ERR_INVALID, "sde_full_std / sde_use_expln must be 0 or 1");
   if (c->activation < 0 || c->activation >= MOBROB_ACT_COUNT) return fail(MOBROB_ERR_INVALID, "activation must be one of MOBROB_ACT_* (0 .. %d)", MOBROB_ACT_COUNT - 1);
   return MOBROB_OK;
 }
@@ -866,7 +869,7 @@ void mobrob_ppo_default_config(mobrob_ppo_config_t* c) {
   c->rollout_graph = 1;
   c->rollout_persistent = 1;
   c->forward_x3 = 1;
-  c->use_sde = 0; c->sde_sample_freq = -1;
+  c->use_sde = 0; c->sde_sample_freq = -1; c->sde_full_std = 1; c->sde_use_expln = 0;
 }
 
 void* mobrob_ppo_host_alloc(size_t bytes) {
@@ -931,7 +934,8 @@ int engine_dims(mobrob_ppo_engine* e, const mobrob_ppo_config_t* cfg) {
   int sizes[kMaxTensors] = {0};
   int nt = 0;
   e->sde = cfg->use_sde != 0;
-  sizes[nt++] = e->sde ? e->HL * e->A : e->A;                     // log_std ([A]; gSDE: [HL][A])
+  e->sde_mode = SdeMode{cfg->sde_full_std != 0, cfg->sde_use_expln != 0};
+  sizes[nt++] = e->sde ? e->HL * (e->sde_mode.full ? e->A : 1) : e->A;   // log_std ([A]; gSDE: [HL][A], or [HL][1] without full_std)
   for (int l = 0; l < e->Lp; ++l) { e->tPW[l] = nt; sizes[nt++] = e->Hp[l] * (l ? e->Hp[l - 1] : e->D); e->tPB[l] = nt; sizes[nt++] = e->Hp[l]; }
   for (int l = 0; l < e->Lv; ++l) { e->tVW[l] = nt; sizes[nt++] = e->Hv[l] * (l ? e->Hv[l - 1] : e->D); e->tVB[l] = nt; sizes[nt++] = e->Hv[l]; }
   e->tAW = nt; sizes[nt++] = e->A * e->HL; e->tAB = nt; sizes[nt++] = e->A;
@@ -979,7 +983,7 @@ int engine_alloc(mobrob_ppo_engine* e) {
   CHK(dalloc(e, &e->pred_obs, R * Dp)); CHK(dalloc(e, &e->pred_act, R * A));
   if (e->sde) {
     CHK(dalloc(e, &e->sde_E, N * (size_t)e->HL * A)); CHK(dalloc(e, &e->sde_E1, (size_t)e->HL * A));
-    CHK(dalloc(e, &e->sde_lat2, Bl * e->HL)); CHK(dalloc(e, &e->sde_gsig, Bl * e->Ap));
+    CHK(dalloc(e, &e->sde_lat2, Bl * e->HL)); CHK(dalloc(e, &e->sde_gsig, Bl * e->Ap)); CHK(dalloc(e, &e->sde_graw, (size_t)e->HL * A));
   }
   CHK(dalloc(e, &e->gstate[0], N * kGoalStateFloats)); CHK(dalloc(e, &e->gstate[1], N * kGoalStateFloats));
   CHK(dalloc(e, &e->ep_stats, kEpStatsDoubles));
@@ -2281,16 +2285,18 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
   L.ent_coef = (float)e->cfg.ent_coef; L.inv_bg = inv_bg; L.dmu = e->dmu; L.lddmu = e->Ap; L.dv = e->dv; L.lddv = 8;
   L.sums = sums; L.g_log_std = Gp(e, T_LOGSTD); L.g_b_action = Gp(e, T_AB); L.g_b_value = Gp(e, T_VB);
   if (e->sde) {
-    L.lat = e->hp[e->Lp - 1]; L.HL = e->HL; L.gsig = e->sde_gsig; L.ldg = e->Ap; L.lat2 = e->sde_lat2;
+    L.lat = e->hp[e->Lp - 1]; L.HL = e->HL; L.sde = e->sde_mode; L.gsig = e->sde_gsig; L.ldg = e->Ap; L.lat2 = e->sde_lat2;
     HIPC(hipMemsetAsync(e->sde_gsig, 0, (size_t)B * e->Ap * 4, e->stream));
+    HIPC(hipMemsetAsync(e->sde_graw, 0, (size_t)e->HL * e->A * 4, e->stream));
   }
   // padding columns of dmu/dv must be zero (K padding of the NN GEMM)
   HIPC(hipMemsetAsync(e->dmu, 0, (size_t)B * e->Ap * 4, e->stream));
   HIPC(hipMemsetAsync(e->dv, 0, (size_t)B * 8 * 4, e->stream));
   hipLaunchKernelGGL(k_loss, dim3(cdiv(B, 256)), dim3(256), 0, e->stream, L);
-  if (e->sde) {   // g_log_std [HL][A] = 2 exp(log_std)^2 * ((latent^2)^T . gsig): the entropy term is inside gsig
-    linear_bwd_weight(e, e->sde_lat2, e->HL, e->sde_gsig, e->Ap, Gp(e, T_LOGSTD), e->A, e->HL, e->A, B);
-    hipLaunchKernelGGL(k_sde_scale_grad, dim3(cdiv(e->HL * e->A, 256)), dim3(256), 0, e->stream, Gp(e, T_LOGSTD), Pp(e, T_LOGSTD), e->HL * e->A);
+  if (e->sde) {   // g_log_std = 2 std (d std / d log_std) * ((latent^2)^T . gsig) (summed over the actions without full_std): the entropy term is inside gsig
+    linear_bwd_weight(e, e->sde_lat2, e->HL, e->sde_gsig, e->Ap, e->sde_graw, e->A, e->HL, e->A, B);
+    hipLaunchKernelGGL(k_sde_scale_grad, dim3(cdiv(e->HL * e->A, 256)), dim3(256), 0, e->stream, Gp(e, T_LOGSTD), e->sde_graw, Pp(e, T_LOGSTD), e->HL,
+                       e->A, e->sde_mode);
   } else {
     hipLaunchKernelGGL(k_entropy_grad, dim3(1), dim3(64), 0, e->stream, Gp(e, T_LOGSTD), e->A, (float)e->cfg.ent_coef,
                        (float)B, inv_bg);
@@ -2463,7 +2469,7 @@ int mobrob_ppo_sde_set_noise(mobrob_ppo_engine_t* e, const float* z) {
   if (n > (size_t)1 << 30) return fail(MOBROB_ERR_INVALID, "sde_set_noise: too many matrix elements");
   // staged through the matrices' own storage: z is uploaded into it and scaled in place
   HIPC(hipMemcpyAsync(e->sde_E, z, n * 4, hipMemcpyHostToDevice, e->stream));
-  hipLaunchKernelGGL(k_sde_from_z, dim3(cdiv((int)n, 256)), dim3(256), 0, e->stream, e->sde_E, Pp(e, T_LOGSTD), (int)HLA, (int)n, e->sde_E);
+  hipLaunchKernelGGL(k_sde_from_z, dim3(cdiv((int)n, 256)), dim3(256), 0, e->stream, e->sde_E, Pp(e, T_LOGSTD), (int)HLA, e->A, e->sde_mode, (int)n, e->sde_E);
   hipLaunchKernelGGL(k_copy_f32, dim3(cdiv((int)HLA, 256)), dim3(256), 0, e->stream, e->sde_E, e->sde_E1, (int)HLA);   // exploration_mat := env 0's
   HIPC(hipGetLastError());
   HIPC(hipStreamSynchronize(e->stream));   // z may be pageable host memory
@@ -3072,7 +3078,7 @@ int mobrob_ppo_predict(mobrob_ppo_engine_t* e, const float* obs, int32_t n, int3
         if (e->sde) {   // get_noise: the environments' own matrices for a batch of n_envs rows, else the single exploration_mat
           const bool own = n == e->N;
           hipLaunchKernelGGL(k_sample_sde, dim3(cdiv(c, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, e->hp[e->Lp - 1], e->HL, Pp(e, T_LOGSTD),
-                             own ? e->sde_E : e->sde_E1, s, own ? 0 : 1, c, e->HL, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high,
+                             own ? e->sde_E : e->sde_E1, s, own ? 0 : 1, c, e->HL, e->A, e->sde_mode, (float)e->cfg.action_low, (float)e->cfg.action_high,
                              (float*)nullptr, scratch, (float*)nullptr);
           HIPC(hipMemcpyAsync(actions + (size_t)s * e->A, scratch, (size_t)c * e->A * 4, hipMemcpyDeviceToHost, e->stream));
           if (values) HIPC(hipMemcpyAsync(values + s, e->vout, (size_t)c * 4, hipMemcpyDeviceToHost, e->stream));

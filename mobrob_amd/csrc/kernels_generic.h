@@ -301,9 +301,22 @@ __global__ void k_sample(const float* __restrict__ mu, int ldmu, const float* __
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kStreamSde = 0x53444531u;   // 'SDE1'
 constexpr float kSdeEpsilon = 1e-6f;
+// The two shape / parametrisation options of the distribution (policy_kwargs full_std, use_expln):
+//   full (SB3's default): log_std is [HL][A]; else [HL][1], one standard deviation per latent unit shared by the actions
+//   expln: std = exp(ls) for ls <= 0, log1p(ls + 1e-6) + 1 above (get_std: keeps the standard deviation from growing too fast)
+struct SdeMode { int full, expln; };
+__device__ __forceinline__ float sde_std(float ls, int expln) {
+  return (expln && ls > 0.f) ? log1pf(ls + kSdeEpsilon) + 1.0f : expf(ls);
+}
+// d std / d log_std
+__device__ __forceinline__ float sde_dstd(float ls, int expln) {
+  return (expln && ls > 0.f) ? 1.0f / (1.0f + (ls + kSdeEpsilon)) : expf(ls);
+}
+// log_std entry of (latent unit k, action a)
+__device__ __forceinline__ float sde_ls(const float* __restrict__ log_std, int k, int a, int A, int full) { return log_std[full ? k * A + a : k]; }
 // theta rows [row0, row0 + nrows) of E [N][HL * A] (+ the single matrix E1 by block row `nrows`): one thread per four elements.
 // The matrix of env n at draw index d is a function of (n, d), not of the launch that draws it.
-__global__ void k_sde_resample(const float* __restrict__ log_std, int HLA, int row0, int nrows, uint64_t seed, uint32_t draw_rel,
+__global__ void k_sde_resample(const float* __restrict__ log_std, int HLA, int A, SdeMode md, int row0, int nrows, uint64_t seed, uint32_t draw_rel,
                                const uint32_t* __restrict__ draw_base, float* __restrict__ E, float* __restrict__ E1) {
   const int per = (HLA + 3) / 4;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -316,17 +329,17 @@ __global__ void k_sde_resample(const float* __restrict__ log_std, int HLA, int r
   float* out = single ? E1 : E + (size_t)(row0 + r) * HLA;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    if (4 * c + j < HLA) out[4 * c + j] = z[j] * expf(log_std[4 * c + j]);
+    if (4 * c + j < HLA) out[4 * c + j] = z[j] * sde_std(sde_ls(log_std, (4 * c + j) / A, (4 * c + j) % A, A, md.full), md.expln);
 }
 // the same from caller-supplied standard normals z [rows][HL * A] (tests / the oracle's noise as an INPUT, like `eps`)
-__global__ void k_sde_from_z(const float* __restrict__ z, const float* __restrict__ log_std, int HLA, int n, float* __restrict__ E) {
+__global__ void k_sde_from_z(const float* __restrict__ z, const float* __restrict__ log_std, int HLA, int A, SdeMode md, int n, float* __restrict__ E) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) E[i] = z[i] * expf(log_std[i % HLA]);
+  if (i < n) E[i] = z[i] * sde_std(sde_ls(log_std, (i % HLA) / A, i % A, A, md.full), md.expln);
 }
 // rollout-time sampling epilogue under gSDE: one thread per env row.  E: the rows' matrices ([row][HL][A], erow0 = matrix row of
 // row 0) or, with single != 0, ONE matrix for every row (SB3 get_noise when the batch is not the exploration batch).
 __global__ void k_sample_sde(const float* __restrict__ mu, int ldmu, const float* __restrict__ lat, int ldl, const float* __restrict__ log_std,
-                             const float* __restrict__ E, int erow0, int single, int n, int HL, int A, float lo, float hi,
+                             const float* __restrict__ E, int erow0, int single, int n, int HL, int A, SdeMode md, float lo, float hi,
                              float* __restrict__ act_raw, float* __restrict__ act_clip, float* __restrict__ logp_out) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n) return;
@@ -336,7 +349,7 @@ __global__ void k_sample_sde(const float* __restrict__ mu, int ldmu, const float
   for (int a = 0; a < A; ++a) {
     float noise = 0.f, var = 0.f;
     for (int k = 0; k < HL; ++k) {
-      const float lk = l[k], sd = expf(log_std[k * A + a]);
+      const float lk = l[k], sd = sde_std(sde_ls(log_std, k, a, A, md.full), md.expln);
       noise = fmaf(lk, Er[k * A + a], noise);
       var = fmaf(lk * lk, sd * sd, var);
     }
@@ -868,7 +881,7 @@ struct LossArgs {
   float* g_log_std; float* g_b_action; float* g_b_value;
   // gSDE (lat != nullptr): the policy's last hidden activations of the minibatch [B][HL] (ld = HL), log_std is [HL][A];
   // gsig [B][ldg] <- dLoss / d sigma^2 per (row, action), lat2 [B][HL] <- latent^2 (the operands of the log_std gradient GEMM)
-  const float* lat; int HL;
+  const float* lat; int HL; SdeMode sde;
   float* gsig; int ldg; float* lat2;
 };
 
@@ -883,10 +896,10 @@ __device__ __forceinline__ void adv_mean_std(const double* st, float* mean, floa
 }
 
 // sigma of action a of one row under gSDE: sqrt(sum_k latent_k^2 exp(log_std[k][a])^2 + 1e-6)
-__device__ __forceinline__ float sde_sigma(const float* __restrict__ l, const float* __restrict__ log_std, int HL, int A, int a) {
+__device__ __forceinline__ float sde_sigma(const float* __restrict__ l, const float* __restrict__ log_std, int HL, int A, int a, SdeMode md) {
   float var = 0.f;
   for (int k = 0; k < HL; ++k) {
-    const float lk = l[k], sd = expf(log_std[k * A + a]);
+    const float lk = l[k], sd = sde_std(sde_ls(log_std, k, a, A, md.full), md.expln);
     var = fmaf(lk * lk, sd * sd, var);
   }
   return sqrtf(var + kSdeEpsilon);
@@ -904,7 +917,7 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs L) {
     if (L.normalize && on) a = (a - mean) / (sd + 1e-8f);
     float lp = 0.f;
     for (int k = 0; k < L.A; ++k) {
-      const float sdv = L.lat != nullptr ? sde_sigma(L.lat + (size_t)i * L.HL, L.log_std, L.HL, L.A, k) : expf(L.log_std[k]);
+      const float sdv = L.lat != nullptr ? sde_sigma(L.lat + (size_t)i * L.HL, L.log_std, L.HL, L.A, k, L.sde) : expf(L.log_std[k]);
       const float d = L.actions[(size_t)i * L.A + k] - L.mu[(size_t)i * L.ldmu + k];
       lp += -(d * d) / (2.0f * (sdv * sdv)) - logf(sdv) - kLogSqrt2Pi;
       s_ent += (0.5f + kLogSqrt2Pi) + logf(sdv);
@@ -929,7 +942,7 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs L) {
   for (int k = 0; k < L.A; ++k) {
     float gm = 0.f, gls = 0.f;
     if (live) {
-      const float sdv = L.lat != nullptr ? sde_sigma(L.lat + (size_t)i * L.HL, L.log_std, L.HL, L.A, k) : expf(L.log_std[k]);
+      const float sdv = L.lat != nullptr ? sde_sigma(L.lat + (size_t)i * L.HL, L.log_std, L.HL, L.A, k, L.sde) : expf(L.log_std[k]);
       const float var = sdv * sdv;
       const float d = L.actions[(size_t)i * L.A + k] - L.mu[(size_t)i * L.ldmu + k];
       gm = g_logp * d / var;
@@ -964,11 +977,21 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs L) {
 }
 
 // gSDE: g_log_std[k][a] = (latent^2)^T . gsig, as the GEMM left it, times d sigma^2 / d log_std[k][a] / latent_k^2 = 2 exp(log_std[k][a])^2
-__global__ void k_sde_scale_grad(float* __restrict__ g_log_std, const float* __restrict__ log_std, int n) {
+// raw [HL][A]: the GEMM's output (== g_log_std itself with full_std); one latent unit's [HL][1] entry sums its row of raw in action order.
+// In general d sigma^2 / d log_std = latent^2 * 2 std (d std / d log_std): 2 exp(2 ls) without expln.
+__global__ void k_sde_scale_grad(float* __restrict__ g_log_std, const float* __restrict__ raw, const float* __restrict__ log_std, int HL, int A,
+                                 SdeMode md) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float sd = expf(log_std[i]);
-  g_log_std[i] *= 2.0f * (sd * sd);
+  if (i >= (md.full ? HL * A : HL)) return;
+  const float ls = log_std[i];
+  const float f = 2.0f * sde_std(ls, md.expln) * sde_dstd(ls, md.expln);
+  if (md.full) {
+    g_log_std[i] = raw[i] * f;
+  } else {
+    float t = 0.f;
+    for (int a = 0; a < A; ++a) t += raw[i * A + a];
+    g_log_std[i] = t * f;
+  }
 }
 
 // entropy term of the loss on log_std: d(-mean(entropy))/dlog_std_a = -(B_local/B_global) * ent_coef

@@ -53,11 +53,12 @@ def activation_name(act) -> str:
     return name
 
 
-def param_shapes(obs_dim, act_dim, pi, vf, use_sde=False):
+def param_shapes(obs_dim, act_dim, pi, vf, use_sde=False, full_std=True):
     """SB3 `policy.state_dict()` key order and shapes (include/mobrob_ppo.h 'Conventions'); one to eight hidden layers per
     network (`nn.Sequential` indices 0, 2, 4 ...: every Linear is followed by its activation module)."""
     s = OrderedDict()
-    s["log_std"] = (pi[-1], act_dim) if use_sde else (act_dim,)   # gSDE: one row per unit of the policy's last hidden layer
+    # gSDE: one row per unit of the policy's last hidden layer (one column without full_std)
+    s["log_std"] = (pi[-1], act_dim if full_std else 1) if use_sde else (act_dim,)
     for net, widths in (("policy_net", pi), ("value_net", vf)):
         prev = obs_dim
         for i, w in enumerate(widths):
@@ -153,7 +154,7 @@ class PPOEngine:
                     learning_rate=3e-4, adam_betas=(0.9, 0.999), adam_eps=1e-5, normalize_advantage=True,
                     action_low=-1.0, action_high=1.0, seed=0, device_id=0, rank=0, world_size=1, fast_kernels=True,
                     rollout_graph=True, rollout_persistent=True, activation="tanh", forward_x3=True, use_sde=False,
-                    sde_sample_freq=-1) -> Config:
+                    sde_sample_freq=-1, sde_full_std=True, sde_use_expln=False) -> Config:
         """PPO(...) keyword arguments -> `mobrob_ppo_config_t` (SB3 defaults, Appendix A.1)."""
         if not (1 <= len(pi) <= MAX_HIDDEN and 1 <= len(vf) <= MAX_HIDDEN):
             raise ValueError(f"net_arch: one to {MAX_HIDDEN} hidden layers per network (pi=[h1, ...], vf=[h1, ...])")
@@ -179,6 +180,7 @@ class PPOEngine:
         cfg.activation = ACTIVATIONS[activation_name(activation)][0]
         cfg.forward_x3 = int(bool(forward_x3))
         cfg.use_sde, cfg.sde_sample_freq = int(bool(use_sde)), int(sde_sample_freq)
+        cfg.sde_full_std, cfg.sde_use_expln = int(bool(sde_full_std)), int(bool(sde_use_expln))
         return cfg
 
     @staticmethod
@@ -198,7 +200,7 @@ class PPOEngine:
         vf = tuple(w for w in (cfg.vf_hidden[0], cfg.vf_hidden[1], cfg.vf_hidden3, *cfg.vf_hidden_ext) if w > 0)
         self.cfg = cfg
         self.D, self.A, self.N, self.T = int(obs_dim), int(act_dim), int(n_envs), int(n_steps)
-        self.shapes = param_shapes(self.D, self.A, pi, vf, bool(cfg.use_sde))
+        self.shapes = param_shapes(self.D, self.A, pi, vf, bool(cfg.use_sde), bool(cfg.sde_full_std))
         self.use_sde, self.HL = bool(cfg.use_sde), int(pi[-1])
         self._h = C.c_void_p()
         if arena is None:

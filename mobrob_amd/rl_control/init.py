@@ -28,17 +28,17 @@ def default_linear_init(rng, rows, cols):
     return (rng.uniform(-b, b, (rows, cols)).astype(np.float32), rng.uniform(-b, b, rows).astype(np.float32))
 
 
-def policy_init(obs_dim, act_dim, pi=(64, 64), vf=(64, 64), seed=0, log_std_init=0.0, ortho_init=True, use_sde=False):
+def policy_init(obs_dim, act_dim, pi=(64, 64), vf=(64, 64), seed=0, log_std_init=0.0, ortho_init=True, use_sde=False, full_std=True):
     """ActorCriticPolicy._build: `ortho_init=True` (SB3's default) -> orthogonal_policy_init; False -> torch's default
     nn.Linear initialisation of every layer.  `log_std_init` fills the state-independent log standard deviation."""
     if ortho_init:
         p = orthogonal_policy_init(obs_dim, act_dim, pi, vf, seed, log_std_init)
-        if use_sde:   # StateDependentNoiseDistribution.proba_distribution_net: ones(latent_sde_dim, action_dim) * log_std_init
-            p["log_std"] = np.full((pi[-1], act_dim), log_std_init, np.float32)
+        if use_sde:   # StateDependentNoiseDistribution.proba_distribution_net: ones(latent_sde_dim, action_dim or 1) * log_std_init
+            p["log_std"] = np.full((pi[-1], act_dim if full_std else 1), log_std_init, np.float32)
         return p
     rng = np.random.default_rng(seed)
     p = OrderedDict()
-    p["log_std"] = np.full((pi[-1], act_dim) if use_sde else (act_dim,), log_std_init, np.float32)
+    p["log_std"] = np.full((pi[-1], act_dim if full_std else 1) if use_sde else (act_dim,), log_std_init, np.float32)
     layers = []
     for net, widths in (("policy_net", pi), ("value_net", vf)):   # one to three hidden layers per network, SB3's registration order
         prev = obs_dim

@@ -225,10 +225,11 @@ class PPO:
         unknown = set(self.policy_kwargs) - {"net_arch", "log_std_init", "ortho_init", "optimizer_kwargs", "activation_fn",
                                              "optimizer_class", "share_features_extractor", "normalize_images", "full_std",
                                              "use_expln", "squash_output"}
-        # gSDE options of ActorCriticPolicy: only SB3's defaults are implemented (they only matter with use_sde)
-        for k, dflt in (("full_std", True), ("use_expln", False), ("squash_output", False)):
-            if k in self.policy_kwargs and bool(self.policy_kwargs[k]) != dflt:
-                raise NotImplementedError(f"policy_kwargs {k}={self.policy_kwargs[k]!r}: only SB3's default ({dflt}) is implemented")
+        # gSDE options of ActorCriticPolicy (they only matter with use_sde): full_std / use_expln are served, squashing is not
+        self.sde_full_std = bool(self.policy_kwargs.get("full_std", True))
+        self.sde_use_expln = bool(self.policy_kwargs.get("use_expln", False))
+        if self.policy_kwargs.get("squash_output", False):
+            raise NotImplementedError("policy_kwargs squash_output=True (tanh-squashed gSDE actions) is not implemented")
         if unknown:
             raise NotImplementedError(f"policy_kwargs {sorted(unknown)} are not supported (MlpPolicy, one to {MAX_HIDDEN} hidden "
                                       "layers per network)")
@@ -273,7 +274,7 @@ class PPO:
                   vf_coef=self.vf_coef, max_grad_norm=self.max_grad_norm, learning_rate=self.learning_rate,
                   normalize_advantage=self.normalize_advantage, seed=0 if self.seed is None else int(self.seed),
                   adam_betas=self.adam_betas, adam_eps=self.adam_eps, activation=self.activation, use_sde=self.use_sde,
-                  sde_sample_freq=self.sde_sample_freq)
+                  sde_sample_freq=self.sde_sample_freq, sde_full_std=self.sde_full_std, sde_use_expln=self.sde_use_expln)
         # data parallel: under torchrun / an initialised process group every rank owns its n_envs
         # environments and rollout shard; batch_size stays SB3's GLOBAL minibatch and must divide by the world size
         from ..parallel import distributed_context
@@ -286,7 +287,8 @@ class PPO:
         self._backend = None
         self.engine.set_params(policy_init(self.obs_dim, self.act_dim, self.net_arch[0], self.net_arch[1],
                                            seed=0 if self.seed is None else int(self.seed),
-                                           log_std_init=self.log_std_init, ortho_init=self.ortho_init, use_sde=self.use_sde))
+                                           log_std_init=self.log_std_init, ortho_init=self.ortho_init, use_sde=self.use_sde,
+                                           full_std=self.sde_full_std))
         self.policy = ActorCriticPolicyHandle(self)
 
     def get_env(self):

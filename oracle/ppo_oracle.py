@@ -300,10 +300,24 @@ def gaussian_entropy(log_std, n):
 SDE_EPSILON = 1e-6
 
 
-def sde_sigma(latent, log_std, acc=None):
+def sde_get_std(log_std, n_act, use_expln=False):
+    """get_std: exp(log_std), or with use_expln exp below 0 and log1p(log_std + epsilon) + 1 above ("avoid NaN: zeros values that are
+    below zero" -- statement by statement); without full_std ([HL, 1]) `ones(latent_sde_dim, action_dim) * std` -> [HL, A]."""
+    ls = np.asarray(log_std, F32)
+    if use_expln:
+        below = (np.exp(ls) * (ls <= 0)).astype(F32)
+        safe = (ls * (ls > 0) + F32(SDE_EPSILON)).astype(F32)
+        above = ((np.log1p(safe) + F32(1.0)) * (ls > 0)).astype(F32)
+        std = (below + above).astype(F32)
+    else:
+        std = np.exp(ls).astype(F32)
+    return std if std.shape[1] == n_act else (np.ones((std.shape[0], n_act), F32) * std).astype(F32)
+
+
+def sde_sigma(latent, log_std, acc=None, n_act=None, use_expln=False):
     """proba_distribution: variance = mm(latent_sde ** 2, get_std(log_std) ** 2); Normal(mean, sqrt(variance + epsilon)).
-    latent [B, HL] (the policy's last hidden activations, detached), log_std [HL, A] -> sigma [B, A]."""
-    std = np.exp(np.asarray(log_std, F32)).astype(F32)
+    latent [B, HL] (the policy's last hidden activations, detached), log_std [HL, A] (or [HL, 1] with n_act given) -> sigma [B, A]."""
+    std = sde_get_std(log_std, np.asarray(log_std).shape[1] if n_act is None else n_act, use_expln)
     latent = np.asarray(latent, F32)
     variance = _mm((latent * latent).astype(F32), (std * std).astype(F32), acc)
     return np.sqrt(variance + F32(SDE_EPSILON)).astype(F32)
@@ -316,13 +330,14 @@ def normal_log_prob(mean, sigma, actions):
     return lp.sum(axis=1, dtype=F32)
 
 
-def sde_exploration_matrices(log_std, z):
+def sde_exploration_matrices(log_std, z, use_expln=False):
     """sample_weights: weights_dist = Normal(0, std); exploration_matrices = rsample((n_envs,)) = z * std.  The standard normals z
     [n_envs, HL, A] are an INPUT (torch's stream cannot be reproduced elsewhere)."""
-    return (np.asarray(z, F32) * np.exp(np.asarray(log_std, F32))).astype(F32)
+    z = np.asarray(z, F32)
+    return (z * sde_get_std(log_std, z.shape[-1], use_expln)).astype(F32)
 
 
-def act_sde(p, obs, theta, low=-1.0, high=1.0, activation="tanh"):
+def act_sde(p, obs, theta, low=-1.0, high=1.0, activation="tanh", use_expln=False):
     """One rollout-time policy call under gSDE: actions = mean + bmm(latent, theta) [get_noise], log-probs under
     Normal(mean, sigma(latent)).  theta [n_envs, HL, A] = the environments' exploration matrices (one shared [HL, A] matrix is
     broadcast: SB3's `exploration_mat` for foreign batch sizes)."""
@@ -336,7 +351,7 @@ def act_sde(p, obs, theta, low=-1.0, high=1.0, activation="tanh"):
     else:
         noise = np.stack([_mm(latent[i:i + 1], theta[i])[0] for i in range(latent.shape[0])]).astype(F32)
     actions = (mean + noise).astype(F32)
-    logp = normal_log_prob(mean, sde_sigma(latent, p["log_std"]), actions)
+    logp = normal_log_prob(mean, sde_sigma(latent, p["log_std"], n_act=mean.shape[1], use_expln=use_expln), actions)
     return actions, np.clip(actions, F32(low), F32(high)), value, logp
 
 
@@ -484,6 +499,7 @@ class Hyper:
     activation: str = "tanh"             # policy_kwargs activation_fn: "tanh" (SB3's MlpPolicy default) or another of ACTIVATIONS
     use_sde: bool = False                # PPO(use_sde=True): generalised state-dependent exploration, log_std is [HL, A]
     sde_sample_freq: int = -1            # PPO(sde_sample_freq): steps between reset_noise calls inside a rollout (-1: never)
+    sde_use_expln: bool = False          # policy_kwargs use_expln (full_std is read off log_std's shape: [HL, A] or [HL, 1])
 
 
 def normalize_advantages(adv, acc=None):
@@ -523,7 +539,7 @@ def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, return
     log_std = p["log_std"].astype(F32)
     std = np.exp(log_std).astype(F32)
     if h.use_sde:   # sigma per (row, action) from the detached latent; entropy = sum_a 0.5 + log sqrt(2 pi) + log sigma
-        sigma = sde_sigma(acts_pi[-1], log_std, acc)
+        sigma = sde_sigma(acts_pi[-1], log_std, acc, n_act=mean.shape[1], use_expln=h.sde_use_expln)
         var = (sigma * sigma).astype(F32)
         log_prob = normal_log_prob(mean, sigma, actions)
         entropy = (F32(0.5) + F32(0.5 * math.log(2 * math.pi)) + np.log(sigma)).astype(F32).sum(axis=1, dtype=F32)
@@ -574,7 +590,15 @@ def loss_and_grads(p, obs, actions, old_values, old_log_prob, advantages, return
         # sigma^2[r, a] = sum_k latent[r, k]^2 exp(2 log_std[k, a]) + eps  ->  d sigma^2 / d log_std[k, a] = 2 latent^2 std^2
         g_var = ((g_logp[:, None] * (d * d / var - F32(1.0)) - F32(h.ent_coef) / Bg) / (F32(2.0) * var)).astype(F32)
         lat = acts_pi[-1]
-        g_log_std = (_mm((lat * lat).astype(F32).T, g_var, acc) * (F32(2.0) * std * std)).astype(F32)
+        g_std2 = _mm((lat * lat).astype(F32).T, g_var, acc)                      # dL / d(std^2) per (latent unit, action)
+        if log_std.shape[1] != g_std2.shape[1]:                                  # full_std=False: one std per latent unit, shared by the actions
+            g_std2 = g_std2.sum(axis=1, keepdims=True, dtype=F32)
+        std_p = sde_get_std(log_std, log_std.shape[1], h.sde_use_expln)          # the parameter's own shape
+        if h.sde_use_expln:   # d std / d log_std = exp(ls) below 0, 1 / (1 + ls + eps) above
+            dstd = np.where(log_std > 0, F32(1.0) / (F32(1.0) + log_std + F32(SDE_EPSILON)), np.exp(log_std)).astype(F32)
+        else:
+            dstd = std_p
+        g_log_std = (g_std2 * (F32(2.0) * std_p * dstd)).astype(F32)
     else:
         g_log_std = _colsum((g_logp[:, None] * (d * d / var - F32(1.0))).astype(F32), acc)
         # entropy: d(-mean(entropy))/dlog_std_a = -(B_local / B_global)
@@ -780,8 +804,8 @@ def collect_rollout(p, env, last_obs, last_episode_starts, T, h: Hyper, eps_sour
     for t in range(T):
         if h.use_sde:
             if t == 0 or (h.sde_sample_freq > 0 and t % h.sde_sample_freq == 0):
-                theta = sde_exploration_matrices(p["log_std"], eps_source(t))
-            actions, clipped, values, logp = act_sde(p, last_obs, theta, activation=h.activation)
+                theta = sde_exploration_matrices(p["log_std"], eps_source(t), h.sde_use_expln)
+            actions, clipped, values, logp = act_sde(p, last_obs, theta, activation=h.activation, use_expln=h.sde_use_expln)
         else:
             actions, clipped, values, logp = act(p, last_obs, eps_source(t), activation=h.activation)
         new_obs, rewards, dones, trunc, terminal_obs = env.step(clipped)

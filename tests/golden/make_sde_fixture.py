@@ -24,40 +24,59 @@ from make_arch_fixture import ACTS, Policy, D, A, N, B  # noqa: E402
 OUT = os.path.dirname(os.path.abspath(__file__))
 torch.set_num_threads(1)
 EPSILON = 1e-6
-CASES = [("sde_tanh_2x2", "tanh", (32, 24), (24, 16)), ("sde_relu_1_3", "relu", (24,), (32, 32, 16)),
-         ("sde_elu_4", "elu", (16, 16, 24, 16), (16, 16, 16, 16))]
+# (name, activation, pi, vf, full_std, use_expln, log_std_init)
+CASES = [("sde_tanh_2x2", "tanh", (32, 24), (24, 16), True, False, -2.0), ("sde_relu_1_3", "relu", (24,), (32, 32, 16), True, False, -2.0),
+         ("sde_elu_4", "elu", (16, 16, 24, 16), (16, 16, 16, 16), True, False, -2.0),
+         # appended later (the cases above keep their seeds): the two non-default options of the distribution
+         ("sde_expln", "tanh", (32, 24), (24, 16), True, True, 0.0), ("sde_shared_std", "relu", (24, 16), (32,), False, False, -1.5),
+         ("sde_shared_expln", "tanh", (16,), (16, 16), False, True, 0.0)]
+
+
+def get_std(log_std, full_std, use_expln, latent_sde_dim, action_dim):
+    """StateDependentNoiseDistribution.get_std, statement by statement."""
+    if use_expln:
+        below_threshold = torch.exp(log_std) * (log_std <= 0)
+        safe_log_std = log_std * (log_std > 0) + EPSILON
+        above_threshold = (torch.log1p(safe_log_std) + 1.0) * (log_std > 0)
+        std = below_threshold + above_threshold
+    else:
+        std = torch.exp(log_std)
+    if full_std:
+        return std
+    return torch.ones(latent_sde_dim, action_dim) * std
 
 
 def dist_of(net, obs):
     latent = net.mlp_extractor.policy_net(obs)
     mean = net.action_net(latent)
-    std = torch.exp(net.log_std)                                       # get_std, use_expln=False, full_std=True
+    std = get_std(net.log_std, net.full_std, net.use_expln, latent.shape[1], mean.shape[1])
     variance = torch.mm(latent.detach() ** 2, std ** 2)                # learn_features=False
     return torch.distributions.Normal(mean, torch.sqrt(variance + EPSILON)), mean, latent
 
 
 def main():
     out = {}
-    for ci, (name, act, pi, vf) in enumerate(CASES):
+    for ci, (name, act, pi, vf, full_std, use_expln, ls_init) in enumerate(CASES):
         torch.manual_seed(900 + ci)
         g = torch.Generator().manual_seed(1900 + ci)
         net = Policy(ACTS[act], pi, vf)
         HL = pi[-1]
-        net.log_std = torch.nn.Parameter(torch.ones(HL, A) * -2.0)     # proba_distribution_net(log_std_init=-2)
+        net.full_std, net.use_expln = full_std, use_expln
+        net.log_std = torch.nn.Parameter(torch.ones(HL, A if full_std else 1) * ls_init)     # proba_distribution_net(log_std_init)
         with torch.no_grad():
             for k, p in net.named_parameters():
                 if k.endswith(".bias"):
                     p.add_(0.1 * torch.randn(p.shape, generator=g))
-            net.log_std.add_(0.3 * torch.randn(HL, A, generator=g))
+            net.log_std.add_((0.3 if ci < 3 else 0.6) * torch.randn(HL, A, generator=g)[:, :net.log_std.shape[1]])
             net.action_net.weight.mul_(30.0)
         keys = [k for k, _ in net.named_parameters()]
         assert keys[0] == "log_std"
-        o = {"activation": np.array(act), "pi": np.array(pi), "vf": np.array(vf)}
+        o = {"activation": np.array(act), "pi": np.array(pi), "vf": np.array(vf), "full_std": np.array(full_std), "use_expln": np.array(use_expln)}
         for k, p in net.named_parameters():
             o[f"p/{k}"] = p.detach().numpy().copy()
         obs = 1.5 * torch.randn(N, D, generator=g)
         with torch.no_grad():
-            std = torch.exp(net.log_std)
+            std = get_std(net.log_std, full_std, use_expln, HL, A)
             weights_dist = torch.distributions.Normal(torch.zeros_like(std), std)
             z = torch.randn(N, HL, A, generator=g)
             theta = weights_dist.loc + z * weights_dist.scale          # rsample((N,)) with the draws kept

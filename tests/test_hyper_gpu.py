@@ -137,7 +137,7 @@ def test_schedules_and_kwargs_through_ppo(tmp_path):
     with pytest.raises(ValueError):
         PPO("MlpPolicy", env, clip_range_vf=-1.0)
     with pytest.raises(NotImplementedError):
-        PPO("MlpPolicy", env, use_sde=True, policy_kwargs=dict(use_expln=True))   # (use_sde itself: tests/test_sde_gpu.py)
+        PPO("MlpPolicy", env, use_sde=True, policy_kwargs=dict(squash_output=True))   # (use_sde itself: tests/test_sde_gpu.py)
 
 
 def test_policy_kwargs_beyond_net_arch(tmp_path):
@@ -174,7 +174,7 @@ def test_policy_kwargs_beyond_net_arch(tmp_path):
     assert again.log_std_init == -0.5 and again.ortho_init is False and again.adam_eps == 1e-3 and again.adam_betas == (0.8, 0.95)
     assert all(np.array_equal(again.engine.get_params()[k], got[k]) for k in got)
     for bad in (dict(activation_fn="PReLU"), dict(optimizer_kwargs=dict(weight_decay=0.1)), dict(optimizer_class="SGD"),
-                dict(features_extractor_class="NatureCNN"), dict(use_expln=True)):
+                dict(features_extractor_class="NatureCNN"), dict(squash_output=True)):
         with pytest.raises(NotImplementedError):
             PPO("MlpPolicy", env, policy_kwargs=bad)
 

@@ -342,12 +342,13 @@ def test_gsde_matches_torch_golden(name):
     gradient through the variance) against torch's own ops (tests/golden/make_sde_fixture.py)."""
     from tests.util import sde_case
     c, act, pi, vf, p, h = sde_case(name)
-    assert p["log_std"].shape == (pi[-1], c["fwd/eps"].shape[1] if "fwd/eps" in c else c["fwd/actions"].shape[1])
-    theta = O.sde_exploration_matrices(p["log_std"], c["fwd/z"])
-    actions, clipped, value, logp = O.act_sde(p, c["fwd/obs"], theta, activation=act)
+    A = c["fwd/actions"].shape[1]
+    assert p["log_std"].shape == (pi[-1], A if bool(c["full_std"]) else 1)
+    theta = O.sde_exploration_matrices(p["log_std"], c["fwd/z"], h.sde_use_expln)
+    actions, clipped, value, logp = O.act_sde(p, c["fwd/obs"], theta, activation=act, use_expln=h.sde_use_expln)
     assert scaled_err(actions, c["fwd/actions"]) < 1e-5 and scaled_err(value, c["fwd/value"]) < 1e-5
     assert np.allclose(logp, c["fwd/log_prob"], rtol=1e-5, atol=1e-4) and np.array_equal(clipped, np.clip(actions, -1, 1))
-    single, _, _, _ = O.act_sde(p, c["fwd/obs"], theta[0], activation=act)
+    single, _, _, _ = O.act_sde(p, c["fwd/obs"], theta[0], activation=act, use_expln=h.sde_use_expln)
     assert scaled_err(single, c["fwd/single"]) < 1e-5
     mb = (c["mb/obs"], c["mb/actions"], c["mb/old_values"], c["mb/old_log_prob"], c["mb/advantages"], c["mb/returns"])
     stats, grads, aux = O.loss_and_grads(p, *mb, h)

@@ -22,14 +22,16 @@ def test_act_and_one_step_match_torch_golden(name):
     c, act, pi, vf, p, h = sde_case(name)
     obs, z = c["fwd/obs"], c["fwd/z"]
     N, D, A = obs.shape[0], obs.shape[1], z.shape[2]
-    e = _engine(D, A, N, 4, pi, vf, batch_size=N, n_epochs=1, activation=act)
-    assert e.shapes["log_std"] == (pi[-1], A) and list(e.shapes.keys()) == O.param_keys(len(pi), len(vf))
+    opts = dict(sde_full_std=bool(c["full_std"]), sde_use_expln=bool(c["use_expln"]))
+    e = _engine(D, A, N, 4, pi, vf, batch_size=N, n_epochs=1, activation=act, **opts)
+    assert e.shapes["log_std"] == (pi[-1], A if opts["sde_full_std"] else 1) and list(e.shapes.keys()) == O.param_keys(len(pi), len(vf))
     assert e.x3_mode() == 0
     e.set_params(p)
     e.sde_set_noise(z)
-    assert scaled_err(e.read("sde_noise"), O.sde_exploration_matrices(p["log_std"], z)) < 1e-6
+    theta = O.sde_exploration_matrices(p["log_std"], z, h.sde_use_expln)
+    assert scaled_err(e.read("sde_noise"), theta) < 1e-6
     a_raw, a_clip, val, lp = e.act(obs)
-    o_raw, _, o_val, o_lp = O.act_sde(p, obs, O.sde_exploration_matrices(p["log_std"], z), activation=act)
+    o_raw, _, o_val, o_lp = O.act_sde(p, obs, theta, activation=act, use_expln=h.sde_use_expln)
     assert scaled_err(a_raw, c["fwd/actions"]) < 1e-4 and scaled_err(a_raw, o_raw) < 1e-4
     assert scaled_err(val, c["fwd/value"]) < 1e-4 and scaled_err(val, o_val) < 1e-4
     assert np.allclose(lp, c["fwd/log_prob"], rtol=1e-4, atol=1e-4) and np.allclose(lp, o_lp, rtol=1e-4, atol=1e-4)
@@ -42,7 +44,7 @@ def test_act_and_one_step_match_torch_golden(name):
     mb_obs, mb_act = c["mb/obs"], c["mb/actions"]
     B = mb_obs.shape[0]
     e = _engine(D, A, 1, B, pi, vf, batch_size=B, n_epochs=1, activation=act, clip_range=h.clip_range, ent_coef=h.ent_coef,
-                vf_coef=h.vf_coef, max_grad_norm=h.max_grad_norm, learning_rate=h.learning_rate, adam_eps=h.adam_eps)
+                vf_coef=h.vf_coef, max_grad_norm=h.max_grad_norm, learning_rate=h.learning_rate, adam_eps=h.adam_eps, **opts)
     e.set_params(p)
     buf = dict(obs=mb_obs[:, None], actions=mb_act[:, None], rewards=np.zeros((B, 1), np.float32),
                episode_starts=np.zeros((B, 1), np.float32), values=c["mb/old_values"][:, None],
@@ -66,18 +68,21 @@ def test_act_and_one_step_match_torch_golden(name):
     e.close()
 
 
-@pytest.mark.parametrize("act,pi,vf", [("tanh", (64, 64), (64, 64)), ("relu", (32,), (48, 24)), ("softsign", (32, 24, 40), (32,))])
-def test_train_matches_oracle(act, pi, vf):
+@pytest.mark.parametrize("act,pi,vf,full,expln", [("tanh", (64, 64), (64, 64), True, False), ("relu", (32,), (48, 24), True, False),
+                                                  ("softsign", (32, 24, 40), (32,), True, False), ("tanh", (32, 32), (32,), False, False),
+                                                  ("elu", (48,), (32, 32), True, True), ("tanh", (24, 24), (24,), False, True)])
+def test_train_matches_oracle(act, pi, vf, full, expln):
     D, A, T, N, B, E = 14, 2, 30, 7, 64, 2
     rng = np.random.default_rng(11)
     p = O.init_params(D, A, pi, vf, seed=2)
-    p["log_std"] = rng.normal(-1.5, 0.3, (pi[-1], A)).astype(np.float32)
+    p["log_std"] = rng.normal(0.0 if expln else -1.5, 0.5 if expln else 0.3, (pi[-1], A if full else 1)).astype(np.float32)
     p["action_net.weight"] *= 30
     buf, lv, dones = synthetic_rollout(T, N, D, A, seed=5)
-    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=E, batch_size=B, learning_rate=3e-4, activation=act, use_sde=True)
+    h = O.Hyper(gamma=0.99, gae_lambda=0.95, ent_coef=0.01, n_epochs=E, batch_size=B, learning_rate=3e-4, activation=act, use_sde=True,
+                sde_use_expln=expln)
     acts_pi, _ = O.mlp_latents(p, buf["obs"].reshape(T * N, D), activation=act)
     mean, val = O.policy_outputs(p, buf["obs"].reshape(T * N, D), activation=act)
-    sigma = O.sde_sigma(acts_pi[-1], p["log_std"])
+    sigma = O.sde_sigma(acts_pi[-1], p["log_std"], n_act=A, use_expln=expln)
     acts = (mean + rng.standard_normal((T * N, A)).astype(np.float32) * sigma).astype(np.float32)
     buf["actions"] = acts.reshape(T, N, A)
     buf["log_probs"] = (O.normal_log_prob(mean, sigma, acts) + rng.normal(0, 0.1, T * N)).astype(np.float32).reshape(T, N)
@@ -85,7 +90,7 @@ def test_train_matches_oracle(act, pi, vf):
     buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, h.gamma, h.gae_lambda)
     perms = np.stack([rng.permutation(T * N) for _ in range(E)])
     e = _engine(D, A, N, T, pi, vf, batch_size=B, n_epochs=E, gamma=h.gamma, gae_lambda=h.gae_lambda, ent_coef=h.ent_coef,
-                learning_rate=h.learning_rate, activation=act)
+                learning_rate=h.learning_rate, activation=act, sde_full_std=full, sde_use_expln=expln)
     e.set_params(p)
     e.load_rollout(buf, lv, dones)
     e.compute_gae()
@@ -229,9 +234,22 @@ def test_ppo_with_sde_learns_saves_and_loads(vec_env_type, tmp_path):
     assert np.array_equal(ppo.predict(obs, deterministic=True)[0], back.predict(obs, deterministic=True)[0])
     noisy = back.predict(obs, deterministic=False)[0]
     assert noisy.shape == (5, ppo.act_dim) and not np.array_equal(noisy, back.predict(obs, deterministic=True)[0])
-    for bad in (dict(use_expln=True), dict(full_std=False), dict(squash_output=True)):
-        with pytest.raises(NotImplementedError):
-            PPO("MlpPolicy", None, use_sde=True, policy_kwargs=bad, _dims=(4, 6, 2))
+    with pytest.raises(NotImplementedError):
+        PPO("MlpPolicy", None, use_sde=True, policy_kwargs=dict(squash_output=True), _dims=(4, 6, 2))
+
+
+def test_ppo_passes_full_std_and_use_expln_through(tmp_path):
+    from mobrob_amd.rl_control.ppo import PPO
+    from mobrob_amd.envs.vec_env import DeviceGoalVecEnv
+    env = DeviceGoalVecEnv.for_robot("point", 32, time_limit=50)
+    ppo = PPO("MlpPolicy", env, n_steps=16, batch_size=128, n_epochs=1, use_sde=True, seed=1,
+              policy_kwargs=dict(net_arch=[32, 16], full_std=False, use_expln=True, log_std_init=0.5))
+    assert ppo.engine.get_params()["log_std"].shape == (16, 1) and ppo.engine.cfg.sde_full_std == 0 and ppo.engine.cfg.sde_use_expln == 1
+    ppo.learn(total_timesteps=2 * 16 * 32)
+    path = str(tmp_path / "opts.zip")
+    ppo.save(path)
+    back = PPO.load(path)
+    assert back.use_sde and not back.sde_full_std and back.sde_use_expln and np.array_equal(back.engine.get_flat_params(), ppo.engine.get_flat_params())
 
 
 def test_supplied_noise_holds_through_a_device_rollout_captured_before_it():

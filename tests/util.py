@@ -94,12 +94,12 @@ def arch_case(name):
 
 
 # ---- tests/golden/sde_cases.npz (make_sde_fixture.py): PPO(use_sde=True) through torch's own ops ----
-SDE_CASES = ["sde_tanh_2x2", "sde_relu_1_3", "sde_elu_4"]
+SDE_CASES = ["sde_tanh_2x2", "sde_relu_1_3", "sde_elu_4", "sde_expln", "sde_shared_std", "sde_shared_expln"]
 _SDE = None
 
 
 def sde_case(name):
-    """-> (case dict, activation, pi, vf, params, Hyper(use_sde=True))"""
+    """-> (case dict, activation, pi, vf, params, Hyper(use_sde=True, sde_use_expln=...)); c["full_std"] / c["use_expln"]: the options"""
     global _SDE
     if _SDE is None:
         _SDE = np.load(os.path.join(GOLDEN, "sde_cases.npz"))
@@ -110,5 +110,5 @@ def sde_case(name):
     p = OrderedDict((k, c["p/" + k].astype(np.float32).copy()) for k in O.param_keys(len(pi), len(vf)))
     lr, clip, ent, vfc, mgn, eps = (float(x) for x in _SDE["hyper"])
     h = O.Hyper(clip_range=clip, ent_coef=ent, vf_coef=vfc, max_grad_norm=mgn, learning_rate=lr, adam_eps=eps, activation=act,
-                batch_size=100, n_epochs=1, use_sde=True)
+                batch_size=100, n_epochs=1, use_sde=True, sde_use_expln=bool(c["use_expln"]))
     return c, act, pi, vf, p, h
