@@ -324,56 +324,96 @@ void prof_resolve(mobrob_ppo_engine* e) {
 }
 
 // ---- GEMM launchers --------------------------------------------------------------------------------
+// One GEMM of the generic chain as the launcher takes it: mode / epilogue (template parameters of k_gemm), arguments, batch split
+struct GemmOp {
+  int mode = 0, epi = 0, ksplit = 1;
+  GemmArgs g{};
+};
+using GemmQueue = std::vector<GemmOp>;
+
 template <int MODE, int EPI, int TM, int TN>
-void launch_gemm_tiles(mobrob_ppo_engine* e, const GemmArgs& g, int ksplit) {
-  dim3 grid(cdiv(cdiv(g.M, 32 * TM), 4), cdiv(g.N, 32 * TN), ksplit);
-  hipLaunchKernelGGL((k_gemm<MODE, EPI, TM, TN>), grid, dim3(256), 0, e->stream, g);
+void launch_gemm_tiles(mobrob_ppo_engine* e, const GemmOp& a, const GemmOp* b) {
+  const int M = b ? std::max(a.g.M, b->g.M) : a.g.M, N = b ? std::max(a.g.N, b->g.N) : a.g.N;
+  const int ks = b ? std::max(a.ksplit, b->ksplit) : a.ksplit;
+  dim3 grid(cdiv(cdiv(M, 32 * TM), 4), cdiv(N, 32 * TN), b ? 2 * ks : ks);
+  hipLaunchKernelGGL((k_gemm<MODE, EPI, TM, TN>), grid, dim3(256), 0, e->stream, a.g, b ? b->g : a.g, b ? 1 : 0);
 }
 // tiles per wave by shape: 2x2 wherever both extents leave room for it, 2x1 for narrow outputs (heads), 1x1 for tiny ones.
 // MOBROB_GEMM_TILES (read when the engine is created): 1 keeps one tile per wave (A/B); 21 / 22 force 2x1 / 2x2 wherever the output
 // has more than one tile in that direction, whatever the wave count (the parity tests drive small shapes through every form).
+// b: a second problem of the same mode / epilogue for the same launch (the other network's GEMM at this point of the chain).
 template <int MODE, int EPI>
-void launch_gemm(mobrob_ppo_engine* e, const GemmArgs& g, int ksplit = 1) {
+void launch_gemm(mobrob_ppo_engine* e, const GemmOp& a, const GemmOp* b = nullptr) {
   const int f = e->gemm_tiles;
-  if (f == 22 && g.M > 32 && g.N > 32) return launch_gemm_tiles<MODE, EPI, 2, 2>(e, g, ksplit);
-  if ((f == 21 || f == 22) && g.M > 32) return launch_gemm_tiles<MODE, EPI, 2, 1>(e, g, ksplit);
+  const int M = b ? std::max(a.g.M, b->g.M) : a.g.M, N = b ? std::max(a.g.N, b->g.N) : a.g.N;
+  if (f == 22 && M > 32 && N > 32) return launch_gemm_tiles<MODE, EPI, 2, 2>(e, a, b);
+  if ((f == 21 || f == 22) && M > 32) return launch_gemm_tiles<MODE, EPI, 2, 1>(e, a, b);
   // fat wave tiles only while they still leave ~8 waves per CU: a rollout step (4096 rows) is 1024 one-tile waves, 256 as 2x2
-  const long w22 = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * ksplit, w21 = (long)cdiv(g.M, 64) * cdiv(g.N, 32) * ksplit;
-  if (f != 0 || g.M <= 32 || w21 < 2048) launch_gemm_tiles<MODE, EPI, 1, 1>(e, g, ksplit);
-  else if (g.N <= 32 || w22 < 2048) launch_gemm_tiles<MODE, EPI, 2, 1>(e, g, ksplit);
-  else launch_gemm_tiles<MODE, EPI, 2, 2>(e, g, ksplit);
+  auto waves = [&](int tm, int tn) {
+    long w = (long)cdiv(a.g.M, 32 * tm) * cdiv(a.g.N, 32 * tn) * a.ksplit;
+    if (b) w += (long)cdiv(b->g.M, 32 * tm) * cdiv(b->g.N, 32 * tn) * b->ksplit;
+    return w;
+  };
+  if (f != 0 || M <= 32 || waves(2, 1) < 2048) launch_gemm_tiles<MODE, EPI, 1, 1>(e, a, b);
+  else if (N <= 32 || waves(2, 2) < 2048) launch_gemm_tiles<MODE, EPI, 2, 1>(e, a, b);
+  else launch_gemm_tiles<MODE, EPI, 2, 2>(e, a, b);
 }
+void launch_op(mobrob_ppo_engine* e, const GemmOp& a, const GemmOp* b = nullptr) {
+  if (a.mode == MODE_NT && a.epi == EPI_BIAS_TANH) launch_gemm<MODE_NT, EPI_BIAS_TANH>(e, a, b);
+  else if (a.mode == MODE_NT) launch_gemm<MODE_NT, EPI_BIAS>(e, a, b);
+  else if (a.mode == MODE_NN) launch_gemm<MODE_NN, EPI_DTANH_COLSUM>(e, a, b);
+  else launch_gemm<MODE_TN, EPI_ATOMIC>(e, a, b);
+}
+// The two networks' chains side by side: the j-th GEMMs of both go out as ONE launch where they are of the same kind (they always
+// are at equal depths; with different depths the tails, and a head opposite a hidden layer, go out alone).  MOBROB_GEMM_PAIR=0: never.
+void run_queues(mobrob_ppo_engine* e, const GemmQueue& qa, const GemmQueue& qb) {
+  static const bool pair = getenv("MOBROB_GEMM_PAIR") == nullptr || atoi(getenv("MOBROB_GEMM_PAIR")) != 0;
+  const size_t n = std::max(qa.size(), qb.size());
+  for (size_t j = 0; j < n; ++j) {
+    const GemmOp* a = j < qa.size() ? &qa[j] : nullptr;
+    const GemmOp* b = j < qb.size() ? &qb[j] : nullptr;
+    if (a && b && pair && a->mode == b->mode && a->epi == b->epi) { launch_op(e, *a, b); continue; }
+    if (a) launch_op(e, *a);
+    if (b) launch_op(e, *b);
+  }
+}
+// q: non-null = the GEMM is queued (run_queues pairs it with the other network's), null = launched now
 
 // Y[M x Nn] = act(X[M x K] . W[Nn x K]^T + bias)
 void linear_fwd(mobrob_ppo_engine* e, const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y,
-                int ldy, int M, int Nn, int K, bool tanh_, float* Z = nullptr) {
-  GemmArgs g{};
+                int ldy, int M, int Nn, int K, bool tanh_, float* Z = nullptr, GemmQueue* q = nullptr) {
+  GemmOp o;
+  GemmArgs& g = o.g;
   g.A = X; g.B = W; g.C = Y; g.M = M; g.N = Nn; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldy; g.bias = bias;
   g.act = e->cfg.activation;
   g.Z = (tanh_ && act_needs_z(g.act)) ? Z : nullptr; g.ldz = ldy;   // pre-activations for SiLU / GELU / Mish backward (same shape as Y)
-  if (tanh_) launch_gemm<MODE_NT, EPI_BIAS_TANH>(e, g);
-  else launch_gemm<MODE_NT, EPI_BIAS>(e, g);
+  o.mode = MODE_NT; o.epi = tanh_ ? EPI_BIAS_TANH : EPI_BIAS;
+  if (q) q->push_back(o); else launch_op(e, o);
 }
-// dZ[M x Nn] = (dY[M x K] . W[K x Nn]) * (1 - H^2) ; column sums -> bias grad
+// dZ[M x Nn] = (dY[M x K] . W[K x Nn]) * act'(.) ; column sums -> bias grad
 void linear_bwd_input(mobrob_ppo_engine* e, const float* dY, int ldd, const float* W, int ldw, const float* H, int ldh,
-                      float* dZ, int ldz, float* bias_grad, int M, int Nn, int K) {
-  GemmArgs g{};
+                      float* dZ, int ldz, float* bias_grad, int M, int Nn, int K, GemmQueue* q = nullptr) {
+  GemmOp o;
+  GemmArgs& g = o.g;
   g.A = dY; g.B = W; g.C = dZ; g.M = M; g.N = Nn; g.K = K; g.lda = ldd; g.ldb = ldw; g.ldc = ldz;
   g.Hact = H; g.ldh = ldh; g.colsum = bias_grad; g.act = e->cfg.activation;
-  launch_gemm<MODE_NN, EPI_DTANH_COLSUM>(e, g);
+  o.mode = MODE_NN; o.epi = EPI_DTANH_COLSUM;
+  if (q) q->push_back(o); else launch_op(e, o);
 }
 // dW[M x Nn] += dY[rows x M]^T . X[rows x Nn]
 void linear_bwd_weight(mobrob_ppo_engine* e, const float* dY, int ldd, const float* X, int ldx, float* dW, int ldw,
-                       int M, int Nn, int rows) {
-  GemmArgs g{};
+                       int M, int Nn, int rows, GemmQueue* q = nullptr) {
+  GemmOp o;
+  GemmArgs& g = o.g;
   g.A = dY; g.B = X; g.C = dW; g.M = M; g.N = Nn; g.K = rows; g.lda = ldd; g.ldb = ldx; g.ldc = ldw;
   // waves of one pass over the output (launch_gemm's tiling: 64-row / 64-column wave tiles where the extents allow); the batch rows
   // are split until ~2048 waves are in flight (8 per CU) -- every split adds M x Nn float atomics, so not further
   const int wtiles = cdiv(M, M <= 32 ? 32 : 64) * cdiv(Nn, (M <= 32 || Nn <= 32) ? 32 : 64);
-  int ksplit = std::max(1, std::min(cdiv(rows, 64), cdiv(2048, wtiles)));   // (launch_gemm then finds w22 / w21 >= 2048 wherever the rows allow)
+  int ksplit = std::max(1, std::min(cdiv(rows, 64), cdiv(2048, wtiles)));   // (launch_gemm then finds >= 2048 waves wherever the rows allow)
   g.kchunk = rup(cdiv(rows, ksplit), 8);
-  ksplit = cdiv(rows, g.kchunk);
-  launch_gemm<MODE_TN, EPI_ATOMIC>(e, g, ksplit);
+  o.ksplit = cdiv(rows, g.kchunk);
+  o.mode = MODE_TN; o.epi = EPI_ATOMIC;
+  if (q) q->push_back(o); else launch_op(e, o);
 }
 
 float* Pp(mobrob_ppo_engine* e, int t) { return e->params + e->offs[t]; }
@@ -429,21 +469,23 @@ void forward_generic(mobrob_ppo_engine* e, const float* X, int rows, bool want_p
                      float* v_out, bool keep_z = false) {
   // layer 0 reads the zero-padded copy of its weights (observation rows are padded to Dp columns); one to eight hidden layers.
   // keep_z (the training forward of a minibatch, rows <= Bl): layer l's pre-activations are left in its dz buffer for the backward
-  // epilogue of the activations that need them (act_needs_z)
+  // epilogue of the activations that need them (act_needs_z).  The two networks' GEMMs are queued and go out pairwise (run_queues).
+  GemmQueue qp, qv;
   if (want_pi) {
-    linear_fwd(e, X, e->Dp, e->pW1p, e->Dp, Pp(e, e->tPB[0]), e->hp[0], e->Hp[0], rows, e->Hp[0], e->Dp, true, keep_z ? e->dzp[0] : nullptr);
+    linear_fwd(e, X, e->Dp, e->pW1p, e->Dp, Pp(e, e->tPB[0]), e->hp[0], e->Hp[0], rows, e->Hp[0], e->Dp, true, keep_z ? e->dzp[0] : nullptr, &qp);
     for (int l = 1; l < e->Lp; ++l)
       linear_fwd(e, e->hp[l - 1], e->Hp[l - 1], Pp(e, e->tPW[l]), e->Hp[l - 1], Pp(e, e->tPB[l]), e->hp[l], e->Hp[l], rows, e->Hp[l], e->Hp[l - 1], true,
-                 keep_z ? e->dzp[l] : nullptr);
-    linear_fwd(e, e->hp[e->Lp - 1], e->HL, e->aWp, e->HL, Pp(e, T_AB), mu_out, e->Ap, rows, e->A, e->HL, false);
+                 keep_z ? e->dzp[l] : nullptr, &qp);
+    linear_fwd(e, e->hp[e->Lp - 1], e->HL, e->aWp, e->HL, Pp(e, T_AB), mu_out, e->Ap, rows, e->A, e->HL, false, nullptr, &qp);
   }
   if (want_v) {
-    linear_fwd(e, X, e->Dp, e->vW1p, e->Dp, Pp(e, e->tVB[0]), e->hv[0], e->Hv[0], rows, e->Hv[0], e->Dp, true, keep_z ? e->dzv[0] : nullptr);
+    linear_fwd(e, X, e->Dp, e->vW1p, e->Dp, Pp(e, e->tVB[0]), e->hv[0], e->Hv[0], rows, e->Hv[0], e->Dp, true, keep_z ? e->dzv[0] : nullptr, &qv);
     for (int l = 1; l < e->Lv; ++l)
       linear_fwd(e, e->hv[l - 1], e->Hv[l - 1], Pp(e, e->tVW[l]), e->Hv[l - 1], Pp(e, e->tVB[l]), e->hv[l], e->Hv[l], rows, e->Hv[l], e->Hv[l - 1], true,
-                 keep_z ? e->dzv[l] : nullptr);
-    linear_fwd(e, e->hv[e->Lv - 1], e->GL, e->vWp, e->GL, Pp(e, T_VB), v_out, 1, rows, 1, e->GL, false);
+                 keep_z ? e->dzv[l] : nullptr, &qv);
+    linear_fwd(e, e->hv[e->Lv - 1], e->GL, e->vWp, e->GL, Pp(e, T_VB), v_out, 1, rows, 1, e->GL, false, nullptr, &qv);
   }
+  run_queues(e, qp, qv);
 }
 
 void forward(mobrob_ppo_engine* e, const float* X, int rows, bool want_pi, float* mu_out, bool want_v, float* v_out) {
@@ -2286,35 +2328,32 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
   L.sums = sums; L.g_log_std = Gp(e, T_LOGSTD); L.g_b_action = Gp(e, T_AB); L.g_b_value = Gp(e, T_VB);
   if (e->sde) {
     L.lat = e->hp[e->Lp - 1]; L.HL = e->HL; L.sde = e->sde_mode; L.gsig = e->sde_gsig; L.ldg = e->Ap; L.lat2 = e->sde_lat2;
-    HIPC(hipMemsetAsync(e->sde_gsig, 0, (size_t)B * e->Ap * 4, e->stream));
     HIPC(hipMemsetAsync(e->sde_graw, 0, (size_t)e->HL * e->A * 4, e->stream));
   }
-  // padding columns of dmu/dv must be zero (K padding of the NN GEMM)
-  HIPC(hipMemsetAsync(e->dmu, 0, (size_t)B * e->Ap * 4, e->stream));
-  HIPC(hipMemsetAsync(e->dv, 0, (size_t)B * 8 * 4, e->stream));
-  hipLaunchKernelGGL(k_loss, dim3(cdiv(B, 256)), dim3(256), 0, e->stream, L);
+  // (the padding columns of dmu / dv -- K padding of the NN GEMMs -- are zeroed by k_loss itself)
+  hipLaunchKernelGGL(k_loss, dim3(cdiv(B, 256)), dim3(256), loss_lds_bytes(e->A), e->stream, L);
   if (e->sde) {   // g_log_std = 2 std (d std / d log_std) * ((latent^2)^T . gsig) (summed over the actions without full_std): the entropy term is inside gsig
     linear_bwd_weight(e, e->sde_lat2, e->HL, e->sde_gsig, e->Ap, e->sde_graw, e->A, e->HL, e->A, B);
     hipLaunchKernelGGL(k_sde_scale_grad, dim3(cdiv(e->HL * e->A, 256)), dim3(256), 0, e->stream, Gp(e, T_LOGSTD), e->sde_graw, Pp(e, T_LOGSTD), e->HL,
                        e->A, e->sde_mode);
-  } else {
-    hipLaunchKernelGGL(k_entropy_grad, dim3(1), dim3(64), 0, e->stream, Gp(e, T_LOGSTD), e->A, (float)e->cfg.ent_coef,
-                       (float)B, inv_bg);
-  }
+  }   // (state-independent log_std: its entropy term is added by k_loss)
   // backward of both networks, last hidden layer first: dW of the layer above, then dz of this layer (dtanh / dReLU + bias sums)
-  auto backward = [&](int L, const int* Hw, float* const* h, float* const* dz, const float* dhead, int ldd, const float* headWp,
+  GemmQueue qp, qv;
+  auto backward = [&](GemmQueue* q, int L, const int* Hw, float* const* h, float* const* dz, const float* dhead, int ldd, const float* headWp,
                       int head_rows, int head_pad, int t_headW, const int* tW, const int* tB) {
     const int HLw = Hw[L - 1];
-    linear_bwd_weight(e, dhead, ldd, h[L - 1], HLw, Gp(e, t_headW), HLw, head_rows, HLw, B);
-    linear_bwd_input(e, dhead, ldd, headWp, HLw, h[L - 1], HLw, dz[L - 1], HLw, Gp(e, tB[L - 1]), B, HLw, head_pad);
+    linear_bwd_weight(e, dhead, ldd, h[L - 1], HLw, Gp(e, t_headW), HLw, head_rows, HLw, B, q);
+    linear_bwd_input(e, dhead, ldd, headWp, HLw, h[L - 1], HLw, dz[L - 1], HLw, Gp(e, tB[L - 1]), B, HLw, head_pad, q);
     for (int l = L - 1; l >= 1; --l) {
-      linear_bwd_weight(e, dz[l], Hw[l], h[l - 1], Hw[l - 1], Gp(e, tW[l]), Hw[l - 1], Hw[l], Hw[l - 1], B);
-      linear_bwd_input(e, dz[l], Hw[l], Pp(e, tW[l]), Hw[l - 1], h[l - 1], Hw[l - 1], dz[l - 1], Hw[l - 1], Gp(e, tB[l - 1]), B, Hw[l - 1], Hw[l]);
+      linear_bwd_weight(e, dz[l], Hw[l], h[l - 1], Hw[l - 1], Gp(e, tW[l]), Hw[l - 1], Hw[l], Hw[l - 1], B, q);
+      linear_bwd_input(e, dz[l], Hw[l], Pp(e, tW[l]), Hw[l - 1], h[l - 1], Hw[l - 1], dz[l - 1], Hw[l - 1], Gp(e, tB[l - 1]), B, Hw[l - 1], Hw[l], q);
     }
-    linear_bwd_weight(e, dz[0], Hw[0], e->Xg, e->Dp, Gp(e, tW[0]), e->D, Hw[0], e->D, B);
+    linear_bwd_weight(e, dz[0], Hw[0], e->Xg, e->Dp, Gp(e, tW[0]), e->D, Hw[0], e->D, B, q);
   };
-  backward(e->Lp, e->Hp, e->hp, e->dzp, e->dmu, e->Ap, e->aWp, e->A, e->Ap, T_AW, e->tPW, e->tPB);
-  backward(e->Lv, e->Hv, e->hv, e->dzv, e->dv, 8, e->vWp, 1, 8, T_VW, e->tVW, e->tVB);
+  // both networks' chains alternate weight-gradient and input-gradient GEMMs from the head down: queued, then launched pairwise
+  backward(&qp, e->Lp, e->Hp, e->hp, e->dzp, e->dmu, e->Ap, e->aWp, e->A, e->Ap, T_AW, e->tPW, e->tPB);
+  backward(&qv, e->Lv, e->Hv, e->hv, e->dzv, e->dv, 8, e->vWp, 1, 8, T_VW, e->tVW, e->tVB);
+  run_queues(e, qp, qv);
   HIPC(hipGetLastError());
   e->grad_pending = true;
   return MOBROB_OK;

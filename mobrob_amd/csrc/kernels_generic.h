@@ -97,12 +97,25 @@ struct GemmArgs {
 // TM x TN: 32x32 tiles per wave (1x1, 2x1 or 2x2).  A wave that owns 2x2 tiles feeds sixteen MFMAs from four operand fetches where
 // four one-tile waves need eight for the same sixteen: the one-tile form ran at 22 - 34 % of the f32 matrix rate on L1 / L2
 // operand traffic (12.8 flop per byte fetched by a block; 25.6 with 2x2), see CHANGELOG round 6.
+// TWO problems per launch (two != 0: blockIdx.z & 1 selects, the batch split of MODE_TN is blockIdx.z >> 1): the policy and the value
+// network run the same sequence of GEMMs on independent data, and at the reference YAMLs' sizes (100-row minibatches, 2 - 16
+// environments) every launch of this chain costs 5 - 8 us whatever it computes -- pairing them halves the launches of a step.
 template <int MODE, int EPI, int TM, int TN>
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs ga, GemmArgs gb, int two) {
+  const bool second = two != 0 && (blockIdx.z & 1) != 0;
+  const int zz = two != 0 ? (int)(blockIdx.z >> 1) : (int)blockIdx.z;
+  GemmArgs g;   // (field by field: wave-uniform selects, the struct stays in scalar registers)
+  g.A = second ? gb.A : ga.A; g.B = second ? gb.B : ga.B; g.C = second ? gb.C : ga.C;
+  g.M = second ? gb.M : ga.M; g.N = second ? gb.N : ga.N; g.K = second ? gb.K : ga.K;
+  g.lda = second ? gb.lda : ga.lda; g.ldb = second ? gb.ldb : ga.ldb; g.ldc = second ? gb.ldc : ga.ldc;
+  g.bias = second ? gb.bias : ga.bias; g.Hact = second ? gb.Hact : ga.Hact; g.ldh = second ? gb.ldh : ga.ldh;
+  g.colsum = second ? gb.colsum : ga.colsum; g.act = second ? gb.act : ga.act; g.Z = second ? gb.Z : ga.Z; g.ldz = second ? gb.ldz : ga.ldz;
+  g.kchunk = second ? gb.kchunk : ga.kchunk;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int m0 = (blockIdx.x * 4 + wv) * (32 * TM), n0 = blockIdx.y * (32 * TN);
-  if (m0 >= g.M) return;  // whole-wave exit (no block-level sync in this kernel)
+  // whole-wave exits (no block-level sync in this kernel): the grid covers the larger of two problems, and the longer batch split
+  if (m0 >= g.M || n0 >= g.N || (MODE == MODE_TN ? zz * g.kchunk >= g.K : zz > 0)) return;
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -111,6 +124,11 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // KB k-steps of 8 are fetched before their MFMAs start.  One-tile waves exist for SMALL launches (a 100-row minibatch of the
+  // reference's YAMLs, a rollout step): there a wave's whole K loop is a chain of dependent L2 round trips, and four steps in
+  // flight make it two round trips for K = 64 instead of eight (profiles/r6/generic_chain.txt).  Fat tiles
+  // keep one step in flight (their registers hold accumulators; the launches are large enough to hide latency across waves).
+  constexpr int KB = TM * TN == 1 ? 4 : (TM * TN == 2 ? 2 : 1);
   if (MODE == MODE_NT) {
     const float* ap[TM];
     const float* bp[TN];
@@ -119,18 +137,26 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) bp[j] = g.B + (size_t)min(n0 + 32 * j + r, g.N - 1) * g.ldb + 4 * h;
 #pragma unroll 2
-    for (int kk = 0; kk < g.K; kk += 8) {
-      f32x4 a[TM], b[TN];
+    for (int kk = 0; kk < g.K; kk += 8 * KB) {
+      f32x4 a[KB][TM], b[KB][TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(ap[i] + kk);
+      for (int u = 0; u < KB; ++u) {
+        const int ku = min(kk + 8 * u, g.K - 8);   // (a step beyond K re-reads the last one; its MFMAs are skipped below)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(bp[j] + kk);
+        for (int i = 0; i < TM; ++i) a[u][i] = *reinterpret_cast<const f32x4*>(ap[i] + ku);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < TN; ++j) b[u][j] = *reinterpret_cast<const f32x4*>(bp[j] + ku);
+      }
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+      for (int u = 0; u < KB; ++u) {
+        if (u > 0 && kk + 8 * u >= g.K) break;
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i][s], b[u][j][s], acc[i][j], 0, 0, 0);
+      }
     }
   } else if (MODE == MODE_NN) {
     const float* ap[TM];
@@ -140,22 +166,30 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) bp[j] = g.B + (size_t)(4 * h) * g.ldb + min(n0 + 32 * j + r, g.N - 1);
 #pragma unroll 2
-    for (int kk = 0; kk < g.K; kk += 8) {
-      f32x4 a[TM];
-      float b[TN][4];
+    for (int kk = 0; kk < g.K; kk += 8 * KB) {
+      f32x4 a[KB][TM];
+      float b[KB][TN][4];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(ap[i] + kk);
+      for (int u = 0; u < KB; ++u) {
+        const int ku = min(kk + 8 * u, g.K - 8);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const float* bk = bp[j] + (size_t)kk * g.ldb;
-        b[j][0] = bk[0]; b[j][1] = bk[g.ldb]; b[j][2] = bk[2 * (size_t)g.ldb]; b[j][3] = bk[3 * (size_t)g.ldb];
+        for (int i = 0; i < TM; ++i) a[u][i] = *reinterpret_cast<const f32x4*>(ap[i] + ku);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const float* bk = bp[j] + (size_t)ku * g.ldb;
+          b[u][j][0] = bk[0]; b[u][j][1] = bk[g.ldb]; b[u][j][2] = bk[2 * (size_t)g.ldb]; b[u][j][3] = bk[3 * (size_t)g.ldb];
+        }
       }
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int u = 0; u < KB; ++u) {
+        if (u > 0 && kk + 8 * u >= g.K) break;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i][s], b[u][j][s], acc[i][j], 0, 0, 0);
+      }
     }
   } else {  // MODE_TN
     int ai[TM], bj[TN];
@@ -163,28 +197,34 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     for (int i = 0; i < TM; ++i) ai[i] = min(m0 + 32 * i + r, g.M - 1);
 #pragma unroll
     for (int j = 0; j < TN; ++j) bj[j] = min(n0 + 32 * j + r, g.N - 1);
-    const int k0 = blockIdx.z * g.kchunk, k1 = min(k0 + g.kchunk, g.K);
-    for (int kk = k0; kk < k1; kk += 8) {
-      float a[TM][4], b[TN][4];
+    const int k0 = zz * g.kchunk, k1 = min(k0 + g.kchunk, g.K);
+    for (int kk = k0; kk < k1; kk += 8 * KB) {
+      float a[KB][TM][4], b[KB][TN][4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int k = kk + 2 * s + h;
-        const bool ok = k < k1;
-        const int kc = ok ? k : k0;
+      for (int u = 0; u < KB; ++u)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const float av = g.A[(size_t)kc * g.lda + ai[i]];
-          a[i][s] = ok ? av : 0.f;
+        for (int s = 0; s < 4; ++s) {
+          const int k = kk + 8 * u + 2 * s + h;
+          const bool ok = k < k1;
+          const int kc = ok ? k : k0;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float av = g.A[(size_t)kc * g.lda + ai[i]];
+            a[u][i][s] = ok ? av : 0.f;   // (rows beyond the chunk contribute zero: their MFMAs need no skipping)
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[u][j][s] = g.B[(size_t)kc * g.ldb + bj[j]];
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j][s] = g.B[(size_t)kc * g.ldb + bj[j]];
+      for (int u = 0; u < KB; ++u) {
+        if (u > 0 && kk + 8 * u >= k1) break;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i][s], b[u][j][s], acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     }
   }
 
@@ -905,8 +945,16 @@ __device__ __forceinline__ float sde_sigma(const float* __restrict__ l, const fl
   return sqrtf(var + kSdeEpsilon);
 }
 
+// Dynamic LDS: [4 waves][2 A + 8] floats.  Every per-action and per-minibatch sum is reduced inside its wave by shuffles and
+// crosses the waves through LDS behind ONE barrier (one block_sum -- two barriers -- per quantity made this kernel 23 us for a
+// 100-row minibatch with twelve actions); the zero padding of dmu / dv (K padding of the backward GEMMs) and the entropy term of
+// the state-independent log_std are written here too (no memsets, no k_entropy_grad launch).
+inline size_t loss_lds_bytes(int A) { return (size_t)4 * (2 * A + 8) * sizeof(float); }
 __global__ __launch_bounds__(256) void k_loss(LossArgs L) {
-  __shared__ float red[16];
+  extern __shared__ float part[];
+  const int nq = 2 * L.A + 8;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* mine = part + wv * nq;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < L.B;
   float s_pl = 0.f, s_vl = 0.f, s_kl = 0.f, s_cf = 0.f, g_logp = 0.f, dvv = 0.f, s_ent = 0.f;
@@ -937,8 +985,12 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs L) {
     value_loss_terms(L.v[i], L.ret[i], L.clip_vf >= 0.f ? L.old_v[i] : 0.f, L.clip_vf, s_vl, gv_);
     dvv = L.vf_coef * gv_ * L.inv_bg;
     L.dv[(size_t)i * L.lddv] = dvv;
+    for (int c = 1; c < L.lddv; ++c) L.dv[(size_t)i * L.lddv + c] = 0.f;                 // K padding of the value head's backward GEMM
+    for (int c = L.A; c < L.lddmu; ++c) L.dmu[(size_t)i * L.lddmu + c] = 0.f;            // ... and of the action head's
+    if (L.lat != nullptr)
+      for (int c = L.A; c < L.ldg; ++c) L.gsig[(size_t)i * L.ldg + c] = 0.f;
   }
-  // per-action pieces + block reductions
+  // per-action pieces, reduced inside the wave
   for (int k = 0; k < L.A; ++k) {
     float gm = 0.f, gls = 0.f;
     if (live) {
@@ -951,29 +1003,36 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs L) {
       if (L.lat != nullptr)   // d logp / d sigma^2 = (d^2 / sigma^2 - 1) / (2 sigma^2); d(-mean entropy) / d sigma^2 = -1 / (2 sigma^2 B)
         L.gsig[(size_t)i * L.ldg + k] = (gls - L.ent_coef * L.inv_bg) / (2.0f * var);
     }
-    const float t1 = block_sum(gm, red);
-    const float t2 = block_sum(gls, red);
-    if (threadIdx.x == 0) {
-      atomicAdd(&L.g_b_action[k], t1);
-      if (L.lat == nullptr) atomicAdd(&L.g_log_std[k], t2);   // (gSDE: log_std's gradient is a GEMM over gsig, see k_sde_scale_grad)
+    const float t1 = wave_sum(gm), t2 = wave_sum(gls);
+    if (lane == 0) { mine[2 * k] = t1; mine[2 * k + 1] = t2; }
+  }
+  if (L.lat != nullptr && live)
+    for (int k = 0; k < L.HL; ++k) { const float lk = L.lat[(size_t)i * L.HL + k]; L.lat2[(size_t)i * L.HL + k] = lk * lk; }
+  {
+    const float r0 = wave_sum(s_pl), r1 = wave_sum(s_vl), r2 = wave_sum(s_kl), r3 = wave_sum(s_cf), r4 = wave_sum(dvv), r5 = wave_sum(s_ent);
+    if (lane == 0) {
+      float* q = mine + 2 * L.A;
+      q[0] = r0; q[1] = r1; q[2] = r2; q[3] = r3; q[4] = r4; q[5] = r5;
     }
   }
-  if (L.lat != nullptr) {
-    if (live)
-      for (int k = 0; k < L.HL; ++k) { const float lk = L.lat[(size_t)i * L.HL + k]; L.lat2[(size_t)i * L.HL + k] = lk * lk; }
-    const float r5 = block_sum(s_ent, red);
-    if (threadIdx.x == 0) atomicAdd(&L.sums[5], r5);   // state-dependent entropy: summed per row (stats_row_from_sums, sde)
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * L.A + 6; t += blockDim.x) {
+    const float tot = ((part[t] + part[nq + t]) + part[2 * nq + t]) + part[3 * nq + t];   // waves in order
+    if (t < 2 * L.A) {
+      const int k = t >> 1;
+      if ((t & 1) == 0) atomicAdd(&L.g_b_action[k], tot);
+      else if (L.lat == nullptr) {   // (gSDE: log_std's gradient is a GEMM over gsig, see k_sde_scale_grad)
+        // + the entropy term of the loss, once: d(-mean(entropy)) / d log_std_a = -(B_local / B_global) * ent_coef
+        atomicAdd(&L.g_log_std[k], blockIdx.x == 0 ? tot + L.ent_coef * (-(float)L.B) * L.inv_bg : tot);
+      }
+    } else {
+      const int j = t - 2 * L.A;
+      if (j < 4) atomicAdd(&L.sums[j], tot);
+      else if (j == 4) atomicAdd(L.g_b_value, tot);
+      else if (L.lat != nullptr) atomicAdd(&L.sums[5], tot);   // state-dependent entropy: summed per row (stats_row_from_sums, sde)
+    }
   }
-  const float r0 = block_sum(s_pl, red), r1 = block_sum(s_vl, red), r2 = block_sum(s_kl, red);
-  const float r3 = block_sum(s_cf, red), r4 = block_sum(dvv, red);
-  if (threadIdx.x == 0) {
-    atomicAdd(&L.sums[0], r0);
-    atomicAdd(&L.sums[1], r1);
-    atomicAdd(&L.sums[2], r2);
-    atomicAdd(&L.sums[3], r3);
-    atomicAdd(&L.sums[4], (float)min(L.B - (int)(blockIdx.x * blockDim.x), (int)blockDim.x));
-    atomicAdd(L.g_b_value, r4);
-  }
+  if (threadIdx.x == 0) atomicAdd(&L.sums[4], (float)min(L.B - (int)(blockIdx.x * blockDim.x), (int)blockDim.x));
 }
 
 // gSDE: g_log_std[k][a] = (latent^2)^T . gsig, as the GEMM left it, times d sigma^2 / d log_std[k][a] / latent_k^2 = 2 exp(log_std[k][a])^2
@@ -992,12 +1051,6 @@ __global__ void k_sde_scale_grad(float* __restrict__ g_log_std, const float* __r
     for (int a = 0; a < A; ++a) t += raw[i * A + a];
     g_log_std[i] = t * f;
   }
-}
-
-// entropy term of the loss on log_std: d(-mean(entropy))/dlog_std_a = -(B_local/B_global) * ent_coef
-__global__ void k_entropy_grad(float* g_log_std, int A, float ent_coef, float b_local, float inv_bg) {
-  const int a = threadIdx.x;
-  if (a < A) g_log_std[a] += ent_coef * (-b_local) * inv_bg;
 }
 
 // ------------------------------------------------------------------------------------------------
