@@ -2312,12 +2312,13 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
     return MOBROB_OK;
   }
   ProfScope ps(e, MOBROB_K_TRAIN_GRAD);
-  HIPC(hipMemsetAsync(e->grads, 0, (size_t)(e->P + 8) * 4, e->stream));
   float* sums = e->grads + e->P;
   const int per = e->Dp / 4;
+  // (the gather also zeroes the gradient vector + loss sums and the gSDE GEMM's output: everything this step adds into with atomics)
   hipLaunchKernelGGL(k_gather, dim3(cdiv(B * per, 256)), dim3(256), 0, e->stream, e->rows + start, B, e->obs, e->Dp,
                      e->actions, e->A, e->logp, e->adv, e->ret, e->Xg, e->actg, e->lpg, e->advg, e->retg, e->values,
-                     e->clip_vf >= 0.0 ? e->oldvg : (float*)nullptr);
+                     e->clip_vf >= 0.0 ? e->oldvg : (float*)nullptr, e->grads, e->P + 8, e->sde ? e->sde_graw : (float*)nullptr,
+                     e->sde ? e->HL * e->A : 0);
   forward_generic(e, e->Xg, B, true, e->mu, true, e->vout, true);
   LossArgs L{};
   L.mu = e->mu; L.ldmu = e->Ap; L.v = e->vout; L.actions = e->actg; L.old_logp = e->lpg; L.adv = e->advg;
@@ -2328,7 +2329,6 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
   L.sums = sums; L.g_log_std = Gp(e, T_LOGSTD); L.g_b_action = Gp(e, T_AB); L.g_b_value = Gp(e, T_VB);
   if (e->sde) {
     L.lat = e->hp[e->Lp - 1]; L.HL = e->HL; L.sde = e->sde_mode; L.gsig = e->sde_gsig; L.ldg = e->Ap; L.lat2 = e->sde_lat2;
-    HIPC(hipMemsetAsync(e->sde_graw, 0, (size_t)e->HL * e->A * 4, e->stream));
   }
   // (the padding columns of dmu / dv -- K padding of the NN GEMMs -- are zeroed by k_loss itself)
   hipLaunchKernelGGL(k_loss, dim3(cdiv(B, 256)), dim3(256), loss_lds_bytes(e->A), e->stream, L);

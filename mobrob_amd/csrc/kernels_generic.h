@@ -877,14 +877,19 @@ __global__ void k_adv_fold(AdvStatArgs a, double* __restrict__ out) {
     out[4 * mb + 3] = 0.0;
   }
 }
-// gather the minibatch rows into contiguous work arrays (generic path)
+// gather the minibatch rows into contiguous work arrays (generic path).  First kernel of an optimizer step: it also zeroes what the
+// step accumulates into with atomics (zero0 / zero1: the gradient vector with its loss sums, the gSDE log_std GEMM's output) -- one
+// launch instead of a memset each.
 __global__ void k_gather(const int* __restrict__ rows, int count, const float* __restrict__ obs, int Dp,
                          const float* __restrict__ actions, int A, const float* __restrict__ logp,
                          const float* __restrict__ adv, const float* __restrict__ ret, float* __restrict__ Xg,
                          float* __restrict__ actg, float* __restrict__ lpg, float* __restrict__ advg,
-                         float* __restrict__ retg, const float* __restrict__ values, float* __restrict__ oldvg) {
+                         float* __restrict__ retg, const float* __restrict__ values, float* __restrict__ oldvg,
+                         float* __restrict__ zero0, int nzero0, float* __restrict__ zero1, int nzero1) {
   const int per = Dp / 4;  // float4 chunks per row
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int z = i; z < nzero0; z += gridDim.x * blockDim.x) zero0[z] = 0.f;
+  for (int z = i; z < nzero1; z += gridDim.x * blockDim.x) zero1[z] = 0.f;
   if (i >= count * per) return;
   const int b = i / per, c = i - b * per;
   const int row = rows[b];
