@@ -364,17 +364,57 @@ void launch_op(mobrob_ppo_engine* e, const GemmOp& a, const GemmOp* b = nullptr)
   else if (a.mode == MODE_NN) launch_gemm<MODE_NN, EPI_DTANH_COLSUM>(e, a, b);
   else launch_gemm<MODE_TN, EPI_ATOMIC>(e, a, b);
 }
-// The two networks' chains side by side: the j-th GEMMs of both go out as ONE launch where they are of the same kind (they always
-// are at equal depths; with different depths the tails, and a head opposite a hidden layer, go out alone).  MOBROB_GEMM_PAIR=0: never.
-void run_queues(mobrob_ppo_engine* e, const GemmQueue& qa, const GemmQueue& qb) {
-  static const bool pair = getenv("MOBROB_GEMM_PAIR") == nullptr || atoi(getenv("MOBROB_GEMM_PAIR")) != 0;
+// tile class launch_gemm would pick for one op on its own: 11, 21 or 22
+int gemm_tile_class(const mobrob_ppo_engine* e, const GemmOp& a) {
+  const int f = e->gemm_tiles, M = a.g.M, N = a.g.N;
+  if (f == 22 && M > 32 && N > 32) return 22;
+  if ((f == 21 || f == 22) && M > 32) return 21;
+  const long w21 = (long)cdiv(M, 64) * cdiv(N, 32) * a.ksplit, w22 = (long)cdiv(M, 64) * cdiv(N, 64) * a.ksplit;
+  if (f != 0 || M <= 32 || w21 < 2048) return 11;
+  return (N <= 32 || w22 < 2048) ? 21 : 22;
+}
+// up to four one-tile problems of any kind in ONE launch (k_gemm_multi)
+void launch_multi(mobrob_ppo_engine* e, const GemmOp* const* ops, int n) {
+  GemmMulti m{};
+  int gx = 1, gy = 1, z = 0;
+  for (int p = 0; p < 4; ++p) {
+    const GemmOp& o = *ops[p < n ? p : n - 1];   // (unused slots repeat the last problem; their z range is empty)
+    m.g[p] = o.g; m.mode[p] = o.mode; m.epi[p] = o.epi;
+    m.zbeg[p] = z;
+    if (p < n) {
+      z += o.ksplit;
+      gx = std::max(gx, cdiv(cdiv(o.g.M, 32), 4)); gy = std::max(gy, cdiv(o.g.N, 32));
+    }
+  }
+  m.zbeg[4] = z;
+  hipLaunchKernelGGL(k_gemm_multi, dim3(gx, gy, z), dim3(256), 0, e->stream, m);
+}
+// The two networks' chains side by side, in STAGES of `width` consecutive GEMMs per network that depend on earlier stages only
+// (forward: 1 -- a layer; backward: 2 -- a layer's weight-gradient and input-gradient GEMM).  A stage whose GEMMs are all of the
+// one-tile class (small minibatches, rollout steps of few environments) goes out as ONE launch of up to four problems; otherwise
+// the j-th GEMMs of both networks go out pairwise where they are of the same kind (they always are at equal depths; the tails of
+// unequal depths, and a head opposite a hidden layer, go alone).  MOBROB_GEMM_PAIR=0: one launch per GEMM; =1: pairs only.
+void run_queues(mobrob_ppo_engine* e, const GemmQueue& qa, const GemmQueue& qb, int width) {
+  static const int pairing = getenv("MOBROB_GEMM_PAIR") == nullptr ? 2 : atoi(getenv("MOBROB_GEMM_PAIR"));
   const size_t n = std::max(qa.size(), qb.size());
-  for (size_t j = 0; j < n; ++j) {
-    const GemmOp* a = j < qa.size() ? &qa[j] : nullptr;
-    const GemmOp* b = j < qb.size() ? &qb[j] : nullptr;
-    if (a && b && pair && a->mode == b->mode && a->epi == b->epi) { launch_op(e, *a, b); continue; }
-    if (a) launch_op(e, *a);
-    if (b) launch_op(e, *b);
+  for (size_t j0 = 0; j0 < n; j0 += width) {
+    const GemmOp* st[4];
+    int ns = 0;
+    bool small = pairing >= 2;
+    for (size_t j = j0; j < j0 + width && j < n; ++j)
+      for (const GemmQueue* q : {&qa, &qb})
+        if (j < q->size()) {
+          st[ns++] = &(*q)[j];
+          small = small && gemm_tile_class(e, (*q)[j]) == 11;
+        }
+    if (small && ns >= 2) { launch_multi(e, st, ns); continue; }
+    for (size_t j = j0; j < j0 + width && j < n; ++j) {
+      const GemmOp* a = j < qa.size() ? &qa[j] : nullptr;
+      const GemmOp* b = j < qb.size() ? &qb[j] : nullptr;
+      if (a && b && pairing >= 1 && a->mode == b->mode && a->epi == b->epi) { launch_op(e, *a, b); continue; }
+      if (a) launch_op(e, *a);
+      if (b) launch_op(e, *b);
+    }
   }
 }
 // q: non-null = the GEMM is queued (run_queues pairs it with the other network's), null = launched now
@@ -485,7 +525,7 @@ void forward_generic(mobrob_ppo_engine* e, const float* X, int rows, bool want_p
                  keep_z ? e->dzv[l] : nullptr, &qv);
     linear_fwd(e, e->hv[e->Lv - 1], e->GL, e->vWp, e->GL, Pp(e, T_VB), v_out, 1, rows, 1, e->GL, false, nullptr, &qv);
   }
-  run_queues(e, qp, qv);
+  run_queues(e, qp, qv, 1);
 }
 
 void forward(mobrob_ppo_engine* e, const float* X, int rows, bool want_pi, float* mu_out, bool want_v, float* v_out) {
@@ -2353,7 +2393,7 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
   // both networks' chains alternate weight-gradient and input-gradient GEMMs from the head down: queued, then launched pairwise
   backward(&qp, e->Lp, e->Hp, e->hp, e->dzp, e->dmu, e->Ap, e->aWp, e->A, e->Ap, T_AW, e->tPW, e->tPB);
   backward(&qv, e->Lv, e->Hv, e->hv, e->dzv, e->dv, 8, e->vWp, 1, 8, T_VW, e->tVW, e->tVB);
-  run_queues(e, qp, qv);
+  run_queues(e, qp, qv, 2);
   HIPC(hipGetLastError());
   e->grad_pending = true;
   return MOBROB_OK;

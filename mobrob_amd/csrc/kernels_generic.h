@@ -100,17 +100,20 @@ struct GemmArgs {
 // TWO problems per launch (two != 0: blockIdx.z & 1 selects, the batch split of MODE_TN is blockIdx.z >> 1): the policy and the value
 // network run the same sequence of GEMMs on independent data, and at the reference YAMLs' sizes (100-row minibatches, 2 - 16
 // environments) every launch of this chain costs 5 - 8 us whatever it computes -- pairing them halves the launches of a step.
-template <int MODE, int EPI, int TM, int TN>
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs ga, GemmArgs gb, int two) {
-  const bool second = two != 0 && (blockIdx.z & 1) != 0;
-  const int zz = two != 0 ? (int)(blockIdx.z >> 1) : (int)blockIdx.z;
-  GemmArgs g;   // (field by field: wave-uniform selects, the struct stays in scalar registers)
+// field by field: wave-uniform selects, the struct stays in scalar registers
+__device__ __forceinline__ GemmArgs gemm_pick(bool second, const GemmArgs& ga, const GemmArgs& gb) {
+  GemmArgs g;
   g.A = second ? gb.A : ga.A; g.B = second ? gb.B : ga.B; g.C = second ? gb.C : ga.C;
   g.M = second ? gb.M : ga.M; g.N = second ? gb.N : ga.N; g.K = second ? gb.K : ga.K;
   g.lda = second ? gb.lda : ga.lda; g.ldb = second ? gb.ldb : ga.ldb; g.ldc = second ? gb.ldc : ga.ldc;
   g.bias = second ? gb.bias : ga.bias; g.Hact = second ? gb.Hact : ga.Hact; g.ldh = second ? gb.ldh : ga.ldh;
   g.colsum = second ? gb.colsum : ga.colsum; g.act = second ? gb.act : ga.act; g.Z = second ? gb.Z : ga.Z; g.ldz = second ? gb.ldz : ga.ldz;
   g.kchunk = second ? gb.kchunk : ga.kchunk;
+  return g;
+}
+// one wave's share of problem g: tiles (blockIdx.x, blockIdx.y), batch split zz (MODE_TN)
+template <int MODE, int EPI, int TM, int TN>
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, int zz) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int m0 = (blockIdx.x * 4 + wv) * (32 * TM), n0 = blockIdx.y * (32 * TN);
@@ -267,6 +270,35 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs ga, GemmArgs gb, int two)
       if (h == 0 && col_ok) atomicAdd(&g.colsum[col], csum);
     }
   }
+}
+template <int MODE, int EPI, int TM, int TN>
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs ga, GemmArgs gb, int two) {
+  const bool second = two != 0 && (blockIdx.z & 1) != 0;
+  const int zz = two != 0 ? (int)(blockIdx.z >> 1) : (int)blockIdx.z;
+  const GemmArgs g = gemm_pick(second, ga, gb);
+  gemm_body<MODE, EPI, TM, TN>(g, zz);
+}
+
+// Up to FOUR problems of ANY kind per launch, one tile per wave: a STAGE of the small-minibatch chain -- at a given depth the two
+// networks' weight-gradient and input-gradient GEMMs (or their forward GEMMs, a head opposite a hidden layer included) depend on
+// earlier stages only.  blockIdx.z runs over the problems' batch splits back to back (zbeg); the kind is a wave-uniform switch over
+// the four (mode, epilogue) combinations the chain uses.  For launches whose cost is the launch (profiles/r6/generic_chain.txt).
+struct GemmMulti {
+  GemmArgs g[4];
+  int mode[4], epi[4];
+  int zbeg[5];   // problem p owns blockIdx.z in [zbeg[p], zbeg[p + 1])
+};
+__global__ __launch_bounds__(256) void k_gemm_multi(GemmMulti m) {
+  const int z = blockIdx.z;
+  const int p = (z >= m.zbeg[1] ? 1 : 0) + (z >= m.zbeg[2] ? 1 : 0) + (z >= m.zbeg[3] ? 1 : 0);
+  const GemmArgs g = gemm_pick(p >= 2, gemm_pick(p == 1, m.g[0], m.g[1]), gemm_pick(p == 3, m.g[2], m.g[3]));
+  const int mode = p == 0 ? m.mode[0] : (p == 1 ? m.mode[1] : (p == 2 ? m.mode[2] : m.mode[3]));
+  const int epi = p == 0 ? m.epi[0] : (p == 1 ? m.epi[1] : (p == 2 ? m.epi[2] : m.epi[3]));
+  const int zz = z - (p == 0 ? m.zbeg[0] : (p == 1 ? m.zbeg[1] : (p == 2 ? m.zbeg[2] : m.zbeg[3])));
+  if (mode == MODE_NT && epi == EPI_BIAS_TANH) gemm_body<MODE_NT, EPI_BIAS_TANH, 1, 1>(g, zz);
+  else if (mode == MODE_NT) gemm_body<MODE_NT, EPI_BIAS, 1, 1>(g, zz);
+  else if (mode == MODE_NN) gemm_body<MODE_NN, EPI_DTANH_COLSUM, 1, 1>(g, zz);
+  else gemm_body<MODE_TN, EPI_ATOMIC, 1, 1>(g, zz);
 }
 
 // ------------------------------------------------------------------------------------------------

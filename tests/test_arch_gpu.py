@@ -280,12 +280,14 @@ def test_every_gemm_tiling_matches_the_oracle(tiles, act, pi, vf, sde, monkeypat
     e.close()
 
 
-@pytest.mark.parametrize("act,sde", [("tanh", False), ("silu", False), ("tanh", True)])
-def test_full_size_minibatch_on_the_generic_chain(act, sde):
+@pytest.mark.parametrize("act,sde,pi,vf", [("tanh", False, (128, 128), (128, 96)), ("silu", False, (128, 128), (128, 96)),
+                                           ("tanh", True, (128, 128), (128, 96)), ("relu", False, (128, 128, 64), (96,))])
+def test_full_size_minibatch_on_the_generic_chain(act, sde, pi, vf):
     """65 536 rows through the launch-size tile selection as shipped (2x2 tiles for the hidden layers, 2x1 for the heads, batch
-    split with float atomics for the weight gradients) at widths no fused family covers: every gradient tensor of one minibatch
-    against the float64-accumulating oracle."""
-    D, A, T, N, pi, vf = 26, 3, 64, 1024, (128, 128), (128, 96)
+    split with float atomics for the weight gradients; the two networks' GEMMs paired per launch, with unequal depths the tails
+    and a head opposite a hidden layer alone) at widths no fused family covers: every gradient tensor of one minibatch against the
+    float64-accumulating oracle."""
+    D, A, T, N = 26, 3, 64, 1024
     B = T * N
     rng = np.random.default_rng(3)
     p = O.init_params(D, A, pi, vf, seed=7)
