@@ -281,12 +281,13 @@ def test_every_gemm_tiling_matches_the_oracle(tiles, act, pi, vf, sde, monkeypat
 
 
 @pytest.mark.parametrize("act,sde,pi,vf", [("tanh", False, (128, 128), (128, 96)), ("silu", False, (128, 128), (128, 96)),
-                                           ("tanh", True, (128, 128), (128, 96)), ("relu", False, (128, 128, 64), (96,))])
+                                           ("tanh", True, (128, 128), (128, 96)), ("elu", False, (128, 128, 64), (96,))])
 def test_full_size_minibatch_on_the_generic_chain(act, sde, pi, vf):
     """65 536 rows through the launch-size tile selection as shipped (2x2 tiles for the hidden layers, 2x1 for the heads, batch
     split with float atomics for the weight gradients; the two networks' GEMMs paired per launch, with unequal depths the tails
     and a head opposite a hidden layer alone) at widths no fused family covers: every gradient tensor of one minibatch against the
-    float64-accumulating oracle."""
+    float64-accumulating oracle.  (Smooth activations only: with 8 M pre-activations a handful sit within rounding of ReLU's kink, and
+    float32 against float64 accumulation then flips their derivative -- 1e-3 of a first-layer gradient, measured.)"""
     D, A, T, N = 26, 3, 64, 1024
     B = T * N
     rng = np.random.default_rng(3)
