@@ -94,13 +94,7 @@ struct GemmArgs {
   int kchunk;           // MODE_TN: batch rows per blockIdx.z
 };
 
-// TM x TN: 32x32 tiles per wave (1x1, 2x1 or 2x2).  A wave that owns 2x2 tiles feeds sixteen MFMAs from four operand fetches where
-// four one-tile waves need eight for the same sixteen: the one-tile form ran at 22 - 34 % of the f32 matrix rate on L1 / L2
-// operand traffic (12.8 flop per byte fetched by a block; 25.6 with 2x2), see CHANGELOG round 6.
-// TWO problems per launch (two != 0: blockIdx.z & 1 selects, the batch split of MODE_TN is blockIdx.z >> 1): the policy and the value
-// network run the same sequence of GEMMs on independent data, and at the reference YAMLs' sizes (100-row minibatches, 2 - 16
-// environments) every launch of this chain costs 5 - 8 us whatever it computes -- pairing them halves the launches of a step.
-// field by field: wave-uniform selects, the struct stays in scalar registers
+// one of two argument structs, field by field: wave-uniform selects, the result stays in scalar registers
 __device__ __forceinline__ GemmArgs gemm_pick(bool second, const GemmArgs& ga, const GemmArgs& gb) {
   GemmArgs g;
   g.A = second ? gb.A : ga.A; g.B = second ? gb.B : ga.B; g.C = second ? gb.C : ga.C;
@@ -111,7 +105,10 @@ __device__ __forceinline__ GemmArgs gemm_pick(bool second, const GemmArgs& ga, c
   g.kchunk = second ? gb.kchunk : ga.kchunk;
   return g;
 }
-// one wave's share of problem g: tiles (blockIdx.x, blockIdx.y), batch split zz (MODE_TN)
+// One wave's share of problem g: tiles (blockIdx.x, blockIdx.y), batch split zz (MODE_TN).
+// TM x TN: 32x32 tiles per wave (1x1, 2x1 or 2x2).  A wave that owns 2x2 tiles feeds sixteen MFMAs from four operand fetches where
+// four one-tile waves need eight for the same sixteen: the one-tile form ran at 22 - 34 % of the f32 matrix rate on L1 / L2
+// operand traffic (12.8 flop per byte fetched by a block; 25.6 with 2x2), profiles/r6/generic_chain.txt.
 template <int MODE, int EPI, int TM, int TN>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, int zz) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -271,6 +268,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int zz) {
     }
   }
 }
+// ONE or TWO problems of the same kind per launch (two != 0: blockIdx.z & 1 selects, the batch split of MODE_TN is blockIdx.z >> 1):
+// the policy and the value network run the same sequence of GEMMs on independent data -- pairing them halves the launches of a
+// step and doubles the blocks of a launch (headline shape through this chain +24 %).
 template <int MODE, int EPI, int TM, int TN>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs ga, GemmArgs gb, int two) {
   const bool second = two != 0 && (blockIdx.z & 1) != 0;
