@@ -416,6 +416,8 @@ int mobrob_ppo_minibatch_apply_checked(mobrob_ppo_engine_t* e, int32_t* stopped)
 int mobrob_ppo_fetch_step_stats(mobrob_ppo_engine_t* e, float* out, int32_t max_rows);
 
 /* ---- inference: policy.predict (examples/control.py:39) -------------------------------------- */
+/* (use_sde engines, deterministic = 0: `eps` is not used -- the noise is latent . exploration matrix, SB3's get_noise: the
+ *  environments' own matrices when n == n_envs, the single exploration_mat otherwise) */
 int mobrob_ppo_predict(mobrob_ppo_engine_t* e, const float* obs, int32_t n, int32_t deterministic,
                        const float* eps /* n*A or NULL */, float* actions_clipped, float* values);
 
