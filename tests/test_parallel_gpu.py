@@ -19,18 +19,30 @@ from tests.util import synthetic_rollout  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 CASES = {"h256": dict(D=58, A=12, H=256, T=12, N=40, B=320, E=2), "h64": dict(D=14, A=2, H=64, T=10, N=24, B=96, E=2),
-         "generic": dict(D=26, A=2, H=32, T=8, N=16, B=64, E=1)}
+         "generic": dict(D=26, A=2, H=32, T=8, N=16, B=64, E=1),
+         # the generic chain's newer keyword surface under data parallel: unequal depths, ELU, gSDE (log_std [HL][A] in the all-reduced vector)
+         "generic_sde": dict(D=26, A=2, H=32, pi=(32, 24), vf=(32,), act="elu", sde=True, T=8, N=16, B=64, E=2)}
+
+
+def _arch(c):
+    return c.get("pi", (c["H"], c["H"])), c.get("vf", (c["H"], c["H"])), c.get("act", "tanh"), bool(c.get("sde", False))
 
 
 def _rank_data(c, rank):
-    D, A, H, T, N = c["D"], c["A"], c["H"], c["T"], c["N"]
-    p = O.init_params(D, A, (H, H), (H, H), seed=4)
-    p["log_std"] = np.full(A, -0.5, np.float32)
+    D, A, T, N = c["D"], c["A"], c["T"], c["N"]
+    pi, vf, act, sde = _arch(c)
+    p = O.init_params(D, A, pi, vf, seed=4)
+    p["log_std"] = np.full((pi[-1], A) if sde else A, -0.5, np.float32)
     buf, lv, dones = synthetic_rollout(T, N, D, A, seed=100 + rank)
-    mean, val = O.policy_outputs(p, buf["obs"].reshape(T * N, D))
-    buf["log_probs"] = O.gaussian_log_prob(mean, p["log_std"], buf["actions"].reshape(T * N, A)).reshape(T, N)
+    flat = buf["obs"].reshape(T * N, D)
+    mean, val = O.policy_outputs(p, flat, activation=act)
+    if sde:
+        sigma = O.sde_sigma(O.mlp_latents(p, flat, activation=act)[0][-1], p["log_std"])
+        buf["log_probs"] = O.normal_log_prob(mean, sigma, buf["actions"].reshape(T * N, A)).reshape(T, N)
+    else:
+        buf["log_probs"] = O.gaussian_log_prob(mean, p["log_std"], buf["actions"].reshape(T * N, A)).reshape(T, N)
     buf["values"] = val.reshape(T, N)
-    h = O.Hyper(n_epochs=c["E"], batch_size=c["B"], ent_coef=0.01)
+    h = O.Hyper(n_epochs=c["E"], batch_size=c["B"], ent_coef=0.01, activation=act, use_sde=sde)
     buf["advantages"], buf["returns"] = O.gae(buf["rewards"], buf["values"], buf["episode_starts"], lv, dones, h.gamma, h.gae_lambda)
     perms = np.stack([np.random.default_rng(7 + rank + 10 * e).permutation(T * N) for e in range(c["E"])])
     return p, buf, lv, dones, h, perms
@@ -45,9 +57,9 @@ def _worker(rank, world, port, case, out):
     from mobrob_amd.parallel import EngineBackend, train_data_parallel
     c = CASES[case]
     p, buf, lv, dones, h, perms = _rank_data(c, rank)
-    H = c["H"]
+    pi, vf, act, sde = _arch(c)
     e = PPOEngine(obs_dim=c["D"], act_dim=c["A"], n_envs=c["N"], n_steps=c["T"], batch_size=c["B"], n_epochs=c["E"],
-                  pi=(H, H), vf=(H, H), ent_coef=h.ent_coef, device_id=0, rank=rank, world_size=world)
+                  pi=pi, vf=vf, activation=act, use_sde=sde, ent_coef=h.ent_coef, device_id=0, rank=rank, world_size=world)
     e.set_params(p)
     e.load_rollout(buf, lv, dones)
     be = EngineBackend(e)
@@ -65,7 +77,7 @@ def test_two_engine_ranks_equal_single_process_union_batch(case, tmp_path):
     out = str(tmp_path / "rank{rank}.npz")
     mp.spawn(_worker, args=(world, port, case, out), nprocs=world, join=True)
     r = [np.load(out.format(rank=i))["flat"] for i in range(world)]
-    if case != "generic":  # fused paths are deterministic -> replicas stay bit-identical without a broadcast
+    if not case.startswith("generic"):  # fused paths are deterministic -> replicas stay bit-identical without a broadcast
         assert np.array_equal(r[0], r[1])
     assert np.max(np.abs(r[0] - r[1])) < 1e-6
     c = CASES[case]
