@@ -333,10 +333,21 @@ using GemmQueue = std::vector<GemmOp>;
 
 template <int MODE, int EPI, int TM, int TN>
 void launch_gemm_tiles(mobrob_ppo_engine* e, const GemmOp& a, const GemmOp* b) {
-  const int M = b ? std::max(a.g.M, b->g.M) : a.g.M, N = b ? std::max(a.g.N, b->g.N) : a.g.N;
+  // Orientation of a block's four waves, per problem.  Forward / input-gradient GEMMs stream a tall A ([rows][K]) against a small B
+  // (weights): with the waves side by side along N the block fetches its A rows ONCE (L1 / one XCD's L2) where four column blocks
+  // scattered over the chip fetched them four times -- at 65 536 x 256 x 256 that was 268 MB through L2 per launch against 67.
+  // Only where the column tiles fill the four waves; the weight-gradient GEMM (both operands tall) keeps them stacked along M.
+  static const bool wn_on = getenv("MOBROB_GEMM_WN") == nullptr || atoi(getenv("MOBROB_GEMM_WN")) != 0;
+  GemmArgs ga = a.g, gb = b ? b->g : a.g;
+  int gx = 1, gy = 1;
+  for (GemmArgs* g : {&ga, &gb}) {
+    const int mt = cdiv(g->M, 32 * TM), nt = cdiv(g->N, 32 * TN);
+    g->wn = (wn_on && MODE != MODE_TN && nt % 4 == 0) ? 1 : 0;
+    gx = std::max(gx, g->wn ? mt : cdiv(mt, 4));
+    gy = std::max(gy, g->wn ? nt / 4 : nt);
+  }
   const int ks = b ? std::max(a.ksplit, b->ksplit) : a.ksplit;
-  dim3 grid(cdiv(cdiv(M, 32 * TM), 4), cdiv(N, 32 * TN), b ? 2 * ks : ks);
-  hipLaunchKernelGGL((k_gemm<MODE, EPI, TM, TN>), grid, dim3(256), 0, e->stream, a.g, b ? b->g : a.g, b ? 1 : 0);
+  hipLaunchKernelGGL((k_gemm<MODE, EPI, TM, TN>), dim3(gx, gy, b ? 2 * ks : ks), dim3(256), 0, e->stream, ga, gb, b ? 1 : 0);
 }
 // tiles per wave by shape: 2x2 wherever both extents leave room for it, 2x1 for narrow outputs (heads), 1x1 for tiny ones.
 // MOBROB_GEMM_TILES (read when the engine is created): 1 keeps one tile per wave (A/B); 21 / 22 force 2x1 / 2x2 wherever the output

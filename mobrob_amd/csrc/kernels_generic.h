@@ -92,6 +92,8 @@ struct GemmArgs {
   int act;              // hidden activation (ACT_*): tanh is SB3's default for MlpPolicy; the others come from policy_kwargs activation_fn
   float* Z; int ldz;    // EPI_BIAS_TANH, act_needs_z: where the pre-activations go (null: not kept).  EPI_DTANH_COLSUM reads them from C
   int kchunk;           // MODE_TN: batch rows per blockIdx.z
+  int wn;               // 1: the block's four waves sit side by side along N (they share the A rows: one fetch per block through L1 / the
+                        // XCD's L2 instead of one per column block somewhere on the chip); 0: stacked along M (they share B)
 };
 
 // one of two argument structs, field by field: wave-uniform selects, the result stays in scalar registers
@@ -102,7 +104,7 @@ __device__ __forceinline__ GemmArgs gemm_pick(bool second, const GemmArgs& ga, c
   g.lda = second ? gb.lda : ga.lda; g.ldb = second ? gb.ldb : ga.ldb; g.ldc = second ? gb.ldc : ga.ldc;
   g.bias = second ? gb.bias : ga.bias; g.Hact = second ? gb.Hact : ga.Hact; g.ldh = second ? gb.ldh : ga.ldh;
   g.colsum = second ? gb.colsum : ga.colsum; g.act = second ? gb.act : ga.act; g.Z = second ? gb.Z : ga.Z; g.ldz = second ? gb.ldz : ga.ldz;
-  g.kchunk = second ? gb.kchunk : ga.kchunk;
+  g.kchunk = second ? gb.kchunk : ga.kchunk; g.wn = second ? gb.wn : ga.wn;
   return g;
 }
 // One wave's share of problem g: tiles (blockIdx.x, blockIdx.y), batch split zz (MODE_TN).
@@ -113,7 +115,8 @@ template <int MODE, int EPI, int TM, int TN>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, int zz) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int m0 = (blockIdx.x * 4 + wv) * (32 * TM), n0 = blockIdx.y * (32 * TN);
+  const int m0 = (g.wn ? (int)blockIdx.x : (int)blockIdx.x * 4 + wv) * (32 * TM);
+  const int n0 = (g.wn ? (int)blockIdx.y * 4 + wv : (int)blockIdx.y) * (32 * TN);
   // whole-wave exits (no block-level sync in this kernel): the grid covers the larger of two problems, and the longer batch split
   if (m0 >= g.M || n0 >= g.N || (MODE == MODE_TN ? zz * g.kchunk >= g.K : zz > 0)) return;
   f32x16 acc[TM][TN];
