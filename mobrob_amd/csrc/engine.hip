@@ -229,6 +229,7 @@ struct mobrob_ppo_engine {
   int gemm_tiles = 0;   // MOBROB_GEMM_TILES: 0 = by shape (launch_gemm)
   bool sde = false, sde_hold = false;   // hold: the caller supplies the noise (mobrob_ppo_sde_set_noise); no automatic resampling
   float *sde_E = nullptr, *sde_E1 = nullptr, *sde_lat2 = nullptr, *sde_gsig = nullptr, *sde_graw = nullptr;
+  float *sde_S2 = nullptr, *sde_var = nullptr;   // std^2 table [HL][A] of the current log_std; variance [rows][Ap] of the rows in flight
   SdeMode sde_mode{1, 0};   // policy_kwargs full_std / use_expln
   // rollout streamer (host-env path): pinned staging + a side stream for the H2D/D2H copies
   hipStream_t cstream = nullptr;
@@ -583,6 +584,14 @@ void sde_resample(mobrob_ppo_engine* e, int r0, int n, uint32_t draw, const uint
                      eps_seed(e) ^ 0x5DE5DE5DE5DE5DEull, draw, draw_base, e->sde_E, single ? e->sde_E1 : (float*)nullptr);
 }
 
+// gSDE: variance of `rows` rows of the policy's last hidden activations (the forward has just produced them) into sde_var.
+// fresh_table: recompute the std^2 table from log_std first (parameters may have changed since it was last built)
+void sde_variance(mobrob_ppo_engine* e, int rows, bool fresh_table) {
+  if (fresh_table)
+    hipLaunchKernelGGL(k_sde_std2, dim3(cdiv(e->HL * e->A, 256)), dim3(256), 0, e->stream, Pp(e, T_LOGSTD), e->HL, e->A, e->sde_mode, e->sde_S2);
+  hipLaunchKernelGGL(k_sde_var, dim3(cdiv(rows, 4)), dim3(256), 0, e->stream, e->hp[e->Lp - 1], e->HL, e->sde_S2, rows, e->HL, e->A, e->sde_var, e->Ap);
+}
+
 // policy forward + sample for rows [r0, r0 + n) of rollout slot t (observations already in the slot).
 // draw = Philox draw index of the step (the whole-step callers pass the running counter and advance it).
 void act_rows(mobrob_ppo_engine* e, int t, int r0, int n, const float* eps_dev_or_null, uint32_t draw,
@@ -608,8 +617,11 @@ void act_rows(mobrob_ppo_engine* e, int t, int r0, int n, const float* eps_dev_o
     // the rows' matrices at this step's draw index (a function of (env, draw), whichever launch draws them)
     const int freq = e->cfg.sde_sample_freq;
     if (!e->sde_hold && (t == 0 || (freq > 0 && t % freq == 0))) sde_resample(e, r0, n, draw, draw_base, r0 == 0);
-    hipLaunchKernelGGL(k_sample_sde, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, e->hp[e->Lp - 1], e->HL, Pp(e, T_LOGSTD),
-                       e->sde_E, r0, 0, n, e->HL, e->A, e->sde_mode, (float)e->cfg.action_low, (float)e->cfg.action_high,
+    // the std^2 table at the first step of a rollout (every row range's: ranges are enqueued independently; the parameters are
+    // fixed from there to the end of the rollout -- and a captured rollout graph must rebuild it on every replay)
+    sde_variance(e, n, t == 0);
+    hipLaunchKernelGGL(k_sample_sde, dim3(cdiv(n, 4)), dim3(256), 0, e->stream, e->mu, e->Ap, e->hp[e->Lp - 1], e->HL, e->sde_var, e->Ap,
+                       e->sde_E, r0, 0, n, e->HL, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high,
                        e->actions + row * e->A, clip_out, e->logp + row);
     return;
   }
@@ -1077,6 +1089,7 @@ int engine_alloc(mobrob_ppo_engine* e) {
   if (e->sde) {
     CHK(dalloc(e, &e->sde_E, N * (size_t)e->HL * A)); CHK(dalloc(e, &e->sde_E1, (size_t)e->HL * A));
     CHK(dalloc(e, &e->sde_lat2, Bl * e->HL)); CHK(dalloc(e, &e->sde_gsig, Bl * e->Ap)); CHK(dalloc(e, &e->sde_graw, (size_t)e->HL * A));
+    CHK(dalloc(e, &e->sde_S2, (size_t)e->HL * A)); CHK(dalloc(e, &e->sde_var, R * e->Ap));
   }
   CHK(dalloc(e, &e->gstate[0], N * kGoalStateFloats)); CHK(dalloc(e, &e->gstate[1], N * kGoalStateFloats));
   CHK(dalloc(e, &e->ep_stats, kEpStatsDoubles));
@@ -2379,7 +2392,8 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
   L.ent_coef = (float)e->cfg.ent_coef; L.inv_bg = inv_bg; L.dmu = e->dmu; L.lddmu = e->Ap; L.dv = e->dv; L.lddv = 8;
   L.sums = sums; L.g_log_std = Gp(e, T_LOGSTD); L.g_b_action = Gp(e, T_AB); L.g_b_value = Gp(e, T_VB);
   if (e->sde) {
-    L.lat = e->hp[e->Lp - 1]; L.HL = e->HL; L.sde = e->sde_mode; L.gsig = e->sde_gsig; L.ldg = e->Ap; L.lat2 = e->sde_lat2;
+    sde_variance(e, B, true);   // (log_std moved in the previous optimizer step)
+    L.lat = e->hp[e->Lp - 1]; L.HL = e->HL; L.var = e->sde_var; L.ldvar = e->Ap; L.gsig = e->sde_gsig; L.ldg = e->Ap; L.lat2 = e->sde_lat2;
   }
   // (the padding columns of dmu / dv -- K padding of the NN GEMMs -- are zeroed by k_loss itself)
   hipLaunchKernelGGL(k_loss, dim3(cdiv(B, 256)), dim3(256), loss_lds_bytes(e->A), e->stream, L);
@@ -3167,8 +3181,9 @@ int mobrob_ppo_predict(mobrob_ppo_engine_t* e, const float* obs, int32_t n, int3
       } else {
         if (e->sde) {   // get_noise: the environments' own matrices for a batch of n_envs rows, else the single exploration_mat
           const bool own = n == e->N;
-          hipLaunchKernelGGL(k_sample_sde, dim3(cdiv(c, 256)), dim3(256), 0, e->stream, e->mu, e->Ap, e->hp[e->Lp - 1], e->HL, Pp(e, T_LOGSTD),
-                             own ? e->sde_E : e->sde_E1, s, own ? 0 : 1, c, e->HL, e->A, e->sde_mode, (float)e->cfg.action_low, (float)e->cfg.action_high,
+          sde_variance(e, c, true);
+          hipLaunchKernelGGL(k_sample_sde, dim3(cdiv(c, 4)), dim3(256), 0, e->stream, e->mu, e->Ap, e->hp[e->Lp - 1], e->HL, e->sde_var, e->Ap,
+                             own ? e->sde_E : e->sde_E1, s, own ? 0 : 1, c, e->HL, e->A, (float)e->cfg.action_low, (float)e->cfg.action_high,
                              (float*)nullptr, scratch, (float*)nullptr);
           HIPC(hipMemcpyAsync(actions + (size_t)s * e->A, scratch, (size_t)c * e->A * 4, hipMemcpyDeviceToHost, e->stream));
           if (values) HIPC(hipMemcpyAsync(values + s, e->vout, (size_t)c * 4, hipMemcpyDeviceToHost, e->stream));

@@ -411,32 +411,74 @@ __global__ void k_sde_from_z(const float* __restrict__ z, const float* __restric
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) E[i] = z[i] * sde_std(sde_ls(log_std, (i % HLA) / A, i % A, A, md.full), md.expln);
 }
-// rollout-time sampling epilogue under gSDE: one thread per env row.  E: the rows' matrices ([row][HL][A], erow0 = matrix row of
-// row 0) or, with single != 0, ONE matrix for every row (SB3 get_noise when the batch is not the exploration batch).
-__global__ void k_sample_sde(const float* __restrict__ mu, int ldmu, const float* __restrict__ lat, int ldl, const float* __restrict__ log_std,
-                             const float* __restrict__ E, int erow0, int single, int n, int HL, int A, SdeMode md, float lo, float hi,
-                             float* __restrict__ act_raw, float* __restrict__ act_clip, float* __restrict__ logp_out) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+// std^2 per (latent unit, action) of the current log_std: [HL][A] (full_std or not): what the variance contracts the squared latent with
+__global__ void k_sde_std2(const float* __restrict__ log_std, int HL, int A, SdeMode md, float* __restrict__ S2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= HL * A) return;
+  const float sd = sde_std(sde_ls(log_std, i / A, i % A, A, md.full), md.expln);
+  S2[i] = sd * sd;
+}
+// sum over a wave of FOUR values at once (the four actions a wave-per-row kernel carries per pass)
+__device__ __forceinline__ void wave_sum4(float (&v)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = wave_sum(v[j]);
+}
+// variance[row][a] = sum_k latent[row][k]^2 S2[k][a] (+ epsilon is added by the consumers' sqrt): ONE WAVE per row, lanes over the
+// latent units, four actions per pass (first version: one thread per row with exp() per (k, a) -- 12.6 M exps and 50 MB of strided
+// reads per rollout step at 4096 envs, 256 units, 12 actions: 1.2 ms; profiles/r6/generic_chain.txt)
+__global__ __launch_bounds__(256) void k_sde_var(const float* __restrict__ lat, int ldl, const float* __restrict__ S2, int n, int HL, int A,
+                                                 float* __restrict__ var, int ldv) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float* l = lat + (size_t)row * ldl;
+  for (int a0 = 0; a0 < A; a0 += 4) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane; k < HL; k += 64) {
+      const float l2 = l[k] * l[k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (a0 + j < A) acc[j] = fmaf(l2, S2[k * A + a0 + j], acc[j]);
+    }
+    wave_sum4(acc);
+    if (lane == 0)
+      for (int j = 0; j < 4 && a0 + j < A; ++j) var[(size_t)row * ldv + a0 + j] = acc[j];
+  }
+}
+// rollout-time sampling epilogue under gSDE: ONE WAVE per env row.  noise = latent . theta_row with the row's matrix read once,
+// contiguously ([k][a]: a lane owns latent unit k and its A consecutive entries); the variance comes from k_sde_var.
+// E: the rows' matrices ([row][HL][A], erow0 = matrix row of row 0) or, with single != 0, ONE matrix for every row (SB3 get_noise when the
+// batch is not the exploration batch).
+__global__ __launch_bounds__(256) void k_sample_sde(const float* __restrict__ mu, int ldmu, const float* __restrict__ lat, int ldl,
+                                                    const float* __restrict__ var, int ldv, const float* __restrict__ E, int erow0, int single,
+                                                    int n, int HL, int A, float lo, float hi, float* __restrict__ act_raw,
+                                                    float* __restrict__ act_clip, float* __restrict__ logp_out) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
   const float* l = lat + (size_t)row * ldl;
   const float* Er = single ? E : E + (size_t)(erow0 + row) * HL * A;
   float lp = 0.f;
-  for (int a = 0; a < A; ++a) {
-    float noise = 0.f, var = 0.f;
-    for (int k = 0; k < HL; ++k) {
-      const float lk = l[k], sd = sde_std(sde_ls(log_std, k, a, A, md.full), md.expln);
-      noise = fmaf(lk, Er[k * A + a], noise);
-      var = fmaf(lk * lk, sd * sd, var);
+  for (int a0 = 0; a0 < A; a0 += 4) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane; k < HL; k += 64) {
+      const float lk = l[k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (a0 + j < A) acc[j] = fmaf(lk, Er[k * A + a0 + j], acc[j]);
     }
-    const float sigma = sqrtf(var + kSdeEpsilon);
-    const float m = mu[(size_t)row * ldmu + a];
-    const float act = m + noise;
-    const float d = act - m;
-    lp += -(d * d) / (2.0f * (sigma * sigma)) - logf(sigma) - kLogSqrt2Pi;
-    if (act_raw) act_raw[(size_t)row * A + a] = act;
-    if (act_clip) act_clip[(size_t)row * A + a] = fminf(fmaxf(act, lo), hi);
+    wave_sum4(acc);
+    if (lane == 0)
+      for (int j = 0; j < 4 && a0 + j < A; ++j) {
+        const int a = a0 + j;
+        const float sigma = sqrtf(var[(size_t)row * ldv + a] + kSdeEpsilon);
+        const float m = mu[(size_t)row * ldmu + a];
+        const float act = m + acc[j];
+        const float d = act - m;
+        lp += -(d * d) / (2.0f * (sigma * sigma)) - logf(sigma) - kLogSqrt2Pi;
+        if (act_raw) act_raw[(size_t)row * A + a] = act;
+        if (act_clip) act_clip[(size_t)row * A + a] = fminf(fmaxf(act, lo), hi);
+      }
   }
-  if (logp_out) logp_out[row] = lp;
+  if (lane == 0 && logp_out) logp_out[row] = lp;
 }
 
 // deterministic predict: clip(mu)
@@ -961,7 +1003,8 @@ struct LossArgs {
   float* g_log_std; float* g_b_action; float* g_b_value;
   // gSDE (lat != nullptr): the policy's last hidden activations of the minibatch [B][HL] (ld = HL), log_std is [HL][A];
   // gsig [B][ldg] <- dLoss / d sigma^2 per (row, action), lat2 [B][HL] <- latent^2 (the operands of the log_std gradient GEMM)
-  const float* lat; int HL; SdeMode sde;
+  const float* lat; int HL;
+  const float* var; int ldvar;   // [B][ldvar] <- k_sde_var: sigma^2 - epsilon per (row, action)
   float* gsig; int ldg; float* lat2;
 };
 
@@ -973,16 +1016,6 @@ __device__ __forceinline__ void adv_mean_std(const double* st, float* mean, floa
   if (var < 0.0) var = 0.0;
   *mean = (float)m;
   *sd = (float)sqrt(var);
-}
-
-// sigma of action a of one row under gSDE: sqrt(sum_k latent_k^2 exp(log_std[k][a])^2 + 1e-6)
-__device__ __forceinline__ float sde_sigma(const float* __restrict__ l, const float* __restrict__ log_std, int HL, int A, int a, SdeMode md) {
-  float var = 0.f;
-  for (int k = 0; k < HL; ++k) {
-    const float lk = l[k], sd = sde_std(sde_ls(log_std, k, a, A, md.full), md.expln);
-    var = fmaf(lk * lk, sd * sd, var);
-  }
-  return sqrtf(var + kSdeEpsilon);
 }
 
 // Dynamic LDS: [4 waves][2 A + 8] floats.  Every per-action and per-minibatch sum is reduced inside its wave by shuffles and
@@ -1005,7 +1038,7 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs L) {
     if (L.normalize && on) a = (a - mean) / (sd + 1e-8f);
     float lp = 0.f;
     for (int k = 0; k < L.A; ++k) {
-      const float sdv = L.lat != nullptr ? sde_sigma(L.lat + (size_t)i * L.HL, L.log_std, L.HL, L.A, k, L.sde) : expf(L.log_std[k]);
+      const float sdv = L.lat != nullptr ? sqrtf(L.var[(size_t)i * L.ldvar + k] + kSdeEpsilon) : expf(L.log_std[k]);
       const float d = L.actions[(size_t)i * L.A + k] - L.mu[(size_t)i * L.ldmu + k];
       lp += -(d * d) / (2.0f * (sdv * sdv)) - logf(sdv) - kLogSqrt2Pi;
       s_ent += (0.5f + kLogSqrt2Pi) + logf(sdv);
@@ -1034,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs L) {
   for (int k = 0; k < L.A; ++k) {
     float gm = 0.f, gls = 0.f;
     if (live) {
-      const float sdv = L.lat != nullptr ? sde_sigma(L.lat + (size_t)i * L.HL, L.log_std, L.HL, L.A, k, L.sde) : expf(L.log_std[k]);
+      const float sdv = L.lat != nullptr ? sqrtf(L.var[(size_t)i * L.ldvar + k] + kSdeEpsilon) : expf(L.log_std[k]);
       const float var = sdv * sdv;
       const float d = L.actions[(size_t)i * L.A + k] - L.mu[(size_t)i * L.ldmu + k];
       gm = g_logp * d / var;
