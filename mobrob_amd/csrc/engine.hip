@@ -586,10 +586,11 @@ void sde_resample(mobrob_ppo_engine* e, int r0, int n, uint32_t draw, const uint
 
 // gSDE: variance of `rows` rows of the policy's last hidden activations (the forward has just produced them) into sde_var.
 // fresh_table: recompute the std^2 table from log_std first (parameters may have changed since it was last built)
-void sde_variance(mobrob_ppo_engine* e, int rows, bool fresh_table) {
+void sde_variance(mobrob_ppo_engine* e, int rows, bool fresh_table, float* lat2 = nullptr) {
   if (fresh_table)
     hipLaunchKernelGGL(k_sde_std2, dim3(cdiv(e->HL * e->A, 256)), dim3(256), 0, e->stream, Pp(e, T_LOGSTD), e->HL, e->A, e->sde_mode, e->sde_S2);
-  hipLaunchKernelGGL(k_sde_var, dim3(cdiv(rows, 4)), dim3(256), 0, e->stream, e->hp[e->Lp - 1], e->HL, e->sde_S2, rows, e->HL, e->A, e->sde_var, e->Ap);
+  hipLaunchKernelGGL(k_sde_var, dim3(cdiv(rows, 4)), dim3(256), 0, e->stream, e->hp[e->Lp - 1], e->HL, e->sde_S2, rows, e->HL, e->A, e->sde_var, e->Ap,
+                     lat2);
 }
 
 // policy forward + sample for rows [r0, r0 + n) of rollout slot t (observations already in the slot).
@@ -2392,8 +2393,8 @@ int mobrob_ppo_minibatch_grad(mobrob_ppo_engine_t* e, int32_t mb) {
   L.ent_coef = (float)e->cfg.ent_coef; L.inv_bg = inv_bg; L.dmu = e->dmu; L.lddmu = e->Ap; L.dv = e->dv; L.lddv = 8;
   L.sums = sums; L.g_log_std = Gp(e, T_LOGSTD); L.g_b_action = Gp(e, T_AB); L.g_b_value = Gp(e, T_VB);
   if (e->sde) {
-    sde_variance(e, B, true);   // (log_std moved in the previous optimizer step)
-    L.lat = e->hp[e->Lp - 1]; L.HL = e->HL; L.var = e->sde_var; L.ldvar = e->Ap; L.gsig = e->sde_gsig; L.ldg = e->Ap; L.lat2 = e->sde_lat2;
+    sde_variance(e, B, true, e->sde_lat2);   // (log_std moved in the previous optimizer step; latent^2 for the gradient GEMM on the way)
+    L.lat = e->hp[e->Lp - 1]; L.HL = e->HL; L.var = e->sde_var; L.ldvar = e->Ap; L.gsig = e->sde_gsig; L.ldg = e->Ap;
   }
   // (the padding columns of dmu / dv -- K padding of the NN GEMMs -- are zeroed by k_loss itself)
   hipLaunchKernelGGL(k_loss, dim3(cdiv(B, 256)), dim3(256), loss_lds_bytes(e->A), e->stream, L);

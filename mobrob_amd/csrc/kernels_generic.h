@@ -426,8 +426,9 @@ __device__ __forceinline__ void wave_sum4(float (&v)[4]) {
 // variance[row][a] = sum_k latent[row][k]^2 S2[k][a] (+ epsilon is added by the consumers' sqrt): ONE WAVE per row, lanes over the
 // latent units, four actions per pass (first version: one thread per row with exp() per (k, a) -- 12.6 M exps and 50 MB of strided
 // reads per rollout step at 4096 envs, 256 units, 12 actions: 1.2 ms; profiles/r6/generic_chain.txt)
+// lat2 (training): the squared latent itself, [n][HL], for the log_std-gradient GEMM -- written here, coalesced, as a by-product.
 __global__ __launch_bounds__(256) void k_sde_var(const float* __restrict__ lat, int ldl, const float* __restrict__ S2, int n, int HL, int A,
-                                                 float* __restrict__ var, int ldv) {
+                                                 float* __restrict__ var, int ldv, float* __restrict__ lat2) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
   const float* l = lat + (size_t)row * ldl;
@@ -435,6 +436,7 @@ __global__ __launch_bounds__(256) void k_sde_var(const float* __restrict__ lat, 
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k = lane; k < HL; k += 64) {
       const float l2 = l[k] * l[k];
+      if (lat2 != nullptr && a0 == 0) lat2[(size_t)row * HL + k] = l2;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (a0 + j < A) acc[j] = fmaf(l2, S2[k * A + a0 + j], acc[j]);
@@ -1002,10 +1004,10 @@ struct LossArgs {
   float* sums;                // [8]
   float* g_log_std; float* g_b_action; float* g_b_value;
   // gSDE (lat != nullptr): the policy's last hidden activations of the minibatch [B][HL] (ld = HL), log_std is [HL][A];
-  // gsig [B][ldg] <- dLoss / d sigma^2 per (row, action), lat2 [B][HL] <- latent^2 (the operands of the log_std gradient GEMM)
+  // gsig [B][ldg] <- dLoss / d sigma^2 per (row, action): one operand of the log_std gradient GEMM (the other, latent^2: k_sde_var)
   const float* lat; int HL;
   const float* var; int ldvar;   // [B][ldvar] <- k_sde_var: sigma^2 - epsilon per (row, action)
-  float* gsig; int ldg; float* lat2;
+  float* gsig; int ldg;
 };
 
 __device__ __forceinline__ void adv_mean_std(const double* st, float* mean, float* sd, bool* on) {
@@ -1079,8 +1081,6 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs L) {
     const float t1 = wave_sum(gm), t2 = wave_sum(gls);
     if (lane == 0) { mine[2 * k] = t1; mine[2 * k + 1] = t2; }
   }
-  if (L.lat != nullptr && live)
-    for (int k = 0; k < L.HL; ++k) { const float lk = L.lat[(size_t)i * L.HL + k]; L.lat2[(size_t)i * L.HL + k] = lk * lk; }
   {
     const float r0 = wave_sum(s_pl), r1 = wave_sum(s_vl), r2 = wave_sum(s_kl), r3 = wave_sum(s_cf), r4 = wave_sum(dvv), r5 = wave_sum(s_ent);
     if (lane == 0) {
