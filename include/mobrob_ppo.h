@@ -19,6 +19,8 @@
  *       vf.0.weight[G1,D], vf.0.bias[G1], vf.2.weight[G2,G1], vf.2.bias[G2],
  *       action_net.weight[A,H2], action_net.bias[A], value_net.weight[1,G2], value_net.bias[1]
  *     (weights row-major [out,in]; verified against data/policies/<env>-ppo.zip:policy.pth).
+ *     Other depths (one to eight hidden layers per network) continue nn.Sequential's numbering: pi.0, pi.2, pi.4 ... then vf.0 ...;
+ *     with use_sde log_std is a matrix [HL,A] (HL = last policy width; [HL,1] without full_std), row-major, still first.
  *   - rollout storage is [T][N][...] on the device; minibatch indices are SB3's ENV-MAJOR flat
  *     index  flat = n*T + t  (SB3 RolloutBuffer.swap_and_flatten).
  *   - every function returns MOBROB_OK (0) or a negative error code; mobrob_ppo_last_error()
