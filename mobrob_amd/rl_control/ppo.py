@@ -195,6 +195,12 @@ class PPO:
         self.target_kl = None if target_kl is None else float(target_kl)
         self.tensorboard_log, self.verbose, self.seed, self.device = tensorboard_log, int(verbose), seed, device
         self.policy_kwargs = dict(policy_kwargs or {})
+        # keys some SB3 writers leave inside policy_kwargs: `use_sde` (the off-policy algorithms store it there; it must agree with the
+        # argument) and the deprecated `sde_net_arch=None`
+        if "use_sde" in self.policy_kwargs and bool(self.policy_kwargs.pop("use_sde")) != bool(use_sde):
+            raise ValueError("policy_kwargs['use_sde'] contradicts PPO(use_sde=...)")
+        if self.policy_kwargs.get("sde_net_arch", None) is None:
+            self.policy_kwargs.pop("sde_net_arch", None)
         net_arch = self.policy_kwargs.get("net_arch", dict(pi=[64, 64], vf=[64, 64]))
         if isinstance(net_arch, (list, tuple)):
             net_arch = dict(pi=list(net_arch), vf=list(net_arch))

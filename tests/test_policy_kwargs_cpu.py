@@ -62,3 +62,10 @@ def test_depth_limit_is_the_engine_s():
     with pytest.raises(ValueError, match=f"one to {MAX_HIDDEN}"):
         PPOEngine.make_config(6, 2, 4, 8, pi=(8,) * (MAX_HIDDEN + 1), vf=(8,))
     assert PPOEngine.device_bytes(obs_dim=6, act_dim=2, n_envs=4, n_steps=8, pi=(8,) * MAX_HIDDEN, vf=(16,)) > 0
+
+
+def test_keys_other_sb3_writers_leave_in_policy_kwargs_are_tolerated():
+    ppo = PPO(env=None, _dims=(4, 6, 2), _init_setup_model=False, use_sde=True, policy_kwargs=dict(use_sde=True, sde_net_arch=None, net_arch=[32]))
+    assert ppo.use_sde and "use_sde" not in ppo.policy_kwargs and "sde_net_arch" not in ppo.policy_kwargs and ppo.net_arch == ((32,), (32,))
+    with pytest.raises(ValueError, match="use_sde"):
+        PPO(env=None, _dims=(4, 6, 2), _init_setup_model=False, use_sde=False, policy_kwargs=dict(use_sde=True))
